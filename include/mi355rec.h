@@ -1,0 +1,179 @@
+/*
+ * mi355rec.h — C-ABI of the MI355X-native cosine top-N engine.
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference
+ * (Iamdarika/Spotify_recommender) has no FFI layer: its boundary is the public
+ * surface of `class Recommender` (Recommender.h:28-83) whose private
+ * `calculateSimilarities` (Recommender.h:114, Recommender.cu:184-254) drives
+ * cuBLAS SGEMV + two CUDA kernels and whose `recommendByIndex`
+ * (Recommender.cu:275-318) does a host heap top-N.  Each entry point below
+ * names the reference interface it replaces.  The C++ shim in
+ * include/Recommender.h + spotify_recommender_amd/csrc/Recommender.cpp keeps
+ * the reference's class API on top of these calls; INTEGRATION.md shows the
+ * binding a reference maintainer would add.
+ *
+ * Conventions: plain pointers and sizes only; 0 = success, negative = error
+ * (never throws across the boundary); the caller owns every in/out buffer; the
+ * library owns device memory it allocates.  A handle is not re-entrant: use it
+ * from one host thread at a time (as the reference's Recommender).
+ * There is NO CPU fallback: without a gfx950 device every call fails with
+ * MI355REC_ERR_NO_DEVICE.
+ *
+ * Numerics: scores are bit-identical to the reference's CPU path
+ * (calculateSimilaritiesCPU, Recommender.cu:256-273): strictly sequential
+ * j=0..11 fp32 multiply-then-add (no FMA), IEEE sqrt and divide, threshold
+ * 1e-8f on sqrt(norm)*qnorm, clamp with std::min/std::max semantics.
+ * Top-N order is canonical: score descending, then row index ascending
+ * (-0.0f is ranked and reported as +0.0f).  The reference's order inside runs
+ * of exactly equal scores is a libstdc++ heap artefact.
+ */
+#ifndef MI355REC_H
+#define MI355REC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355REC_DIM 12 /* Song.h:12 FEATURE_COUNT */
+#define MI355REC_MAX_TOPN_FAST 1024 /* larger topn takes the sort path */
+
+#define MI355REC_OK 0
+#define MI355REC_ERR_INVALID_ARG (-1)
+#define MI355REC_ERR_NO_DEVICE (-2)
+#define MI355REC_ERR_HIP (-3)
+#define MI355REC_ERR_OUT_OF_MEMORY (-4)
+
+typedef struct mi355rec mi355rec_t;
+
+/* Packed candidate key: high 32 bits = order-preserving image of the fp32
+ * score, low 32 bits = ~(global row index).  Larger key = better candidate in
+ * canonical order.  0 = empty slot.  This is what crosses xGMI in the
+ * multi-GPU merge (one all-gather of topn keys per rank). */
+typedef uint64_t mi355rec_key_t;
+
+typedef struct {
+    int64_t rows;              /* rows held by this handle (local shard)      */
+    int64_t row_base;          /* global index of local row 0                 */
+    int32_t device;            /* HIP device ordinal                          */
+    int32_t compute_units;     /* CUs of the device                           */
+    int32_t grid_blocks;       /* resident workgroups of the streaming kernel */
+    int32_t block_threads;
+    int64_t bytes_per_query;   /* algorithmic bytes of one pass: rows * 48    */
+    float last_scan_ms;        /* HIP-event time of the last timed scan       */
+    float last_merge_ms;       /* HIP-event time of the last timed merge      */
+} mi355rec_stats_t;
+
+/* Number of visible HIP devices (0 when there is none / no driver). */
+int mi355rec_device_count(void);
+
+/* Thread-local text of the last error raised with no handle to attach it to
+ * (e.g. a failed create); with a handle, use mi355rec_last_error. */
+const char* mi355rec_last_global_error(void);
+
+/* Replaces Recommender::initialize's device half (Recommender.cu:155-168:
+ * cudaMalloc + flatten + cudaMemcpy H2D).  `feats_host` is the row-major
+ * n x 12 fp32 matrix (the reference flattens vector<Song> into exactly this,
+ * Recommender.cu:162-167).  The matrix is copied to `device` once.
+ * `row_base` is the global index of row 0 (0 unless this is one shard of a
+ * row-sharded catalogue).  dim must be 12.  n in [1, 2^32-2]. */
+int mi355rec_create(const float* feats_host, int64_t n, int dim, int device,
+                    int64_t row_base, mi355rec_t** out);
+
+/* Same, over a matrix that is ALREADY resident in device memory (e.g. a torch
+ * tensor's data_ptr).  The memory is borrowed, not copied, and must outlive
+ * the handle; it must be 16-byte aligned. */
+int mi355rec_create_device(const float* feats_dev, int64_t n, int dim,
+                           int device, int64_t row_base, mi355rec_t** out);
+
+/* Replaces Recommender::~Recommender (Recommender.cu:86-98). */
+void mi355rec_destroy(mi355rec_t* h);
+
+const char* mi355rec_last_error(const mi355rec_t* h);
+
+int mi355rec_stats(const mi355rec_t* h, mi355rec_stats_t* out);
+
+/* ---- synchronous host API (what the C++ Recommender shim calls) ---------- */
+
+/* Replaces the private Recommender::calculateSimilarities(int, float*)
+ * (Recommender.h:114, Recommender.cu:184-254): cosine of catalogue row
+ * `local_row` against every local row, n floats written to host memory. */
+int mi355rec_scores_row(mi355rec_t* h, int64_t local_row, float* out_host);
+
+/* Same for an arbitrary query vector (12 floats, host). */
+int mi355rec_scores(mi355rec_t* h, const float* query12, float* out_host);
+
+/* Replaces Recommender::recommendByIndex (Recommender.cu:275-318): query =
+ * local row `local_row`, that row excluded by index, best `topn` returned as
+ * global row indices (best first) with their scores.  *out_count =
+ * min(topn, rows-1).  topn <= 0 is MI355REC_ERR_INVALID_ARG (the reference
+ * segfaults); a bad row is MI355REC_ERR_INVALID_ARG (the
+ * reference prints and returns {}, Recommender.cu:281-284). */
+int mi355rec_query_row_topn(mi355rec_t* h, int64_t local_row, int topn,
+                            int64_t* out_idx, float* out_score, int* out_count);
+
+/* Arbitrary query vector; `exclude_global` = global row index to skip or -1. */
+int mi355rec_query_topn(mi355rec_t* h, const float* query12,
+                        int64_t exclude_global, int topn, int64_t* out_idx,
+                        float* out_score, int* out_count);
+
+/* `batch` independent queries (batch x 12 floats); exclude may be NULL.
+ * Outputs are batch x topn, each row padded with idx -1 / score 0;
+ * out_count has `batch` entries. */
+int mi355rec_query_batch_topn(mi355rec_t* h, const float* queries, int batch,
+                              const int64_t* exclude_global, int topn,
+                              int64_t* out_idx, float* out_score, int* out_count);
+
+/* ---- asynchronous device API (serving loop, bench.py, multi-GPU) ---------
+ * Everything below only ENQUEUES work on `stream` (a hipStream_t; NULL = the
+ * device's default stream) and returns; outputs live in caller-provided
+ * device memory.  No allocation, no synchronisation (hipGraph-capturable). */
+
+/* Streaming scan of the local shard for one query: writes the shard's best
+ * `topn` candidates as `topn` packed keys (sorted descending, 0-padded) to
+ * out_keys_dev.  query = local row. */
+int mi355rec_enqueue_row_keys(mi355rec_t* h, int64_t local_row, int topn,
+                              mi355rec_key_t* out_keys_dev, void* stream);
+
+/* Same for a host query vector (passed by value to the kernel). */
+int mi355rec_enqueue_query_keys(mi355rec_t* h, const float* query12,
+                                int64_t exclude_global, int topn,
+                                mi355rec_key_t* out_keys_dev, void* stream);
+
+/* Merge `n_lists` lists of `list_len` packed keys each (each sorted
+ * descending, 0-padded — e.g. the all-gathered per-rank outputs of
+ * mi355rec_enqueue_*_keys) into the global best `topn` keys (sorted
+ * descending, 0-padded), and optionally unpack them.  out_idx_dev /
+ * out_score_dev may be NULL.  Unused idx slots are -1. */
+int mi355rec_enqueue_merge_keys(mi355rec_t* h, const mi355rec_key_t* lists_dev,
+                                int n_lists, int list_len, int topn,
+                                mi355rec_key_t* out_keys_dev,
+                                int64_t* out_idx_dev, float* out_score_dev,
+                                void* stream);
+
+/* Full score vector into device memory (local_row >= 0: query = that row and
+ * query12 is ignored; local_row < 0: query12 is used). */
+int mi355rec_enqueue_scores(mi355rec_t* h, int64_t local_row,
+                            const float* query12, float* out_scores_dev,
+                            void* stream);
+
+/* Plain read-only streaming kernel over the same matrix (the achievable-HBM
+ * ceiling probe of SURVEY.md §8(d)); writes one checksum word per workgroup
+ * to sink_dev (>= grid_blocks uint32). */
+int mi355rec_enqueue_stream_probe(mi355rec_t* h, uint32_t* sink_dev, void* stream);
+
+/* Brackets the NEXT enqueue_*_keys / enqueue_merge_keys calls with HIP events
+ * on their stream so that mi355rec_stats reports last_scan_ms/last_merge_ms
+ * (reading them synchronises the events).  0 disables. */
+int mi355rec_set_timing(mi355rec_t* h, int enabled);
+
+/* ---- key helpers (host side, no device needed) --------------------------- */
+mi355rec_key_t mi355rec_pack_key(float score, int64_t global_row);
+float mi355rec_key_score(mi355rec_key_t key);
+int64_t mi355rec_key_row(mi355rec_key_t key); /* -1 for the empty key */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355REC_H */

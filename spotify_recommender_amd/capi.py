@@ -1,0 +1,97 @@
+"""ctypes binding of the C-ABI in include/mi355rec.h.
+
+This is plumbing only: every compute call goes to the HIP library.  If the
+library is missing the import of :func:`lib` raises — there is no Python or CPU
+fallback for the hot path.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "libmi355rec.so"
+
+DIM = 12
+MAX_TOPN_FAST = 1024
+
+OK = 0
+ERR_INVALID_ARG = -1
+ERR_NO_DEVICE = -2
+ERR_HIP = -3
+ERR_OUT_OF_MEMORY = -4
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [
+        ("rows", c_int64),
+        ("row_base", c_int64),
+        ("device", c_int32),
+        ("compute_units", c_int32),
+        ("grid_blocks", c_int32),
+        ("block_threads", c_int32),
+        ("bytes_per_query", c_int64),
+        ("last_scan_ms", c_float),
+        ("last_merge_ms", c_float),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/mi355rec.h one to one
+SIGNATURES = {
+    "mi355rec_device_count": (c_int, []),
+    "mi355rec_last_global_error": (c_char_p, []),
+    "mi355rec_create": (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, POINTER(c_void_p)]),
+    "mi355rec_create_device": (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, POINTER(c_void_p)]),
+    "mi355rec_destroy": (None, [c_void_p]),
+    "mi355rec_last_error": (c_char_p, [c_void_p]),
+    "mi355rec_stats": (c_int, [c_void_p, POINTER(Stats)]),
+    "mi355rec_scores_row": (c_int, [c_void_p, c_int64, c_void_p]),
+    "mi355rec_scores": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "mi355rec_query_row_topn": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, POINTER(c_int)]),
+    "mi355rec_query_topn": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, POINTER(c_int)]),
+    "mi355rec_query_batch_topn": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "mi355rec_enqueue_row_keys": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "mi355rec_enqueue_query_keys": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "mi355rec_enqueue_merge_keys": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mi355rec_enqueue_scores": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "mi355rec_enqueue_stream_probe": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "mi355rec_set_timing": (c_int, [c_void_p, c_int]),
+    "mi355rec_pack_key": (c_uint64, [c_float, c_int64]),
+    "mi355rec_key_score": (c_float, [c_uint64]),
+    "mi355rec_key_row": (c_int64, [c_uint64]),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load libmi355rec.so (built by ``spotify_recommender_amd.build``)."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m spotify_recommender_amd.build` "
+                "(hipcc --offload-arch=gfx950). The cosine top-N path has no fallback."
+            )
+        handle = ctypes.CDLL(str(LIB_PATH))
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+class Mi355Error(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"mi355rec error {code}: {message}")
+        self.code = code
+
+
+def check(rc: int, handle=None) -> None:
+    if rc == OK:
+        return
+    L = lib()
+    msg = L.mi355rec_last_error(handle) if handle else L.mi355rec_last_global_error()
+    raise Mi355Error(rc, (msg or b"").decode("utf-8", "replace"))

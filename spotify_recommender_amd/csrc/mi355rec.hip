@@ -1,0 +1,529 @@
+// mi355rec.hip — C-ABI (include/mi355rec.h) over the gfx950 kernels.
+//
+// Host side of the drop-in boundary: owns the device-resident catalogue shard
+// (replaces Recommender::initialize's cudaMalloc/cudaMemcpy,
+// Recommender.cu:155-168), launches the fused scan + merge (replaces
+// calculateSimilarities + the host heap, Recommender.cu:184-254,293-315) and
+// hands back indices/scores.  No CPU fallback anywhere in this file.
+#include "mi355rec.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hip.h"
+
+using namespace mi355;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+constexpr int kTimingPairs = 8192;
+
+}  // namespace
+
+struct mi355rec {
+    int device = 0;
+    int64_t n = 0;
+    int64_t row_base = 0;
+    const float* d_feats = nullptr;
+    float* owned_feats = nullptr;
+
+    int cus = 0;
+    int grid = 0;
+    int64_t rows_per_block = 0;
+    int iters = 0;
+
+    uint64_t* d_block_lists = nullptr;  // grid x kMaxTopK
+
+    // resources of the synchronous host API
+    hipStream_t stream = nullptr;
+    int batch_cap = 0;
+    uint64_t* d_keys = nullptr;
+    int64_t* d_idx = nullptr;
+    float* d_score = nullptr;
+    int64_t* h_idx = nullptr;   // pinned
+    float* h_score = nullptr;   // pinned
+    float* d_scores_full = nullptr;
+
+    // optional HIP-event timing of the enqueued kernels
+    bool timing = false;
+    std::vector<hipEvent_t> ev_scan, ev_merge;  // (start, stop) pairs
+    int n_scan_pairs = 0, n_merge_pairs = 0;
+    float last_scan_ms = 0.f, last_merge_ms = 0.f;
+
+    std::string err;
+};
+
+namespace {
+
+int fail(mi355rec* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                          \
+    do {                                                                          \
+        hipError_t e_ = (expr);                                                   \
+        if (e_ != hipSuccess)                                                     \
+            return fail((h), e_ == hipErrorOutOfMemory ? MI355REC_ERR_OUT_OF_MEMORY \
+                                                       : MI355REC_ERR_HIP,        \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                        __FILE__, __LINE__);                                      \
+    } while (0)
+
+void plan_grid(mi355rec* h, int blocks_per_cu) {
+    int64_t max_blocks = static_cast<int64_t>(h->cus) * blocks_per_cu;
+    if (max_blocks > kMergeMaxLists) max_blocks = kMergeMaxLists;
+    int64_t rpb = (h->n + max_blocks - 1) / max_blocks;
+    rpb = (rpb + 63) / 64 * 64;
+    if (rpb < 64) rpb = 64;
+    h->rows_per_block = rpb;
+    h->grid = static_cast<int>((h->n + rpb - 1) / rpb);
+    h->iters = static_cast<int>((rpb + kTileRows - 1) / kTileRows);
+}
+
+int create_common(const float* feats, bool on_device, int64_t n, int dim, int device,
+                  int64_t row_base, mi355rec_t** out) {
+    if (out) *out = nullptr;
+    if (!out || !feats) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (dim != kDim) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "dim must be %d, got %d", kDim, dim);
+    if (n < 1 || row_base < 0 || n + row_base > 0xfffffffell)
+        return fail(nullptr, MI355REC_ERR_INVALID_ARG, "rows %lld (base %lld) out of range",
+                    (long long)n, (long long)row_base);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(nullptr, MI355REC_ERR_NO_DEVICE,
+                    "no HIP device visible: the MI355X engine has no CPU fallback");
+    if (device < 0 || device >= count)
+        return fail(nullptr, MI355REC_ERR_INVALID_ARG, "device %d not in [0,%d)", device, count);
+
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(nullptr, MI355REC_ERR_HIP, "hipSetDevice(%d) failed", device);
+
+    mi355rec* h = new mi355rec();
+    h->device = device;
+    h->n = n;
+    h->row_base = row_base;
+
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(nullptr, MI355REC_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    }
+    h->cus = prop.multiProcessorCount;
+
+    int occ = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel<true, false>, kBlock, 0);
+    if (e != hipSuccess || occ < 1) occ = 1;
+    if (occ > 2) occ = 2;
+    plan_grid(h, occ);
+
+    int rc = MI355REC_OK;
+    auto cleanup = [&](int code, const char* what, hipError_t he) {
+        rc = fail(nullptr, code, "%s: %s", what, hipGetErrorString(he));
+        mi355rec_destroy(h);
+        return rc;
+    };
+
+    if (on_device) {
+        if (reinterpret_cast<uintptr_t>(feats) & 15) {
+            delete h;
+            return fail(nullptr, MI355REC_ERR_INVALID_ARG, "device matrix must be 16-byte aligned");
+        }
+        h->d_feats = feats;
+    } else {
+        const size_t bytes = static_cast<size_t>(n) * kDim * sizeof(float);
+        if ((e = hipMalloc(&h->owned_feats, bytes)) != hipSuccess)
+            return cleanup(MI355REC_ERR_OUT_OF_MEMORY, "hipMalloc(catalogue)", e);
+        if ((e = hipMemcpy(h->owned_feats, feats, bytes, hipMemcpyHostToDevice)) != hipSuccess)
+            return cleanup(MI355REC_ERR_HIP, "hipMemcpy(catalogue H2D)", e);
+        h->d_feats = h->owned_feats;
+    }
+
+    if ((e = hipMalloc(&h->d_block_lists, sizeof(uint64_t) * static_cast<size_t>(h->grid) * kMaxTopK)) != hipSuccess)
+        return cleanup(MI355REC_ERR_OUT_OF_MEMORY, "hipMalloc(block lists)", e);
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess)
+        return cleanup(MI355REC_ERR_HIP, "hipStreamCreate", e);
+
+    *out = h;
+    return MI355REC_OK;
+}
+
+int ensure_batch(mi355rec* h, int batch) {
+    if (batch <= h->batch_cap) return MI355REC_OK;
+    int cap = h->batch_cap ? h->batch_cap : 1;
+    while (cap < batch) cap *= 2;
+    if (h->d_keys) (void)hipFree(h->d_keys);
+    if (h->d_idx) (void)hipFree(h->d_idx);
+    if (h->d_score) (void)hipFree(h->d_score);
+    if (h->h_idx) (void)hipHostFree(h->h_idx);
+    if (h->h_score) (void)hipHostFree(h->h_score);
+    h->d_keys = nullptr; h->d_idx = nullptr; h->d_score = nullptr;
+    h->h_idx = nullptr; h->h_score = nullptr;
+    h->batch_cap = 0;
+    const size_t slots = static_cast<size_t>(cap) * kMaxTopK;
+    HIP_TRY(h, hipMalloc(&h->d_keys, slots * sizeof(uint64_t)));
+    HIP_TRY(h, hipMalloc(&h->d_idx, slots * sizeof(int64_t)));
+    HIP_TRY(h, hipMalloc(&h->d_score, slots * sizeof(float)));
+    HIP_TRY(h, hipHostMalloc(&h->h_idx, slots * sizeof(int64_t), hipHostMallocDefault));
+    HIP_TRY(h, hipHostMalloc(&h->h_score, slots * sizeof(float), hipHostMallocDefault));
+    h->batch_cap = cap;
+    return MI355REC_OK;
+}
+
+int timing_begin(mi355rec* h, std::vector<hipEvent_t>& evs, int& pairs, hipStream_t s) {
+    if (!h->timing) return -1;
+    if (pairs >= kTimingPairs) return -1;
+    if (static_cast<int>(evs.size()) < 2 * (pairs + 1)) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess) return -1;
+        if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return -1; }
+        evs.push_back(a);
+        evs.push_back(b);
+    }
+    (void)hipEventRecord(evs[2 * pairs], s);
+    return pairs;
+}
+
+void timing_end(mi355rec* h, std::vector<hipEvent_t>& evs, int& pairs, int slot, hipStream_t s) {
+    (void)h;
+    if (slot < 0) return;
+    (void)hipEventRecord(evs[2 * slot + 1], s);
+    pairs = slot + 1;
+}
+
+// Enqueue the scan for one query.  query_row >= 0: query is that local row.
+int enqueue_scan(mi355rec* h, int64_t query_row, const float* query12,
+                 int64_t exclude_global, int topn, hipStream_t s) {
+    QueryArg qa;
+    std::memset(&qa, 0, sizeof qa);
+    const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, s);
+    if (query_row >= 0) {
+        hipLaunchKernelGGL((scan_kernel<true, false>), dim3(h->grid), dim3(kBlock), 0, s,
+                           h->d_feats, h->n, h->rows_per_block, h->iters, h->row_base, qa,
+                           query_row, exclude_global, topn, h->d_block_lists,
+                           static_cast<float*>(nullptr));
+    } else {
+        std::memcpy(qa.q, query12, sizeof qa.q);
+        hipLaunchKernelGGL((scan_kernel<false, false>), dim3(h->grid), dim3(kBlock), 0, s,
+                           h->d_feats, h->n, h->rows_per_block, h->iters, h->row_base, qa,
+                           static_cast<int64_t>(0), exclude_global, topn, h->d_block_lists,
+                           static_cast<float*>(nullptr));
+    }
+    timing_end(h, h->ev_scan, h->n_scan_pairs, slot, s);
+    HIP_TRY(h, hipGetLastError());
+    return MI355REC_OK;
+}
+
+int enqueue_merge(mi355rec* h, const uint64_t* lists, int n_lists, int list_len, int topn,
+                  uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s) {
+    const int slot = timing_begin(h, h->ev_merge, h->n_merge_pairs, s);
+    hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(kMergeBlock), 0, s, lists, n_lists, list_len,
+                       static_cast<int64_t>(0), topn, out_keys, out_idx, out_score,
+                       static_cast<int64_t>(0));
+    timing_end(h, h->ev_merge, h->n_merge_pairs, slot, s);
+    HIP_TRY(h, hipGetLastError());
+    return MI355REC_OK;
+}
+
+int check_topn(mi355rec* h, int topn) {
+    if (topn <= 0)
+        return fail(h, MI355REC_ERR_INVALID_ARG, "topn must be positive, got %d", topn);
+    if (topn > kMaxTopK)
+        return fail(h, MI355REC_ERR_INVALID_ARG, "topn %d > %d is not supported yet", topn, kMaxTopK);
+    return MI355REC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355rec_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+const char* mi355rec_last_global_error(void) { return g_last_error.c_str(); }
+
+int mi355rec_create(const float* feats_host, int64_t n, int dim, int device, int64_t row_base,
+                    mi355rec_t** out) {
+    return create_common(feats_host, false, n, dim, device, row_base, out);
+}
+
+int mi355rec_create_device(const float* feats_dev, int64_t n, int dim, int device,
+                           int64_t row_base, mi355rec_t** out) {
+    return create_common(feats_dev, true, n, dim, device, row_base, out);
+}
+
+void mi355rec_destroy(mi355rec_t* h) {
+    if (!h) return;
+    DeviceGuard guard(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (hipEvent_t e : h->ev_scan) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_merge) (void)hipEventDestroy(e);
+    if (h->owned_feats) (void)hipFree(h->owned_feats);
+    if (h->d_block_lists) (void)hipFree(h->d_block_lists);
+    if (h->d_keys) (void)hipFree(h->d_keys);
+    if (h->d_idx) (void)hipFree(h->d_idx);
+    if (h->d_score) (void)hipFree(h->d_score);
+    if (h->d_scores_full) (void)hipFree(h->d_scores_full);
+    if (h->h_idx) (void)hipHostFree(h->h_idx);
+    if (h->h_score) (void)hipHostFree(h->h_score);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char* mi355rec_last_error(const mi355rec_t* h) {
+    return h ? h->err.c_str() : g_last_error.c_str();
+}
+
+int mi355rec_set_timing(mi355rec_t* h, int enabled) {
+    if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    h->timing = enabled != 0;
+    h->n_scan_pairs = 0;
+    h->n_merge_pairs = 0;
+    return MI355REC_OK;
+}
+
+int mi355rec_stats(const mi355rec_t* hc, mi355rec_stats_t* out) {
+    mi355rec_t* h = const_cast<mi355rec_t*>(hc);
+    if (!h || !out) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    DeviceGuard guard(h->device);
+    // average over the pairs recorded since set_timing(1)
+    auto avg = [&](std::vector<hipEvent_t>& evs, int pairs, float& last) {
+        if (pairs <= 0) return;
+        double sum = 0.0;
+        int good = 0;
+        for (int i = 0; i < pairs; ++i) {
+            float ms = 0.f;
+            if (hipEventSynchronize(evs[2 * i + 1]) == hipSuccess &&
+                hipEventElapsedTime(&ms, evs[2 * i], evs[2 * i + 1]) == hipSuccess) {
+                sum += ms;
+                ++good;
+            }
+        }
+        if (good) last = static_cast<float>(sum / good);
+    };
+    avg(h->ev_scan, h->n_scan_pairs, h->last_scan_ms);
+    avg(h->ev_merge, h->n_merge_pairs, h->last_merge_ms);
+    out->rows = h->n;
+    out->row_base = h->row_base;
+    out->device = h->device;
+    out->compute_units = h->cus;
+    out->grid_blocks = h->grid;
+    out->block_threads = kBlock;
+    out->bytes_per_query = h->n * kDim * static_cast<int64_t>(sizeof(float));
+    out->last_scan_ms = h->last_scan_ms;
+    out->last_merge_ms = h->last_merge_ms;
+    return MI355REC_OK;
+}
+
+// ---- asynchronous device API -------------------------------------------------
+
+int mi355rec_enqueue_row_keys(mi355rec_t* h, int64_t local_row, int topn,
+                              mi355rec_key_t* out_keys_dev, void* stream) {
+    if (!h || !out_keys_dev) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (local_row < 0 || local_row >= h->n)
+        return fail(h, MI355REC_ERR_INVALID_ARG, "Invalid song index: %lld", (long long)local_row);
+    int rc = check_topn(h, topn);
+    if (rc) return rc;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = enqueue_scan(h, local_row, nullptr, h->row_base + local_row, topn, s);
+    if (rc) return rc;
+    return enqueue_merge(h, h->d_block_lists, h->grid, topn, topn, out_keys_dev, nullptr, nullptr, s);
+}
+
+int mi355rec_enqueue_query_keys(mi355rec_t* h, const float* query12, int64_t exclude_global,
+                                int topn, mi355rec_key_t* out_keys_dev, void* stream) {
+    if (!h || !out_keys_dev || !query12) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    int rc = check_topn(h, topn);
+    if (rc) return rc;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = enqueue_scan(h, -1, query12, exclude_global, topn, s);
+    if (rc) return rc;
+    return enqueue_merge(h, h->d_block_lists, h->grid, topn, topn, out_keys_dev, nullptr, nullptr, s);
+}
+
+int mi355rec_enqueue_merge_keys(mi355rec_t* h, const mi355rec_key_t* lists_dev, int n_lists,
+                                int list_len, int topn, mi355rec_key_t* out_keys_dev,
+                                int64_t* out_idx_dev, float* out_score_dev, void* stream) {
+    if (!h || !lists_dev || !out_keys_dev) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (n_lists < 1 || n_lists > kMergeMaxLists || list_len < 1)
+        return fail(h, MI355REC_ERR_INVALID_ARG, "n_lists %d / list_len %d out of range", n_lists, list_len);
+    int rc = check_topn(h, topn);
+    if (rc) return rc;
+    DeviceGuard guard(h->device);
+    return enqueue_merge(h, lists_dev, n_lists, list_len, topn, out_keys_dev, out_idx_dev,
+                         out_score_dev, static_cast<hipStream_t>(stream));
+}
+
+int mi355rec_enqueue_scores(mi355rec_t* h, int64_t local_row, const float* query12,
+                            float* out_scores_dev, void* stream) {
+    if (!h || !out_scores_dev) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (local_row >= h->n) return fail(h, MI355REC_ERR_INVALID_ARG, "Invalid song index: %lld", (long long)local_row);
+    if (local_row < 0 && !query12) return fail(h, MI355REC_ERR_INVALID_ARG, "null query");
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    QueryArg qa;
+    std::memset(&qa, 0, sizeof qa);
+    if (local_row >= 0) {
+        hipLaunchKernelGGL((scan_kernel<true, true>), dim3(h->grid), dim3(kBlock), 0, s, h->d_feats,
+                           h->n, h->rows_per_block, h->iters, h->row_base, qa, local_row,
+                           static_cast<int64_t>(-1), 1, static_cast<uint64_t*>(nullptr), out_scores_dev);
+    } else {
+        std::memcpy(qa.q, query12, sizeof qa.q);
+        hipLaunchKernelGGL((scan_kernel<false, true>), dim3(h->grid), dim3(kBlock), 0, s, h->d_feats,
+                           h->n, h->rows_per_block, h->iters, h->row_base, qa, static_cast<int64_t>(0),
+                           static_cast<int64_t>(-1), 1, static_cast<uint64_t*>(nullptr), out_scores_dev);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return MI355REC_OK;
+}
+
+int mi355rec_enqueue_stream_probe(mi355rec_t* h, uint32_t* sink_dev, void* stream) {
+    if (!h || !sink_dev) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, s);
+    hipLaunchKernelGGL(stream_probe_kernel, dim3(h->grid), dim3(kBlock), 0, s,
+                       reinterpret_cast<const float4*>(h->d_feats), h->n * 3, sink_dev);
+    timing_end(h, h->ev_scan, h->n_scan_pairs, slot, s);
+    HIP_TRY(h, hipGetLastError());
+    return MI355REC_OK;
+}
+
+// ---- synchronous host API ------------------------------------------------------
+
+static int scores_common(mi355rec_t* h, int64_t local_row, const float* query12, float* out_host) {
+    if (!h || !out_host) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    DeviceGuard guard(h->device);
+    if (!h->d_scores_full) HIP_TRY(h, hipMalloc(&h->d_scores_full, sizeof(float) * static_cast<size_t>(h->n)));
+    int rc = mi355rec_enqueue_scores(h, local_row, query12, h->d_scores_full, h->stream);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(out_host, h->d_scores_full, sizeof(float) * static_cast<size_t>(h->n),
+                              hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MI355REC_OK;
+}
+
+int mi355rec_scores_row(mi355rec_t* h, int64_t local_row, float* out_host) {
+    if (h && (local_row < 0 || local_row >= h->n))
+        return fail(h, MI355REC_ERR_INVALID_ARG, "Invalid song index: %lld", (long long)local_row);
+    return scores_common(h, local_row, nullptr, out_host);
+}
+
+int mi355rec_scores(mi355rec_t* h, const float* query12, float* out_host) {
+    if (!query12) return fail(h, MI355REC_ERR_INVALID_ARG, "null query");
+    return scores_common(h, -1, query12, out_host);
+}
+
+int mi355rec_query_batch_topn(mi355rec_t* h, const float* queries, int batch,
+                              const int64_t* exclude_global, int topn, int64_t* out_idx,
+                              float* out_score, int* out_count) {
+    if (!h || !queries || !out_idx) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (batch < 1) return fail(h, MI355REC_ERR_INVALID_ARG, "batch must be positive");
+    int rc = check_topn(h, topn);
+    if (rc) return rc;
+    DeviceGuard guard(h->device);
+    rc = ensure_batch(h, batch);
+    if (rc) return rc;
+    for (int b = 0; b < batch; ++b) {
+        rc = enqueue_scan(h, -1, queries + static_cast<int64_t>(b) * kDim,
+                          exclude_global ? exclude_global[b] : -1, topn, h->stream);
+        if (rc) return rc;
+        rc = enqueue_merge(h, h->d_block_lists, h->grid, topn, topn,
+                           h->d_keys + static_cast<int64_t>(b) * topn,
+                           h->d_idx + static_cast<int64_t>(b) * topn,
+                           h->d_score + static_cast<int64_t>(b) * topn, h->stream);
+        if (rc) return rc;
+    }
+    const size_t cnt = static_cast<size_t>(batch) * topn;
+    HIP_TRY(h, hipMemcpyAsync(h->h_idx, h->d_idx, cnt * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->h_score, h->d_score, cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::memcpy(out_idx, h->h_idx, cnt * sizeof(int64_t));
+    if (out_score) std::memcpy(out_score, h->h_score, cnt * sizeof(float));
+    if (out_count) {
+        for (int b = 0; b < batch; ++b) {
+            int c = 0;
+            while (c < topn && h->h_idx[static_cast<int64_t>(b) * topn + c] >= 0) ++c;
+            out_count[b] = c;
+        }
+    }
+    return MI355REC_OK;
+}
+
+int mi355rec_query_topn(mi355rec_t* h, const float* query12, int64_t exclude_global, int topn,
+                        int64_t* out_idx, float* out_score, int* out_count) {
+    return mi355rec_query_batch_topn(h, query12, 1, &exclude_global, topn, out_idx, out_score, out_count);
+}
+
+int mi355rec_query_row_topn(mi355rec_t* h, int64_t local_row, int topn, int64_t* out_idx,
+                            float* out_score, int* out_count) {
+    if (!h || !out_idx) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (local_row < 0 || local_row >= h->n)
+        return fail(h, MI355REC_ERR_INVALID_ARG, "Invalid song index: %lld", (long long)local_row);
+    int rc = check_topn(h, topn);
+    if (rc) return rc;
+    DeviceGuard guard(h->device);
+    rc = ensure_batch(h, 1);
+    if (rc) return rc;
+    rc = enqueue_scan(h, local_row, nullptr, h->row_base + local_row, topn, h->stream);
+    if (rc) return rc;
+    rc = enqueue_merge(h, h->d_block_lists, h->grid, topn, topn, h->d_keys, h->d_idx, h->d_score, h->stream);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->h_idx, h->d_idx, topn * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->h_score, h->d_score, topn * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    int c = 0;
+    while (c < topn && h->h_idx[c] >= 0) ++c;
+    std::memcpy(out_idx, h->h_idx, static_cast<size_t>(topn) * sizeof(int64_t));
+    if (out_score) std::memcpy(out_score, h->h_score, static_cast<size_t>(topn) * sizeof(float));
+    if (out_count) *out_count = c;
+    return MI355REC_OK;
+}
+
+// ---- key helpers -----------------------------------------------------------------
+
+mi355rec_key_t mi355rec_pack_key(float score, int64_t global_row) {
+    return pack_key(score, static_cast<uint32_t>(global_row));
+}
+
+float mi355rec_key_score(mi355rec_key_t key) {
+    return key ? ordered_to_score(static_cast<uint32_t>(key >> 32)) : 0.0f;
+}
+
+int64_t mi355rec_key_row(mi355rec_key_t key) {
+    return key ? static_cast<int64_t>(static_cast<uint32_t>(~static_cast<uint32_t>(key))) : -1;
+}
+
+}  // extern "C"

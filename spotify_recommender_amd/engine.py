@@ -1,0 +1,259 @@
+"""Host-side plumbing over the C-ABI: device memory via torch, streams, RCCL.
+
+`CosineEngine` owns one catalogue shard on one GPU.  `ShardedEngine` is the
+multi-GPU path required by BASELINE.json's north_star: one process per GPU,
+rows sharded contiguously, ONE all-gather of `topn` packed keys per rank per
+query over RCCL, then the same device merge kernel that merges the
+per-workgroup lists.  No arithmetic happens in Python.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import capi
+
+
+def _np_f32(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+class CosineEngine:
+    """One row shard of the N x 12 fp32 catalogue resident on one MI355X.
+
+    Replaces the reference's device state (d_features / d_queryFeature /
+    d_similarities, Recommender.h:91-94) and its per-query pipeline
+    (Recommender.cu:184-254 + :293-315).
+    """
+
+    def __init__(self, feats, device: int = 0, row_base: int = 0):
+        self._lib = capi.lib()
+        self._h = ctypes.c_void_p()
+        self._keepalive = None
+        self.device = int(device)
+        try:
+            import torch
+        except Exception:  # pragma: no cover - torch is part of the image
+            torch = None
+        if torch is not None and isinstance(feats, torch.Tensor):
+            if not feats.is_cuda:
+                feats = feats.numpy()
+            else:
+                if feats.dtype != torch.float32 or feats.dim() != 2 or feats.shape[1] != capi.DIM:
+                    raise ValueError("catalogue must be float32 [n, 12]")
+                if not feats.is_contiguous():
+                    raise ValueError("catalogue tensor must be contiguous (row-major)")
+                self._keepalive = feats
+                self.device = feats.device.index if feats.device.index is not None else 0
+                rc = self._lib.mi355rec_create_device(
+                    ctypes.c_void_p(feats.data_ptr()), feats.shape[0], feats.shape[1],
+                    self.device, int(row_base), ctypes.byref(self._h))
+                capi.check(rc)
+                self.rows = int(feats.shape[0])
+                self.row_base = int(row_base)
+                return
+        arr = _np_f32(feats)
+        if arr.ndim != 2 or arr.shape[1] != capi.DIM:
+            raise ValueError("catalogue must be float32 [n, 12]")
+        rc = self._lib.mi355rec_create(
+            arr.ctypes.data_as(ctypes.c_void_p), arr.shape[0], arr.shape[1], self.device,
+            int(row_base), ctypes.byref(self._h))
+        capi.check(rc)
+        self.rows = int(arr.shape[0])
+        self.row_base = int(row_base)
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.mi355rec_destroy(self._h)
+            self._h = ctypes.c_void_p()
+        self._keepalive = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- synchronous host API ------------------------------------------------
+    def scores_row(self, local_row: int) -> np.ndarray:
+        out = np.empty(self.rows, dtype=np.float32)
+        capi.check(self._lib.mi355rec_scores_row(self._h, int(local_row), out.ctypes.data_as(ctypes.c_void_p)), self._h)
+        return out
+
+    def scores(self, query) -> np.ndarray:
+        q = _np_f32(query).reshape(capi.DIM)
+        out = np.empty(self.rows, dtype=np.float32)
+        capi.check(self._lib.mi355rec_scores(self._h, q.ctypes.data_as(ctypes.c_void_p),
+                                             out.ctypes.data_as(ctypes.c_void_p)), self._h)
+        return out
+
+    def query_row_topn(self, local_row: int, topn: int) -> Tuple[np.ndarray, np.ndarray]:
+        n_out = max(int(topn), 1)
+        idx = np.empty(n_out, dtype=np.int64)
+        score = np.empty(n_out, dtype=np.float32)
+        count = ctypes.c_int(0)
+        capi.check(self._lib.mi355rec_query_row_topn(
+            self._h, int(local_row), int(topn), idx.ctypes.data_as(ctypes.c_void_p),
+            score.ctypes.data_as(ctypes.c_void_p), ctypes.byref(count)), self._h)
+        return idx[:count.value].copy(), score[:count.value].copy()
+
+    def query_topn(self, query, exclude_global: int, topn: int) -> Tuple[np.ndarray, np.ndarray]:
+        q = _np_f32(query).reshape(capi.DIM)
+        n_out = max(int(topn), 1)
+        idx = np.empty(n_out, dtype=np.int64)
+        score = np.empty(n_out, dtype=np.float32)
+        count = ctypes.c_int(0)
+        capi.check(self._lib.mi355rec_query_topn(
+            self._h, q.ctypes.data_as(ctypes.c_void_p), int(exclude_global), int(topn),
+            idx.ctypes.data_as(ctypes.c_void_p), score.ctypes.data_as(ctypes.c_void_p),
+            ctypes.byref(count)), self._h)
+        return idx[:count.value].copy(), score[:count.value].copy()
+
+    def query_batch_topn(self, queries, exclude_global, topn: int):
+        q = _np_f32(queries).reshape(-1, capi.DIM)
+        b = q.shape[0]
+        excl = None
+        if exclude_global is not None:
+            excl = np.ascontiguousarray(np.asarray(exclude_global, dtype=np.int64).reshape(b))
+        n_out = max(int(topn), 1)
+        idx = np.empty((b, n_out), dtype=np.int64)
+        score = np.empty((b, n_out), dtype=np.float32)
+        counts = np.zeros(b, dtype=np.int32)
+        capi.check(self._lib.mi355rec_query_batch_topn(
+            self._h, q.ctypes.data_as(ctypes.c_void_p), b,
+            excl.ctypes.data_as(ctypes.c_void_p) if excl is not None else None, int(topn),
+            idx.ctypes.data_as(ctypes.c_void_p), score.ctypes.data_as(ctypes.c_void_p),
+            counts.ctypes.data_as(ctypes.c_void_p)), self._h)
+        return idx, score, counts
+
+    # -- asynchronous device API -------------------------------------------
+    @staticmethod
+    def _stream_ptr(stream) -> ctypes.c_void_p:
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream()
+        if hasattr(stream, "cuda_stream"):
+            return ctypes.c_void_p(stream.cuda_stream)
+        return ctypes.c_void_p(int(stream))
+
+    def enqueue_row_keys(self, local_row: int, topn: int, out_keys, stream=None) -> None:
+        capi.check(self._lib.mi355rec_enqueue_row_keys(
+            self._h, int(local_row), int(topn), ctypes.c_void_p(out_keys.data_ptr()),
+            self._stream_ptr(stream)), self._h)
+
+    def enqueue_query_keys(self, query, exclude_global: int, topn: int, out_keys, stream=None) -> None:
+        q = _np_f32(query).reshape(capi.DIM)
+        capi.check(self._lib.mi355rec_enqueue_query_keys(
+            self._h, q.ctypes.data_as(ctypes.c_void_p), int(exclude_global), int(topn),
+            ctypes.c_void_p(out_keys.data_ptr()), self._stream_ptr(stream)), self._h)
+
+    def enqueue_merge_keys(self, lists, n_lists: int, list_len: int, topn: int, out_keys,
+                           out_idx=None, out_score=None, stream=None) -> None:
+        capi.check(self._lib.mi355rec_enqueue_merge_keys(
+            self._h, ctypes.c_void_p(lists.data_ptr()), int(n_lists), int(list_len), int(topn),
+            ctypes.c_void_p(out_keys.data_ptr()),
+            ctypes.c_void_p(out_idx.data_ptr()) if out_idx is not None else None,
+            ctypes.c_void_p(out_score.data_ptr()) if out_score is not None else None,
+            self._stream_ptr(stream)), self._h)
+
+    def enqueue_scores(self, local_row: int, query, out_scores, stream=None) -> None:
+        q = None if query is None else _np_f32(query).reshape(capi.DIM)
+        capi.check(self._lib.mi355rec_enqueue_scores(
+            self._h, int(local_row), q.ctypes.data_as(ctypes.c_void_p) if q is not None else None,
+            ctypes.c_void_p(out_scores.data_ptr()), self._stream_ptr(stream)), self._h)
+
+    def enqueue_stream_probe(self, sink, stream=None) -> None:
+        capi.check(self._lib.mi355rec_enqueue_stream_probe(
+            self._h, ctypes.c_void_p(sink.data_ptr()), self._stream_ptr(stream)), self._h)
+
+    def set_timing(self, enabled: bool) -> None:
+        capi.check(self._lib.mi355rec_set_timing(self._h, 1 if enabled else 0), self._h)
+
+    def stats(self) -> capi.Stats:
+        st = capi.Stats()
+        capi.check(self._lib.mi355rec_stats(self._h, ctypes.byref(st)), self._h)
+        return st
+
+
+# ---- packed keys on the host (pure bit manipulation, mirrors kernels.hip.h) ----
+
+def unpack_keys(keys) -> Tuple[np.ndarray, np.ndarray]:
+    """(row, score) arrays from packed uint64/int64 keys; empty keys dropped."""
+    k = np.asarray(keys).astype(np.uint64, copy=False).reshape(-1)
+    k = k[k != 0]
+    rows = (~k.astype(np.uint32)).astype(np.int64)  # low 32 bits = ~row
+    hi = (k >> np.uint64(32)).astype(np.uint32)
+    neg = (hi & np.uint32(0x80000000)) == 0
+    bits = np.where(neg, ~hi, hi & np.uint32(0x7FFFFFFF)).astype(np.uint32)
+    return rows, bits.view(np.float32)
+
+
+# ---- row sharding -----------------------------------------------------------
+
+def shard_bounds(n_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous row block of `rank`: [lo, hi)."""
+    per = -(-int(n_rows) // int(world_size))
+    lo = min(int(n_rows), rank * per)
+    hi = min(int(n_rows), (rank + 1) * per)
+    return lo, hi
+
+
+class ShardedEngine:
+    """Row-sharded catalogue, one process per GPU, one all-gather per query.
+
+    `local` is this rank's engine over rows [lo, hi) created with
+    row_base=lo, so the keys it emits already carry GLOBAL row ids and the
+    merged result does not depend on the number of ranks.  Everything is
+    enqueued on the current stream; nothing synchronises the host.
+    """
+
+    def __init__(self, local, max_topn: int, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+
+        self._torch = torch
+        self._dist = dist
+        self.local = local
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.max_topn = int(max_topn)
+        dev = device if device is not None else torch.device("cuda", local.device)
+        self.device = dev
+        self.local_keys = torch.zeros(self.max_topn, dtype=torch.int64, device=dev)
+        self.gathered = torch.zeros(self.world * self.max_topn, dtype=torch.int64, device=dev)
+        self.out_keys = torch.zeros(self.max_topn, dtype=torch.int64, device=dev)
+        self.out_idx = torch.full((self.max_topn,), -1, dtype=torch.int64, device=dev)
+        self.out_score = torch.zeros(self.max_topn, dtype=torch.float32, device=dev)
+
+    def enqueue_query(self, query, exclude_global: int, topn: int) -> None:
+        """Scan the local shard, all-gather the candidates, merge on device."""
+        if topn > self.max_topn:
+            raise ValueError(f"topn {topn} > max_topn {self.max_topn}")
+        k = int(topn)
+        local = self.local_keys[:k]
+        self.local.enqueue_query_keys(query, exclude_global, k, local)
+        if self.world == 1:
+            gathered = local
+        else:
+            gathered = self.gathered[: self.world * k]
+            self._dist.all_gather_into_tensor(gathered, local, group=self.group)
+        self.local.enqueue_merge_keys(gathered, self.world, k, k, self.out_keys[:k],
+                                      self.out_idx[:k], self.out_score[:k])
+
+    def query(self, query, exclude_global: int, topn: int):
+        """Synchronous convenience wrapper: (rows, scores) as numpy arrays."""
+        self.enqueue_query(query, exclude_global, topn)
+        idx = self.out_idx[:topn].cpu().numpy()
+        score = self.out_score[:topn].cpu().numpy()
+        keep = idx >= 0
+        return idx[keep], score[keep]

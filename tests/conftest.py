@@ -1,0 +1,26 @@
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return ROOT / "tests" / "golden"
+
+
+@pytest.fixture(scope="session")
+def engine_lib():
+    """The built HIP library; building is part of __graft_entry__.build()."""
+    from spotify_recommender_amd import build, capi
+    if not capi.LIB_PATH.exists():
+        build.build_engine()
+    return capi.lib()

@@ -1,0 +1,77 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol the
+header declares, and fails loudly (no fallback) when there is no device."""
+import ctypes
+import re
+
+import numpy as np
+import pytest
+
+from spotify_recommender_amd import capi, engine
+
+
+def declared_symbols(root):
+    text = (root / "include" / "mi355rec.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi355rec_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(engine_lib, golden_dir):
+    root = golden_dir.parents[1]
+    names = declared_symbols(root)
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(engine_lib, name), f"{name} declared in mi355rec.h but not exported"
+    assert set(names) == set(capi.SIGNATURES), "capi.py and mi355rec.h disagree"
+
+
+def test_key_helpers_roundtrip(engine_lib):
+    L = engine_lib
+    rng = np.random.default_rng(3)
+    scores = np.concatenate([rng.uniform(-1, 1, 200).astype(np.float32),
+                             np.array([0.0, -0.0, 1.0, -1.0, 1e-40, -1e-40], np.float32)])
+    rows = rng.integers(0, 2**32 - 2, size=scores.shape[0])
+    keys = np.array([L.mi355rec_pack_key(float(s), int(r)) for s, r in zip(scores, rows)], dtype=np.uint64)
+    for k, s, r in zip(keys, scores, rows):
+        assert L.mi355rec_key_row(int(k)) == r
+        assert L.mi355rec_key_score(int(k)) == s  # -0.0 == +0.0
+    # numpy unpack mirrors the C helpers
+    u_rows, u_scores = engine.unpack_keys(keys)
+    assert np.array_equal(u_rows, rows)
+    assert np.array_equal(u_scores, scores + np.float32(0))
+    # key order == canonical order (score desc, row asc)
+    order = np.argsort(keys)[::-1]
+    for a, b in zip(order[:-1], order[1:]):
+        assert scores[a] > scores[b] or (scores[a] == scores[b] and rows[a] < rows[b])
+    assert L.mi355rec_key_row(0) == -1
+
+
+def test_no_device_is_a_loud_error(engine_lib):
+    L = engine_lib
+    if L.mi355rec_device_count() > 0:
+        pytest.skip("a GPU is visible; the no-device path is covered on the CPU container")
+    feats = np.zeros((8, 12), dtype=np.float32)
+    h = ctypes.c_void_p()
+    rc = L.mi355rec_create(feats.ctypes.data_as(ctypes.c_void_p), 8, 12, 0, 0, ctypes.byref(h))
+    assert rc == capi.ERR_NO_DEVICE and not h
+    assert b"no CPU fallback" in L.mi355rec_last_global_error()
+    with pytest.raises(capi.Mi355Error):
+        engine.CosineEngine(feats)
+
+
+def test_argument_validation_without_device(engine_lib):
+    L = engine_lib
+    h = ctypes.c_void_p()
+    feats = np.zeros((8, 12), dtype=np.float32)
+    assert L.mi355rec_create(feats.ctypes.data_as(ctypes.c_void_p), 8, 11, 0, 0, ctypes.byref(h)) == capi.ERR_INVALID_ARG
+    assert L.mi355rec_create(feats.ctypes.data_as(ctypes.c_void_p), 0, 12, 0, 0, ctypes.byref(h)) == capi.ERR_INVALID_ARG
+    assert L.mi355rec_create(None, 8, 12, 0, 0, ctypes.byref(h)) == capi.ERR_INVALID_ARG
+    L.mi355rec_destroy(None)  # no-op
+
+
+def test_shard_bounds_cover_rows():
+    for n in (1, 7, 64, 1000, 10_000_000):
+        for w in (1, 2, 3, 4, 8):
+            spans = [engine.shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b), (c, d) in zip(spans[:-1], spans[1:]):
+                assert b == c and a <= b
