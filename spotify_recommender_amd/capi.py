@@ -74,6 +74,15 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} is missing: build it with `python -m spotify_recommender_amd.build` "
                 "(hipcc --offload-arch=gfx950). The cosine top-N path has no fallback."
             )
+        # One HIP runtime per process: torch bundles its own libamdhip64 and
+        # whichever runtime touches the GPU first owns it.  Importing torch
+        # first maps its runtime, and our library's libamdhip64.so dependency
+        # then resolves to that same copy (same SONAME).  Without torch the
+        # library uses /opt/rocm's runtime (the C++ CLI path).
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover
+            pass
         handle = ctypes.CDLL(str(LIB_PATH))
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported

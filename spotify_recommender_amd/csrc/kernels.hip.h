@@ -29,6 +29,7 @@ constexpr int kCandLimit = kCandCap - kTileRows;  // compact above this
 constexpr int kMergeBlock = 1024;
 constexpr int kMergeMaxLists = 2048;
 constexpr int kMergeSurvCap = 4096;
+constexpr int kMergeChunk = 16;      // keys probed per list per merge round
 
 static_assert(kCandLimit >= kMaxTopK, "threshold needs topk survivors");
 
@@ -105,11 +106,12 @@ __device__ __forceinline__ Row load_row(const float* __restrict__ feats, int64_t
 // threshold (the topk-th key, or 0 while fewer than topk candidates exist).
 // Must be called by every thread of the workgroup.
 
+template <int kThreads>
 __device__ inline uint64_t compact_candidates(uint64_t* s_cand, uint64_t* s_top,
                                               int* s_count, int topk) {
     __syncthreads();
     const int c = *s_count;
-    for (int i = threadIdx.x; i < c; i += blockDim.x) {
+    for (int i = threadIdx.x; i < c; i += kThreads) {
         const uint64_t mine = s_cand[i];
         int rank = 0;
         int j = 0;
@@ -122,7 +124,7 @@ __device__ inline uint64_t compact_candidates(uint64_t* s_cand, uint64_t* s_top,
     }
     __syncthreads();
     const int kept = c < topk ? c : topk;
-    for (int i = threadIdx.x; i < kept; i += blockDim.x) s_cand[i] = s_top[i];
+    for (int i = threadIdx.x; i < kept; i += kThreads) s_cand[i] = s_top[i];
     const uint64_t thr = (c >= topk) ? s_top[topk - 1] : 0ull;
     __syncthreads();
     if (threadIdx.x == 0) *s_count = kept;
@@ -143,7 +145,9 @@ __device__ inline uint64_t compact_candidates(uint64_t* s_cand, uint64_t* s_top,
 // survivors to an LDS buffer, and leave the workgroup's sorted top-k list in
 // block_lists[b][0..topk).
 
-template <bool kQueryFromRow, bool kScoresOnly>
+// kDebug (development A/B only; 0 in the product): 1 = no end-of-tile barrier pair,
+// 2 = ballot only, no LDS append, 4 = skip the seed compaction (threshold preset).
+template <bool kQueryFromRow, bool kScoresOnly, int kDebug = 0>
 __global__ __launch_bounds__(kBlock) void scan_kernel(
     const float* __restrict__ feats, int64_t n, int64_t rows_per_block, int iters,
     int64_t row_base, QueryArg qarg, int64_t query_row, int64_t exclude_global,
@@ -168,20 +172,29 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
     const int64_t blk_begin = static_cast<int64_t>(blockIdx.x) * rows_per_block;
     int64_t blk_end = blk_begin + rows_per_block;
     if (blk_end > n) blk_end = n;
-    const int64_t last_row = n - 1;
+    // rows past the block's end re-read its last row (one cached line) so the
+    // prefetch can be unconditional: a conditional load would make the compiler
+    // wait vmcnt(0) at the join and serialise the pipeline
+    const int64_t last_row = blk_end - 1;  // the host launches only non-empty blocks
 
     if constexpr (!kScoresOnly) {
         if (tid == 0) s_count = 0;
         __syncthreads();
     }
     uint64_t thr = 0;
+    if constexpr ((kDebug & 4) != 0) thr = pack_key(0.985f, 0u);
+    // Re-tighten the threshold once ~topk NEW candidates have piled up: ranking
+    // c candidates costs ~c*c/32 LDS cycles, so c must stay a small multiple of
+    // topk (a stale threshold that lets 2000+ candidates through costs ~85 us).
+    int compact_at = 2 * topk > 256 ? 2 * topk : 256;
+    if (compact_at > kCandLimit) compact_at = kCandLimit;
 
     auto load_tile = [&](Row (&dst)[kRowsPerThread], int it) {
         const int64_t tile_begin = blk_begin + static_cast<int64_t>(it) * kTileRows;
 #pragma unroll
         for (int u = 0; u < kRowsPerThread; ++u) {
             const int64_t r = tile_begin + u * kBlock + tid;
-            dst[u] = load_row(feats, r < last_row ? r : last_row);
+            dst[u] = load_row(feats, r < blk_end ? r : last_row);
         }
     };
 
@@ -200,30 +213,30 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
                 if (!in_range || g == exclude_global) key = 0;
                 const bool pass = key > thr;
                 const uint64_t ballot = __ballot(pass);
-                if (ballot) {
+                if (ballot && (kDebug & 2) == 0) {
                     int base = 0;
                     if (lane == 0) base = atomicAdd(&s_count, __popcll(ballot));
                     base = __builtin_amdgcn_readfirstlane(base);
                     const int pos = base + __popcll(ballot & ((1ull << lane) - 1ull));
                     if (pass) s_cand[pos] = key;
                 }
-                if (thr == 0) {
+                if (thr == 0 && (kDebug & 4) == 0) {
                     // seed: establish the threshold from the first rows instead
                     // of letting whole unfiltered tiles pile up (thr is uniform)
                     __syncthreads();
                     const int c = s_count;
                     __syncthreads();
-                    if (c >= topk) thr = compact_candidates(s_cand, s_top, &s_count, topk);
+                    if (c >= topk) thr = compact_candidates<kBlock>(s_cand, s_top, &s_count, topk);
                 }
             }
         }
-        if constexpr (!kScoresOnly) {
+        if constexpr (!kScoresOnly && (kDebug & 1) == 0) {
             // keep room for one more unfiltered tile (two barriers: every wave
             // must have read the count before any wave appends again)
             __syncthreads();
             const int c = s_count;
             __syncthreads();
-            if (c > kCandLimit) thr = compact_candidates(s_cand, s_top, &s_count, topk);
+            if (c >= compact_at) thr = compact_candidates<kBlock>(s_cand, s_top, &s_count, topk);
         }
     };
 
@@ -231,16 +244,14 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
     Row buf_b[kRowsPerThread];
     load_tile(buf_a, 0);
     for (int it = 0; it < iters; it += 2) {
-        if (it + 1 < iters) load_tile(buf_b, it + 1);
+        load_tile(buf_b, it + 1);
         process_tile(buf_a, it);
-        if (it + 1 < iters) {
-            if (it + 2 < iters) load_tile(buf_a, it + 2);
-            process_tile(buf_b, it + 1);
-        }
+        load_tile(buf_a, it + 2);
+        process_tile(buf_b, it + 1);  // fully masked when it + 1 == iters
     }
 
     if constexpr (!kScoresOnly) {
-        compact_candidates(s_cand, s_top, &s_count, topk);
+        compact_candidates<kBlock>(s_cand, s_top, &s_count, topk);
         const int kept = s_count;
         uint64_t* out = block_lists + static_cast<int64_t>(blockIdx.x) * topk;
         for (int i = tid; i < topk; i += kBlock) out[i] = (i < kept) ? s_cand[i] : 0ull;
@@ -305,11 +316,10 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
     __shared__ int s_hist[256];
     __shared__ int s_count;
     __shared__ int s_overflow;
+    __shared__ int s_more;
+    __shared__ unsigned short s_active[kMergeMaxLists];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int n_waves = kMergeBlock / 64;
     const uint64_t* lists = lists_base + static_cast<int64_t>(blockIdx.x) * lists_query_stride;
     uint64_t* out_keys = out_keys_base + static_cast<int64_t>(blockIdx.x) * out_query_stride;
 
@@ -346,25 +356,39 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
     if (thr == 0) thr = 1;  // accept every non-empty key
     __syncthreads();
 
-    // survivors: the prefix of each list with key >= thr (one wave per list)
-    for (int l = wave; l < n_lists; l += n_waves) {
-        const uint64_t* lp = lists + static_cast<int64_t>(l) * list_len;
-        for (int c0 = 0; c0 < list_len; c0 += 64) {
-            const int i = c0 + lane;
-            const uint64_t k = (i < list_len) ? lp[i] : 0ull;
-            const bool pass = k >= thr;
-            const uint64_t ballot = __ballot(pass);
-            if (!ballot) break;
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&s_count, __popcll(ballot));
-            base = __builtin_amdgcn_readfirstlane(base);
-            const int pos = base + __popcll(ballot & ((1ull << lane) - 1ull));
-            if (pass) {
-                if (pos < kMergeSurvCap) s_surv[pos] = k;
-                else s_overflow = 1;
+    // survivors: the prefix of each list with key >= thr.  Round d looks at
+    // keys [d*C, (d+1)*C) of every list that is still active (its previous
+    // chunk passed entirely); all loads of a round are independent.  Typically
+    // one round (a fraction of a key per list survives).
+    for (int l = tid; l < n_lists; l += kMergeBlock) s_active[l] = 0;
+    __syncthreads();
+    for (int round = 0; round * kMergeChunk < list_len; ++round) {
+        if (tid == 0) s_more = 0;
+        __syncthreads();
+        for (int t = tid; t < n_lists * kMergeChunk; t += kMergeBlock) {
+            const int l = t / kMergeChunk;
+            const int pos = round * kMergeChunk + (t % kMergeChunk);
+            if (pos < list_len && s_active[l] == round) {
+                const uint64_t k = lists[static_cast<int64_t>(l) * list_len + pos];
+                if (k >= thr) {
+                    const int slot = atomicAdd(&s_count, 1);
+                    if (slot < kMergeSurvCap) s_surv[slot] = k;
+                    else s_overflow = 1;
+                    if ((t % kMergeChunk) == kMergeChunk - 1) s_more = 1;
+                }
             }
-            if (ballot != ~0ull) break;
         }
+        __syncthreads();
+        if (!s_more || s_overflow) break;
+        // a list stays active iff the LAST key of this chunk passed
+        for (int l = tid; l < n_lists; l += kMergeBlock) {
+            if (s_active[l] == round) {
+                const int last = (round + 1) * kMergeChunk - 1;
+                if (last < list_len && lists[static_cast<int64_t>(l) * list_len + last] >= thr)
+                    s_active[l] = static_cast<unsigned short>(round + 1);
+            }
+        }
+        __syncthreads();
     }
     __syncthreads();
 
