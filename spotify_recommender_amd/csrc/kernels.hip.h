@@ -25,13 +25,17 @@ constexpr int kRowsPerThread = 4;     // rows in flight per lane per tile
 constexpr int kTileRows = kBlock * kRowsPerThread;
 constexpr int kMaxTopK = 1024;        // MI355REC_MAX_TOPN_FAST
 constexpr int kCandCap = 4096;        // LDS candidate slots per workgroup
-constexpr int kCandLimit = kCandCap - kTileRows;  // compact above this
+constexpr int kCandLimit = kCandCap - kTileRows;  // never enter a tile above this
+constexpr int kCandPerThread = kCandCap / kBlock;
 constexpr int kMergeBlock = 1024;
 constexpr int kMergeMaxLists = 2048;
 constexpr int kMergeSurvCap = 4096;
-constexpr int kMergeChunk = 16;      // keys probed per list per merge round
+constexpr int kMergeChunk = 16;       // keys probed per list per merge round
+constexpr int kMergeSurvPerThread = kMergeSurvCap / kMergeBlock;
+constexpr int kMergeHeadsPerThread = kMergeMaxLists / kMergeBlock;
 
-static_assert(kCandLimit >= kMaxTopK, "threshold needs topk survivors");
+static_assert(kCandLimit >= 2 * kMaxTopK, "room for topk survivors + slack");
+static_assert(kCandCap % kBlock == 0 && kMergeSurvCap % kMergeBlock == 0, "even shares");
 
 struct QueryArg {
     float q[kDim];
@@ -100,36 +104,172 @@ __device__ __forceinline__ Row load_row(const float* __restrict__ feats, int64_t
     return r;
 }
 
-// ---- workgroup-level candidate compaction --------------------------------------
-// Keeps the best min(count, topk) keys of s_cand[0..count) in s_cand[0..) sorted
-// descending (rank by counting: keys are unique), and returns the new filter
-// threshold (the topk-th key, or 0 while fewer than topk candidates exist).
-// Must be called by every thread of the workgroup.
+// ---- workgroup-level selection ------------------------------------------------
+// Ranking c candidates by counting costs ~c*c/32 LDS cycles (85 us at c = 2560),
+// so thresholds come from an O(c) MSB-first radix select on LDS histograms and
+// only the final <= topk survivors are ever ranked.
 
-template <int kThreads>
-__device__ inline uint64_t compact_candidates(uint64_t* s_cand, uint64_t* s_top,
-                                              int* s_count, int topk) {
-    __syncthreads();
-    const int c = *s_count;
-    for (int i = threadIdx.x; i < c; i += kThreads) {
-        const uint64_t mine = s_cand[i];
-        int rank = 0;
-        int j = 0;
-        for (; j + 4 <= c; j += 4) {
-            rank += (s_cand[j] > mine) + (s_cand[j + 1] > mine) +
-                    (s_cand[j + 2] > mine) + (s_cand[j + 3] > mine);
+struct SelectSmem {
+    int hist[256];
+    unsigned long long vmax;
+    unsigned long long vmin;
+    int digit;
+    int above;
+    int in_bin;
+    int pad;
+};
+
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint64_t o = __shfl_xor(v, off);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint64_t o = __shfl_xor(v, off);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// Every thread of the workgroup calls this with its share of the keys in
+// registers (0 = empty slot; keys are unique).  Precondition: at least `need`
+// non-empty keys in total, need >= 1.  Returns T with |{key >= T}| >= need;
+// with `exact` the count is exactly `need`, otherwise up to `slack` extra keys
+// may remain (fewer passes).  Digits are taken relative to the smallest key so
+// the first pass already separates the candidates.
+template <int kThreads, int kPerThread>
+__device__ inline uint64_t block_select_threshold(const uint64_t (&mine)[kPerThread], int need,
+                                                  bool exact, int slack, SelectSmem& sm) {
+    static_assert(kThreads >= 256, "histogram is cleared by the first 256 threads");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+
+    uint64_t mx = 0, mn = ~0ull;
+#pragma unroll
+    for (int r = 0; r < kPerThread; ++r) {
+        if (mine[r]) {
+            mx = mine[r] > mx ? mine[r] : mx;
+            mn = mine[r] < mn ? mine[r] : mn;
         }
-        for (; j < c; ++j) rank += (s_cand[j] > mine);
-        if (rank < topk) s_top[rank] = mine;
+    }
+    mx = wave_max_u64(mx);
+    mn = wave_min_u64(mn);
+    if (tid == 0) {
+        sm.vmax = 0ull;
+        sm.vmin = ~0ull;
     }
     __syncthreads();
-    const int kept = c < topk ? c : topk;
-    for (int i = threadIdx.x; i < kept; i += kThreads) s_cand[i] = s_top[i];
-    const uint64_t thr = (c >= topk) ? s_top[topk - 1] : 0ull;
+    if (lane == 0) {
+        atomicMax(&sm.vmax, static_cast<unsigned long long>(mx));
+        atomicMin(&sm.vmin, static_cast<unsigned long long>(mn));
+    }
     __syncthreads();
-    if (threadIdx.x == 0) *s_count = kept;
+    const uint64_t base = sm.vmin;
+    const uint64_t span = sm.vmax - base;
+    int shift = span ? (64 - __clzll(static_cast<long long>(span))) - 8 : 0;
+    if (shift < 0) shift = 0;
+    uint64_t prefix = 0, mask = 0;
+
+    for (;;) {
+        if (tid < 256) sm.hist[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kPerThread; ++r) {
+            const uint64_t k = mine[r];
+            if (k) {
+                const uint64_t v = k - base;
+                if ((v & mask) == prefix) atomicAdd(&sm.hist[static_cast<int>((v >> shift) & 255u)], 1);
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // lane l owns bins 4l..4l+3; suffix sums from the top bin down
+            const int h0 = sm.hist[4 * lane + 0], h1 = sm.hist[4 * lane + 1];
+            const int h2 = sm.hist[4 * lane + 2], h3 = sm.hist[4 * lane + 3];
+            const int lane_sum = h0 + h1 + h2 + h3;
+            int incl = lane_sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_down(incl, off);
+                if (lane + off < 64) incl += o;
+            }
+            int cum = incl - lane_sum;  // keys in bins above this lane's
+            const int hs[4] = {h0, h1, h2, h3};
+#pragma unroll
+            for (int b = 3; b >= 0; --b) {
+                if (cum < need && cum + hs[b] >= need) {
+                    sm.digit = 4 * lane + b;
+                    sm.above = cum;
+                    sm.in_bin = hs[b];
+                }
+                cum += hs[b];
+            }
+        }
+        __syncthreads();
+        const int digit = sm.digit, above = sm.above, in_bin = sm.in_bin;
+        prefix |= static_cast<uint64_t>(digit) << shift;
+        mask |= 255ull << shift;
+        need -= above;
+        if (shift == 0 || in_bin == need || (!exact && in_bin - need <= slack)) break;
+        shift = shift > 8 ? shift - 8 : 0;
+    }
+    return base + prefix;
+}
+
+// Ranks the `c` unique keys in s_keys (c <= kMaxTopK) by counting and writes
+// them in descending order to dst[0..c), zero-filling dst[c..pad_to).
+template <int kThreads>
+__device__ inline void block_rank_and_store(const uint64_t* s_keys, int c, uint64_t* dst, int pad_to) {
+    for (int i = threadIdx.x; i < pad_to; i += kThreads) {
+        if (i >= c) dst[i] = 0ull;
+    }
+    for (int i = threadIdx.x; i < c; i += kThreads) {
+        const uint64_t mine = s_keys[i];
+        int rank = 0;
+        int j = 0;
+        for (; j + 8 <= c; j += 8) {
+            const uint64_t k0 = s_keys[j], k1 = s_keys[j + 1], k2 = s_keys[j + 2], k3 = s_keys[j + 3];
+            const uint64_t k4 = s_keys[j + 4], k5 = s_keys[j + 5], k6 = s_keys[j + 6], k7 = s_keys[j + 7];
+            rank += (k0 > mine) + (k1 > mine) + (k2 > mine) + (k3 > mine) +
+                    (k4 > mine) + (k5 > mine) + (k6 > mine) + (k7 > mine);
+        }
+        for (; j < c; ++j) rank += (s_keys[j] > mine);
+        dst[rank] = mine;
+    }
+}
+
+// Shrinks s_cand[0..*s_count) to the keys >= T where T bounds the topk-th best
+// (exactly topk keys remain with `exact`), and returns the filter threshold for
+// the streaming loop: later keys pass iff key > return value.
+template <int kThreads>
+__device__ inline uint64_t compact_candidates(uint64_t* s_cand, int* s_count, int topk,
+                                              bool exact, SelectSmem& sm) {
     __syncthreads();
-    return thr;
+    const int c = *s_count;
+    if (c <= topk) return 0ull;  // uniform: nothing to drop yet
+    uint64_t mine[kCandPerThread];
+#pragma unroll
+    for (int r = 0; r < kCandPerThread; ++r) {
+        const int i = threadIdx.x + r * kThreads;
+        mine[r] = i < c ? s_cand[i] : 0ull;
+    }
+    int slack = topk / 4;
+    if (slack < 16) slack = 16;
+    const uint64_t t = block_select_threshold<kThreads, kCandPerThread>(mine, topk, exact, slack, sm);
+    if (threadIdx.x == 0) *s_count = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kCandPerThread; ++r) {
+        if (mine[r] >= t) s_cand[atomicAdd(s_count, 1)] = mine[r];
+    }
+    __syncthreads();
+    return t - 1ull;
 }
 
 // ---- streaming scan ----------------------------------------------------------
@@ -153,7 +293,7 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
     int64_t row_base, QueryArg qarg, int64_t query_row, int64_t exclude_global,
     int topk, uint64_t* __restrict__ block_lists, float* __restrict__ scores_out) {
     __shared__ uint64_t s_cand[kScoresOnly ? 1 : kCandCap];
-    __shared__ uint64_t s_top[kScoresOnly ? 1 : kMaxTopK];
+    __shared__ SelectSmem s_sel;
     __shared__ int s_count;
 
     float q[kDim];
@@ -183,9 +323,9 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
     }
     uint64_t thr = 0;
     if constexpr ((kDebug & 4) != 0) thr = pack_key(0.985f, 0u);
-    // Re-tighten the threshold once ~topk NEW candidates have piled up: ranking
-    // c candidates costs ~c*c/32 LDS cycles, so c must stay a small multiple of
-    // topk (a stale threshold that lets 2000+ candidates through costs ~85 us).
+    // Re-tighten the threshold once ~topk NEW candidates have piled up (the
+    // select is O(c), but every candidate that slips past a stale threshold
+    // costs an LDS atomic round trip in the streaming loop).
     int compact_at = 2 * topk > 256 ? 2 * topk : 256;
     if (compact_at > kCandLimit) compact_at = kCandLimit;
 
@@ -220,23 +360,15 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
                     const int pos = base + __popcll(ballot & ((1ull << lane) - 1ull));
                     if (pass) s_cand[pos] = key;
                 }
-                if (thr == 0 && (kDebug & 4) == 0) {
-                    // seed: establish the threshold from the first rows instead
-                    // of letting whole unfiltered tiles pile up (thr is uniform)
-                    __syncthreads();
-                    const int c = s_count;
-                    __syncthreads();
-                    if (c >= topk) thr = compact_candidates<kBlock>(s_cand, s_top, &s_count, topk);
-                }
             }
         }
-        if constexpr (!kScoresOnly && (kDebug & 1) == 0) {
-            // keep room for one more unfiltered tile (two barriers: every wave
-            // must have read the count before any wave appends again)
+        if constexpr (!kScoresOnly && (kDebug & 5) == 0) {
+            // Two barriers: every wave must have read the count before any wave
+            // appends again, or the waves could disagree about compacting.
             __syncthreads();
             const int c = s_count;
             __syncthreads();
-            if (c >= compact_at) thr = compact_candidates<kBlock>(s_cand, s_top, &s_count, topk);
+            if (c >= compact_at) thr = compact_candidates<kBlock>(s_cand, &s_count, topk, false, s_sel);
         }
     };
 
@@ -251,10 +383,10 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
     }
 
     if constexpr (!kScoresOnly) {
-        compact_candidates<kBlock>(s_cand, s_top, &s_count, topk);
-        const int kept = s_count;
-        uint64_t* out = block_lists + static_cast<int64_t>(blockIdx.x) * topk;
-        for (int i = tid; i < topk; i += kBlock) out[i] = (i < kept) ? s_cand[i] : 0ull;
+        compact_candidates<kBlock>(s_cand, &s_count, topk, true, s_sel);
+        __syncthreads();
+        const int kept = s_count < topk ? s_count : topk;
+        block_rank_and_store<kBlock>(s_cand, kept, block_lists + static_cast<int64_t>(blockIdx.x) * topk, topk);
     }
 }
 
@@ -264,24 +396,26 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
 // One workgroup per query (blockIdx.x = query in a batch; list / output bases
 // advance by the per-query strides).
 //
-// Fast path: a key can only be in the global top-k if it is >= T, where T is
-// the topk-th largest list HEAD (topk different lists each hold a key >= T).
-// Lists are sorted, so the survivors of each list are a prefix; for
-// statistically similar shards about 1.3*topk keys survive in total.  They are
-// ranked by counting in LDS.  If more than kMergeSurvCap survive (adversarial
-// input), an exact MSB-first radix select over all keys finds the topk-th key.
+// A key can only be in the global top-k if it is >= T whenever m lists each
+// hold >= j keys that are >= T with m*j >= topk.  With plenty of lists j = 1:
+// T = the topk-th largest list HEAD; with few (8 per-rank lists) deeper probes.
+// Lists are sorted, so each list's survivors are a prefix; for statistically
+// similar shards ~1.2*topk keys survive in total.  They are cut to exactly
+// topk by the radix select and ranked.  If more than kMergeSurvCap survive
+// (adversarial input), an exact radix select over all keys in global memory
+// finds the topk-th key instead.
 
-__device__ inline uint64_t merge_radix_select(const uint64_t* __restrict__ lists,
-                                              int64_t total, int topk, int* s_hist,
-                                              uint64_t* s_sel) {
+__device__ inline uint64_t merge_global_radix_select(const uint64_t* __restrict__ lists,
+                                                     int64_t total, int topk, int* s_hist,
+                                                     int* s_pair) {
     // returns the topk-th largest key (0 if fewer than topk non-zero keys)
     uint64_t prefix = 0, mask = 0;
     int remaining = topk;
     for (int pass = 7; pass >= 0; --pass) {
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) s_hist[i] = 0;
+        for (int i = threadIdx.x; i < 256; i += kMergeBlock) s_hist[i] = 0;
         __syncthreads();
         const int shift = pass * 8;
-        for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
+        for (int64_t i = threadIdx.x; i < total; i += kMergeBlock) {
             const uint64_t k = lists[i];
             if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255], 1);
         }
@@ -292,13 +426,13 @@ __device__ inline uint64_t merge_radix_select(const uint64_t* __restrict__ lists
                 if (acc + s_hist[d] >= remaining) break;
                 acc += s_hist[d];
             }
-            s_sel[0] = static_cast<uint64_t>(d);
-            s_sel[1] = static_cast<uint64_t>(remaining - acc);
+            s_pair[0] = d;
+            s_pair[1] = remaining - acc;
         }
         __syncthreads();
-        prefix |= s_sel[0] << shift;
+        prefix |= static_cast<uint64_t>(s_pair[0]) << shift;
         mask |= 255ull << shift;
-        remaining = static_cast<int>(s_sel[1]);
+        remaining = s_pair[1];
         __syncthreads();
     }
     return prefix;
@@ -310,10 +444,9 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
     int64_t* __restrict__ out_idx_base, float* __restrict__ out_score_base,
     int64_t out_query_stride) {
     __shared__ uint64_t s_surv[kMergeSurvCap];
-    __shared__ uint64_t s_heads[kMergeMaxLists];
     __shared__ uint64_t s_top[kMaxTopK];
-    __shared__ uint64_t s_sel[2];
-    __shared__ int s_hist[256];
+    __shared__ SelectSmem s_sel;
+    __shared__ int s_pair[2];
     __shared__ int s_count;
     __shared__ int s_overflow;
     __shared__ int s_more;
@@ -326,55 +459,55 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
     if (tid == 0) {
         s_count = 0;
         s_overflow = 0;
-        s_sel[0] = 0;
+        s_pair[0] = 0;
     }
-    // Threshold: if m lists each hold >= j keys that are >= T, then m*j keys
-    // are >= T, so T is a valid lower bound of the topk-th key when m*j >= topk.
-    // Take j = 1 when there are plenty of lists (T = topk-th largest head),
-    // deeper probes when there are few (e.g. 8 per-rank lists).
+    __syncthreads();
     int probe = 1;
     if (n_lists < 2 * topk) probe = (2 * topk + n_lists - 1) / n_lists;
     if (probe > list_len) probe = list_len;
     const int need_lists = (topk + probe - 1) / probe;
-    for (int l = tid; l < n_lists; l += kMergeBlock)
-        s_heads[l] = lists[static_cast<int64_t>(l) * list_len + (probe - 1)];
-    __syncthreads();
 
-    if (need_lists <= n_lists) {
-        for (int l = tid; l < n_lists; l += kMergeBlock) {
-            const uint64_t mine = s_heads[l];
-            int rank = 0;
-            for (int m = 0; m < n_lists; ++m) {
-                const uint64_t o = s_heads[m];
-                rank += (o > mine) || (o == mine && m < l);
-            }
-            if (rank == need_lists - 1) s_sel[0] = mine;
-        }
+    uint64_t heads[kMergeHeadsPerThread];
+    int local_nonzero = 0;
+#pragma unroll
+    for (int r = 0; r < kMergeHeadsPerThread; ++r) {
+        const int l = tid + r * kMergeBlock;
+        heads[r] = l < n_lists ? lists[static_cast<int64_t>(l) * list_len + (probe - 1)] : 0ull;
+        local_nonzero += heads[r] != 0ull;
+        if (l < n_lists) s_active[l] = 0;
     }
+    if (local_nonzero) atomicAdd(&s_pair[0], local_nonzero);
     __syncthreads();
-    uint64_t thr = s_sel[0];
-    if (thr == 0) thr = 1;  // accept every non-empty key
+    uint64_t thr = 1;  // accept every non-empty key
+    if (s_pair[0] >= need_lists)  // uniform; the select needs >= need_lists non-empty probes
+        thr = block_select_threshold<kMergeBlock, kMergeHeadsPerThread>(heads, need_lists, true, 0, s_sel);
     __syncthreads();
 
     // survivors: the prefix of each list with key >= thr.  Round d looks at
     // keys [d*C, (d+1)*C) of every list that is still active (its previous
-    // chunk passed entirely); all loads of a round are independent.  Typically
-    // one round (a fraction of a key per list survives).
-    for (int l = tid; l < n_lists; l += kMergeBlock) s_active[l] = 0;
-    __syncthreads();
+    // chunk passed entirely); the loads of a round are independent and issued
+    // before any of them is consumed.  Typically one round.
     for (int round = 0; round * kMergeChunk < list_len; ++round) {
         if (tid == 0) s_more = 0;
         __syncthreads();
-        for (int t = tid; t < n_lists * kMergeChunk; t += kMergeBlock) {
-            const int l = t / kMergeChunk;
-            const int pos = round * kMergeChunk + (t % kMergeChunk);
-            if (pos < list_len && s_active[l] == round) {
-                const uint64_t k = lists[static_cast<int64_t>(l) * list_len + pos];
-                if (k >= thr) {
+        const int total = n_lists * kMergeChunk;
+        for (int t0 = 0; t0 < total; t0 += kMergeBlock * 8) {
+            uint64_t k[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u * kMergeBlock + tid;
+                const int l = t / kMergeChunk;
+                const int pos = round * kMergeChunk + (t % kMergeChunk);
+                const bool live = t < total && pos < list_len && s_active[l] == round;
+                k[u] = live ? lists[static_cast<int64_t>(l) * list_len + pos] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (k[u] >= thr) {
                     const int slot = atomicAdd(&s_count, 1);
-                    if (slot < kMergeSurvCap) s_surv[slot] = k;
+                    if (slot < kMergeSurvCap) s_surv[slot] = k[u];
                     else s_overflow = 1;
-                    if ((t % kMergeChunk) == kMergeChunk - 1) s_more = 1;
+                    if (((t0 + u * kMergeBlock + tid) % kMergeChunk) == kMergeChunk - 1) s_more = 1;
                 }
             }
         }
@@ -395,7 +528,7 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
     if (s_overflow) {
         // exact fallback: radix-select the topk-th key over everything
         const int64_t total = static_cast<int64_t>(n_lists) * list_len;
-        uint64_t kth = merge_radix_select(lists, total, topk, s_hist, s_sel);
+        uint64_t kth = merge_global_radix_select(lists, total, topk, s_sel.hist, s_pair);
         if (kth == 0) kth = 1;
         if (tid == 0) s_count = 0;
         __syncthreads();
@@ -410,22 +543,32 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
         __syncthreads();
     }
 
-    const int c = s_count < kMergeSurvCap ? s_count : kMergeSurvCap;
-    for (int i = tid; i < c; i += kMergeBlock) {
-        const uint64_t mine = s_surv[i];
-        int rank = 0;
-        int j = 0;
-        for (; j + 4 <= c; j += 4) {
-            rank += (s_surv[j] > mine) + (s_surv[j + 1] > mine) +
-                    (s_surv[j + 2] > mine) + (s_surv[j + 3] > mine);
-        }
-        for (; j < c; ++j) rank += (s_surv[j] > mine);
-        if (rank < topk) s_top[rank] = mine;
-    }
+    int c = s_count < kMergeSurvCap ? s_count : kMergeSurvCap;
     __syncthreads();
-    const int kept = c < topk ? c : topk;
+    if (c > topk) {  // uniform: cut to exactly topk, O(c)
+        uint64_t mine[kMergeSurvPerThread];
+#pragma unroll
+        for (int r = 0; r < kMergeSurvPerThread; ++r) {
+            const int i = tid + r * kMergeBlock;
+            mine[r] = i < c ? s_surv[i] : 0ull;
+        }
+        const uint64_t t = block_select_threshold<kMergeBlock, kMergeSurvPerThread>(mine, topk, true, 0, s_sel);
+        if (tid == 0) s_count = 0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kMergeSurvPerThread; ++r) {
+            if (mine[r] >= t) {
+                const int pos = atomicAdd(&s_count, 1);
+                if (pos < kMergeSurvCap) s_surv[pos] = mine[r];
+            }
+        }
+        __syncthreads();
+        c = s_count < topk ? s_count : topk;
+    }
+    block_rank_and_store<kMergeBlock>(s_surv, c, s_top, topk);
+    __syncthreads();
     for (int i = tid; i < topk; i += kMergeBlock) {
-        const uint64_t k = (i < kept) ? s_top[i] : 0ull;
+        const uint64_t k = s_top[i];
         out_keys[i] = k;
         if (out_idx_base) {
             out_idx_base[static_cast<int64_t>(blockIdx.x) * out_query_stride + i] =
