@@ -20,22 +20,34 @@
 namespace mi355 {
 
 constexpr int kDim = 12;              // Song.h:12
-constexpr int kBlock = 512;           // threads per workgroup (8 waves)
-constexpr int kRowsPerThread = 4;     // rows in flight per lane per tile
-constexpr int kTileRows = kBlock * kRowsPerThread;
 constexpr int kMaxTopK = 1024;        // MI355REC_MAX_TOPN_FAST
-constexpr int kCandCap = 4096;        // LDS candidate slots per workgroup
-constexpr int kCandLimit = kCandCap - kTileRows;  // never enter a tile above this
-constexpr int kCandPerThread = kCandCap / kBlock;
+constexpr int kCandLimit = 2 * kMaxTopK;  // a tile is never entered with more candidates
+
+// Geometry of the streaming scan: threads per workgroup, rows in flight per lane
+// per tile, and the minimum waves per SIMD the register allocator must leave
+// room for (__launch_bounds__'s second argument).
+template <int kBlockT, int kRowsT, int kMinWavesT>
+struct ScanCfg {
+    static constexpr int kBlock = kBlockT;
+    static constexpr int kRowsPerThread = kRowsT;
+    static constexpr int kMinWaves = kMinWavesT;
+    static constexpr int kTileRows = kBlockT * kRowsT;
+    static constexpr int kCandCap = kCandLimit + kTileRows;  // LDS candidate slots
+    static constexpr int kCandPerThread = (kCandCap + kBlockT - 1) / kBlockT;
+};
+using DefaultScanCfg = ScanCfg<256, 2, 4>;
+constexpr int kProbeBlock = 512;      // stream_probe_kernel
 constexpr int kMergeBlock = 1024;
 constexpr int kMergeMaxLists = 2048;
 constexpr int kMergeSurvCap = 4096;
-constexpr int kMergeChunk = 16;       // keys probed per list per merge round
+constexpr int kMergeChunk = 16;       // keys probed per list per deeper merge round
+constexpr int kMergeFirst = 4;        // keys of every list loaded up front (many-lists case)
+constexpr int kMergeFirstPerThread = 8;  // covers kMergeMaxLists * kMergeFirst keys
 constexpr int kMergeSurvPerThread = kMergeSurvCap / kMergeBlock;
 constexpr int kMergeHeadsPerThread = kMergeMaxLists / kMergeBlock;
 
-static_assert(kCandLimit >= 2 * kMaxTopK, "room for topk survivors + slack");
-static_assert(kCandCap % kBlock == 0 && kMergeSurvCap % kMergeBlock == 0, "even shares");
+static_assert(kMergeSurvCap % kMergeBlock == 0, "even shares");
+static_assert(kMergeBlock % kMergeFirst == 0 && kMergeMaxLists * kMergeFirst <= kMergeBlock * kMergeFirstPerThread, "first-chunk phase covers every list");
 
 struct QueryArg {
     float q[kDim];
@@ -95,6 +107,32 @@ __device__ __forceinline__ float cosine_score(const float (&q)[kDim], float qn,
     return s;
 }
 
+// Cheap UPPER-BOUND test used only to skip rows that cannot beat the running
+// threshold: the cosine evaluated with packed FMAs (even/odd partial sums) and
+// v_rsq_f32.  Against the exactly rounded reference chain its error is
+// <= ~2e-6 (12-term fp32 accumulation in a different order + 1-ulp rsq + two
+// multiplies), so a row is skipped only when approx < threshold_score -
+// kApproxMargin; everything else (NaN included) is re-scored with
+// cosine_score().  Only used while the threshold score is > 0, where the
+// reference's "den <= 1e-8 -> 0" rows can never qualify.
+constexpr float kApproxMargin = 8e-6f;
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float approx_cosine(const float (&q)[kDim], float inv_qn, const Row& r) {
+    const float f[kDim] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y,
+                           r.b.z, r.b.w, r.c.x, r.c.y, r.c.z, r.c.w};
+    v2f d = {0.0f, 0.0f};
+    v2f m = {0.0f, 0.0f};
+#pragma unroll
+    for (int p = 0; p < kDim / 2; ++p) {
+        const v2f ff = {f[2 * p], f[2 * p + 1]};
+        const v2f qq = {q[2 * p], q[2 * p + 1]};
+        d = __builtin_elementwise_fma(ff, qq, d);
+        m = __builtin_elementwise_fma(ff, ff, m);
+    }
+    return (d.x + d.y) * __builtin_amdgcn_rsqf(m.x + m.y) * inv_qn;
+}
+
 __device__ __forceinline__ Row load_row(const float* __restrict__ feats, int64_t row) {
     const float4* p = reinterpret_cast<const float4*>(feats + row * kDim);
     Row r;
@@ -111,38 +149,49 @@ __device__ __forceinline__ Row load_row(const float* __restrict__ feats, int64_t
 
 struct SelectSmem {
     int hist[256];
-    unsigned long long vmax;
-    unsigned long long vmin;
+    unsigned int hi_max;
+    unsigned int hi_min;
     int digit;
     int above;
     int in_bin;
     int pad;
 };
 
-__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const uint64_t o = __shfl_xor(v, off);
-        v = o > v ? o : v;
-    }
-    return v;
+// Inclusive prefix sum across the 64 lanes of a wave in DPP (no LDS traffic):
+// four row_shr steps scan each row of 16 lanes, row_bcast:15 / row_bcast:31
+// carry the row totals forward.
+__device__ __forceinline__ int wave_inclusive_scan(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1,3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2,3
+    return x;
 }
 
-__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const uint64_t o = __shfl_xor(v, off);
-        v = o < v ? o : v;
-    }
-    return v;
+// Wave-wide max / min of a 32-bit value in DPP; the result is returned in every lane.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    x = mx(x, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x111, 0xf, 0xf, true)));
+    x = mx(x, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x112, 0xf, 0xf, true)));
+    x = mx(x, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x114, 0xf, 0xf, true)));
+    x = mx(x, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x118, 0xf, 0xf, true)));
+    x = mx(x, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x142, 0xa, 0xf, false)));
+    x = mx(x, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x143, 0xc, 0xf, false)));
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(x), 63));
 }
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) { return ~wave_max_u32(~x); }
 
 // Every thread of the workgroup calls this with its share of the keys in
 // registers (0 = empty slot; keys are unique).  Precondition: at least `need`
 // non-empty keys in total, need >= 1.  Returns T with |{key >= T}| >= need;
 // with `exact` the count is exactly `need`, otherwise up to `slack` extra keys
 // may remain (fewer passes).  Digits are taken relative to the smallest key so
-// the first pass already separates the candidates.
+// the first pass already separates the candidates.  Two barriers per pass:
+// wave 0 scans the 256 bins (lane l owns bins 255-4l .. 252-4l, so a prefix
+// scan over lanes is a suffix scan over bins) and clears them for the next pass.
 template <int kThreads, int kPerThread>
 __device__ inline uint64_t block_select_threshold(const uint64_t (&mine)[kPerThread], int need,
                                                   bool exact, int slack, SelectSmem& sm) {
@@ -150,35 +199,37 @@ __device__ inline uint64_t block_select_threshold(const uint64_t (&mine)[kPerThr
     const int tid = threadIdx.x;
     const int lane = tid & 63;
 
-    uint64_t mx = 0, mn = ~0ull;
+    // range of the score halves (32-bit, one LDS atomic per wave); the digits
+    // below are relative to base = smallest score << 32
+    uint32_t mx = 0, mn = ~0u;
 #pragma unroll
     for (int r = 0; r < kPerThread; ++r) {
         if (mine[r]) {
-            mx = mine[r] > mx ? mine[r] : mx;
-            mn = mine[r] < mn ? mine[r] : mn;
+            const uint32_t hi = static_cast<uint32_t>(mine[r] >> 32);
+            mx = hi > mx ? hi : mx;
+            mn = hi < mn ? hi : mn;
         }
     }
-    mx = wave_max_u64(mx);
-    mn = wave_min_u64(mn);
+    mx = wave_max_u32(mx);
+    mn = wave_min_u32(mn);
+    if (tid < 256) sm.hist[tid] = 0;
     if (tid == 0) {
-        sm.vmax = 0ull;
-        sm.vmin = ~0ull;
+        sm.hi_max = 0u;
+        sm.hi_min = ~0u;
     }
     __syncthreads();
     if (lane == 0) {
-        atomicMax(&sm.vmax, static_cast<unsigned long long>(mx));
-        atomicMin(&sm.vmin, static_cast<unsigned long long>(mn));
+        atomicMax(&sm.hi_max, mx);
+        atomicMin(&sm.hi_min, mn);
     }
     __syncthreads();
-    const uint64_t base = sm.vmin;
-    const uint64_t span = sm.vmax - base;
+    const uint64_t base = static_cast<uint64_t>(sm.hi_min) << 32;
+    const uint64_t span = (static_cast<uint64_t>(sm.hi_max - sm.hi_min) << 32) | 0xffffffffull;
     int shift = span ? (64 - __clzll(static_cast<long long>(span))) - 8 : 0;
     if (shift < 0) shift = 0;
     uint64_t prefix = 0, mask = 0;
 
     for (;;) {
-        if (tid < 256) sm.hist[tid] = 0;
-        __syncthreads();
 #pragma unroll
         for (int r = 0; r < kPerThread; ++r) {
             const uint64_t k = mine[r];
@@ -189,22 +240,16 @@ __device__ inline uint64_t block_select_threshold(const uint64_t (&mine)[kPerThr
         }
         __syncthreads();
         if (tid < 64) {
-            // lane l owns bins 4l..4l+3; suffix sums from the top bin down
-            const int h0 = sm.hist[4 * lane + 0], h1 = sm.hist[4 * lane + 1];
-            const int h2 = sm.hist[4 * lane + 2], h3 = sm.hist[4 * lane + 3];
+            const int top = 255 - 4 * lane;  // this lane's highest bin
+            const int h0 = sm.hist[top], h1 = sm.hist[top - 1], h2 = sm.hist[top - 2], h3 = sm.hist[top - 3];
+            sm.hist[top] = 0; sm.hist[top - 1] = 0; sm.hist[top - 2] = 0; sm.hist[top - 3] = 0;
             const int lane_sum = h0 + h1 + h2 + h3;
-            int incl = lane_sum;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_down(incl, off);
-                if (lane + off < 64) incl += o;
-            }
-            int cum = incl - lane_sum;  // keys in bins above this lane's
+            int cum = wave_inclusive_scan(lane_sum) - lane_sum;  // keys in bins above this lane's
             const int hs[4] = {h0, h1, h2, h3};
 #pragma unroll
-            for (int b = 3; b >= 0; --b) {
+            for (int b = 0; b < 4; ++b) {
                 if (cum < need && cum + hs[b] >= need) {
-                    sm.digit = 4 * lane + b;
+                    sm.digit = top - b;
                     sm.above = cum;
                     sm.in_bin = hs[b];
                 }
@@ -222,11 +267,13 @@ __device__ inline uint64_t block_select_threshold(const uint64_t (&mine)[kPerThr
     return base + prefix;
 }
 
-// Ranks the `c` unique keys in s_keys (c <= kMaxTopK) by counting and writes
-// them in descending order to dst[0..c), zero-filling dst[c..pad_to).
+// Ranks the `c` unique keys in s_keys by counting and writes the best
+// min(c, topk) in descending order to dst, zero-filling up to dst[topk).
+// Costs ~c*c/32 LDS cycles: callers keep c within a few hundred.
+constexpr int kRankDirectMax = 384;
 template <int kThreads>
-__device__ inline void block_rank_and_store(const uint64_t* s_keys, int c, uint64_t* dst, int pad_to) {
-    for (int i = threadIdx.x; i < pad_to; i += kThreads) {
+__device__ inline void block_rank_and_store(const uint64_t* s_keys, int c, uint64_t* dst, int topk) {
+    for (int i = threadIdx.x; i < topk; i += kThreads) {
         if (i >= c) dst[i] = 0ull;
     }
     for (int i = threadIdx.x; i < c; i += kThreads) {
@@ -240,14 +287,14 @@ __device__ inline void block_rank_and_store(const uint64_t* s_keys, int c, uint6
                     (k4 > mine) + (k5 > mine) + (k6 > mine) + (k7 > mine);
         }
         for (; j < c; ++j) rank += (s_keys[j] > mine);
-        dst[rank] = mine;
+        if (rank < topk) dst[rank] = mine;
     }
 }
 
 // Shrinks s_cand[0..*s_count) to the keys >= T where T bounds the topk-th best
 // (exactly topk keys remain with `exact`), and returns the filter threshold for
 // the streaming loop: later keys pass iff key > return value.
-template <int kThreads>
+template <int kThreads, int kCandPerThread>
 __device__ inline uint64_t compact_candidates(uint64_t* s_cand, int* s_count, int topk,
                                               bool exact, SelectSmem& sm) {
     __syncthreads();
@@ -287,12 +334,15 @@ __device__ inline uint64_t compact_candidates(uint64_t* s_cand, int* s_count, in
 
 // kDebug (development A/B only; 0 in the product): 1 = no end-of-tile barrier pair,
 // 2 = ballot only, no LDS append, 4 = skip the seed compaction (threshold preset).
-template <bool kQueryFromRow, bool kScoresOnly, int kDebug = 0>
-__global__ __launch_bounds__(kBlock) void scan_kernel(
+template <typename Cfg, bool kQueryFromRow, bool kScoresOnly, int kDebug = 0>
+__global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
     const float* __restrict__ feats, int64_t n, int64_t rows_per_block, int iters,
     int64_t row_base, QueryArg qarg, int64_t query_row, int64_t exclude_global,
     int topk, uint64_t* __restrict__ block_lists, float* __restrict__ scores_out) {
-    __shared__ uint64_t s_cand[kScoresOnly ? 1 : kCandCap];
+    constexpr int kBlock = Cfg::kBlock;
+    constexpr int kRowsPerThread = Cfg::kRowsPerThread;
+    constexpr int kTileRows = Cfg::kTileRows;
+    __shared__ uint64_t s_cand[kScoresOnly ? 1 : Cfg::kCandCap];
     __shared__ SelectSmem s_sel;
     __shared__ int s_count;
 
@@ -322,7 +372,12 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
         __syncthreads();
     }
     uint64_t thr = 0;
-    if constexpr ((kDebug & 4) != 0) thr = pack_key(0.985f, 0u);
+    float cutoff = 0.0f;  // approx pre-filter active only while > 0
+    const float inv_qn = 1.0f / qn;
+    if constexpr ((kDebug & 4) != 0) {
+        thr = pack_key(0.985f, 0u);
+        cutoff = 0.985f - kApproxMargin;
+    }
     // Re-tighten the threshold once ~topk NEW candidates have piled up (the
     // select is O(c), but every candidate that slips past a stale threshold
     // costs an LDS atomic round trip in the streaming loop).
@@ -344,21 +399,28 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
         for (int u = 0; u < kRowsPerThread; ++u) {
             const int64_t r = tile_begin + u * kBlock + tid;
             const bool in_range = r < blk_end;
-            const float s = cosine_score(q, qn, rows[u]);
             if constexpr (kScoresOnly) {
+                const float s = cosine_score(q, qn, rows[u]);
                 if (in_range) scores_out[r] = s;
             } else {
-                const int64_t g = row_base + r;
-                uint64_t key = pack_key(s, static_cast<uint32_t>(g));
-                if (!in_range || g == exclude_global) key = 0;
-                const bool pass = key > thr;
-                const uint64_t ballot = __ballot(pass);
-                if (ballot && (kDebug & 2) == 0) {
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(&s_count, __popcll(ballot));
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    const int pos = base + __popcll(ballot & ((1ull << lane) - 1ull));
-                    if (pass) s_cand[pos] = key;
+                // While the threshold score is positive, rows whose cheap upper
+                // bound cannot reach it are dropped without the exact chain.
+                bool maybe = true;
+                if (cutoff > 0.0f) maybe = !(approx_cosine(q, inv_qn, rows[u]) < cutoff);
+                if (__ballot(maybe)) {
+                    const float s = cosine_score(q, qn, rows[u]);
+                    const int64_t g = row_base + r;
+                    uint64_t key = pack_key(s, static_cast<uint32_t>(g));
+                    if (!in_range || g == exclude_global) key = 0;
+                    const bool pass = maybe && key > thr;
+                    const uint64_t ballot = __ballot(pass);
+                    if (ballot && (kDebug & 2) == 0) {
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&s_count, __popcll(ballot));
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        const int pos = base + __popcll(ballot & ((1ull << lane) - 1ull));
+                        if (pass) s_cand[pos] = key;
+                    }
                 }
             }
         }
@@ -368,7 +430,13 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
             __syncthreads();
             const int c = s_count;
             __syncthreads();
-            if (c >= compact_at) thr = compact_candidates<kBlock>(s_cand, &s_count, topk, false, s_sel);
+            if (c >= compact_at) {
+                const uint64_t local_thr = compact_candidates<kBlock, Cfg::kCandPerThread>(s_cand, &s_count, topk, false, s_sel);
+                if (local_thr > thr) {
+                    thr = local_thr;
+                    cutoff = ordered_to_score(static_cast<uint32_t>(thr >> 32)) - kApproxMargin;
+                }
+            }
         }
     };
 
@@ -383,10 +451,11 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(
     }
 
     if constexpr (!kScoresOnly) {
-        compact_candidates<kBlock>(s_cand, &s_count, topk, true, s_sel);
         __syncthreads();
-        const int kept = s_count < topk ? s_count : topk;
-        block_rank_and_store<kBlock>(s_cand, kept, block_lists + static_cast<int64_t>(blockIdx.x) * topk, topk);
+        if (s_count > kRankDirectMax && s_count > topk)  // uniform
+            compact_candidates<kBlock, Cfg::kCandPerThread>(s_cand, &s_count, topk, true, s_sel);
+        __syncthreads();
+        block_rank_and_store<kBlock>(s_cand, s_count, block_lists + static_cast<int64_t>(blockIdx.x) * topk, topk);
     }
 }
 
@@ -442,7 +511,7 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
     const uint64_t* __restrict__ lists_base, int n_lists, int list_len,
     int64_t lists_query_stride, int topk, uint64_t* __restrict__ out_keys_base,
     int64_t* __restrict__ out_idx_base, float* __restrict__ out_score_base,
-    int64_t out_query_stride) {
+    int64_t out_query_stride, int dbg_stop = 0) {
     __shared__ uint64_t s_surv[kMergeSurvCap];
     __shared__ uint64_t s_top[kMaxTopK];
     __shared__ SelectSmem s_sel;
@@ -466,29 +535,78 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
     if (n_lists < 2 * topk) probe = (2 * topk + n_lists - 1) / n_lists;
     if (probe > list_len) probe = list_len;
     const int need_lists = (topk + probe - 1) / probe;
-
-    uint64_t heads[kMergeHeadsPerThread];
-    int local_nonzero = 0;
-#pragma unroll
-    for (int r = 0; r < kMergeHeadsPerThread; ++r) {
-        const int l = tid + r * kMergeBlock;
-        heads[r] = l < n_lists ? lists[static_cast<int64_t>(l) * list_len + (probe - 1)] : 0ull;
-        local_nonzero += heads[r] != 0ull;
-        if (l < n_lists) s_active[l] = 0;
-    }
-    if (local_nonzero) atomicAdd(&s_pair[0], local_nonzero);
-    __syncthreads();
+    int slack = need_lists / 8;
     uint64_t thr = 1;  // accept every non-empty key
-    if (s_pair[0] >= need_lists)  // uniform; the select needs >= need_lists non-empty probes
-        thr = block_select_threshold<kMergeBlock, kMergeHeadsPerThread>(heads, need_lists, true, 0, s_sel);
+    int first = 0;     // keys [0, first) of every list are already dealt with
+
+    if (probe == 1 && n_lists * kMergeFirst <= kMergeBlock * kMergeFirstPerThread) {
+        // Many lists (the per-workgroup lists of one scan).  ONE load phase brings
+        // in the first kMergeFirst keys of every list; the heads among them give
+        // the threshold and the rest is filtered from registers, so the usual
+        // case costs a single global-memory round trip.
+        first = kMergeFirst < list_len ? kMergeFirst : list_len;
+        uint64_t k[kMergeFirstPerThread];
+        uint64_t hk[kMergeFirstPerThread];
+        const int j = tid % kMergeFirst;  // kMergeBlock % kMergeFirst == 0
+        int local_nonzero = 0;
+#pragma unroll
+        for (int u = 0; u < kMergeFirstPerThread; ++u) {
+            const int l = (u * kMergeBlock + tid) / kMergeFirst;
+            k[u] = (l < n_lists && j < list_len) ? lists[static_cast<int64_t>(l) * list_len + j] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < kMergeFirstPerThread; ++u) {
+            hk[u] = j == 0 ? k[u] : 0ull;
+            local_nonzero += hk[u] != 0ull;
+        }
+        for (int l = tid; l < n_lists; l += kMergeBlock) s_active[l] = 0xffff;
+        if (local_nonzero) atomicAdd(&s_pair[0], local_nonzero);
+        __syncthreads();
+        if (dbg_stop == 1) { if (k[0] == 12345ull) out_keys[0] = k[1] + k[2] + k[3] + k[4] + k[5] + k[6] + k[7]; return; }
+        if (s_pair[0] >= need_lists)  // uniform
+            thr = block_select_threshold<kMergeBlock, kMergeFirstPerThread>(hk, need_lists, false, slack, s_sel);
+        __syncthreads();
+        if (dbg_stop == 2) { if (thr == 12345ull) out_keys[0] = k[1] + k[2] + k[3] + k[4] + k[5] + k[6] + k[7]; return; }
+#pragma unroll
+        for (int u = 0; u < kMergeFirstPerThread; ++u) {
+            if (k[u] >= thr) {
+                const int slot = atomicAdd(&s_count, 1);
+                if (slot < kMergeSurvCap) s_surv[slot] = k[u];
+                else s_overflow = 1;
+                if (j == first - 1) s_active[(u * kMergeBlock + tid) / kMergeFirst] = 0;  // look deeper
+            }
+        }
+    } else {
+        // Few lists (e.g. one per rank) or very many: probe each list at depth
+        // `probe` and start the rounds from the top of every list.
+        uint64_t heads[kMergeHeadsPerThread];
+        int local_nonzero = 0;
+#pragma unroll
+        for (int r = 0; r < kMergeHeadsPerThread; ++r) {
+            const int l = tid + r * kMergeBlock;
+            heads[r] = l < n_lists ? lists[static_cast<int64_t>(l) * list_len + (probe - 1)] : 0ull;
+            local_nonzero += heads[r] != 0ull;
+            if (l < n_lists) s_active[l] = 0;
+        }
+        if (local_nonzero) atomicAdd(&s_pair[0], local_nonzero);
+        __syncthreads();
+        if (s_pair[0] >= need_lists)  // uniform; the select needs >= need_lists non-empty probes
+            thr = block_select_threshold<kMergeBlock, kMergeHeadsPerThread>(heads, need_lists, false, slack, s_sel);
+    }
     __syncthreads();
 
-    // survivors: the prefix of each list with key >= thr.  Round d looks at
-    // keys [d*C, (d+1)*C) of every list that is still active (its previous
-    // chunk passed entirely); the loads of a round are independent and issued
-    // before any of them is consumed.  Typically one round.
-    for (int round = 0; round * kMergeChunk < list_len; ++round) {
+    // Deeper rounds: round d looks at keys [first + d*C, first + (d+1)*C) of every
+    // list that is still active (its previous chunk passed entirely); the loads
+    // of a round are independent and issued before any of them is consumed.
+    // With the first-chunk phase above this loop usually does not run at all.
+    for (int round = 0; first + round * kMergeChunk < list_len && !s_overflow; ++round) {
+        // any list active for this round?
         if (tid == 0) s_more = 0;
+        __syncthreads();
+        for (int l = tid; l < n_lists; l += kMergeBlock)
+            if (s_active[l] == round) s_more = 1;
+        __syncthreads();
+        if (!s_more) break;
         __syncthreads();
         const int total = n_lists * kMergeChunk;
         for (int t0 = 0; t0 < total; t0 += kMergeBlock * 8) {
@@ -497,7 +615,7 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
             for (int u = 0; u < 8; ++u) {
                 const int t = t0 + u * kMergeBlock + tid;
                 const int l = t / kMergeChunk;
-                const int pos = round * kMergeChunk + (t % kMergeChunk);
+                const int pos = first + round * kMergeChunk + (t % kMergeChunk);
                 const bool live = t < total && pos < list_len && s_active[l] == round;
                 k[u] = live ? lists[static_cast<int64_t>(l) * list_len + pos] : 0ull;
             }
@@ -507,16 +625,14 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
                     const int slot = atomicAdd(&s_count, 1);
                     if (slot < kMergeSurvCap) s_surv[slot] = k[u];
                     else s_overflow = 1;
-                    if (((t0 + u * kMergeBlock + tid) % kMergeChunk) == kMergeChunk - 1) s_more = 1;
                 }
             }
         }
         __syncthreads();
-        if (!s_more || s_overflow) break;
         // a list stays active iff the LAST key of this chunk passed
         for (int l = tid; l < n_lists; l += kMergeBlock) {
             if (s_active[l] == round) {
-                const int last = (round + 1) * kMergeChunk - 1;
+                const int last = first + (round + 1) * kMergeChunk - 1;
                 if (last < list_len && lists[static_cast<int64_t>(l) * list_len + last] >= thr)
                     s_active[l] = static_cast<unsigned short>(round + 1);
             }
@@ -525,6 +641,7 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
     }
     __syncthreads();
 
+    if (dbg_stop == 3) { if (tid == 0) out_keys[0] = s_count; return; }
     if (s_overflow) {
         // exact fallback: radix-select the topk-th key over everything
         const int64_t total = static_cast<int64_t>(n_lists) * list_len;
@@ -545,7 +662,7 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
 
     int c = s_count < kMergeSurvCap ? s_count : kMergeSurvCap;
     __syncthreads();
-    if (c > topk) {  // uniform: cut to exactly topk, O(c)
+    if (c > topk && c > kRankDirectMax) {  // uniform: too many to rank, cut to exactly topk in O(c)
         uint64_t mine[kMergeSurvPerThread];
 #pragma unroll
         for (int r = 0; r < kMergeSurvPerThread; ++r) {
@@ -563,10 +680,12 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
             }
         }
         __syncthreads();
-        c = s_count < topk ? s_count : topk;
+        c = s_count < kMergeSurvCap ? s_count : kMergeSurvCap;
     }
+    if (dbg_stop == 4) { if (tid == 0) out_keys[0] = s_count; return; }
     block_rank_and_store<kMergeBlock>(s_surv, c, s_top, topk);
     __syncthreads();
+    if (dbg_stop == 5) { if (tid == 0) out_keys[0] = s_top[0]; return; }
     for (int i = tid; i < topk; i += kMergeBlock) {
         const uint64_t k = s_top[i];
         out_keys[i] = k;
@@ -583,11 +702,11 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
 
 // ---- read-only streaming probe (achievable-HBM ceiling) ---------------------
 
-__global__ __launch_bounds__(kBlock) void stream_probe_kernel(
+__global__ __launch_bounds__(kProbeBlock) void stream_probe_kernel(
     const float4* __restrict__ data, int64_t n_vec, uint32_t* __restrict__ sink) {
     uint32_t acc = 0;
-    const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
-    int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kProbeBlock;
+    int64_t i = static_cast<int64_t>(blockIdx.x) * kProbeBlock + threadIdx.x;
     for (; i + 3 * stride < n_vec; i += 4 * stride) {
         const float4 a = data[i];
         const float4 b = data[i + stride];

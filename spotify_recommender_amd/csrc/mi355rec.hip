@@ -38,6 +38,10 @@ struct DeviceGuard {
 
 constexpr int kTimingPairs = 8192;
 
+using ScanConfig = DefaultScanCfg;
+constexpr int kScanBlock = ScanConfig::kBlock;
+constexpr int kScanTileRows = ScanConfig::kTileRows;
+
 }  // namespace
 
 struct mi355rec {
@@ -104,7 +108,7 @@ void plan_grid(mi355rec* h, int blocks_per_cu) {
     if (rpb < 64) rpb = 64;
     h->rows_per_block = rpb;
     h->grid = static_cast<int>((h->n + rpb - 1) / rpb);
-    h->iters = static_cast<int>((rpb + kTileRows - 1) / kTileRows);
+    h->iters = static_cast<int>((rpb + kScanTileRows - 1) / kScanTileRows);
 }
 
 int create_common(const float* feats, bool on_device, int64_t n, int dim, int device,
@@ -139,9 +143,9 @@ int create_common(const float* feats, bool on_device, int64_t n, int dim, int de
     h->cus = prop.multiProcessorCount;
 
     int occ = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel<true, false>, kBlock, 0);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel<ScanConfig, true, false>, kScanBlock, 0);
     if (e != hipSuccess || occ < 1) occ = 1;
-    if (occ > 2) occ = 2;
+    if (occ > 4) occ = 4;
     plan_grid(h, occ);
 
     int rc = MI355REC_OK;
@@ -225,13 +229,13 @@ int enqueue_scan(mi355rec* h, int64_t query_row, const float* query12,
     std::memset(&qa, 0, sizeof qa);
     const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, s);
     if (query_row >= 0) {
-        hipLaunchKernelGGL((scan_kernel<true, false>), dim3(h->grid), dim3(kBlock), 0, s,
+        hipLaunchKernelGGL((scan_kernel<ScanConfig, true, false>), dim3(h->grid), dim3(kScanBlock), 0, s,
                            h->d_feats, h->n, h->rows_per_block, h->iters, h->row_base, qa,
                            query_row, exclude_global, topn, h->d_block_lists,
                            static_cast<float*>(nullptr));
     } else {
         std::memcpy(qa.q, query12, sizeof qa.q);
-        hipLaunchKernelGGL((scan_kernel<false, false>), dim3(h->grid), dim3(kBlock), 0, s,
+        hipLaunchKernelGGL((scan_kernel<ScanConfig, false, false>), dim3(h->grid), dim3(kScanBlock), 0, s,
                            h->d_feats, h->n, h->rows_per_block, h->iters, h->row_base, qa,
                            static_cast<int64_t>(0), exclude_global, topn, h->d_block_lists,
                            static_cast<float*>(nullptr));
@@ -338,7 +342,7 @@ int mi355rec_stats(const mi355rec_t* hc, mi355rec_stats_t* out) {
     out->device = h->device;
     out->compute_units = h->cus;
     out->grid_blocks = h->grid;
-    out->block_threads = kBlock;
+    out->block_threads = kScanBlock;
     out->bytes_per_query = h->n * kDim * static_cast<int64_t>(sizeof(float));
     out->last_scan_ms = h->last_scan_ms;
     out->last_merge_ms = h->last_merge_ms;
@@ -396,12 +400,12 @@ int mi355rec_enqueue_scores(mi355rec_t* h, int64_t local_row, const float* query
     QueryArg qa;
     std::memset(&qa, 0, sizeof qa);
     if (local_row >= 0) {
-        hipLaunchKernelGGL((scan_kernel<true, true>), dim3(h->grid), dim3(kBlock), 0, s, h->d_feats,
+        hipLaunchKernelGGL((scan_kernel<ScanConfig, true, true>), dim3(h->grid), dim3(kScanBlock), 0, s, h->d_feats,
                            h->n, h->rows_per_block, h->iters, h->row_base, qa, local_row,
                            static_cast<int64_t>(-1), 1, static_cast<uint64_t*>(nullptr), out_scores_dev);
     } else {
         std::memcpy(qa.q, query12, sizeof qa.q);
-        hipLaunchKernelGGL((scan_kernel<false, true>), dim3(h->grid), dim3(kBlock), 0, s, h->d_feats,
+        hipLaunchKernelGGL((scan_kernel<ScanConfig, false, true>), dim3(h->grid), dim3(kScanBlock), 0, s, h->d_feats,
                            h->n, h->rows_per_block, h->iters, h->row_base, qa, static_cast<int64_t>(0),
                            static_cast<int64_t>(-1), 1, static_cast<uint64_t*>(nullptr), out_scores_dev);
     }
@@ -414,7 +418,7 @@ int mi355rec_enqueue_stream_probe(mi355rec_t* h, uint32_t* sink_dev, void* strea
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, s);
-    hipLaunchKernelGGL(stream_probe_kernel, dim3(h->grid), dim3(kBlock), 0, s,
+    hipLaunchKernelGGL(stream_probe_kernel, dim3(h->grid), dim3(kProbeBlock), 0, s,
                        reinterpret_cast<const float4*>(h->d_feats), h->n * 3, sink_dev);
     timing_end(h, h->ev_scan, h->n_scan_pairs, slot, s);
     HIP_TRY(h, hipGetLastError());
