@@ -44,8 +44,27 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="skip the per-kernel HIP events (roofline.achieved becomes null)")
+    ap.add_argument("--event-stride", type=int, default=10,
+                    help="time every k-th kernel launch inside the timed region (an event pair costs ~3 us)")
     ap.add_argument("--latency-queries", type=int, default=200)
     return ap.parse_args()
+
+
+def host_threads(omp_max: int) -> int:
+    """Threads the CPU baseline may really use: affinity mask, cgroup quota, and
+    the GPU box's per-GPU CPU share (16) bound it, not the socket's core count."""
+    n = omp_max
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("BENCH_CPU_THREADS", "16"))))
 
 
 def cpu_baseline(feats_host, topn, query_rows):
@@ -53,7 +72,7 @@ def cpu_baseline(feats_host, topn, query_rows):
     value, B0 (the reference's serial loop + heap) rides along.  Bounded sample."""
     from oracle import oracle
 
-    threads = oracle.max_threads()
+    threads = host_threads(oracle.max_threads())
     oracle.recommend_omp(feats_host, query_rows[0], topn, threads)  # touch pages / spin up the team
     t0 = time.perf_counter()
     done = 0
@@ -139,7 +158,7 @@ def main():
         step(k)
     fence()
     if not args.no_kernel_events:
-        eng.set_timing(True)
+        eng.set_timing(args.event_stride)  # HIP events around every k-th scan / merge launch
     t0 = time.perf_counter()
     for k in range(args.warmup, total_q):
         step(k)

@@ -163,9 +163,11 @@ int mi355rec_enqueue_scores(mi355rec_t* h, int64_t local_row,
  * to sink_dev (>= grid_blocks uint32). */
 int mi355rec_enqueue_stream_probe(mi355rec_t* h, uint32_t* sink_dev, void* stream);
 
-/* Brackets the NEXT enqueue_*_keys / enqueue_merge_keys calls with HIP events
- * on their stream so that mi355rec_stats reports last_scan_ms/last_merge_ms
- * (reading them synchronises the events).  0 disables. */
+/* Brackets the following scan / merge launches with HIP events on their stream
+ * so that mi355rec_stats reports last_scan_ms / last_merge_ms (averages over
+ * the recorded launches; reading them synchronises the events).  enabled = 0
+ * disables, 1 times every launch, k > 1 times every k-th launch of each kind
+ * (an event pair costs a few microseconds of stream time). */
 int mi355rec_set_timing(mi355rec_t* h, int enabled);
 
 /* ---- key helpers (host side, no device needed) --------------------------- */

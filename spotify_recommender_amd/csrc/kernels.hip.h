@@ -35,7 +35,7 @@ struct ScanCfg {
     static constexpr int kCandCap = kCandLimit + kTileRows;  // LDS candidate slots
     static constexpr int kCandPerThread = (kCandCap + kBlockT - 1) / kBlockT;
 };
-using DefaultScanCfg = ScanCfg<256, 2, 4>;
+using DefaultScanCfg = ScanCfg<512, 1, 6>;
 constexpr int kProbeBlock = 512;      // stream_probe_kernel
 constexpr int kMergeBlock = 1024;
 constexpr int kMergeMaxLists = 2048;

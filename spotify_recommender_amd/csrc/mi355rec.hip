@@ -70,6 +70,8 @@ struct mi355rec {
 
     // optional HIP-event timing of the enqueued kernels
     bool timing = false;
+    int timing_stride = 1;      // time every stride-th launch of each kind
+    int scan_launches = 0, merge_launches = 0;
     std::vector<hipEvent_t> ev_scan, ev_merge;  // (start, stop) pairs
     int n_scan_pairs = 0, n_merge_pairs = 0;
     float last_scan_ms = 0.f, last_merge_ms = 0.f;
@@ -201,8 +203,9 @@ int ensure_batch(mi355rec* h, int batch) {
     return MI355REC_OK;
 }
 
-int timing_begin(mi355rec* h, std::vector<hipEvent_t>& evs, int& pairs, hipStream_t s) {
+int timing_begin(mi355rec* h, std::vector<hipEvent_t>& evs, int& pairs, int& launches, hipStream_t s) {
     if (!h->timing) return -1;
+    if ((launches++ % h->timing_stride) != 0) return -1;
     if (pairs >= kTimingPairs) return -1;
     if (static_cast<int>(evs.size()) < 2 * (pairs + 1)) {
         hipEvent_t a, b;
@@ -227,7 +230,7 @@ int enqueue_scan(mi355rec* h, int64_t query_row, const float* query12,
                  int64_t exclude_global, int topn, hipStream_t s) {
     QueryArg qa;
     std::memset(&qa, 0, sizeof qa);
-    const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, s);
+    const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, s);
     if (query_row >= 0) {
         hipLaunchKernelGGL((scan_kernel<ScanConfig, true, false>), dim3(h->grid), dim3(kScanBlock), 0, s,
                            h->d_feats, h->n, h->rows_per_block, h->iters, h->row_base, qa,
@@ -247,7 +250,7 @@ int enqueue_scan(mi355rec* h, int64_t query_row, const float* query12,
 
 int enqueue_merge(mi355rec* h, const uint64_t* lists, int n_lists, int list_len, int topn,
                   uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s) {
-    const int slot = timing_begin(h, h->ev_merge, h->n_merge_pairs, s);
+    const int slot = timing_begin(h, h->ev_merge, h->n_merge_pairs, h->merge_launches, s);
     hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(kMergeBlock), 0, s, lists, n_lists, list_len,
                        static_cast<int64_t>(0), topn, out_keys, out_idx, out_score,
                        static_cast<int64_t>(0));
@@ -311,8 +314,11 @@ const char* mi355rec_last_error(const mi355rec_t* h) {
 int mi355rec_set_timing(mi355rec_t* h, int enabled) {
     if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
     h->timing = enabled != 0;
+    h->timing_stride = enabled > 1 ? enabled : 1;
     h->n_scan_pairs = 0;
     h->n_merge_pairs = 0;
+    h->scan_launches = 0;
+    h->merge_launches = 0;
     return MI355REC_OK;
 }
 
@@ -417,7 +423,7 @@ int mi355rec_enqueue_stream_probe(mi355rec_t* h, uint32_t* sink_dev, void* strea
     if (!h || !sink_dev) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, s);
+    const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, s);
     hipLaunchKernelGGL(stream_probe_kernel, dim3(h->grid), dim3(kProbeBlock), 0, s,
                        reinterpret_cast<const float4*>(h->d_feats), h->n * 3, sink_dev);
     timing_end(h, h->ev_scan, h->n_scan_pairs, slot, s);

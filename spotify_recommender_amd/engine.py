@@ -175,8 +175,9 @@ class CosineEngine:
         capi.check(self._lib.mi355rec_enqueue_stream_probe(
             self._h, ctypes.c_void_p(sink.data_ptr()), self._stream_ptr(stream)), self._h)
 
-    def set_timing(self, enabled: bool) -> None:
-        capi.check(self._lib.mi355rec_set_timing(self._h, 1 if enabled else 0), self._h)
+    def set_timing(self, enabled) -> None:
+        """0/False off, 1/True every launch, k > 1 every k-th launch."""
+        capi.check(self._lib.mi355rec_set_timing(self._h, int(enabled)), self._h)
 
     def stats(self) -> capi.Stats:
         st = capi.Stats()

@@ -32,7 +32,7 @@ struct Timer {
 
 static int64_t g_n; static float* d_feats; static float* d_scores; static uint64_t* d_lists; static uint64_t* d_out; static uint32_t* d_sink;
 static QueryArg g_qa; static int g_reps; static int g_topk; static double g_gb;
-static std::vector<uint64_t> g_ref;
+static std::vector<uint64_t> g_ref; static int g_stages = 0;
 
 static void report(const char* name, float ms) { printf("  %-40s %8.3f us  %8.1f GB/s\n", name, ms * 1e3, g_gb / (ms * 1e-3)); fflush(stdout); }
 
@@ -48,7 +48,7 @@ void run_cfg(const char* label, int blocks_per_cu) {
     report("topk", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr); }, g_reps));
     float mm = T.run([&] { hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)0, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)0); }, g_reps);
     report("merge", mm);
-    for (int stop = 1; stop <= 5; ++stop) { char nm[64]; snprintf(nm, sizeof nm, "  merge stopped at stage %d", stop);
+    if (g_stages) for (int stop = 1; stop <= 5; ++stop) { char nm[64]; snprintf(nm, sizeof nm, "  merge stopped at stage %d", stop);
         report(nm, T.run([&] { hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)0, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)0, stop); }, g_reps)); }
     report("  empty-ish kernel (probe, 64 vec)", T.run([&] { hipLaunchKernelGGL(stream_probe_kernel, dim3(1), dim3(kProbeBlock), 0, 0, (const float4*)d_feats, (int64_t)64, d_sink); }, g_reps));
     std::vector<uint64_t> got(g_topk);
@@ -63,6 +63,7 @@ int main(int argc, char** argv) {
     g_reps = argc > 2 ? atoi(argv[2]) : 20;
     g_topk = argc > 3 ? atoi(argv[3]) : 100;
     g_gb = g_n * 48.0 / 1e9;
+    g_stages = argc <= 4;
     CK(hipMalloc(&d_feats, g_n * 48));
     std::vector<float> h(g_n * 12);
     uint64_t s = 88172645463325252ull;
@@ -79,7 +80,25 @@ int main(int argc, char** argv) {
         for (int g : {512, 1024, 2048}) { char nm[64]; snprintf(nm, sizeof nm, "grid %d", g);
             report(nm, T.run([&] { hipLaunchKernelGGL(stream_probe_kernel, dim3(g), dim3(kProbeBlock), 0, 0, (const float4*)d_feats, g_n * 3, d_sink); }, g_reps)); }
     }
+    if (argc > 4) {
+    run_cfg<ScanCfg<512, 4, 2>>("A", 1);
+    run_cfg<ScanCfg<512, 2, 4>>("B", 2);
+    run_cfg<ScanCfg<512, 2, 4>>("B", 4);
+    run_cfg<ScanCfg<512, 2, 4>>("B", 6);
+    run_cfg<ScanCfg<256, 2, 4>>("D", 4);
+    run_cfg<ScanCfg<256, 2, 4>>("D", 6);
+    run_cfg<ScanCfg<256, 2, 4>>("D", 8);
+    run_cfg<ScanCfg<256, 3, 3>>("G", 3);
+    run_cfg<ScanCfg<256, 3, 3>>("G", 6);
+    run_cfg<ScanCfg<256, 1, 6>>("H", 6);
+    run_cfg<ScanCfg<256, 1, 6>>("H", 8);
+    run_cfg<ScanCfg<512, 1, 6>>("I", 3);
+    run_cfg<ScanCfg<512, 1, 6>>("I", 4);
+    run_cfg<ScanCfg<1024, 2, 4>>("E", 1);
+    run_cfg<ScanCfg<1024, 1, 6>>("J", 2);
+    } else {
     run_cfg<ScanCfg<512, 2, 4>>("B", 4);
     run_cfg<ScanCfg<256, 2, 4>>("D", 4);
+    }
     return 0;
 }
