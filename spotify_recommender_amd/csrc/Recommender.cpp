@@ -1,0 +1,163 @@
+// Recommender.cpp — host shim: the reference's Recommender class on top of the
+// C-ABI (include/mi355rec.h).  Replaces Recommender.cu:80-372; every method
+// names the reference lines whose observable behaviour it keeps.
+#include "Recommender.h"
+
+#include <algorithm>
+#include <cctype>
+#include <iostream>
+#include <unordered_map>
+
+#include "mi355rec.h"
+
+struct Recommender::Impl {
+    bool initialized = false;
+    bool gpuEnabled = false;
+    int numSongs = 0;
+    mi355rec_t* engine = nullptr;
+
+    // Only what the lookups need is kept (the reference deep-copies every Song,
+    // Recommender.cu:109).  `byId` maps a track id to its FIRST row, which is
+    // what the reference's linear scan returns; `lowerNames` is lowered once
+    // instead of once per row per query (Recommender.cu:340-351).
+    std::vector<std::string> lowerNames;
+    std::unordered_map<std::string, int> byId;
+
+    std::vector<int64_t> idxBuf;
+    std::vector<float> scoreBuf;
+    std::vector<float> lastScores;
+};
+
+namespace {
+
+std::string toLower(const std::string& str) {  // Recommender.cu:329-334
+    std::string result = str;
+    for (char& c : result) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+    return result;
+}
+
+}  // namespace
+
+Recommender::Recommender() : impl_(new Impl()) {}
+
+Recommender::~Recommender() {  // Recommender.cu:86-98
+    if (impl_->engine) mi355rec_destroy(impl_->engine);
+    delete impl_;
+}
+
+bool Recommender::initialize(const std::vector<Song>& songs) {  // Recommender.cu:100-182
+    std::cout << "Initializing GPU-accelerated recommender..." << std::endl;
+    if (songs.empty()) {  // :103-106
+        std::cerr << "Error: Empty song database" << std::endl;
+        return false;
+    }
+    if (impl_->engine) {
+        mi355rec_destroy(impl_->engine);
+        impl_->engine = nullptr;
+    }
+    impl_->initialized = false;
+    impl_->gpuEnabled = false;
+    impl_->numSongs = static_cast<int>(songs.size());
+
+    // AoS -> row-major N x 12 (the reference's staging matrix, :162-167)
+    std::vector<float> matrix(songs.size() * FEATURE_COUNT);
+    impl_->lowerNames.clear();
+    impl_->lowerNames.reserve(songs.size());
+    impl_->byId.clear();
+    impl_->byId.reserve(songs.size() * 2);
+    for (size_t i = 0; i < songs.size(); ++i) {
+        std::copy(songs[i].features, songs[i].features + FEATURE_COUNT, matrix.begin() + i * FEATURE_COUNT);
+        impl_->lowerNames.push_back(toLower(songs[i].track_name));
+        impl_->byId.emplace(songs[i].track_id, static_cast<int>(i));  // keeps the first
+    }
+
+    const int rc = mi355rec_create(matrix.data(), static_cast<int64_t>(songs.size()), FEATURE_COUNT,
+                                   /*device=*/0, /*row_base=*/0, &impl_->engine);
+    if (rc != MI355REC_OK) {
+        // The reference would say "[GPU Disabled] ... Falling back to CPU" and go
+        // on (:117-181).  There is no CPU path here: fail loudly.
+        std::cerr << "[GPU Disabled] " << mi355rec_last_global_error() << std::endl;
+        std::cerr << "Error: the MI355X recommender needs a HIP device (no CPU fallback)" << std::endl;
+        return false;
+    }
+    impl_->gpuEnabled = true;
+    impl_->initialized = true;
+    std::cout << "Successfully initialized with " << impl_->numSongs << " songs on GPU" << std::endl;
+    return true;
+}
+
+std::vector<int> Recommender::recommendByIndex(int songIndex, int topN) {  // Recommender.cu:275-318
+    if (!impl_->initialized) {
+        std::cerr << "Error: Recommender not initialized" << std::endl;
+        return {};
+    }
+    if (songIndex < 0 || songIndex >= impl_->numSongs) {
+        std::cerr << "Error: Invalid song index: " << songIndex << std::endl;
+        return {};
+    }
+    if (topN <= 0) {
+        std::cerr << "Error: topN must be positive" << std::endl;
+        return {};
+    }
+    impl_->idxBuf.assign(static_cast<size_t>(topN), -1);
+    impl_->scoreBuf.assign(static_cast<size_t>(topN), 0.0f);
+    int count = 0;
+    const int rc = mi355rec_query_row_topn(impl_->engine, songIndex, topN, impl_->idxBuf.data(),
+                                           impl_->scoreBuf.data(), &count);
+    if (rc != MI355REC_OK) {
+        std::cerr << "Error: " << mi355rec_last_error(impl_->engine) << std::endl;
+        return {};
+    }
+    std::vector<int> results(static_cast<size_t>(count));
+    for (int i = 0; i < count; ++i) results[i] = static_cast<int>(impl_->idxBuf[i]);
+    impl_->lastScores.assign(impl_->scoreBuf.begin(), impl_->scoreBuf.begin() + count);
+    return results;
+}
+
+std::vector<int> Recommender::recommend(const std::string& trackId, int topN) {  // :356-363
+    const auto it = impl_->byId.find(trackId);
+    if (it == impl_->byId.end()) {
+        std::cerr << "Error: Song with track_id '" << trackId << "' not found" << std::endl;
+        return {};
+    }
+    return recommendByIndex(it->second, topN);
+}
+
+std::vector<int> Recommender::recommendByName(const std::string& trackName, int topN) {  // :365-372
+    const std::string needle = toLower(trackName);
+    int index = -1;
+    for (size_t i = 0; i < impl_->lowerNames.size(); ++i) {  // exact pass, :340-344
+        if (impl_->lowerNames[i] == needle) {
+            index = static_cast<int>(i);
+            break;
+        }
+    }
+    if (index < 0) {
+        for (size_t i = 0; i < impl_->lowerNames.size(); ++i) {  // substring pass, :347-351
+            if (impl_->lowerNames[i].find(needle) != std::string::npos) {
+                index = static_cast<int>(i);
+                break;
+            }
+        }
+    }
+    if (index < 0) {
+        std::cerr << "Error: Song with name '" << trackName << "' not found" << std::endl;
+        return {};
+    }
+    return recommendByIndex(index, topN);
+}
+
+bool Recommender::isInitialized() const { return impl_->initialized; }
+bool Recommender::isGPUEnabled() const { return impl_->gpuEnabled; }
+int Recommender::getSongCount() const { return impl_->numSongs; }
+
+const std::vector<float>& Recommender::lastScores() const { return impl_->lastScores; }
+
+bool Recommender::similarities(int songIndex, std::vector<float>& out) {  // Recommender.cu:184-254
+    if (!impl_->initialized || songIndex < 0 || songIndex >= impl_->numSongs) {
+        std::cerr << "Error: Invalid query index or recommender not initialized" << std::endl;
+        return false;
+    }
+    out.resize(static_cast<size_t>(impl_->numSongs));
+    return mi355rec_scores_row(impl_->engine, songIndex, out.data()) == MI355REC_OK;
+}

@@ -1,0 +1,145 @@
+// main.cpp — the drop-in CLI: the reference's three modes (main.cpp:133-189)
+// over the MI355X engine.  Written against include/Recommender.h /
+// DataManager.h / Song.h only, exactly as the reference's main.cpp is written
+// against its own headers — the reference's main.cpp compiles against these
+// headers unchanged; this file exists so the repo is self-contained.
+//
+//   recommender --preprocess <csv>
+//   recommender --song "<name>" [-n N]
+//   recommender --id "<track_id>" [-n N]
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "DataManager.h"
+#include "Recommender.h"
+#include "Song.h"
+
+static const std::string kBinaryDataFile = "songs_data.bin";  // main.cpp:11
+
+static void usage(const char* prog) {
+    std::cout << "Music Recommendation Engine - Usage:\n\n"
+              << "1. Preprocessing Mode:\n   " << prog << " --preprocess <path_to_csv>\n"
+              << "   Processes CSV file and creates binary data file.\n\n"
+              << "2. Recommendation Mode (by song name):\n   " << prog << " --song \"Song Name\" [-n N]\n"
+              << "   Returns top N similar songs (default N=10).\n\n"
+              << "3. Recommendation Mode (by track ID):\n   " << prog << " --id \"track_id\" [-n N]\n"
+              << "   Returns top N similar songs (default N=10).\n" << std::endl;
+}
+
+static bool preprocessMode(const std::string& csvPath) {  // main.cpp:33-44
+    std::cout << "=== PREPROCESSING MODE ===" << std::endl;
+    if (!DataManager::preprocessData(csvPath, kBinaryDataFile)) {
+        std::cerr << "Preprocessing failed!" << std::endl;
+        return false;
+    }
+    std::cout << "\nPreprocessing successful!\nBinary data saved to: " << kBinaryDataFile << std::endl;
+    return true;
+}
+
+static void printSong(const Song& s, std::map<int, std::string>& genres, const char* indent) {
+    std::cout << indent << "Artist: " << s.artists << "\n"
+              << indent << "Genre:  " << genres[s.genre_id] << "\n"
+              << indent << "ID:     " << s.track_id << std::endl;
+}
+
+static bool recommendationMode(const std::string& query, bool isTrackId, int topN) {  // main.cpp:46-131
+    std::cout << "=== RECOMMENDATION MODE ===" << std::endl;
+    std::vector<Song> songs;
+    std::map<int, std::string> genreMap;
+    if (!DataManager::loadData(kBinaryDataFile, songs, genreMap)) {
+        std::cerr << "Failed to load data. Have you run preprocessing?" << std::endl;
+        return false;
+    }
+    Recommender recommender;
+    if (!recommender.initialize(songs)) {
+        std::cerr << "Failed to initialize recommender" << std::endl;
+        return false;
+    }
+
+    std::vector<int> recs;
+    int queryIndex = -1;
+    if (isTrackId) {
+        std::cout << "\nSearching for track ID: " << query << std::endl;
+        recs = recommender.recommend(query, topN);
+        for (size_t i = 0; i < songs.size(); ++i)
+            if (songs[i].track_id == query) { queryIndex = static_cast<int>(i); break; }
+    } else {
+        std::cout << "\nSearching for song: " << query << std::endl;
+        recs = recommender.recommendByName(query, topN);
+        // The reference finds the song it DISPLAYS with a single exact-or-substring
+        // pass (main.cpp:85-95), not the engine's exact-then-substring rule; kept.
+        std::string needle = query;
+        std::transform(needle.begin(), needle.end(), needle.begin(), ::tolower);
+        for (size_t i = 0; i < songs.size(); ++i) {
+            std::string name = songs[i].track_name;
+            std::transform(name.begin(), name.end(), name.begin(), ::tolower);
+            if (name == needle || name.find(needle) != std::string::npos) { queryIndex = static_cast<int>(i); break; }
+        }
+    }
+    if (recs.empty()) {
+        std::cerr << "No recommendations found. Please check the query." << std::endl;
+        return false;
+    }
+    if (queryIndex >= 0) {
+        std::cout << "\n----------------------------------------------\nQuery Song:\n"
+                  << "  Title:   " << songs[queryIndex].track_name << "\n"
+                  << "  Artist:  " << songs[queryIndex].artists << "\n"
+                  << "  Genre:   " << genreMap[songs[queryIndex].genre_id] << "\n"
+                  << "  ID:      " << songs[queryIndex].track_id
+                  << "\n----------------------------------------------" << std::endl;
+    }
+    std::cout << "\nTop " << recs.size() << " Recommendations:\n" << std::endl;
+    for (size_t i = 0; i < recs.size(); ++i) {
+        const Song& s = songs[recs[i]];
+        std::cout << (i + 1) << ". \"" << s.track_name << "\"" << std::endl;
+        printSong(s, genreMap, "   ");
+        if (i + 1 < recs.size()) std::cout << std::endl;
+    }
+    std::cout << "\nRecommendation complete!" << std::endl;
+    return true;
+}
+
+int main(int argc, char* argv[]) {
+    std::cout << "== High-Performance Music Recommendation Engine ==\n"
+              << "==   MI355X-native (HIP / gfx950) cosine top-N  ==\n" << std::endl;
+    if (argc < 2) {
+        usage(argv[0]);
+        return 1;
+    }
+    const std::string mode = argv[1];
+    if (mode == "--preprocess") {
+        if (argc < 3) {
+            std::cerr << "Error: CSV path required for preprocessing mode" << std::endl;
+            usage(argv[0]);
+            return 1;
+        }
+        return preprocessMode(argv[2]) ? 0 : 1;
+    }
+    if (mode == "--song" || mode == "--id") {
+        if (argc < 3) {
+            std::cerr << "Error: Song name or track ID required" << std::endl;
+            usage(argv[0]);
+            return 1;
+        }
+        int topN = 10;
+        for (int i = 3; i < argc - 1; ++i) {  // main.cpp:169-178
+            if (std::strcmp(argv[i], "-n") == 0) {
+                topN = std::atoi(argv[i + 1]);
+                if (topN <= 0) {
+                    std::cerr << "Error: Invalid value for -n (must be positive)" << std::endl;
+                    return 1;
+                }
+                break;
+            }
+        }
+        return recommendationMode(argv[2], mode == "--id", topN) ? 0 : 1;
+    }
+    std::cerr << "Error: Unknown mode '" << mode << "'" << std::endl;
+    usage(argv[0]);
+    return 1;
+}
