@@ -50,6 +50,23 @@ def parse_args():
     return ap.parse_args()
 
 
+def pmc_traffic(rows_local: int):
+    """HBM bytes per scan launch from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_hbm_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs
+    of this same script, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950
+    correction).  PMC counters cannot be read from inside the timed process, so
+    this is only reported when the profiled launch had the same row count."""
+    try:
+        files = sorted((ROOT / "profiles").glob("*_pmc_hbm_traffic.json"))
+        data = json.loads(files[-1].read_text())
+        for name, k in data["kernels"].items():
+            if "scan_kernel" in name and k.get("algorithmic_bytes_per_launch") == rows_local * BYTES_PER_ROW:
+                return int(k["hbm_bytes_per_launch"]), f"profiles/{files[-1].name}"
+    except Exception:
+        pass
+    return None, None
+
+
 def host_threads(omp_max: int) -> int:
     """Threads the CPU baseline may really use: affinity mask, cgroup quota, and
     the GPU box's per-GPU CPU share (16) bound it, not the socket's core count."""
@@ -204,6 +221,7 @@ def main():
         scan_ms = float(st.last_scan_ms) if not args.no_kernel_events else 0.0
         achieved = ((hi - lo) * BYTES_PER_ROW / (scan_ms * 1e-3) / 1e9) if scan_ms > 0 else None
         cache_resident = (hi - lo) * BYTES_PER_ROW <= 256 * 2**20
+        traffic_bytes, traffic_source = pmc_traffic(hi - lo)
         line = {
             "metric": "queries/sec, cosine top-100 over a 10M x 12 fp32 catalogue",
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
@@ -223,7 +241,7 @@ def main():
                 "bound": "hbm", "kernel": "mi355::scan_kernel<true,false>" if world == 1 else "mi355::scan_kernel<false,false>",
                 "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None,
-                "traffic": None,
+                "traffic": traffic_bytes, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": (hi - lo) * BYTES_PER_ROW,
                 "avg_kernel_ms": round(scan_ms, 5) if scan_ms else None,
                 "merge_kernel_ms": round(float(st.last_merge_ms), 5),
