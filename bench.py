@@ -135,9 +135,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_sharded = os.environ.get("BENCH_FORCE_SHARDED") == "1"  # exercise the RCCL path on one GPU
+    if world > 1 or force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     n, topn = args.rows, args.topn
     total_q = args.warmup + args.steps
@@ -156,7 +158,7 @@ def main():
     torch.cuda.empty_cache()
 
     eng = CosineEngine(shard, row_base=lo)
-    sharded = ShardedEngine(eng, max_topn=topn) if world > 1 else None
+    sharded = ShardedEngine(eng, max_topn=topn, always_gather=force_sharded) if (world > 1 or force_sharded) else None
     out_keys = torch.zeros(topn, dtype=torch.int64, device=dev)
 
     def step(k):
@@ -261,7 +263,7 @@ def main():
         print(json.dumps(line), flush=True)
 
     eng.close()
-    if world > 1:
+    if world > 1 or force_sharded:
         dist.destroy_process_group()
 
 

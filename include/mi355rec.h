@@ -37,7 +37,7 @@ extern "C" {
 #endif
 
 #define MI355REC_DIM 12 /* Song.h:12 FEATURE_COUNT */
-#define MI355REC_MAX_TOPN_FAST 1024 /* larger topn takes the sort path */
+#define MI355REC_MAX_TOPN_FAST 1024 /* larger topn is served in rounds of this many (one scan each) */
 
 #define MI355REC_OK 0
 #define MI355REC_ERR_INVALID_ARG (-1)
@@ -145,7 +145,8 @@ int mi355rec_enqueue_query_keys(mi355rec_t* h, const float* query12,
  * descending, 0-padded — e.g. the all-gathered per-rank outputs of
  * mi355rec_enqueue_*_keys) into the global best `topn` keys (sorted
  * descending, 0-padded), and optionally unpack them.  out_idx_dev /
- * out_score_dev may be NULL.  Unused idx slots are -1. */
+ * out_score_dev may be NULL.  Unused idx slots are -1.
+ * topn <= MI355REC_MAX_TOPN_FAST here. */
 int mi355rec_enqueue_merge_keys(mi355rec_t* h, const mi355rec_key_t* lists_dev,
                                 int n_lists, int list_len, int topn,
                                 mi355rec_key_t* out_keys_dev,

@@ -338,7 +338,8 @@ template <typename Cfg, bool kQueryFromRow, bool kScoresOnly, int kDebug = 0>
 __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
     const float* __restrict__ feats, int64_t n, int64_t rows_per_block, int iters,
     int64_t row_base, QueryArg qarg, int64_t query_row, int64_t exclude_global,
-    int topk, uint64_t* __restrict__ block_lists, float* __restrict__ scores_out) {
+    int topk, uint64_t* __restrict__ block_lists, float* __restrict__ scores_out,
+    const uint64_t* __restrict__ upper_ptr) {
     constexpr int kBlock = Cfg::kBlock;
     constexpr int kRowsPerThread = Cfg::kRowsPerThread;
     constexpr int kTileRows = Cfg::kTileRows;
@@ -356,6 +357,10 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
         for (int j = 0; j < kDim; ++j) q[j] = qarg.q[j];
     }
     const float qn = query_norm(q);
+    // Only keys strictly below *upper_ptr take part (nullptr: no bound).  This is
+    // how topn > kMaxTopK is served: round r asks for the best kMaxTopK keys
+    // below the last key of round r-1 (0 there = catalogue exhausted).
+    const uint64_t upper = upper_ptr ? *upper_ptr : ~0ull;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
                     const float s = cosine_score(q, qn, rows[u]);
                     const int64_t g = row_base + r;
                     uint64_t key = pack_key(s, static_cast<uint32_t>(g));
-                    if (!in_range || g == exclude_global) key = 0;
+                    if (!in_range || g == exclude_global || key >= upper) key = 0;
                     const bool pass = maybe && key > thr;
                     const uint64_t ballot = __ballot(pass);
                     if (ballot && (kDebug & 2) == 0) {

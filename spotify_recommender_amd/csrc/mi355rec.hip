@@ -60,7 +60,7 @@ struct mi355rec {
 
     // resources of the synchronous host API
     hipStream_t stream = nullptr;
-    int batch_cap = 0;
+    size_t slot_cap = 0;
     uint64_t* d_keys = nullptr;
     int64_t* d_idx = nullptr;
     float* d_score = nullptr;
@@ -181,10 +181,11 @@ int create_common(const float* feats, bool on_device, int64_t n, int dim, int de
     return MI355REC_OK;
 }
 
-int ensure_batch(mi355rec* h, int batch) {
-    if (batch <= h->batch_cap) return MI355REC_OK;
-    int cap = h->batch_cap ? h->batch_cap : 1;
-    while (cap < batch) cap *= 2;
+// Result slots of the synchronous host API (device + pinned host mirrors).
+int ensure_slots(mi355rec* h, size_t slots) {
+    if (slots <= h->slot_cap) return MI355REC_OK;
+    size_t cap = h->slot_cap ? h->slot_cap : 1024;
+    while (cap < slots) cap *= 2;
     if (h->d_keys) (void)hipFree(h->d_keys);
     if (h->d_idx) (void)hipFree(h->d_idx);
     if (h->d_score) (void)hipFree(h->d_score);
@@ -192,14 +193,13 @@ int ensure_batch(mi355rec* h, int batch) {
     if (h->h_score) (void)hipHostFree(h->h_score);
     h->d_keys = nullptr; h->d_idx = nullptr; h->d_score = nullptr;
     h->h_idx = nullptr; h->h_score = nullptr;
-    h->batch_cap = 0;
-    const size_t slots = static_cast<size_t>(cap) * kMaxTopK;
-    HIP_TRY(h, hipMalloc(&h->d_keys, slots * sizeof(uint64_t)));
-    HIP_TRY(h, hipMalloc(&h->d_idx, slots * sizeof(int64_t)));
-    HIP_TRY(h, hipMalloc(&h->d_score, slots * sizeof(float)));
-    HIP_TRY(h, hipHostMalloc(&h->h_idx, slots * sizeof(int64_t), hipHostMallocDefault));
-    HIP_TRY(h, hipHostMalloc(&h->h_score, slots * sizeof(float), hipHostMallocDefault));
-    h->batch_cap = cap;
+    h->slot_cap = 0;
+    HIP_TRY(h, hipMalloc(&h->d_keys, cap * sizeof(uint64_t)));
+    HIP_TRY(h, hipMalloc(&h->d_idx, cap * sizeof(int64_t)));
+    HIP_TRY(h, hipMalloc(&h->d_score, cap * sizeof(float)));
+    HIP_TRY(h, hipHostMalloc(&h->h_idx, cap * sizeof(int64_t), hipHostMallocDefault));
+    HIP_TRY(h, hipHostMalloc(&h->h_score, cap * sizeof(float), hipHostMallocDefault));
+    h->slot_cap = cap;
     return MI355REC_OK;
 }
 
@@ -227,7 +227,7 @@ void timing_end(mi355rec* h, std::vector<hipEvent_t>& evs, int& pairs, int slot,
 
 // Enqueue the scan for one query.  query_row >= 0: query is that local row.
 int enqueue_scan(mi355rec* h, int64_t query_row, const float* query12,
-                 int64_t exclude_global, int topn, hipStream_t s) {
+                 int64_t exclude_global, int topn, const uint64_t* upper_dev, hipStream_t s) {
     QueryArg qa;
     std::memset(&qa, 0, sizeof qa);
     const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, s);
@@ -235,13 +235,13 @@ int enqueue_scan(mi355rec* h, int64_t query_row, const float* query12,
         hipLaunchKernelGGL((scan_kernel<ScanConfig, true, false>), dim3(h->grid), dim3(kScanBlock), 0, s,
                            h->d_feats, h->n, h->rows_per_block, h->iters, h->row_base, qa,
                            query_row, exclude_global, topn, h->d_block_lists,
-                           static_cast<float*>(nullptr));
+                           static_cast<float*>(nullptr), upper_dev);
     } else {
         std::memcpy(qa.q, query12, sizeof qa.q);
         hipLaunchKernelGGL((scan_kernel<ScanConfig, false, false>), dim3(h->grid), dim3(kScanBlock), 0, s,
                            h->d_feats, h->n, h->rows_per_block, h->iters, h->row_base, qa,
                            static_cast<int64_t>(0), exclude_global, topn, h->d_block_lists,
-                           static_cast<float*>(nullptr));
+                           static_cast<float*>(nullptr), upper_dev);
     }
     timing_end(h, h->ev_scan, h->n_scan_pairs, slot, s);
     HIP_TRY(h, hipGetLastError());
@@ -259,11 +259,28 @@ int enqueue_merge(mi355rec* h, const uint64_t* lists, int n_lists, int list_len,
     return MI355REC_OK;
 }
 
-int check_topn(mi355rec* h, int topn) {
+int check_topn(mi355rec* h, int topn, bool allow_rounds) {
     if (topn <= 0)
         return fail(h, MI355REC_ERR_INVALID_ARG, "topn must be positive, got %d", topn);
-    if (topn > kMaxTopK)
-        return fail(h, MI355REC_ERR_INVALID_ARG, "topn %d > %d is not supported yet", topn, kMaxTopK);
+    if (!allow_rounds && topn > kMaxTopK)
+        return fail(h, MI355REC_ERR_INVALID_ARG, "topn %d > %d is not supported by this call", topn, kMaxTopK);
+    return MI355REC_OK;
+}
+
+// One query end to end on stream `s`: scan + merge, in rounds of kMaxTopK when
+// topn is larger (round r only sees keys below the last key of round r-1, read
+// from device memory, so the rounds are enqueued back to back without a sync).
+int enqueue_query(mi355rec* h, int64_t query_row, const float* query12, int64_t exclude_global,
+                  int topn, uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s) {
+    for (int done = 0; done < topn; done += kMaxTopK) {
+        const int k = topn - done < kMaxTopK ? topn - done : kMaxTopK;
+        const uint64_t* upper = done ? out_keys + done - 1 : nullptr;
+        int rc = enqueue_scan(h, query_row, query12, exclude_global, k, upper, s);
+        if (rc) return rc;
+        rc = enqueue_merge(h, h->d_block_lists, h->grid, k, k, out_keys + done,
+                           out_idx ? out_idx + done : nullptr, out_score ? out_score + done : nullptr, s);
+        if (rc) return rc;
+    }
     return MI355REC_OK;
 }
 
@@ -362,25 +379,21 @@ int mi355rec_enqueue_row_keys(mi355rec_t* h, int64_t local_row, int topn,
     if (!h || !out_keys_dev) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
     if (local_row < 0 || local_row >= h->n)
         return fail(h, MI355REC_ERR_INVALID_ARG, "Invalid song index: %lld", (long long)local_row);
-    int rc = check_topn(h, topn);
+    int rc = check_topn(h, topn, true);
     if (rc) return rc;
     DeviceGuard guard(h->device);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    rc = enqueue_scan(h, local_row, nullptr, h->row_base + local_row, topn, s);
-    if (rc) return rc;
-    return enqueue_merge(h, h->d_block_lists, h->grid, topn, topn, out_keys_dev, nullptr, nullptr, s);
+    return enqueue_query(h, local_row, nullptr, h->row_base + local_row, topn, out_keys_dev, nullptr, nullptr,
+                         static_cast<hipStream_t>(stream));
 }
 
 int mi355rec_enqueue_query_keys(mi355rec_t* h, const float* query12, int64_t exclude_global,
                                 int topn, mi355rec_key_t* out_keys_dev, void* stream) {
     if (!h || !out_keys_dev || !query12) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
-    int rc = check_topn(h, topn);
+    int rc = check_topn(h, topn, true);
     if (rc) return rc;
     DeviceGuard guard(h->device);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    rc = enqueue_scan(h, -1, query12, exclude_global, topn, s);
-    if (rc) return rc;
-    return enqueue_merge(h, h->d_block_lists, h->grid, topn, topn, out_keys_dev, nullptr, nullptr, s);
+    return enqueue_query(h, -1, query12, exclude_global, topn, out_keys_dev, nullptr, nullptr,
+                         static_cast<hipStream_t>(stream));
 }
 
 int mi355rec_enqueue_merge_keys(mi355rec_t* h, const mi355rec_key_t* lists_dev, int n_lists,
@@ -389,7 +402,7 @@ int mi355rec_enqueue_merge_keys(mi355rec_t* h, const mi355rec_key_t* lists_dev, 
     if (!h || !lists_dev || !out_keys_dev) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
     if (n_lists < 1 || n_lists > kMergeMaxLists || list_len < 1)
         return fail(h, MI355REC_ERR_INVALID_ARG, "n_lists %d / list_len %d out of range", n_lists, list_len);
-    int rc = check_topn(h, topn);
+    int rc = check_topn(h, topn, false);
     if (rc) return rc;
     DeviceGuard guard(h->device);
     return enqueue_merge(h, lists_dev, n_lists, list_len, topn, out_keys_dev, out_idx_dev,
@@ -408,12 +421,14 @@ int mi355rec_enqueue_scores(mi355rec_t* h, int64_t local_row, const float* query
     if (local_row >= 0) {
         hipLaunchKernelGGL((scan_kernel<ScanConfig, true, true>), dim3(h->grid), dim3(kScanBlock), 0, s, h->d_feats,
                            h->n, h->rows_per_block, h->iters, h->row_base, qa, local_row,
-                           static_cast<int64_t>(-1), 1, static_cast<uint64_t*>(nullptr), out_scores_dev);
+                           static_cast<int64_t>(-1), 1, static_cast<uint64_t*>(nullptr), out_scores_dev,
+                           static_cast<const uint64_t*>(nullptr));
     } else {
         std::memcpy(qa.q, query12, sizeof qa.q);
         hipLaunchKernelGGL((scan_kernel<ScanConfig, false, true>), dim3(h->grid), dim3(kScanBlock), 0, s, h->d_feats,
                            h->n, h->rows_per_block, h->iters, h->row_base, qa, static_cast<int64_t>(0),
-                           static_cast<int64_t>(-1), 1, static_cast<uint64_t*>(nullptr), out_scores_dev);
+                           static_cast<int64_t>(-1), 1, static_cast<uint64_t*>(nullptr), out_scores_dev,
+                           static_cast<const uint64_t*>(nullptr));
     }
     HIP_TRY(h, hipGetLastError());
     return MI355REC_OK;
@@ -461,22 +476,19 @@ int mi355rec_query_batch_topn(mi355rec_t* h, const float* queries, int batch,
                               float* out_score, int* out_count) {
     if (!h || !queries || !out_idx) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
     if (batch < 1) return fail(h, MI355REC_ERR_INVALID_ARG, "batch must be positive");
-    int rc = check_topn(h, topn);
+    int rc = check_topn(h, topn, true);
     if (rc) return rc;
     DeviceGuard guard(h->device);
-    rc = ensure_batch(h, batch);
+    const size_t cnt = static_cast<size_t>(batch) * topn;
+    rc = ensure_slots(h, cnt);
     if (rc) return rc;
     for (int b = 0; b < batch; ++b) {
-        rc = enqueue_scan(h, -1, queries + static_cast<int64_t>(b) * kDim,
-                          exclude_global ? exclude_global[b] : -1, topn, h->stream);
-        if (rc) return rc;
-        rc = enqueue_merge(h, h->d_block_lists, h->grid, topn, topn,
-                           h->d_keys + static_cast<int64_t>(b) * topn,
-                           h->d_idx + static_cast<int64_t>(b) * topn,
-                           h->d_score + static_cast<int64_t>(b) * topn, h->stream);
+        const size_t off = static_cast<size_t>(b) * topn;
+        rc = enqueue_query(h, -1, queries + static_cast<int64_t>(b) * kDim,
+                           exclude_global ? exclude_global[b] : -1, topn, h->d_keys + off,
+                           h->d_idx + off, h->d_score + off, h->stream);
         if (rc) return rc;
     }
-    const size_t cnt = static_cast<size_t>(batch) * topn;
     HIP_TRY(h, hipMemcpyAsync(h->h_idx, h->d_idx, cnt * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->h_score, h->d_score, cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -485,7 +497,7 @@ int mi355rec_query_batch_topn(mi355rec_t* h, const float* queries, int batch,
     if (out_count) {
         for (int b = 0; b < batch; ++b) {
             int c = 0;
-            while (c < topn && h->h_idx[static_cast<int64_t>(b) * topn + c] >= 0) ++c;
+            while (c < topn && h->h_idx[static_cast<size_t>(b) * topn + c] >= 0) ++c;
             out_count[b] = c;
         }
     }
@@ -502,14 +514,13 @@ int mi355rec_query_row_topn(mi355rec_t* h, int64_t local_row, int topn, int64_t*
     if (!h || !out_idx) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
     if (local_row < 0 || local_row >= h->n)
         return fail(h, MI355REC_ERR_INVALID_ARG, "Invalid song index: %lld", (long long)local_row);
-    int rc = check_topn(h, topn);
+    int rc = check_topn(h, topn, true);
     if (rc) return rc;
     DeviceGuard guard(h->device);
-    rc = ensure_batch(h, 1);
+    rc = ensure_slots(h, static_cast<size_t>(topn));
     if (rc) return rc;
-    rc = enqueue_scan(h, local_row, nullptr, h->row_base + local_row, topn, h->stream);
-    if (rc) return rc;
-    rc = enqueue_merge(h, h->d_block_lists, h->grid, topn, topn, h->d_keys, h->d_idx, h->d_score, h->stream);
+    rc = enqueue_query(h, local_row, nullptr, h->row_base + local_row, topn, h->d_keys, h->d_idx,
+                       h->d_score, h->stream);
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->h_idx, h->d_idx, topn * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->h_score, h->d_score, topn * sizeof(float), hipMemcpyDeviceToHost, h->stream));

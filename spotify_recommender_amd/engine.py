@@ -217,7 +217,7 @@ class ShardedEngine:
     enqueued on the current stream; nothing synchronises the host.
     """
 
-    def __init__(self, local, max_topn: int, group=None, device=None):
+    def __init__(self, local, max_topn: int, group=None, device=None, always_gather: bool = False):
         import torch
         import torch.distributed as dist
 
@@ -228,6 +228,7 @@ class ShardedEngine:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.max_topn = int(max_topn)
+        self.always_gather = bool(always_gather)  # run the collective even at world size 1
         dev = device if device is not None else torch.device("cuda", local.device)
         self.device = dev
         self.local_keys = torch.zeros(self.max_topn, dtype=torch.int64, device=dev)
@@ -243,7 +244,7 @@ class ShardedEngine:
         k = int(topn)
         local = self.local_keys[:k]
         self.local.enqueue_query_keys(query, exclude_global, k, local)
-        if self.world == 1:
+        if self.world == 1 and not self.always_gather:
             gathered = local
         else:
             gathered = self.gathered[: self.world * k]

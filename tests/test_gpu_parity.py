@@ -172,6 +172,47 @@ def test_topn_larger_than_rows_and_bad_args(Engine):
         assert len(idx) == 0
 
 
+def test_topn_above_the_fast_limit_runs_in_rounds(Engine):
+    """topn > 1024: rounds of 1024 bounded by the previous round's last key."""
+    rng = np.random.default_rng(77)
+    f = rng.random((60_000, 12), dtype=np.float32)
+    f[100:140] = f[7]                                  # exact ties straddling a round boundary
+    with Engine(f) as eng:
+        want = oracle.scores(f, f[7])
+        for topn in (1025, 2048, 3000):
+            idx, sc = eng.query_row_topn(7, topn)
+            assert_topn_matches(idx, sc, want, 7, topn, ref_idx=oracle.topn_heap(want, 7, topn))
+            assert_canonical_order(idx, want)
+    small = rng.random((1500, 12), dtype=np.float32)
+    with Engine(small) as eng:                         # catalogue exhausted inside round 2
+        want = oracle.scores(small, small[0])
+        idx, sc = eng.query_row_topn(0, 5000)
+        assert len(idx) == 1499
+        assert_topn_matches(idx, sc, want, 0, 5000)
+
+
+def test_near_ties_inside_the_prefilter_margin(Engine):
+    """Thousands of rows whose scores differ by a few ulps around the running
+    threshold: the approximate pre-filter (margin 8e-6) must never drop a row
+    the exact chain would keep."""
+    rng = np.random.default_rng(31)
+    n = 300_000
+    f = rng.random((n, 12), dtype=np.float32)
+    q = f[0].copy()
+    cluster = rng.choice(np.arange(1, n), size=6000, replace=False)
+    scale = rng.uniform(0.5, 2.0, size=(6000, 1)).astype(np.float32)
+    noise = 1.0 + rng.uniform(-3e-7, 3e-7, size=(6000, 12))
+    f[cluster] = (q[None, :] * scale * noise).astype(np.float32)   # cos within ~1e-7 of 1.0
+    want = oracle.scores(f, q)
+    assert np.unique(want[cluster]).size > 3            # several distinct top scores, many ties
+    with Engine(f) as eng:
+        got = eng.scores_row(0)
+        assert np.array_equal(bits(got), bits(want))
+        for topn in (10, 100, 1000):
+            idx, sc = eng.query_row_topn(0, topn)
+            assert_topn_matches(idx, sc, want, 0, topn, ref_idx=oracle.topn_heap(want, 0, topn))
+
+
 def test_external_query_and_exclude(Engine):
     rng = np.random.default_rng(21)
     f = rng.random((100_000, 12), dtype=np.float32)

@@ -44,8 +44,8 @@ void run_cfg(const char* label, int blocks_per_cu) {
     int grid = (int)((g_n + rpb - 1) / rpb); int iters = (int)((rpb + Cfg::kTileRows - 1) / Cfg::kTileRows);
     int occ = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel<Cfg, false, false>, Cfg::kBlock, 0));
     printf("-- %s: block %d x %d rows, minwaves %d, grid %d (%d/CU asked, occupancy API %d), rows/block %lld, iters %d\n", label, Cfg::kBlock, Cfg::kRowsPerThread, Cfg::kMinWaves, grid, blocks_per_cu, occ, (long long)rpb, iters);
-    report("scores-only", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, true>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)-1, 1, (uint64_t*)nullptr, d_scores); }, g_reps));
-    report("topk", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr); }, g_reps));
+    report("scores-only", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, true>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)-1, 1, (uint64_t*)nullptr, d_scores, (const uint64_t*)nullptr); }, g_reps));
+    report("topk", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr, (const uint64_t*)nullptr); }, g_reps));
     float mm = T.run([&] { hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)0, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)0); }, g_reps);
     report("merge", mm);
     if (g_stages) for (int stop = 1; stop <= 5; ++stop) { char nm[64]; snprintf(nm, sizeof nm, "  merge stopped at stage %d", stop);
@@ -55,7 +55,7 @@ void run_cfg(const char* label, int blocks_per_cu) {
     CK(hipMemcpy(got.data(), d_out, 8 * g_topk, hipMemcpyDeviceToHost));
     if (g_ref.empty()) g_ref = got;
     printf("  result %s\n", got == g_ref ? "matches first config" : "DIFFERS from first config");
-    report("topk, preset threshold (floor)", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false, 4>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr); }, g_reps));
+    report("topk, preset threshold (floor)", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false, 4>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr, (const uint64_t*)nullptr); }, g_reps));
 }
 
 int main(int argc, char** argv) {
