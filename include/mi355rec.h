@@ -141,6 +141,14 @@ int mi355rec_enqueue_query_keys(mi355rec_t* h, const float* query12,
                                 int64_t exclude_global, int topn,
                                 mi355rec_key_t* out_keys_dev, void* stream);
 
+/* `batch` queries (batch x 12 floats, host; exclude_global may be NULL) in
+ * multi-query passes: every pass streams the shard ONCE for up to 8 queries
+ * (topn <= 128; larger topn falls back to one scan per query).  Writes
+ * batch x topn packed keys (each row sorted descending, 0-padded). */
+int mi355rec_enqueue_batch_keys(mi355rec_t* h, const float* queries,
+                                const int64_t* exclude_global, int batch, int topn,
+                                mi355rec_key_t* out_keys_dev, void* stream);
+
 /* Merge `n_lists` lists of `list_len` packed keys each (each sorted
  * descending, 0-padded — e.g. the all-gathered per-rank outputs of
  * mi355rec_enqueue_*_keys) into the global best `topn` keys (sorted

@@ -464,6 +464,306 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
     }
 }
 
+// ---- multi-query streaming scan ------------------------------------------------
+// One pass over the catalogue scores kQ queries at once: the 48 B of a row are
+// fetched once and reused from registers, so the pass costs about the same HBM
+// time as a single query while answering kQ of them (still memory-bound at
+// kQ = 8: ~8 + 14*kQ VALU instructions per row).  Per query the logic is the
+// single-query kernel's: packed-FMA upper bound against that query's running
+// threshold, exact in-order re-score of the rare rows that may beat it, LDS
+// candidate buffer, O(c) radix select when candidates pile up.  Differences:
+//  * each query has its own candidate buffer, count and threshold in LDS;
+//  * compaction is WAVE-level (wave w serves queries w, w + waves, ...), so the
+//    kQ compactions of a tile boundary run in parallel between two barriers;
+//  * the row norm (6 packed FMAs + rsq) is shared by all queries.
+// Output: block_lists[q][workgroup][topk], each list sorted descending.
+
+constexpr int kMultiQueries = 8;      // queries per pass
+constexpr int kMultiChain = 32;       // queries whose seed / final merges share one launch
+constexpr int kMultiMaxTopK = 128;    // larger topn goes through the single-query kernel
+constexpr int kMultiCompactAt = 256;  // >= 2 * kMultiMaxTopK
+
+template <int kBlockT, int kRowsT, int kMinWavesT>
+struct MultiCfg {
+    static constexpr int kBlock = kBlockT;
+    static constexpr int kRowsPerThread = kRowsT;
+    static constexpr int kMinWaves = kMinWavesT;
+    static constexpr int kTileRows = kBlockT * kRowsT;
+    static constexpr int kWaves = kBlockT / 64;
+    static constexpr int kCap = kMultiCompactAt + kTileRows;   // per-query candidate slots
+    static constexpr int kKeysPerLane = (kCap + 63) / 64;
+};
+using DefaultMultiCfg = MultiCfg<512, 1, 4>;
+
+struct MultiQueryArg {
+    float q[kMultiQueries][kDim];
+    long long exclude[kMultiQueries];   // global row to skip per query, -1 = none
+};
+
+// Wave-level twin of block_select_threshold: the calling wave holds `c` unique
+// keys in registers (0 = empty), `hist` is 256 ints of LDS private to the wave.
+// No barriers: LDS operations of one wave execute in order.
+template <int kKeys>
+__device__ inline uint64_t wave_select_threshold(const uint64_t (&mine)[kKeys], int need, bool exact,
+                                                 int slack, int* hist) {
+    const int lane = threadIdx.x & 63;
+    uint32_t mx = 0, mn = ~0u;
+#pragma unroll
+    for (int r = 0; r < kKeys; ++r) {
+        if (mine[r]) {
+            const uint32_t hi = static_cast<uint32_t>(mine[r] >> 32);
+            mx = hi > mx ? hi : mx;
+            mn = hi < mn ? hi : mn;
+        }
+    }
+    mx = wave_max_u32(mx);
+    mn = wave_min_u32(mn);
+    const uint64_t base = static_cast<uint64_t>(mn) << 32;
+    const uint64_t span = (static_cast<uint64_t>(mx - mn) << 32) | 0xffffffffull;
+    int shift = (64 - __clzll(static_cast<long long>(span))) - 8;
+    if (shift < 0) shift = 0;
+    uint64_t prefix = 0, mask = 0;
+    const int top = 255 - 4 * lane;
+    hist[top] = 0; hist[top - 1] = 0; hist[top - 2] = 0; hist[top - 3] = 0;
+    for (;;) {
+#pragma unroll
+        for (int r = 0; r < kKeys; ++r) {
+            const uint64_t k = mine[r];
+            if (k) {
+                const uint64_t v = k - base;
+                if ((v & mask) == prefix) atomicAdd(&hist[static_cast<int>((v >> shift) & 255u)], 1);
+            }
+        }
+        const int h0 = hist[top], h1 = hist[top - 1], h2 = hist[top - 2], h3 = hist[top - 3];
+        hist[top] = 0; hist[top - 1] = 0; hist[top - 2] = 0; hist[top - 3] = 0;
+        const int lane_sum = h0 + h1 + h2 + h3;
+        int cum = wave_inclusive_scan(lane_sum) - lane_sum;
+        const int hs[4] = {h0, h1, h2, h3};
+        int digit = 0, above = 0, in_bin = 0;
+        bool found = false;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (cum < need && cum + hs[b] >= need) {
+                found = true;
+                digit = top - b;
+                above = cum;
+                in_bin = hs[b];
+            }
+            cum += hs[b];
+        }
+        const uint64_t who = __ballot(found);
+        const int src = __ffsll(static_cast<long long>(who)) - 1;  // exactly one lane when the precondition holds
+        digit = __builtin_amdgcn_readlane(digit, src);
+        above = __builtin_amdgcn_readlane(above, src);
+        in_bin = __builtin_amdgcn_readlane(in_bin, src);
+        prefix |= static_cast<uint64_t>(digit) << shift;
+        mask |= 255ull << shift;
+        need -= above;
+        if (shift == 0 || in_bin == need || (!exact && in_bin - need <= slack)) break;
+        shift = shift > 8 ? shift - 8 : 0;
+    }
+    return base + prefix;
+}
+
+// Wave-level compaction of one query's candidate buffer: keep the keys >= T where
+// T bounds the topk-th best.  Returns the new filter threshold (key > thr passes).
+template <int kKeys>
+__device__ inline uint64_t wave_compact(uint64_t* cand, int* count, int topk, bool exact, int* hist) {
+    const int lane = threadIdx.x & 63;
+    const int c = *count;
+    if (c <= topk) return 0ull;
+    uint64_t mine[kKeys];
+#pragma unroll
+    for (int r = 0; r < kKeys; ++r) {
+        const int i = lane + r * 64;
+        mine[r] = i < c ? cand[i] : 0ull;
+    }
+    int slack = topk / 4;
+    if (slack < 16) slack = 16;
+    const uint64_t t = wave_select_threshold<kKeys>(mine, topk, exact, slack, hist);
+    int base = 0;
+#pragma unroll
+    for (int r = 0; r < kKeys; ++r) {
+        const bool keep = mine[r] >= t;  // t >= 1, so empty slots drop out
+        const uint64_t b = __ballot(keep);
+        if (keep) cand[base + __popcll(b & ((1ull << lane) - 1ull))] = mine[r];
+        base += __popcll(b);
+    }
+    if (lane == 0) *count = base;
+    return t - 1ull;
+}
+
+// Wave-level ranking of c <= kRankDirectMax unique keys into dst (descending, best topk).
+__device__ inline void wave_rank_and_store(const uint64_t* keys, int c, uint64_t* dst, int topk) {
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < topk; i += 64)
+        if (i >= c) dst[i] = 0ull;
+    for (int i = lane; i < c; i += 64) {
+        const uint64_t mine = keys[i];
+        int rank = 0;
+        int j = 0;
+        for (; j + 8 <= c; j += 8) {
+            const uint64_t k0 = keys[j], k1 = keys[j + 1], k2 = keys[j + 2], k3 = keys[j + 3];
+            const uint64_t k4 = keys[j + 4], k5 = keys[j + 5], k6 = keys[j + 6], k7 = keys[j + 7];
+            rank += (k0 > mine) + (k1 > mine) + (k2 > mine) + (k3 > mine) +
+                    (k4 > mine) + (k5 > mine) + (k6 > mine) + (k7 > mine);
+        }
+        for (; j < c; ++j) rank += (keys[j] > mine);
+        if (rank < topk) dst[rank] = mine;
+    }
+}
+
+template <typename Cfg>
+__global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel(
+    const float* __restrict__ feats, int64_t n, int64_t rows_per_block, int64_t block_stride, int iters,
+    int64_t row_base, MultiQueryArg qarg, int n_queries, int query_slot0, int topk,
+    uint64_t* __restrict__ block_lists, const uint64_t* __restrict__ seed_keys) {
+    constexpr int kBlock = Cfg::kBlock;
+    constexpr int kRowsPerThread = Cfg::kRowsPerThread;
+    constexpr int kTileRows = Cfg::kTileRows;
+    constexpr int kQ = kMultiQueries;
+    __shared__ uint64_t s_cand[kQ][Cfg::kCap];
+    __shared__ int s_hist[Cfg::kWaves][256];
+    __shared__ int s_count[kQ];
+    __shared__ uint64_t s_thr[kQ];   // running filter threshold per query (key > thr passes)
+    __shared__ float4 s_qc[kQ];      // {cutoff of the approx pre-filter, 1/|q|, |q|, unused}
+    __shared__ float4 s_q[kQ][3];    // the query vectors (broadcast reads; 96 SGPRs would spill)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    // block_stride == rows_per_block: the workgroups tile the shard.  A larger
+    // stride makes each workgroup scan only the head of its region (seed pass).
+    const int64_t blk_begin = static_cast<int64_t>(blockIdx.x) * block_stride;
+    int64_t blk_end = blk_begin + rows_per_block;
+    if (blk_end > n) blk_end = n;
+    const int64_t last_row = blk_end - 1;
+
+    // Per-query state lives in LDS (broadcast reads), not in ~50 scalar registers.
+    // cutoff = -inf disables the pre-filter until the threshold score is > 0.
+    // seed_keys (optional): [kQ][topk] sorted best keys of a SAMPLE of the catalogue
+    // (a first launch of this kernel over each workgroup's first tile, merged).
+    // The sample's topk-th key bounds the global topk-th from below, so every
+    // workgroup starts with a chip-wide threshold instead of re-deriving a weak
+    // local one — the exact re-score path then runs for ~1e-4 of the rows.
+    if (tid < kQ) {
+        const float norm = query_norm(qarg.q[tid]);
+        uint64_t t = 0ull;
+        if (seed_keys && tid < n_queries) t = seed_keys[static_cast<int64_t>(query_slot0 + tid) * topk + (topk - 1)];
+        float cut = -__builtin_inff();
+        if (t) {
+            const float score = ordered_to_score(static_cast<uint32_t>(t >> 32));
+            if (score > 0.0f) cut = score - kApproxMargin;
+            t -= 1ull;
+        }
+        s_count[tid] = 0;
+        s_thr[tid] = t;
+        s_qc[tid] = make_float4(cut, 1.0f / norm, norm, 0.0f);
+        s_q[tid][0] = make_float4(qarg.q[tid][0], qarg.q[tid][1], qarg.q[tid][2], qarg.q[tid][3]);
+        s_q[tid][1] = make_float4(qarg.q[tid][4], qarg.q[tid][5], qarg.q[tid][6], qarg.q[tid][7]);
+        s_q[tid][2] = make_float4(qarg.q[tid][8], qarg.q[tid][9], qarg.q[tid][10], qarg.q[tid][11]);
+    }
+    __syncthreads();
+
+    auto load_tile = [&](Row (&dst)[kRowsPerThread], int it) {
+        const int64_t tile_begin = blk_begin + static_cast<int64_t>(it) * kTileRows;
+#pragma unroll
+        for (int u = 0; u < kRowsPerThread; ++u) {
+            const int64_t r = tile_begin + u * kBlock + tid;
+            dst[u] = load_row(feats, r < blk_end ? r : last_row);
+        }
+    };
+
+    auto process_tile = [&](const Row (&rows)[kRowsPerThread], int it) {
+        const int64_t tile_begin = blk_begin + static_cast<int64_t>(it) * kTileRows;
+        // shared by all queries: approximate 1/|row| of this lane's rows
+        float inv_norm[kRowsPerThread];
+#pragma unroll
+        for (int u = 0; u < kRowsPerThread; ++u) {
+            const Row& row = rows[u];
+            v2f m = {row.a.x * row.a.x, row.a.y * row.a.y};
+            m = __builtin_elementwise_fma(v2f{row.a.z, row.a.w}, v2f{row.a.z, row.a.w}, m);
+            m = __builtin_elementwise_fma(v2f{row.b.x, row.b.y}, v2f{row.b.x, row.b.y}, m);
+            m = __builtin_elementwise_fma(v2f{row.b.z, row.b.w}, v2f{row.b.z, row.b.w}, m);
+            m = __builtin_elementwise_fma(v2f{row.c.x, row.c.y}, v2f{row.c.x, row.c.y}, m);
+            m = __builtin_elementwise_fma(v2f{row.c.z, row.c.w}, v2f{row.c.z, row.c.w}, m);
+            inv_norm[u] = __builtin_amdgcn_rsqf(m.x + m.y);
+        }
+        for (int qi = 0; qi < n_queries; ++qi) {  // uniform trip count
+            const float4 qa = s_q[qi][0], qb = s_q[qi][1], qcv = s_q[qi][2];
+            const float4 qc = s_qc[qi];
+            const float q[kDim] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, qcv.x, qcv.y, qcv.z, qcv.w};
+#pragma unroll
+            for (int u = 0; u < kRowsPerThread; ++u) {
+                const Row& row = rows[u];
+                v2f d = {row.a.x * q[0], row.a.y * q[1]};
+                d = __builtin_elementwise_fma(v2f{row.a.z, row.a.w}, v2f{q[2], q[3]}, d);
+                d = __builtin_elementwise_fma(v2f{row.b.x, row.b.y}, v2f{q[4], q[5]}, d);
+                d = __builtin_elementwise_fma(v2f{row.b.z, row.b.w}, v2f{q[6], q[7]}, d);
+                d = __builtin_elementwise_fma(v2f{row.c.x, row.c.y}, v2f{q[8], q[9]}, d);
+                d = __builtin_elementwise_fma(v2f{row.c.z, row.c.w}, v2f{q[10], q[11]}, d);
+                const bool maybe = !((d.x + d.y) * inv_norm[u] * qc.y < qc.x);
+                if (__ballot(maybe)) {
+                    const int64_t r = tile_begin + u * kBlock + tid;
+                    const int64_t g = row_base + r;
+                    const float s = cosine_score(q, qc.z, row);
+                    uint64_t key = pack_key(s, static_cast<uint32_t>(g));
+                    if (r >= blk_end || g == qarg.exclude[qi]) key = 0;
+                    const bool pass = maybe && key > s_thr[qi];
+                    const uint64_t ballot = __ballot(pass);
+                    if (ballot) {
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&s_count[qi], __popcll(ballot));
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        const int pos = base + __popcll(ballot & ((1ull << lane) - 1ull));
+                        if (pass) s_cand[qi][pos] = key;
+                    }
+                }
+            }
+        }
+        // tile boundary: does any query need its threshold tightened?
+        __syncthreads();
+        bool any = false;
+#pragma unroll
+        for (int qi = 0; qi < kQ; ++qi) any = any || s_count[qi] >= kMultiCompactAt;
+        __syncthreads();
+        if (any) {  // uniform (every thread read the same counts between the barriers)
+            for (int qi = wave; qi < kQ; qi += Cfg::kWaves) {
+                if (s_count[qi] >= kMultiCompactAt) {
+                    const uint64_t t = wave_compact<Cfg::kKeysPerLane>(s_cand[qi], &s_count[qi], topk, false, s_hist[wave]);
+                    if (lane == 0 && t > s_thr[qi]) {
+                        s_thr[qi] = t;
+                        const float score = ordered_to_score(static_cast<uint32_t>(t >> 32));
+                        if (score > 0.0f) s_qc[qi].x = score - kApproxMargin;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    };
+
+    Row buf_a[kRowsPerThread];
+    Row buf_b[kRowsPerThread];
+    load_tile(buf_a, 0);
+    for (int it = 0; it < iters; it += 2) {
+        load_tile(buf_b, it + 1);   // clamped to the block's rows: harmless past the end
+        process_tile(buf_a, it);
+        if (it + 1 >= iters) break;  // uniform
+        load_tile(buf_a, it + 2);
+        process_tile(buf_b, it + 1);
+    }
+
+    // final: every query's best topk of this workgroup, sorted, one wave per query
+    __syncthreads();
+    for (int qi = wave; qi < n_queries; qi += Cfg::kWaves) {
+        if (s_count[qi] > kRankDirectMax && s_count[qi] > topk)
+            wave_compact<Cfg::kKeysPerLane>(s_cand[qi], &s_count[qi], topk, true, s_hist[wave]);
+        const int c = __builtin_amdgcn_readfirstlane(s_count[qi]);
+        uint64_t* dst = block_lists + (static_cast<int64_t>(query_slot0 + qi) * gridDim.x + blockIdx.x) * topk;
+        wave_rank_and_store(s_cand[qi], c, dst, topk);
+    }
+}
+
 // ---- merge of sorted candidate lists -----------------------------------------
 // n_lists lists of list_len keys (each sorted descending, 0-padded) -> the best
 // topk keys, sorted descending, 0-padded; optional unpack to (row, score).

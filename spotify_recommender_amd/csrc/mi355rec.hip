@@ -39,6 +39,7 @@ struct DeviceGuard {
 constexpr int kTimingPairs = 8192;
 
 using ScanConfig = DefaultScanCfg;
+using MultiConfig = DefaultMultiCfg;
 constexpr int kScanBlock = ScanConfig::kBlock;
 constexpr int kScanTileRows = ScanConfig::kTileRows;
 
@@ -55,8 +56,13 @@ struct mi355rec {
     int grid = 0;
     int64_t rows_per_block = 0;
     int iters = 0;
+    // geometry of the multi-query pass (scan_multi_kernel)
+    int mgrid = 0;
+    int64_t mrows_per_block = 0;
+    int miters = 0;
 
     uint64_t* d_block_lists = nullptr;  // grid x kMaxTopK
+    uint64_t* d_seed_keys = nullptr;    // kMultiChain x kMultiMaxTopK: sample top-k per query of a multi-query chain
 
     // resources of the synchronous host API
     hipStream_t stream = nullptr;
@@ -113,6 +119,17 @@ void plan_grid(mi355rec* h, int blocks_per_cu) {
     h->iters = static_cast<int>((rpb + kScanTileRows - 1) / kScanTileRows);
 }
 
+void plan_multi_grid(mi355rec* h, int blocks_per_cu) {
+    int64_t max_blocks = static_cast<int64_t>(h->cus) * blocks_per_cu;
+    if (max_blocks > kMergeMaxLists) max_blocks = kMergeMaxLists;
+    int64_t rpb = (h->n + max_blocks - 1) / max_blocks;
+    rpb = (rpb + 63) / 64 * 64;
+    if (rpb < 64) rpb = 64;
+    h->mrows_per_block = rpb;
+    h->mgrid = static_cast<int>((h->n + rpb - 1) / rpb);
+    h->miters = static_cast<int>((rpb + MultiConfig::kTileRows - 1) / MultiConfig::kTileRows);
+}
+
 int create_common(const float* feats, bool on_device, int64_t n, int dim, int device,
                   int64_t row_base, mi355rec_t** out) {
     if (out) *out = nullptr;
@@ -149,6 +166,11 @@ int create_common(const float* feats, bool on_device, int64_t n, int dim, int de
     if (e != hipSuccess || occ < 1) occ = 1;
     if (occ > 4) occ = 4;
     plan_grid(h, occ);
+    int mocc = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&mocc, scan_multi_kernel<MultiConfig>, MultiConfig::kBlock, 0);
+    if (e != hipSuccess || mocc < 1) mocc = 1;
+    if (mocc > 4) mocc = 4;
+    plan_multi_grid(h, mocc);
 
     int rc = MI355REC_OK;
     auto cleanup = [&](int code, const char* what, hipError_t he) {
@@ -172,8 +194,13 @@ int create_common(const float* feats, bool on_device, int64_t n, int dim, int de
         h->d_feats = h->owned_feats;
     }
 
-    if ((e = hipMalloc(&h->d_block_lists, sizeof(uint64_t) * static_cast<size_t>(h->grid) * kMaxTopK)) != hipSuccess)
+    size_t list_words = static_cast<size_t>(h->grid) * kMaxTopK;
+    const size_t multi_words = static_cast<size_t>(h->mgrid) * kMultiChain * kMultiMaxTopK;
+    if (multi_words > list_words) list_words = multi_words;
+    if ((e = hipMalloc(&h->d_block_lists, sizeof(uint64_t) * list_words)) != hipSuccess)
         return cleanup(MI355REC_ERR_OUT_OF_MEMORY, "hipMalloc(block lists)", e);
+    if ((e = hipMalloc(&h->d_seed_keys, sizeof(uint64_t) * kMultiChain * kMultiMaxTopK)) != hipSuccess)
+        return cleanup(MI355REC_ERR_OUT_OF_MEMORY, "hipMalloc(seed keys)", e);
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess)
         return cleanup(MI355REC_ERR_HIP, "hipStreamCreate", e);
 
@@ -259,6 +286,58 @@ int enqueue_merge(mi355rec* h, const uint64_t* lists, int n_lists, int list_len,
     return MI355REC_OK;
 }
 
+// Multi-query passes for up to kMultiChain queries: per group of kMultiQueries a
+// seed pass (every workgroup scans the first tile of its region: a ~2.5 % sample
+// that yields a chip-wide starting threshold per query), ONE merge launch for all
+// seeds, then per group the full pass (the catalogue is streamed once per group),
+// then ONE merge launch with a workgroup per query.  topn <= kMultiMaxTopK.
+int enqueue_multi(mi355rec* h, const float* queries, const int64_t* exclude, int count, int topn,
+                  uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s) {
+    MultiQueryArg qa[kMultiChain / kMultiQueries];
+    const int groups = (count + kMultiQueries - 1) / kMultiQueries;
+    for (int g = 0; g < groups; ++g) {
+        std::memset(&qa[g], 0, sizeof qa[g]);
+        for (int q = 0; q < kMultiQueries; ++q) {
+            const int src = g * kMultiQueries + q;
+            qa[g].exclude[q] = -1;
+            if (src < count) {
+                std::memcpy(qa[g].q[q], queries + static_cast<size_t>(src) * kDim, sizeof(float) * kDim);
+                if (exclude) qa[g].exclude[q] = exclude[src];
+            }
+        }
+    }
+    const int64_t list_stride = static_cast<int64_t>(h->mgrid) * topn;
+    const bool seeded = h->miters >= 8;
+    if (seeded) {
+        for (int g = 0; g < groups; ++g) {
+            const int nq = count - g * kMultiQueries < kMultiQueries ? count - g * kMultiQueries : kMultiQueries;
+            hipLaunchKernelGGL((scan_multi_kernel<MultiConfig>), dim3(h->mgrid), dim3(MultiConfig::kBlock), 0, s,
+                               h->d_feats, h->n, static_cast<int64_t>(MultiConfig::kTileRows), h->mrows_per_block, 1,
+                               h->row_base, qa[g], nq, g * kMultiQueries, topn, h->d_block_lists,
+                               static_cast<const uint64_t*>(nullptr));
+        }
+        hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(kMergeBlock), 0, s, h->d_block_lists, h->mgrid, topn,
+                           list_stride, topn, h->d_seed_keys, static_cast<int64_t*>(nullptr),
+                           static_cast<float*>(nullptr), static_cast<int64_t>(topn), 0);
+    }
+    for (int g = 0; g < groups; ++g) {
+        const int nq = count - g * kMultiQueries < kMultiQueries ? count - g * kMultiQueries : kMultiQueries;
+        const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, s);
+        hipLaunchKernelGGL((scan_multi_kernel<MultiConfig>), dim3(h->mgrid), dim3(MultiConfig::kBlock), 0, s,
+                           h->d_feats, h->n, h->mrows_per_block, h->mrows_per_block, h->miters, h->row_base,
+                           qa[g], nq, g * kMultiQueries, topn, h->d_block_lists,
+                           seeded ? h->d_seed_keys : static_cast<const uint64_t*>(nullptr));
+        timing_end(h, h->ev_scan, h->n_scan_pairs, slot, s);
+    }
+    HIP_TRY(h, hipGetLastError());
+    const int slot = timing_begin(h, h->ev_merge, h->n_merge_pairs, h->merge_launches, s);
+    hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(kMergeBlock), 0, s, h->d_block_lists, h->mgrid, topn,
+                       list_stride, topn, out_keys, out_idx, out_score, static_cast<int64_t>(topn), 0);
+    timing_end(h, h->ev_merge, h->n_merge_pairs, slot, s);
+    HIP_TRY(h, hipGetLastError());
+    return MI355REC_OK;
+}
+
 int check_topn(mi355rec* h, int topn, bool allow_rounds) {
     if (topn <= 0)
         return fail(h, MI355REC_ERR_INVALID_ARG, "topn must be positive, got %d", topn);
@@ -314,6 +393,7 @@ void mi355rec_destroy(mi355rec_t* h) {
     for (hipEvent_t e : h->ev_merge) (void)hipEventDestroy(e);
     if (h->owned_feats) (void)hipFree(h->owned_feats);
     if (h->d_block_lists) (void)hipFree(h->d_block_lists);
+    if (h->d_seed_keys) (void)hipFree(h->d_seed_keys);
     if (h->d_keys) (void)hipFree(h->d_keys);
     if (h->d_idx) (void)hipFree(h->d_idx);
     if (h->d_score) (void)hipFree(h->d_score);
@@ -394,6 +474,31 @@ int mi355rec_enqueue_query_keys(mi355rec_t* h, const float* query12, int64_t exc
     DeviceGuard guard(h->device);
     return enqueue_query(h, -1, query12, exclude_global, topn, out_keys_dev, nullptr, nullptr,
                          static_cast<hipStream_t>(stream));
+}
+
+int mi355rec_enqueue_batch_keys(mi355rec_t* h, const float* queries, const int64_t* exclude_global,
+                                int batch, int topn, mi355rec_key_t* out_keys_dev, void* stream) {
+    if (!h || !queries || !out_keys_dev) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (batch < 1) return fail(h, MI355REC_ERR_INVALID_ARG, "batch must be positive");
+    int rc = check_topn(h, topn, true);
+    if (rc) return rc;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (topn > kMultiMaxTopK) {  // one scan per query
+        for (int b = 0; b < batch; ++b) {
+            rc = enqueue_query(h, -1, queries + static_cast<size_t>(b) * kDim, exclude_global ? exclude_global[b] : -1,
+                               topn, out_keys_dev + static_cast<size_t>(b) * topn, nullptr, nullptr, s);
+            if (rc) return rc;
+        }
+        return MI355REC_OK;
+    }
+    for (int b = 0; b < batch; b += kMultiChain) {
+        const int count = batch - b < kMultiChain ? batch - b : kMultiChain;
+        rc = enqueue_multi(h, queries + static_cast<size_t>(b) * kDim, exclude_global ? exclude_global + b : nullptr,
+                           count, topn, out_keys_dev + static_cast<size_t>(b) * topn, nullptr, nullptr, s);
+        if (rc) return rc;
+    }
+    return MI355REC_OK;
 }
 
 int mi355rec_enqueue_merge_keys(mi355rec_t* h, const mi355rec_key_t* lists_dev, int n_lists,
@@ -482,12 +587,22 @@ int mi355rec_query_batch_topn(mi355rec_t* h, const float* queries, int batch,
     const size_t cnt = static_cast<size_t>(batch) * topn;
     rc = ensure_slots(h, cnt);
     if (rc) return rc;
-    for (int b = 0; b < batch; ++b) {
-        const size_t off = static_cast<size_t>(b) * topn;
-        rc = enqueue_query(h, -1, queries + static_cast<int64_t>(b) * kDim,
-                           exclude_global ? exclude_global[b] : -1, topn, h->d_keys + off,
-                           h->d_idx + off, h->d_score + off, h->stream);
-        if (rc) return rc;
+    if (batch > 1 && topn <= kMultiMaxTopK) {
+        for (int b = 0; b < batch; b += kMultiChain) {
+            const int count = batch - b < kMultiChain ? batch - b : kMultiChain;
+            const size_t off = static_cast<size_t>(b) * topn;
+            rc = enqueue_multi(h, queries + static_cast<size_t>(b) * kDim, exclude_global ? exclude_global + b : nullptr,
+                               count, topn, h->d_keys + off, h->d_idx + off, h->d_score + off, h->stream);
+            if (rc) return rc;
+        }
+    } else {
+        for (int b = 0; b < batch; ++b) {
+            const size_t off = static_cast<size_t>(b) * topn;
+            rc = enqueue_query(h, -1, queries + static_cast<int64_t>(b) * kDim,
+                               exclude_global ? exclude_global[b] : -1, topn, h->d_keys + off,
+                               h->d_idx + off, h->d_score + off, h->stream);
+            if (rc) return rc;
+        }
     }
     HIP_TRY(h, hipMemcpyAsync(h->h_idx, h->d_idx, cnt * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->h_score, h->d_score, cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream));

@@ -156,6 +156,17 @@ class CosineEngine:
             self._h, q.ctypes.data_as(ctypes.c_void_p), int(exclude_global), int(topn),
             ctypes.c_void_p(out_keys.data_ptr()), self._stream_ptr(stream)), self._h)
 
+    def enqueue_batch_keys(self, queries, exclude_global, topn: int, out_keys, stream=None) -> None:
+        """Multi-query passes: 8 queries share one scan of the shard (topn <= 128)."""
+        q = _np_f32(queries).reshape(-1, capi.DIM)
+        excl = None
+        if exclude_global is not None:
+            excl = np.ascontiguousarray(np.asarray(exclude_global, dtype=np.int64).reshape(q.shape[0]))
+        capi.check(self._lib.mi355rec_enqueue_batch_keys(
+            self._h, q.ctypes.data_as(ctypes.c_void_p),
+            excl.ctypes.data_as(ctypes.c_void_p) if excl is not None else None, q.shape[0], int(topn),
+            ctypes.c_void_p(out_keys.data_ptr()), self._stream_ptr(stream)), self._h)
+
     def enqueue_merge_keys(self, lists, n_lists: int, list_len: int, topn: int, out_keys,
                            out_idx=None, out_score=None, stream=None) -> None:
         capi.check(self._lib.mi355rec_enqueue_merge_keys(

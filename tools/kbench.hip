@@ -58,6 +58,39 @@ void run_cfg(const char* label, int blocks_per_cu) {
     report("topk, preset threshold (floor)", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false, 4>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr, (const uint64_t*)nullptr); }, g_reps));
 }
 
+template <typename Cfg>
+void run_multi(const char* label, int blocks_per_cu, int nq, const std::vector<float>& h) {
+    Timer T;
+    int64_t maxb = 256 * blocks_per_cu; if (maxb > kMergeMaxLists) maxb = kMergeMaxLists;
+    int64_t rpb = (g_n + maxb - 1) / maxb; rpb = (rpb + 63) / 64 * 64;
+    int grid = (int)((g_n + rpb - 1) / rpb); int iters = (int)((rpb + Cfg::kTileRows - 1) / Cfg::kTileRows);
+    int occ = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_multi_kernel<Cfg>, Cfg::kBlock, 0));
+    MultiQueryArg qa; memset(&qa, 0, sizeof qa);
+    for (int q = 0; q < kMultiQueries; ++q) { qa.exclude[q] = 7919 + 1000 * q; for (int j = 0; j < 12; ++j) qa.q[q][j] = h[12 * (7919 + 1000 * q) + j]; }
+    printf("-- multi %s: block %d x %d rows, minwaves %d, grid %d (%d/CU asked, occupancy API %d), queries %d\n", label, Cfg::kBlock, Cfg::kRowsPerThread, Cfg::kMinWaves, grid, blocks_per_cu, occ, nq);
+    float ms = T.run([&] { hipLaunchKernelGGL((scan_multi_kernel<Cfg>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, rpb, iters, (int64_t)0, qa, nq, 0, g_topk, d_lists, (const uint64_t*)nullptr); }, g_reps);
+    printf("  %-40s %8.3f us  %8.1f GB/s  %9.0f queries/s\n", "multi-query pass (no seed)", ms * 1e3, g_gb / (ms * 1e-3), nq / (ms * 1e-3));
+    static uint64_t* d_seed = nullptr; if (!d_seed) CK(hipMalloc(&d_seed, 8 * 8 * 1024));
+    float ms1 = T.run([&] { hipLaunchKernelGGL((scan_multi_kernel<Cfg>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, (int64_t)Cfg::kTileRows, rpb, 1, (int64_t)0, qa, nq, 0, g_topk, d_lists, (const uint64_t*)nullptr); }, g_reps);
+    report("seed pass (first tile of every workgroup)", ms1);
+    hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)grid * g_topk, g_topk, d_seed, (int64_t*)nullptr, (float*)nullptr, (int64_t)g_topk, 0);
+    CK(hipDeviceSynchronize());
+    ms = T.run([&] { hipLaunchKernelGGL((scan_multi_kernel<Cfg>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, rpb, iters, (int64_t)0, qa, nq, 0, g_topk, d_lists, (const uint64_t*)d_seed); }, g_reps);
+    printf("  %-40s %8.3f us  %8.1f GB/s  %9.0f queries/s\n", "multi-query pass (seeded)", ms * 1e3, g_gb / (ms * 1e-3), nq / (ms * 1e-3));
+    float chain = T.run([&] {
+        hipLaunchKernelGGL((scan_multi_kernel<Cfg>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, (int64_t)Cfg::kTileRows, rpb, 1, (int64_t)0, qa, nq, 0, g_topk, d_lists, (const uint64_t*)nullptr);
+        hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)grid * g_topk, g_topk, d_seed, (int64_t*)nullptr, (float*)nullptr, (int64_t)g_topk, 0);
+        hipLaunchKernelGGL((scan_multi_kernel<Cfg>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, rpb, iters, (int64_t)0, qa, nq, 0, g_topk, d_lists, (const uint64_t*)d_seed);
+        hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)grid * g_topk, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)g_topk, 0);
+    }, g_reps);
+    printf("  %-40s %8.3f us  %8.1f GB/s  %9.0f queries/s\n", "seed+merge+pass+merge chain", chain * 1e3, g_gb / (chain * 1e-3), nq / (chain * 1e-3));
+    float mm = T.run([&] { hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)grid * g_topk, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)g_topk, 0); }, g_reps);
+    report("merge (one workgroup per query)", mm);
+    std::vector<uint64_t> got(g_topk);
+    CK(hipMemcpy(got.data(), d_out, 8 * g_topk, hipMemcpyDeviceToHost));
+    if (!g_ref.empty()) printf("  query 0 result %s\n", got == g_ref ? "matches the single-query kernel" : "DIFFERS from the single-query kernel");
+}
+
 int main(int argc, char** argv) {
     g_n = argc > 1 ? atoll(argv[1]) : 10000000;
     g_reps = argc > 2 ? atoi(argv[2]) : 20;
@@ -72,7 +105,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_scores, g_n * 4));
     CK(hipMalloc(&d_sink, 1 << 20));
     CK(hipMalloc(&d_lists, 8ull * 2048 * 1024));
-    CK(hipMalloc(&d_out, 8 * 1024));
+    CK(hipMalloc(&d_out, 8 * 1024 * 16));
     for (int j = 0; j < 12; ++j) g_qa.q[j] = h[12 * 7919 + j];
     {
         Timer T;
@@ -97,8 +130,13 @@ int main(int argc, char** argv) {
     run_cfg<ScanCfg<1024, 2, 4>>("E", 1);
     run_cfg<ScanCfg<1024, 1, 6>>("J", 2);
     } else {
-    run_cfg<ScanCfg<512, 2, 4>>("B", 4);
-    run_cfg<ScanCfg<256, 2, 4>>("D", 4);
+    run_cfg<ScanCfg<512, 1, 6>>("I", 3);
+    run_multi<MultiCfg<512, 1, 4>>("M512x1", 2, 8, h);
+    run_multi<MultiCfg<512, 1, 4>>("M512x1", 2, 4, h);
+    run_multi<MultiCfg<512, 1, 4>>("M512x1", 2, 1, h);
+    run_multi<MultiCfg<256, 2, 4>>("M256x2", 3, 8, h);
+    run_multi<MultiCfg<256, 1, 4>>("M256x1", 4, 8, h);
+    run_multi<MultiCfg<1024, 1, 4>>("M1024x1", 1, 8, h);
     }
     return 0;
 }
