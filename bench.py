@@ -205,25 +205,38 @@ def main():
     # micro-batched throughput, outside the timed region:
     # 8 queries share one pass over the catalogue, seed/final merges shared by 32
     micro = None
-    if sharded is None and topn <= 128:
+    if topn <= 128:
         nb = 64
-        b_rows = q_rows[:nb]
+        b_rows = np.array(q_rows[:nb], dtype=np.int64)
         b_keys = torch.zeros(nb * topn, dtype=torch.int64, device=dev)
-        eng.enqueue_batch_keys(q_vecs[:nb], b_rows, topn, b_keys)
-        torch.cuda.synchronize()
+
+        def batch_step():
+            if sharded is None:
+                eng.enqueue_batch_keys(q_vecs[:nb], b_rows, topn, b_keys)
+            else:
+                sharded.enqueue_batch(q_vecs[:nb], b_rows, topn)
+
+        batch_step()
+        fence()
         reps = 6
         t1 = time.perf_counter()
         for _ in range(reps):
-            eng.enqueue_batch_keys(q_vecs[:nb], b_rows, topn, b_keys)
+            batch_step()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
+        fence()
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
         micro = {"queries_per_pass": 8, "queries_per_call": nb, "value": round(reps * nb / dt, 1),
                  "unit": "queries/s", "ms_per_pass": round(dt / (reps * nb / 8) * 1e3, 5),
-                 "note": "one scan of the catalogue answers 8 queries (mi355::scan_multi_kernel)"}
-        eng.enqueue_row_keys(q_rows[0], topn, out_keys)
+                 "note": "one scan of the (local) catalogue answers 8 queries (mi355::scan_multi_kernel); "
+                         + ("single GPU" if sharded is None else "one all-gather per 64-query call")}
+        step(0)
         torch.cuda.synchronize()
-        a, _ = unpack_keys(out_keys.cpu().numpy())
-        b, _ = unpack_keys(b_keys[:topn].cpu().numpy())
+        a, _ = unpack_keys((out_keys if sharded is None else sharded.out_keys[:topn]).cpu().numpy())
+        b, _ = unpack_keys((b_keys[:topn] if sharded is None else sharded.batch_keys[0]).cpu().numpy())
         micro["matches_single_query_path"] = bool(a.tolist() == b.tolist())
 
     # achievable-HBM ceiling probe on the same buffer (plain read-only stream)

@@ -161,6 +161,16 @@ int mi355rec_enqueue_merge_keys(mi355rec_t* h, const mi355rec_key_t* lists_dev,
                                 int64_t* out_idx_dev, float* out_score_dev,
                                 void* stream);
 
+/* Batched merge: query b's list l starts at lists_dev + b*query_stride +
+ * l*list_stride (in keys).  [rank][query][key] data straight out of an
+ * all-gather of per-rank batch results is list_stride = batch*topn,
+ * query_stride = topn.  Outputs are batch x topn. */
+int mi355rec_enqueue_merge_keys_batch(mi355rec_t* h, const mi355rec_key_t* lists_dev,
+                                      int n_lists, int list_len, int64_t list_stride,
+                                      int64_t query_stride, int batch, int topn,
+                                      mi355rec_key_t* out_keys_dev, int64_t* out_idx_dev,
+                                      float* out_score_dev, void* stream);
+
 /* Full score vector into device memory (local_row >= 0: query = that row and
  * query12 is ignored; local_row < 0: query12 is used). */
 int mi355rec_enqueue_scores(mi355rec_t* h, int64_t local_row,

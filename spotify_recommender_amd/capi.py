@@ -55,6 +55,8 @@ SIGNATURES = {
     "mi355rec_enqueue_query_keys": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "mi355rec_enqueue_batch_keys": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mi355rec_enqueue_merge_keys": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mi355rec_enqueue_merge_keys_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int, c_int,
+                                                  c_void_p, c_void_p, c_void_p, c_void_p]),
     "mi355rec_enqueue_scores": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "mi355rec_enqueue_stream_probe": (c_int, [c_void_p, c_void_p, c_void_p]),
     "mi355rec_set_timing": (c_int, [c_void_p, c_int]),

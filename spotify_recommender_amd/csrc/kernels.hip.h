@@ -767,8 +767,10 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
 // ---- merge of sorted candidate lists -----------------------------------------
 // n_lists lists of list_len keys (each sorted descending, 0-padded) -> the best
 // topk keys, sorted descending, 0-padded; optional unpack to (row, score).
-// One workgroup per query (blockIdx.x = query in a batch; list / output bases
-// advance by the per-query strides).
+// One workgroup per query (blockIdx.x = query in a batch): list l of query b starts
+// at lists_base + b*lists_query_stride + l*list_stride, so both layouts work:
+// [query][list][key] (per-workgroup lists of a scan) and [list][query][key]
+// (per-rank results of a batch after the all-gather).
 //
 // A key can only be in the global top-k if it is >= T whenever m lists each
 // hold >= j keys that are >= T with m*j >= topk.  With plenty of lists j = 1:
@@ -780,8 +782,8 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
 // finds the topk-th key instead.
 
 __device__ inline uint64_t merge_global_radix_select(const uint64_t* __restrict__ lists,
-                                                     int64_t total, int topk, int* s_hist,
-                                                     int* s_pair) {
+                                                     int64_t total, int list_len, int64_t list_stride,
+                                                     int topk, int* s_hist, int* s_pair) {
     // returns the topk-th largest key (0 if fewer than topk non-zero keys)
     uint64_t prefix = 0, mask = 0;
     int remaining = topk;
@@ -790,7 +792,7 @@ __device__ inline uint64_t merge_global_radix_select(const uint64_t* __restrict_
         __syncthreads();
         const int shift = pass * 8;
         for (int64_t i = threadIdx.x; i < total; i += kMergeBlock) {
-            const uint64_t k = lists[i];
+            const uint64_t k = lists[(i / list_len) * list_stride + (i % list_len)];
             if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255], 1);
         }
         __syncthreads();
@@ -813,7 +815,7 @@ __device__ inline uint64_t merge_global_radix_select(const uint64_t* __restrict_
 }
 
 __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
-    const uint64_t* __restrict__ lists_base, int n_lists, int list_len,
+    const uint64_t* __restrict__ lists_base, int n_lists, int list_len, int64_t list_stride,
     int64_t lists_query_stride, int topk, uint64_t* __restrict__ out_keys_base,
     int64_t* __restrict__ out_idx_base, float* __restrict__ out_score_base,
     int64_t out_query_stride, int dbg_stop = 0) {
@@ -857,7 +859,7 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
 #pragma unroll
         for (int u = 0; u < kMergeFirstPerThread; ++u) {
             const int l = (u * kMergeBlock + tid) / kMergeFirst;
-            k[u] = (l < n_lists && j < list_len) ? lists[static_cast<int64_t>(l) * list_len + j] : 0ull;
+            k[u] = (l < n_lists && j < list_len) ? lists[static_cast<int64_t>(l) * list_stride + j] : 0ull;
         }
 #pragma unroll
         for (int u = 0; u < kMergeFirstPerThread; ++u) {
@@ -889,7 +891,7 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
 #pragma unroll
         for (int r = 0; r < kMergeHeadsPerThread; ++r) {
             const int l = tid + r * kMergeBlock;
-            heads[r] = l < n_lists ? lists[static_cast<int64_t>(l) * list_len + (probe - 1)] : 0ull;
+            heads[r] = l < n_lists ? lists[static_cast<int64_t>(l) * list_stride + (probe - 1)] : 0ull;
             local_nonzero += heads[r] != 0ull;
             if (l < n_lists) s_active[l] = 0;
         }
@@ -922,7 +924,7 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
                 const int l = t / kMergeChunk;
                 const int pos = first + round * kMergeChunk + (t % kMergeChunk);
                 const bool live = t < total && pos < list_len && s_active[l] == round;
-                k[u] = live ? lists[static_cast<int64_t>(l) * list_len + pos] : 0ull;
+                k[u] = live ? lists[static_cast<int64_t>(l) * list_stride + pos] : 0ull;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -938,7 +940,7 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
         for (int l = tid; l < n_lists; l += kMergeBlock) {
             if (s_active[l] == round) {
                 const int last = first + (round + 1) * kMergeChunk - 1;
-                if (last < list_len && lists[static_cast<int64_t>(l) * list_len + last] >= thr)
+                if (last < list_len && lists[static_cast<int64_t>(l) * list_stride + last] >= thr)
                     s_active[l] = static_cast<unsigned short>(round + 1);
             }
         }
@@ -950,13 +952,13 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
     if (s_overflow) {
         // exact fallback: radix-select the topk-th key over everything
         const int64_t total = static_cast<int64_t>(n_lists) * list_len;
-        uint64_t kth = merge_global_radix_select(lists, total, topk, s_sel.hist, s_pair);
+        uint64_t kth = merge_global_radix_select(lists, total, list_len, list_stride, topk, s_sel.hist, s_pair);
         if (kth == 0) kth = 1;
         if (tid == 0) s_count = 0;
         __syncthreads();
         for (int64_t i0 = 0; i0 < total; i0 += kMergeBlock) {
             const int64_t i = i0 + tid;
-            const uint64_t k = (i < total) ? lists[i] : 0ull;
+            const uint64_t k = (i < total) ? lists[(i / list_len) * list_stride + (i % list_len)] : 0ull;
             if (k >= kth) {
                 const int pos = atomicAdd(&s_count, 1);  // exactly topk keys when unique
                 if (pos < kMergeSurvCap) s_surv[pos] = k;

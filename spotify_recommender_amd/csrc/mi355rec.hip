@@ -279,7 +279,7 @@ int enqueue_merge(mi355rec* h, const uint64_t* lists, int n_lists, int list_len,
                   uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s) {
     const int slot = timing_begin(h, h->ev_merge, h->n_merge_pairs, h->merge_launches, s);
     hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(kMergeBlock), 0, s, lists, n_lists, list_len,
-                       static_cast<int64_t>(0), topn, out_keys, out_idx, out_score,
+                       static_cast<int64_t>(list_len), static_cast<int64_t>(0), topn, out_keys, out_idx, out_score,
                        static_cast<int64_t>(0));
     timing_end(h, h->ev_merge, h->n_merge_pairs, slot, s);
     HIP_TRY(h, hipGetLastError());
@@ -317,7 +317,7 @@ int enqueue_multi(mi355rec* h, const float* queries, const int64_t* exclude, int
                                static_cast<const uint64_t*>(nullptr));
         }
         hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(kMergeBlock), 0, s, h->d_block_lists, h->mgrid, topn,
-                           list_stride, topn, h->d_seed_keys, static_cast<int64_t*>(nullptr),
+                           static_cast<int64_t>(topn), list_stride, topn, h->d_seed_keys, static_cast<int64_t*>(nullptr),
                            static_cast<float*>(nullptr), static_cast<int64_t>(topn), 0);
     }
     for (int g = 0; g < groups; ++g) {
@@ -332,7 +332,7 @@ int enqueue_multi(mi355rec* h, const float* queries, const int64_t* exclude, int
     HIP_TRY(h, hipGetLastError());
     const int slot = timing_begin(h, h->ev_merge, h->n_merge_pairs, h->merge_launches, s);
     hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(kMergeBlock), 0, s, h->d_block_lists, h->mgrid, topn,
-                       list_stride, topn, out_keys, out_idx, out_score, static_cast<int64_t>(topn), 0);
+                       static_cast<int64_t>(topn), list_stride, topn, out_keys, out_idx, out_score, static_cast<int64_t>(topn), 0);
     timing_end(h, h->ev_merge, h->n_merge_pairs, slot, s);
     HIP_TRY(h, hipGetLastError());
     return MI355REC_OK;
@@ -512,6 +512,26 @@ int mi355rec_enqueue_merge_keys(mi355rec_t* h, const mi355rec_key_t* lists_dev, 
     DeviceGuard guard(h->device);
     return enqueue_merge(h, lists_dev, n_lists, list_len, topn, out_keys_dev, out_idx_dev,
                          out_score_dev, static_cast<hipStream_t>(stream));
+}
+
+int mi355rec_enqueue_merge_keys_batch(mi355rec_t* h, const mi355rec_key_t* lists_dev, int n_lists,
+                                      int list_len, int64_t list_stride, int64_t query_stride, int batch,
+                                      int topn, mi355rec_key_t* out_keys_dev, int64_t* out_idx_dev,
+                                      float* out_score_dev, void* stream) {
+    if (!h || !lists_dev || !out_keys_dev) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (n_lists < 1 || n_lists > kMergeMaxLists || list_len < 1 || batch < 1 || list_stride < list_len)
+        return fail(h, MI355REC_ERR_INVALID_ARG, "merge geometry out of range");
+    int rc = check_topn(h, topn, false);
+    if (rc) return rc;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int slot = timing_begin(h, h->ev_merge, h->n_merge_pairs, h->merge_launches, s);
+    hipLaunchKernelGGL(merge_kernel, dim3(batch), dim3(kMergeBlock), 0, s, lists_dev, n_lists, list_len,
+                       list_stride, query_stride, topn, out_keys_dev, out_idx_dev, out_score_dev,
+                       static_cast<int64_t>(topn), 0);
+    timing_end(h, h->ev_merge, h->n_merge_pairs, slot, s);
+    HIP_TRY(h, hipGetLastError());
+    return MI355REC_OK;
 }
 
 int mi355rec_enqueue_scores(mi355rec_t* h, int64_t local_row, const float* query12,

@@ -176,6 +176,15 @@ class CosineEngine:
             ctypes.c_void_p(out_score.data_ptr()) if out_score is not None else None,
             self._stream_ptr(stream)), self._h)
 
+    def enqueue_merge_keys_batch(self, lists, n_lists: int, list_len: int, list_stride: int, query_stride: int,
+                                 batch: int, topn: int, out_keys, out_idx=None, out_score=None, stream=None) -> None:
+        capi.check(self._lib.mi355rec_enqueue_merge_keys_batch(
+            self._h, ctypes.c_void_p(lists.data_ptr()), int(n_lists), int(list_len), int(list_stride),
+            int(query_stride), int(batch), int(topn), ctypes.c_void_p(out_keys.data_ptr()),
+            ctypes.c_void_p(out_idx.data_ptr()) if out_idx is not None else None,
+            ctypes.c_void_p(out_score.data_ptr()) if out_score is not None else None,
+            self._stream_ptr(stream)), self._h)
+
     def enqueue_scores(self, local_row: int, query, out_scores, stream=None) -> None:
         q = None if query is None else _np_f32(query).reshape(capi.DIM)
         capi.check(self._lib.mi355rec_enqueue_scores(
@@ -262,6 +271,35 @@ class ShardedEngine:
             self._dist.all_gather_into_tensor(gathered, local, group=self.group)
         self.local.enqueue_merge_keys(gathered, self.world, k, k, self.out_keys[:k],
                                       self.out_idx[:k], self.out_score[:k])
+
+    def enqueue_batch(self, queries, exclude_global, topn: int):
+        """`batch` queries: local multi-query passes, ONE all-gather of batch*topn
+        keys per rank, one merge launch (a workgroup per query).  Results in
+        self.batch_keys / batch_idx / batch_score ([batch, topn])."""
+        torch = self._torch
+        q = np.ascontiguousarray(np.asarray(queries, dtype=np.float32).reshape(-1, 12))
+        b, k = q.shape[0], int(topn)
+        need = b * k
+        if getattr(self, "_batch_cap", 0) < need:
+            dev = self.device
+            self._b_local = torch.zeros(need, dtype=torch.int64, device=dev)
+            self._b_gather = torch.zeros(self.world * need, dtype=torch.int64, device=dev)
+            self._b_keys = torch.zeros(need, dtype=torch.int64, device=dev)
+            self._b_idx = torch.full((need,), -1, dtype=torch.int64, device=dev)
+            self._b_score = torch.zeros(need, dtype=torch.float32, device=dev)
+            self._batch_cap = need
+        local = self._b_local[:need]
+        self.local.enqueue_batch_keys(q, exclude_global, k, local)
+        if self.world == 1 and not self.always_gather:
+            gathered = local
+        else:
+            gathered = self._b_gather[: self.world * need]
+            self._dist.all_gather_into_tensor(gathered, local, group=self.group)
+        self.local.enqueue_merge_keys_batch(gathered, self.world, k, need, k, b, k, self._b_keys[:need],
+                                            self._b_idx[:need], self._b_score[:need])
+        self.batch_keys = self._b_keys[:need].view(b, k)
+        self.batch_idx = self._b_idx[:need].view(b, k)
+        self.batch_score = self._b_score[:need].view(b, k)
 
     def query(self, query, exclude_global: int, topn: int):
         """Synchronous convenience wrapper: (rows, scores) as numpy arrays."""

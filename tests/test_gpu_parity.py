@@ -341,6 +341,37 @@ def test_two_shard_merge_equals_single(Engine, torch_cuda):
                 sh.close()
 
 
+def test_sharded_batch_merge_layout(Engine, torch_cuda):
+    """Batch of queries over 3 shards: per-shard multi-query passes, the
+    [rank][query][key] layout an all-gather produces, one batched merge launch ==
+    the whole-catalogue engine, query by query."""
+    torch = torch_cuda
+    rng = np.random.default_rng(4242)
+    f = rng.random((250_003, 12), dtype=np.float32)
+    t = torch.from_numpy(f).cuda()
+    from spotify_recommender_amd.engine import shard_bounds
+    parts, batch, topn = 3, 11, 50
+    qrows = rng.integers(0, f.shape[0], size=batch)
+    with Engine(t) as whole:
+        shards = [Engine(t[lo:hi], row_base=lo) for lo, hi in
+                  (shard_bounds(f.shape[0], parts, r) for r in range(parts))]
+        gathered = torch.zeros(parts * batch * topn, dtype=torch.int64, device="cuda")
+        for r, sh in enumerate(shards):
+            sh.enqueue_batch_keys(f[qrows], qrows, topn, gathered[r * batch * topn:(r + 1) * batch * topn])
+        out_keys = torch.zeros(batch * topn, dtype=torch.int64, device="cuda")
+        out_idx = torch.zeros(batch * topn, dtype=torch.int64, device="cuda")
+        out_score = torch.zeros(batch * topn, dtype=torch.float32, device="cuda")
+        shards[0].enqueue_merge_keys_batch(gathered, parts, topn, batch * topn, topn, batch, topn,
+                                           out_keys, out_idx, out_score)
+        torch.cuda.synchronize()
+        got = out_idx.cpu().numpy().reshape(batch, topn)
+        for b, q in enumerate(qrows):
+            ref_idx, ref_sc = whole.query_row_topn(int(q), topn)
+            assert got[b].tolist() == ref_idx.tolist()
+        for sh in shards:
+            sh.close()
+
+
 # ---- full BASELINE sizes ------------------------------------------------------
 
 def test_reference_recorded_top3_at_1m_and_10m(Engine, golden_dir):

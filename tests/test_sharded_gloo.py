@@ -43,6 +43,22 @@ class OracleShard:
         out[: len(keys)] = keys
         out_keys.copy_(torch.from_numpy(out.view(np.int64)))
 
+    def enqueue_batch_keys(self, queries, exclude_global, topn, out_keys, stream=None):
+        q = np.asarray(queries, np.float32).reshape(-1, 12)
+        for b in range(q.shape[0]):
+            self.enqueue_query_keys(q[b], int(exclude_global[b]), topn, out_keys[b * topn:(b + 1) * topn])
+
+    def enqueue_merge_keys_batch(self, lists, n_lists, list_len, list_stride, query_stride, batch, topn,
+                                 out_keys, out_idx=None, out_score=None, stream=None):
+        flat = lists.numpy().view(np.uint64)
+        for b in range(batch):
+            rows = np.concatenate([flat[b * query_stride + l * list_stride: b * query_stride + l * list_stride + list_len]
+                                   for l in range(n_lists)])
+            view = torch.from_numpy(rows.view(np.int64).copy())
+            self.enqueue_merge_keys(view, n_lists, list_len, topn, out_keys[b * topn:(b + 1) * topn],
+                                    None if out_idx is None else out_idx[b * topn:(b + 1) * topn],
+                                    None if out_score is None else out_score[b * topn:(b + 1) * topn])
+
     def enqueue_merge_keys(self, lists, n_lists, list_len, topn, out_keys, out_idx=None,
                            out_score=None, stream=None):
         k = np.sort(lists.numpy().view(np.uint64)[: n_lists * list_len])[::-1][:topn].copy()
@@ -80,6 +96,14 @@ def _worker(rank, world, port, n_rows, result_dir):
                 ci, cs = oracle.topn_canonical(want, q, topn)
                 assert idx.tolist() == ci.tolist(), (rank, q, topn)
                 assert np.array_equal(sc, cs + np.float32(0))
+        # batched path: one all-gather for the whole batch
+        qrows = [3, n_rows // 2, n_rows - 1, 17, 4242]
+        eng.enqueue_batch(f[qrows], np.array(qrows), 10)
+        for b, q in enumerate(qrows):
+            want = oracle.scores(f, f[q])
+            ci, _ = oracle.topn_canonical(want, q, 10)
+            assert eng.batch_idx[b].numpy().tolist() == ci.tolist(), (rank, q)
+            out[f"batch_{q}"] = eng.batch_idx[b].numpy()
         np.savez(Path(result_dir) / f"rank{rank}.npz", **out)
     finally:
         dist.destroy_process_group()

@@ -46,10 +46,10 @@ void run_cfg(const char* label, int blocks_per_cu) {
     printf("-- %s: block %d x %d rows, minwaves %d, grid %d (%d/CU asked, occupancy API %d), rows/block %lld, iters %d\n", label, Cfg::kBlock, Cfg::kRowsPerThread, Cfg::kMinWaves, grid, blocks_per_cu, occ, (long long)rpb, iters);
     report("scores-only", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, true>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)-1, 1, (uint64_t*)nullptr, d_scores, (const uint64_t*)nullptr); }, g_reps));
     report("topk", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr, (const uint64_t*)nullptr); }, g_reps));
-    float mm = T.run([&] { hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)0, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)0); }, g_reps);
+    float mm = T.run([&] { hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)g_topk, (int64_t)0, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)0); }, g_reps);
     report("merge", mm);
     if (g_stages) for (int stop = 1; stop <= 5; ++stop) { char nm[64]; snprintf(nm, sizeof nm, "  merge stopped at stage %d", stop);
-        report(nm, T.run([&] { hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)0, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)0, stop); }, g_reps)); }
+        report(nm, T.run([&] { hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)g_topk, (int64_t)0, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)0, stop); }, g_reps)); }
     report("  empty-ish kernel (probe, 64 vec)", T.run([&] { hipLaunchKernelGGL(stream_probe_kernel, dim3(1), dim3(kProbeBlock), 0, 0, (const float4*)d_feats, (int64_t)64, d_sink); }, g_reps));
     std::vector<uint64_t> got(g_topk);
     CK(hipMemcpy(got.data(), d_out, 8 * g_topk, hipMemcpyDeviceToHost));
@@ -73,18 +73,18 @@ void run_multi(const char* label, int blocks_per_cu, int nq, const std::vector<f
     static uint64_t* d_seed = nullptr; if (!d_seed) CK(hipMalloc(&d_seed, 8 * 8 * 1024));
     float ms1 = T.run([&] { hipLaunchKernelGGL((scan_multi_kernel<Cfg>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, (int64_t)Cfg::kTileRows, rpb, 1, (int64_t)0, qa, nq, 0, g_topk, d_lists, (const uint64_t*)nullptr); }, g_reps);
     report("seed pass (first tile of every workgroup)", ms1);
-    hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)grid * g_topk, g_topk, d_seed, (int64_t*)nullptr, (float*)nullptr, (int64_t)g_topk, 0);
+    hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)g_topk, (int64_t)grid * g_topk, g_topk, d_seed, (int64_t*)nullptr, (float*)nullptr, (int64_t)g_topk, 0);
     CK(hipDeviceSynchronize());
     ms = T.run([&] { hipLaunchKernelGGL((scan_multi_kernel<Cfg>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, rpb, iters, (int64_t)0, qa, nq, 0, g_topk, d_lists, (const uint64_t*)d_seed); }, g_reps);
     printf("  %-40s %8.3f us  %8.1f GB/s  %9.0f queries/s\n", "multi-query pass (seeded)", ms * 1e3, g_gb / (ms * 1e-3), nq / (ms * 1e-3));
     float chain = T.run([&] {
         hipLaunchKernelGGL((scan_multi_kernel<Cfg>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, (int64_t)Cfg::kTileRows, rpb, 1, (int64_t)0, qa, nq, 0, g_topk, d_lists, (const uint64_t*)nullptr);
-        hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)grid * g_topk, g_topk, d_seed, (int64_t*)nullptr, (float*)nullptr, (int64_t)g_topk, 0);
+        hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)g_topk, (int64_t)grid * g_topk, g_topk, d_seed, (int64_t*)nullptr, (float*)nullptr, (int64_t)g_topk, 0);
         hipLaunchKernelGGL((scan_multi_kernel<Cfg>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, rpb, iters, (int64_t)0, qa, nq, 0, g_topk, d_lists, (const uint64_t*)d_seed);
-        hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)grid * g_topk, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)g_topk, 0);
+        hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)g_topk, (int64_t)grid * g_topk, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)g_topk, 0);
     }, g_reps);
     printf("  %-40s %8.3f us  %8.1f GB/s  %9.0f queries/s\n", "seed+merge+pass+merge chain", chain * 1e3, g_gb / (chain * 1e-3), nq / (chain * 1e-3));
-    float mm = T.run([&] { hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)grid * g_topk, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)g_topk, 0); }, g_reps);
+    float mm = T.run([&] { hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)g_topk, (int64_t)grid * g_topk, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)g_topk, 0); }, g_reps);
     report("merge (one workgroup per query)", mm);
     std::vector<uint64_t> got(g_topk);
     CK(hipMemcpy(got.data(), d_out, 8 * g_topk, hipMemcpyDeviceToHost));
