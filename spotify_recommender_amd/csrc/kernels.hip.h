@@ -320,9 +320,9 @@ __device__ inline uint64_t compact_candidates(uint64_t* s_cand, int* s_count, in
 }
 
 // ---- streaming scan ----------------------------------------------------------
-// Workgroup b owns the contiguous rows [b*rows_per_block, (b+1)*rows_per_block)
-// (rows_per_block is a multiple of 64, so every wave-level load instruction
-// covers one contiguous 3 KiB span).  One lane = one row: the 12-term sums are
+// Tiles of kTileRows rows are dealt round-robin over the workgroups (or, with
+// rows_per_block > 0, workgroup b owns a contiguous 64-row-aligned block); every
+// wave-level load instruction covers one contiguous 3 KiB span.  One lane = one row: the 12-term sums are
 // sequential in-lane, which is what makes the result bit-identical to the
 // reference CPU loop.  The next tile is loaded before the current one is
 // scored so ~200 KiB per CU stay in flight.
@@ -364,8 +364,13 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int64_t blk_begin = static_cast<int64_t>(blockIdx.x) * rows_per_block;
-    int64_t blk_end = blk_begin + rows_per_block;
+    // rows_per_block > 0: workgroup b owns the contiguous rows [b*rpb, (b+1)*rpb).
+    // rows_per_block == 0: tiles are dealt round-robin (tile t -> workgroup t % grid),
+    // so at any moment the whole chip reads one moving ~20 MB window of the matrix.
+    const bool interleaved = rows_per_block == 0;
+    const int64_t blk_begin = static_cast<int64_t>(blockIdx.x) * (interleaved ? kTileRows : rows_per_block);
+    const int64_t tile_stride = interleaved ? static_cast<int64_t>(gridDim.x) * kTileRows : kTileRows;
+    int64_t blk_end = interleaved ? n : blk_begin + rows_per_block;
     if (blk_end > n) blk_end = n;
     // rows past the block's end re-read its last row (one cached line) so the
     // prefetch can be unconditional: a conditional load would make the compiler
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
     if (compact_at > kCandLimit) compact_at = kCandLimit;
 
     auto load_tile = [&](Row (&dst)[kRowsPerThread], int it) {
-        const int64_t tile_begin = blk_begin + static_cast<int64_t>(it) * kTileRows;
+        const int64_t tile_begin = blk_begin + static_cast<int64_t>(it) * tile_stride;
 #pragma unroll
         for (int u = 0; u < kRowsPerThread; ++u) {
             const int64_t r = tile_begin + u * kBlock + tid;
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
     };
 
     auto process_tile = [&](const Row (&rows)[kRowsPerThread], int it) {
-        const int64_t tile_begin = blk_begin + static_cast<int64_t>(it) * kTileRows;
+        const int64_t tile_begin = blk_begin + static_cast<int64_t>(it) * tile_stride;
 #pragma unroll
         for (int u = 0; u < kRowsPerThread; ++u) {
             const int64_t r = tile_begin + u * kBlock + tid;

@@ -55,6 +55,16 @@ void run_cfg(const char* label, int blocks_per_cu) {
     CK(hipMemcpy(got.data(), d_out, 8 * g_topk, hipMemcpyDeviceToHost));
     if (g_ref.empty()) g_ref = got;
     printf("  result %s\n", got == g_ref ? "matches first config" : "DIFFERS from first config");
+    {
+        int64_t tiles = (g_n + Cfg::kTileRows - 1) / Cfg::kTileRows;
+        int ig = (int)std::min<int64_t>(256 * blocks_per_cu, tiles); int it2 = (int)((tiles + ig - 1) / ig);
+        report("topk, interleaved tiles", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false>), dim3(ig), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, (int64_t)0, it2, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr, (const uint64_t*)nullptr); }, g_reps));
+        hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(kMergeBlock), 0, 0, d_lists, ig, g_topk, (int64_t)g_topk, (int64_t)0, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)0, 0);
+        std::vector<uint64_t> got2(g_topk); CK(hipMemcpy(got2.data(), d_out, 8 * g_topk, hipMemcpyDeviceToHost));
+        printf("  interleaved result %s\n", got2 == g_ref ? "matches" : "DIFFERS");
+        report("topk contiguous (again)", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr, (const uint64_t*)nullptr); }, g_reps));
+        report("topk, interleaved tiles (again)", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false>), dim3(ig), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, (int64_t)0, it2, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr, (const uint64_t*)nullptr); }, g_reps));
+    }
     report("topk, preset threshold (floor)", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false, 4>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr, (const uint64_t*)nullptr); }, g_reps));
 }
 
@@ -131,12 +141,17 @@ int main(int argc, char** argv) {
     run_cfg<ScanCfg<1024, 1, 6>>("J", 2);
     } else {
     run_cfg<ScanCfg<512, 1, 6>>("I", 3);
+    run_cfg<ScanCfg<512, 1, 6>>("I", 2);
+    run_cfg<ScanCfg<256, 1, 6>>("K", 6);
+    run_cfg<ScanCfg<512, 2, 4>>("B", 2);
+    if (argc > 5) {
     run_multi<MultiCfg<512, 1, 4>>("M512x1", 2, 8, h);
     run_multi<MultiCfg<512, 1, 4>>("M512x1", 2, 4, h);
     run_multi<MultiCfg<512, 1, 4>>("M512x1", 2, 1, h);
     run_multi<MultiCfg<256, 2, 4>>("M256x2", 3, 8, h);
     run_multi<MultiCfg<256, 1, 4>>("M256x1", 4, 8, h);
     run_multi<MultiCfg<1024, 1, 4>>("M1024x1", 1, 8, h);
+    }
     }
     return 0;
 }
