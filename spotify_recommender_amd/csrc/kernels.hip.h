@@ -639,8 +639,11 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
     const int wave = tid >> 6;
     // block_stride == rows_per_block: the workgroups tile the shard.  A larger
     // stride makes each workgroup scan only the head of its region (seed pass).
-    const int64_t blk_begin = static_cast<int64_t>(blockIdx.x) * block_stride;
-    int64_t blk_end = blk_begin + rows_per_block;
+    // rows_per_block == 0: tiles dealt round-robin over the workgroups (full pass).
+    const bool interleaved = rows_per_block == 0;
+    const int64_t blk_begin = static_cast<int64_t>(blockIdx.x) * (interleaved ? kTileRows : block_stride);
+    const int64_t tile_stride = interleaved ? static_cast<int64_t>(gridDim.x) * kTileRows : kTileRows;
+    int64_t blk_end = interleaved ? n : blk_begin + rows_per_block;
     if (blk_end > n) blk_end = n;
     const int64_t last_row = blk_end - 1;
 
@@ -671,7 +674,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
     __syncthreads();
 
     auto load_tile = [&](Row (&dst)[kRowsPerThread], int it) {
-        const int64_t tile_begin = blk_begin + static_cast<int64_t>(it) * kTileRows;
+        const int64_t tile_begin = blk_begin + static_cast<int64_t>(it) * tile_stride;
 #pragma unroll
         for (int u = 0; u < kRowsPerThread; ++u) {
             const int64_t r = tile_begin + u * kBlock + tid;
@@ -680,7 +683,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
     };
 
     auto process_tile = [&](const Row (&rows)[kRowsPerThread], int it) {
-        const int64_t tile_begin = blk_begin + static_cast<int64_t>(it) * kTileRows;
+        const int64_t tile_begin = blk_begin + static_cast<int64_t>(it) * tile_stride;
         // shared by all queries: approximate 1/|row| of this lane's rows
         float inv_norm[kRowsPerThread];
 #pragma unroll

@@ -121,15 +121,19 @@ void plan_grid(mi355rec* h, int blocks_per_cu) {
     h->iters = static_cast<int>((tiles + h->grid - 1) / h->grid);
 }
 
+// Multi-query pass: same round-robin tile mapping for the full pass; the seed
+// pass scans the first tile of `mgrid` evenly spaced regions (mseed_stride rows
+// apart) so that the sample also represents catalogues that are ordered.
 void plan_multi_grid(mi355rec* h, int blocks_per_cu) {
     int64_t max_blocks = static_cast<int64_t>(h->cus) * blocks_per_cu;
     if (max_blocks > kMergeMaxLists) max_blocks = kMergeMaxLists;
-    int64_t rpb = (h->n + max_blocks - 1) / max_blocks;
-    rpb = (rpb + 63) / 64 * 64;
-    if (rpb < 64) rpb = 64;
-    h->mrows_per_block = rpb;
-    h->mgrid = static_cast<int>((h->n + rpb - 1) / rpb);
-    h->miters = static_cast<int>((rpb + MultiConfig::kTileRows - 1) / MultiConfig::kTileRows);
+    const int64_t tiles = (h->n + MultiConfig::kTileRows - 1) / MultiConfig::kTileRows;
+    h->mgrid = static_cast<int>(tiles < max_blocks ? tiles : max_blocks);
+    h->miters = static_cast<int>((tiles + h->mgrid - 1) / h->mgrid);
+    int64_t stride = h->n / h->mgrid;
+    stride = stride / 64 * 64;
+    if (stride < MultiConfig::kTileRows) stride = MultiConfig::kTileRows;
+    h->mrows_per_block = stride;  // seed pass only: distance between sampled regions
 }
 
 int create_common(const float* feats, bool on_device, int64_t n, int dim, int device,
@@ -326,7 +330,7 @@ int enqueue_multi(mi355rec* h, const float* queries, const int64_t* exclude, int
         const int nq = count - g * kMultiQueries < kMultiQueries ? count - g * kMultiQueries : kMultiQueries;
         const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, s);
         hipLaunchKernelGGL((scan_multi_kernel<MultiConfig>), dim3(h->mgrid), dim3(MultiConfig::kBlock), 0, s,
-                           h->d_feats, h->n, h->mrows_per_block, h->mrows_per_block, h->miters, h->row_base,
+                           h->d_feats, h->n, static_cast<int64_t>(0), static_cast<int64_t>(0), h->miters, h->row_base,
                            qa[g], nq, g * kMultiQueries, topn, h->d_block_lists,
                            seeded ? h->d_seed_keys : static_cast<const uint64_t*>(nullptr));
         timing_end(h, h->ev_scan, h->n_scan_pairs, slot, s);
