@@ -826,7 +826,7 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
     const uint64_t* __restrict__ lists_base, int n_lists, int list_len, int64_t list_stride,
     int64_t lists_query_stride, int topk, uint64_t* __restrict__ out_keys_base,
     int64_t* __restrict__ out_idx_base, float* __restrict__ out_score_base,
-    int64_t out_query_stride, int dbg_stop = 0) {
+    int64_t out_query_stride) {
     __shared__ uint64_t s_surv[kMergeSurvCap];
     __shared__ uint64_t s_top[kMaxTopK];
     __shared__ SelectSmem s_sel;
@@ -877,11 +877,9 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
         for (int l = tid; l < n_lists; l += kMergeBlock) s_active[l] = 0xffff;
         if (local_nonzero) atomicAdd(&s_pair[0], local_nonzero);
         __syncthreads();
-        if (dbg_stop == 1) { if (k[0] == 12345ull) out_keys[0] = k[1] + k[2] + k[3] + k[4] + k[5] + k[6] + k[7]; return; }
         if (s_pair[0] >= need_lists)  // uniform
             thr = block_select_threshold<kMergeBlock, kMergeFirstPerThread>(hk, need_lists, false, slack, s_sel);
         __syncthreads();
-        if (dbg_stop == 2) { if (thr == 12345ull) out_keys[0] = k[1] + k[2] + k[3] + k[4] + k[5] + k[6] + k[7]; return; }
 #pragma unroll
         for (int u = 0; u < kMergeFirstPerThread; ++u) {
             if (k[u] >= thr) {
@@ -955,8 +953,6 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
         __syncthreads();
     }
     __syncthreads();
-
-    if (dbg_stop == 3) { if (tid == 0) out_keys[0] = s_count; return; }
     if (s_overflow) {
         // exact fallback: radix-select the topk-th key over everything
         const int64_t total = static_cast<int64_t>(n_lists) * list_len;
@@ -997,10 +993,8 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
         __syncthreads();
         c = s_count < kMergeSurvCap ? s_count : kMergeSurvCap;
     }
-    if (dbg_stop == 4) { if (tid == 0) out_keys[0] = s_count; return; }
     block_rank_and_store<kMergeBlock>(s_surv, c, s_top, topk);
     __syncthreads();
-    if (dbg_stop == 5) { if (tid == 0) out_keys[0] = s_top[0]; return; }
     for (int i = tid; i < topk; i += kMergeBlock) {
         const uint64_t k = s_top[i];
         out_keys[i] = k;

@@ -324,7 +324,7 @@ int enqueue_multi(mi355rec* h, const float* queries, const int64_t* exclude, int
         }
         hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(kMergeBlock), 0, s, h->d_block_lists, h->mgrid, topn,
                            static_cast<int64_t>(topn), list_stride, topn, h->d_seed_keys, static_cast<int64_t*>(nullptr),
-                           static_cast<float*>(nullptr), static_cast<int64_t>(topn), 0);
+                           static_cast<float*>(nullptr), static_cast<int64_t>(topn));
     }
     for (int g = 0; g < groups; ++g) {
         const int nq = count - g * kMultiQueries < kMultiQueries ? count - g * kMultiQueries : kMultiQueries;
@@ -338,7 +338,7 @@ int enqueue_multi(mi355rec* h, const float* queries, const int64_t* exclude, int
     HIP_TRY(h, hipGetLastError());
     const int slot = timing_begin(h, h->ev_merge, h->n_merge_pairs, h->merge_launches, s);
     hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(kMergeBlock), 0, s, h->d_block_lists, h->mgrid, topn,
-                       static_cast<int64_t>(topn), list_stride, topn, out_keys, out_idx, out_score, static_cast<int64_t>(topn), 0);
+                       static_cast<int64_t>(topn), list_stride, topn, out_keys, out_idx, out_score, static_cast<int64_t>(topn));
     timing_end(h, h->ev_merge, h->n_merge_pairs, slot, s);
     HIP_TRY(h, hipGetLastError());
     return MI355REC_OK;
@@ -534,7 +534,7 @@ int mi355rec_enqueue_merge_keys_batch(mi355rec_t* h, const mi355rec_key_t* lists
     const int slot = timing_begin(h, h->ev_merge, h->n_merge_pairs, h->merge_launches, s);
     hipLaunchKernelGGL(merge_kernel, dim3(batch), dim3(kMergeBlock), 0, s, lists_dev, n_lists, list_len,
                        list_stride, query_stride, topn, out_keys_dev, out_idx_dev, out_score_dev,
-                       static_cast<int64_t>(topn), 0);
+                       static_cast<int64_t>(topn));
     timing_end(h, h->ev_merge, h->n_merge_pairs, slot, s);
     HIP_TRY(h, hipGetLastError());
     return MI355REC_OK;

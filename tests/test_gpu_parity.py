@@ -421,3 +421,36 @@ def test_full_size_10m_top100_properties(Engine, torch_cuda):
         got = eng.scores_row(q)
         want = oracle.scores(f, f[q], threads=0)
         assert np.array_equal(bits(got), bits(want))
+
+
+def test_config5_shard_1024_query_batch(Engine, torch_cuda):
+    """BASELINE configs[4] as seen by ONE of its 8 GPUs: a 12.5 M-row shard (row_base
+    set as for rank 3), one batch of 1024 queries, top-100.  Served as 128
+    multi-query passes; sampled queries are checked against the oracle."""
+    torch = torch_cuda
+    from spotify_recommender_amd.engine import unpack_keys
+    from spotify_recommender_amd.synth import synthetic_catalogue
+    n_local, base, batch, topn = 12_500_000, 3 * 12_500_000, 1024, 100
+    t = synthetic_catalogue(n_local, seed=5)
+    f = t.cpu().numpy()
+    rng = np.random.default_rng(55)
+    local_rows = rng.integers(0, n_local, size=batch)
+    queries = f[local_rows].copy()
+    queries[1::2] = rng.random((batch // 2, 12), dtype=np.float32)      # half of them external
+    excl = (local_rows + base).astype(np.int64)
+    excl[1::2] = -1
+    keys = torch.zeros(batch * topn, dtype=torch.int64, device="cuda")
+    with Engine(t, row_base=base) as eng:
+        eng.enqueue_batch_keys(queries, excl, topn, keys)
+        torch.cuda.synchronize()
+        got = keys.cpu().numpy().reshape(batch, topn)
+        for b in (0, 1, 510, 1023):
+            want = oracle.scores(f, queries[b], threads=0)
+            rows, scores = unpack_keys(got[b])
+            ex = int(excl[b]) - base if excl[b] >= 0 else -1
+            assert_topn_matches(rows - base, scores, want, ex, topn, ref_idx=oracle.topn_heap(want, ex, topn))
+        # every list is sorted in canonical order and carries global ids of this shard
+        u = got.view(np.uint64)
+        assert np.all(u[:, :-1] > u[:, 1:])
+        all_rows, _ = unpack_keys(got.reshape(-1))
+        assert all_rows.min() >= base and all_rows.max() < base + n_local

@@ -109,3 +109,49 @@ def test_cli_end_to_end(tmp_path, golden_dir):
     p = run("--id", "dupA", "-n", "0")
     assert p.returncode == 1 and "must be positive" in p.stderr
     assert run().returncode == 1 and run("--bogus").returncode == 1
+
+
+def test_config1_114k_csv_through_the_cli_classes(shim, tmp_path):
+    """BASELINE configs[0] plumbing: a 114 000-row Spotify-shaped CSV (114 genres
+    x 1000 tracks, grouped by genre like the Kaggle file) -> preprocess ->
+    songs_data.bin -> Recommender, top-10, against the oracle on the loaded
+    features.  (The reference runs this config on its CPU path; here it is the
+    same HIP path.)"""
+    from tests.test_datamanager import make_csv
+    csv = tmp_path / "dataset.csv"
+    rng = np.random.default_rng(114)
+    cols = ("track_id,track_name,artists,danceability,energy,key,loudness,mode,speechiness,"
+            "acousticness,instrumentalness,liveness,valence,tempo,track_genre")
+    lines = [cols]
+    for g in range(114):
+        block = rng.random((1000, 9))
+        for i in range(1000):
+            r = block[i]
+            k = g * 1000 + i
+            lines.append(f"t{k:06d},Track {k},Artist {k % 5000},{r[0]:.4f},{r[1]:.4f},{int(r[2] * 12)},"
+                         f"{-60 * r[3]:.3f},{int(r[4] * 2)},{r[5]:.4f},{r[6]:.5f},{r[7] ** 6:.6f},"
+                         f"{r[8]:.4f},{(r[0] + r[1]) / 2:.4f},{60 + 140 * r[2]:.3f},genre{g:03d}")
+    csv.write_text("\n".join(lines) + "\n")
+    shim.shim_preprocess.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    out = tmp_path / "songs_data.bin"
+    assert shim.shim_preprocess(str(csv).encode(), str(out).encode()) == 1
+    h = shim.shim_load(str(out).encode())
+    assert h
+    try:
+        assert shim.shim_initialize(h) == 1 and shim.shim_get_song_count(h) == 114_000
+        shim.shim_song_features = shim.shim_song_features
+        feats = np.zeros((114_000, 12), np.float32)
+        shim.shim_song_features.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        g = ctypes.c_int(0)
+        for i in range(114_000):
+            shim.shim_song_features(h, i, feats[i].ctypes.data, ctypes.byref(g))
+        assert feats[:, :11].min() == 0.0 and feats[:, :11].max() == 1.0      # min-max normalised
+        assert feats[113_999, 11] == 1.0 and feats[0, 11] == 0.0              # genre_id / (G-1)
+        for q in (0, 56_789, 113_999):
+            want = oracle.scores(feats, feats[q])
+            idx, sc = rec(shim, h, shim.shim_recommend_by_index, q, 10)
+            assert_topn_matches(idx, sc, want, q, 10, ref_idx=oracle.topn_heap(want, q, 10))
+        idx, _ = rec(shim, h, shim.shim_recommend, b"t056789", 10)
+        assert idx.tolist() == oracle.topn_canonical(oracle.scores(feats, feats[56_789]), 56_789, 10)[0].tolist()
+    finally:
+        shim.shim_free(h)

@@ -48,8 +48,6 @@ void run_cfg(const char* label, int blocks_per_cu) {
     report("topk", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr, (const uint64_t*)nullptr); }, g_reps));
     float mm = T.run([&] { hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)g_topk, (int64_t)0, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)0); }, g_reps);
     report("merge", mm);
-    if (g_stages) for (int stop = 1; stop <= 5; ++stop) { char nm[64]; snprintf(nm, sizeof nm, "  merge stopped at stage %d", stop);
-        report(nm, T.run([&] { hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)g_topk, (int64_t)0, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)0, stop); }, g_reps)); }
     report("  empty-ish kernel (probe, 64 vec)", T.run([&] { hipLaunchKernelGGL(stream_probe_kernel, dim3(1), dim3(kProbeBlock), 0, 0, (const float4*)d_feats, (int64_t)64, d_sink); }, g_reps));
     std::vector<uint64_t> got(g_topk);
     CK(hipMemcpy(got.data(), d_out, 8 * g_topk, hipMemcpyDeviceToHost));
@@ -59,7 +57,7 @@ void run_cfg(const char* label, int blocks_per_cu) {
         int64_t tiles = (g_n + Cfg::kTileRows - 1) / Cfg::kTileRows;
         int ig = (int)std::min<int64_t>(256 * blocks_per_cu, tiles); int it2 = (int)((tiles + ig - 1) / ig);
         report("topk, interleaved tiles", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false>), dim3(ig), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, (int64_t)0, it2, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr, (const uint64_t*)nullptr); }, g_reps));
-        hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(kMergeBlock), 0, 0, d_lists, ig, g_topk, (int64_t)g_topk, (int64_t)0, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)0, 0);
+        hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(kMergeBlock), 0, 0, d_lists, ig, g_topk, (int64_t)g_topk, (int64_t)0, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)0);
         std::vector<uint64_t> got2(g_topk); CK(hipMemcpy(got2.data(), d_out, 8 * g_topk, hipMemcpyDeviceToHost));
         printf("  interleaved result %s\n", got2 == g_ref ? "matches" : "DIFFERS");
         report("topk contiguous (again)", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr, (const uint64_t*)nullptr); }, g_reps));
@@ -83,18 +81,18 @@ void run_multi(const char* label, int blocks_per_cu, int nq, const std::vector<f
     static uint64_t* d_seed = nullptr; if (!d_seed) CK(hipMalloc(&d_seed, 8 * 8 * 1024));
     float ms1 = T.run([&] { hipLaunchKernelGGL((scan_multi_kernel<Cfg>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, (int64_t)Cfg::kTileRows, rpb, 1, (int64_t)0, qa, nq, 0, g_topk, d_lists, (const uint64_t*)nullptr); }, g_reps);
     report("seed pass (first tile of every workgroup)", ms1);
-    hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)g_topk, (int64_t)grid * g_topk, g_topk, d_seed, (int64_t*)nullptr, (float*)nullptr, (int64_t)g_topk, 0);
+    hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)g_topk, (int64_t)grid * g_topk, g_topk, d_seed, (int64_t*)nullptr, (float*)nullptr, (int64_t)g_topk);
     CK(hipDeviceSynchronize());
     ms = T.run([&] { hipLaunchKernelGGL((scan_multi_kernel<Cfg>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, rpb, iters, (int64_t)0, qa, nq, 0, g_topk, d_lists, (const uint64_t*)d_seed); }, g_reps);
     printf("  %-40s %8.3f us  %8.1f GB/s  %9.0f queries/s\n", "multi-query pass (seeded)", ms * 1e3, g_gb / (ms * 1e-3), nq / (ms * 1e-3));
     float chain = T.run([&] {
         hipLaunchKernelGGL((scan_multi_kernel<Cfg>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, (int64_t)Cfg::kTileRows, rpb, 1, (int64_t)0, qa, nq, 0, g_topk, d_lists, (const uint64_t*)nullptr);
-        hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)g_topk, (int64_t)grid * g_topk, g_topk, d_seed, (int64_t*)nullptr, (float*)nullptr, (int64_t)g_topk, 0);
+        hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)g_topk, (int64_t)grid * g_topk, g_topk, d_seed, (int64_t*)nullptr, (float*)nullptr, (int64_t)g_topk);
         hipLaunchKernelGGL((scan_multi_kernel<Cfg>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, rpb, iters, (int64_t)0, qa, nq, 0, g_topk, d_lists, (const uint64_t*)d_seed);
-        hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)g_topk, (int64_t)grid * g_topk, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)g_topk, 0);
+        hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)g_topk, (int64_t)grid * g_topk, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)g_topk);
     }, g_reps);
     printf("  %-40s %8.3f us  %8.1f GB/s  %9.0f queries/s\n", "seed+merge+pass+merge chain", chain * 1e3, g_gb / (chain * 1e-3), nq / (chain * 1e-3));
-    float mm = T.run([&] { hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)g_topk, (int64_t)grid * g_topk, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)g_topk, 0); }, g_reps);
+    float mm = T.run([&] { hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)g_topk, (int64_t)grid * g_topk, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)g_topk); }, g_reps);
     report("merge (one workgroup per query)", mm);
     std::vector<uint64_t> got(g_topk);
     CK(hipMemcpy(got.data(), d_out, 8 * g_topk, hipMemcpyDeviceToHost));
@@ -124,21 +122,21 @@ int main(int argc, char** argv) {
             report(nm, T.run([&] { hipLaunchKernelGGL(stream_probe_kernel, dim3(g), dim3(kProbeBlock), 0, 0, (const float4*)d_feats, g_n * 3, d_sink); }, g_reps)); }
     }
     if (argc > 4) {
-    run_cfg<ScanCfg<512, 4, 2>>("A", 1);
-    run_cfg<ScanCfg<512, 2, 4>>("B", 2);
-    run_cfg<ScanCfg<512, 2, 4>>("B", 4);
-    run_cfg<ScanCfg<512, 2, 4>>("B", 6);
-    run_cfg<ScanCfg<256, 2, 4>>("D", 4);
-    run_cfg<ScanCfg<256, 2, 4>>("D", 6);
-    run_cfg<ScanCfg<256, 2, 4>>("D", 8);
-    run_cfg<ScanCfg<256, 3, 3>>("G", 3);
-    run_cfg<ScanCfg<256, 3, 3>>("G", 6);
-    run_cfg<ScanCfg<256, 1, 6>>("H", 6);
-    run_cfg<ScanCfg<256, 1, 6>>("H", 8);
+    run_cfg<ScanCfg<512, 1, 6>>("I", 1);
+    run_cfg<ScanCfg<512, 1, 6>>("I", 2);
     run_cfg<ScanCfg<512, 1, 6>>("I", 3);
-    run_cfg<ScanCfg<512, 1, 6>>("I", 4);
+    run_cfg<ScanCfg<512, 2, 4>>("B", 1);
+    run_cfg<ScanCfg<512, 2, 4>>("B", 2);
+    run_cfg<ScanCfg<512, 4, 2>>("A", 1);
+    run_cfg<ScanCfg<256, 2, 4>>("D", 1);
+    run_cfg<ScanCfg<256, 2, 4>>("D", 2);
+    run_cfg<ScanCfg<256, 2, 4>>("D", 4);
+    run_cfg<ScanCfg<256, 4, 2>>("C", 1);
+    run_cfg<ScanCfg<256, 4, 2>>("C", 2);
+    run_cfg<ScanCfg<1024, 1, 4>>("L", 1);
     run_cfg<ScanCfg<1024, 2, 4>>("E", 1);
-    run_cfg<ScanCfg<1024, 1, 6>>("J", 2);
+    run_cfg<ScanCfg<256, 1, 6>>("K", 2);
+    run_cfg<ScanCfg<256, 1, 6>>("K", 4);
     } else {
     run_cfg<ScanCfg<512, 1, 6>>("I", 3);
     run_cfg<ScanCfg<512, 1, 6>>("I", 2);
