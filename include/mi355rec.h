@@ -120,7 +120,8 @@ int mi355rec_query_topn(mi355rec_t* h, const float* query12,
 
 /* `batch` independent queries (batch x 12 floats); exclude may be NULL.
  * Outputs are batch x topn, each row padded with idx -1 / score 0;
- * out_count has `batch` entries. */
+ * out_count has `batch` entries.  With batch > 1 and topn <= 128 the queries
+ * run as multi-query passes (8 queries per scan of the catalogue). */
 int mi355rec_query_batch_topn(mi355rec_t* h, const float* queries, int batch,
                               const int64_t* exclude_global, int topn,
                               int64_t* out_idx, float* out_score, int* out_count);

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 #include "kernels.hip.h"
 
@@ -104,7 +105,7 @@ int main(int argc, char** argv) {
     g_reps = argc > 2 ? atoi(argv[2]) : 20;
     g_topk = argc > 3 ? atoi(argv[3]) : 100;
     g_gb = g_n * 48.0 / 1e9;
-    g_stages = argc <= 4;
+    g_stages = 0;
     CK(hipMalloc(&d_feats, g_n * 48));
     std::vector<float> h(g_n * 12);
     uint64_t s = 88172645463325252ull;
@@ -121,7 +122,8 @@ int main(int argc, char** argv) {
         for (int g : {512, 1024, 2048}) { char nm[64]; snprintf(nm, sizeof nm, "grid %d", g);
             report(nm, T.run([&] { hipLaunchKernelGGL(stream_probe_kernel, dim3(g), dim3(kProbeBlock), 0, 0, (const float4*)d_feats, g_n * 3, d_sink); }, g_reps)); }
     }
-    if (argc > 4) {
+    const std::string mode = argc > 4 ? argv[4] : "default";
+    if (mode == "sweep") {
     run_cfg<ScanCfg<512, 1, 6>>("I", 1);
     run_cfg<ScanCfg<512, 1, 6>>("I", 2);
     run_cfg<ScanCfg<512, 1, 6>>("I", 3);
@@ -139,10 +141,7 @@ int main(int argc, char** argv) {
     run_cfg<ScanCfg<256, 1, 6>>("K", 4);
     } else {
     run_cfg<ScanCfg<512, 1, 6>>("I", 3);
-    run_cfg<ScanCfg<512, 1, 6>>("I", 2);
-    run_cfg<ScanCfg<256, 1, 6>>("K", 6);
-    run_cfg<ScanCfg<512, 2, 4>>("B", 2);
-    if (argc > 5) {
+    if (mode == "multi") {
     run_multi<MultiCfg<512, 1, 4>>("M512x1", 2, 8, h);
     run_multi<MultiCfg<512, 1, 4>>("M512x1", 2, 4, h);
     run_multi<MultiCfg<512, 1, 4>>("M512x1", 2, 1, h);
