@@ -46,7 +46,7 @@ def parse_args():
                     help="skip the per-kernel HIP events (roofline.achieved becomes null)")
     ap.add_argument("--event-stride", type=int, default=10,
                     help="time every k-th kernel launch inside the timed region (an event pair costs ~3 us)")
-    ap.add_argument("--latency-queries", type=int, default=200)
+    ap.add_argument("--latency-queries", type=int, default=1000)
     return ap.parse_args()
 
 
@@ -99,10 +99,17 @@ def cpu_baseline(feats_host, topn, query_rows):
         if time.perf_counter() - t0 > 12.0:
             break
     omp_qps = done / (time.perf_counter() - t0)
+    # B0: the reference's serial loop over its AoS layout —
+    # features at a 152-byte stride inside vector<Song> (Song.h:21-32)
+    import numpy as np
+    aos = np.zeros((feats_host.shape[0], 38), dtype=np.float32)
+    aos[:, 25:37] = feats_host
+    aos_feats = aos[:, 25:37]
+    oracle.recommend_by_index(aos_feats, query_rows[0], topn)
     t0 = time.perf_counter()
     serial = 0
     for q in query_rows[:8]:
-        oracle.recommend_by_index(feats_host, q, topn)
+        oracle.recommend_by_index(aos_feats, q, topn)
         serial += 1
         if time.perf_counter() - t0 > 8.0:
             break
@@ -112,7 +119,7 @@ def cpu_baseline(feats_host, topn, query_rows):
         "sample": f"{done} queries x {feats_host.shape[0]} rows top-{topn}, OpenMP rows + per-thread top-N "
                   f"(oracle/cosine_oracle.c, gcc -O3, no -march)",
         "serial_reference_loop_qps": round(serial_qps, 3),
-        "serial_sample": f"{serial} queries, 1 core (Recommender.cu:256-318 restated)",
+        "serial_sample": f"{serial} queries, 1 core, 152-byte AoS row stride (Recommender.cu:256-318 restated)",
     }
 
 
@@ -285,6 +292,7 @@ def main():
                 "avg_kernel_ms": round(scan_ms, 5) if scan_ms else None,
                 "merge_kernel_ms": round(float(st.last_merge_ms), 5),
                 "stream_probe_gbps": round(probe_gbps, 1) if probe_gbps else None,
+                "frac_of_stream_probe": round(achieved / probe_gbps, 4) if (achieved and probe_gbps) else None,
                 "infinity_cache_resident": bool(cache_resident),
             },
         }

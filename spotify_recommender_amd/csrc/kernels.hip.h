@@ -26,11 +26,12 @@ constexpr int kCandLimit = 2 * kMaxTopK;  // a tile is never entered with more c
 // Geometry of the streaming scan: threads per workgroup, rows in flight per lane
 // per tile, and the minimum waves per SIMD the register allocator must leave
 // room for (__launch_bounds__'s second argument).
-template <int kBlockT, int kRowsT, int kMinWavesT>
+template <int kBlockT, int kRowsT, int kMinWavesT, int kDepthT = 2>
 struct ScanCfg {
     static constexpr int kBlock = kBlockT;
     static constexpr int kRowsPerThread = kRowsT;
     static constexpr int kMinWaves = kMinWavesT;
+    static constexpr int kDepth = kDepthT;   // tiles in flight per lane (register ring)
     static constexpr int kTileRows = kBlockT * kRowsT;
     static constexpr int kCandCap = kCandLimit + kTileRows;  // LDS candidate slots
     static constexpr int kCandPerThread = (kCandCap + kBlockT - 1) / kBlockT;
@@ -450,14 +451,18 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
         }
     };
 
-    Row buf_a[kRowsPerThread];
-    Row buf_b[kRowsPerThread];
-    load_tile(buf_a, 0);
-    for (int it = 0; it < iters; it += 2) {
-        load_tile(buf_b, it + 1);
-        process_tile(buf_a, it);
-        load_tile(buf_a, it + 2);
-        process_tile(buf_b, it + 1);  // fully masked when it + 1 == iters
+    // kDepth tiles in flight per lane: the loads of tile it + kDepth - 1 are issued
+    // before tile it is scored (register ring, statically indexed).
+    constexpr int kDepth = Cfg::kDepth;
+    Row ring[kDepth][kRowsPerThread];
+#pragma unroll
+    for (int d = 0; d < kDepth - 1; ++d) load_tile(ring[d], d);
+    for (int it = 0; it < iters; it += kDepth) {
+#pragma unroll
+        for (int sidx = 0; sidx < kDepth; ++sidx) {
+            load_tile(ring[(sidx + kDepth - 1) % kDepth], it + sidx + kDepth - 1);
+            if (it + sidx < iters) process_tile(ring[sidx], it + sidx);  // uniform
+        }
     }
 
     if constexpr (!kScoresOnly) {

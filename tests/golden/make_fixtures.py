@@ -17,6 +17,11 @@ Provenance of each file:
       SURVEY.md §8(c) (tests/test_oracle_pins.py).  The reference's
       Recommender.cu itself is not buildable here (needs CUDA header
       stand-ins), so these are oracle outputs, not direct reference outputs.
+  seeded_top100.npz
+      top-100 rows/scores + CRC32 of the full score vector for 4 query rows of the
+      1 M and 10 M mt19937(12345) catalogues (the survey's generator), from the
+      pinned oracle; its first three entries for query 0 ARE the reference's
+      recorded outputs (survey_pins.json).
   survey_pins.json
       the reference outputs recorded in SURVEY.md §8(c)/§6.2, verbatim.
 """
@@ -113,6 +118,27 @@ def make_catalogue() -> None:
     print("catalogue4096: scores", scores.shape, "q5 top3", out["heap_top10"][0][:3])
 
 
+def make_seeded_top100() -> None:
+    """SURVEY.md §8(c) fixture (4): for the 1 M and 10 M mt19937(12345) catalogues the
+    top-100 (row, score) of a few query rows + a checksum of the whole score
+    vector, from the pinned oracle.  A few KB; lets the GPU tests check full-size
+    results without trusting anything computed on the GPU box."""
+    import zlib
+    out = {}
+    for rows in (1_000_000, 10_000_000):
+        f = oracle.mt19937_uniform(12345, rows)
+        qs = np.array([0, 7919, rows // 2, rows - 1], dtype=np.int64)
+        out[f"queries_{rows}"] = qs
+        for q in qs:
+            s = oracle.scores(f, f[q], threads=0)
+            idx = oracle.topn_heap(s, int(q), 100)
+            out[f"heap_idx_{rows}_{q}"] = idx
+            out[f"scores_{rows}_{q}"] = s[idx]
+            out[f"crc32_{rows}_{q}"] = np.uint32(zlib.crc32(s.tobytes()))
+    np.savez_compressed(GOLD / "seeded_top100.npz", **out)
+    print("seeded_top100:", sorted(out)[:4], "...")
+
+
 def make_pins() -> None:
     pins = {
         "source": "SURVEY.md §8(c) and §6.2 — outputs of the reference CPU path recorded by the survey",
@@ -135,4 +161,5 @@ def make_pins() -> None:
 if __name__ == "__main__":
     make_sample_bin()
     make_catalogue()
+    make_seeded_top100()
     make_pins()

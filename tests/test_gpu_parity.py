@@ -390,6 +390,26 @@ def test_reference_recorded_top3_at_1m_and_10m(Engine, golden_dir):
             assert_topn_matches(idx, sc, want, 0, topn, ref_idx=oracle.topn_heap(want, 0, topn))
 
 
+def test_committed_full_size_fixture(Engine, golden_dir):
+    """1 M / 10 M results against the COMMITTED fixture (tests/golden/
+    seeded_top100.npz): ids, bit-exact scores and the CRC32 of the whole score
+    vector — nothing here is recomputed by the oracle on the GPU box."""
+    import zlib
+    g = np.load(golden_dir / "seeded_top100.npz")
+    for rows in (1_000_000, 10_000_000):
+        f = oracle.mt19937_uniform(12345, rows)      # generator only (data, not results)
+        with Engine(f) as eng:
+            for q in g[f"queries_{rows}"]:
+                idx, sc = eng.query_row_topn(int(q), 100)
+                want_idx, want_sc = g[f"heap_idx_{rows}_{q}"], g[f"scores_{rows}_{q}"]
+                assert np.array_equal(bits(sc), bits(want_sc + np.float32(0)))
+                ties = np.concatenate([[False], want_sc[1:] == want_sc[:-1]]) | np.concatenate([want_sc[1:] == want_sc[:-1], [False]])
+                assert np.array_equal(idx[~ties], want_idx[~ties])
+                assert sorted(idx[ties].tolist()) == sorted(want_idx[ties].tolist()) or ties[-1]
+                full = eng.scores_row(int(q))
+                assert np.uint32(zlib.crc32(full.tobytes())) == g[f"crc32_{rows}_{q}"]
+
+
 def test_full_size_10m_top100_properties(Engine, torch_cuda):
     """configs[2]: 10 M x 12, top-100, device-generated data.  Direct oracle
     comparison on a few queries plus size-independent properties."""

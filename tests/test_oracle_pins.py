@@ -91,3 +91,10 @@ def test_observable_semantics(golden_dir):
     assert np.array_equal(oracle.scores(aos[:, 26:38], f[5]), s5[:64])
     # topn > n-1 -> n-1 results
     assert len(oracle.topn_heap(s5[:4], 1, 10)) == 3
+
+
+def test_seeded_top100_fixture_matches_survey_pins(golden_dir, pins):
+    g = np.load(golden_dir / "seeded_top100.npz")
+    for rows, key in ((1_000_000, "1M_q0_top3"), (10_000_000, "10M_q0_top3")):
+        for (want_i, want_s), got_i, got_s in zip(pins[key], g[f"heap_idx_{rows}_0"][:3], g[f"scores_{rows}_0"][:3]):
+            assert got_i == want_i and f"{got_s:.7f}" == f"{want_s:.7f}"

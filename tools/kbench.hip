@@ -44,7 +44,7 @@ void run_cfg(const char* label, int blocks_per_cu) {
     int64_t rpb = (g_n + maxb - 1) / maxb; rpb = (rpb + 63) / 64 * 64;
     int grid = (int)((g_n + rpb - 1) / rpb); int iters = (int)((rpb + Cfg::kTileRows - 1) / Cfg::kTileRows);
     int occ = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel<Cfg, false, false>, Cfg::kBlock, 0));
-    printf("-- %s: block %d x %d rows, minwaves %d, grid %d (%d/CU asked, occupancy API %d), rows/block %lld, iters %d\n", label, Cfg::kBlock, Cfg::kRowsPerThread, Cfg::kMinWaves, grid, blocks_per_cu, occ, (long long)rpb, iters);
+    printf("-- %s: block %d x %d rows, depth %d, minwaves %d, grid %d (%d/CU asked, occupancy API %d), rows/block %lld, iters %d\n", label, Cfg::kBlock, Cfg::kRowsPerThread, Cfg::kDepth, Cfg::kMinWaves, grid, blocks_per_cu, occ, (long long)rpb, iters);
     report("scores-only", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, true>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)-1, 1, (uint64_t*)nullptr, d_scores, (const uint64_t*)nullptr); }, g_reps));
     report("topk", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr, (const uint64_t*)nullptr); }, g_reps));
     float mm = T.run([&] { hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)g_topk, (int64_t)0, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)0); }, g_reps);
@@ -124,21 +124,19 @@ int main(int argc, char** argv) {
     }
     const std::string mode = argc > 4 ? argv[4] : "default";
     if (mode == "sweep") {
-    run_cfg<ScanCfg<512, 1, 6>>("I", 1);
-    run_cfg<ScanCfg<512, 1, 6>>("I", 2);
-    run_cfg<ScanCfg<512, 1, 6>>("I", 3);
-    run_cfg<ScanCfg<512, 2, 4>>("B", 1);
-    run_cfg<ScanCfg<512, 2, 4>>("B", 2);
-    run_cfg<ScanCfg<512, 4, 2>>("A", 1);
-    run_cfg<ScanCfg<256, 2, 4>>("D", 1);
-    run_cfg<ScanCfg<256, 2, 4>>("D", 2);
-    run_cfg<ScanCfg<256, 2, 4>>("D", 4);
-    run_cfg<ScanCfg<256, 4, 2>>("C", 1);
-    run_cfg<ScanCfg<256, 4, 2>>("C", 2);
-    run_cfg<ScanCfg<1024, 1, 4>>("L", 1);
-    run_cfg<ScanCfg<1024, 2, 4>>("E", 1);
-    run_cfg<ScanCfg<256, 1, 6>>("K", 2);
-    run_cfg<ScanCfg<256, 1, 6>>("K", 4);
+    run_cfg<ScanCfg<512, 1, 6, 2>>("I d2", 3);
+    run_cfg<ScanCfg<512, 1, 6, 3>>("I d3", 3);
+    run_cfg<ScanCfg<512, 1, 6, 4>>("I d4", 3);
+    run_cfg<ScanCfg<512, 1, 6, 3>>("I d3", 2);
+    run_cfg<ScanCfg<512, 1, 6, 4>>("I d4", 2);
+    run_cfg<ScanCfg<512, 1, 6, 4>>("I d4", 1);
+    run_cfg<ScanCfg<512, 1, 4, 6>>("I d6", 1);
+    run_cfg<ScanCfg<512, 1, 4, 6>>("I d6", 2);
+    run_cfg<ScanCfg<256, 1, 4, 4>>("K d4", 2);
+    run_cfg<ScanCfg<256, 1, 4, 6>>("K d6", 1);
+    run_cfg<ScanCfg<256, 1, 4, 6>>("K d6", 2);
+    run_cfg<ScanCfg<256, 1, 4, 8>>("K d8", 1);
+    run_cfg<ScanCfg<256, 1, 4, 8>>("K d8", 2);
     } else {
     run_cfg<ScanCfg<512, 1, 6>>("I", 3);
     if (mode == "multi") {
