@@ -7,8 +7,14 @@
 // code by tests/test_datamanager.py.
 #include "DataManager.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <limits>
@@ -267,23 +273,69 @@ bool DataManager::loadData(const std::string& binaryPath, std::vector<Song>& son
     return true;
 }
 
+// Same bytes, one pass over a read-only mapping: no iostream call per field and
+// no intermediate vector<Song> (the reference's loadData + initialize copy the
+// catalogue three times, DataManager.cpp:396-402 and Recommender.cu:109,162-167).
 bool DataManager::loadFeatureMatrix(const std::string& binaryPath, std::vector<float>& features,
                                     std::vector<std::string>& trackIds,
                                     std::vector<std::string>& trackNames) {
-    std::ifstream in(binaryPath, std::ios::binary);
-    if (!in.is_open()) return false;
-    size_t numSongs = 0;
-    if (!readHeader(in, numSongs, nullptr)) return false;
-    features.resize(numSongs * FEATURE_COUNT);
-    trackIds.resize(numSongs);
-    trackNames.resize(numSongs);
-    Song s;
-    for (size_t i = 0; i < numSongs; ++i) {
-        s.deserialize(in);
-        if (!in) return false;
-        std::copy(s.features, s.features + FEATURE_COUNT, features.begin() + i * FEATURE_COUNT);
-        trackIds[i].swap(s.track_id);
-        trackNames[i].swap(s.track_name);
+    const int fd = ::open(binaryPath.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (::fstat(fd, &st) != 0 || st.st_size < 16) {
+        ::close(fd);
+        return false;
     }
-    return true;
+    const size_t size = static_cast<size_t>(st.st_size);
+    void* map = ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (map == MAP_FAILED) return false;
+    const unsigned char* p = static_cast<const unsigned char*>(map);
+    const unsigned char* const end = p + size;
+    bool ok = true;
+    auto take = [&](void* dst, size_t n) {
+        if (!ok || static_cast<size_t>(end - p) < n) { ok = false; return; }
+        std::memcpy(dst, p, n);
+        p += n;
+    };
+    auto takeString = [&](std::string* dst) {
+        size_t len = 0;
+        take(&len, sizeof len);
+        if (!ok || static_cast<size_t>(end - p) < len) { ok = false; return; }
+        if (dst) dst->assign(reinterpret_cast<const char*>(p), len);
+        p += len;
+    };
+    size_t numSongs = 0, numGenres = 0;
+    take(&numSongs, sizeof numSongs);
+    take(&numGenres, sizeof numGenres);
+    if (!ok || numSongs > (size_t(1) << 32) || numGenres > (size_t(1) << 24)) ok = false;
+    for (size_t g = 0; ok && g < numGenres; ++g) {
+        int id = 0;
+        take(&id, sizeof id);
+        takeString(nullptr);
+    }
+    if (ok) {
+        // every song needs at least 3 lengths + genre + features
+        if (numSongs > size / (3 * sizeof(size_t) + sizeof(int) + FEATURE_COUNT * sizeof(float))) ok = false;
+    }
+    if (ok) {
+        features.resize(numSongs * FEATURE_COUNT);
+        trackIds.resize(numSongs);
+        trackNames.resize(numSongs);
+    }
+    for (size_t i = 0; ok && i < numSongs; ++i) {
+        takeString(&trackIds[i]);
+        takeString(&trackNames[i]);
+        takeString(nullptr);  // artists
+        int genre = 0;
+        take(&genre, sizeof genre);
+        take(&features[i * FEATURE_COUNT], FEATURE_COUNT * sizeof(float));
+    }
+    ::munmap(map, size);
+    if (!ok) {
+        features.clear();
+        trackIds.clear();
+        trackNames.clear();
+    }
+    return ok;
 }
