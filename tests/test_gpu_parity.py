@@ -252,7 +252,7 @@ def test_multi_query_pass_matches_single_queries(Engine, torch_cuda, rows):
         f[50:60] = f[3]                                   # ties with a query
     from spotify_recommender_amd.engine import unpack_keys
     with Engine(f) as eng:
-        for batch, topn in ((1, 10), (3, 5), (8, 100), (19, 128), (9, 1)):
+        for batch, topn in ((1, 10), (3, 5), (8, 100), (19, 128), (9, 1), (40, 16), (5, 200)):
             qrows = rng.integers(0, rows, size=batch)
             qrows[0] = min(3, rows - 1)
             queries = f[qrows].copy()

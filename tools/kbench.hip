@@ -123,6 +123,10 @@ int main(int argc, char** argv) {
             report(nm, T.run([&] { hipLaunchKernelGGL(stream_probe_kernel, dim3(g), dim3(kProbeBlock), 0, 0, (const float4*)d_feats, g_n * 3, d_sink); }, g_reps)); }
     }
     const std::string mode = argc > 4 ? argv[4] : "default";
+    if (mode == "multi8") {   // one clean configuration for counter collection
+        run_multi<MultiCfg<512, 1, 4>>("M512x1", 2, 8, h);
+        return 0;
+    }
     if (mode == "sweep") {
     run_cfg<ScanCfg<512, 1, 6, 2>>("I d2", 3);
     run_cfg<ScanCfg<512, 1, 6, 3>>("I d3", 3);
