@@ -859,7 +859,16 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
     uint64_t thr = 1;  // accept every non-empty key
     int first = 0;     // keys [0, first) of every list are already dealt with
 
-    if (probe == 1 && n_lists * kMergeFirst <= kMergeBlock * kMergeFirstPerThread) {
+    const int64_t total_keys = static_cast<int64_t>(n_lists) * list_len;
+    if (total_keys <= kMergeSurvCap) {
+        // Small input (e.g. one list of topn keys per rank after the all-gather):
+        // take every key in one load phase; the select / rank below does the rest.
+        first = list_len;
+        for (int64_t i = tid; i < total_keys; i += kMergeBlock) {
+            const uint64_t k = lists[(i / list_len) * list_stride + (i % list_len)];
+            if (k) s_surv[atomicAdd(&s_count, 1)] = k;
+        }
+    } else if (probe == 1 && n_lists * kMergeFirst <= kMergeBlock * kMergeFirstPerThread) {
         // Many lists (the per-workgroup lists of one scan).  ONE load phase brings
         // in the first kMergeFirst keys of every list; the heads among them give
         // the threshold and the rest is filtered from registers, so the usual

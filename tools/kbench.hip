@@ -123,6 +123,20 @@ int main(int argc, char** argv) {
             report(nm, T.run([&] { hipLaunchKernelGGL(stream_probe_kernel, dim3(g), dim3(kProbeBlock), 0, 0, (const float4*)d_feats, g_n * 3, d_sink); }, g_reps)); }
     }
     const std::string mode = argc > 4 ? argv[4] : "default";
+    if (mode == "merge8") {   // the per-rank merge of an 8-GPU run: 8 sorted lists of topk keys
+        Timer T;
+        std::vector<uint64_t> keys(8 * g_topk);
+        uint64_t sd = 12345;
+        for (int l = 0; l < 8; ++l) { std::vector<uint64_t> v(g_topk); for (auto& k : v) { sd ^= sd << 13; sd ^= sd >> 7; sd ^= sd << 17; k = (0xBF700000ull + (sd & 0xFFFFF)) << 32 | (sd >> 40); }
+            std::sort(v.rbegin(), v.rend()); std::copy(v.begin(), v.end(), keys.begin() + l * g_topk); }
+        CK(hipMemcpy(d_lists, keys.data(), keys.size() * 8, hipMemcpyHostToDevice));
+        report("merge of 8 rank lists", T.run([&] { hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(kMergeBlock), 0, 0, d_lists, 8, g_topk, (int64_t)g_topk, (int64_t)0, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)0); }, g_reps));
+        std::vector<uint64_t> got(g_topk); CK(hipMemcpy(got.data(), d_out, 8 * g_topk, hipMemcpyDeviceToHost));
+        std::sort(keys.rbegin(), keys.rend());
+        printf("  result %s\n", std::equal(got.begin(), got.end(), keys.begin()) ? "correct" : "WRONG");
+        report("empty-ish kernel", T.run([&] { hipLaunchKernelGGL(stream_probe_kernel, dim3(1), dim3(kProbeBlock), 0, 0, (const float4*)d_feats, (int64_t)64, d_sink); }, g_reps));
+        return 0;
+    }
     if (mode == "multi8") {   // one clean configuration for counter collection
         run_multi<MultiCfg<512, 1, 4>>("M512x1", 2, 8, h);
         return 0;
