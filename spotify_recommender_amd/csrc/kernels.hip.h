@@ -849,6 +849,7 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
         s_count = 0;
         s_overflow = 0;
         s_pair[0] = 0;
+        s_more = 0;
     }
     __syncthreads();
     int probe = 1;
@@ -900,7 +901,10 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
                 const int slot = atomicAdd(&s_count, 1);
                 if (slot < kMergeSurvCap) s_surv[slot] = k[u];
                 else s_overflow = 1;
-                if (j == first - 1) s_active[(u * kMergeBlock + tid) / kMergeFirst] = 0;  // look deeper
+                if (j == first - 1) {  // the whole first chunk passed: look deeper
+                    s_active[(u * kMergeBlock + tid) / kMergeFirst] = 0;
+                    s_more = 1;
+                }
             }
         }
     } else {
@@ -915,6 +919,7 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
             local_nonzero += heads[r] != 0ull;
             if (l < n_lists) s_active[l] = 0;
         }
+        if (tid == 0) s_more = 1;  // every list starts active
         if (local_nonzero) atomicAdd(&s_pair[0], local_nonzero);
         __syncthreads();
         if (s_pair[0] >= need_lists)  // uniform; the select needs >= need_lists non-empty probes
@@ -927,13 +932,10 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
     // of a round are independent and issued before any of them is consumed.
     // With the first-chunk phase above this loop usually does not run at all.
     for (int round = 0; first + round * kMergeChunk < list_len && !s_overflow; ++round) {
-        // any list active for this round?
+        // s_more was raised by whoever marked a list active for this round
+        if (!s_more) break;  // uniform: read after a barrier, rewritten only after the next one
+        __syncthreads();
         if (tid == 0) s_more = 0;
-        __syncthreads();
-        for (int l = tid; l < n_lists; l += kMergeBlock)
-            if (s_active[l] == round) s_more = 1;
-        __syncthreads();
-        if (!s_more) break;
         __syncthreads();
         const int total = n_lists * kMergeChunk;
         for (int t0 = 0; t0 < total; t0 += kMergeBlock * 8) {
@@ -960,8 +962,10 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
         for (int l = tid; l < n_lists; l += kMergeBlock) {
             if (s_active[l] == round) {
                 const int last = first + (round + 1) * kMergeChunk - 1;
-                if (last < list_len && lists[static_cast<int64_t>(l) * list_stride + last] >= thr)
+                if (last < list_len && lists[static_cast<int64_t>(l) * list_stride + last] >= thr) {
                     s_active[l] = static_cast<unsigned short>(round + 1);
+                    s_more = 1;
+                }
             }
         }
         __syncthreads();
