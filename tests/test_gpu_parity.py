@@ -474,3 +474,22 @@ def test_config5_shard_1024_query_batch(Engine, torch_cuda):
         assert np.all(u[:, :-1] > u[:, 1:])
         all_rows, _ = unpack_keys(got.reshape(-1))
         assert all_rows.min() >= base and all_rows.max() < base + n_local
+
+
+def test_100m_rows_on_one_gpu(Engine, torch_cuda):
+    """The whole 100 M x 12 catalogue of BASELINE configs[4] (4.8 GB) resident on ONE
+    MI355X: 64-bit row offsets, > 2^31 matrix elements, top-100 against the oracle."""
+    torch = torch_cuda
+    from spotify_recommender_amd.synth import synthetic_catalogue
+    n = 100_000_000
+    t = synthetic_catalogue(n, seed=100)
+    f = t.cpu().numpy()
+    with Engine(t) as eng:
+        for q in (99_999_999, 53_687_091):        # beyond 2^31 / 48 and 2^32 / 48 bytes-offsets
+            want = oracle.scores(f, f[q], threads=0)
+            idx, sc = eng.query_row_topn(q, 100)
+            assert_topn_matches(idx, sc, want, q, 100, ref_idx=oracle.topn_heap(want, q, 100))
+        idx, sc, counts = eng.query_batch_topn(f[[7, 50_000_000]], [7, 50_000_000], 10)
+        for b, q in enumerate((7, 50_000_000)):
+            want = oracle.scores(f, f[q], threads=0)
+            assert_topn_matches(idx[b], sc[b], want, q, 10)
