@@ -180,7 +180,7 @@ int mi355rec_enqueue_scores(mi355rec_t* h, int64_t local_row,
 
 /* Plain read-only streaming kernel over the same matrix (the achievable-HBM
  * ceiling probe of SURVEY.md §8(d)); writes one checksum word per workgroup
- * to sink_dev (>= grid_blocks uint32). */
+ * to sink_dev (>= compute_units uint32). */
 int mi355rec_enqueue_stream_probe(mi355rec_t* h, uint32_t* sink_dev, void* stream);
 
 /* Brackets the following scan / merge launches with HIP events on their stream

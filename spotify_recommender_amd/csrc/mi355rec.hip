@@ -570,7 +570,7 @@ int mi355rec_enqueue_stream_probe(mi355rec_t* h, uint32_t* sink_dev, void* strea
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, s);
-    hipLaunchKernelGGL(stream_probe_kernel, dim3(h->grid), dim3(kProbeBlock), 0, s,
+    hipLaunchKernelGGL(stream_probe_kernel, dim3(h->cus), dim3(kProbeBlock), 0, s,
                        reinterpret_cast<const float4*>(h->d_feats), h->n * 3, sink_dev);
     timing_end(h, h->ev_scan, h->n_scan_pairs, slot, s);
     HIP_TRY(h, hipGetLastError());

@@ -119,7 +119,7 @@ int main(int argc, char** argv) {
     {
         Timer T;
         printf("-- stream probe (coalesced float4 reads)\n");
-        for (int g : {512, 1024, 2048}) { char nm[64]; snprintf(nm, sizeof nm, "grid %d", g);
+        for (int g : {256, 512, 768}) { char nm[64]; snprintf(nm, sizeof nm, "grid %d", g);
             report(nm, T.run([&] { hipLaunchKernelGGL(stream_probe_kernel, dim3(g), dim3(kProbeBlock), 0, 0, (const float4*)d_feats, g_n * 3, d_sink); }, g_reps)); }
     }
     const std::string mode = argc > 4 ? argv[4] : "default";
@@ -143,18 +143,17 @@ int main(int argc, char** argv) {
     }
     if (mode == "sweep") {
     run_cfg<ScanCfg<512, 1, 6, 2>>("I d2", 3);
-    run_cfg<ScanCfg<512, 1, 6, 3>>("I d3", 3);
-    run_cfg<ScanCfg<512, 1, 6, 4>>("I d4", 3);
-    run_cfg<ScanCfg<512, 1, 6, 3>>("I d3", 2);
-    run_cfg<ScanCfg<512, 1, 6, 4>>("I d4", 2);
-    run_cfg<ScanCfg<512, 1, 6, 4>>("I d4", 1);
-    run_cfg<ScanCfg<512, 1, 4, 6>>("I d6", 1);
-    run_cfg<ScanCfg<512, 1, 4, 6>>("I d6", 2);
-    run_cfg<ScanCfg<256, 1, 4, 4>>("K d4", 2);
-    run_cfg<ScanCfg<256, 1, 4, 6>>("K d6", 1);
-    run_cfg<ScanCfg<256, 1, 4, 6>>("K d6", 2);
-    run_cfg<ScanCfg<256, 1, 4, 8>>("K d8", 1);
-    run_cfg<ScanCfg<256, 1, 4, 8>>("K d8", 2);
+    run_cfg<ScanCfg<512, 1, 6, 2>>("I d2", 1);
+    run_cfg<ScanCfg<512, 1, 2, 1>>("I d1", 1);
+    run_cfg<ScanCfg<512, 1, 2, 1>>("I d1", 2);
+    run_cfg<ScanCfg<512, 2, 2, 1>>("B d1", 1);
+    run_cfg<ScanCfg<512, 3, 2, 1>>("F d1", 1);
+    run_cfg<ScanCfg<1024, 1, 2, 1>>("L d1", 1);
+    run_cfg<ScanCfg<1024, 1, 2, 2>>("L d2", 1);
+    run_cfg<ScanCfg<256, 2, 2, 1>>("D d1", 1);
+    run_cfg<ScanCfg<256, 2, 2, 1>>("D d1", 2);
+    run_cfg<ScanCfg<256, 1, 2, 2>>("K d2", 1);
+    run_cfg<ScanCfg<256, 1, 2, 2>>("K d2", 2);
     } else {
     run_cfg<ScanCfg<512, 1, 6>>("I", 3);
     if (mode == "multi") {
