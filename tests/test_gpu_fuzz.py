@@ -1,0 +1,101 @@
+"""Randomised parity sweep: many small/medium catalogues with hostile score
+distributions (heavy ties, clusters, signed, sparse special values), random
+topN and batch sizes, every result checked against the oracle.  FUZZ_CASES
+(environment) scales the number of cases; the default keeps the test short."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.parity import assert_topn_matches
+
+pytestmark = pytest.mark.gpu
+
+
+def make_catalogue(rng, rows):
+    kind = rng.integers(0, 7)
+    if kind == 0:
+        f = rng.random((rows, 12), dtype=np.float32)
+    elif kind == 1:   # few distinct values per feature -> massive exact ties
+        f = (rng.integers(0, 3, size=(rows, 12)) / np.float32(2)).astype(np.float32)
+    elif kind == 2:   # tight clusters around a handful of centres
+        centres = rng.random((5, 12), dtype=np.float32)
+        f = centres[rng.integers(0, 5, size=rows)] * (1 + rng.normal(0, 1e-6, size=(rows, 12))).astype(np.float32)
+    elif kind == 3:   # signed, wide dynamic range
+        f = (rng.normal(0, 1, size=(rows, 12)) * 10.0 ** rng.integers(-3, 4, size=(rows, 1))).astype(np.float32)
+    elif kind == 4:   # sorted by similarity to the all-ones vector (ascending): adversarial for thresholds
+        t = np.sort(rng.random(rows)).astype(np.float32)[:, None]
+        f = np.ones((rows, 12), np.float32)
+        f[:, :6] = 0.1 + 0.9 * t
+    elif kind == 5:   # mostly duplicates of a few rows
+        base = rng.random((3, 12), dtype=np.float32)
+        f = base[rng.integers(0, 3, size=rows)].copy()
+        k = max(1, rows // 50)
+        f[rng.integers(0, rows, size=k)] = rng.random((k, 12), dtype=np.float32)
+    else:             # sparse rows + special values
+        f = rng.random((rows, 12), dtype=np.float32)
+        f[rng.random((rows, 12)) < 0.6] = 0.0
+        for val in (np.nan, np.inf, -np.inf, 1e-42, 3e19):
+            if rows > 4:
+                f[rng.integers(0, rows), rng.integers(0, 12)] = val
+    return np.ascontiguousarray(f.astype(np.float32))
+
+
+def test_randomised_parity():
+    import torch
+    assert torch.cuda.is_available()
+    from spotify_recommender_amd.engine import CosineEngine
+    cases = int(os.environ.get("FUZZ_CASES", "60"))
+    rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "20251017")))
+    for case in range(cases):
+        rows = int(rng.choice([1, 2, 5, 63, 64, 65, 300, 513, 2049, 7000, 40_000, 150_000, 600_000],
+                              p=[.03, .03, .05, .05, .05, .05, .1, .1, .1, .14, .15, .1, .05]))
+        f = make_catalogue(rng, rows)
+        with CosineEngine(f) as eng:
+            for _ in range(3):
+                topn = int(rng.choice([1, 2, 10, 100, 128, 129, 1000, 1024, 1025, 2500]))
+                q = int(rng.integers(0, rows))
+                want = oracle.scores(f, f[q])
+                got = eng.scores_row(q)
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (case, rows, q)
+                idx, sc = eng.query_row_topn(q, topn)
+                try:
+                    assert_topn_matches(idx, sc, want, q, topn, ref_idx=oracle.topn_heap(want, q, topn))
+                except AssertionError as e:  # pragma: no cover - keep the failing case reproducible
+                    raise AssertionError(f"case {case}: rows {rows} q {q} topn {topn}: {e}") from e
+            batch = int(rng.integers(2, 20))
+            topn = int(rng.choice([1, 7, 100, 128]))
+            qrows = rng.integers(0, rows, size=batch)
+            excl = np.where(rng.random(batch) < 0.8, qrows, -1).astype(np.int64)
+            idx, sc, counts = eng.query_batch_topn(f[qrows], excl, topn)
+            for b in range(batch):
+                want = oracle.scores(f, f[qrows[b]])
+                try:
+                    assert_topn_matches(idx[b][:counts[b]], sc[b][:counts[b]], want, int(excl[b]), topn)
+                except AssertionError as e:  # pragma: no cover
+                    raise AssertionError(f"case {case} batch {b}: rows {rows} q {qrows[b]} excl {excl[b]} topn {topn}: {e}") from e
+
+
+def test_two_handles_on_two_streams_share_one_matrix():
+    """Concurrency the documented way: one handle per stream over the same
+    borrowed device matrix; interleaved queries must not disturb each other."""
+    import torch
+    from spotify_recommender_amd.engine import CosineEngine, unpack_keys
+    rng = np.random.default_rng(9)
+    f = rng.random((500_000, 12), dtype=np.float32)
+    t = torch.from_numpy(f).cuda()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    rows = rng.integers(0, f.shape[0], size=24).tolist()
+    with CosineEngine(t) as a, CosineEngine(t) as b:
+        out = torch.zeros(len(rows) * 50, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        for i, r in enumerate(rows):
+            eng, st = (a, s1) if i % 2 == 0 else (b, s2)
+            eng.enqueue_row_keys(r, 50, out[i * 50:(i + 1) * 50], stream=st)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().reshape(len(rows), 50)
+        for i, r in enumerate(rows):
+            want = oracle.scores(f, f[r])
+            ci, _ = oracle.topn_canonical(want, r, 50)
+            assert unpack_keys(got[i])[0].tolist() == ci.tolist()
