@@ -55,6 +55,24 @@ __global__ void p_dwordx3(const f3* __restrict__ d, int64_t n_vec, uint32_t* sin
     if (acc == 0x12345678u) sink[blockIdx.x] = acc;
 }
 
+// (d) fp16 shadow rows: 24 B per row, row per lane as 3 x dwordx2
+template <int kRows>
+__global__ void p_half_rowlane(const float2* __restrict__ d, int64_t n_rows, uint32_t* sink) {
+    uint32_t acc = 0;
+    const int64_t tile = (int64_t)blockDim.x * kRows;
+    for (int64_t t0 = (int64_t)blockIdx.x * tile; t0 < n_rows; t0 += (int64_t)gridDim.x * tile) {
+        float2 v[kRows][3];
+#pragma unroll
+        for (int u = 0; u < kRows; ++u) { int64_t r = t0 + u * blockDim.x + threadIdx.x; if (r >= n_rows) r = n_rows - 1;
+            v[u][0] = d[r * 3]; v[u][1] = d[r * 3 + 1]; v[u][2] = d[r * 3 + 2]; }
+#pragma unroll
+        for (int u = 0; u < kRows; ++u)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc ^= __float_as_uint(v[u][k].x) ^ __float_as_uint(v[u][k].y);
+    }
+    if (acc == 0x12345678u) sink[blockIdx.x] = acc;
+}
+
 int main() {
     const int64_t n = 10000000;
     float* d; CK(hipMalloc(&d, n * 48)); CK(hipMemset(d, 1, n * 48));
@@ -72,6 +90,10 @@ int main() {
         float r2 = time([&] { hipLaunchKernelGGL(p_rowlane<2>, dim3(grid), dim3(block), 0, 0, (const float4*)d, n, sink); });
         float x4 = time([&] { hipLaunchKernelGGL(p_dwordx3<4>, dim3(grid), dim3(block), 0, 0, (const f3*)d, n * 4, sink); });
         float x8 = time([&] { hipLaunchKernelGGL(p_dwordx3<8>, dim3(grid), dim3(block), 0, 0, (const f3*)d, n * 4, sink); });
+        float h1 = time([&] { hipLaunchKernelGGL(p_half_rowlane<1>, dim3(grid), dim3(block), 0, 0, (const float2*)d, n, sink); });
+        float h2 = time([&] { hipLaunchKernelGGL(p_half_rowlane<2>, dim3(grid), dim3(block), 0, 0, (const float2*)d, n, sink); });
+        float h4 = time([&] { hipLaunchKernelGGL(p_half_rowlane<4>, dim3(grid), dim3(block), 0, 0, (const float2*)d, n, sink); });
+        printf("   fp16-shadow rows (240 MB): r1 %5.1f r2 %5.1f r4 %5.1f us\n", h1, h2, h4);
         printf("block %3d x %d/CU: float4 u3 %5.1f u6 %5.1f | rowlane r1 %5.1f r2 %5.1f | dwordx3 u4 %5.1f u8 %5.1f  (us)\n", block, bpc, f4a, f4b, r1, r2, x4, x8);
     }
     return 0;
