@@ -313,7 +313,7 @@ int enqueue_multi(mi355rec* h, const float* queries, const int64_t* exclude, int
         }
     }
     const int64_t list_stride = static_cast<int64_t>(h->mgrid) * topn;
-    const bool seeded = h->miters >= 8;
+    const bool seeded = h->miters >= 3;
     if (seeded) {
         for (int g = 0; g < groups; ++g) {
             const int nq = count - g * kMultiQueries < kMultiQueries ? count - g * kMultiQueries : kMultiQueries;
