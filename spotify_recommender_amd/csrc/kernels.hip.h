@@ -654,11 +654,11 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
 
     // Per-query state lives in LDS (broadcast reads), not in ~50 scalar registers.
     // cutoff = -inf disables the pre-filter until the threshold score is > 0.
-    // seed_keys (optional): [kQ][topk] sorted best keys of a SAMPLE of the catalogue
-    // (a first launch of this kernel over each workgroup's first tile, merged).
-    // The sample's topk-th key bounds the global topk-th from below, so every
-    // workgroup starts with a chip-wide threshold instead of re-deriving a weak
-    // local one — the exact re-score path then runs for ~1e-4 of the rows.
+    // seed_keys (optional): slot [query][topk - 1] holds a key that bounds the
+    // catalogue's topk-th best from below (seed_multi_kernel + seed_select_kernel
+    // over a sample, or 0 = none), so every workgroup starts with a chip-wide
+    // threshold instead of re-deriving a weak local one — the exact re-score path
+    // then runs for ~1e-4 of the rows.
     if (tid < kQ) {
         const float norm = query_norm(qarg.q[tid]);
         uint64_t t = 0ull;
@@ -775,6 +775,98 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
         uint64_t* dst = block_lists + (static_cast<int64_t>(query_slot0 + qi) * gridDim.x + blockIdx.x) * topk;
         wave_rank_and_store(s_cand[qi], c, dst, topk);
     }
+}
+
+// ---- seed for the multi-query pass ----------------------------------------------
+// A chip-wide starting threshold per query from a small sample, with the cheap
+// arithmetic only.  seed_multi_kernel: workgroup b looks at the first kSeedBlock
+// rows of region b (regions are `block_stride` rows apart, so the sample is spread
+// over the catalogue) and, per query, every wave writes the best APPROXIMATE
+// cosine of its 64 rows (order-preserving u32 image).  seed_select_kernel: per
+// query the topk-th largest of those grid*waves values, a_K.  Then topk distinct
+// rows have approx >= a_K, hence exact score >= a_K - 2e-6, so
+//     T = a_K - kApproxMargin
+// bounds the catalogue's topk-th exact score from below.  Rows whose exact score
+// is not the plain quotient (|row|*|q| <= 1e-8 -> 0 in the reference, NaN, the
+// excluded row) never enter the sample, and the bound is only used when T > 0.
+constexpr int kSeedBlock = 512;
+constexpr int kSeedWaves = kSeedBlock / 64;
+
+struct SeedQueryArg {
+    float q[kMultiChain][kDim];
+    long long exclude[kMultiChain];
+};
+
+__global__ __launch_bounds__(kSeedBlock) void seed_multi_kernel(
+    const float* __restrict__ feats, int64_t n, int64_t block_stride, int64_t row_base,
+    SeedQueryArg qarg, int n_queries, uint32_t* __restrict__ out /* [query][grid * kSeedWaves] */) {
+    __shared__ float4 s_q[kMultiChain][3];
+    __shared__ float4 s_qc[kMultiChain];  // {1/|q|, |q|^2, unused, unused}
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    if (tid < kMultiChain) {
+        const float norm = query_norm(qarg.q[tid]);
+        s_qc[tid] = make_float4(1.0f / norm, norm * norm, 0.0f, 0.0f);
+        s_q[tid][0] = make_float4(qarg.q[tid][0], qarg.q[tid][1], qarg.q[tid][2], qarg.q[tid][3]);
+        s_q[tid][1] = make_float4(qarg.q[tid][4], qarg.q[tid][5], qarg.q[tid][6], qarg.q[tid][7]);
+        s_q[tid][2] = make_float4(qarg.q[tid][8], qarg.q[tid][9], qarg.q[tid][10], qarg.q[tid][11]);
+    }
+    __syncthreads();
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * block_stride + tid;
+    const bool in_range = r < n;
+    const Row row = load_row(feats, in_range ? r : n - 1);
+    const int64_t g = row_base + r;
+    v2f m = {row.a.x * row.a.x, row.a.y * row.a.y};
+    m = __builtin_elementwise_fma(v2f{row.a.z, row.a.w}, v2f{row.a.z, row.a.w}, m);
+    m = __builtin_elementwise_fma(v2f{row.b.x, row.b.y}, v2f{row.b.x, row.b.y}, m);
+    m = __builtin_elementwise_fma(v2f{row.b.z, row.b.w}, v2f{row.b.z, row.b.w}, m);
+    m = __builtin_elementwise_fma(v2f{row.c.x, row.c.y}, v2f{row.c.x, row.c.y}, m);
+    m = __builtin_elementwise_fma(v2f{row.c.z, row.c.w}, v2f{row.c.z, row.c.w}, m);
+    const float nrm2 = m.x + m.y;
+    const float inv_norm = __builtin_amdgcn_rsqf(nrm2);
+    const int64_t per_query = static_cast<int64_t>(gridDim.x) * kSeedWaves;
+    for (int qi = 0; qi < n_queries; ++qi) {
+        const float4 qa = s_q[qi][0], qb = s_q[qi][1], qcv = s_q[qi][2];
+        const float4 qc = s_qc[qi];
+        v2f d = {row.a.x * qa.x, row.a.y * qa.y};
+        d = __builtin_elementwise_fma(v2f{row.a.z, row.a.w}, v2f{qa.z, qa.w}, d);
+        d = __builtin_elementwise_fma(v2f{row.b.x, row.b.y}, v2f{qb.x, qb.y}, d);
+        d = __builtin_elementwise_fma(v2f{row.b.z, row.b.w}, v2f{qb.z, qb.w}, d);
+        d = __builtin_elementwise_fma(v2f{row.c.x, row.c.y}, v2f{qcv.x, qcv.y}, d);
+        d = __builtin_elementwise_fma(v2f{row.c.z, row.c.w}, v2f{qcv.z, qcv.w}, d);
+        float a = (d.x + d.y) * inv_norm * qc.x;
+        // (|row| * |q|)^2 comfortably above (1e-8)^2, finite, not the excluded row
+        const bool ok = in_range && g != qarg.exclude[qi] && (nrm2 * qc.y > 4e-16f) && (a - a == 0.0f);
+        if (!ok) a = -__builtin_inff();
+        const uint32_t best = wave_max_u32(score_to_ordered(a));
+        if (lane == 0) out[qi * per_query + static_cast<int64_t>(blockIdx.x) * kSeedWaves + wave] = best;
+    }
+}
+
+constexpr int kSeedSelectPerThread = 8;  // up to kMergeBlock * 8 sample maxima per query
+
+__global__ __launch_bounds__(kMergeBlock) void seed_select_kernel(
+    const uint32_t* __restrict__ vals, int count, int topk, uint64_t* __restrict__ seed_keys) {
+    __shared__ SelectSmem s_sel;
+    const int tid = threadIdx.x;
+    const uint32_t* mine_vals = vals + static_cast<int64_t>(blockIdx.x) * count;
+    uint64_t mine[kSeedSelectPerThread];
+#pragma unroll
+    for (int r = 0; r < kSeedSelectPerThread; ++r) {
+        const int i = tid + r * kMergeBlock;
+        // unique keys: value in the high word, position in the low word
+        mine[r] = i < count ? ((static_cast<uint64_t>(mine_vals[i]) << 32) | static_cast<uint32_t>(i + 1)) : 0ull;
+    }
+    uint64_t t = 0ull;
+    if (count >= topk) {  // uniform
+        const uint64_t kth = block_select_threshold<kMergeBlock, kSeedSelectPerThread>(mine, topk, true, 0, s_sel);
+        const float a_k = ordered_to_score(static_cast<uint32_t>(kth >> 32));
+        const float bound = a_k - kApproxMargin;  // -inf stays -inf
+        if (bound > 0.0f) t = static_cast<uint64_t>(score_to_ordered(bound)) << 32;
+    }
+    // scan_multi_kernel reads slot [query][topk - 1] as "the sample's topk-th key"
+    if (tid == 0) seed_keys[static_cast<int64_t>(blockIdx.x) * topk + (topk - 1)] = t;
 }
 
 // ---- merge of sorted candidate lists -----------------------------------------

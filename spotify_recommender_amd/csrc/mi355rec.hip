@@ -62,6 +62,7 @@ struct mi355rec {
     int miters = 0;
 
     uint64_t* d_block_lists = nullptr;  // grid x kMaxTopK
+    uint32_t* d_seed_vals = nullptr;    // kMultiChain x (mgrid * kSeedWaves) sample maxima
     uint64_t* d_seed_keys = nullptr;    // kMultiChain x kMultiMaxTopK: sample top-k per query of a multi-query chain
 
     // resources of the synchronous host API
@@ -205,6 +206,8 @@ int create_common(const float* feats, bool on_device, int64_t n, int dim, int de
     if (multi_words > list_words) list_words = multi_words;
     if ((e = hipMalloc(&h->d_block_lists, sizeof(uint64_t) * list_words)) != hipSuccess)
         return cleanup(MI355REC_ERR_OUT_OF_MEMORY, "hipMalloc(block lists)", e);
+    if ((e = hipMalloc(&h->d_seed_vals, sizeof(uint32_t) * kMultiChain * static_cast<size_t>(h->mgrid) * kSeedWaves)) != hipSuccess)
+        return cleanup(MI355REC_ERR_OUT_OF_MEMORY, "hipMalloc(seed values)", e);
     if ((e = hipMalloc(&h->d_seed_keys, sizeof(uint64_t) * kMultiChain * kMultiMaxTopK)) != hipSuccess)
         return cleanup(MI355REC_ERR_OUT_OF_MEMORY, "hipMalloc(seed keys)", e);
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess)
@@ -313,18 +316,22 @@ int enqueue_multi(mi355rec* h, const float* queries, const int64_t* exclude, int
         }
     }
     const int64_t list_stride = static_cast<int64_t>(h->mgrid) * topn;
-    const bool seeded = h->miters >= 3;
+    const int seed_count = h->mgrid * kSeedWaves;
+    const bool seeded = h->miters >= 3 && seed_count >= topn && seed_count <= kMergeBlock * kSeedSelectPerThread;
     if (seeded) {
-        for (int g = 0; g < groups; ++g) {
-            const int nq = count - g * kMultiQueries < kMultiQueries ? count - g * kMultiQueries : kMultiQueries;
-            hipLaunchKernelGGL((scan_multi_kernel<MultiConfig>), dim3(h->mgrid), dim3(MultiConfig::kBlock), 0, s,
-                               h->d_feats, h->n, static_cast<int64_t>(MultiConfig::kTileRows), h->mrows_per_block, 1,
-                               h->row_base, qa[g], nq, g * kMultiQueries, topn, h->d_block_lists,
-                               static_cast<const uint64_t*>(nullptr));
+        // one cheap launch for the whole chain: approximate scores of a spread
+        // 2.6 % sample, then the per-query bound (kernels.hip.h, "seed")
+        SeedQueryArg sq;
+        std::memset(&sq, 0, sizeof sq);
+        for (int q = 0; q < kMultiChain; ++q) sq.exclude[q] = -1;
+        for (int q = 0; q < count; ++q) {
+            std::memcpy(sq.q[q], queries + static_cast<size_t>(q) * kDim, sizeof(float) * kDim);
+            if (exclude) sq.exclude[q] = exclude[q];
         }
-        hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(kMergeBlock), 0, s, h->d_block_lists, h->mgrid, topn,
-                           static_cast<int64_t>(topn), list_stride, topn, h->d_seed_keys, static_cast<int64_t*>(nullptr),
-                           static_cast<float*>(nullptr), static_cast<int64_t>(topn));
+        hipLaunchKernelGGL(seed_multi_kernel, dim3(h->mgrid), dim3(kSeedBlock), 0, s, h->d_feats, h->n,
+                           h->mrows_per_block, h->row_base, sq, count, h->d_seed_vals);
+        hipLaunchKernelGGL(seed_select_kernel, dim3(count), dim3(kMergeBlock), 0, s, h->d_seed_vals, seed_count,
+                           topn, h->d_seed_keys);
     }
     for (int g = 0; g < groups; ++g) {
         const int nq = count - g * kMultiQueries < kMultiQueries ? count - g * kMultiQueries : kMultiQueries;
@@ -400,6 +407,7 @@ void mi355rec_destroy(mi355rec_t* h) {
     if (h->owned_feats) (void)hipFree(h->owned_feats);
     if (h->d_block_lists) (void)hipFree(h->d_block_lists);
     if (h->d_seed_keys) (void)hipFree(h->d_seed_keys);
+    if (h->d_seed_vals) (void)hipFree(h->d_seed_vals);
     if (h->d_keys) (void)hipFree(h->d_keys);
     if (h->d_idx) (void)hipFree(h->d_idx);
     if (h->d_score) (void)hipFree(h->d_score);
