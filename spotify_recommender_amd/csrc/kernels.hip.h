@@ -118,6 +118,7 @@ __device__ __forceinline__ float cosine_score(const float (&q)[kDim], float qn,
 // reference's "den <= 1e-8 -> 0" rows can never qualify.
 constexpr float kApproxMargin = 8e-6f;
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float approx_cosine(const float (&q)[kDim], float inv_qn, const Row& r) {
     const float f[kDim] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y,
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
     __shared__ int s_count[kQ];
     __shared__ uint64_t s_thr[kQ];   // running filter threshold per query (key > thr passes)
     __shared__ float4 s_qc[kQ];      // {cutoff of the approx pre-filter, 1/|q|, |q|, unused}
-    __shared__ float4 s_q[kQ][3];    // the query vectors (broadcast reads; 96 SGPRs would spill)
+    __shared__ v4f s_q[kQ][3];       // the query vectors (broadcast ds_read_b128; 96 SGPRs would spill)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -672,9 +673,9 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
         s_count[tid] = 0;
         s_thr[tid] = t;
         s_qc[tid] = make_float4(cut, 1.0f / norm, norm, 0.0f);
-        s_q[tid][0] = make_float4(qarg.q[tid][0], qarg.q[tid][1], qarg.q[tid][2], qarg.q[tid][3]);
-        s_q[tid][1] = make_float4(qarg.q[tid][4], qarg.q[tid][5], qarg.q[tid][6], qarg.q[tid][7]);
-        s_q[tid][2] = make_float4(qarg.q[tid][8], qarg.q[tid][9], qarg.q[tid][10], qarg.q[tid][11]);
+        s_q[tid][0] = v4f{qarg.q[tid][0], qarg.q[tid][1], qarg.q[tid][2], qarg.q[tid][3]};
+        s_q[tid][1] = v4f{qarg.q[tid][4], qarg.q[tid][5], qarg.q[tid][6], qarg.q[tid][7]};
+        s_q[tid][2] = v4f{qarg.q[tid][8], qarg.q[tid][9], qarg.q[tid][10], qarg.q[tid][11]};
     }
     __syncthreads();
 
@@ -703,22 +704,23 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
             inv_norm[u] = __builtin_amdgcn_rsqf(m.x + m.y);
         }
         for (int qi = 0; qi < n_queries; ++qi) {  // uniform trip count
-            const float4 qa = s_q[qi][0], qb = s_q[qi][1], qcv = s_q[qi][2];
+            // three broadcast ds_read_b128; the .xy / .zw halves feed the packed FMAs directly
+            const v4f qa = s_q[qi][0], qb = s_q[qi][1], qcv = s_q[qi][2];
             const float4 qc = s_qc[qi];
-            const float q[kDim] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, qcv.x, qcv.y, qcv.z, qcv.w};
 #pragma unroll
             for (int u = 0; u < kRowsPerThread; ++u) {
                 const Row& row = rows[u];
-                v2f d = {row.a.x * q[0], row.a.y * q[1]};
-                d = __builtin_elementwise_fma(v2f{row.a.z, row.a.w}, v2f{q[2], q[3]}, d);
-                d = __builtin_elementwise_fma(v2f{row.b.x, row.b.y}, v2f{q[4], q[5]}, d);
-                d = __builtin_elementwise_fma(v2f{row.b.z, row.b.w}, v2f{q[6], q[7]}, d);
-                d = __builtin_elementwise_fma(v2f{row.c.x, row.c.y}, v2f{q[8], q[9]}, d);
-                d = __builtin_elementwise_fma(v2f{row.c.z, row.c.w}, v2f{q[10], q[11]}, d);
+                v2f d = v2f{row.a.x, row.a.y} * qa.xy;
+                d = __builtin_elementwise_fma(v2f{row.a.z, row.a.w}, qa.zw, d);
+                d = __builtin_elementwise_fma(v2f{row.b.x, row.b.y}, qb.xy, d);
+                d = __builtin_elementwise_fma(v2f{row.b.z, row.b.w}, qb.zw, d);
+                d = __builtin_elementwise_fma(v2f{row.c.x, row.c.y}, qcv.xy, d);
+                d = __builtin_elementwise_fma(v2f{row.c.z, row.c.w}, qcv.zw, d);
                 const bool maybe = !((d.x + d.y) * inv_norm[u] * qc.y < qc.x);
                 if (__ballot(maybe)) {
                     const int64_t r = tile_begin + u * kBlock + tid;
                     const int64_t g = row_base + r;
+                    const float q[kDim] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, qcv.x, qcv.y, qcv.z, qcv.w};
                     const float s = cosine_score(q, qc.z, row);
                     uint64_t key = pack_key(s, static_cast<uint32_t>(g));
                     if (r >= blk_end || g == qarg.exclude[qi]) key = 0;
@@ -800,7 +802,7 @@ struct SeedQueryArg {
 __global__ __launch_bounds__(kSeedBlock) void seed_multi_kernel(
     const float* __restrict__ feats, int64_t n, int64_t block_stride, int64_t row_base,
     SeedQueryArg qarg, int n_queries, uint32_t* __restrict__ out /* [query][grid * kSeedWaves] */) {
-    __shared__ float4 s_q[kMultiChain][3];
+    __shared__ v4f s_q[kMultiChain][3];
     __shared__ float4 s_qc[kMultiChain];  // {1/|q|, |q|^2, unused, unused}
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -808,9 +810,9 @@ __global__ __launch_bounds__(kSeedBlock) void seed_multi_kernel(
     if (tid < kMultiChain) {
         const float norm = query_norm(qarg.q[tid]);
         s_qc[tid] = make_float4(1.0f / norm, norm * norm, 0.0f, 0.0f);
-        s_q[tid][0] = make_float4(qarg.q[tid][0], qarg.q[tid][1], qarg.q[tid][2], qarg.q[tid][3]);
-        s_q[tid][1] = make_float4(qarg.q[tid][4], qarg.q[tid][5], qarg.q[tid][6], qarg.q[tid][7]);
-        s_q[tid][2] = make_float4(qarg.q[tid][8], qarg.q[tid][9], qarg.q[tid][10], qarg.q[tid][11]);
+        s_q[tid][0] = v4f{qarg.q[tid][0], qarg.q[tid][1], qarg.q[tid][2], qarg.q[tid][3]};
+        s_q[tid][1] = v4f{qarg.q[tid][4], qarg.q[tid][5], qarg.q[tid][6], qarg.q[tid][7]};
+        s_q[tid][2] = v4f{qarg.q[tid][8], qarg.q[tid][9], qarg.q[tid][10], qarg.q[tid][11]};
     }
     __syncthreads();
     const int64_t r = static_cast<int64_t>(blockIdx.x) * block_stride + tid;
@@ -827,14 +829,14 @@ __global__ __launch_bounds__(kSeedBlock) void seed_multi_kernel(
     const float inv_norm = __builtin_amdgcn_rsqf(nrm2);
     const int64_t per_query = static_cast<int64_t>(gridDim.x) * kSeedWaves;
     for (int qi = 0; qi < n_queries; ++qi) {
-        const float4 qa = s_q[qi][0], qb = s_q[qi][1], qcv = s_q[qi][2];
+        const v4f qa = s_q[qi][0], qb = s_q[qi][1], qcv = s_q[qi][2];
         const float4 qc = s_qc[qi];
-        v2f d = {row.a.x * qa.x, row.a.y * qa.y};
-        d = __builtin_elementwise_fma(v2f{row.a.z, row.a.w}, v2f{qa.z, qa.w}, d);
-        d = __builtin_elementwise_fma(v2f{row.b.x, row.b.y}, v2f{qb.x, qb.y}, d);
-        d = __builtin_elementwise_fma(v2f{row.b.z, row.b.w}, v2f{qb.z, qb.w}, d);
-        d = __builtin_elementwise_fma(v2f{row.c.x, row.c.y}, v2f{qcv.x, qcv.y}, d);
-        d = __builtin_elementwise_fma(v2f{row.c.z, row.c.w}, v2f{qcv.z, qcv.w}, d);
+        v2f d = v2f{row.a.x, row.a.y} * qa.xy;
+        d = __builtin_elementwise_fma(v2f{row.a.z, row.a.w}, qa.zw, d);
+        d = __builtin_elementwise_fma(v2f{row.b.x, row.b.y}, qb.xy, d);
+        d = __builtin_elementwise_fma(v2f{row.b.z, row.b.w}, qb.zw, d);
+        d = __builtin_elementwise_fma(v2f{row.c.x, row.c.y}, qcv.xy, d);
+        d = __builtin_elementwise_fma(v2f{row.c.z, row.c.w}, qcv.zw, d);
         float a = (d.x + d.y) * inv_norm * qc.x;
         // (|row| * |q|)^2 comfortably above (1e-8)^2, finite, not the excluded row
         const bool ok = in_range && g != qarg.exclude[qi] && (nrm2 * qc.y > 4e-16f) && (a - a == 0.0f);
