@@ -327,7 +327,7 @@ __device__ inline uint64_t compact_candidates(uint64_t* s_cand, int* s_count, in
 // wave-level load instruction covers one contiguous 3 KiB span.  One lane = one row: the 12-term sums are
 // sequential in-lane, which is what makes the result bit-identical to the
 // reference CPU loop.  The next tile is loaded before the current one is
-// scored so ~200 KiB per CU stay in flight.
+// scored (24 waves x 64 lanes x 2 tiles x 48 B = ~150 KiB per CU in flight).
 //
 // kScoresOnly: write the n scores (mirrors calculateSimilarities' output).
 // else: filter keys against the workgroup's running topk-th key, append the
@@ -643,8 +643,8 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    // block_stride == rows_per_block: the workgroups tile the shard.  A larger
-    // stride makes each workgroup scan only the head of its region (seed pass).
+    // rows_per_block > 0 (development harness): workgroup b scans rows_per_block
+    // rows starting at b * block_stride.
     // rows_per_block == 0: tiles dealt round-robin over the workgroups (full pass).
     const bool interleaved = rows_per_block == 0;
     const int64_t blk_begin = static_cast<int64_t>(blockIdx.x) * (interleaved ? kTileRows : block_stride);

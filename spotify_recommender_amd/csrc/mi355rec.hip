@@ -123,7 +123,7 @@ void plan_grid(mi355rec* h, int blocks_per_cu) {
 }
 
 // Multi-query pass: same round-robin tile mapping for the full pass; the seed
-// pass scans the first tile of `mgrid` evenly spaced regions (mseed_stride rows
+// kernel samples the first 512 rows of `mgrid` evenly spaced regions (mrows_per_block rows
 // apart) so that the sample also represents catalogues that are ordered.
 void plan_multi_grid(mi355rec* h, int blocks_per_cu) {
     int64_t max_blocks = static_cast<int64_t>(h->cus) * blocks_per_cu;
@@ -134,7 +134,7 @@ void plan_multi_grid(mi355rec* h, int blocks_per_cu) {
     int64_t stride = h->n / h->mgrid;
     stride = stride / 64 * 64;
     if (stride < MultiConfig::kTileRows) stride = MultiConfig::kTileRows;
-    h->mrows_per_block = stride;  // seed pass only: distance between sampled regions
+    h->mrows_per_block = stride;  // seed kernel only: distance between sampled regions
 }
 
 int create_common(const float* feats, bool on_device, int64_t n, int dim, int device,
@@ -295,11 +295,10 @@ int enqueue_merge(mi355rec* h, const uint64_t* lists, int n_lists, int list_len,
     return MI355REC_OK;
 }
 
-// Multi-query passes for up to kMultiChain queries: per group of kMultiQueries a
-// seed pass (every workgroup scans the first tile of its region: a ~2.5 % sample
-// that yields a chip-wide starting threshold per query), ONE merge launch for all
-// seeds, then per group the full pass (the catalogue is streamed once per group),
-// then ONE merge launch with a workgroup per query.  topn <= kMultiMaxTopK.
+// Multi-query passes for up to kMultiChain queries: ONE cheap seed (approximate
+// scores of a spread ~2.6 % sample -> a chip-wide starting threshold per query),
+// then per group of kMultiQueries the full pass (the catalogue is streamed once per
+// group), then ONE merge launch with a workgroup per query.  topn <= kMultiMaxTopK.
 int enqueue_multi(mi355rec* h, const float* queries, const int64_t* exclude, int count, int topn,
                   uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s) {
     MultiQueryArg qa[kMultiChain / kMultiQueries];

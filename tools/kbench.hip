@@ -138,7 +138,8 @@ int main(int argc, char** argv) {
         return 0;
     }
     if (mode == "multi8") {   // one clean configuration for counter collection
-        run_multi<MultiCfg<512, 1, 4>>("M512x1", 2, 8, h);
+        const int nq = argc > 5 ? atoi(argv[5]) : 8;   // <= kMultiQueries of this build
+        run_multi<MultiCfg<512, 1, 4>>("M512x1", 2, nq, h);
         return 0;
     }
     if (mode == "sweep") {
