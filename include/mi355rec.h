@@ -121,7 +121,7 @@ int mi355rec_query_topn(mi355rec_t* h, const float* query12,
 /* `batch` independent queries (batch x 12 floats); exclude may be NULL.
  * Outputs are batch x topn, each row padded with idx -1 / score 0;
  * out_count has `batch` entries.  With batch > 1 and topn <= 128 the queries
- * run as multi-query passes (8 queries per scan of the catalogue). */
+ * run as multi-query passes (12 queries per scan of the catalogue). */
 int mi355rec_query_batch_topn(mi355rec_t* h, const float* queries, int batch,
                               const int64_t* exclude_global, int topn,
                               int64_t* out_idx, float* out_score, int* out_count);
@@ -143,7 +143,7 @@ int mi355rec_enqueue_query_keys(mi355rec_t* h, const float* query12,
                                 mi355rec_key_t* out_keys_dev, void* stream);
 
 /* `batch` queries (batch x 12 floats, host; exclude_global may be NULL) in
- * multi-query passes: every pass streams the shard ONCE for up to 8 queries
+ * multi-query passes: every pass streams the shard ONCE for up to 12 queries
  * (topn <= 128; larger topn falls back to one scan per query).  Writes
  * batch x topn packed keys (each row sorted descending, 0-padded). */
 int mi355rec_enqueue_batch_keys(mi355rec_t* h, const float* queries,

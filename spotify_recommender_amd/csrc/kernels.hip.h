@@ -478,8 +478,8 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
 // ---- multi-query streaming scan ------------------------------------------------
 // One pass over the catalogue scores kQ queries at once: the 48 B of a row are
 // fetched once and reused from registers, so the pass costs about the same HBM
-// time as a single query while answering kQ of them (still memory-bound at
-// kQ = 8: ~8 + 14*kQ VALU instructions per row).  Per query the logic is the
+// time as a single query while answering kQ of them (~8 + 16*kQ VALU instructions
+// per 64 rows; 135 us for 12 queries vs 84 us for one at 10 M rows).  Per query the logic is the
 // single-query kernel's: packed-FMA upper bound against that query's running
 // threshold, exact in-order re-score of the rare rows that may beat it, LDS
 // candidate buffer, O(c) radix select when candidates pile up.  Differences:
@@ -489,10 +489,10 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
 //  * the row norm (6 packed FMAs + rsq) is shared by all queries.
 // Output: block_lists[q][workgroup][topk], each list sorted descending.
 
-constexpr int kMultiQueries = 8;      // queries per pass
-constexpr int kMultiChain = 32;       // queries whose seed / final merges share one launch
+constexpr int kMultiQueries = 12;     // queries per pass (12 x 5.5 KB of candidates: 2 workgroups per CU)
+constexpr int kMultiChain = 36;       // queries whose seed / final merges share one launch
 constexpr int kMultiMaxTopK = 128;    // larger topn goes through the single-query kernel
-constexpr int kMultiCompactAt = 256;  // >= 2 * kMultiMaxTopK
+constexpr int kMultiCompactAt = 192;  // > kMultiMaxTopK + the select's slack (32): a compaction always makes room
 
 template <int kBlockT, int kRowsT, int kMinWavesT>
 struct MultiCfg {

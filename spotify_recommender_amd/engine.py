@@ -157,7 +157,7 @@ class CosineEngine:
             ctypes.c_void_p(out_keys.data_ptr()), self._stream_ptr(stream)), self._h)
 
     def enqueue_batch_keys(self, queries, exclude_global, topn: int, out_keys, stream=None) -> None:
-        """Multi-query passes: 8 queries share one scan of the shard (topn <= 128)."""
+        """Multi-query passes: 12 queries share one scan of the shard (topn <= 128)."""
         q = _np_f32(queries).reshape(-1, capi.DIM)
         excl = None
         if exclude_global is not None:
