@@ -249,6 +249,10 @@ class ShardedEngine:
         self.rank = dist.get_rank(group)
         self.max_topn = int(max_topn)
         self.always_gather = bool(always_gather)  # run the collective even at world size 1
+        # RCCL gathers device tensors directly.  Under gloo (CPU rehearsals, or several
+        # ranks sharing one GPU in a test) the keys are staged through host memory.
+        self._stage_host = str(dist.get_backend(group)).lower() == "gloo" and torch.device(
+            device if device is not None else "cuda").type == "cuda"
         dev = device if device is not None else torch.device("cuda", local.device)
         self.device = dev
         self.local_keys = torch.zeros(self.max_topn, dtype=torch.int64, device=dev)
@@ -256,6 +260,14 @@ class ShardedEngine:
         self.out_keys = torch.zeros(self.max_topn, dtype=torch.int64, device=dev)
         self.out_idx = torch.full((self.max_topn,), -1, dtype=torch.int64, device=dev)
         self.out_score = torch.zeros(self.max_topn, dtype=torch.float32, device=dev)
+
+    def _all_gather(self, gathered, local) -> None:
+        if not self._stage_host:
+            self._dist.all_gather_into_tensor(gathered, local, group=self.group)
+            return
+        host_out = self._torch.empty(gathered.shape, dtype=gathered.dtype)
+        self._dist.all_gather_into_tensor(host_out, local.cpu(), group=self.group)
+        gathered.copy_(host_out)
 
     def enqueue_query(self, query, exclude_global: int, topn: int) -> None:
         """Scan the local shard, all-gather the candidates, merge on device."""
@@ -268,7 +280,7 @@ class ShardedEngine:
             gathered = local
         else:
             gathered = self.gathered[: self.world * k]
-            self._dist.all_gather_into_tensor(gathered, local, group=self.group)
+            self._all_gather(gathered, local)
         self.local.enqueue_merge_keys(gathered, self.world, k, k, self.out_keys[:k],
                                       self.out_idx[:k], self.out_score[:k])
 
@@ -294,7 +306,7 @@ class ShardedEngine:
             gathered = local
         else:
             gathered = self._b_gather[: self.world * need]
-            self._dist.all_gather_into_tensor(gathered, local, group=self.group)
+            self._all_gather(gathered, local)
         self.local.enqueue_merge_keys_batch(gathered, self.world, k, need, k, b, k, self._b_keys[:need],
                                             self._b_idx[:need], self._b_score[:need])
         self.batch_keys = self._b_keys[:need].view(b, k)
