@@ -16,6 +16,13 @@
  * (never throws across the boundary); the caller owns every in/out buffer; the
  * library owns device memory it allocates.  A handle is not re-entrant: use it
  * from one host thread at a time (as the reference's Recommender).
+ * Streams: all launches of one handle share its scratch buffers.  Calls on the
+ * same stream are ordered by the stream; when the stream changes from one call
+ * to the next (including between the asynchronous API and the synchronous one,
+ * which runs on a private stream) the library inserts an event so the later
+ * call waits for the earlier one.  For CONCURRENT queries use one handle per
+ * stream (handles may share one device matrix through mi355rec_create_device).
+ * A stream passed to a call must stay alive until the handle's next call.
  * There is NO CPU fallback: without a gfx950 device every call fails with
  * MI355REC_ERR_NO_DEVICE.
  *
@@ -77,13 +84,17 @@ const char* mi355rec_last_global_error(void);
  * n x 12 fp32 matrix (the reference flattens vector<Song> into exactly this,
  * Recommender.cu:162-167).  The matrix is copied to `device` once.
  * `row_base` is the global index of row 0 (0 unless this is one shard of a
- * row-sharded catalogue).  dim must be 12.  n in [1, 2^32-2]. */
+ * row-sharded catalogue).  dim must be 12.  n in [0, 2^32-2]; n == 0 is an
+ * EMPTY SHARD (feats may be NULL): its queries return all-empty lists, so a
+ * rank that owns no rows still takes part in the merge. */
 int mi355rec_create(const float* feats_host, int64_t n, int dim, int device,
                     int64_t row_base, mi355rec_t** out);
 
 /* Same, over a matrix that is ALREADY resident in device memory (e.g. a torch
  * tensor's data_ptr).  The memory is borrowed, not copied, and must outlive
- * the handle; it must be 16-byte aligned. */
+ * the handle; it must be 16-byte aligned.  The call synchronises the device
+ * once, so a matrix still being produced on another stream is complete before
+ * the first query; ordering LATER writes to it is the caller's business. */
 int mi355rec_create_device(const float* feats_dev, int64_t n, int dim,
                            int device, int64_t row_base, mi355rec_t** out);
 

@@ -259,6 +259,19 @@ bool DataManager::loadData(const std::string& binaryPath, std::vector<Song>& son
         std::cerr << "Error: Corrupt binary file: " << binaryPath << std::endl;
         return false;
     }
+    // The header is not trusted (the reference trusts it, DataManager.cpp:375-402):
+    // every song occupies at least 3 lengths + genre id + 12 features, so a count
+    // the remaining bytes cannot hold is a corrupt file, not a 650 GB resize.
+    const std::streampos body = in.tellg();
+    in.seekg(0, std::ios::end);
+    const std::streampos fileEnd = in.tellg();
+    in.seekg(body);
+    const size_t minRecord = 3 * sizeof(size_t) + sizeof(int) + FEATURE_COUNT * sizeof(float);
+    if (!in || body < 0 || fileEnd < body ||
+        numSongs > static_cast<size_t>(fileEnd - body) / minRecord) {
+        std::cerr << "Error: Corrupt binary file: " << binaryPath << std::endl;
+        return false;
+    }
     songs.clear();
     songs.resize(numSongs);
     for (size_t i = 0; i < numSongs; ++i) {

@@ -99,6 +99,10 @@ std::vector<int> Recommender::recommendByIndex(int songIndex, int topN) {  // Re
         std::cerr << "Error: topN must be positive" << std::endl;
         return {};
     }
+    // The reference's heap never holds more than N-1 entries (Recommender.cu:296-305):
+    // a larger topN returns N-1 results, and must not size any buffer.
+    if (topN > impl_->numSongs - 1) topN = impl_->numSongs - 1;
+    if (topN == 0) return {};  // a one-song catalogue has nothing to recommend
     impl_->idxBuf.assign(static_cast<size_t>(topN), -1);
     impl_->scoreBuf.assign(static_cast<size_t>(topN), 0.0f);
     int count = 0;

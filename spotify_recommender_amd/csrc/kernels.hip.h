@@ -116,7 +116,17 @@ __device__ __forceinline__ float cosine_score(const float (&q)[kDim], float qn,
 // kApproxMargin; everything else (NaN included) is re-scored with
 // cosine_score().  Only used while the threshold score is > 0, where the
 // reference's "den <= 1e-8 -> 0" rows can never qualify.
+// The bound only holds while no fp32 sum overflows: in a different summation
+// order an overflow can appear in one chain and not in the other (e.g. q =
+// (1e19,1e19,1e19,0..), f = (3e19,3e19,-3e19,0..): the reference's sequential
+// chain gives inf/inf = NaN -> clamped to 1.0, the paired chain a finite 0).
+// So the pre-filter is trusted only for |row|^2 < kApproxMaxNorm2 (checked per
+// row: anything else is re-scored exactly) and |q| < kApproxMaxQueryNorm
+// (checked once per query: otherwise the pre-filter stays off); then
+// |partial sums| <= |row||q| < 1e37 in every order.
 constexpr float kApproxMargin = 8e-6f;
+constexpr float kApproxMaxNorm2 = 1e37f;
+constexpr float kApproxMaxQueryNorm = 3e18f;
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -132,7 +142,9 @@ __device__ __forceinline__ float approx_cosine(const float (&q)[kDim], float inv
         d = __builtin_elementwise_fma(ff, qq, d);
         m = __builtin_elementwise_fma(ff, ff, m);
     }
-    return (d.x + d.y) * __builtin_amdgcn_rsqf(m.x + m.y) * inv_qn;
+    const float nrm2 = m.x + m.y;
+    const float a = (d.x + d.y) * __builtin_amdgcn_rsqf(nrm2) * inv_qn;
+    return nrm2 < kApproxMaxNorm2 ? a : __builtin_nanf("");  // NaN = "cannot tell": the caller re-scores exactly
 }
 
 __device__ __forceinline__ Row load_row(const float* __restrict__ feats, int64_t row) {
@@ -386,6 +398,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
     uint64_t thr = 0;
     float cutoff = 0.0f;  // approx pre-filter active only while > 0
     const float inv_qn = 1.0f / qn;
+    const bool prefilter_ok = qn < kApproxMaxQueryNorm;  // false for inf / NaN norms too
     if constexpr ((kDebug & 4) != 0) {
         thr = pack_key(0.985f, 0u);
         cutoff = 0.985f - kApproxMargin;
@@ -446,7 +459,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
                 const uint64_t local_thr = compact_candidates<kBlock, Cfg::kCandPerThread>(s_cand, &s_count, topk, false, s_sel);
                 if (local_thr > thr) {
                     thr = local_thr;
-                    cutoff = ordered_to_score(static_cast<uint32_t>(thr >> 32)) - kApproxMargin;
+                    if (prefilter_ok) cutoff = ordered_to_score(static_cast<uint32_t>(thr >> 32)) - kApproxMargin;
                 }
             }
         }
@@ -667,7 +680,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
         float cut = -__builtin_inff();
         if (t) {
             const float score = ordered_to_score(static_cast<uint32_t>(t >> 32));
-            if (score > 0.0f) cut = score - kApproxMargin;
+            if (score > 0.0f && norm < kApproxMaxQueryNorm) cut = score - kApproxMargin;
             t -= 1ull;
         }
         s_count[tid] = 0;
@@ -701,7 +714,10 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
             m = __builtin_elementwise_fma(v2f{row.b.z, row.b.w}, v2f{row.b.z, row.b.w}, m);
             m = __builtin_elementwise_fma(v2f{row.c.x, row.c.y}, v2f{row.c.x, row.c.y}, m);
             m = __builtin_elementwise_fma(v2f{row.c.z, row.c.w}, v2f{row.c.z, row.c.w}, m);
-            inv_norm[u] = __builtin_amdgcn_rsqf(m.x + m.y);
+            const float nrm2 = m.x + m.y;
+            // NaN makes every "approx < cutoff" below false: rows whose sums may
+            // overflow are always re-scored exactly (see kApproxMaxNorm2)
+            inv_norm[u] = nrm2 < kApproxMaxNorm2 ? __builtin_amdgcn_rsqf(nrm2) : __builtin_nanf("");
         }
         for (int qi = 0; qi < n_queries; ++qi) {  // uniform trip count
             // three broadcast ds_read_b128; the .xy / .zw halves feed the packed FMAs directly
@@ -749,7 +765,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
                     if (lane == 0 && t > s_thr[qi]) {
                         s_thr[qi] = t;
                         const float score = ordered_to_score(static_cast<uint32_t>(t >> 32));
-                        if (score > 0.0f) s_qc[qi].x = score - kApproxMargin;
+                        if (score > 0.0f && s_qc[qi].z < kApproxMaxQueryNorm) s_qc[qi].x = score - kApproxMargin;
                     }
                 }
             }
@@ -839,7 +855,8 @@ __global__ __launch_bounds__(kSeedBlock) void seed_multi_kernel(
         d = __builtin_elementwise_fma(v2f{row.c.z, row.c.w}, qcv.zw, d);
         float a = (d.x + d.y) * inv_norm * qc.x;
         // (|row| * |q|)^2 comfortably above (1e-8)^2, finite, not the excluded row
-        const bool ok = in_range && g != qarg.exclude[qi] && (nrm2 * qc.y > 4e-16f) && (a - a == 0.0f);
+        const bool ok = in_range && g != qarg.exclude[qi] && (nrm2 * qc.y > 4e-16f) && (a - a == 0.0f) &&
+                        nrm2 < kApproxMaxNorm2 && qc.y < kApproxMaxNorm2;
         if (!ok) a = -__builtin_inff();
         const uint32_t best = wave_max_u32(score_to_ordered(a));
         if (lane == 0) out[qi * per_query + static_cast<int64_t>(blockIdx.x) * kSeedWaves + wave] = best;

@@ -65,6 +65,13 @@ struct mi355rec {
     uint32_t* d_seed_vals = nullptr;    // kMultiChain x (mgrid * kSeedWaves) sample maxima
     uint64_t* d_seed_keys = nullptr;    // kMultiChain x kMultiMaxTopK: sample top-k per query of a multi-query chain
 
+    // Every enqueue uses the handle's scratch (block lists, seed buffers) on the
+    // caller's stream: consecutive uses on DIFFERENT streams are ordered with an
+    // event (order_stream), so results never depend on a sync the caller forgot.
+    hipStream_t last_stream = nullptr;
+    bool has_last_stream = false;
+    hipEvent_t order_ev = nullptr;
+
     // resources of the synchronous host API
     hipStream_t stream = nullptr;
     size_t slot_cap = 0;
@@ -109,6 +116,27 @@ int fail(mi355rec* h, int code, const char* fmt, ...) {
                         __FILE__, __LINE__);                                      \
     } while (0)
 
+// The handle's scratch is shared by all its launches.  When the stream changes
+// between two calls, the new stream first waits for everything the handle has
+// enqueued on the previous one (one event record + one stream wait; nothing when
+// the stream stays the same, which is the serving-loop case).
+int order_stream(mi355rec* h, hipStream_t s) {
+    if (h->has_last_stream && h->last_stream != s) {
+        if (hipEventRecord(h->order_ev, h->last_stream) == hipSuccess) {
+            HIP_TRY(h, hipStreamWaitEvent(s, h->order_ev, 0));
+        } else {
+            (void)hipGetLastError();  // the previous stream no longer exists: nothing left to order against
+        }
+    }
+    h->last_stream = s;
+    h->has_last_stream = true;
+    return MI355REC_OK;
+}
+
+// Synchronous host API: runs on the handle's private stream, after any
+// asynchronous work the caller enqueued through this handle.
+int sync_api_begin(mi355rec* h) { return order_stream(h, h->stream); }
+
 // Single-query scan: tiles of kScanTileRows rows are dealt round-robin over the
 // resident workgroups (rows_per_block = 0 selects that mapping in the kernel), so
 // the chip reads one moving window of the matrix — 3 % faster than a contiguous
@@ -140,9 +168,11 @@ void plan_multi_grid(mi355rec* h, int blocks_per_cu) {
 int create_common(const float* feats, bool on_device, int64_t n, int dim, int device,
                   int64_t row_base, mi355rec_t** out) {
     if (out) *out = nullptr;
-    if (!out || !feats) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (!out || (!feats && n != 0)) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null argument");
     if (dim != kDim) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "dim must be %d, got %d", kDim, dim);
-    if (n < 1 || row_base < 0 || n + row_base > 0xfffffffell)
+    // n == 0 is an EMPTY SHARD (a rank of a row-sharded catalogue with more ranks
+    // than rows): every query answers with an all-empty list, merges work as usual.
+    if (n < 0 || row_base < 0 || n + row_base > 0xfffffffell)
         return fail(nullptr, MI355REC_ERR_INVALID_ARG, "rows %lld (base %lld) out of range",
                     (long long)n, (long long)row_base);
     int count = 0;
@@ -168,16 +198,20 @@ int create_common(const float* feats, bool on_device, int64_t n, int dim, int de
     }
     h->cus = prop.multiProcessorCount;
 
-    int occ = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel<ScanConfig, true, false>, kScanBlock, 0);
-    if (e != hipSuccess || occ < 1) occ = 1;
-    if (occ > 4) occ = 4;
-    plan_grid(h, occ);
-    int mocc = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&mocc, scan_multi_kernel<MultiConfig>, MultiConfig::kBlock, 0);
-    if (e != hipSuccess || mocc < 1) mocc = 1;
-    if (mocc > 4) mocc = 4;
-    plan_multi_grid(h, mocc);
+    if (n > 0) {
+        int occ = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel<ScanConfig, true, false>, kScanBlock, 0);
+        if (e != hipSuccess || occ < 1) occ = 1;
+        if (occ > 4) occ = 4;
+        plan_grid(h, occ);
+        int mocc = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&mocc, scan_multi_kernel<MultiConfig>, MultiConfig::kBlock, 0);
+        if (e != hipSuccess || mocc < 1) mocc = 1;
+        if (mocc > 4) mocc = 4;
+        plan_multi_grid(h, mocc);
+    } else {
+        h->grid = h->mgrid = 1;  // sizes the (unused) scratch; no scan is ever launched
+    }
 
     int rc = MI355REC_OK;
     auto cleanup = [&](int code, const char* what, hipError_t he) {
@@ -186,7 +220,9 @@ int create_common(const float* feats, bool on_device, int64_t n, int dim, int de
         return rc;
     };
 
-    if (on_device) {
+    if (n == 0) {
+        h->d_feats = nullptr;
+    } else if (on_device) {
         if (reinterpret_cast<uintptr_t>(feats) & 15) {
             delete h;
             return fail(nullptr, MI355REC_ERR_INVALID_ARG, "device matrix must be 16-byte aligned");
@@ -212,6 +248,15 @@ int create_common(const float* feats, bool on_device, int64_t n, int dim, int de
         return cleanup(MI355REC_ERR_OUT_OF_MEMORY, "hipMalloc(seed keys)", e);
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess)
         return cleanup(MI355REC_ERR_HIP, "hipStreamCreate", e);
+    if ((e = hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming)) != hipSuccess)
+        return cleanup(MI355REC_ERR_HIP, "hipEventCreate", e);
+    if (on_device) {
+        // A borrowed matrix may still be being written by a kernel on some caller
+        // stream (e.g. a torch generator): wait once, here, so that no query can
+        // scan it half-written.  Later writes to it are the caller's to order.
+        if ((e = hipDeviceSynchronize()) != hipSuccess)
+            return cleanup(MI355REC_ERR_HIP, "hipDeviceSynchronize", e);
+    }
 
     *out = h;
     return MI355REC_OK;
@@ -362,7 +407,17 @@ int check_topn(mi355rec* h, int topn, bool allow_rounds) {
 // topn is larger (round r only sees keys below the last key of round r-1, read
 // from device memory, so the rounds are enqueued back to back without a sync).
 int enqueue_query(mi355rec* h, int64_t query_row, const float* query12, int64_t exclude_global,
-                  int topn, uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s) {
+                  int topn_asked, uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s) {
+    // A shard of n rows has at most n results (the reference's heap never grows
+    // past N-1, Recommender.cu:300): run only the rounds that can produce keys and
+    // pad the rest, so an absurd topn costs a memset, not topn/1024 catalogue scans.
+    const int topn = static_cast<int64_t>(topn_asked) < h->n ? topn_asked : static_cast<int>(h->n);
+    if (topn < topn_asked) {
+        const size_t pad = static_cast<size_t>(topn_asked - topn);
+        HIP_TRY(h, hipMemsetAsync(out_keys + topn, 0, pad * sizeof(uint64_t), s));
+        if (out_idx) HIP_TRY(h, hipMemsetAsync(out_idx + topn, 0xff, pad * sizeof(int64_t), s));
+        if (out_score) HIP_TRY(h, hipMemsetAsync(out_score + topn, 0, pad * sizeof(float), s));
+    }
     for (int done = 0; done < topn; done += kMaxTopK) {
         const int k = topn - done < kMaxTopK ? topn - done : kMaxTopK;
         const uint64_t* upper = done ? out_keys + done - 1 : nullptr;
@@ -370,6 +425,31 @@ int enqueue_query(mi355rec* h, int64_t query_row, const float* query12, int64_t 
         if (rc) return rc;
         rc = enqueue_merge(h, h->d_block_lists, h->grid, k, k, out_keys + done,
                            out_idx ? out_idx + done : nullptr, out_score ? out_score + done : nullptr, s);
+        if (rc) return rc;
+    }
+    return MI355REC_OK;
+}
+
+// `batch` queries on stream `s`: multi-query passes where they apply (topn <=
+// kMultiMaxTopK), otherwise one scan per query.  Outputs are batch x topn.
+int enqueue_batch(mi355rec* h, const float* queries, const int64_t* exclude_global, int batch, int topn,
+                  uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s) {
+    if (batch > 1 && topn <= kMultiMaxTopK && h->n > 0) {
+        for (int b = 0; b < batch; b += kMultiChain) {
+            const int count = batch - b < kMultiChain ? batch - b : kMultiChain;
+            const size_t off = static_cast<size_t>(b) * topn;
+            const int rc = enqueue_multi(h, queries + static_cast<size_t>(b) * kDim,
+                                         exclude_global ? exclude_global + b : nullptr, count, topn, out_keys + off,
+                                         out_idx ? out_idx + off : nullptr, out_score ? out_score + off : nullptr, s);
+            if (rc) return rc;
+        }
+        return MI355REC_OK;
+    }
+    for (int b = 0; b < batch; ++b) {
+        const size_t off = static_cast<size_t>(b) * topn;
+        const int rc = enqueue_query(h, -1, queries + static_cast<size_t>(b) * kDim,
+                                     exclude_global ? exclude_global[b] : -1, topn, out_keys + off,
+                                     out_idx ? out_idx + off : nullptr, out_score ? out_score + off : nullptr, s);
         if (rc) return rc;
     }
     return MI355REC_OK;
@@ -414,6 +494,7 @@ void mi355rec_destroy(mi355rec_t* h) {
     if (h->h_idx) (void)hipHostFree(h->h_idx);
     if (h->h_score) (void)hipHostFree(h->h_score);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->order_ev) (void)hipEventDestroy(h->order_ev);
     delete h;
 }
 
@@ -475,6 +556,8 @@ int mi355rec_enqueue_row_keys(mi355rec_t* h, int64_t local_row, int topn,
     int rc = check_topn(h, topn, true);
     if (rc) return rc;
     DeviceGuard guard(h->device);
+    rc = order_stream(h, static_cast<hipStream_t>(stream));
+    if (rc) return rc;
     return enqueue_query(h, local_row, nullptr, h->row_base + local_row, topn, out_keys_dev, nullptr, nullptr,
                          static_cast<hipStream_t>(stream));
 }
@@ -485,6 +568,8 @@ int mi355rec_enqueue_query_keys(mi355rec_t* h, const float* query12, int64_t exc
     int rc = check_topn(h, topn, true);
     if (rc) return rc;
     DeviceGuard guard(h->device);
+    rc = order_stream(h, static_cast<hipStream_t>(stream));
+    if (rc) return rc;
     return enqueue_query(h, -1, query12, exclude_global, topn, out_keys_dev, nullptr, nullptr,
                          static_cast<hipStream_t>(stream));
 }
@@ -497,21 +582,9 @@ int mi355rec_enqueue_batch_keys(mi355rec_t* h, const float* queries, const int64
     if (rc) return rc;
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (topn > kMultiMaxTopK) {  // one scan per query
-        for (int b = 0; b < batch; ++b) {
-            rc = enqueue_query(h, -1, queries + static_cast<size_t>(b) * kDim, exclude_global ? exclude_global[b] : -1,
-                               topn, out_keys_dev + static_cast<size_t>(b) * topn, nullptr, nullptr, s);
-            if (rc) return rc;
-        }
-        return MI355REC_OK;
-    }
-    for (int b = 0; b < batch; b += kMultiChain) {
-        const int count = batch - b < kMultiChain ? batch - b : kMultiChain;
-        rc = enqueue_multi(h, queries + static_cast<size_t>(b) * kDim, exclude_global ? exclude_global + b : nullptr,
-                           count, topn, out_keys_dev + static_cast<size_t>(b) * topn, nullptr, nullptr, s);
-        if (rc) return rc;
-    }
-    return MI355REC_OK;
+    rc = order_stream(h, s);
+    if (rc) return rc;
+    return enqueue_batch(h, queries, exclude_global, batch, topn, out_keys_dev, nullptr, nullptr, s);
 }
 
 int mi355rec_enqueue_merge_keys(mi355rec_t* h, const mi355rec_key_t* lists_dev, int n_lists,
@@ -523,6 +596,8 @@ int mi355rec_enqueue_merge_keys(mi355rec_t* h, const mi355rec_key_t* lists_dev, 
     int rc = check_topn(h, topn, false);
     if (rc) return rc;
     DeviceGuard guard(h->device);
+    rc = order_stream(h, static_cast<hipStream_t>(stream));
+    if (rc) return rc;
     return enqueue_merge(h, lists_dev, n_lists, list_len, topn, out_keys_dev, out_idx_dev,
                          out_score_dev, static_cast<hipStream_t>(stream));
 }
@@ -538,6 +613,8 @@ int mi355rec_enqueue_merge_keys_batch(mi355rec_t* h, const mi355rec_key_t* lists
     if (rc) return rc;
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = order_stream(h, s);
+    if (rc) return rc;
     const int slot = timing_begin(h, h->ev_merge, h->n_merge_pairs, h->merge_launches, s);
     hipLaunchKernelGGL(merge_kernel, dim3(batch), dim3(kMergeBlock), 0, s, lists_dev, n_lists, list_len,
                        list_stride, query_stride, topn, out_keys_dev, out_idx_dev, out_score_dev,
@@ -552,8 +629,11 @@ int mi355rec_enqueue_scores(mi355rec_t* h, int64_t local_row, const float* query
     if (!h || !out_scores_dev) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
     if (local_row >= h->n) return fail(h, MI355REC_ERR_INVALID_ARG, "Invalid song index: %lld", (long long)local_row);
     if (local_row < 0 && !query12) return fail(h, MI355REC_ERR_INVALID_ARG, "null query");
+    if (h->n == 0) return MI355REC_OK;  // empty shard: no scores
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = order_stream(h, s);
+    if (rc) return rc;
     QueryArg qa;
     std::memset(&qa, 0, sizeof qa);
     if (local_row >= 0) {
@@ -574,6 +654,7 @@ int mi355rec_enqueue_scores(mi355rec_t* h, int64_t local_row, const float* query
 
 int mi355rec_enqueue_stream_probe(mi355rec_t* h, uint32_t* sink_dev, void* stream) {
     if (!h || !sink_dev) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (h->n == 0) return MI355REC_OK;
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, s);
@@ -589,6 +670,7 @@ int mi355rec_enqueue_stream_probe(mi355rec_t* h, uint32_t* sink_dev, void* strea
 static int scores_common(mi355rec_t* h, int64_t local_row, const float* query12, float* out_host) {
     if (!h || !out_host) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
     DeviceGuard guard(h->device);
+    if (h->n == 0) return MI355REC_OK;
     if (!h->d_scores_full) HIP_TRY(h, hipMalloc(&h->d_scores_full, sizeof(float) * static_cast<size_t>(h->n)));
     int rc = mi355rec_enqueue_scores(h, local_row, query12, h->d_scores_full, h->stream);
     if (rc) return rc;
@@ -617,35 +699,32 @@ int mi355rec_query_batch_topn(mi355rec_t* h, const float* queries, int batch,
     int rc = check_topn(h, topn, true);
     if (rc) return rc;
     DeviceGuard guard(h->device);
-    const size_t cnt = static_cast<size_t>(batch) * topn;
+    // internal lists are `eff` long: a shard of n rows cannot return more
+    const int eff = static_cast<int64_t>(topn) < h->n ? topn : static_cast<int>(h->n);
+    const size_t cnt = static_cast<size_t>(batch) * eff;
     rc = ensure_slots(h, cnt);
     if (rc) return rc;
-    if (batch > 1 && topn <= kMultiMaxTopK) {
-        for (int b = 0; b < batch; b += kMultiChain) {
-            const int count = batch - b < kMultiChain ? batch - b : kMultiChain;
-            const size_t off = static_cast<size_t>(b) * topn;
-            rc = enqueue_multi(h, queries + static_cast<size_t>(b) * kDim, exclude_global ? exclude_global + b : nullptr,
-                               count, topn, h->d_keys + off, h->d_idx + off, h->d_score + off, h->stream);
-            if (rc) return rc;
-        }
-    } else {
-        for (int b = 0; b < batch; ++b) {
-            const size_t off = static_cast<size_t>(b) * topn;
-            rc = enqueue_query(h, -1, queries + static_cast<int64_t>(b) * kDim,
-                               exclude_global ? exclude_global[b] : -1, topn, h->d_keys + off,
-                               h->d_idx + off, h->d_score + off, h->stream);
-            if (rc) return rc;
-        }
-    }
+    rc = sync_api_begin(h);
+    if (rc) return rc;
+    rc = enqueue_batch(h, queries, exclude_global, batch, eff, h->d_keys, h->d_idx, h->d_score, h->stream);
+    if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->h_idx, h->d_idx, cnt * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->h_score, h->d_score, cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    std::memcpy(out_idx, h->h_idx, cnt * sizeof(int64_t));
-    if (out_score) std::memcpy(out_score, h->h_score, cnt * sizeof(float));
-    if (out_count) {
-        for (int b = 0; b < batch; ++b) {
+    for (int b = 0; b < batch; ++b) {
+        const int64_t* src_i = h->h_idx + static_cast<size_t>(b) * eff;
+        const float* src_s = h->h_score + static_cast<size_t>(b) * eff;
+        int64_t* dst_i = out_idx + static_cast<size_t>(b) * topn;
+        std::memcpy(dst_i, src_i, static_cast<size_t>(eff) * sizeof(int64_t));
+        for (int i = eff; i < topn; ++i) dst_i[i] = -1;
+        if (out_score) {
+            float* dst_s = out_score + static_cast<size_t>(b) * topn;
+            std::memcpy(dst_s, src_s, static_cast<size_t>(eff) * sizeof(float));
+            for (int i = eff; i < topn; ++i) dst_s[i] = 0.0f;
+        }
+        if (out_count) {
             int c = 0;
-            while (c < topn && h->h_idx[static_cast<size_t>(b) * topn + c] >= 0) ++c;
+            while (c < eff && src_i[c] >= 0) ++c;
             out_count[b] = c;
         }
     }
@@ -665,18 +744,26 @@ int mi355rec_query_row_topn(mi355rec_t* h, int64_t local_row, int topn, int64_t*
     int rc = check_topn(h, topn, true);
     if (rc) return rc;
     DeviceGuard guard(h->device);
-    rc = ensure_slots(h, static_cast<size_t>(topn));
+    // device / pinned slots are sized by what the shard can return, not by topn
+    const int eff = static_cast<int64_t>(topn) < h->n ? topn : static_cast<int>(h->n);
+    rc = ensure_slots(h, static_cast<size_t>(eff));
     if (rc) return rc;
-    rc = enqueue_query(h, local_row, nullptr, h->row_base + local_row, topn, h->d_keys, h->d_idx,
+    rc = sync_api_begin(h);
+    if (rc) return rc;
+    rc = enqueue_query(h, local_row, nullptr, h->row_base + local_row, eff, h->d_keys, h->d_idx,
                        h->d_score, h->stream);
     if (rc) return rc;
-    HIP_TRY(h, hipMemcpyAsync(h->h_idx, h->d_idx, topn * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->h_score, h->d_score, topn * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->h_idx, h->d_idx, eff * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->h_score, h->d_score, eff * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     int c = 0;
-    while (c < topn && h->h_idx[c] >= 0) ++c;
-    std::memcpy(out_idx, h->h_idx, static_cast<size_t>(topn) * sizeof(int64_t));
-    if (out_score) std::memcpy(out_score, h->h_score, static_cast<size_t>(topn) * sizeof(float));
+    while (c < eff && h->h_idx[c] >= 0) ++c;
+    std::memcpy(out_idx, h->h_idx, static_cast<size_t>(eff) * sizeof(int64_t));
+    if (out_score) std::memcpy(out_score, h->h_score, static_cast<size_t>(eff) * sizeof(float));
+    for (int i = eff; i < topn; ++i) {
+        out_idx[i] = -1;
+        if (out_score) out_score[i] = 0.0f;
+    }
     if (out_count) *out_count = c;
     return MI355REC_OK;
 }

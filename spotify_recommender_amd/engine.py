@@ -221,10 +221,17 @@ def unpack_keys(keys) -> Tuple[np.ndarray, np.ndarray]:
 # ---- row sharding -----------------------------------------------------------
 
 def shard_bounds(n_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
-    """Contiguous row block of `rank`: [lo, hi)."""
-    per = -(-int(n_rows) // int(world_size))
-    lo = min(int(n_rows), rank * per)
-    hi = min(int(n_rows), (rank + 1) * per)
+    """Contiguous row block of `rank`: [lo, hi).
+
+    Balanced: the first n_rows % world_size ranks hold one row more, so a rank is
+    empty only when n_rows < world_size (a ceil-division split leaves trailing
+    ranks empty much earlier, e.g. 10 rows over 8 ranks).  An empty rank takes
+    part in the collective with an all-zero key list (`ShardedEngine(local=None)`).
+    """
+    n, w, r = int(n_rows), int(world_size), int(rank)
+    per, rem = divmod(n, w)
+    lo = r * per + min(r, rem)
+    hi = lo + per + (1 if r < rem else 0)
     return lo, hi
 
 
@@ -248,6 +255,9 @@ class ShardedEngine:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.max_topn = int(max_topn)
+        if not 1 <= self.max_topn <= capi.MAX_TOPN_FAST:
+            # the merge of the gathered lists is a single launch (mi355rec_enqueue_merge_keys)
+            raise ValueError(f"max_topn must be in [1, {capi.MAX_TOPN_FAST}], got {max_topn}")
         self.always_gather = bool(always_gather)  # run the collective even at world size 1
         # RCCL gathers device tensors directly.  Under gloo (CPU rehearsals, or several
         # ranks sharing one GPU in a test) the keys are staged through host memory.

@@ -9,11 +9,24 @@
 #include <queue>
 #include <vector>
 
+#ifdef HEAP_CHECK_REFERENCE_HEADER
+// Build container only (-I /root/reference): the reference's OWN Recommendation
+// struct and comparator (Recommender.h:12-22), not a restatement.
+#include "Recommender.h"
+typedef Recommendation Rec;
+static inline int rec_idx(const Rec& r) { return r.songIndex; }
+static inline float rec_sim(const Rec& r) { return r.similarity; }
+#else
+// Where /root/reference is absent (the GPU box): the same 3 lines restated.
 struct Rec {
-    int idx;
-    float sim;
-    bool operator<(const Rec& o) const { return sim > o.sim; }
+    int songIndex;
+    float similarity;
+    Rec(int i, float s) : songIndex(i), similarity(s) {}
+    bool operator<(const Rec& o) const { return similarity > o.similarity; }
 };
+static inline int rec_idx(const Rec& r) { return r.songIndex; }
+static inline float rec_sim(const Rec& r) { return r.similarity; }
+#endif
 
 int main(int argc, char** argv) {
     if (argc < 4) return 2;
@@ -23,12 +36,12 @@ int main(int argc, char** argv) {
     std::priority_queue<Rec> heap;
     for (long i = 0; i < n; ++i) {
         if (i == exclude) continue;
-        Rec r{(int)i, s[i]};
+        Rec r((int)i, s[i]);
         if (heap.size() < (size_t)topn) heap.push(r);
-        else if (r.sim > heap.top().sim) { heap.pop(); heap.push(r); }
+        else if (rec_sim(r) > rec_sim(heap.top())) { heap.pop(); heap.push(r); }
     }
     std::vector<int> out;
-    while (!heap.empty()) { out.push_back(heap.top().idx); heap.pop(); }
+    while (!heap.empty()) { out.push_back(rec_idx(heap.top())); heap.pop(); }
     std::reverse(out.begin(), out.end());
     for (int v : out) printf("%d\n", v);
     return 0;

@@ -63,7 +63,12 @@ def test_argument_validation_without_device(engine_lib):
     h = ctypes.c_void_p()
     feats = np.zeros((8, 12), dtype=np.float32)
     assert L.mi355rec_create(feats.ctypes.data_as(ctypes.c_void_p), 8, 11, 0, 0, ctypes.byref(h)) == capi.ERR_INVALID_ARG
-    assert L.mi355rec_create(feats.ctypes.data_as(ctypes.c_void_p), 0, 12, 0, 0, ctypes.byref(h)) == capi.ERR_INVALID_ARG
+    assert L.mi355rec_create(feats.ctypes.data_as(ctypes.c_void_p), -1, 12, 0, 0, ctypes.byref(h)) == capi.ERR_INVALID_ARG
+    # n == 0 is a legal EMPTY SHARD; without a device it fails as any other create
+    assert L.mi355rec_create(None, 0, 12, 0, 0, ctypes.byref(h)) in (capi.OK, capi.ERR_NO_DEVICE)
+    if h:
+        L.mi355rec_destroy(h)
+        h = ctypes.c_void_p()
     assert L.mi355rec_create(None, 8, 12, 0, 0, ctypes.byref(h)) == capi.ERR_INVALID_ARG
     L.mi355rec_destroy(None)  # no-op
 
@@ -75,3 +80,8 @@ def test_shard_bounds_cover_rows():
             assert spans[0][0] == 0 and spans[-1][1] == n
             for (a, b), (c, d) in zip(spans[:-1], spans[1:]):
                 assert b == c and a <= b
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1, "balanced split"
+            # a rank is empty only when there are fewer rows than ranks
+            assert (min(sizes) == 0) == (n < w)
+    assert [engine.shard_bounds(10, 8, r) for r in range(8)] == [(0, 2), (2, 4), (4, 5), (5, 6), (6, 7), (7, 8), (8, 9), (9, 10)]

@@ -123,6 +123,44 @@ def test_special_values(Engine):
             assert_topn_matches(idx, sc, want, q, 20)
 
 
+def test_sums_that_overflow_in_one_order_only(Engine):
+    """fp32 sums that overflow in the reference's sequential order but not in a
+    paired order (and vice versa): q = (1e19,1e19,1e19,0..) against
+    (3e19,3e19,-3e19,0..) is inf/inf = NaN -> clamped to 1.0 in the reference.  The
+    packed-FMA pre-filter must not be trusted there (kApproxMaxNorm2 /
+    kApproxMaxQueryNorm); single-query and multi-query kernels, pre-filter active
+    (200 k rows, thresholds > 0)."""
+    rng = np.random.default_rng(77)
+    f = rng.random((200_000, 12), dtype=np.float32)
+    big = np.zeros(12, dtype=np.float32)
+    big[:3] = (3e19, 3e19, -3e19)
+    mid = np.zeros(12, dtype=np.float32)
+    mid[:3] = (1e19, 1e19, -1e19)        # |row|^2 = 3e38: finite, but partial sums may overflow
+    where = rng.choice(200_000, size=300, replace=False)
+    f[where[:150]] = big
+    f[where[150:]] = mid
+    f[where[::7], 5] = 1e18
+    queries = np.zeros((6, 12), dtype=np.float32)
+    queries[0, :3] = 1e19
+    queries[1, :3] = 2e19
+    queries[2, :3] = 1e18                # |q| below the guard: pre-filter on, rows guarded one by one
+    queries[3, :3] = (1e19, -1e19, 1e19)
+    queries[4] = f[0]
+    queries[5] = f[1] * np.float32(1e18)
+    with Engine(f) as eng:
+        wants = [oracle.scores(f, q) for q in queries]
+        assert np.count_nonzero(wants[0] == 1.0) >= 150
+        for q, want in zip(queries, wants):
+            got = eng.scores(q)
+            assert np.array_equal(bits(got), bits(want))
+            for topn in (10, 100):
+                idx, sc = eng.query_topn(q, -1, topn)
+                assert_topn_matches(idx, sc, want, -1, topn, ref_idx=oracle.topn_heap(want, -1, topn))
+        idx, sc, counts = eng.query_batch_topn(queries, None, 100)
+        for b, want in enumerate(wants):
+            assert_topn_matches(idx[b][:counts[b]], sc[b][:counts[b]], want, -1, 100)
+
+
 def test_all_rows_identical_exercises_merge_fallback(Engine):
     """Every score ties: each workgroup list is full of equal scores, the head
     threshold cannot prune, and the merge takes its exact radix-select path."""
@@ -337,6 +375,10 @@ def test_two_shard_merge_equals_single(Engine, torch_cuda):
                 ref_idx, ref_sc = whole.query_row_topn(qrow, topn)
                 assert out_idx.cpu().numpy().tolist() == ref_idx.tolist()
                 assert np.array_equal(bits(out_score.cpu().numpy()), bits(ref_sc))
+                # ... and both against the ORACLE, not only against each other
+                want = oracle.scores(f, f[qrow])
+                assert_topn_matches(out_idx.cpu().numpy(), out_score.cpu().numpy(), want, qrow, topn,
+                                    ref_idx=oracle.topn_heap(want, qrow, topn))
             for sh in shards:
                 sh.close()
 
@@ -365,9 +407,12 @@ def test_sharded_batch_merge_layout(Engine, torch_cuda):
                                            out_keys, out_idx, out_score)
         torch.cuda.synchronize()
         got = out_idx.cpu().numpy().reshape(batch, topn)
+        got_sc = out_score.cpu().numpy().reshape(batch, topn)
         for b, q in enumerate(qrows):
             ref_idx, ref_sc = whole.query_row_topn(int(q), topn)
             assert got[b].tolist() == ref_idx.tolist()
+            want = oracle.scores(f, f[int(q)])
+            assert_topn_matches(got[b], got_sc[b], want, int(q), topn, ref_idx=oracle.topn_heap(want, int(q), topn))
         for sh in shards:
             sh.close()
 

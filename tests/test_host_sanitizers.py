@@ -72,6 +72,16 @@ def test_corrupt_inputs_are_clean(exe, golden_dir, tmp_path):
         f.write_bytes(bytes(bad))
         p = run(exe, "load", str(f))
         assert p.returncode in (0, 1) and "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr
+    # header claims 2^32 songs (passes the old range check): must be rejected by the
+    # file-size bound, not answered with a 650 GB resize / bad_alloc
+    for claimed in (2**32, 2**31, 5):
+        bad = bytearray(data)
+        bad[0:8] = claimed.to_bytes(8, "little")
+        f = tmp_path / f"claims{claimed}.bin"
+        f.write_bytes(bytes(bad))
+        p = run(exe, "load", str(f))
+        assert p.returncode == 1, (claimed, p.returncode, p.stderr[-500:])
+        assert "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr and "bad_alloc" not in p.stderr
     weird = tmp_path / "weird.csv"
     weird.write_text('track_id,track_name,artists,danceability,energy,key,loudness,mode,speechiness,acousticness,'
                      'instrumentalness,liveness,valence,tempo,track_genre\n'

@@ -47,7 +47,12 @@ def test_seeded_catalogue_top3_match_reference(pins, rows, key):
 def test_heap_replay_equals_libstdcxx(tmp_path):
     exe = tmp_path / "heap_check"
     src = __file__.rsplit("/", 1)[0] + "/heap_check.cpp"
-    subprocess.run(["g++", "-std=c++11", "-O2", "-o", str(exe), src], check=True)
+    cmd = ["g++", "-std=c++11", "-O2", "-o", str(exe), src]
+    from pathlib import Path
+    if Path("/root/reference/Recommender.h").exists():
+        # the reference's own Recommendation struct + comparator (Recommender.h:12-22)
+        cmd += ["-DHEAP_CHECK_REFERENCE_HEADER", "-I", "/root/reference"]
+    subprocess.run(cmd, check=True)
     rng = np.random.default_rng(7)
     for trial in range(40):
         n = int(rng.integers(1, 400))
