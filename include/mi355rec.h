@@ -70,6 +70,8 @@ typedef struct {
     int64_t bytes_per_query;   /* algorithmic bytes of one pass: rows * 48    */
     float last_scan_ms;        /* HIP-event time of the last timed scan       */
     float last_merge_ms;       /* HIP-event time of the last timed merge      */
+    float last_pass_ms;        /* HIP-event time of the batched path's passes (mean of pass 1 and pass 2) */
+    int32_t batched_grid_blocks; /* workgroups of a batched pass (0 before the first batched call) */
 } mi355rec_stats_t;
 
 /* Number of visible HIP devices (0 when there is none / no driver). */
@@ -155,11 +157,46 @@ int mi355rec_enqueue_query_keys(mi355rec_t* h, const float* query12,
 
 /* `batch` queries (batch x 12 floats, host; exclude_global may be NULL) in
  * multi-query passes: every pass streams the shard ONCE for up to 12 queries
- * (topn <= 128; larger topn falls back to one scan per query).  Writes
+ * (topn <= 128; larger topn falls back to one scan per query); 13 and more
+ * queries take the batched matrix-core path (mi355rec_set_batch_path).  Writes
  * batch x topn packed keys (each row sorted descending, 0-padded). */
 int mi355rec_enqueue_batch_keys(mi355rec_t* h, const float* queries,
                                 const int64_t* exclude_global, int batch, int topn,
                                 mi355rec_key_t* out_keys_dev, void* stream);
+
+/* The same for queries that are ALREADY in device memory (batch x 12 floats;
+ * exclude_global_dev = batch int64 global row ids or NULL): always the batched
+ * matrix-core path below, nothing is staged through the host, the call is
+ * hipGraph-capturable after a first (allocating) call.  topn <= 128. */
+int mi355rec_enqueue_batch_keys_dev(mi355rec_t* h, const float* queries_dev,
+                                    const int64_t* exclude_global_dev, int batch,
+                                    int topn, mi355rec_key_t* out_keys_dev, void* stream);
+
+/* How batches (topn <= 128) are served.  AUTO: up to 12 queries as one
+ * multi-query pass; 13 and more on shards of >= 65536 rows through the batched
+ * path: two passes over the shard per chunk of up to 1024 queries, in which a
+ * conservative fp16 pre-filter on the matrix cores (v_mfma_f32_32x32x16_f16 on
+ * L2-normalised rows x queries, error bound 1.5e-3 derived in
+ * csrc/batched.hip.h) selects a few hundred candidate rows per query that are
+ * then scored with the exact fp32 chain — results stay bit-identical to the
+ * single-query path.  Queries the bound cannot be claimed for (tiny / huge /
+ * non-finite norms, fewer than topn+1 clearly positive groups, more than 1024
+ * candidates) are served by the exact multi-query scan inside the same call.
+ * MULTI / MFMA force one path (tests, A/B measurements).  The first batched
+ * call allocates the path's scratch (~0.3 GB); later calls allocate nothing. */
+#define MI355REC_BATCH_AUTO 0
+#define MI355REC_BATCH_MULTI 1
+#define MI355REC_BATCH_MFMA 2
+int mi355rec_set_batch_path(mi355rec_t* h, int path);
+
+/* Diagnostics of the LAST chunk (<= 1024 queries) the batched path served on
+ * this handle (synchronises the device): special rows listed, queries handed to
+ * the exact multi-query scan, and the candidates the pre-filter let through
+ * (total and per-query maximum, over the queries it served itself).  Any
+ * pointer may be NULL. */
+int mi355rec_batched_last_counters(mi355rec_t* h, int32_t* special_rows,
+                                   int32_t* queued_queries, int64_t* candidates_total,
+                                   int32_t* candidates_max);
 
 /* Merge `n_lists` lists of `list_len` packed keys each (each sorted
  * descending, 0-padded — e.g. the all-gathered per-rank outputs of

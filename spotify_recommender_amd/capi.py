@@ -15,6 +15,7 @@ LIB_PATH = PKG / "libmi355rec.so"
 
 DIM = 12
 MAX_TOPN_FAST = 1024
+BATCH_AUTO, BATCH_MULTI, BATCH_MFMA = 0, 1, 2
 
 OK = 0
 ERR_INVALID_ARG = -1
@@ -34,6 +35,8 @@ class Stats(ctypes.Structure):
         ("bytes_per_query", c_int64),
         ("last_scan_ms", c_float),
         ("last_merge_ms", c_float),
+        ("last_pass_ms", c_float),
+        ("batched_grid_blocks", c_int32),
     ]
 
 
@@ -54,6 +57,10 @@ SIGNATURES = {
     "mi355rec_enqueue_row_keys": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "mi355rec_enqueue_query_keys": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "mi355rec_enqueue_batch_keys": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "mi355rec_enqueue_batch_keys_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "mi355rec_set_batch_path": (c_int, [c_void_p, c_int]),
+    "mi355rec_batched_last_counters": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int64),
+                                               POINTER(c_int32)]),
     "mi355rec_enqueue_merge_keys": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mi355rec_enqueue_merge_keys_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int, c_int,
                                                   c_void_p, c_void_p, c_void_p, c_void_p]),

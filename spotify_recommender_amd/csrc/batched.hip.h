@@ -1,0 +1,426 @@
+// batched.hip.h — the batched ("GEMM-shaped") path of BASELINE configs[4]:
+// hundreds to 1024 queries against one pass-pair over the catalogue shard.
+//
+// The reference has no batched path (one query per process, main.cpp:46-131);
+// per query the contract is still recommendByIndex's (Recommender.cu:275-318):
+// the exact fp32 cosine of calculateSimilaritiesCPU (:256-273) and the best
+// topN rows.  N x Q exact scores are 24 flop each and cannot be materialised
+// (12.5 M x 1024 x 4 B = 51 GB), so the work is split into
+//
+//   1. a CONSERVATIVE pre-filter on the matrix cores: rows and queries are
+//      L2-normalised in fp32, rounded to fp16 and multiplied 32 rows x 32 queries
+//      at a time with v_mfma_f32_32x32x16_f16 (K = 16: 12 features + 2 slots that
+//      carry the query's threshold + 2 zeros).  |approx - exact| <= kBqMargin for
+//      every (row, query) pair the bound is claimed for (derivation below);
+//   2. the EXACT chain (cosine_score(), kernels.hip.h) on the few hundred rows
+//      per query that the pre-filter cannot rule out, and an exact top-N of those.
+//
+// Results are therefore bit-identical to the single-query path.
+//
+// Pipeline for one chunk of up to 1024 queries (all launches on one stream, no
+// host synchronisation, no allocation):
+//   bq_prepare_kernel   queries -> fp16 B fragments (registers of every wave)
+//   bq_pass_kernel<NB,false>  pass 1: per (query, workgroup-half) the MAXIMUM approx
+//                       cosine over that group's rows            -> gmax
+//   bq_select_kernel    per query the (topN+1)-th largest group maximum T: topN+1
+//                       distinct rows have approx >= T, so (self excluded) topN rows
+//                       have exact >= T - margin; everything in the true top-N has
+//                       approx >= T - 2*margin =: T'.  T' goes into the B fragment's
+//                       threshold slots (as -T', split hi/lo over two fp16).
+//   bq_pass_kernel<NB,true>   pass 2: D = approx - T' straight out of the MFMA; the
+//                       sign is the test.  Hits (a few hundred per query) append the
+//                       row id to the query's candidate list.
+//   bq_finalize_kernel  per query: exact scores of its candidates, exact top-N,
+//                       sorted packed keys out.
+// Queries (or whole chunks) the bound cannot be claimed for are QUEUED on the
+// device and served by the exact multi-query scan (scan_multi_queued_kernel):
+// tiny / huge / non-finite query norms, T' <= 0 (fewer than topN+1 groups with a
+// clearly positive maximum), more candidates than kBqCap (mass ties at the
+// threshold), more special rows than kBqSpecialCap.
+//
+// Rows: "valid" = |row|^2 in [kBqMinNorm2, kBqMaxNorm2] (then, with a valid
+// query, |row||q| > 1e-8 so the reference's zero branch is not taken, and no fp32
+// sum can overflow in any order).  Exactly-zero rows score 0 against every query
+// (Recommender.cu:271) and can never reach a positive threshold: they are
+// skipped.  Every other row (tiny norm, huge, inf, NaN) is SPECIAL: it is listed
+// once and scored exactly against every query in the finalize step.
+//
+// Margin.  r^ = r / |r| and q^ = q / |q| in fp32 (relative error < 1e-6 each),
+// then x~ = fp16(x) with |x~ - x| <= 2^-11 |x| for normal results and <= 2^-14
+// absolute if a subnormal result were flushed.  The products of fp16 values are
+// exact in the MFMA's fp32 accumulator.  So
+//   |sum r~_j q~_j - sum r^_j q^_j| <= (2^-10 + 2^-22) sum |r^_j q^_j|
+//                                      + 2^-14 (sum |r^_j| + sum |q^_j|)
+//                                   <= 9.77e-4 + 2 sqrt(12) 2^-14 = 1.40e-3
+// (Cauchy-Schwarz; the second term only if subnormals flush), plus < 6e-6 for the
+// normalisations, the 16-term fp32 accumulation and the reference chain's own
+// rounding.  kBqMargin = 1.5e-3.  tests/test_batched_margin.py checks the bound
+// on hostile data with a numpy model of exactly this arithmetic.
+#pragma once
+
+#include "kernels.hip.h"
+
+namespace mi355 {
+
+typedef _Float16 bq_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 bq_h2 __attribute__((ext_vector_type(2)));
+typedef float bq_f16v __attribute__((ext_vector_type(16)));
+
+constexpr int kBqMaxBlocks = 32;             // 32 queries per block -> 1024 queries per chunk
+constexpr int kBqMaxQueries = kBqMaxBlocks * 32;
+constexpr int kBqCap = 1024;                 // candidate rows kept per query
+constexpr int kBqSpecialCap = 1024;          // special rows kept per chunk
+constexpr int kBqFinalBlock = 256;           // threads of the finalize workgroup
+constexpr int kBqFinalPerThread = (kBqCap + kBqSpecialCap) / kBqFinalBlock;
+constexpr int kBqPassBlock = 256;            // 4 waves, one per SIMD; 2 workgroups per CU
+constexpr float kBqMargin = 1.5e-3f;
+constexpr float kBqSlack = 4e-6f;            // fp16 hi/lo split of T' and the fused subtraction
+constexpr float kBqMinNorm2 = 1.01e-8f;      // |x| >= 1.005e-4 for rows and queries alike
+constexpr float kBqMaxNorm2 = 1e36f;
+constexpr float kBqMinNorm = 1.005e-4f;
+constexpr float kBqMaxNorm = 1e18f;
+constexpr int kBqGroupsPerBlock = 2;         // the two lane halves of a workgroup stay separate groups
+
+// per-query flags written by prepare / select, read by finalize
+constexpr uint32_t kBqFlagOk = 0u;
+constexpr uint32_t kBqFlagQueue = 1u;        // serve through the exact multi-query scan
+constexpr uint32_t kBqFlagPad = 2u;          // not a query (padding up to a multiple of 32)
+
+__device__ __forceinline__ uint32_t bq_pack_h2(float a, float b) {
+    const float __attribute__((ext_vector_type(2))) f = {a, b};
+    const bq_h2 h = __builtin_convertvector(f, bq_h2);   // v_cvt_pk_f16_f32, round to nearest even
+    return __builtin_bit_cast(uint32_t, h);
+}
+
+// ---- queries -> B fragments -----------------------------------------------------
+// B operand of v_mfma_f32_32x32x16_f16: lane l (c = l & 31, h = l >> 5) holds
+// B[k = 8h + j][col c], j = 0..7, i.e. 4 dwords.  bfrag[blk][lane][4].
+// k = 0..11 the normalised query, k = 12, 13 the threshold (select kernel), 14, 15 zero.
+__global__ __launch_bounds__(256) void bq_prepare_kernel(
+    const float* __restrict__ queries, int n_queries, int n_blocks, uint32_t* __restrict__ bfrag,
+    float* __restrict__ qnorm, uint32_t* __restrict__ qflags, int* __restrict__ cand_count,
+    int* __restrict__ counters /* [0] special rows, [1] queued queries, [2] chunk-wide queue flag */) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q == 0) {
+        counters[0] = 0;
+        counters[1] = 0;
+        counters[2] = 0;
+    }
+    if (q >= n_blocks * 32) return;
+    const bool real = q < n_queries;
+    float v[kDim];
+#pragma unroll
+    for (int j = 0; j < kDim; ++j) v[j] = real ? queries[static_cast<int64_t>(q) * kDim + j] : 0.0f;
+    const float qn = query_norm(v);
+    const bool ok = real && qn >= kBqMinNorm && qn <= kBqMaxNorm;   // false for NaN
+    const float inv = ok ? 1.0f / qn : 0.0f;
+    float u[kDim];
+#pragma unroll
+    for (int j = 0; j < kDim; ++j) u[j] = ok ? v[j] * inv : 0.0f;
+    const int blk = q >> 5, c = q & 31;
+    uint4* lo = reinterpret_cast<uint4*>(bfrag) + (blk * 64 + c);
+    uint4* hi = reinterpret_cast<uint4*>(bfrag) + (blk * 64 + 32 + c);
+    *lo = make_uint4(bq_pack_h2(u[0], u[1]), bq_pack_h2(u[2], u[3]), bq_pack_h2(u[4], u[5]), bq_pack_h2(u[6], u[7]));
+    *hi = make_uint4(bq_pack_h2(u[8], u[9]), bq_pack_h2(u[10], u[11]), 0u, 0u);
+    qnorm[q] = qn;
+    qflags[q] = ok ? kBqFlagOk : (real ? kBqFlagQueue : kBqFlagPad);
+    cand_count[q] = 0;
+}
+
+// ---- the two passes ---------------------------------------------------------------
+// One wave = one 32-row tile at a time against all NB query blocks held in
+// registers (NB x 4 VGPRs).  Lane l (r = l & 31, h = l >> 5) loads floats
+// [0,8) (h = 0) or [8,12) (h = 1) of row tile*32 + r: exactly its share of the A
+// operand, A[row r][k = 8h + j].  Tiles are dealt round-robin over all waves of the
+// grid, so the chip reads one moving window of the matrix.
+// C/D layout (cdna_hip_programming.md §3): lane holds column c = l & 31 (the query)
+// and rows (i & 3) + 8 (i >> 2) + 4 h for register i = 0..15.
+template <int NB, bool kCollect>
+__global__ __launch_bounds__(kBqPassBlock, 2) void bq_pass_kernel(
+    const float* __restrict__ feats, int64_t n, int64_t n_tiles, const uint32_t* __restrict__ bfrag,
+    float* __restrict__ gmax /* [grid][NB][64] */, int* __restrict__ cand_count,
+    uint32_t* __restrict__ cand_rows /* [query][kBqCap] */, int* __restrict__ counters,
+    uint32_t* __restrict__ special_rows) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r = lane & 31;
+    const int h = lane >> 5;
+
+    bq_h8 B[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const uint4 w = reinterpret_cast<const uint4*>(bfrag)[b * 64 + lane];
+        B[b] = __builtin_bit_cast(bq_h8, w);
+    }
+    int mx[kCollect ? 1 : NB];   // running group maxima (bit patterns of floats >= 0)
+    if constexpr (!kCollect) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) mx[b] = 0;
+    }
+
+    const int64_t total_waves = static_cast<int64_t>(gridDim.x) * (kBqPassBlock / 64);
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * (kBqPassBlock / 64) + wave;
+    const int64_t last_row = n - 1;
+    const float4* base = reinterpret_cast<const float4*>(feats);
+
+    // rows past the end re-read the last row (cached) so the prefetch is unconditional
+    auto load_a = [&](int64_t tile) {
+        int64_t row = tile * 32 + r;
+        row = row < n ? row : last_row;
+        return base[row * 3 + 2 * h];          // floats [0,4) or [8,12)
+    };
+    auto load_b = [&](int64_t tile) {
+        int64_t row = tile * 32 + r;
+        row = row < n ? row : last_row;
+        return base[row * 3 + 1];              // floats [4,8): used by the lower half only
+    };
+
+    float4 na = load_a(first), nb = load_b(first);
+    for (int64_t tile = first; tile < n_tiles; tile += total_waves) {
+        const float4 a = na, b = nb;
+        na = load_a(tile + total_waves);
+        nb = load_b(tile + total_waves);
+
+        const int64_t row = tile * 32 + r;
+        float ss = a.x * a.x;
+        ss = __builtin_fmaf(a.y, a.y, ss);
+        ss = __builtin_fmaf(a.z, a.z, ss);
+        ss = __builtin_fmaf(a.w, a.w, ss);
+        float sb = b.x * b.x;
+        sb = __builtin_fmaf(b.y, b.y, sb);
+        sb = __builtin_fmaf(b.z, b.z, sb);
+        sb = __builtin_fmaf(b.w, b.w, sb);
+        ss = h == 0 ? ss + sb : ss;
+        // lower-half sum + upper-half sum, in that order in both halves
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
+        const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        const bool in_range = row < n;
+        const bool valid = in_range && tot >= kBqMinNorm2 && tot <= kBqMaxNorm2;
+        const float inv = valid ? __builtin_amdgcn_rsqf(tot) : 0.0f;
+        if constexpr (kCollect) {
+            // neither valid nor exactly zero: scored exactly against every query later
+            const bool special = in_range && !valid && !(tot == 0.0f);
+            if (special && h == 0) {
+                const int pos = atomicAdd(&counters[0], 1);
+                if (pos < kBqSpecialCap) special_rows[pos] = static_cast<uint32_t>(row);
+            }
+        }
+        // zero (not NaN) for rows the bound is not claimed for: 0 * inf would poison D
+        const float e0 = valid ? a.x * inv : 0.0f, e1 = valid ? a.y * inv : 0.0f;
+        const float e2 = valid ? a.z * inv : 0.0f, e3 = valid ? a.w * inv : 0.0f;
+        const float e4 = valid ? b.x * inv : 0.0f, e5 = valid ? b.y * inv : 0.0f;
+        const float e6 = valid ? b.z * inv : 0.0f, e7 = valid ? b.w * inv : 0.0f;
+        uint4 aw;
+        aw.x = bq_pack_h2(e0, e1);
+        aw.y = bq_pack_h2(e2, e3);
+        // upper half: k = 12, 13 multiply the threshold slots of B by 1.0 (ALL rows, so a
+        // masked row yields D = -T' < 0), k = 14, 15 are zero
+        aw.z = h == 0 ? bq_pack_h2(e4, e5) : 0x3c003c00u;
+        aw.w = h == 0 ? bq_pack_h2(e6, e7) : 0u;
+        const bq_h8 A = __builtin_bit_cast(bq_h8, aw);
+
+        const bq_f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f,
+                              0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        // Two accumulator tiles: the MFMA of block blk + 1 is issued before block blk's
+        // 16 results are reduced, so the matrix pipe does not wait for the VALU chain.
+        // The reductions run on the BIT PATTERNS as signed integers (v_max3_i32): for
+        // the values that matter (>= 0) integer order is float order, negative floats
+        // are negative integers, and there is no NaN canonicalisation to pay for.
+        bq_f16v D[2];
+        D[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B[0], zero, 0, 0, 0);
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+            if (blk + 1 < NB) D[(blk + 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B[blk + 1], zero, 0, 0, 0);
+            const bq_f16v& d = D[blk & 1];
+            auto bits = [&](int i) { return static_cast<int>(__float_as_uint(d[i])); };
+            auto max3 = [](int x, int y, int z) { return max(max(x, y), z); };
+            if constexpr (!kCollect) {
+                int m = mx[blk];
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) m = max3(m, bits(i), bits(i + 1));
+                mx[blk] = m;
+            } else {
+                int m = max3(bits(0), bits(1), bits(2));
+#pragma unroll
+                for (int i = 3; i < 15; i += 2) m = max3(m, bits(i), bits(i + 1));
+                m = max(m, bits(15));
+                if (__builtin_expect(__ballot(m >= 0) != 0ull, 0)) {   // some D >= +0: approx >= T'
+                    const int q = blk * 32 + r;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        if (bits(i) >= 0) {
+                            const int pos = atomicAdd(&cand_count[q], 1);
+                            if (pos < kBqCap)
+                                cand_rows[static_cast<int64_t>(q) * kBqCap + pos] =
+                                    static_cast<uint32_t>(tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if constexpr (!kCollect) {
+        // group = (workgroup, lane half): max over the workgroup's 4 waves through LDS
+        __shared__ float s_mx[kBqPassBlock / 64][NB][64];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) s_mx[wave][b][lane] = __uint_as_float(static_cast<uint32_t>(mx[b]));
+        __syncthreads();
+        for (int i = threadIdx.x; i < NB * 64; i += kBqPassBlock) {
+            const int b = i >> 6, l = i & 63;
+            float m = s_mx[0][b][l];
+#pragma unroll
+            for (int w = 1; w < kBqPassBlock / 64; ++w) m = __builtin_fmaxf(m, s_mx[w][b][l]);
+            gmax[(static_cast<int64_t>(blockIdx.x) * NB + b) * 64 + l] = m;
+        }
+    }
+}
+
+// ---- per-query threshold ----------------------------------------------------------
+// One workgroup of 1024 threads per query block: the block's group maxima
+// ([grid][64] floats, 256 B per workgroup of pass 1) are staged in LDS, then wave w
+// selects the (topk+1)-th largest value for queries w and w + 16 (32 per block).
+constexpr int kBqSelectBlock = 512;
+constexpr int kBqSelectMaxGroups = 2048;   // 2 per pass-1 workgroup -> pass-1 grid <= 1024
+constexpr int kBqSelectKeys = kBqSelectMaxGroups / 64;
+
+__global__ __launch_bounds__(kBqSelectBlock) void bq_select_kernel(
+    const float* __restrict__ gmax, int grid_pass1, int n_blocks, int topk, uint32_t* __restrict__ bfrag,
+    uint32_t* __restrict__ qflags, float* __restrict__ qthr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bq_smem[];
+    float* s_vals = reinterpret_cast<float*>(bq_smem);                       // [grid][65]
+    int* s_hist = reinterpret_cast<int*>(s_vals + static_cast<size_t>(grid_pass1) * 65);  // [16][256]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int blk = blockIdx.x;
+    for (int i = tid; i < grid_pass1 * 64; i += kBqSelectBlock) {
+        const int g = i >> 6, l = i & 63;
+        s_vals[g * 65 + l] = gmax[(static_cast<int64_t>(g) * n_blocks + blk) * 64 + l];
+    }
+    __syncthreads();
+    const int groups = grid_pass1 * kBqGroupsPerBlock;
+    for (int c = wave; c < 32; c += kBqSelectBlock / 64) {
+        const int q = blk * 32 + c;
+        uint32_t flag = qflags[q];
+        float thr_out = 0.0f;
+        if (flag == kBqFlagOk) {   // wave-uniform
+            // unique keys: value image in the high word, group id in the low word
+            uint64_t mine[kBqSelectKeys];
+            int positive = 0;
+#pragma unroll
+            for (int u = 0; u < kBqSelectKeys; ++u) {
+                // group index -> (half, workgroup); consecutive lanes read consecutive
+                // workgroups' rows of s_vals (stride 65 words: conflict-free)
+                const int gi = lane + u * 64;
+                uint64_t key = 0ull;
+                if (gi < groups) {
+                    const int half = gi >= grid_pass1 ? 1 : 0;
+                    const float v = s_vals[(gi - half * grid_pass1) * 65 + half * 32 + c];
+                    if (v > 0.0f) {
+                        key = (static_cast<uint64_t>(score_to_ordered(v)) << 32) | static_cast<uint32_t>(gi + 1);
+                        ++positive;
+                    }
+                }
+                mine[u] = key;
+            }
+            int total = positive;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+            const int need = topk + 1;   // + 1: the query's own row may be among them and is excluded
+            float t_prime = 0.0f;
+            if (total >= need) {
+                const uint64_t kth = wave_select_threshold<kBqSelectKeys>(mine, need, true, 0, s_hist + wave * 256);
+                const float t = ordered_to_score(static_cast<uint32_t>(kth >> 32));
+                t_prime = t - 2.0f * kBqMargin - kBqSlack;
+            }
+            if (t_prime > 0.0f) {
+                thr_out = t_prime;
+            } else {
+                flag = kBqFlagQueue;   // the bound cannot be claimed: exact scan for this query
+            }
+        }
+        if (lane == 0) {
+            // B[k = 12][c] + B[k = 13][c] = -T' (fp16 hi + lo); a query that is not served
+            // here gets -65504 so that nothing ever passes
+            float hi = -65504.0f, lo = 0.0f;
+            if (flag == kBqFlagOk) {
+                const _Float16 hh = static_cast<_Float16>(-thr_out);
+                hi = static_cast<float>(hh);
+                lo = -thr_out - hi;
+            }
+            bfrag[(blk * 64 + 32 + c) * 4 + 2] = bq_pack_h2(hi, lo);
+            qflags[q] = flag;
+            qthr[q] = thr_out;
+        }
+    }
+}
+
+// ---- exact scores and top-N of the candidates ---------------------------------------
+// One workgroup per query.  Candidates = rows that passed the pre-filter + the
+// chunk's special rows (disjoint sets).  Queries that cannot be served here are
+// appended to the queue of the exact multi-query scan.
+__global__ __launch_bounds__(kBqFinalBlock) void bq_finalize_kernel(
+    const float* __restrict__ feats, int64_t row_base, const float* __restrict__ queries,
+    const long long* __restrict__ exclude /* may be null */, int n_queries, int topk,
+    const uint32_t* __restrict__ qflags, const int* __restrict__ cand_count,
+    const uint32_t* __restrict__ cand_rows, int* __restrict__ counters,
+    const uint32_t* __restrict__ special_rows, int* __restrict__ queue /* [n_queries] */,
+    uint64_t* __restrict__ out_keys, int64_t* __restrict__ out_idx, float* __restrict__ out_score) {
+    __shared__ uint64_t s_keys[kBqCap + kBqSpecialCap];
+    __shared__ uint64_t s_top[kMultiMaxTopK];
+    __shared__ SelectSmem s_sel;
+    __shared__ int s_n;
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n_cand = cand_count[q];
+    const int n_special = counters[0];
+    const bool served = qflags[q] == kBqFlagOk && n_cand <= kBqCap && n_special <= kBqSpecialCap;
+    if (!served) {   // uniform
+        if (tid == 0) queue[atomicAdd(&counters[1], 1)] = q;
+        return;
+    }
+    float qv[kDim];
+#pragma unroll
+    for (int j = 0; j < kDim; ++j) qv[j] = queries[static_cast<int64_t>(q) * kDim + j];
+    const float qn = query_norm(qv);
+    const long long excl = exclude ? exclude[q] : -1ll;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const int total = n_cand + n_special;
+    for (int i = tid; i < total; i += kBqFinalBlock) {
+        const uint32_t row = i < n_cand ? cand_rows[static_cast<int64_t>(q) * kBqCap + i] : special_rows[i - n_cand];
+        const Row rr = load_row(feats, static_cast<int64_t>(row));
+        const float s = cosine_score(qv, qn, rr);
+        const int64_t g = row_base + row;
+        if (g != excl) s_keys[atomicAdd(&s_n, 1)] = pack_key(s, static_cast<uint32_t>(g));
+    }
+    __syncthreads();
+    int c = s_n;
+    if (c > topk && c > kRankDirectMax) {   // uniform: cut to exactly topk in O(c), then rank
+        uint64_t mine[kBqFinalPerThread];
+#pragma unroll
+        for (int u = 0; u < kBqFinalPerThread; ++u) {
+            const int i = tid + u * kBqFinalBlock;
+            mine[u] = i < c ? s_keys[i] : 0ull;
+        }
+        const uint64_t t = block_select_threshold<kBqFinalBlock, kBqFinalPerThread>(mine, topk, true, 0, s_sel);
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kBqFinalPerThread; ++u)
+            if (mine[u] >= t) s_keys[atomicAdd(&s_n, 1)] = mine[u];
+        __syncthreads();
+        c = s_n;
+    }
+    block_rank_and_store<kBqFinalBlock>(s_keys, c, s_top, topk);
+    __syncthreads();
+    for (int i = tid; i < topk; i += kBqFinalBlock) {
+        const uint64_t k = s_top[i];
+        out_keys[static_cast<int64_t>(q) * topk + i] = k;
+        if (out_idx) out_idx[static_cast<int64_t>(q) * topk + i] = k ? static_cast<int64_t>(static_cast<uint32_t>(~static_cast<uint32_t>(k))) : -1;
+        if (out_score) out_score[static_cast<int64_t>(q) * topk + i] = k ? ordered_to_score(static_cast<uint32_t>(k >> 32)) : 0.0f;
+    }
+}
+
+}  // namespace mi355

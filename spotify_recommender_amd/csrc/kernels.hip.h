@@ -637,11 +637,16 @@ __device__ inline void wave_rank_and_store(const uint64_t* keys, int c, uint64_t
     }
 }
 
-template <typename Cfg>
-__global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel(
+// One group of up to kMultiQueries queries against the whole shard.  `load_query(t,
+// q12, excl)` hands thread t < kQ its query (called by the first kQ threads only).
+// Lists go to block_lists[list_slot0 + qi][workgroup][topk].  Called by every thread
+// of the workgroup; may be called again after it returns (it ends on a barrier-free
+// tail, so the caller puts a __syncthreads() between two groups).
+template <typename Cfg, typename LoadQuery>
+__device__ __forceinline__ void multi_scan_group(
     const float* __restrict__ feats, int64_t n, int64_t rows_per_block, int64_t block_stride, int iters,
-    int64_t row_base, MultiQueryArg qarg, int n_queries, int query_slot0, int topk,
-    uint64_t* __restrict__ block_lists, const uint64_t* __restrict__ seed_keys) {
+    int64_t row_base, LoadQuery load_query, int n_queries, int list_slot0, int topk,
+    uint64_t* __restrict__ block_lists, const uint64_t* __restrict__ seed_keys, int seed_slot0) {
     constexpr int kBlock = Cfg::kBlock;
     constexpr int kRowsPerThread = Cfg::kRowsPerThread;
     constexpr int kTileRows = Cfg::kTileRows;
@@ -652,6 +657,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
     __shared__ uint64_t s_thr[kQ];   // running filter threshold per query (key > thr passes)
     __shared__ float4 s_qc[kQ];      // {cutoff of the approx pre-filter, 1/|q|, |q|, unused}
     __shared__ v4f s_q[kQ][3];       // the query vectors (broadcast ds_read_b128; 96 SGPRs would spill)
+    __shared__ long long s_excl[kQ]; // global row to skip per query, -1 = none (read on the rare exact path only)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -674,9 +680,17 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
     // threshold instead of re-deriving a weak local one — the exact re-score path
     // then runs for ~1e-4 of the rows.
     if (tid < kQ) {
-        const float norm = query_norm(qarg.q[tid]);
+        float qv[kDim];
+        long long excl = -1;
+        if (tid < n_queries) {
+            load_query(tid, qv, excl);
+        } else {
+#pragma unroll
+            for (int j = 0; j < kDim; ++j) qv[j] = 0.0f;
+        }
+        const float norm = query_norm(qv);
         uint64_t t = 0ull;
-        if (seed_keys && tid < n_queries) t = seed_keys[static_cast<int64_t>(query_slot0 + tid) * topk + (topk - 1)];
+        if (seed_keys && tid < n_queries) t = seed_keys[static_cast<int64_t>(seed_slot0 + tid) * topk + (topk - 1)];
         float cut = -__builtin_inff();
         if (t) {
             const float score = ordered_to_score(static_cast<uint32_t>(t >> 32));
@@ -685,10 +699,11 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
         }
         s_count[tid] = 0;
         s_thr[tid] = t;
+        s_excl[tid] = excl;
         s_qc[tid] = make_float4(cut, 1.0f / norm, norm, 0.0f);
-        s_q[tid][0] = v4f{qarg.q[tid][0], qarg.q[tid][1], qarg.q[tid][2], qarg.q[tid][3]};
-        s_q[tid][1] = v4f{qarg.q[tid][4], qarg.q[tid][5], qarg.q[tid][6], qarg.q[tid][7]};
-        s_q[tid][2] = v4f{qarg.q[tid][8], qarg.q[tid][9], qarg.q[tid][10], qarg.q[tid][11]};
+        s_q[tid][0] = v4f{qv[0], qv[1], qv[2], qv[3]};
+        s_q[tid][1] = v4f{qv[4], qv[5], qv[6], qv[7]};
+        s_q[tid][2] = v4f{qv[8], qv[9], qv[10], qv[11]};
     }
     __syncthreads();
 
@@ -739,7 +754,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
                     const float q[kDim] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, qcv.x, qcv.y, qcv.z, qcv.w};
                     const float s = cosine_score(q, qc.z, row);
                     uint64_t key = pack_key(s, static_cast<uint32_t>(g));
-                    if (r >= blk_end || g == qarg.exclude[qi]) key = 0;
+                    if (r >= blk_end || g == s_excl[qi]) key = 0;
                     const bool pass = maybe && key > s_thr[qi];
                     const uint64_t ballot = __ballot(pass);
                     if (ballot) {
@@ -790,8 +805,48 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
         if (s_count[qi] > kRankDirectMax && s_count[qi] > topk)
             wave_compact<Cfg::kKeysPerLane>(s_cand[qi], &s_count[qi], topk, true, s_hist[wave]);
         const int c = __builtin_amdgcn_readfirstlane(s_count[qi]);
-        uint64_t* dst = block_lists + (static_cast<int64_t>(query_slot0 + qi) * gridDim.x + blockIdx.x) * topk;
+        uint64_t* dst = block_lists + (static_cast<int64_t>(list_slot0 + qi) * gridDim.x + blockIdx.x) * topk;
         wave_rank_and_store(s_cand[qi], c, dst, topk);
+    }
+}
+
+template <typename Cfg>
+__global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel(
+    const float* __restrict__ feats, int64_t n, int64_t rows_per_block, int64_t block_stride, int iters,
+    int64_t row_base, MultiQueryArg qarg, int n_queries, int query_slot0, int topk,
+    uint64_t* __restrict__ block_lists, const uint64_t* __restrict__ seed_keys) {
+    auto load_query = [&](int t, float (&qv)[kDim], long long& excl) {
+#pragma unroll
+        for (int j = 0; j < kDim; ++j) qv[j] = qarg.q[t][j];
+        excl = qarg.exclude[t];
+    };
+    multi_scan_group<Cfg>(feats, n, rows_per_block, block_stride, iters, row_base, load_query, n_queries,
+                          query_slot0, topk, block_lists, seed_keys, query_slot0);
+}
+
+// The same pass for queries QUEUED on the device (batched.hip.h): queue[0..*count)
+// are indices into queries_dev / exclude_dev; they are served in groups of
+// kMultiQueries inside ONE launch (no seed: this is the rare, robust path), lists go
+// to block_lists[position in the queue][workgroup][topk].  Exits at once when the
+// queue is empty.
+template <typename Cfg>
+__global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_queued_kernel(
+    const float* __restrict__ feats, int64_t n, int iters, int64_t row_base,
+    const float* __restrict__ queries_dev, const long long* __restrict__ exclude_dev,
+    const int* __restrict__ queue, const int* __restrict__ queue_count, int topk,
+    uint64_t* __restrict__ block_lists) {
+    const int count = *queue_count;
+    for (int g0 = 0; g0 < count; g0 += kMultiQueries) {
+        const int nq = count - g0 < kMultiQueries ? count - g0 : kMultiQueries;
+        auto load_query = [&](int t, float (&qv)[kDim], long long& excl) {
+            const int q = queue[g0 + t];
+#pragma unroll
+            for (int j = 0; j < kDim; ++j) qv[j] = queries_dev[static_cast<int64_t>(q) * kDim + j];
+            excl = exclude_dev ? exclude_dev[q] : -1ll;
+        };
+        multi_scan_group<Cfg>(feats, n, static_cast<int64_t>(0), static_cast<int64_t>(0), iters, row_base, load_query,
+                              nq, g0, topk, block_lists, static_cast<const uint64_t*>(nullptr), 0);
+        __syncthreads();
     }
 }
 
@@ -938,11 +993,13 @@ __device__ inline uint64_t merge_global_radix_select(const uint64_t* __restrict_
     return prefix;
 }
 
-__global__ __launch_bounds__(kMergeBlock) void merge_kernel(
+// `slot` = which list set (lists_base + slot * lists_query_stride), `out_slot` = which
+// output row (out_*_base + out_slot * out_query_stride).
+__device__ __forceinline__ void merge_body(
     const uint64_t* __restrict__ lists_base, int n_lists, int list_len, int64_t list_stride,
     int64_t lists_query_stride, int topk, uint64_t* __restrict__ out_keys_base,
     int64_t* __restrict__ out_idx_base, float* __restrict__ out_score_base,
-    int64_t out_query_stride) {
+    int64_t out_query_stride, int64_t slot, int64_t out_slot) {
     __shared__ uint64_t s_surv[kMergeSurvCap];
     __shared__ uint64_t s_top[kMaxTopK];
     __shared__ SelectSmem s_sel;
@@ -953,8 +1010,8 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
     __shared__ unsigned short s_active[kMergeMaxLists];
 
     const int tid = threadIdx.x;
-    const uint64_t* lists = lists_base + static_cast<int64_t>(blockIdx.x) * lists_query_stride;
-    uint64_t* out_keys = out_keys_base + static_cast<int64_t>(blockIdx.x) * out_query_stride;
+    const uint64_t* lists = lists_base + slot * lists_query_stride;
+    uint64_t* out_keys = out_keys_base + out_slot * out_query_stride;
 
     if (tid == 0) {
         s_count = 0;
@@ -1128,14 +1185,35 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
         const uint64_t k = s_top[i];
         out_keys[i] = k;
         if (out_idx_base) {
-            out_idx_base[static_cast<int64_t>(blockIdx.x) * out_query_stride + i] =
+            out_idx_base[out_slot * out_query_stride + i] =
                 k ? static_cast<int64_t>(static_cast<uint32_t>(~static_cast<uint32_t>(k))) : -1;
         }
         if (out_score_base) {
-            out_score_base[static_cast<int64_t>(blockIdx.x) * out_query_stride + i] =
+            out_score_base[out_slot * out_query_stride + i] =
                 k ? ordered_to_score(static_cast<uint32_t>(k >> 32)) : 0.0f;
         }
     }
+}
+
+__global__ __launch_bounds__(kMergeBlock) void merge_kernel(
+    const uint64_t* __restrict__ lists_base, int n_lists, int list_len, int64_t list_stride,
+    int64_t lists_query_stride, int topk, uint64_t* __restrict__ out_keys_base,
+    int64_t* __restrict__ out_idx_base, float* __restrict__ out_score_base,
+    int64_t out_query_stride) {
+    merge_body(lists_base, n_lists, list_len, list_stride, lists_query_stride, topk, out_keys_base, out_idx_base,
+               out_score_base, out_query_stride, blockIdx.x, blockIdx.x);
+}
+
+// Merge of the lists written by scan_multi_queued_kernel: workgroup b serves the b-th
+// queued query (if there is one) and writes to that query's output row.
+__global__ __launch_bounds__(kMergeBlock) void merge_queued_kernel(
+    const uint64_t* __restrict__ lists_base, int n_lists, int list_len, int64_t list_stride,
+    int64_t lists_query_stride, int topk, const int* __restrict__ queue, const int* __restrict__ queue_count,
+    uint64_t* __restrict__ out_keys_base, int64_t* __restrict__ out_idx_base, float* __restrict__ out_score_base,
+    int64_t out_query_stride) {
+    if (static_cast<int>(blockIdx.x) >= *queue_count) return;
+    merge_body(lists_base, n_lists, list_len, list_stride, lists_query_stride, topk, out_keys_base, out_idx_base,
+               out_score_base, out_query_stride, blockIdx.x, queue[blockIdx.x]);
 }
 
 // ---- read-only streaming probe (achievable-HBM ceiling) ---------------------

@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include "batched.hip.h"
 #include "kernels.hip.h"
 
 using namespace mi355;
@@ -82,13 +83,43 @@ struct mi355rec {
     float* h_score = nullptr;   // pinned
     float* d_scores_full = nullptr;
 
+    // batched path (batched.hip.h): allocated by the first batched call
+    struct Batched {
+        bool ready = false;
+        int grid = 0;                 // workgroups of the two passes (2 per CU, <= 512)
+        int qgrid = 0, qiters = 0;    // geometry of the queued exact scan
+        uint32_t* bfrag = nullptr;    // [32][64][4]
+        float* qnorm = nullptr;
+        float* qthr = nullptr;
+        uint32_t* qflags = nullptr;
+        int* cand_count = nullptr;
+        uint32_t* cand_rows = nullptr;   // [1024][kBqCap]
+        int* counters = nullptr;         // [4]
+        uint32_t* special_rows = nullptr;
+        float* gmax = nullptr;           // [grid][32][64]
+        int* queue = nullptr;            // [1024]
+        uint64_t* qlists = nullptr;      // [1024][qgrid][kMultiMaxTopK]
+        float* d_queries = nullptr;      // device copies of host queries / excludes (one chunk)
+        long long* d_exclude = nullptr;
+        // pinned staging ring for host queries (slot reused after its copy has completed)
+        static constexpr int kSlots = 4;
+        float* h_queries[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+        long long* h_exclude[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+        hipEvent_t slot_ev[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+        bool slot_used[kSlots] = {false, false, false, false};
+        int next_slot = 0;
+        int launches = 0;                // chunks enqueued (stats)
+    } bq;
+    int batch_path = 0;               // MI355REC_BATCH_AUTO / _MULTI / _MFMA
+
     // optional HIP-event timing of the enqueued kernels
     bool timing = false;
     int timing_stride = 1;      // time every stride-th launch of each kind
     int scan_launches = 0, merge_launches = 0;
-    std::vector<hipEvent_t> ev_scan, ev_merge;  // (start, stop) pairs
-    int n_scan_pairs = 0, n_merge_pairs = 0;
-    float last_scan_ms = 0.f, last_merge_ms = 0.f;
+    std::vector<hipEvent_t> ev_scan, ev_merge, ev_pass;  // (start, stop) pairs
+    int n_scan_pairs = 0, n_merge_pairs = 0, n_pass_pairs = 0;
+    int pass_launches = 0;
+    float last_scan_ms = 0.f, last_merge_ms = 0.f, last_pass_ms = 0.f;
 
     std::string err;
 };
@@ -430,10 +461,155 @@ int enqueue_query(mi355rec* h, int64_t query_row, const float* query12, int64_t 
     return MI355REC_OK;
 }
 
+// ---- batched path (batched.hip.h) -----------------------------------------------
+
+constexpr int64_t kBqMinRows = 65536;   // below this the launch count, not the arithmetic, decides
+constexpr int kBqMinBatch = 13;          // up to 12 queries are ONE multi-query pass
+
+int ensure_bq(mi355rec* h) {
+    auto& b = h->bq;
+    if (b.ready) return MI355REC_OK;
+    int grid = h->cus * 2;
+    if (grid > kBqSelectMaxGroups / kBqGroupsPerBlock / 2) grid = kBqSelectMaxGroups / kBqGroupsPerBlock / 2;  // 512: select's LDS
+    b.grid = grid;
+    b.qgrid = h->cus < kMergeMaxLists ? h->cus : kMergeMaxLists;
+    const int64_t tiles = (h->n + MultiConfig::kTileRows - 1) / MultiConfig::kTileRows;
+    if (tiles < b.qgrid) b.qgrid = static_cast<int>(tiles);
+    b.qiters = static_cast<int>((tiles + b.qgrid - 1) / b.qgrid);
+    HIP_TRY(h, hipMalloc(&b.bfrag, sizeof(uint32_t) * kBqMaxBlocks * 64 * 4));
+    HIP_TRY(h, hipMalloc(&b.qnorm, sizeof(float) * kBqMaxQueries));
+    HIP_TRY(h, hipMalloc(&b.qthr, sizeof(float) * kBqMaxQueries));
+    HIP_TRY(h, hipMalloc(&b.qflags, sizeof(uint32_t) * kBqMaxQueries));
+    HIP_TRY(h, hipMalloc(&b.cand_count, sizeof(int) * kBqMaxQueries));
+    HIP_TRY(h, hipMalloc(&b.cand_rows, sizeof(uint32_t) * static_cast<size_t>(kBqMaxQueries) * kBqCap));
+    HIP_TRY(h, hipMalloc(&b.counters, sizeof(int) * 4));
+    HIP_TRY(h, hipMalloc(&b.special_rows, sizeof(uint32_t) * kBqSpecialCap));
+    HIP_TRY(h, hipMalloc(&b.gmax, sizeof(float) * static_cast<size_t>(grid) * kBqMaxBlocks * 64));
+    HIP_TRY(h, hipMalloc(&b.queue, sizeof(int) * kBqMaxQueries));
+    HIP_TRY(h, hipMalloc(&b.qlists, sizeof(uint64_t) * static_cast<size_t>(kBqMaxQueries) * b.qgrid * kMultiMaxTopK));
+    HIP_TRY(h, hipMalloc(&b.d_queries, sizeof(float) * kBqMaxQueries * kDim));
+    HIP_TRY(h, hipMalloc(&b.d_exclude, sizeof(long long) * kBqMaxQueries));
+    for (int i = 0; i < mi355rec::Batched::kSlots; ++i) {
+        HIP_TRY(h, hipHostMalloc(&b.h_queries[i], sizeof(float) * kBqMaxQueries * kDim, hipHostMallocDefault));
+        HIP_TRY(h, hipHostMalloc(&b.h_exclude[i], sizeof(long long) * kBqMaxQueries, hipHostMallocDefault));
+        HIP_TRY(h, hipEventCreateWithFlags(&b.slot_ev[i], hipEventDisableTiming));
+    }
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bq_select_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(sizeof(float) * grid * 65 + sizeof(int) * (kBqSelectBlock / 64) * 256)));
+    b.ready = true;
+    return MI355REC_OK;
+}
+
+void free_bq(mi355rec* h) {
+    auto& b = h->bq;
+    void* dev[] = {b.bfrag, b.qnorm, b.qthr, b.qflags, b.cand_count, b.cand_rows, b.counters, b.special_rows,
+                   b.gmax, b.queue, b.qlists, b.d_queries, b.d_exclude};
+    for (void* p : dev)
+        if (p) (void)hipFree(p);
+    for (int i = 0; i < mi355rec::Batched::kSlots; ++i) {
+        if (b.h_queries[i]) (void)hipHostFree(b.h_queries[i]);
+        if (b.h_exclude[i]) (void)hipHostFree(b.h_exclude[i]);
+        if (b.slot_ev[i]) (void)hipEventDestroy(b.slot_ev[i]);
+    }
+    b = mi355rec::Batched();
+}
+
+template <int NB>
+void launch_bq_passes(mi355rec* h, int topn, hipStream_t s) {
+    auto& b = h->bq;
+    const int64_t n_tiles = (h->n + 31) / 32;
+    const size_t smem = sizeof(float) * b.grid * 65 + sizeof(int) * (kBqSelectBlock / 64) * 256;
+    int slot = timing_begin(h, h->ev_pass, h->n_pass_pairs, h->pass_launches, s);
+    hipLaunchKernelGGL((bq_pass_kernel<NB, false>), dim3(b.grid), dim3(kBqPassBlock), 0, s, h->d_feats, h->n, n_tiles,
+                       b.bfrag, b.gmax, b.cand_count, b.cand_rows, b.counters, b.special_rows);
+    timing_end(h, h->ev_pass, h->n_pass_pairs, slot, s);
+    hipLaunchKernelGGL(bq_select_kernel, dim3(NB), dim3(kBqSelectBlock), smem, s, b.gmax, b.grid, NB, topn, b.bfrag,
+                       b.qflags, b.qthr);
+    slot = timing_begin(h, h->ev_pass, h->n_pass_pairs, h->pass_launches, s);
+    hipLaunchKernelGGL((bq_pass_kernel<NB, true>), dim3(b.grid), dim3(kBqPassBlock), 0, s, h->d_feats, h->n, n_tiles,
+                       b.bfrag, b.gmax, b.cand_count, b.cand_rows, b.counters, b.special_rows);
+    timing_end(h, h->ev_pass, h->n_pass_pairs, slot, s);
+}
+
+// One chunk of up to kBqMaxQueries queries that are already in device memory.
+int enqueue_bq_chunk(mi355rec* h, const float* d_queries, const long long* d_exclude, int count, int topn,
+                     uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s) {
+    auto& b = h->bq;
+    const int blocks = (count + 31) / 32;
+    int nb = 2;
+    while (nb < blocks) nb *= 2;
+    hipLaunchKernelGGL(bq_prepare_kernel, dim3((nb * 32 + 255) / 256), dim3(256), 0, s, d_queries, count, nb, b.bfrag,
+                       b.qnorm, b.qflags, b.cand_count, b.counters);
+    switch (nb) {
+        case 2: launch_bq_passes<2>(h, topn, s); break;
+        case 4: launch_bq_passes<4>(h, topn, s); break;
+        case 8: launch_bq_passes<8>(h, topn, s); break;
+        case 16: launch_bq_passes<16>(h, topn, s); break;
+        default: launch_bq_passes<32>(h, topn, s); break;
+    }
+    hipLaunchKernelGGL(bq_finalize_kernel, dim3(count), dim3(kBqFinalBlock), 0, s, h->d_feats, h->row_base, d_queries,
+                       d_exclude, count, topn, b.qflags, b.cand_count, b.cand_rows, b.counters, b.special_rows, b.queue,
+                       out_keys, out_idx, out_score);
+    // The exact multi-query scan for whatever the bound could not be claimed for
+    // (usually nothing: both launches exit at once on an empty queue).
+    hipLaunchKernelGGL((scan_multi_queued_kernel<MultiConfig>), dim3(b.qgrid), dim3(MultiConfig::kBlock), 0, s,
+                       h->d_feats, h->n, b.qiters, h->row_base, d_queries, d_exclude, b.queue, b.counters + 1, topn,
+                       b.qlists);
+    hipLaunchKernelGGL(merge_queued_kernel, dim3(count), dim3(kMergeBlock), 0, s, b.qlists, b.qgrid, topn,
+                       static_cast<int64_t>(topn), static_cast<int64_t>(b.qgrid) * topn, topn, b.queue, b.counters + 1,
+                       out_keys, out_idx, out_score, static_cast<int64_t>(topn));
+    HIP_TRY(h, hipGetLastError());
+    ++b.launches;
+    return MI355REC_OK;
+}
+
+// Host queries: through a pinned staging slot into the handle's device buffers.
+int stage_queries(mi355rec* h, const float* queries, const int64_t* exclude, int count, hipStream_t s) {
+    auto& b = h->bq;
+    const int slot = b.next_slot;
+    b.next_slot = (slot + 1) % mi355rec::Batched::kSlots;
+    if (b.slot_used[slot]) HIP_TRY(h, hipEventSynchronize(b.slot_ev[slot]));  // its previous copy has long finished
+    std::memcpy(b.h_queries[slot], queries, sizeof(float) * static_cast<size_t>(count) * kDim);
+    for (int i = 0; i < count; ++i) b.h_exclude[slot][i] = exclude ? static_cast<long long>(exclude[i]) : -1ll;
+    HIP_TRY(h, hipMemcpyAsync(b.d_queries, b.h_queries[slot], sizeof(float) * static_cast<size_t>(count) * kDim,
+                              hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(b.d_exclude, b.h_exclude[slot], sizeof(long long) * static_cast<size_t>(count),
+                              hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipEventRecord(b.slot_ev[slot], s));
+    b.slot_used[slot] = true;
+    return MI355REC_OK;
+}
+
+bool use_bq(const mi355rec* h, int batch, int topn) {
+    if (topn > kMultiMaxTopK || h->n < 1) return false;
+    if (h->batch_path == MI355REC_BATCH_MULTI) return false;
+    if (h->batch_path == MI355REC_BATCH_MFMA) return true;
+    return batch >= kBqMinBatch && h->n >= kBqMinRows;
+}
+
+int enqueue_bq_host(mi355rec* h, const float* queries, const int64_t* exclude, int batch, int topn,
+                    uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s) {
+    int rc = ensure_bq(h);
+    if (rc) return rc;
+    for (int b0 = 0; b0 < batch; b0 += kBqMaxQueries) {
+        const int count = batch - b0 < kBqMaxQueries ? batch - b0 : kBqMaxQueries;
+        rc = stage_queries(h, queries + static_cast<size_t>(b0) * kDim, exclude ? exclude + b0 : nullptr, count, s);
+        if (rc) return rc;
+        const size_t off = static_cast<size_t>(b0) * topn;
+        rc = enqueue_bq_chunk(h, h->bq.d_queries, h->bq.d_exclude, count, topn, out_keys + off,
+                              out_idx ? out_idx + off : nullptr, out_score ? out_score + off : nullptr, s);
+        if (rc) return rc;
+    }
+    return MI355REC_OK;
+}
+
 // `batch` queries on stream `s`: multi-query passes where they apply (topn <=
 // kMultiMaxTopK), otherwise one scan per query.  Outputs are batch x topn.
 int enqueue_batch(mi355rec* h, const float* queries, const int64_t* exclude_global, int batch, int topn,
                   uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s) {
+    if (use_bq(h, batch, topn))
+        return enqueue_bq_host(h, queries, exclude_global, batch, topn, out_keys, out_idx, out_score, s);
     if (batch > 1 && topn <= kMultiMaxTopK && h->n > 0) {
         for (int b = 0; b < batch; b += kMultiChain) {
             const int count = batch - b < kMultiChain ? batch - b : kMultiChain;
@@ -483,6 +659,8 @@ void mi355rec_destroy(mi355rec_t* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (hipEvent_t e : h->ev_scan) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev_merge) (void)hipEventDestroy(e);
+    free_bq(h);
+    for (hipEvent_t e : h->ev_pass) (void)hipEventDestroy(e);
     if (h->owned_feats) (void)hipFree(h->owned_feats);
     if (h->d_block_lists) (void)hipFree(h->d_block_lists);
     if (h->d_seed_keys) (void)hipFree(h->d_seed_keys);
@@ -508,8 +686,10 @@ int mi355rec_set_timing(mi355rec_t* h, int enabled) {
     h->timing_stride = enabled > 1 ? enabled : 1;
     h->n_scan_pairs = 0;
     h->n_merge_pairs = 0;
+    h->n_pass_pairs = 0;
     h->scan_launches = 0;
     h->merge_launches = 0;
+    h->pass_launches = 0;
     return MI355REC_OK;
 }
 
@@ -534,6 +714,7 @@ int mi355rec_stats(const mi355rec_t* hc, mi355rec_stats_t* out) {
     };
     avg(h->ev_scan, h->n_scan_pairs, h->last_scan_ms);
     avg(h->ev_merge, h->n_merge_pairs, h->last_merge_ms);
+    avg(h->ev_pass, h->n_pass_pairs, h->last_pass_ms);
     out->rows = h->n;
     out->row_base = h->row_base;
     out->device = h->device;
@@ -543,6 +724,8 @@ int mi355rec_stats(const mi355rec_t* hc, mi355rec_stats_t* out) {
     out->bytes_per_query = h->n * kDim * static_cast<int64_t>(sizeof(float));
     out->last_scan_ms = h->last_scan_ms;
     out->last_merge_ms = h->last_merge_ms;
+    out->last_pass_ms = h->last_pass_ms;
+    out->batched_grid_blocks = h->bq.ready ? h->bq.grid : 0;
     return MI355REC_OK;
 }
 
@@ -585,6 +768,65 @@ int mi355rec_enqueue_batch_keys(mi355rec_t* h, const float* queries, const int64
     rc = order_stream(h, s);
     if (rc) return rc;
     return enqueue_batch(h, queries, exclude_global, batch, topn, out_keys_dev, nullptr, nullptr, s);
+}
+
+int mi355rec_enqueue_batch_keys_dev(mi355rec_t* h, const float* queries_dev, const int64_t* exclude_global_dev,
+                                    int batch, int topn, mi355rec_key_t* out_keys_dev, void* stream) {
+    if (!h || !queries_dev || !out_keys_dev) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (batch < 1) return fail(h, MI355REC_ERR_INVALID_ARG, "batch must be positive");
+    if (topn <= 0 || topn > kMultiMaxTopK)
+        return fail(h, MI355REC_ERR_INVALID_ARG, "topn must be in [1, %d] for device-resident batches, got %d",
+                    kMultiMaxTopK, topn);
+    if (h->n < 1) return fail(h, MI355REC_ERR_INVALID_ARG, "empty shard: use the host-query entry point");
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = order_stream(h, s);
+    if (rc) return rc;
+    rc = ensure_bq(h);
+    if (rc) return rc;
+    static_assert(sizeof(long long) == sizeof(int64_t), "exclude ids are passed through unchanged");
+    for (int b0 = 0; b0 < batch; b0 += kBqMaxQueries) {
+        const int count = batch - b0 < kBqMaxQueries ? batch - b0 : kBqMaxQueries;
+        rc = enqueue_bq_chunk(h, queries_dev + static_cast<size_t>(b0) * kDim,
+                              exclude_global_dev ? reinterpret_cast<const long long*>(exclude_global_dev) + b0 : nullptr,
+                              count, topn, out_keys_dev + static_cast<size_t>(b0) * topn, nullptr, nullptr, s);
+        if (rc) return rc;
+    }
+    return MI355REC_OK;
+}
+
+int mi355rec_batched_last_counters(mi355rec_t* h, int32_t* special_rows, int32_t* queued_queries,
+                                   int64_t* candidates_total, int32_t* candidates_max) {
+    if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    if (!h->bq.ready) return fail(h, MI355REC_ERR_INVALID_ARG, "no batched call has been made on this handle");
+    DeviceGuard guard(h->device);
+    HIP_TRY(h, hipDeviceSynchronize());
+    int counters[4] = {0, 0, 0, 0};
+    std::vector<int> cand(kBqMaxQueries);
+    std::vector<uint32_t> flags(kBqMaxQueries);
+    HIP_TRY(h, hipMemcpy(counters, h->bq.counters, sizeof counters, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(cand.data(), h->bq.cand_count, sizeof(int) * kBqMaxQueries, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(flags.data(), h->bq.qflags, sizeof(uint32_t) * kBqMaxQueries, hipMemcpyDeviceToHost));
+    int64_t total = 0;
+    int mx = 0;
+    for (int q = 0; q < kBqMaxQueries; ++q) {
+        if (flags[q] != kBqFlagOk) continue;   // padding, or rows of an earlier, larger chunk
+        total += cand[q];
+        if (cand[q] > mx) mx = cand[q];
+    }
+    if (special_rows) *special_rows = counters[0];
+    if (queued_queries) *queued_queries = counters[1];
+    if (candidates_total) *candidates_total = total;
+    if (candidates_max) *candidates_max = mx;
+    return MI355REC_OK;
+}
+
+int mi355rec_set_batch_path(mi355rec_t* h, int path) {
+    if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    if (path != MI355REC_BATCH_AUTO && path != MI355REC_BATCH_MULTI && path != MI355REC_BATCH_MFMA)
+        return fail(h, MI355REC_ERR_INVALID_ARG, "unknown batch path %d", path);
+    h->batch_path = path;
+    return MI355REC_OK;
 }
 
 int mi355rec_enqueue_merge_keys(mi355rec_t* h, const mi355rec_key_t* lists_dev, int n_lists,

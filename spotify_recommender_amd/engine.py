@@ -167,6 +167,28 @@ class CosineEngine:
             excl.ctypes.data_as(ctypes.c_void_p) if excl is not None else None, q.shape[0], int(topn),
             ctypes.c_void_p(out_keys.data_ptr()), self._stream_ptr(stream)), self._h)
 
+    def enqueue_batch_keys_dev(self, queries_dev, exclude_dev, topn: int, out_keys, stream=None) -> None:
+        """Batched matrix-core path over queries already in device memory
+        (float32 [batch, 12] tensor; exclude_dev int64 [batch] tensor or None)."""
+        capi.check(self._lib.mi355rec_enqueue_batch_keys_dev(
+            self._h, ctypes.c_void_p(queries_dev.data_ptr()),
+            ctypes.c_void_p(exclude_dev.data_ptr()) if exclude_dev is not None else None,
+            int(queries_dev.shape[0]), int(topn), ctypes.c_void_p(out_keys.data_ptr()),
+            self._stream_ptr(stream)), self._h)
+
+    def batched_last_counters(self) -> dict:
+        """Diagnostics of the last chunk served by the batched path (synchronises)."""
+        sp, qd, mx = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        tot = ctypes.c_int64(0)
+        capi.check(self._lib.mi355rec_batched_last_counters(
+            self._h, ctypes.byref(sp), ctypes.byref(qd), ctypes.byref(tot), ctypes.byref(mx)), self._h)
+        return {"special_rows": sp.value, "queued_queries": qd.value, "candidates_total": tot.value,
+                "candidates_max": mx.value}
+
+    def set_batch_path(self, path: int) -> None:
+        """capi.BATCH_AUTO / BATCH_MULTI / BATCH_MFMA (tests, A/B measurements)."""
+        capi.check(self._lib.mi355rec_set_batch_path(self._h, int(path)), self._h)
+
     def enqueue_merge_keys(self, lists, n_lists: int, list_len: int, topn: int, out_keys,
                            out_idx=None, out_score=None, stream=None) -> None:
         capi.check(self._lib.mi355rec_enqueue_merge_keys(
