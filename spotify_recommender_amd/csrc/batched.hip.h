@@ -68,11 +68,11 @@ typedef float bq_f16v __attribute__((ext_vector_type(16)));
 
 constexpr int kBqMaxBlocks = 32;             // 32 queries per block -> 1024 queries per chunk
 constexpr int kBqMaxQueries = kBqMaxBlocks * 32;
-constexpr int kBqCap = 1024;                 // candidate rows kept per query
+constexpr int kBqCap = 4096;                 // candidate rows kept per query
 constexpr int kBqSpecialCap = 1024;          // special rows kept per chunk
 constexpr int kBqFinalBlock = 256;           // threads of the finalize workgroup
 constexpr int kBqFinalPerThread = (kBqCap + kBqSpecialCap) / kBqFinalBlock;
-constexpr int kBqPassBlock = 256;            // 4 waves, one per SIMD; 2 workgroups per CU
+constexpr int kBqPassBlock = 256;            // 4 waves, one per SIMD; 4-5 workgroups per CU
 constexpr float kBqMargin = 1.5e-3f;
 constexpr float kBqSlack = 4e-6f;            // fp16 hi/lo split of T' and the fused subtraction
 constexpr float kBqMinNorm2 = 1.01e-8f;      // |x| >= 1.005e-4 for rows and queries alike
@@ -128,38 +128,71 @@ __global__ __launch_bounds__(256) void bq_prepare_kernel(
 }
 
 // ---- the two passes ---------------------------------------------------------------
-// One wave = one 32-row tile at a time against all NB query blocks held in
-// registers (NB x 4 VGPRs).  Lane l (r = l & 31, h = l >> 5) loads floats
-// [0,8) (h = 0) or [8,12) (h = 1) of row tile*32 + r: exactly its share of the A
-// operand, A[row r][k = 8h + j].  Tiles are dealt round-robin over all waves of the
-// grid, so the chip reads one moving window of the matrix.
+// One wave = one 32-row tile at a time against all NB query blocks.  Lane l
+// (r = l & 31, h = l >> 5) loads floats [0,8) (h = 0) or [8,12) (h = 1) of row
+// tile*32 + r: exactly its share of the A operand, A[row r][k = 8h + j].  Tiles are
+// dealt round-robin over all waves of the grid, so the chip reads one moving window
+// of the matrix.  The B fragments (NB KiB) live in LDS and are read one
+// ds_read_b128 per MFMA, one block ahead: in registers they would cost 128 VGPRs and
+// leave two waves per SIMD, too few to cover the MFMA -> VALU latency of the
+// reduction (measured: 454 / 584 us per pass at 12.5 M rows x 1024 queries with B
+// in registers; tools/mfma_probe.hip has the issue-rate model).
 // C/D layout (cdna_hip_programming.md §3): lane holds column c = l & 31 (the query)
 // and rows (i & 3) + 8 (i >> 2) + 4 h for register i = 0..15.
-template <int NB, bool kCollect>
-__global__ __launch_bounds__(kBqPassBlock, 2) void bq_pass_kernel(
-    const float* __restrict__ feats, int64_t n, int64_t n_tiles, const uint32_t* __restrict__ bfrag,
+// Per MFMA (1024 outputs) the VALU does 8 three-operand integer maxima; with the
+// MFMA's own 8 issue cycles that is ~40 cycles per block and SIMD against the 32 of
+// the matrix pipe: the passes are VALU-issue bound by construction.
+// Pass 2 stages its hits per wave in LDS; a flush hands 64 of them per round trip to
+// the global per-query lists.  Wave-synchronous: one wave's LDS operations execute in
+// order, no barrier involved.
+constexpr int kBqStage = 256;   // entries per wave (2 KiB); a block adds at most 64 per register
+
+__device__ __forceinline__ void bq_flush_stage(const uint2* stage, int staged, int lane, int* __restrict__ cand_count,
+                                               uint32_t* __restrict__ cand_rows) {
+    for (int e = lane; e < staged; e += 64) {
+        const uint2 qr = stage[e];
+        const int pos = atomicAdd(&cand_count[qr.x], 1);
+        if (pos < kBqCap) cand_rows[static_cast<int64_t>(qr.x) * kBqCap + pos] = qr.y;
+    }
+}
+
+template <bool kCollect>
+struct BqPassCfg {
+    static constexpr int kMinBlocksPerCu = 4;   // waves per SIMD the register budget must allow
+};
+
+// kVariant (development A/B only, tools/bqbench.hip; 0 in the product): 1 = one VALU
+// operation per MFMA instead of the 8-operation reduction, 2 = no ds_read in the block
+// loop (every MFMA uses block 0's fragment), 3 = both, 4 = synthetic rows (no HBM reads).
+template <int NB, bool kCollect, int kVariant = 0>
+__global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu) void bq_pass_kernel(
+    const float* __restrict__ feats, int64_t n, int64_t n_tiles, int tile_step, const uint32_t* __restrict__ bfrag,
     float* __restrict__ gmax /* [grid][NB][64] */, int* __restrict__ cand_count,
     uint32_t* __restrict__ cand_rows /* [query][kBqCap] */, int* __restrict__ counters,
     uint32_t* __restrict__ special_rows) {
+    // tile_step = 1: every 32-row tile.  tile_step = 2 (pass 1 only): every other tile —
+    // a threshold derived from ANY subset of the rows is a valid lower bound; from half of
+    // them it lets about twice as many candidates through and costs half a pass.
+    __shared__ uint4 s_b[NB][64];   // reused for the group maxima at the end of pass 1
+    __shared__ uint2 s_stage[kCollect ? kBqPassBlock / 64 : 1][kCollect ? kBqStage : 1];   // (query, row) per wave
+    uint2* const stage = s_stage[kCollect ? (threadIdx.x >> 6) : 0];
+    int staged = 0;   // wave-uniform
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r = lane & 31;
     const int h = lane >> 5;
 
-    bq_h8 B[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const uint4 w = reinterpret_cast<const uint4*>(bfrag)[b * 64 + lane];
-        B[b] = __builtin_bit_cast(bq_h8, w);
-    }
+    for (int i = threadIdx.x; i < NB * 64; i += kBqPassBlock) (&s_b[0][0])[i] = reinterpret_cast<const uint4*>(bfrag)[i];
+    __syncthreads();
+
     int mx[kCollect ? 1 : NB];   // running group maxima (bit patterns of floats >= 0)
     if constexpr (!kCollect) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) mx[b] = 0;
     }
 
-    const int64_t total_waves = static_cast<int64_t>(gridDim.x) * (kBqPassBlock / 64);
-    const int64_t first = static_cast<int64_t>(blockIdx.x) * (kBqPassBlock / 64) + wave;
+    const int64_t total_waves = static_cast<int64_t>(gridDim.x) * (kBqPassBlock / 64) * tile_step;
+    const int64_t first = (static_cast<int64_t>(blockIdx.x) * (kBqPassBlock / 64) + wave) * tile_step;
     const int64_t last_row = n - 1;
     const float4* base = reinterpret_cast<const float4*>(feats);
 
@@ -177,9 +210,15 @@ __global__ __launch_bounds__(kBqPassBlock, 2) void bq_pass_kernel(
 
     float4 na = load_a(first), nb = load_b(first);
     for (int64_t tile = first; tile < n_tiles; tile += total_waves) {
-        const float4 a = na, b = nb;
-        na = load_a(tile + total_waves);
-        nb = load_b(tile + total_waves);
+        float4 a = na, b = nb;
+        if constexpr ((kVariant & 4) != 0) {   // A/B probe: no HBM traffic, synthetic rows
+            const float t = static_cast<float>(tile & 1023) * 1e-3f + lane * 0.01f;
+            a = make_float4(t, 0.3f, 0.5f, t * 0.5f);
+            b = make_float4(0.1f, t, 0.7f, 0.2f);
+        } else {
+            na = load_a(tile + total_waves);
+            nb = load_b(tile + total_waves);
+        }
 
         const int64_t row = tile * 32 + r;
         float ss = a.x * a.x;
@@ -222,85 +261,121 @@ __global__ __launch_bounds__(kBqPassBlock, 2) void bq_pass_kernel(
         const bq_f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f,
                               0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         // Two accumulator tiles: the MFMA of block blk + 1 is issued before block blk's
-        // 16 results are reduced, so the matrix pipe does not wait for the VALU chain.
+        // 16 results are reduced, so the matrix pipe does not wait for the VALU tree.
         // The reductions run on the BIT PATTERNS as signed integers (v_max3_i32): for
         // the values that matter (>= 0) integer order is float order, negative floats
         // are negative integers, and there is no NaN canonicalisation to pay for.
         bq_f16v D[2];
-        D[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B[0], zero, 0, 0, 0);
+        uint4 bw[2];
+        // the fragments are loop-invariant: without this the compiler hoists all NB
+        // ds_reads out of the tile loop, back into 4 * NB registers (and spills them)
+        asm volatile("" ::: "memory");
+        bw[0] = s_b[0][lane];
+        if (NB > 1) bw[1] = s_b[1][lane];
+        D[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, __builtin_bit_cast(bq_h8, bw[0]), zero, 0, 0, 0);
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk) {
-            if (blk + 1 < NB) D[(blk + 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B[blk + 1], zero, 0, 0, 0);
+            if (blk + 1 < NB) {
+                D[(blk + 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                    A, __builtin_bit_cast(bq_h8, bw[(kVariant & 2) ? 0 : ((blk + 1) & 1)]), zero, 0, 0, 0);
+                if (blk + 2 < NB && (kVariant & 2) == 0) bw[blk & 1] = s_b[blk + 2][lane];
+            }
             const bq_f16v& d = D[blk & 1];
             auto bits = [&](int i) { return static_cast<int>(__float_as_uint(d[i])); };
             auto max3 = [](int x, int y, int z) { return max(max(x, y), z); };
+            if constexpr ((kVariant & 1) != 0 && !kCollect) {
+                mx[blk] = max(mx[blk], bits(0));
+                continue;
+            }
+            // depth-3 tree over the 16 results (8 operations, the last one folds the running maximum in)
+            const int t0 = max3(bits(0), bits(1), bits(2));
+            const int t1 = max3(bits(3), bits(4), bits(5));
+            const int t2 = max3(bits(6), bits(7), bits(8));
+            const int t3 = max3(bits(9), bits(10), bits(11));
+            const int t4 = max3(bits(12), bits(13), bits(14));
+            const int u0 = max3(t0, t1, t2);
+            const int u1 = max3(t3, t4, bits(15));
             if constexpr (!kCollect) {
-                int m = mx[blk];
-#pragma unroll
-                for (int i = 0; i < 16; i += 2) m = max3(m, bits(i), bits(i + 1));
-                mx[blk] = m;
+                mx[blk] = max3(mx[blk], u0, u1);
             } else {
-                int m = max3(bits(0), bits(1), bits(2));
-#pragma unroll
-                for (int i = 3; i < 15; i += 2) m = max3(m, bits(i), bits(i + 1));
-                m = max(m, bits(15));
+                const int m = max(u0, u1);
                 if (__builtin_expect(__ballot(m >= 0) != 0ull, 0)) {   // some D >= +0: approx >= T'
-                    const int q = blk * 32 + r;
+                    // Hits go to the wave's LDS staging buffer (ballot + prefix count, no atomics);
+                    // the global per-query counters are only touched when the buffer is flushed,
+                    // 64 entries per round trip.  A returning global atomic per hit kept each wave
+                    // waiting ~1.5 us about 160 times per pass (measured: 555 vs 485 us).
+                    const uint32_t q = static_cast<uint32_t>(blk * 32 + r);
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        if (bits(i) >= 0) {
-                            const int pos = atomicAdd(&cand_count[q], 1);
-                            if (pos < kBqCap)
-                                cand_rows[static_cast<int64_t>(q) * kBqCap + pos] =
-                                    static_cast<uint32_t>(tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h);
+                        const bool hit = bits(i) >= 0;
+                        const uint64_t who = __ballot(hit);
+                        if (who) {   // wave-uniform
+                            const int n_hit = __popcll(who);
+                            if (staged + n_hit > kBqStage) {
+                                bq_flush_stage(stage, staged, lane, cand_count, cand_rows);
+                                staged = 0;
+                            }
+                            if (hit) {
+                                const int slot = staged + __popcll(who & ((1ull << lane) - 1ull));
+                                stage[slot] = make_uint2(q, static_cast<uint32_t>(tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h));
+                            }
+                            staged += n_hit;
                         }
                     }
                 }
             }
         }
     }
+    if constexpr (kCollect) bq_flush_stage(stage, staged, lane, cand_count, cand_rows);
 
     if constexpr (!kCollect) {
         // group = (workgroup, lane half): max over the workgroup's 4 waves through LDS
-        __shared__ float s_mx[kBqPassBlock / 64][NB][64];
+        // (the B fragments are no longer needed: their NB KiB hold [wave][NB][64] floats)
+        __syncthreads();
+        float* s_mx = reinterpret_cast<float*>(&s_b[0][0]);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) s_mx[wave][b][lane] = __uint_as_float(static_cast<uint32_t>(mx[b]));
+        for (int b = 0; b < NB; ++b) s_mx[(wave * NB + b) * 64 + lane] = __uint_as_float(static_cast<uint32_t>(mx[b]));
         __syncthreads();
         for (int i = threadIdx.x; i < NB * 64; i += kBqPassBlock) {
-            const int b = i >> 6, l = i & 63;
-            float m = s_mx[0][b][l];
+            float m = s_mx[i];
 #pragma unroll
-            for (int w = 1; w < kBqPassBlock / 64; ++w) m = __builtin_fmaxf(m, s_mx[w][b][l]);
-            gmax[(static_cast<int64_t>(blockIdx.x) * NB + b) * 64 + l] = m;
+            for (int w = 1; w < kBqPassBlock / 64; ++w) m = __builtin_fmaxf(m, s_mx[w * NB * 64 + i]);
+            gmax[static_cast<int64_t>(blockIdx.x) * NB * 64 + i] = m;
         }
     }
 }
 
 // ---- per-query threshold ----------------------------------------------------------
-// One workgroup of 1024 threads per query block: the block's group maxima
-// ([grid][64] floats, 256 B per workgroup of pass 1) are staged in LDS, then wave w
-// selects the (topk+1)-th largest value for queries w and w + 16 (32 per block).
-constexpr int kBqSelectBlock = 512;
-constexpr int kBqSelectMaxGroups = 2048;   // 2 per pass-1 workgroup -> pass-1 grid <= 1024
-constexpr int kBqSelectKeys = kBqSelectMaxGroups / 64;
+// One workgroup of 256 threads per (query block, quarter): the group maxima of its 8
+// queries ([grid][2 halves] values each) are staged in LDS, then wave w selects the
+// (topk+1)-th largest value for queries 2w and 2w + 1 of the quarter.
+constexpr int kBqSelectBlock = 256;
+constexpr int kBqSelectQueries = 8;           // queries per workgroup
+constexpr int kBqMaxPassGrid = 1280;          // 5 workgroups per CU on 256 CUs
+constexpr int kBqSelectKeys = kBqMaxPassGrid * kBqGroupsPerBlock / 64;   // group maxima per lane
 
 __global__ __launch_bounds__(kBqSelectBlock) void bq_select_kernel(
     const float* __restrict__ gmax, int grid_pass1, int n_blocks, int topk, uint32_t* __restrict__ bfrag,
     uint32_t* __restrict__ qflags, float* __restrict__ qthr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bq_smem[];
-    float* s_vals = reinterpret_cast<float*>(bq_smem);                       // [grid][65]
-    int* s_hist = reinterpret_cast<int*>(s_vals + static_cast<size_t>(grid_pass1) * 65);  // [16][256]
+    float* s_vals = reinterpret_cast<float*>(bq_smem);                        // [2 * grid][9]
+    int* s_hist = reinterpret_cast<int*>(s_vals + static_cast<size_t>(grid_pass1) * 2 * 9);  // [4][256]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int blk = blockIdx.x;
-    for (int i = tid; i < grid_pass1 * 64; i += kBqSelectBlock) {
-        const int g = i >> 6, l = i & 63;
-        s_vals[g * 65 + l] = gmax[(static_cast<int64_t>(g) * n_blocks + blk) * 64 + l];
+    const int blk = blockIdx.x >> 2;
+    const int quarter = blockIdx.x & 3;
+    const int groups = grid_pass1 * kBqGroupsPerBlock;
+    // group gi = half * grid + workgroup; 8 consecutive floats (32 B) per group
+    for (int i = tid; i < groups * kBqSelectQueries; i += kBqSelectBlock) {
+        const int gi = i >> 3, j = i & 7;
+        const int half = gi >= grid_pass1 ? 1 : 0;
+        const int g = gi - half * grid_pass1;
+        s_vals[gi * 9 + j] = gmax[(static_cast<int64_t>(g) * n_blocks + blk) * 64 + half * 32 + quarter * 8 + j];
     }
     __syncthreads();
-    const int groups = grid_pass1 * kBqGroupsPerBlock;
-    for (int c = wave; c < 32; c += kBqSelectBlock / 64) {
+    for (int j = wave; j < kBqSelectQueries; j += kBqSelectBlock / 64) {
+        const int c = quarter * 8 + j;
         const int q = blk * 32 + c;
         uint32_t flag = qflags[q];
         float thr_out = 0.0f;
@@ -310,13 +385,10 @@ __global__ __launch_bounds__(kBqSelectBlock) void bq_select_kernel(
             int positive = 0;
 #pragma unroll
             for (int u = 0; u < kBqSelectKeys; ++u) {
-                // group index -> (half, workgroup); consecutive lanes read consecutive
-                // workgroups' rows of s_vals (stride 65 words: conflict-free)
-                const int gi = lane + u * 64;
+                const int gi = lane + u * 64;   // consecutive lanes: stride 9 words, conflict-free
                 uint64_t key = 0ull;
                 if (gi < groups) {
-                    const int half = gi >= grid_pass1 ? 1 : 0;
-                    const float v = s_vals[(gi - half * grid_pass1) * 65 + half * 32 + c];
+                    const float v = s_vals[gi * 9 + j];
                     if (v > 0.0f) {
                         key = (static_cast<uint64_t>(score_to_ordered(v)) << 32) | static_cast<uint32_t>(gi + 1);
                         ++positive;

@@ -11,6 +11,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -86,7 +87,10 @@ struct mi355rec {
     // batched path (batched.hip.h): allocated by the first batched call
     struct Batched {
         bool ready = false;
-        int grid = 0;                 // workgroups of the two passes (2 per CU, <= 512)
+        int grid = 0;                 // workgroups of pass 1 (= groups / 2 of the threshold select)
+        int grid2 = 0;                // workgroups of pass 2
+        int occ1 = 0, occ2 = 0;
+        int step1 = 4;                // pass 1 looks at every step1-th tile (tuning knob MI355REC_BQ_STEP1)
         int qgrid = 0, qiters = 0;    // geometry of the queued exact scan
         uint32_t* bfrag = nullptr;    // [32][64][4]
         float* qnorm = nullptr;
@@ -469,9 +473,21 @@ constexpr int kBqMinBatch = 13;          // up to 12 queries are ONE multi-query
 int ensure_bq(mi355rec* h) {
     auto& b = h->bq;
     if (b.ready) return MI355REC_OK;
-    int grid = h->cus * 2;
-    if (grid > kBqSelectMaxGroups / kBqGroupsPerBlock / 2) grid = kBqSelectMaxGroups / kBqGroupsPerBlock / 2;  // 512: select's LDS
+    // workgroups of a pass: what the 1024-query kernels can keep resident (LDS: 32 KiB of B
+    // fragments per workgroup; registers: 4 resp. 5 waves per SIMD), the same for both passes
+    int occ1 = 0, occ2 = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ1, bq_pass_kernel<kBqMaxBlocks, false>, kBqPassBlock, 0) != hipSuccess || occ1 < 1) occ1 = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ2, bq_pass_kernel<kBqMaxBlocks, true>, kBqPassBlock, 0) != hipSuccess || occ2 < 1) occ2 = 1;
+    b.occ1 = occ1 < 5 ? occ1 : 5;
+    b.occ2 = occ2 < 5 ? occ2 : 5;
+    int grid = h->cus * b.occ1;
+    if (grid > kBqMaxPassGrid) grid = kBqMaxPassGrid;
     b.grid = grid;
+    b.grid2 = h->cus * b.occ2;
+    if (const char* e = std::getenv("MI355REC_BQ_STEP1")) {
+        const int v = std::atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8) b.step1 = v;
+    }
     b.qgrid = h->cus < kMergeMaxLists ? h->cus : kMergeMaxLists;
     const int64_t tiles = (h->n + MultiConfig::kTileRows - 1) / MultiConfig::kTileRows;
     if (tiles < b.qgrid) b.qgrid = static_cast<int>(tiles);
@@ -496,7 +512,7 @@ int ensure_bq(mi355rec* h) {
     }
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bq_select_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   static_cast<int>(sizeof(float) * grid * 65 + sizeof(int) * (kBqSelectBlock / 64) * 256)));
+                                   static_cast<int>(sizeof(float) * grid * 2 * 9 + sizeof(int) * (kBqSelectBlock / 64) * 256)));
     b.ready = true;
     return MI355REC_OK;
 }
@@ -519,16 +535,19 @@ template <int NB>
 void launch_bq_passes(mi355rec* h, int topn, hipStream_t s) {
     auto& b = h->bq;
     const int64_t n_tiles = (h->n + 31) / 32;
-    const size_t smem = sizeof(float) * b.grid * 65 + sizeof(int) * (kBqSelectBlock / 64) * 256;
+    // pass 1 looks at every other tile once each wave still gets a few dozen of them
+    int step1 = n_tiles >= static_cast<int64_t>(b.grid) * (kBqPassBlock / 64) * 16 ? b.step1 : 1;
+    while (step1 > 1 && n_tiles < static_cast<int64_t>(b.grid) * (kBqPassBlock / 64) * 8 * step1) step1 /= 2;
+    const size_t smem = sizeof(float) * b.grid * 2 * 9 + sizeof(int) * (kBqSelectBlock / 64) * 256;
     int slot = timing_begin(h, h->ev_pass, h->n_pass_pairs, h->pass_launches, s);
     hipLaunchKernelGGL((bq_pass_kernel<NB, false>), dim3(b.grid), dim3(kBqPassBlock), 0, s, h->d_feats, h->n, n_tiles,
-                       b.bfrag, b.gmax, b.cand_count, b.cand_rows, b.counters, b.special_rows);
+                       step1, b.bfrag, b.gmax, b.cand_count, b.cand_rows, b.counters, b.special_rows);
     timing_end(h, h->ev_pass, h->n_pass_pairs, slot, s);
-    hipLaunchKernelGGL(bq_select_kernel, dim3(NB), dim3(kBqSelectBlock), smem, s, b.gmax, b.grid, NB, topn, b.bfrag,
+    hipLaunchKernelGGL(bq_select_kernel, dim3(NB * 4), dim3(kBqSelectBlock), smem, s, b.gmax, b.grid, NB, topn, b.bfrag,
                        b.qflags, b.qthr);
     slot = timing_begin(h, h->ev_pass, h->n_pass_pairs, h->pass_launches, s);
-    hipLaunchKernelGGL((bq_pass_kernel<NB, true>), dim3(b.grid), dim3(kBqPassBlock), 0, s, h->d_feats, h->n, n_tiles,
-                       b.bfrag, b.gmax, b.cand_count, b.cand_rows, b.counters, b.special_rows);
+    hipLaunchKernelGGL((bq_pass_kernel<NB, true>), dim3(b.grid2), dim3(kBqPassBlock), 0, s, h->d_feats, h->n, n_tiles,
+                       1, b.bfrag, b.gmax, b.cand_count, b.cand_rows, b.counters, b.special_rows);
     timing_end(h, h->ev_pass, h->n_pass_pairs, slot, s);
 }
 

@@ -68,7 +68,7 @@ def test_uniform_catalogue_matches_oracle(Engine, batch, topn):
         assert d["queued_queries"] == 0 and d["special_rows"] == 0, d
         served = batch if batch <= 1024 else batch - 1024       # diagnostics cover the last chunk
         assert d["candidates_total"] >= served * min(topn, 1), d
-        assert d["candidates_max"] <= 1024
+        assert d["candidates_max"] <= 4096
         # every list equals the single-query path, bit for bit
         for b in range(0, batch, 7):
             si, ss = eng.query_topn(queries[b], int(excl[b]), topn)
@@ -214,7 +214,7 @@ def test_config5_shard_1024_queries_every_list(Engine, torch_cuda):
         torch.cuda.synchronize()
         d = eng.batched_last_counters()
         assert d["queued_queries"] == 0 and d["special_rows"] == 0, d
-        assert batch * topn <= d["candidates_total"] <= batch * 8 * topn, d
+        assert batch * topn <= d["candidates_total"] <= batch * 24 * topn, d
         got = keys.cpu().numpy().reshape(batch, topn)
         for b in range(batch):
             eng.enqueue_query_keys(queries[b], int(excl[b]), topn, single)

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Timing / profiling driver for the batched matrix-core path (BASELINE configs[4] as one
+GPU sees it): `--rows` catalogue rows, `--batch` device-resident queries per call.
+  python3 tools/run_batched.py --rows 12500000 --batch 1024 --reps 10
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/x -- python3 tools/run_batched.py ...
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=12_500_000)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--topn", type=int, default=100)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--path", type=int, default=0, help="0 auto, 1 multi-query passes, 2 batched MFMA")
+    ap.add_argument("--host-queries", action="store_true")
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    from spotify_recommender_amd import CosineEngine
+    from spotify_recommender_amd.synth import synthetic_catalogue
+
+    t = synthetic_catalogue(args.rows, seed=12345)
+    rows = np.array([(k * 7919) % args.rows for k in range(args.batch)], dtype=np.int64)
+    qd = t[torch.from_numpy(rows).cuda()].contiguous()
+    ed = torch.from_numpy(rows).cuda()
+    qh = qd.cpu().numpy()
+    keys = torch.zeros(args.batch * args.topn, dtype=torch.int64, device="cuda")
+    with CosineEngine(t) as eng:
+        eng.set_batch_path(args.path)
+
+        def call():
+            if args.host_queries or args.path == 1:
+                eng.enqueue_batch_keys(qh, rows, args.topn, keys)
+            else:
+                eng.enqueue_batch_keys_dev(qd, ed, args.topn, keys)
+
+        call()
+        torch.cuda.synchronize()
+        eng.set_timing(1)
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            call()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.reps
+        st = eng.stats()
+        out = {"rows": args.rows, "batch": args.batch, "topn": args.topn, "path": args.path,
+               "ms_per_batch": round(dt * 1e3, 4), "queries_per_s": round(args.batch / dt, 1),
+               "pass_kernel_ms": round(float(st.last_pass_ms), 4),
+               "effective_tflops_24flop_per_pair": round(24.0 * args.rows * args.batch / dt / 1e12, 2)}
+        if args.path != 1:
+            out.update(eng.batched_last_counters())
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
