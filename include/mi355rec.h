@@ -238,6 +238,65 @@ int mi355rec_enqueue_stream_probe(mi355rec_t* h, uint32_t* sink_dev, void* strea
  * (an event pair costs a few microseconds of stream time). */
 int mi355rec_set_timing(mi355rec_t* h, int enabled);
 
+/* The 12 features of one resident row, copied back to the host (48 bytes). */
+int mi355rec_fetch_row(mi355rec_t* h, int64_t local_row, float* out12_host);
+
+/* ---- row-sharded catalogue: ONE host process, every GPU of the node ---------
+ * Replaces the reference's single-device residency (cudaSetDevice(0),
+ * Recommender.cu:124) for a C / C++ host: shard r holds a contiguous block of
+ * rows on its own device (balanced split, global row ids), every query runs the
+ * fused scan + local merge on all shards concurrently, the per-shard top-N key
+ * lists meet on the first device and the same merge kernel produces the global
+ * top-N.  The result is independent of the number of shards.
+ *
+ * The only inter-GPU exchange is topn x batch uint64 keys per shard:
+ *   MI355REC_TRANSPORT_PEER  the shards' merge kernels store their keys straight
+ *       into the first device's gather buffer through a peer mapping (xGMI
+ *       point-to-point) and an event per shard orders the final merge behind
+ *       them — no collective, no copy launch.  Default when peer access exists.
+ *   MI355REC_TRANSPORT_RCCL  one grouped ncclAllGather per call (ncclCommInitAll,
+ *       ncclGroupStart/End); librccl is opened on first use of this transport.
+ * All calls are synchronous (results in host memory on return); one host thread
+ * at a time per handle.  topn > 1024 is served exactly but slowly (per-shard
+ * rounds, the G sorted key lists merged on the host). */
+typedef struct mi355rec_sharded mi355rec_sharded_t;
+
+#define MI355REC_MAX_SHARDS 64
+#define MI355REC_TRANSPORT_PEER 1
+#define MI355REC_TRANSPORT_RCCL 2
+
+/* n_devices = 0: every visible device (at most MI355REC_MAX_SHARDS); otherwise
+ * devices 0 .. n_devices-1.  `feats_host` is the whole row-major n x 12 matrix;
+ * each device receives its own block only. */
+int mi355rec_create_sharded(const float* feats_host, int64_t n, int dim, int n_devices,
+                            mi355rec_sharded_t** out);
+
+/* Explicit placement: shard r on device devices[r].  A device may appear more
+ * than once (virtual shards: several shards of one GPU; how the orchestration is
+ * exercised on a one-GPU box) — the RCCL transport then refuses, the peer
+ * transport degenerates to stores into local memory. */
+int mi355rec_create_sharded_on(const float* feats_host, int64_t n, int dim, const int* devices,
+                               int n_shards, mi355rec_sharded_t** out);
+
+void mi355rec_sharded_destroy(mi355rec_sharded_t* h);
+const char* mi355rec_sharded_last_error(const mi355rec_sharded_t* h);
+int mi355rec_sharded_set_transport(mi355rec_sharded_t* h, int transport);
+
+/* Any out pointer may be NULL; devices_out / shard_rows_out need n_shards slots. */
+int mi355rec_sharded_info(const mi355rec_sharded_t* h, int* n_shards, int* transport,
+                          int64_t* rows, int* devices_out, int64_t* shard_rows_out);
+
+/* Same contracts as mi355rec_query_row_topn / _query_topn / _query_batch_topn /
+ * _scores_row, with GLOBAL row indices. */
+int mi355rec_sharded_query_row_topn(mi355rec_sharded_t* h, int64_t global_row, int topn,
+                                    int64_t* out_idx, float* out_score, int* out_count);
+int mi355rec_sharded_query_topn(mi355rec_sharded_t* h, const float* query12, int64_t exclude_global,
+                                int topn, int64_t* out_idx, float* out_score, int* out_count);
+int mi355rec_sharded_query_batch_topn(mi355rec_sharded_t* h, const float* queries, int batch,
+                                      const int64_t* exclude_global, int topn, int64_t* out_idx,
+                                      float* out_score, int* out_count);
+int mi355rec_sharded_scores_row(mi355rec_sharded_t* h, int64_t global_row, float* out_host);
+
 /* ---- key helpers (host side, no device needed) --------------------------- */
 mi355rec_key_t mi355rec_pack_key(float score, int64_t global_row);
 float mi355rec_key_score(mi355rec_key_t key);

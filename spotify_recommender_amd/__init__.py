@@ -7,6 +7,6 @@ Layout (hot path only — see DESIGN.md):
   capi.py, engine.py   ctypes + torch plumbing (device memory, streams, RCCL)
 """
 from . import capi  # noqa: F401
-from .engine import CosineEngine, ShardedEngine, shard_bounds, unpack_keys  # noqa: F401
+from .engine import CosineEngine, NodeEngine, ShardedEngine, shard_bounds, unpack_keys  # noqa: F401
 
 FEATURE_COUNT = capi.DIM  # Song.h:12

@@ -22,14 +22,14 @@ BIN_CLI = PKG / "recommender"              # drop-in CLI (main.cpp equivalent)
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 OFFLOAD_ARCH = "gfx950"
 
-ENGINE_SOURCES = [CSRC / "mi355rec.hip"]
+ENGINE_SOURCES = [CSRC / "mi355rec.hip", CSRC / "sharded.hip"]
 ENGINE_DEPS = ENGINE_SOURCES + [CSRC / "kernels.hip.h", CSRC / "batched.hip.h", INCLUDE / "mi355rec.h"]
 
 # -ffp-contract=off: the parity contract is sequential multiply-then-add with no
 # FMA contraction (Recommender.cu:264-269 compiled by the reference Makefile:9).
 HIP_FLAGS = [
     f"--offload-arch={OFFLOAD_ARCH}", "-O3", "-std=c++17", "-ffp-contract=off",
-    "-fPIC", "-shared", f"-I{INCLUDE}", f"-I{CSRC}",
+    "-fPIC", "-shared", f"-I{INCLUDE}", f"-I{CSRC}", "-ldl",
 ]
 
 

@@ -16,6 +16,7 @@ LIB_PATH = PKG / "libmi355rec.so"
 DIM = 12
 MAX_TOPN_FAST = 1024
 BATCH_AUTO, BATCH_MULTI, BATCH_MFMA = 0, 1, 2
+TRANSPORT_PEER, TRANSPORT_RCCL = 1, 2
 
 OK = 0
 ERR_INVALID_ARG = -1
@@ -67,6 +68,17 @@ SIGNATURES = {
     "mi355rec_enqueue_scores": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "mi355rec_enqueue_stream_probe": (c_int, [c_void_p, c_void_p, c_void_p]),
     "mi355rec_set_timing": (c_int, [c_void_p, c_int]),
+    "mi355rec_fetch_row": (c_int, [c_void_p, c_int64, c_void_p]),
+    "mi355rec_create_sharded": (c_int, [c_void_p, c_int64, c_int, c_int, POINTER(c_void_p)]),
+    "mi355rec_create_sharded_on": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, POINTER(c_void_p)]),
+    "mi355rec_sharded_destroy": (None, [c_void_p]),
+    "mi355rec_sharded_last_error": (c_char_p, [c_void_p]),
+    "mi355rec_sharded_set_transport": (c_int, [c_void_p, c_int]),
+    "mi355rec_sharded_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int64), c_void_p, c_void_p]),
+    "mi355rec_sharded_query_row_topn": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, POINTER(c_int)]),
+    "mi355rec_sharded_query_topn": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, POINTER(c_int)]),
+    "mi355rec_sharded_query_batch_topn": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "mi355rec_sharded_scores_row": (c_int, [c_void_p, c_int64, c_void_p]),
     "mi355rec_pack_key": (c_uint64, [c_float, c_int64]),
     "mi355rec_key_score": (c_float, [c_uint64]),
     "mi355rec_key_row": (c_int64, [c_uint64]),

@@ -14,7 +14,8 @@ struct Recommender::Impl {
     bool initialized = false;
     bool gpuEnabled = false;
     int numSongs = 0;
-    mi355rec_t* engine = nullptr;
+    mi355rec_sharded_t* engine = nullptr;   // the catalogue row-sharded over every visible GPU
+    int numDevices = 0;
 
     // Only what the lookups need is kept (the reference deep-copies every Song,
     // Recommender.cu:109).  `byId` maps a track id to its FIRST row, which is
@@ -41,7 +42,7 @@ std::string toLower(const std::string& str) {  // Recommender.cu:329-334
 Recommender::Recommender() : impl_(new Impl()) {}
 
 Recommender::~Recommender() {  // Recommender.cu:86-98
-    if (impl_->engine) mi355rec_destroy(impl_->engine);
+    if (impl_->engine) mi355rec_sharded_destroy(impl_->engine);
     delete impl_;
 }
 
@@ -52,7 +53,7 @@ bool Recommender::initialize(const std::vector<Song>& songs) {  // Recommender.c
         return false;
     }
     if (impl_->engine) {
-        mi355rec_destroy(impl_->engine);
+        mi355rec_sharded_destroy(impl_->engine);
         impl_->engine = nullptr;
     }
     impl_->initialized = false;
@@ -71,18 +72,24 @@ bool Recommender::initialize(const std::vector<Song>& songs) {  // Recommender.c
         impl_->byId.emplace(songs[i].track_id, static_cast<int>(i));  // keeps the first
     }
 
-    const int rc = mi355rec_create(matrix.data(), static_cast<int64_t>(songs.size()), FEATURE_COUNT,
-                                   /*device=*/0, /*row_base=*/0, &impl_->engine);
+    // The reference pins device 0 (Recommender.cu:124); here the rows are sharded over
+    // every visible GPU (one process, one stream per device, xGMI peer stores or one RCCL
+    // all-gather of the per-shard top-N keys: include/mi355rec.h, "row-sharded catalogue").
+    const int rc = mi355rec_create_sharded(matrix.data(), static_cast<int64_t>(songs.size()), FEATURE_COUNT,
+                                           /*n_devices=*/0, &impl_->engine);
     if (rc != MI355REC_OK) {
         // The reference would say "[GPU Disabled] ... Falling back to CPU" and go
         // on (:117-181).  There is no CPU path here: fail loudly.
-        std::cerr << "[GPU Disabled] " << mi355rec_last_global_error() << std::endl;
+        std::cerr << "[GPU Disabled] " << mi355rec_sharded_last_error(nullptr) << std::endl;
         std::cerr << "Error: the MI355X recommender needs a HIP device (no CPU fallback)" << std::endl;
         return false;
     }
+    mi355rec_sharded_info(impl_->engine, &impl_->numDevices, nullptr, nullptr, nullptr, nullptr);
     impl_->gpuEnabled = true;
     impl_->initialized = true;
-    std::cout << "Successfully initialized with " << impl_->numSongs << " songs on GPU" << std::endl;
+    std::cout << "Successfully initialized with " << impl_->numSongs << " songs on GPU";
+    if (impl_->numDevices > 1) std::cout << " (row-sharded over " << impl_->numDevices << " devices)";
+    std::cout << std::endl;
     return true;
 }
 
@@ -106,10 +113,10 @@ std::vector<int> Recommender::recommendByIndex(int songIndex, int topN) {  // Re
     impl_->idxBuf.assign(static_cast<size_t>(topN), -1);
     impl_->scoreBuf.assign(static_cast<size_t>(topN), 0.0f);
     int count = 0;
-    const int rc = mi355rec_query_row_topn(impl_->engine, songIndex, topN, impl_->idxBuf.data(),
-                                           impl_->scoreBuf.data(), &count);
+    const int rc = mi355rec_sharded_query_row_topn(impl_->engine, songIndex, topN, impl_->idxBuf.data(),
+                                                   impl_->scoreBuf.data(), &count);
     if (rc != MI355REC_OK) {
-        std::cerr << "Error: " << mi355rec_last_error(impl_->engine) << std::endl;
+        std::cerr << "Error: " << mi355rec_sharded_last_error(impl_->engine) << std::endl;
         return {};
     }
     std::vector<int> results(static_cast<size_t>(count));
@@ -163,5 +170,5 @@ bool Recommender::similarities(int songIndex, std::vector<float>& out) {  // Rec
         return false;
     }
     out.resize(static_cast<size_t>(impl_->numSongs));
-    return mi355rec_scores_row(impl_->engine, songIndex, out.data()) == MI355REC_OK;
+    return mi355rec_sharded_scores_row(impl_->engine, songIndex, out.data()) == MI355REC_OK;
 }

@@ -941,6 +941,15 @@ static int scores_common(mi355rec_t* h, int64_t local_row, const float* query12,
     return MI355REC_OK;
 }
 
+int mi355rec_fetch_row(mi355rec_t* h, int64_t local_row, float* out12_host) {
+    if (!h || !out12_host) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (local_row < 0 || local_row >= h->n)
+        return fail(h, MI355REC_ERR_INVALID_ARG, "Invalid song index: %lld", (long long)local_row);
+    DeviceGuard guard(h->device);
+    HIP_TRY(h, hipMemcpy(out12_host, h->d_feats + local_row * kDim, sizeof(float) * kDim, hipMemcpyDeviceToHost));
+    return MI355REC_OK;
+}
+
 int mi355rec_scores_row(mi355rec_t* h, int64_t local_row, float* out_host) {
     if (h && (local_row < 0 || local_row >= h->n))
         return fail(h, MI355REC_ERR_INVALID_ARG, "Invalid song index: %lld", (long long)local_row);

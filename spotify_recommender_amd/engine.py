@@ -227,6 +227,106 @@ class CosineEngine:
         return st
 
 
+class NodeEngine:
+    """The row-sharded catalogue driven by ONE process (mi355rec_create_sharded):
+    what the C++ Recommender shim uses.  `devices=None` -> every visible GPU;
+    a list may repeat a device (virtual shards on a one-GPU box)."""
+
+    def __init__(self, feats, devices=None, n_devices: int = 0):
+        self._lib = capi.lib()
+        self._h = ctypes.c_void_p()
+        arr = _np_f32(feats)
+        if arr.ndim != 2 or arr.shape[1] != capi.DIM:
+            raise ValueError("catalogue must be float32 [n, 12]")
+        if devices is None:
+            rc = self._lib.mi355rec_create_sharded(arr.ctypes.data_as(ctypes.c_void_p), arr.shape[0], arr.shape[1],
+                                                   int(n_devices), ctypes.byref(self._h))
+        else:
+            devs = np.ascontiguousarray(np.asarray(devices, dtype=np.int32))
+            rc = self._lib.mi355rec_create_sharded_on(arr.ctypes.data_as(ctypes.c_void_p), arr.shape[0], arr.shape[1],
+                                                      devs.ctypes.data_as(ctypes.c_void_p), len(devs), ctypes.byref(self._h))
+        if rc != capi.OK:
+            raise capi.Mi355Error(rc, (self._lib.mi355rec_sharded_last_error(None) or b"").decode("utf-8", "replace"))
+        self.rows = int(arr.shape[0])
+
+    def _check(self, rc: int) -> None:
+        if rc != capi.OK:
+            raise capi.Mi355Error(rc, (self._lib.mi355rec_sharded_last_error(self._h) or b"").decode("utf-8", "replace"))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.mi355rec_sharded_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def info(self) -> dict:
+        n, t = ctypes.c_int(0), ctypes.c_int(0)
+        rows = ctypes.c_int64(0)
+        devs = np.zeros(64, dtype=np.int32)
+        per = np.zeros(64, dtype=np.int64)
+        self._check(self._lib.mi355rec_sharded_info(self._h, ctypes.byref(n), ctypes.byref(t), ctypes.byref(rows),
+                                                    devs.ctypes.data_as(ctypes.c_void_p), per.ctypes.data_as(ctypes.c_void_p)))
+        return {"n_shards": n.value, "transport": t.value, "rows": rows.value,
+                "devices": devs[: n.value].tolist(), "shard_rows": per[: n.value].tolist()}
+
+    def set_transport(self, transport: int) -> None:
+        self._check(self._lib.mi355rec_sharded_set_transport(self._h, int(transport)))
+
+    def query_row_topn(self, global_row: int, topn: int) -> Tuple[np.ndarray, np.ndarray]:
+        n_out = max(int(topn), 1)
+        idx = np.empty(n_out, dtype=np.int64)
+        score = np.empty(n_out, dtype=np.float32)
+        count = ctypes.c_int(0)
+        self._check(self._lib.mi355rec_sharded_query_row_topn(
+            self._h, int(global_row), int(topn), idx.ctypes.data_as(ctypes.c_void_p),
+            score.ctypes.data_as(ctypes.c_void_p), ctypes.byref(count)))
+        return idx[:count.value].copy(), score[:count.value].copy()
+
+    def query_topn(self, query, exclude_global: int, topn: int) -> Tuple[np.ndarray, np.ndarray]:
+        q = _np_f32(query).reshape(capi.DIM)
+        n_out = max(int(topn), 1)
+        idx = np.empty(n_out, dtype=np.int64)
+        score = np.empty(n_out, dtype=np.float32)
+        count = ctypes.c_int(0)
+        self._check(self._lib.mi355rec_sharded_query_topn(
+            self._h, q.ctypes.data_as(ctypes.c_void_p), int(exclude_global), int(topn),
+            idx.ctypes.data_as(ctypes.c_void_p), score.ctypes.data_as(ctypes.c_void_p), ctypes.byref(count)))
+        return idx[:count.value].copy(), score[:count.value].copy()
+
+    def query_batch_topn(self, queries, exclude_global, topn: int):
+        q = _np_f32(queries).reshape(-1, capi.DIM)
+        b = q.shape[0]
+        excl = None
+        if exclude_global is not None:
+            excl = np.ascontiguousarray(np.asarray(exclude_global, dtype=np.int64).reshape(b))
+        n_out = max(int(topn), 1)
+        idx = np.empty((b, n_out), dtype=np.int64)
+        score = np.empty((b, n_out), dtype=np.float32)
+        counts = np.zeros(b, dtype=np.int32)
+        self._check(self._lib.mi355rec_sharded_query_batch_topn(
+            self._h, q.ctypes.data_as(ctypes.c_void_p), b,
+            excl.ctypes.data_as(ctypes.c_void_p) if excl is not None else None, int(topn),
+            idx.ctypes.data_as(ctypes.c_void_p), score.ctypes.data_as(ctypes.c_void_p),
+            counts.ctypes.data_as(ctypes.c_void_p)))
+        return idx, score, counts
+
+    def scores_row(self, global_row: int) -> np.ndarray:
+        out = np.empty(self.rows, dtype=np.float32)
+        self._check(self._lib.mi355rec_sharded_scores_row(self._h, int(global_row), out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+
 # ---- packed keys on the host (pure bit manipulation, mirrors kernels.hip.h) ----
 
 def unpack_keys(keys) -> Tuple[np.ndarray, np.ndarray]:

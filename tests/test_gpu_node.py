@@ -1,0 +1,117 @@
+"""The row-sharded engine behind the C-ABI (mi355rec_create_sharded*, csrc/sharded.hip):
+one process, one stream per shard, peer stores or one RCCL all-gather, merge on the
+first device.  On a one-GPU box the orchestration is exercised with VIRTUAL shards
+(the same device listed several times); the RCCL transport runs a real
+ncclAllGather at one rank.  Everything is compared with the oracle."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.parity import assert_topn_matches
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Node():
+    import torch
+    assert torch.cuda.is_available()
+    from spotify_recommender_amd.engine import NodeEngine
+    return NodeEngine
+
+
+def check(node, f, q, excl, topn):
+    idx, sc = node.query_topn(q, excl, topn)
+    want = oracle.scores(f, q)
+    assert_topn_matches(idx, sc, want, excl, topn, ref_idx=oracle.topn_heap(want, excl, topn))
+    return idx, sc
+
+
+def test_one_device_equals_the_single_engine(Node):
+    from spotify_recommender_amd import capi
+    from spotify_recommender_amd.engine import CosineEngine
+    rng = np.random.default_rng(1)
+    f = rng.random((300_000, 12), dtype=np.float32)
+    with Node(f, n_devices=0) as node, CosineEngine(f) as eng:
+        info = node.info()
+        assert info["n_shards"] >= 1 and info["rows"] == 300_000 and sum(info["shard_rows"]) == 300_000
+        for row in (0, 12345, 299_999):
+            a_idx, a_sc = node.query_row_topn(row, 100)
+            b_idx, b_sc = eng.query_row_topn(row, 100)
+            assert a_idx.tolist() == b_idx.tolist() and np.array_equal(a_sc.view(np.uint32), b_sc.view(np.uint32))
+            want = oracle.scores(f, f[row])
+            assert_topn_matches(a_idx, a_sc, want, row, 100, ref_idx=oracle.topn_heap(want, row, 100))
+        assert np.array_equal(node.scores_row(777).view(np.uint32), oracle.scores(f, f[777]).view(np.uint32))
+
+
+@pytest.mark.parametrize("shards", [2, 3, 8])
+def test_virtual_shards_match_the_oracle(Node, shards):
+    from spotify_recommender_amd import capi
+    rng = np.random.default_rng(shards)
+    n = 400_003
+    f = rng.random((n, 12), dtype=np.float32)
+    f[n - 5] = f[7]                            # a duplicate of a query row in the last shard
+    with Node(f, devices=[0] * shards) as node:
+        info = node.info()
+        assert info["n_shards"] == shards and info["transport"] == capi.TRANSPORT_PEER
+        assert max(info["shard_rows"]) - min(info["shard_rows"]) <= 1
+        for row in (7, n // 2, n - 1):
+            idx, sc = node.query_row_topn(row, 100)
+            want = oracle.scores(f, f[row])
+            assert_topn_matches(idx, sc, want, row, 100, ref_idx=oracle.topn_heap(want, row, 100))
+        check(node, f, rng.random(12, dtype=np.float32), -1, 1)
+        # a batch: per-shard batched passes, ONE exchange, one batched merge launch
+        qrows = rng.integers(0, n, size=40)
+        idx, sc, counts = node.query_batch_topn(f[qrows], qrows, 50)
+        for b, row in enumerate(qrows):
+            want = oracle.scores(f, f[row])
+            assert_topn_matches(idx[b][:counts[b]], sc[b][:counts[b]], want, int(row), 50)
+        # the full score vector is assembled shard by shard
+        assert np.array_equal(node.scores_row(n - 5).view(np.uint32), oracle.scores(f, f[n - 5]).view(np.uint32))
+        # topn above the single-launch merge limit: per-shard rounds + host key merge
+        idx, sc = node.query_row_topn(11, 3000)
+        want = oracle.scores(f, f[11])
+        assert_topn_matches(idx, sc, want, 11, 3000)
+        # the RCCL transport refuses several shards on one device, loudly
+        with pytest.raises(capi.Mi355Error):
+            node.set_transport(capi.TRANSPORT_RCCL)
+            node.query_row_topn(7, 10)
+
+
+def test_more_shards_than_rows_and_bad_arguments(Node):
+    from spotify_recommender_amd import capi
+    rng = np.random.default_rng(5)
+    f = rng.random((5, 12), dtype=np.float32)
+    with Node(f, devices=[0] * 8) as node:
+        assert node.info()["shard_rows"] == [1, 1, 1, 1, 1, 0, 0, 0]
+        idx, sc = node.query_row_topn(2, 10)       # topn > rows - 1
+        want = oracle.scores(f, f[2])
+        assert_topn_matches(idx, sc, want, 2, 10)
+        with pytest.raises(capi.Mi355Error):
+            node.query_row_topn(5, 3)
+        with pytest.raises(capi.Mi355Error):
+            node.query_row_topn(0, 0)
+    with pytest.raises(capi.Mi355Error):
+        Node(f, devices=[0, 99])
+    with pytest.raises(capi.Mi355Error):
+        Node(f, n_devices=4096)
+
+
+def test_rccl_transport_issues_a_real_all_gather(Node):
+    """One shard per device is what RCCL wants; with one visible device that is one
+    rank: ncclCommInitAll + a grouped ncclAllGather really run on the box."""
+    from spotify_recommender_amd import capi
+    rng = np.random.default_rng(9)
+    f = rng.random((250_000, 12), dtype=np.float32)
+    with Node(f, n_devices=1) as node:
+        node.set_transport(capi.TRANSPORT_RCCL)
+        assert node.info()["transport"] == capi.TRANSPORT_RCCL
+        for row in (3, 200_000):
+            idx, sc = node.query_row_topn(row, 100)
+            want = oracle.scores(f, f[row])
+            assert_topn_matches(idx, sc, want, row, 100, ref_idx=oracle.topn_heap(want, row, 100))
+        qrows = rng.integers(0, 250_000, size=20)
+        idx, sc, counts = node.query_batch_topn(f[qrows], qrows, 10)
+        for b, row in enumerate(qrows):
+            want = oracle.scores(f, f[row])
+            assert_topn_matches(idx[b][:counts[b]], sc[b][:counts[b]], want, int(row), 10)
