@@ -5,6 +5,7 @@
 #ifndef DATAMANAGER_H
 #define DATAMANAGER_H
 
+#include <cstdint>
 #include <map>
 #include <string>
 #include <vector>
@@ -29,6 +30,24 @@ public:
     static bool loadFeatureMatrix(const std::string& binaryPath, std::vector<float>& features,
                                   std::vector<std::string>& trackIds,
                                   std::vector<std::string>& trackNames);
+
+    // What the query modes of the CLI need, in ONE pass over a read-only mapping
+    // (replaces loadData + Recommender::initialize's copies, reference
+    // DataManager.cpp:363-409 and Recommender.cu:109,162-167): the feature matrix the
+    // engine uploads as is, ids and names for the lookups, the genre map, and the file
+    // offset of every record so that the few songs that get PRINTED can be read back
+    // in full (readSong) without ever materialising vector<Song>.
+    struct Catalogue {
+        std::string path;
+        std::vector<float> features;            // row-major n x FEATURE_COUNT
+        std::vector<std::string> trackIds;
+        std::vector<std::string> trackNames;
+        std::vector<uint64_t> recordOffsets;    // byte offset of song i in the file
+        std::map<int, std::string> genreMap;
+        size_t size() const { return trackIds.size(); }
+    };
+    static bool loadCatalogue(const std::string& binaryPath, Catalogue& out);
+    static bool readSong(const Catalogue& catalogue, size_t index, Song& out);
 
 private:
     static std::vector<std::string> parseCSVLine(const std::string& line);

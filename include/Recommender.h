@@ -58,14 +58,22 @@ public:
     bool isGPUEnabled() const;
     int getSongCount() const;
 
+    // Extension: the same initialisation from what DataManager::loadCatalogue read —
+    // the row-major N x 12 matrix goes to the GPUs as it is, ids / names feed the
+    // lookups; no vector<Song> is ever built (the reference deep-copies it,
+    // Recommender.cu:109, then flattens it, :162-167).
+    bool initialize(const std::vector<float>& features, const std::vector<std::string>& trackIds,
+                    const std::vector<std::string>& trackNames);
+
     // Extensions (not in the reference): the scores of the last
     // recommendByIndex result, and the full score vector of one query row
     // (what the reference's private calculateSimilarities produced).
     const std::vector<float>& lastScores() const;
     bool similarities(int songIndex, std::vector<float>& out);
 
+    struct Impl;   // opaque: defined in Recommender.cpp
+
 private:
-    struct Impl;
     Impl* impl_;
 };
 

@@ -289,9 +289,11 @@ bool DataManager::loadData(const std::string& binaryPath, std::vector<Song>& son
 // Same bytes, one pass over a read-only mapping: no iostream call per field and
 // no intermediate vector<Song> (the reference's loadData + initialize copy the
 // catalogue three times, DataManager.cpp:396-402 and Recommender.cu:109,162-167).
-bool DataManager::loadFeatureMatrix(const std::string& binaryPath, std::vector<float>& features,
-                                    std::vector<std::string>& trackIds,
-                                    std::vector<std::string>& trackNames) {
+namespace {
+
+bool walkBinary(const std::string& binaryPath, std::vector<float>& features, std::vector<std::string>& trackIds,
+                std::vector<std::string>& trackNames, std::vector<uint64_t>* offsets,
+                std::map<int, std::string>* genreMap) {
     const int fd = ::open(binaryPath.c_str(), O_RDONLY);
     if (fd < 0) return false;
     struct stat st;
@@ -303,7 +305,9 @@ bool DataManager::loadFeatureMatrix(const std::string& binaryPath, std::vector<f
     void* map = ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
     ::close(fd);
     if (map == MAP_FAILED) return false;
-    const unsigned char* p = static_cast<const unsigned char*>(map);
+    (void)::madvise(map, size, MADV_SEQUENTIAL);
+    const unsigned char* const begin = static_cast<const unsigned char*>(map);
+    const unsigned char* p = begin;
     const unsigned char* const end = p + size;
     bool ok = true;
     auto take = [&](void* dst, size_t n) {
@@ -322,10 +326,13 @@ bool DataManager::loadFeatureMatrix(const std::string& binaryPath, std::vector<f
     take(&numSongs, sizeof numSongs);
     take(&numGenres, sizeof numGenres);
     if (!ok || numSongs > (size_t(1) << 32) || numGenres > (size_t(1) << 24)) ok = false;
+    if (genreMap) genreMap->clear();
     for (size_t g = 0; ok && g < numGenres; ++g) {
         int id = 0;
         take(&id, sizeof id);
-        takeString(nullptr);
+        std::string name;
+        takeString(genreMap ? &name : nullptr);
+        if (ok && genreMap) (*genreMap)[id] = name;
     }
     if (ok) {
         // every song needs at least 3 lengths + genre + features
@@ -335,8 +342,10 @@ bool DataManager::loadFeatureMatrix(const std::string& binaryPath, std::vector<f
         features.resize(numSongs * FEATURE_COUNT);
         trackIds.resize(numSongs);
         trackNames.resize(numSongs);
+        if (offsets) offsets->resize(numSongs);
     }
     for (size_t i = 0; ok && i < numSongs; ++i) {
+        if (offsets) (*offsets)[i] = static_cast<uint64_t>(p - begin);
         takeString(&trackIds[i]);
         takeString(&trackNames[i]);
         takeString(nullptr);  // artists
@@ -349,6 +358,36 @@ bool DataManager::loadFeatureMatrix(const std::string& binaryPath, std::vector<f
         features.clear();
         trackIds.clear();
         trackNames.clear();
+        if (offsets) offsets->clear();
+        if (genreMap) genreMap->clear();
     }
     return ok;
+}
+
+}  // namespace
+
+bool DataManager::loadFeatureMatrix(const std::string& binaryPath, std::vector<float>& features,
+                                    std::vector<std::string>& trackIds,
+                                    std::vector<std::string>& trackNames) {
+    return walkBinary(binaryPath, features, trackIds, trackNames, nullptr, nullptr);
+}
+
+bool DataManager::loadCatalogue(const std::string& binaryPath, Catalogue& out) {
+    std::cout << "Loading preprocessed data from: " << binaryPath << std::endl;
+    out.path = binaryPath;
+    if (!walkBinary(binaryPath, out.features, out.trackIds, out.trackNames, &out.recordOffsets, &out.genreMap)) {
+        std::cerr << "Error: Could not read binary file: " << binaryPath << std::endl;
+        return false;
+    }
+    std::cout << "Loaded " << out.size() << " songs and " << out.genreMap.size() << " genres." << std::endl;
+    return true;
+}
+
+bool DataManager::readSong(const Catalogue& catalogue, size_t index, Song& out) {
+    if (index >= catalogue.recordOffsets.size()) return false;
+    std::ifstream in(catalogue.path, std::ios::binary);
+    if (!in.is_open()) return false;
+    in.seekg(static_cast<std::streamoff>(catalogue.recordOffsets[index]));
+    out.deserialize(in);
+    return static_cast<bool>(in);
 }

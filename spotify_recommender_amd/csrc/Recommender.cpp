@@ -46,20 +46,19 @@ Recommender::~Recommender() {  // Recommender.cu:86-98
     delete impl_;
 }
 
+namespace {
+
+// Shared tail of the two initialize() overloads: lookup tables + upload.
+bool startEngine(Recommender::Impl* impl, const float* matrix, size_t n);
+
+}  // namespace
+
 bool Recommender::initialize(const std::vector<Song>& songs) {  // Recommender.cu:100-182
     std::cout << "Initializing GPU-accelerated recommender..." << std::endl;
     if (songs.empty()) {  // :103-106
         std::cerr << "Error: Empty song database" << std::endl;
         return false;
     }
-    if (impl_->engine) {
-        mi355rec_sharded_destroy(impl_->engine);
-        impl_->engine = nullptr;
-    }
-    impl_->initialized = false;
-    impl_->gpuEnabled = false;
-    impl_->numSongs = static_cast<int>(songs.size());
-
     // AoS -> row-major N x 12 (the reference's staging matrix, :162-167)
     std::vector<float> matrix(songs.size() * FEATURE_COUNT);
     impl_->lowerNames.clear();
@@ -71,12 +70,45 @@ bool Recommender::initialize(const std::vector<Song>& songs) {  // Recommender.c
         impl_->lowerNames.push_back(toLower(songs[i].track_name));
         impl_->byId.emplace(songs[i].track_id, static_cast<int>(i));  // keeps the first
     }
+    return startEngine(impl_, matrix.data(), songs.size());
+}
 
+bool Recommender::initialize(const std::vector<float>& features, const std::vector<std::string>& trackIds,
+                             const std::vector<std::string>& trackNames) {
+    std::cout << "Initializing GPU-accelerated recommender..." << std::endl;
+    if (trackIds.empty()) {
+        std::cerr << "Error: Empty song database" << std::endl;
+        return false;
+    }
+    if (features.size() != trackIds.size() * FEATURE_COUNT || trackNames.size() != trackIds.size()) {
+        std::cerr << "Error: feature matrix / id / name sizes disagree" << std::endl;
+        return false;
+    }
+    impl_->lowerNames.clear();
+    impl_->lowerNames.reserve(trackIds.size());
+    impl_->byId.clear();
+    impl_->byId.reserve(trackIds.size() * 2);
+    for (size_t i = 0; i < trackIds.size(); ++i) {
+        impl_->lowerNames.push_back(toLower(trackNames[i]));
+        impl_->byId.emplace(trackIds[i], static_cast<int>(i));
+    }
+    return startEngine(impl_, features.data(), trackIds.size());
+}
+
+namespace {
+
+bool startEngine(Recommender::Impl* impl, const float* matrix, size_t n) {
+    if (impl->engine) {
+        mi355rec_sharded_destroy(impl->engine);
+        impl->engine = nullptr;
+    }
+    impl->initialized = false;
+    impl->gpuEnabled = false;
+    impl->numSongs = static_cast<int>(n);
     // The reference pins device 0 (Recommender.cu:124); here the rows are sharded over
     // every visible GPU (one process, one stream per device, xGMI peer stores or one RCCL
     // all-gather of the per-shard top-N keys: include/mi355rec.h, "row-sharded catalogue").
-    const int rc = mi355rec_create_sharded(matrix.data(), static_cast<int64_t>(songs.size()), FEATURE_COUNT,
-                                           /*n_devices=*/0, &impl_->engine);
+    const int rc = mi355rec_create_sharded(matrix, static_cast<int64_t>(n), FEATURE_COUNT, /*n_devices=*/0, &impl->engine);
     if (rc != MI355REC_OK) {
         // The reference would say "[GPU Disabled] ... Falling back to CPU" and go
         // on (:117-181).  There is no CPU path here: fail loudly.
@@ -84,14 +116,16 @@ bool Recommender::initialize(const std::vector<Song>& songs) {  // Recommender.c
         std::cerr << "Error: the MI355X recommender needs a HIP device (no CPU fallback)" << std::endl;
         return false;
     }
-    mi355rec_sharded_info(impl_->engine, &impl_->numDevices, nullptr, nullptr, nullptr, nullptr);
-    impl_->gpuEnabled = true;
-    impl_->initialized = true;
-    std::cout << "Successfully initialized with " << impl_->numSongs << " songs on GPU";
-    if (impl_->numDevices > 1) std::cout << " (row-sharded over " << impl_->numDevices << " devices)";
+    mi355rec_sharded_info(impl->engine, &impl->numDevices, nullptr, nullptr, nullptr, nullptr);
+    impl->gpuEnabled = true;
+    impl->initialized = true;
+    std::cout << "Successfully initialized with " << impl->numSongs << " songs on GPU";
+    if (impl->numDevices > 1) std::cout << " (row-sharded over " << impl->numDevices << " devices)";
     std::cout << std::endl;
     return true;
 }
+
+}  // namespace
 
 std::vector<int> Recommender::recommendByIndex(int songIndex, int topN) {  // Recommender.cu:275-318
     if (!impl_->initialized) {

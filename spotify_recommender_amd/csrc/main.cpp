@@ -47,27 +47,31 @@ static void printSong(const Song& s, std::map<int, std::string>& genres, const c
               << indent << "ID:     " << s.track_id << std::endl;
 }
 
+// The reference loads every Song, deep-copies the vector into the recommender and
+// flattens it again (main.cpp:50-60, Recommender.cu:109,162-167).  Here the file is
+// walked once (DataManager::loadCatalogue): the feature matrix goes to the engine as
+// it is, and only the handful of songs that are PRINTED are read back in full.
 static bool recommendationMode(const std::string& query, bool isTrackId, int topN) {  // main.cpp:46-131
     std::cout << "=== RECOMMENDATION MODE ===" << std::endl;
-    std::vector<Song> songs;
-    std::map<int, std::string> genreMap;
-    if (!DataManager::loadData(kBinaryDataFile, songs, genreMap)) {
+    DataManager::Catalogue catalogue;
+    if (!DataManager::loadCatalogue(kBinaryDataFile, catalogue)) {
         std::cerr << "Failed to load data. Have you run preprocessing?" << std::endl;
         return false;
     }
     Recommender recommender;
-    if (!recommender.initialize(songs)) {
+    if (!recommender.initialize(catalogue.features, catalogue.trackIds, catalogue.trackNames)) {
         std::cerr << "Failed to initialize recommender" << std::endl;
         return false;
     }
+    std::map<int, std::string>& genreMap = catalogue.genreMap;
 
     std::vector<int> recs;
     int queryIndex = -1;
     if (isTrackId) {
         std::cout << "\nSearching for track ID: " << query << std::endl;
         recs = recommender.recommend(query, topN);
-        for (size_t i = 0; i < songs.size(); ++i)
-            if (songs[i].track_id == query) { queryIndex = static_cast<int>(i); break; }
+        for (size_t i = 0; i < catalogue.size(); ++i)
+            if (catalogue.trackIds[i] == query) { queryIndex = static_cast<int>(i); break; }
     } else {
         std::cout << "\nSearching for song: " << query << std::endl;
         recs = recommender.recommendByName(query, topN);
@@ -75,8 +79,8 @@ static bool recommendationMode(const std::string& query, bool isTrackId, int top
         // pass (main.cpp:85-95), not the engine's exact-then-substring rule; kept.
         std::string needle = query;
         std::transform(needle.begin(), needle.end(), needle.begin(), ::tolower);
-        for (size_t i = 0; i < songs.size(); ++i) {
-            std::string name = songs[i].track_name;
+        for (size_t i = 0; i < catalogue.size(); ++i) {
+            std::string name = catalogue.trackNames[i];
             std::transform(name.begin(), name.end(), name.begin(), ::tolower);
             if (name == needle || name.find(needle) != std::string::npos) { queryIndex = static_cast<int>(i); break; }
         }
@@ -85,19 +89,23 @@ static bool recommendationMode(const std::string& query, bool isTrackId, int top
         std::cerr << "No recommendations found. Please check the query." << std::endl;
         return false;
     }
-    if (queryIndex >= 0) {
+    Song song;
+    if (queryIndex >= 0 && DataManager::readSong(catalogue, static_cast<size_t>(queryIndex), song)) {
         std::cout << "\n----------------------------------------------\nQuery Song:\n"
-                  << "  Title:   " << songs[queryIndex].track_name << "\n"
-                  << "  Artist:  " << songs[queryIndex].artists << "\n"
-                  << "  Genre:   " << genreMap[songs[queryIndex].genre_id] << "\n"
-                  << "  ID:      " << songs[queryIndex].track_id
+                  << "  Title:   " << song.track_name << "\n"
+                  << "  Artist:  " << song.artists << "\n"
+                  << "  Genre:   " << genreMap[song.genre_id] << "\n"
+                  << "  ID:      " << song.track_id
                   << "\n----------------------------------------------" << std::endl;
     }
     std::cout << "\nTop " << recs.size() << " Recommendations:\n" << std::endl;
     for (size_t i = 0; i < recs.size(); ++i) {
-        const Song& s = songs[recs[i]];
-        std::cout << (i + 1) << ". \"" << s.track_name << "\"" << std::endl;
-        printSong(s, genreMap, "   ");
+        if (!DataManager::readSong(catalogue, static_cast<size_t>(recs[i]), song)) {
+            std::cerr << "Error: could not read song " << recs[i] << " from " << catalogue.path << std::endl;
+            return false;
+        }
+        std::cout << (i + 1) << ". \"" << song.track_name << "\"" << std::endl;
+        printSong(song, genreMap, "   ");
         if (i + 1 < recs.size()) std::cout << std::endl;
     }
     std::cout << "\nRecommendation complete!" << std::endl;

@@ -3,6 +3,7 @@
 // main.cpp does.  Test/tooling surface only; applications use the classes.
 #include <cstdint>
 #include <cstring>
+#include <fstream>
 #include <map>
 #include <string>
 #include <vector>
@@ -46,6 +47,73 @@ void* shim_from_matrix(const float* feats, int64_t n) {
         std::memcpy(c->songs[i].features, feats + i * FEATURE_COUNT, sizeof(float) * FEATURE_COUNT);
     }
     return c;
+}
+
+// The CLI's query-mode path: DataManager::loadCatalogue + the matrix overload of
+// Recommender::initialize.  Songs are only materialised one at a time (readSong).
+struct FastCatalogue {
+    DataManager::Catalogue cat;
+    Recommender rec;
+};
+
+void* shim_fast_load(const char* bin) {
+    FastCatalogue* c = new FastCatalogue();
+    if (!DataManager::loadCatalogue(bin, c->cat)) {
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+int shim_fast_initialize(void* h) {
+    FastCatalogue* c = static_cast<FastCatalogue*>(h);
+    return c->rec.initialize(c->cat.features, c->cat.trackIds, c->cat.trackNames) ? 1 : 0;
+}
+void shim_fast_free(void* h) { delete static_cast<FastCatalogue*>(h); }
+int64_t shim_fast_song_count(void* h) { return static_cast<int64_t>(static_cast<FastCatalogue*>(h)->cat.size()); }
+int64_t shim_fast_recommend(void* h, const char* id, int topn, int* out, int64_t cap) {
+    FastCatalogue* c = static_cast<FastCatalogue*>(h);
+    const std::vector<int> r = c->rec.recommend(id, topn);
+    for (size_t i = 0; i < r.size() && static_cast<int64_t>(i) < cap; ++i) out[i] = r[i];
+    return static_cast<int64_t>(r.size());
+}
+int64_t shim_fast_recommend_by_name(void* h, const char* name, int topn, int* out, int64_t cap) {
+    FastCatalogue* c = static_cast<FastCatalogue*>(h);
+    const std::vector<int> r = c->rec.recommendByName(name, topn);
+    for (size_t i = 0; i < r.size() && static_cast<int64_t>(i) < cap; ++i) out[i] = r[i];
+    return static_cast<int64_t>(r.size());
+}
+// which: 0 id, 1 name, 2 artists, 3 genre name — read back from the file through readSong
+int64_t shim_fast_song_string(void* h, int64_t i, int which, char* out, int64_t cap) {
+    FastCatalogue* c = static_cast<FastCatalogue*>(h);
+    Song s;
+    if (i < 0 || !DataManager::readSong(c->cat, static_cast<size_t>(i), s)) return -1;
+    if (which == 3) return copyOut(c->cat.genreMap[s.genre_id], out, cap);
+    return copyOut(which == 0 ? s.track_id : which == 1 ? s.track_name : s.artists, out, cap);
+}
+// writes a synthetic songs_data.bin (Song::serialize) straight from a feature matrix: test fixture
+int shim_write_synthetic_bin(const char* path, const float* feats, int64_t n, int genres) {
+    std::ofstream out(path, std::ios::binary);
+    if (!out.is_open()) return 0;
+    const size_t numSongs = static_cast<size_t>(n), numGenres = static_cast<size_t>(genres);
+    out.write(reinterpret_cast<const char*>(&numSongs), sizeof numSongs);
+    out.write(reinterpret_cast<const char*>(&numGenres), sizeof numGenres);
+    for (int g = 0; g < genres; ++g) {
+        const std::string name = "genre-" + std::to_string(g);
+        const size_t len = name.size();
+        out.write(reinterpret_cast<const char*>(&g), sizeof g);
+        out.write(reinterpret_cast<const char*>(&len), sizeof len);
+        out.write(name.data(), static_cast<std::streamsize>(len));
+    }
+    Song s;
+    for (int64_t i = 0; i < n; ++i) {
+        s.track_id = "id" + std::to_string(i);
+        s.track_name = "Song " + std::to_string(i);
+        s.artists = "Artist " + std::to_string(i % 977);
+        s.genre_id = static_cast<int>(i % genres);
+        std::memcpy(s.features, feats + i * FEATURE_COUNT, sizeof(float) * FEATURE_COUNT);
+        s.serialize(out);
+    }
+    return out.good() ? 1 : 0;
 }
 
 void shim_free(void* h) { delete static_cast<Catalogue*>(h); }

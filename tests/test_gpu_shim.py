@@ -108,6 +108,10 @@ def test_cli_end_to_end(tmp_path, golden_dir):
     assert p.returncode == 1 and "not found" in p.stderr
     p = run("--id", "dupA", "-n", "0")
     assert p.returncode == 1 and "must be positive" in p.stderr
+    # an absurd topN is clamped to N-1 like the reference's heap (Recommender.cu:300): no
+    # buffer is sized by it, no scan round is run for it
+    p = run("--id", "dupA", "-n", "2000000000")
+    assert p.returncode == 0 and "Top 3 Recommendations" in p.stdout, p.stderr
     assert run().returncode == 1 and run("--bogus").returncode == 1
 
 
@@ -155,3 +159,60 @@ def test_config1_114k_csv_through_the_cli_classes(shim, tmp_path):
         assert idx.tolist() == oracle.topn_canonical(oracle.scores(feats, feats[56_789]), 56_789, 10)[0].tolist()
     finally:
         shim.shim_free(h)
+
+
+def test_fast_loader_path_on_a_million_songs(shim, tmp_path):
+    """the CLI's query modes load songs_data.bin through
+    DataManager::loadCatalogue (one pass over a mapping -> matrix + ids + names + record
+    offsets) and Recommender::initialize(matrix, ids, names); nothing builds vector<Song>.
+    Same recommendations as the loadData + initialize(vector<Song>) path on a 1 M-song
+    file, checked against the oracle; load + init wall times of both are reported."""
+    import time
+    L = shim
+    for name, res, args in (("shim_fast_load", ctypes.c_void_p, [ctypes.c_char_p]),
+                            ("shim_fast_initialize", ctypes.c_int, [ctypes.c_void_p]),
+                            ("shim_fast_free", None, [ctypes.c_void_p]),
+                            ("shim_fast_song_count", ctypes.c_int64, [ctypes.c_void_p]),
+                            ("shim_fast_recommend", ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]),
+                            ("shim_fast_recommend_by_name", ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]),
+                            ("shim_fast_song_string", ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_char_p, ctypes.c_int64]),
+                            ("shim_write_synthetic_bin", ctypes.c_int, [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int])):
+        getattr(L, name).restype = res
+        getattr(L, name).argtypes = args
+    n = 1_000_000
+    rng = np.random.default_rng(2026)
+    f = rng.random((n, 12), dtype=np.float32)
+    path = tmp_path / "songs_data.bin"
+    assert L.shim_write_synthetic_bin(str(path).encode(), f.ctypes.data, n, 114) == 1
+    t0 = time.perf_counter()
+    slow = L.shim_load(str(path).encode())
+    assert slow and L.shim_initialize(slow) == 1
+    t_slow = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    fast = L.shim_fast_load(str(path).encode())
+    assert fast and L.shim_fast_initialize(fast) == 1
+    t_fast = time.perf_counter() - t0
+    print(f"\n1M songs ({path.stat().st_size / 1e6:.0f} MB): loadData + initialize {t_slow:.2f} s, "
+          f"loadCatalogue + initialize(matrix) {t_fast:.2f} s")
+    try:
+        assert L.shim_fast_song_count(fast) == n
+        for q in (0, 123_456, n - 1):
+            a, _ = rec(L, slow, L.shim_recommend, f"id{q}".encode(), 10)
+            out = np.full(10, -1, np.int32)
+            cnt = L.shim_fast_recommend(fast, f"id{q}".encode(), 10, out.ctypes.data, 10)
+            assert cnt == 10 and out.tolist() == a.tolist()
+            want = oracle.scores(f, f[q], threads=0)
+            ci, _ = oracle.topn_canonical(want, q, 10)
+            assert out.tolist() == ci.tolist()
+        out = np.full(5, -1, np.int32)
+        assert L.shim_fast_recommend_by_name(fast, b"song 4242", 5, out.ctypes.data, 5) == 5   # exact, case-insensitive
+        want = oracle.scores(f, f[4242], threads=0)
+        assert out.tolist() == oracle.topn_canonical(want, 4242, 5)[0].tolist()
+        buf = ctypes.create_string_buffer(64)
+        for which, text in ((0, b"id777777"), (1, b"Song 777777"), (2, b"Artist %d" % (777777 % 977)), (3, b"genre-%d" % (777777 % 114))):
+            k = L.shim_fast_song_string(fast, 777_777, which, buf, 64)
+            assert buf.raw[:k] == text
+        assert t_fast < t_slow
+    finally:
+        L.shim_free(slow)
+        L.shim_fast_free(fast)
