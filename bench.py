@@ -5,7 +5,10 @@ synthetic catalogue (BASELINE.json configs[2]; configs[3] when --gpus > 1).
 A step = one query = one fused streaming pass over the catalogue (row-sharded
 over the ranks when N > 1, merged with ONE all-gather of 100 packed keys per
 rank) + the device merge.  The catalogue is resident in HBM before the timed
-region; results stay on the device (800 B of keys per query).
+region; results stay on the device (800 B of keys per query).  Outside the
+timed region the same line carries `microbatch` (12 queries per exact pass) and
+`batched` (BASELINE configs[4]'s 1024-query batches on the matrix-core path,
+with its compute roofline).
 
   python bench.py --gpus 1 --steps 300 --warmup 30
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
@@ -31,6 +34,9 @@ if str(ROOT) not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 BYTES_PER_ROW = 48      # algorithmic bytes per catalogue row per query
+FP32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 vector = fp32 matrix peak (configs[4]'s roofline)
+FP16_MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (never the 2:1-sparsity figure)
+FLOP_PER_PAIR = 24          # 12 mul + 12 add per (row, query) pair of the batched path
 
 
 def parse_args():
@@ -44,8 +50,11 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="skip the per-kernel HIP events (roofline.achieved becomes null)")
-    ap.add_argument("--event-stride", type=int, default=10,
-                    help="time every k-th kernel launch inside the timed region (an event pair costs ~3 us)")
+    ap.add_argument("--event-stride", type=int, default=0,
+                    help="time every k-th kernel launch inside the timed region (an event pair costs ~3 us); "
+                         "0 = choose so that at least 16 launches are timed")
+    ap.add_argument("--batch", type=int, default=1024, help="queries per call of the batched (configs[4]) leg")
+    ap.add_argument("--no-batched", action="store_true")
     ap.add_argument("--latency-queries", type=int, default=1000)
     return ap.parse_args()
 
@@ -179,8 +188,9 @@ def main():
     for k in range(args.warmup):
         step(k)
     fence()
+    stride = args.event_stride if args.event_stride > 0 else max(1, min(10, args.steps // 16))
     if not args.no_kernel_events:
-        eng.set_timing(args.event_stride)  # HIP events around every k-th scan / merge launch
+        eng.set_timing(stride)  # HIP events around every k-th scan / merge launch
     t0 = time.perf_counter()
     for k in range(args.warmup, total_q):
         step(k)
@@ -207,24 +217,14 @@ def main():
 
     # micro-batched throughput, outside the timed region:
     # 12 queries share one pass over the catalogue, seed/final merge launches shared by 36
-    micro = None
-    if topn <= 128:
-        nb = 72   # two chains of 36 = six passes of 12 queries
-        b_rows = np.array(q_rows[:nb], dtype=np.int64)
-        b_keys = torch.zeros(nb * topn, dtype=torch.int64, device=dev)
+    from spotify_recommender_amd import capi
 
-        def batch_step():
-            if sharded is None:
-                eng.enqueue_batch_keys(q_vecs[:nb], b_rows, topn, b_keys)
-            else:
-                sharded.enqueue_batch(q_vecs[:nb], b_rows, topn)
-
-        batch_step()
+    def timed(fn, reps):
+        fn()
         fence()
-        reps = 6
         t1 = time.perf_counter()
         for _ in range(reps):
-            batch_step()
+            fn()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
         fence()
@@ -232,15 +232,107 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        micro = {"queries_per_pass": 12, "queries_per_call": nb, "value": round(reps * nb / dt, 1),
-                 "unit": "queries/s", "ms_per_pass": round(dt / (reps * nb / 12) * 1e3, 5),
-                 "note": "one scan of the (local) catalogue answers 12 queries (mi355::scan_multi_kernel); "
+        return dt / reps
+
+    # micro-batched throughput, outside the timed region:
+    # 12 queries share one exact pass over the catalogue (mi355::scan_multi_kernel)
+    micro = None
+    if topn <= 128:
+        nb = 72   # two chains of 36 = six passes of 12 queries
+        b_rows = np.array(q_rows[:nb], dtype=np.int64)
+        b_keys = torch.zeros(nb * topn, dtype=torch.int64, device=dev)
+        eng.set_batch_path(capi.BATCH_MULTI)
+
+        def batch_step():
+            if sharded is None:
+                eng.enqueue_batch_keys(q_vecs[:nb], b_rows, topn, b_keys)
+            else:
+                sharded.enqueue_batch(q_vecs[:nb], b_rows, topn)
+
+        dt = timed(batch_step, 6)
+        micro = {"queries_per_pass": 12, "queries_per_call": nb, "value": round(nb / dt, 1),
+                 "unit": "queries/s", "ms_per_pass": round(dt / (nb / 12) * 1e3, 5),
+                 "note": "one exact scan of the (local) catalogue answers 12 queries (mi355::scan_multi_kernel); "
                          + ("single GPU" if sharded is None else "one all-gather per 72-query call")}
         step(0)
         torch.cuda.synchronize()
         a, _ = unpack_keys((out_keys if sharded is None else sharded.out_keys[:topn]).cpu().numpy())
         b, _ = unpack_keys((b_keys[:topn] if sharded is None else sharded.batch_keys[0]).cpu().numpy())
         micro["matches_single_query_path"] = bool(a.tolist() == b.tolist())
+        eng.set_batch_path(capi.BATCH_AUTO)
+
+    # the batched path of BASELINE configs[4] (csrc/batched.hip.h): `--batch` queries per call,
+    # queries resident in HBM, fp16 matrix-core pre-filter + exact fp32 re-score
+    batched = None
+    if topn <= 128 and not args.no_batched and (hi - lo) >= 65536:
+        bq = args.batch
+        bq_rows = np.array([(k * 104729) % n for k in range(bq)], dtype=np.int64)
+        bq_dev = torch.from_numpy(bq_rows).to(dev)
+        if world == 1:
+            q_dev = shard[bq_dev].contiguous()
+        q_host = None
+        if sharded is not None:
+            # every rank needs the query VECTORS: rows live on different ranks, so take them from the seed
+            q_host = synthetic_catalogue(n, seed=args.seed, device=dev)[bq_dev].cpu().numpy()
+        bq_keys = torch.zeros(bq * topn, dtype=torch.int64, device=dev)
+
+        def bq_step():
+            if sharded is None:
+                eng.enqueue_batch_keys_dev(q_dev, bq_dev, topn, bq_keys)
+            else:
+                sharded.enqueue_batch(q_host, bq_rows, topn)
+
+        bq_step()
+        fence()
+        eng.set_timing(1)
+        dt = timed(bq_step, 10)
+        pass_ms = float(eng.stats().last_pass_ms)
+        eng.set_timing(False)
+        diag = eng.batched_last_counters()
+        rows_local = hi - lo
+        flops = FLOP_PER_PAIR * float(rows_local) * bq
+        # matrix-core work really issued: v_mfma_f32_32x32x16_f16 = 2*32*32*16 flop; pass 1 visits
+        # every 4th 32-row tile, pass 2 every tile; one MFMA per (tile, block of 32 queries)
+        tiles = (rows_local + 31) // 32
+        blocks = 2
+        while blocks * 32 < min(bq, 1024):
+            blocks *= 2
+        chunks = (bq + 1023) // 1024
+        mfma_flops = 2.0 * 32 * 32 * 16 * tiles * blocks * chunks * (1.0 + 0.25)
+        batched = {
+            "queries_per_call": bq, "value": round(bq / dt, 1),
+            "unit": "queries/s", "ms_per_call": round(dt * 1e3, 4), "rows_per_gpu": rows_local,
+            "roofline": {
+                "bound": "compute", "kernel": "mi355::bq_pass_kernel (pass 1 + pass 2)",
+                "algorithmic_flops_per_call_per_gpu": flops,
+                "achieved": round(flops / dt / 1e12, 1), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(flops / dt / 1e12 / FP32_PEAK_TFLOPS, 3),
+                "note": "24 flop per (row, query) pair against the fp32 peak (SURVEY.md §8(d)); the pre-filter runs "
+                        "in fp16 on the matrix cores, so the fraction may exceed 1 — the exact fp32 chain only "
+                        "touches the candidates",
+                "mfma": {"issued_tflops": round(mfma_flops / dt / 1e12, 1), "peak": FP16_MFMA_PEAK_TFLOPS,
+                         "frac": round(mfma_flops / dt / 1e12 / FP16_MFMA_PEAK_TFLOPS, 3),
+                         "avg_pass_kernel_ms": round(pass_ms, 4),
+                         "binding_unit": "VALU issue: 8 v_max3_i32 per MFMA (1024 outputs) + chip power (DESIGN.md §4.6)"},
+            },
+            "candidates_per_query": round(diag["candidates_total"] / max(1, min(bq, 1024) - diag["queued_queries"]), 1),
+            "queued_to_exact_scan": diag["queued_queries"], "special_rows": diag["special_rows"],
+        }
+        # the first and last query of the batch against the single-query path
+        ok = True
+        for k in (0, bq - 1):
+            if sharded is None:
+                eng.enqueue_row_keys(int(bq_rows[k]), topn, out_keys)
+                torch.cuda.synchronize()
+                a = out_keys.cpu().numpy()
+                b = bq_keys[k * topn:(k + 1) * topn].cpu().numpy()
+            else:
+                sharded.enqueue_query(q_host[k], int(bq_rows[k]), topn)
+                torch.cuda.synchronize()
+                a = sharded.out_keys[:topn].cpu().numpy()
+                b = sharded.batch_keys[k].cpu().numpy()
+            ok = ok and bool(np.array_equal(a, b))
+        batched["matches_single_query_path"] = ok
 
     # achievable-HBM ceiling probe on the same buffer (plain read-only stream)
     probe_gbps = None
@@ -294,15 +386,32 @@ def main():
         }
         if micro is not None:
             line["microbatch"] = micro
+        if batched is not None:
+            line["batched"] = batched
         if feats_host is not None:
             line["cpu_baseline"] = cpu_baseline(feats_host, topn, q_rows[:64])
-            # the last latency query, checked against the oracle (checker only)
+            # several queries of the run, checked against the oracle (checker only)
             from oracle import oracle
-            k_last = total_q + args.latency_queries - 1
-            rows_got, _ = unpack_keys(host_idx.numpy())
-            want = oracle.scores(feats_host, feats_host[q_rows[k_last]], threads=0)
-            ci, _ = oracle.topn_canonical(want, q_rows[k_last], topn)
-            line["verified_against_oracle"] = bool(rows_got.tolist() == ci.tolist())
+            ok = True
+            checked = 0
+            for k in (0, total_q // 2, total_q + args.latency_queries - 1):
+                eng.enqueue_row_keys(q_rows[k], topn, out_keys)
+                torch.cuda.synchronize()
+                rows_got, sc_got = unpack_keys(out_keys.cpu().numpy())
+                want = oracle.scores(feats_host, feats_host[q_rows[k]], threads=0)
+                ci, cs = oracle.topn_canonical(want, q_rows[k], topn)
+                ok = ok and rows_got.tolist() == ci.tolist() and bool(np.array_equal(sc_got, cs + np.float32(0)))
+                checked += 1
+            if batched is not None:
+                for k in (1, args.batch // 2):
+                    row = int((k * 104729) % n)
+                    rows_got, sc_got = unpack_keys(bq_keys[k * topn:(k + 1) * topn].cpu().numpy())
+                    want = oracle.scores(feats_host, feats_host[row], threads=0)
+                    ci, cs = oracle.topn_canonical(want, row, topn)
+                    ok = ok and rows_got.tolist() == ci.tolist() and bool(np.array_equal(sc_got, cs + np.float32(0)))
+                    checked += 1
+            line["verified_against_oracle"] = bool(ok)
+            line["verified_queries"] = checked
         print(json.dumps(line), flush=True)
 
     eng.close()

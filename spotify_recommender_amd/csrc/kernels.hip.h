@@ -281,14 +281,44 @@ __device__ inline uint64_t block_select_threshold(const uint64_t (&mine)[kPerThr
     return base + prefix;
 }
 
-// Ranks the `c` unique keys in s_keys by counting and writes the best
-// min(c, topk) in descending order to dst, zero-filling up to dst[topk).
-// Costs ~c*c/32 LDS cycles: callers keep c within a few hundred.
-constexpr int kRankDirectMax = 384;
+// Writes the best min(c, topk) of the `c` unique keys in s_keys to dst in descending
+// order, zero-filling up to dst[topk).  Small sets are ranked by counting (~c*c/32 LDS
+// cycles); from kRankCountMax keys up the keys are sorted IN PLACE by a bitonic
+// network in LDS (log2(P)*(log2(P)+1)/2 stages of one compare-exchange per thread
+// pair: 55 stages for 1024 keys, ~1 us, where counting cost 12 us per workgroup at
+// topN = 1000).  Needs room for the next power of two >= c in s_keys; every thread of
+// the workgroup must call it (barriers inside).
+constexpr int kRankDirectMax = 384;   // callers cut larger survivor sets to exactly topk first (O(c) select)
+constexpr int kRankCountMax = 160;
 template <int kThreads>
-__device__ inline void block_rank_and_store(const uint64_t* s_keys, int c, uint64_t* dst, int topk) {
+__device__ inline void block_rank_and_store(uint64_t* s_keys, int c, uint64_t* dst, int topk) {
     for (int i = threadIdx.x; i < topk; i += kThreads) {
         if (i >= c) dst[i] = 0ull;
+    }
+    if (c > kRankCountMax) {   // uniform
+        int p2 = 256;
+        while (p2 < c) p2 <<= 1;
+        for (int i = c + threadIdx.x; i < p2; i += kThreads) s_keys[i] = 0ull;   // empty keys sort last
+        __syncthreads();
+        for (int k = 2; k <= p2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = threadIdx.x; t < (p2 >> 1); t += kThreads) {
+                    // pair (lo, lo + j) with bit j clear in lo; descending overall
+                    const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int hi = lo | j;
+                    const uint64_t a = s_keys[lo], b = s_keys[hi];
+                    const bool down = (lo & k) == 0;   // this run sorts descending
+                    if ((a < b) == down) {
+                        s_keys[lo] = b;
+                        s_keys[hi] = a;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        const int n_out = c < topk ? c : topk;
+        for (int i = threadIdx.x; i < n_out; i += kThreads) dst[i] = s_keys[i];
+        return;
     }
     for (int i = threadIdx.x; i < c; i += kThreads) {
         const uint64_t mine = s_keys[i];

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 outputs of a round (gpurun_out/) into the small files kept
-under profiles/:  python tools/summarize_profiles.py r01 <kernel-trace dir> <FETCH dir> <WRITE dir> <bench json>"""
+under profiles/:
+  python tools/summarize_profiles.py r02 <kernel-trace dir> <FETCH dir> <WRITE dir> <bench json> [rows]
+All three runs profile the same command, `python3 bench.py ...` (10 M rows unless given)."""
 import collections
 import csv
 import glob
@@ -9,15 +11,26 @@ import shutil
 import sys
 
 tag, trace_dir, fetch_dir, write_dir, bench_json = sys.argv[1:6]
+rows = int(sys.argv[6]) if len(sys.argv) > 6 else 10_000_000
 stats = glob.glob(f"{trace_dir}/**/*kernel_stats.csv", recursive=True)[0]
-shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
+keep = []
+with open(stats) as f:
+    rd = csv.DictReader(f)
+    for r in rd:
+        if "mi355::" in r["Name"]:
+            r["Name"] = r["Name"].split("(")[0].replace("void ", "")
+            keep.append(r)
+with open(f"profiles/{tag}_kernel_stats.csv", "w", newline="") as f:
+    w = csv.DictWriter(f, fieldnames=list(keep[0].keys()))
+    w.writeheader()
+    w.writerows(keep)
 shutil.copy(bench_json, f"profiles/{tag}_bench_n1.json")
 out = {
     "command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 40 --warmup 5 "
                "--no-cpu-baseline --latency-queries 5   (one counter per pass, kernel-trace in its own run)",
     "unit_note": "rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB. On gfx950 FETCH_SIZE counts 64 B per 128 B request "
                  "of a wide coalesced read, so read bytes = 2 * FETCH_SIZE * 1024 (MI355X_MICROARCH.md, HBM section); "
-                 "the stream probe (a pure coalesced read of the same 480 MB) calibrates that factor; WRITE_SIZE is exact.",
+                 "the stream probe (a pure coalesced read of the same bytes) calibrates that factor; WRITE_SIZE is exact.",
     "kernels": {},
 }
 for name, d in (("FETCH_SIZE", fetch_dir), ("WRITE_SIZE", write_dir)):
@@ -30,16 +43,22 @@ for name, d in (("FETCH_SIZE", fetch_dir), ("WRITE_SIZE", write_dir)):
         e = out["kernels"].setdefault(k, {})
         e[name + "_KiB_mean"] = sum(v) / len(v)
         e[name + "_launches"] = len(v)
-rows = 10_000_000
 for k, d in out["kernels"].items():
     if "FETCH_SIZE_KiB_mean" in d:
         d["read_bytes_per_launch_corrected"] = 2 * d["FETCH_SIZE_KiB_mean"] * 1024
     if "WRITE_SIZE_KiB_mean" in d:
         d["write_bytes_per_launch"] = d["WRITE_SIZE_KiB_mean"] * 1024
-    if "scan_kernel" in k or "stream_probe" in k:
-        d["algorithmic_bytes_per_launch"] = rows * 48
+    alg = None
+    if "scan_kernel" in k or "stream_probe" in k or "scan_multi_kernel" in k:
+        alg = rows * 48
+    elif "bq_pass_kernel" in k:
+        # pass 2 (<.., true, ..>) reads every row once; pass 1 every 4th 32-row tile
+        alg = rows * 48 if ", true" in k else rows * 48 // 4
+        d["note"] = "batched path: rows are read once per pass whatever the number of queries (<= 1024 per pass)"
+    if alg is not None:
+        d["algorithmic_bytes_per_launch"] = alg
         d["hbm_bytes_per_launch"] = d.get("read_bytes_per_launch_corrected", 0) + d.get("write_bytes_per_launch", 0)
-        d["traffic_over_algorithmic"] = d["hbm_bytes_per_launch"] / (rows * 48)
+        d["traffic_over_algorithmic"] = d["hbm_bytes_per_launch"] / alg
 json.dump(out, open(f"profiles/{tag}_pmc_hbm_traffic.json", "w"), indent=1)
 for k, d in out["kernels"].items():
     print(k[:70], {kk: round(vv, 3) if isinstance(vv, float) else vv for kk, vv in d.items() if "per_launch" in kk or "over" in kk})
