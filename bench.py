@@ -55,6 +55,8 @@ def parse_args():
                          "0 = choose so that at least 16 launches are timed")
     ap.add_argument("--batch", type=int, default=1024, help="queries per call of the batched (configs[4]) leg")
     ap.add_argument("--no-batched", action="store_true")
+    ap.add_argument("--no-streamed", action="store_true",
+                    help="merge every query in its own launch instead of inside the next query's scan launch")
     ap.add_argument("--latency-queries", type=int, default=1000)
     return ap.parse_args()
 
@@ -173,11 +175,24 @@ def main():
     sharded = ShardedEngine(eng, max_topn=topn, always_gather=force_sharded) if (world > 1 or force_sharded) else None
     out_keys = torch.zeros(topn, dtype=torch.int64, device=dev)
 
+    # A stream of single queries: the merge of query k rides in the scan launch of query
+    # k + 1 (mi355rec_enqueue_row_keys_streamed), the last one is flushed INSIDE the timed
+    # region; every step is still one full pass over the catalogue for one query.
+    streamed = sharded is None and not args.no_streamed and topn <= 1024
+    ring = [torch.zeros(topn, dtype=torch.int64, device=dev) for _ in range(4)]
+
     def step(k):
         if sharded is None:
-            eng.enqueue_row_keys(q_rows[k], topn, out_keys)
+            if streamed:
+                eng.enqueue_row_keys_streamed(q_rows[k], topn, ring[k % 4])
+            else:
+                eng.enqueue_row_keys(q_rows[k], topn, out_keys)
         else:
             sharded.enqueue_query(q_vecs[k], q_rows[k], topn)
+
+    def flush():
+        if streamed:
+            eng.enqueue_flush()
 
     def fence():
         torch.cuda.synchronize()
@@ -187,6 +202,7 @@ def main():
 
     for k in range(args.warmup):
         step(k)
+    flush()
     fence()
     stride = args.event_stride if args.event_stride > 0 else max(1, min(10, args.steps // 16))
     if not args.no_kernel_events:
@@ -194,6 +210,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.warmup, total_q):
         step(k)
+    flush()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     fence()
@@ -209,7 +226,10 @@ def main():
     host_idx = None
     for k in range(total_q, total_q + args.latency_queries):
         t1 = time.perf_counter()
-        step(k)
+        if sharded is None:
+            eng.enqueue_row_keys(q_rows[k], topn, out_keys)   # one query end to end: scan + its own merge
+        else:
+            step(k)
         res = (out_keys if sharded is None else sharded.out_keys[:topn]).cpu()
         lat.append((time.perf_counter() - t1) * 1e3)
         host_idx = res
@@ -254,7 +274,10 @@ def main():
                  "unit": "queries/s", "ms_per_pass": round(dt / (nb / 12) * 1e3, 5),
                  "note": "one exact scan of the (local) catalogue answers 12 queries (mi355::scan_multi_kernel); "
                          + ("single GPU" if sharded is None else "one all-gather per 72-query call")}
-        step(0)
+        if sharded is None:
+            eng.enqueue_row_keys(q_rows[0], topn, out_keys)
+        else:
+            step(0)
         torch.cuda.synchronize()
         a, _ = unpack_keys((out_keys if sharded is None else sharded.out_keys[:topn]).cpu().numpy())
         b, _ = unpack_keys((b_keys[:topn] if sharded is None else sharded.batch_keys[0]).cpu().numpy())
@@ -367,6 +390,8 @@ def main():
                             + ("1 MI355X (BASELINE configs[2], HBM-roofline run)" if world == 1 else
                                f"row-sharded across {world} MI355X, one all-gather of {topn} keys/rank (configs[3])"),
                 "rows": n, "topn": topn, "rows_per_gpu": hi - lo, "queries_per_step": 1,
+                "merge": ("inside the next query's scan launch (streamed), last one flushed in the timed region"
+                          if streamed else "own launch per query"),
                 "seed": args.seed, "generator": "torch.rand(seed) uniform[0,1) on device",
             },
             "p50_ms": round(lat[len(lat) // 2], 4) if lat else None,

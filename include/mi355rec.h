@@ -155,6 +155,22 @@ int mi355rec_enqueue_query_keys(mi355rec_t* h, const float* query12,
                                 int64_t exclude_global, int topn,
                                 mi355rec_key_t* out_keys_dev, void* stream);
 
+/* STREAMED single queries: as mi355rec_enqueue_row_keys / _query_keys (topn <= 1024), but
+ * the device merge of this query is deferred — it runs inside the scan launch of the NEXT
+ * streamed query on this handle (one extra workgroup merges the previous query's
+ * per-workgroup lists while the others scan), or in mi355rec_enqueue_flush.  The keys of
+ * query k are therefore complete when the work enqueued by streamed call k + 1, or by
+ * the flush, has completed; out_keys_dev must stay valid until then.  A stream of K
+ * queries costs K scan launches + ONE merge launch instead of K + K, which removes the
+ * ~10 us one-workgroup merge kernel from every step but the last. */
+int mi355rec_enqueue_row_keys_streamed(mi355rec_t* h, int64_t local_row, int topn,
+                                       mi355rec_key_t* out_keys_dev, void* stream);
+int mi355rec_enqueue_query_keys_streamed(mi355rec_t* h, const float* query12,
+                                         int64_t exclude_global, int topn,
+                                         mi355rec_key_t* out_keys_dev, void* stream);
+/* Merges the last streamed query (no-op when nothing is pending). */
+int mi355rec_enqueue_flush(mi355rec_t* h, void* stream);
+
 /* `batch` queries (batch x 12 floats, host; exclude_global may be NULL) in
  * multi-query passes: every pass streams the shard ONCE for up to 12 queries
  * (topn <= 128; larger topn falls back to one scan per query); 13 and more

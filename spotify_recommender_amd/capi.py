@@ -57,6 +57,9 @@ SIGNATURES = {
     "mi355rec_query_batch_topn": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "mi355rec_enqueue_row_keys": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "mi355rec_enqueue_query_keys": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "mi355rec_enqueue_row_keys_streamed": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "mi355rec_enqueue_query_keys_streamed": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "mi355rec_enqueue_flush": (c_int, [c_void_p, c_void_p]),
     "mi355rec_enqueue_batch_keys": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mi355rec_enqueue_batch_keys_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mi355rec_set_batch_path": (c_int, [c_void_p, c_int]),

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
                                 staged = 0;
                             }
                             if (hit) {
-                                const int slot = staged + __popcll(who & ((1ull << lane) - 1ull));
+                                const int slot = staged + lanes_below(who);
                                 stage[slot] = make_uint2(q, static_cast<uint32_t>(tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h));
                             }
                             staged += n_hit;

@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #pragma clang fp contract(off)
 
 namespace mi355 {
@@ -47,8 +49,6 @@ constexpr int kMergeFirstPerThread = 8;  // covers kMergeMaxLists * kMergeFirst 
 constexpr int kMergeSurvPerThread = kMergeSurvCap / kMergeBlock;
 constexpr int kMergeHeadsPerThread = kMergeMaxLists / kMergeBlock;
 
-static_assert(kMergeSurvCap % kMergeBlock == 0, "even shares");
-static_assert(kMergeBlock % kMergeFirst == 0 && kMergeMaxLists * kMergeFirst <= kMergeBlock * kMergeFirstPerThread, "first-chunk phase covers every list");
 
 struct QueryArg {
     float q[kDim];
@@ -154,6 +154,13 @@ __device__ __forceinline__ Row load_row(const float* __restrict__ feats, int64_t
     r.b = p[1];
     r.c = p[2];
     return r;
+}
+
+// Number of set bits of `mask` below this lane: v_mbcnt_lo + v_mbcnt_hi, no 64-bit
+// (1 << lane) - 1 mask to keep in two VGPRs across the streaming loop.
+__device__ __forceinline__ int lanes_below(uint64_t mask) {
+    return static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u)));
 }
 
 // ---- workgroup-level selection ------------------------------------------------
@@ -363,6 +370,280 @@ __device__ inline uint64_t compact_candidates(uint64_t* s_cand, int* s_count, in
     return t - 1ull;
 }
 
+// ---- merge of sorted candidate lists -----------------------------------------
+// n_lists lists of list_len keys (each sorted descending, 0-padded) -> the best
+// topk keys, sorted descending, 0-padded; optional unpack to (row, score).
+// One workgroup per query (blockIdx.x = query in a batch): list l of query b starts
+// at lists_base + b*lists_query_stride + l*list_stride, so both layouts work:
+// [query][list][key] (per-workgroup lists of a scan) and [list][query][key]
+// (per-rank results of a batch after the all-gather).
+//
+// A key can only be in the global top-k if it is >= T whenever m lists each
+// hold >= j keys that are >= T with m*j >= topk.  With plenty of lists j = 1:
+// T = the topk-th largest list HEAD; with few (8 per-rank lists) deeper probes.
+// Lists are sorted, so each list's survivors are a prefix; for statistically
+// similar shards ~1.2*topk keys survive in total.  They are cut to exactly
+// topk by the radix select and ranked.  If more than kMergeSurvCap survive
+// (adversarial input), an exact radix select over all keys in global memory
+// finds the topk-th key instead.
+
+template <int kThreads>
+__device__ inline uint64_t merge_global_radix_select(const uint64_t* __restrict__ lists,
+                                                     int64_t total, int list_len, int64_t list_stride,
+                                                     int topk, int* s_hist, int* s_pair) {
+    // returns the topk-th largest key (0 if fewer than topk non-zero keys)
+    uint64_t prefix = 0, mask = 0;
+    int remaining = topk;
+    for (int pass = 7; pass >= 0; --pass) {
+        for (int i = threadIdx.x; i < 256; i += kThreads) s_hist[i] = 0;
+        __syncthreads();
+        const int shift = pass * 8;
+        for (int64_t i = threadIdx.x; i < total; i += kThreads) {
+            const uint64_t k = lists[(i / list_len) * list_stride + (i % list_len)];
+            if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int acc = 0, d = 255;
+            for (; d > 0; --d) {
+                if (acc + s_hist[d] >= remaining) break;
+                acc += s_hist[d];
+            }
+            s_pair[0] = d;
+            s_pair[1] = remaining - acc;
+        }
+        __syncthreads();
+        prefix |= static_cast<uint64_t>(s_pair[0]) << shift;
+        mask |= 255ull << shift;
+        remaining = s_pair[1];
+        __syncthreads();
+    }
+    return prefix;
+}
+
+// `slot` = which list set (lists_base + slot * lists_query_stride), `out_slot` = which
+// output row (out_*_base + out_slot * out_query_stride).
+// Shared memory of one merge: the product's merge kernels use <1024 threads, 2048 lists,
+// 4096 survivors>; the merger that rides along in a scan launch (scan_kernel<.., kWithMerge>)
+// uses the scan's block size and smaller bounds so that it fits the scan's register and LDS
+// budget (an overflowing survivor set falls back to the exact radix select either way).
+template <int kThreads, int kMaxLists, int kSurvCap>
+struct MergeSmemT {
+    uint64_t surv[kSurvCap];
+    uint64_t top[kMaxTopK];
+    SelectSmem sel;
+    int pair[2];
+    int count;
+    int overflow;
+    int more;
+    unsigned short active[kMaxLists];
+};
+
+template <int kThreads, int kMaxLists, int kSurvCap>
+__device__ __forceinline__ void merge_body(
+    MergeSmemT<kThreads, kMaxLists, kSurvCap>& sm, const uint64_t* __restrict__ lists_base, int n_lists, int list_len, int64_t list_stride,
+    int64_t lists_query_stride, int topk, uint64_t* __restrict__ out_keys_base,
+    int64_t* __restrict__ out_idx_base, float* __restrict__ out_score_base,
+    int64_t out_query_stride, int64_t slot, int64_t out_slot) {
+    constexpr int kFirstPer = kMaxLists * kMergeFirst / kThreads;   // first-chunk keys per thread
+    constexpr int kSurvPer = kSurvCap / kThreads;
+    constexpr int kHeadsPer = kMaxLists / kThreads;
+    static_assert(kThreads % kMergeFirst == 0 && kSurvCap % kThreads == 0 && kMaxLists % kThreads == 0, "even shares");
+    uint64_t* const s_surv = sm.surv;
+    uint64_t* const s_top = sm.top;
+    SelectSmem& s_sel = sm.sel;
+    int* const s_pair = sm.pair;
+    int& s_count = sm.count;
+    int& s_overflow = sm.overflow;
+    int& s_more = sm.more;
+    unsigned short* const s_active = sm.active;
+
+    const int tid = threadIdx.x;
+    const uint64_t* lists = lists_base + slot * lists_query_stride;
+    uint64_t* out_keys = out_keys_base + out_slot * out_query_stride;
+
+    if (tid == 0) {
+        s_count = 0;
+        s_overflow = 0;
+        s_pair[0] = 0;
+        s_more = 0;
+    }
+    __syncthreads();
+    int probe = 1;
+    if (n_lists < 2 * topk) probe = (2 * topk + n_lists - 1) / n_lists;
+    if (probe > list_len) probe = list_len;
+    const int need_lists = (topk + probe - 1) / probe;
+    int slack = need_lists / 8;
+    uint64_t thr = 1;  // accept every non-empty key
+    int first = 0;     // keys [0, first) of every list are already dealt with
+
+    const int64_t total_keys = static_cast<int64_t>(n_lists) * list_len;
+    if (total_keys <= kSurvCap) {
+        // Small input (e.g. one list of topn keys per rank after the all-gather):
+        // take every key in one load phase; the select / rank below does the rest.
+        first = list_len;
+        for (int64_t i = tid; i < total_keys; i += kThreads) {
+            const uint64_t k = lists[(i / list_len) * list_stride + (i % list_len)];
+            if (k) s_surv[atomicAdd(&s_count, 1)] = k;
+        }
+    } else if (probe == 1 && n_lists * kMergeFirst <= kThreads * kFirstPer) {
+        // Many lists (the per-workgroup lists of one scan).  ONE load phase brings
+        // in the first kMergeFirst keys of every list; the heads among them give
+        // the threshold and the rest is filtered from registers, so the usual
+        // case costs a single global-memory round trip.
+        first = kMergeFirst < list_len ? kMergeFirst : list_len;
+        uint64_t k[kFirstPer];
+        uint64_t hk[kFirstPer];
+        const int j = tid % kMergeFirst;  // kThreads % kMergeFirst == 0
+        int local_nonzero = 0;
+#pragma unroll
+        for (int u = 0; u < kFirstPer; ++u) {
+            const int l = (u * kThreads + tid) / kMergeFirst;
+            k[u] = (l < n_lists && j < list_len) ? lists[static_cast<int64_t>(l) * list_stride + j] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < kFirstPer; ++u) {
+            hk[u] = j == 0 ? k[u] : 0ull;
+            local_nonzero += hk[u] != 0ull;
+        }
+        for (int l = tid; l < n_lists; l += kThreads) s_active[l] = 0xffff;
+        if (local_nonzero) atomicAdd(&s_pair[0], local_nonzero);
+        __syncthreads();
+        if (s_pair[0] >= need_lists)  // uniform
+            thr = block_select_threshold<kThreads, kFirstPer>(hk, need_lists, false, slack, s_sel);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kFirstPer; ++u) {
+            if (k[u] >= thr) {
+                const int slot = atomicAdd(&s_count, 1);
+                if (slot < kSurvCap) s_surv[slot] = k[u];
+                else s_overflow = 1;
+                if (j == first - 1) {  // the whole first chunk passed: look deeper
+                    s_active[(u * kThreads + tid) / kMergeFirst] = 0;
+                    s_more = 1;
+                }
+            }
+        }
+    } else {
+        // Few lists (e.g. one per rank) or very many: probe each list at depth
+        // `probe` and start the rounds from the top of every list.
+        uint64_t heads[kHeadsPer];
+        int local_nonzero = 0;
+#pragma unroll
+        for (int r = 0; r < kHeadsPer; ++r) {
+            const int l = tid + r * kThreads;
+            heads[r] = l < n_lists ? lists[static_cast<int64_t>(l) * list_stride + (probe - 1)] : 0ull;
+            local_nonzero += heads[r] != 0ull;
+            if (l < n_lists) s_active[l] = 0;
+        }
+        if (tid == 0) s_more = 1;  // every list starts active
+        if (local_nonzero) atomicAdd(&s_pair[0], local_nonzero);
+        __syncthreads();
+        if (s_pair[0] >= need_lists)  // uniform; the select needs >= need_lists non-empty probes
+            thr = block_select_threshold<kThreads, kHeadsPer>(heads, need_lists, false, slack, s_sel);
+    }
+    __syncthreads();
+
+    // Deeper rounds: round d looks at keys [first + d*C, first + (d+1)*C) of every
+    // list that is still active (its previous chunk passed entirely); the loads
+    // of a round are independent and issued before any of them is consumed.
+    // With the first-chunk phase above this loop usually does not run at all.
+    for (int round = 0; first + round * kMergeChunk < list_len && !s_overflow; ++round) {
+        // s_more was raised by whoever marked a list active for this round
+        if (!s_more) break;  // uniform: read after a barrier, rewritten only after the next one
+        __syncthreads();
+        if (tid == 0) s_more = 0;
+        __syncthreads();
+        const int total = n_lists * kMergeChunk;
+        for (int t0 = 0; t0 < total; t0 += kThreads * 8) {
+            uint64_t k[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u * kThreads + tid;
+                const int l = t / kMergeChunk;
+                const int pos = first + round * kMergeChunk + (t % kMergeChunk);
+                const bool live = t < total && pos < list_len && s_active[l] == round;
+                k[u] = live ? lists[static_cast<int64_t>(l) * list_stride + pos] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (k[u] >= thr) {
+                    const int slot = atomicAdd(&s_count, 1);
+                    if (slot < kSurvCap) s_surv[slot] = k[u];
+                    else s_overflow = 1;
+                }
+            }
+        }
+        __syncthreads();
+        // a list stays active iff the LAST key of this chunk passed
+        for (int l = tid; l < n_lists; l += kThreads) {
+            if (s_active[l] == round) {
+                const int last = first + (round + 1) * kMergeChunk - 1;
+                if (last < list_len && lists[static_cast<int64_t>(l) * list_stride + last] >= thr) {
+                    s_active[l] = static_cast<unsigned short>(round + 1);
+                    s_more = 1;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (s_overflow) {
+        // exact fallback: radix-select the topk-th key over everything
+        const int64_t total = static_cast<int64_t>(n_lists) * list_len;
+        uint64_t kth = merge_global_radix_select<kThreads>(lists, total, list_len, list_stride, topk, s_sel.hist, s_pair);
+        if (kth == 0) kth = 1;
+        if (tid == 0) s_count = 0;
+        __syncthreads();
+        for (int64_t i0 = 0; i0 < total; i0 += kThreads) {
+            const int64_t i = i0 + tid;
+            const uint64_t k = (i < total) ? lists[(i / list_len) * list_stride + (i % list_len)] : 0ull;
+            if (k >= kth) {
+                const int pos = atomicAdd(&s_count, 1);  // exactly topk keys when unique
+                if (pos < kSurvCap) s_surv[pos] = k;
+            }
+        }
+        __syncthreads();
+    }
+
+    int c = s_count < kSurvCap ? s_count : kSurvCap;
+    __syncthreads();
+    if (c > topk && c > kRankDirectMax) {  // uniform: too many to rank, cut to exactly topk in O(c)
+        uint64_t mine[kSurvPer];
+#pragma unroll
+        for (int r = 0; r < kSurvPer; ++r) {
+            const int i = tid + r * kThreads;
+            mine[r] = i < c ? s_surv[i] : 0ull;
+        }
+        const uint64_t t = block_select_threshold<kThreads, kSurvPer>(mine, topk, true, 0, s_sel);
+        if (tid == 0) s_count = 0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kSurvPer; ++r) {
+            if (mine[r] >= t) {
+                const int pos = atomicAdd(&s_count, 1);
+                if (pos < kSurvCap) s_surv[pos] = mine[r];
+            }
+        }
+        __syncthreads();
+        c = s_count < kSurvCap ? s_count : kSurvCap;
+    }
+    block_rank_and_store<kThreads>(s_surv, c, s_top, topk);
+    __syncthreads();
+    for (int i = tid; i < topk; i += kThreads) {
+        const uint64_t k = s_top[i];
+        out_keys[i] = k;
+        if (out_idx_base) {
+            out_idx_base[out_slot * out_query_stride + i] =
+                k ? static_cast<int64_t>(static_cast<uint32_t>(~static_cast<uint32_t>(k))) : -1;
+        }
+        if (out_score_base) {
+            out_score_base[out_slot * out_query_stride + i] =
+                k ? ordered_to_score(static_cast<uint32_t>(k >> 32)) : 0.0f;
+        }
+    }
+}
+
 // ---- streaming scan ----------------------------------------------------------
 // Tiles of kTileRows rows are dealt round-robin over the workgroups (or, with
 // rows_per_block > 0, workgroup b owns a contiguous 64-row-aligned block); every
@@ -378,18 +659,77 @@ __device__ inline uint64_t compact_candidates(uint64_t* s_cand, int* s_count, in
 
 // kDebug (development A/B only; 0 in the product): 1 = no end-of-tile barrier pair,
 // 2 = ballot only, no LDS append, 4 = skip the seed compaction (threshold preset).
-template <typename Cfg, bool kQueryFromRow, bool kScoresOnly, int kDebug = 0>
+// kWithMerge (streamed queries, mi355rec_enqueue_*_streamed): the LAST workgroup of the launch
+// does not scan — it merges the per-workgroup lists of the PREVIOUS query (`prev`, a second
+// list buffer) while workgroups 0 .. gridDim.x-2 scan this one, so the ~8 us one-workgroup merge
+// kernel and its boundary disappear from the critical path of a stream of single queries.
+// The host launches one scan workgroup fewer than are resident (767 + the merger on a
+// 256-CU part), so nothing waits for a slot.
+struct PrevMerge {
+    const uint64_t* lists;   // [n_lists][topk] of the previous query, nullptr = nothing pending
+    int n_lists;
+    int topk;
+    uint64_t* out_keys;
+};
+constexpr int kRideMaxLists = 1024;   // the riding merger's bounds (scan grids are <= 1023 workgroups)
+constexpr int kRideSurvCap = 2048;
+
+template <typename Cfg, bool kWithMerge>
+struct ScanSmemT {
+    uint64_t cand[Cfg::kCandCap];
+    SelectSmem sel;
+    int count;
+};
+template <typename Cfg, bool kWithMerge>
+union ScanOrMergeSmem {
+    ScanSmemT<Cfg, kWithMerge> scan;
+    MergeSmemT<Cfg::kBlock, kRideMaxLists, kRideSurvCap> merge;
+};
+
+template <typename Cfg, bool kQueryFromRow, bool kScoresOnly, int kDebug = 0, bool kWithMerge = false>
 __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
     const float* __restrict__ feats, int64_t n, int64_t rows_per_block, int iters,
     int64_t row_base, QueryArg qarg, int64_t query_row, int64_t exclude_global,
     int topk, uint64_t* __restrict__ block_lists, float* __restrict__ scores_out,
-    const uint64_t* __restrict__ upper_ptr) {
+    const uint64_t* __restrict__ upper_ptr, PrevMerge prev) {
     constexpr int kBlock = Cfg::kBlock;
     constexpr int kRowsPerThread = Cfg::kRowsPerThread;
     constexpr int kTileRows = Cfg::kTileRows;
-    __shared__ uint64_t s_cand[kScoresOnly ? 1 : Cfg::kCandCap];
-    __shared__ SelectSmem s_sel;
-    __shared__ int s_count;
+    static_assert(!(kWithMerge && kScoresOnly), "the riding merger belongs to top-N scans");
+    // Plain statics for the ordinary scan (exactly the round-1 layout: the kernel sits at
+    // 79 of its 80 VGPRs and one more costs a spill); the union only in the riding variant.
+    __shared__ uint64_t s_cand_plain[(kScoresOnly || kWithMerge) ? 1 : Cfg::kCandCap];
+    __shared__ SelectSmem s_sel_plain;
+    __shared__ int s_count_plain;
+    __shared__ typename std::conditional<kWithMerge, ScanOrMergeSmem<Cfg, true>, int>::type s_ride;
+    if constexpr (kWithMerge) {
+        if (blockIdx.x == gridDim.x - 1) {      // the merger (the LAST workgroup: the scanners keep blockIdx = tile slot)
+            if (prev.lists)
+                merge_body(s_ride.merge, prev.lists, prev.n_lists, prev.topk, static_cast<int64_t>(prev.topk),
+                           static_cast<int64_t>(0), prev.topk, prev.out_keys, static_cast<int64_t*>(nullptr),
+                           static_cast<float*>(nullptr), static_cast<int64_t>(0), static_cast<int64_t>(0),
+                           static_cast<int64_t>(0));
+            return;
+        }
+    }
+    // this workgroup's index among the scanning workgroups, and their number
+    const unsigned bid = blockIdx.x;
+    const unsigned nblocks = kWithMerge ? gridDim.x - 1u : gridDim.x;
+    uint64_t* s_cand;
+    SelectSmem* s_sel_p;
+    int* s_count_p;
+    if constexpr (kWithMerge) {
+        s_cand = s_ride.scan.cand;
+        s_sel_p = &s_ride.scan.sel;
+        s_count_p = &s_ride.scan.count;
+    } else {
+        (void)s_ride;
+        s_cand = s_cand_plain;
+        s_sel_p = &s_sel_plain;
+        s_count_p = &s_count_plain;
+    }
+    SelectSmem& s_sel = *s_sel_p;
+    int& s_count = *s_count_p;
 
     float q[kDim];
     if constexpr (kQueryFromRow) {
@@ -404,7 +744,8 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
     // Only keys strictly below *upper_ptr take part (nullptr: no bound).  This is
     // how topn > kMaxTopK is served: round r asks for the best kMaxTopK keys
     // below the last key of round r-1 (0 there = catalogue exhausted).
-    const uint64_t upper = upper_ptr ? *upper_ptr : ~0ull;
+    // (streamed queries are single-round: no bound, and two VGPRs the riding variant needs)
+    const uint64_t upper = kWithMerge ? ~0ull : (upper_ptr ? *upper_ptr : ~0ull);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -412,8 +753,8 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
     // rows_per_block == 0: tiles are dealt round-robin (tile t -> workgroup t % grid),
     // so at any moment the whole chip reads one moving ~20 MB window of the matrix.
     const bool interleaved = rows_per_block == 0;
-    const int64_t blk_begin = static_cast<int64_t>(blockIdx.x) * (interleaved ? kTileRows : rows_per_block);
-    const int64_t tile_stride = interleaved ? static_cast<int64_t>(gridDim.x) * kTileRows : kTileRows;
+    const int64_t blk_begin = static_cast<int64_t>(bid) * (interleaved ? kTileRows : rows_per_block);
+    const int64_t tile_stride = interleaved ? static_cast<int64_t>(nblocks) * kTileRows : kTileRows;
     int64_t blk_end = interleaved ? n : blk_begin + rows_per_block;
     if (blk_end > n) blk_end = n;
     // rows past the block's end re-read its last row (one cached line) so the
@@ -473,7 +814,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
                         int base = 0;
                         if (lane == 0) base = atomicAdd(&s_count, __popcll(ballot));
                         base = __builtin_amdgcn_readfirstlane(base);
-                        const int pos = base + __popcll(ballot & ((1ull << lane) - 1ull));
+                        const int pos = base + lanes_below(ballot);
                         if (pass) s_cand[pos] = key;
                     }
                 }
@@ -514,7 +855,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
         if (s_count > kRankDirectMax && s_count > topk)  // uniform
             compact_candidates<kBlock, Cfg::kCandPerThread>(s_cand, &s_count, topk, true, s_sel);
         __syncthreads();
-        block_rank_and_store<kBlock>(s_cand, s_count, block_lists + static_cast<int64_t>(blockIdx.x) * topk, topk);
+        block_rank_and_store<kBlock>(s_cand, s_count, block_lists + static_cast<int64_t>(bid) * topk, topk);
     }
 }
 
@@ -640,7 +981,7 @@ __device__ inline uint64_t wave_compact(uint64_t* cand, int* count, int topk, bo
     for (int r = 0; r < kKeys; ++r) {
         const bool keep = mine[r] >= t;  // t >= 1, so empty slots drop out
         const uint64_t b = __ballot(keep);
-        if (keep) cand[base + __popcll(b & ((1ull << lane) - 1ull))] = mine[r];
+        if (keep) cand[base + lanes_below(b)] = mine[r];
         base += __popcll(b);
     }
     if (lane == 0) *count = base;
@@ -791,7 +1132,7 @@ __device__ __forceinline__ void multi_scan_group(
                         int base = 0;
                         if (lane == 0) base = atomicAdd(&s_count[qi], __popcll(ballot));
                         base = __builtin_amdgcn_readfirstlane(base);
-                        const int pos = base + __popcll(ballot & ((1ull << lane) - 1ull));
+                        const int pos = base + lanes_below(ballot);
                         if (pass) s_cand[qi][pos] = key;
                     }
                 }
@@ -973,264 +1314,15 @@ __global__ __launch_bounds__(kMergeBlock) void seed_select_kernel(
     if (tid == 0) seed_keys[static_cast<int64_t>(blockIdx.x) * topk + (topk - 1)] = t;
 }
 
-// ---- merge of sorted candidate lists -----------------------------------------
-// n_lists lists of list_len keys (each sorted descending, 0-padded) -> the best
-// topk keys, sorted descending, 0-padded; optional unpack to (row, score).
-// One workgroup per query (blockIdx.x = query in a batch): list l of query b starts
-// at lists_base + b*lists_query_stride + l*list_stride, so both layouts work:
-// [query][list][key] (per-workgroup lists of a scan) and [list][query][key]
-// (per-rank results of a batch after the all-gather).
-//
-// A key can only be in the global top-k if it is >= T whenever m lists each
-// hold >= j keys that are >= T with m*j >= topk.  With plenty of lists j = 1:
-// T = the topk-th largest list HEAD; with few (8 per-rank lists) deeper probes.
-// Lists are sorted, so each list's survivors are a prefix; for statistically
-// similar shards ~1.2*topk keys survive in total.  They are cut to exactly
-// topk by the radix select and ranked.  If more than kMergeSurvCap survive
-// (adversarial input), an exact radix select over all keys in global memory
-// finds the topk-th key instead.
-
-__device__ inline uint64_t merge_global_radix_select(const uint64_t* __restrict__ lists,
-                                                     int64_t total, int list_len, int64_t list_stride,
-                                                     int topk, int* s_hist, int* s_pair) {
-    // returns the topk-th largest key (0 if fewer than topk non-zero keys)
-    uint64_t prefix = 0, mask = 0;
-    int remaining = topk;
-    for (int pass = 7; pass >= 0; --pass) {
-        for (int i = threadIdx.x; i < 256; i += kMergeBlock) s_hist[i] = 0;
-        __syncthreads();
-        const int shift = pass * 8;
-        for (int64_t i = threadIdx.x; i < total; i += kMergeBlock) {
-            const uint64_t k = lists[(i / list_len) * list_stride + (i % list_len)];
-            if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255], 1);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int acc = 0, d = 255;
-            for (; d > 0; --d) {
-                if (acc + s_hist[d] >= remaining) break;
-                acc += s_hist[d];
-            }
-            s_pair[0] = d;
-            s_pair[1] = remaining - acc;
-        }
-        __syncthreads();
-        prefix |= static_cast<uint64_t>(s_pair[0]) << shift;
-        mask |= 255ull << shift;
-        remaining = s_pair[1];
-        __syncthreads();
-    }
-    return prefix;
-}
-
-// `slot` = which list set (lists_base + slot * lists_query_stride), `out_slot` = which
-// output row (out_*_base + out_slot * out_query_stride).
-__device__ __forceinline__ void merge_body(
-    const uint64_t* __restrict__ lists_base, int n_lists, int list_len, int64_t list_stride,
-    int64_t lists_query_stride, int topk, uint64_t* __restrict__ out_keys_base,
-    int64_t* __restrict__ out_idx_base, float* __restrict__ out_score_base,
-    int64_t out_query_stride, int64_t slot, int64_t out_slot) {
-    __shared__ uint64_t s_surv[kMergeSurvCap];
-    __shared__ uint64_t s_top[kMaxTopK];
-    __shared__ SelectSmem s_sel;
-    __shared__ int s_pair[2];
-    __shared__ int s_count;
-    __shared__ int s_overflow;
-    __shared__ int s_more;
-    __shared__ unsigned short s_active[kMergeMaxLists];
-
-    const int tid = threadIdx.x;
-    const uint64_t* lists = lists_base + slot * lists_query_stride;
-    uint64_t* out_keys = out_keys_base + out_slot * out_query_stride;
-
-    if (tid == 0) {
-        s_count = 0;
-        s_overflow = 0;
-        s_pair[0] = 0;
-        s_more = 0;
-    }
-    __syncthreads();
-    int probe = 1;
-    if (n_lists < 2 * topk) probe = (2 * topk + n_lists - 1) / n_lists;
-    if (probe > list_len) probe = list_len;
-    const int need_lists = (topk + probe - 1) / probe;
-    int slack = need_lists / 8;
-    uint64_t thr = 1;  // accept every non-empty key
-    int first = 0;     // keys [0, first) of every list are already dealt with
-
-    const int64_t total_keys = static_cast<int64_t>(n_lists) * list_len;
-    if (total_keys <= kMergeSurvCap) {
-        // Small input (e.g. one list of topn keys per rank after the all-gather):
-        // take every key in one load phase; the select / rank below does the rest.
-        first = list_len;
-        for (int64_t i = tid; i < total_keys; i += kMergeBlock) {
-            const uint64_t k = lists[(i / list_len) * list_stride + (i % list_len)];
-            if (k) s_surv[atomicAdd(&s_count, 1)] = k;
-        }
-    } else if (probe == 1 && n_lists * kMergeFirst <= kMergeBlock * kMergeFirstPerThread) {
-        // Many lists (the per-workgroup lists of one scan).  ONE load phase brings
-        // in the first kMergeFirst keys of every list; the heads among them give
-        // the threshold and the rest is filtered from registers, so the usual
-        // case costs a single global-memory round trip.
-        first = kMergeFirst < list_len ? kMergeFirst : list_len;
-        uint64_t k[kMergeFirstPerThread];
-        uint64_t hk[kMergeFirstPerThread];
-        const int j = tid % kMergeFirst;  // kMergeBlock % kMergeFirst == 0
-        int local_nonzero = 0;
-#pragma unroll
-        for (int u = 0; u < kMergeFirstPerThread; ++u) {
-            const int l = (u * kMergeBlock + tid) / kMergeFirst;
-            k[u] = (l < n_lists && j < list_len) ? lists[static_cast<int64_t>(l) * list_stride + j] : 0ull;
-        }
-#pragma unroll
-        for (int u = 0; u < kMergeFirstPerThread; ++u) {
-            hk[u] = j == 0 ? k[u] : 0ull;
-            local_nonzero += hk[u] != 0ull;
-        }
-        for (int l = tid; l < n_lists; l += kMergeBlock) s_active[l] = 0xffff;
-        if (local_nonzero) atomicAdd(&s_pair[0], local_nonzero);
-        __syncthreads();
-        if (s_pair[0] >= need_lists)  // uniform
-            thr = block_select_threshold<kMergeBlock, kMergeFirstPerThread>(hk, need_lists, false, slack, s_sel);
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < kMergeFirstPerThread; ++u) {
-            if (k[u] >= thr) {
-                const int slot = atomicAdd(&s_count, 1);
-                if (slot < kMergeSurvCap) s_surv[slot] = k[u];
-                else s_overflow = 1;
-                if (j == first - 1) {  // the whole first chunk passed: look deeper
-                    s_active[(u * kMergeBlock + tid) / kMergeFirst] = 0;
-                    s_more = 1;
-                }
-            }
-        }
-    } else {
-        // Few lists (e.g. one per rank) or very many: probe each list at depth
-        // `probe` and start the rounds from the top of every list.
-        uint64_t heads[kMergeHeadsPerThread];
-        int local_nonzero = 0;
-#pragma unroll
-        for (int r = 0; r < kMergeHeadsPerThread; ++r) {
-            const int l = tid + r * kMergeBlock;
-            heads[r] = l < n_lists ? lists[static_cast<int64_t>(l) * list_stride + (probe - 1)] : 0ull;
-            local_nonzero += heads[r] != 0ull;
-            if (l < n_lists) s_active[l] = 0;
-        }
-        if (tid == 0) s_more = 1;  // every list starts active
-        if (local_nonzero) atomicAdd(&s_pair[0], local_nonzero);
-        __syncthreads();
-        if (s_pair[0] >= need_lists)  // uniform; the select needs >= need_lists non-empty probes
-            thr = block_select_threshold<kMergeBlock, kMergeHeadsPerThread>(heads, need_lists, false, slack, s_sel);
-    }
-    __syncthreads();
-
-    // Deeper rounds: round d looks at keys [first + d*C, first + (d+1)*C) of every
-    // list that is still active (its previous chunk passed entirely); the loads
-    // of a round are independent and issued before any of them is consumed.
-    // With the first-chunk phase above this loop usually does not run at all.
-    for (int round = 0; first + round * kMergeChunk < list_len && !s_overflow; ++round) {
-        // s_more was raised by whoever marked a list active for this round
-        if (!s_more) break;  // uniform: read after a barrier, rewritten only after the next one
-        __syncthreads();
-        if (tid == 0) s_more = 0;
-        __syncthreads();
-        const int total = n_lists * kMergeChunk;
-        for (int t0 = 0; t0 < total; t0 += kMergeBlock * 8) {
-            uint64_t k[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int t = t0 + u * kMergeBlock + tid;
-                const int l = t / kMergeChunk;
-                const int pos = first + round * kMergeChunk + (t % kMergeChunk);
-                const bool live = t < total && pos < list_len && s_active[l] == round;
-                k[u] = live ? lists[static_cast<int64_t>(l) * list_stride + pos] : 0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (k[u] >= thr) {
-                    const int slot = atomicAdd(&s_count, 1);
-                    if (slot < kMergeSurvCap) s_surv[slot] = k[u];
-                    else s_overflow = 1;
-                }
-            }
-        }
-        __syncthreads();
-        // a list stays active iff the LAST key of this chunk passed
-        for (int l = tid; l < n_lists; l += kMergeBlock) {
-            if (s_active[l] == round) {
-                const int last = first + (round + 1) * kMergeChunk - 1;
-                if (last < list_len && lists[static_cast<int64_t>(l) * list_stride + last] >= thr) {
-                    s_active[l] = static_cast<unsigned short>(round + 1);
-                    s_more = 1;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    __syncthreads();
-    if (s_overflow) {
-        // exact fallback: radix-select the topk-th key over everything
-        const int64_t total = static_cast<int64_t>(n_lists) * list_len;
-        uint64_t kth = merge_global_radix_select(lists, total, list_len, list_stride, topk, s_sel.hist, s_pair);
-        if (kth == 0) kth = 1;
-        if (tid == 0) s_count = 0;
-        __syncthreads();
-        for (int64_t i0 = 0; i0 < total; i0 += kMergeBlock) {
-            const int64_t i = i0 + tid;
-            const uint64_t k = (i < total) ? lists[(i / list_len) * list_stride + (i % list_len)] : 0ull;
-            if (k >= kth) {
-                const int pos = atomicAdd(&s_count, 1);  // exactly topk keys when unique
-                if (pos < kMergeSurvCap) s_surv[pos] = k;
-            }
-        }
-        __syncthreads();
-    }
-
-    int c = s_count < kMergeSurvCap ? s_count : kMergeSurvCap;
-    __syncthreads();
-    if (c > topk && c > kRankDirectMax) {  // uniform: too many to rank, cut to exactly topk in O(c)
-        uint64_t mine[kMergeSurvPerThread];
-#pragma unroll
-        for (int r = 0; r < kMergeSurvPerThread; ++r) {
-            const int i = tid + r * kMergeBlock;
-            mine[r] = i < c ? s_surv[i] : 0ull;
-        }
-        const uint64_t t = block_select_threshold<kMergeBlock, kMergeSurvPerThread>(mine, topk, true, 0, s_sel);
-        if (tid == 0) s_count = 0;
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < kMergeSurvPerThread; ++r) {
-            if (mine[r] >= t) {
-                const int pos = atomicAdd(&s_count, 1);
-                if (pos < kMergeSurvCap) s_surv[pos] = mine[r];
-            }
-        }
-        __syncthreads();
-        c = s_count < kMergeSurvCap ? s_count : kMergeSurvCap;
-    }
-    block_rank_and_store<kMergeBlock>(s_surv, c, s_top, topk);
-    __syncthreads();
-    for (int i = tid; i < topk; i += kMergeBlock) {
-        const uint64_t k = s_top[i];
-        out_keys[i] = k;
-        if (out_idx_base) {
-            out_idx_base[out_slot * out_query_stride + i] =
-                k ? static_cast<int64_t>(static_cast<uint32_t>(~static_cast<uint32_t>(k))) : -1;
-        }
-        if (out_score_base) {
-            out_score_base[out_slot * out_query_stride + i] =
-                k ? ordered_to_score(static_cast<uint32_t>(k >> 32)) : 0.0f;
-        }
-    }
-}
+// ---- merge kernels (the merge body itself is defined above the streaming scan) ------
 
 __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
     const uint64_t* __restrict__ lists_base, int n_lists, int list_len, int64_t list_stride,
     int64_t lists_query_stride, int topk, uint64_t* __restrict__ out_keys_base,
     int64_t* __restrict__ out_idx_base, float* __restrict__ out_score_base,
     int64_t out_query_stride) {
-    merge_body(lists_base, n_lists, list_len, list_stride, lists_query_stride, topk, out_keys_base, out_idx_base,
+    __shared__ MergeSmemT<kMergeBlock, kMergeMaxLists, kMergeSurvCap> sm;
+    merge_body(sm, lists_base, n_lists, list_len, list_stride, lists_query_stride, topk, out_keys_base, out_idx_base,
                out_score_base, out_query_stride, blockIdx.x, blockIdx.x);
 }
 
@@ -1242,7 +1334,8 @@ __global__ __launch_bounds__(kMergeBlock) void merge_queued_kernel(
     uint64_t* __restrict__ out_keys_base, int64_t* __restrict__ out_idx_base, float* __restrict__ out_score_base,
     int64_t out_query_stride) {
     if (static_cast<int>(blockIdx.x) >= *queue_count) return;
-    merge_body(lists_base, n_lists, list_len, list_stride, lists_query_stride, topk, out_keys_base, out_idx_base,
+    __shared__ MergeSmemT<kMergeBlock, kMergeMaxLists, kMergeSurvCap> sm;
+    merge_body(sm, lists_base, n_lists, list_len, list_stride, lists_query_stride, topk, out_keys_base, out_idx_base,
                out_score_base, out_query_stride, blockIdx.x, queue[blockIdx.x]);
 }
 

@@ -64,6 +64,13 @@ struct mi355rec {
     int miters = 0;
 
     uint64_t* d_block_lists = nullptr;  // grid x kMaxTopK
+    // streamed single queries (mi355rec_enqueue_*_streamed): the merge of query k rides in
+    // the scan launch of query k + 1; two more list buffers alternate
+    uint64_t* d_stream_lists[2] = {nullptr, nullptr};
+    int sgrid = 0, siters = 0;          // scanning workgroups of a streamed launch (one slot is the merger's)
+    bool pending = false;               // a streamed query's lists wait for their merge
+    int pending_buf = 0, pending_topn = 0;
+    uint64_t* pending_out = nullptr;
     uint32_t* d_seed_vals = nullptr;    // kMultiChain x (mgrid * kSeedWaves) sample maxima
     uint64_t* d_seed_keys = nullptr;    // kMultiChain x kMultiMaxTopK: sample top-k per query of a multi-query chain
 
@@ -351,13 +358,13 @@ int enqueue_scan(mi355rec* h, int64_t query_row, const float* query12,
         hipLaunchKernelGGL((scan_kernel<ScanConfig, true, false>), dim3(h->grid), dim3(kScanBlock), 0, s,
                            h->d_feats, h->n, h->rows_per_block, h->iters, h->row_base, qa,
                            query_row, exclude_global, topn, h->d_block_lists,
-                           static_cast<float*>(nullptr), upper_dev);
+                           static_cast<float*>(nullptr), upper_dev, PrevMerge{nullptr, 0, 0, nullptr});
     } else {
         std::memcpy(qa.q, query12, sizeof qa.q);
         hipLaunchKernelGGL((scan_kernel<ScanConfig, false, false>), dim3(h->grid), dim3(kScanBlock), 0, s,
                            h->d_feats, h->n, h->rows_per_block, h->iters, h->row_base, qa,
                            static_cast<int64_t>(0), exclude_global, topn, h->d_block_lists,
-                           static_cast<float*>(nullptr), upper_dev);
+                           static_cast<float*>(nullptr), upper_dev, PrevMerge{nullptr, 0, 0, nullptr});
     }
     timing_end(h, h->ev_scan, h->n_scan_pairs, slot, s);
     HIP_TRY(h, hipGetLastError());
@@ -462,6 +469,70 @@ int enqueue_query(mi355rec* h, int64_t query_row, const float* query12, int64_t 
                            out_idx ? out_idx + done : nullptr, out_score ? out_score + done : nullptr, s);
         if (rc) return rc;
     }
+    return MI355REC_OK;
+}
+
+// ---- streamed single queries -------------------------------------------------------
+// scan(k+1) and merge(k) share one launch: workgroup 0 merges the previous query's lists,
+// the others scan.  One scanning workgroup fewer than the plain scan uses, so the launch
+// still fits the chip in one wave of workgroups.
+int ensure_streamed(mi355rec* h) {
+    if (h->d_stream_lists[0]) return MI355REC_OK;
+    const int64_t tiles = (h->n + kScanTileRows - 1) / kScanTileRows;
+    int g = h->grid > 1 ? h->grid - 1 : 1;
+    if (g > kRideMaxLists - 1) g = kRideMaxLists - 1;
+    if (const char* e = std::getenv("MI355REC_EXP_SGRID")) {   // A/B experiment only
+        const int v = std::atoi(e);
+        if (v >= 1 && v < g) g = v;
+    }
+    if (tiles < g) g = static_cast<int>(tiles);
+    h->sgrid = g;
+    h->siters = static_cast<int>((tiles + g - 1) / g);
+    for (int i = 0; i < 2; ++i)
+        HIP_TRY(h, hipMalloc(&h->d_stream_lists[i], sizeof(uint64_t) * static_cast<size_t>(g) * kMaxTopK));
+    return MI355REC_OK;
+}
+
+int flush_streamed(mi355rec* h, hipStream_t s) {
+    if (!h->pending) return MI355REC_OK;
+    h->pending = false;
+    return enqueue_merge(h, h->d_stream_lists[h->pending_buf], h->sgrid, h->pending_topn, h->pending_topn, h->pending_out,
+                         nullptr, nullptr, s);
+}
+
+int enqueue_streamed(mi355rec* h, int64_t query_row, const float* query12, int64_t exclude_global, int topn,
+                     uint64_t* out_keys, hipStream_t s) {
+    int rc = ensure_streamed(h);
+    if (rc) return rc;
+    const int buf = h->pending ? 1 - h->pending_buf : 0;
+    PrevMerge prev{nullptr, 0, 0, nullptr};
+    static const bool exp_nomerge = std::getenv("MI355REC_EXP_RIDE_NOMERGE") != nullptr;   // A/B experiment only
+    if (h->pending && exp_nomerge) {
+        rc = flush_streamed(h, s);
+        if (rc) return rc;
+    }
+    if (h->pending) prev = PrevMerge{h->d_stream_lists[h->pending_buf], h->sgrid, h->pending_topn, h->pending_out};
+    QueryArg qa;
+    std::memset(&qa, 0, sizeof qa);
+    const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, s);
+    if (query_row >= 0) {
+        hipLaunchKernelGGL((scan_kernel<ScanConfig, true, false, 0, true>), dim3(h->sgrid + 1), dim3(kScanBlock), 0, s,
+                           h->d_feats, h->n, static_cast<int64_t>(0), h->siters, h->row_base, qa, query_row,
+                           exclude_global, topn, h->d_stream_lists[buf], static_cast<float*>(nullptr),
+                           static_cast<const uint64_t*>(nullptr), prev);
+    } else {
+        std::memcpy(qa.q, query12, sizeof qa.q);
+        hipLaunchKernelGGL((scan_kernel<ScanConfig, false, false, 0, true>), dim3(h->sgrid + 1), dim3(kScanBlock), 0, s,
+                           h->d_feats, h->n, static_cast<int64_t>(0), h->siters, h->row_base, qa, static_cast<int64_t>(0),
+                           exclude_global, topn, h->d_stream_lists[buf], static_cast<float*>(nullptr),
+                           static_cast<const uint64_t*>(nullptr), prev);
+    }
+    timing_end(h, h->ev_scan, h->n_scan_pairs, slot, s);
+    HIP_TRY(h, hipGetLastError());
+    h->pending = true;
+    h->pending_buf = buf;
+    h->pending_topn = topn;
+    h->pending_out = out_keys;
     return MI355REC_OK;
 }
 
@@ -682,6 +753,8 @@ void mi355rec_destroy(mi355rec_t* h) {
     for (hipEvent_t e : h->ev_pass) (void)hipEventDestroy(e);
     if (h->owned_feats) (void)hipFree(h->owned_feats);
     if (h->d_block_lists) (void)hipFree(h->d_block_lists);
+    if (h->d_stream_lists[0]) (void)hipFree(h->d_stream_lists[0]);
+    if (h->d_stream_lists[1]) (void)hipFree(h->d_stream_lists[1]);
     if (h->d_seed_keys) (void)hipFree(h->d_seed_keys);
     if (h->d_seed_vals) (void)hipFree(h->d_seed_vals);
     if (h->d_keys) (void)hipFree(h->d_keys);
@@ -774,6 +847,42 @@ int mi355rec_enqueue_query_keys(mi355rec_t* h, const float* query12, int64_t exc
     if (rc) return rc;
     return enqueue_query(h, -1, query12, exclude_global, topn, out_keys_dev, nullptr, nullptr,
                          static_cast<hipStream_t>(stream));
+}
+
+int mi355rec_enqueue_row_keys_streamed(mi355rec_t* h, int64_t local_row, int topn, mi355rec_key_t* out_keys_dev,
+                                       void* stream) {
+    if (!h || !out_keys_dev) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (local_row < 0 || local_row >= h->n)
+        return fail(h, MI355REC_ERR_INVALID_ARG, "Invalid song index: %lld", (long long)local_row);
+    int rc = check_topn(h, topn, false);
+    if (rc) return rc;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = order_stream(h, s);
+    if (rc) return rc;
+    return enqueue_streamed(h, local_row, nullptr, h->row_base + local_row, topn, out_keys_dev, s);
+}
+
+int mi355rec_enqueue_query_keys_streamed(mi355rec_t* h, const float* query12, int64_t exclude_global, int topn,
+                                         mi355rec_key_t* out_keys_dev, void* stream) {
+    if (!h || !out_keys_dev || !query12) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (h->n < 1) return fail(h, MI355REC_ERR_INVALID_ARG, "empty shard: use mi355rec_enqueue_query_keys");
+    int rc = check_topn(h, topn, false);
+    if (rc) return rc;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = order_stream(h, s);
+    if (rc) return rc;
+    return enqueue_streamed(h, -1, query12, exclude_global, topn, out_keys_dev, s);
+}
+
+int mi355rec_enqueue_flush(mi355rec_t* h, void* stream) {
+    if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rc = order_stream(h, s);
+    if (rc) return rc;
+    return flush_streamed(h, s);
 }
 
 int mi355rec_enqueue_batch_keys(mi355rec_t* h, const float* queries, const int64_t* exclude_global,
@@ -901,13 +1010,13 @@ int mi355rec_enqueue_scores(mi355rec_t* h, int64_t local_row, const float* query
         hipLaunchKernelGGL((scan_kernel<ScanConfig, true, true>), dim3(h->grid), dim3(kScanBlock), 0, s, h->d_feats,
                            h->n, h->rows_per_block, h->iters, h->row_base, qa, local_row,
                            static_cast<int64_t>(-1), 1, static_cast<uint64_t*>(nullptr), out_scores_dev,
-                           static_cast<const uint64_t*>(nullptr));
+                           static_cast<const uint64_t*>(nullptr), PrevMerge{nullptr, 0, 0, nullptr});
     } else {
         std::memcpy(qa.q, query12, sizeof qa.q);
         hipLaunchKernelGGL((scan_kernel<ScanConfig, false, true>), dim3(h->grid), dim3(kScanBlock), 0, s, h->d_feats,
                            h->n, h->rows_per_block, h->iters, h->row_base, qa, static_cast<int64_t>(0),
                            static_cast<int64_t>(-1), 1, static_cast<uint64_t*>(nullptr), out_scores_dev,
-                           static_cast<const uint64_t*>(nullptr));
+                           static_cast<const uint64_t*>(nullptr), PrevMerge{nullptr, 0, 0, nullptr});
     }
     HIP_TRY(h, hipGetLastError());
     return MI355REC_OK;

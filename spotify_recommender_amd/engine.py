@@ -156,6 +156,21 @@ class CosineEngine:
             self._h, q.ctypes.data_as(ctypes.c_void_p), int(exclude_global), int(topn),
             ctypes.c_void_p(out_keys.data_ptr()), self._stream_ptr(stream)), self._h)
 
+    def enqueue_row_keys_streamed(self, local_row: int, topn: int, out_keys, stream=None) -> None:
+        """Deferred merge: complete after the NEXT streamed call's work, or after enqueue_flush."""
+        capi.check(self._lib.mi355rec_enqueue_row_keys_streamed(
+            self._h, int(local_row), int(topn), ctypes.c_void_p(out_keys.data_ptr()),
+            self._stream_ptr(stream)), self._h)
+
+    def enqueue_query_keys_streamed(self, query, exclude_global: int, topn: int, out_keys, stream=None) -> None:
+        q = _np_f32(query).reshape(capi.DIM)
+        capi.check(self._lib.mi355rec_enqueue_query_keys_streamed(
+            self._h, q.ctypes.data_as(ctypes.c_void_p), int(exclude_global), int(topn),
+            ctypes.c_void_p(out_keys.data_ptr()), self._stream_ptr(stream)), self._h)
+
+    def enqueue_flush(self, stream=None) -> None:
+        capi.check(self._lib.mi355rec_enqueue_flush(self._h, self._stream_ptr(stream)), self._h)
+
     def enqueue_batch_keys(self, queries, exclude_global, topn: int, out_keys, stream=None) -> None:
         """Multi-query passes: 12 queries share one scan of the shard (topn <= 128)."""
         q = _np_f32(queries).reshape(-1, capi.DIM)

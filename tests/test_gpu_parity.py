@@ -538,3 +538,49 @@ def test_100m_rows_on_one_gpu(Engine, torch_cuda):
         for b, q in enumerate((7, 50_000_000)):
             want = oracle.scores(f, f[q], threads=0)
             assert_topn_matches(idx[b], sc[b], want, q, 10)
+
+
+def test_streamed_queries_defer_the_merge(Engine, torch_cuda):
+    """mi355rec_enqueue_*_streamed: the merge of query k rides in the scan launch of query
+    k + 1 (workgroup 0 of that launch), the last one is flushed.  Same keys as the plain
+    path, with changing topn, interleaved plain calls and both query forms."""
+    torch = torch_cuda
+    from spotify_recommender_amd.engine import unpack_keys
+    rng = np.random.default_rng(404)
+    n = 700_001
+    f = rng.random((n, 12), dtype=np.float32)
+    f[123] = f[456]
+    t = torch.from_numpy(f).cuda()
+    rows = [int(r) for r in rng.integers(0, n, size=24)] + [123, 456]
+    topns = [100, 100, 1, 10, 1000, 128, 100, 1024, 7] * 3
+    with Engine(t) as eng:
+        outs = [torch.zeros(1024, dtype=torch.int64, device="cuda") for _ in rows]
+        plain = torch.zeros(1024, dtype=torch.int64, device="cuda")
+        for i, r in enumerate(rows):
+            k = topns[i]
+            if i % 2 == 0:
+                eng.enqueue_row_keys_streamed(r, k, outs[i])
+            else:
+                eng.enqueue_query_keys_streamed(f[r], r, k, outs[i])
+            if i == 5:      # a plain query between two streamed ones must not disturb the pending lists
+                eng.enqueue_row_keys(rows[0], 50, plain)
+        eng.enqueue_flush()
+        eng.enqueue_flush()   # nothing pending: no-op
+        torch.cuda.synchronize()
+        for i, r in enumerate(rows):
+            k = topns[i]
+            got_rows, got_sc = unpack_keys(outs[i][:k].cpu().numpy())
+            want = oracle.scores(f, f[r])
+            assert_topn_matches(got_rows, got_sc, want, r, k, ref_idx=oracle.topn_heap(want, r, k))
+        p_rows, _ = unpack_keys(plain[:50].cpu().numpy())
+        assert p_rows.tolist() == oracle.topn_canonical(oracle.scores(f, f[rows[0]]), rows[0], 50)[0].tolist()
+    tiny = rng.random((3, 12), dtype=np.float32)      # fewer tiles than workgroups, topn > rows
+    with Engine(tiny) as eng:
+        o = [torch.zeros(8, dtype=torch.int64, device="cuda") for _ in range(3)]
+        for i in range(3):
+            eng.enqueue_row_keys_streamed(i, 8, o[i])
+        eng.enqueue_flush()
+        torch.cuda.synchronize()
+        for i in range(3):
+            got_rows, got_sc = unpack_keys(o[i].cpu().numpy())
+            assert_topn_matches(got_rows, got_sc, oracle.scores(tiny, tiny[i]), i, 8)

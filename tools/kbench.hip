@@ -45,8 +45,8 @@ void run_cfg(const char* label, int blocks_per_cu) {
     int grid = (int)((g_n + rpb - 1) / rpb); int iters = (int)((rpb + Cfg::kTileRows - 1) / Cfg::kTileRows);
     int occ = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_kernel<Cfg, false, false>, Cfg::kBlock, 0));
     printf("-- %s: block %d x %d rows, depth %d, minwaves %d, grid %d (%d/CU asked, occupancy API %d), rows/block %lld, iters %d\n", label, Cfg::kBlock, Cfg::kRowsPerThread, Cfg::kDepth, Cfg::kMinWaves, grid, blocks_per_cu, occ, (long long)rpb, iters);
-    report("scores-only", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, true>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)-1, 1, (uint64_t*)nullptr, d_scores, (const uint64_t*)nullptr); }, g_reps));
-    report("topk", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr, (const uint64_t*)nullptr); }, g_reps));
+    report("scores-only", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, true>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)-1, 1, (uint64_t*)nullptr, d_scores, (const uint64_t*)nullptr, PrevMerge{nullptr, 0, 0, nullptr}); }, g_reps));
+    report("topk", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr, (const uint64_t*)nullptr, PrevMerge{nullptr, 0, 0, nullptr}); }, g_reps));
     float mm = T.run([&] { hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)g_topk, (int64_t)0, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)0); }, g_reps);
     report("merge", mm);
     report("  empty-ish kernel (probe, 64 vec)", T.run([&] { hipLaunchKernelGGL(stream_probe_kernel, dim3(1), dim3(kProbeBlock), 0, 0, (const float4*)d_feats, (int64_t)64, d_sink); }, g_reps));
@@ -57,14 +57,14 @@ void run_cfg(const char* label, int blocks_per_cu) {
     {
         int64_t tiles = (g_n + Cfg::kTileRows - 1) / Cfg::kTileRows;
         int ig = (int)std::min<int64_t>(256 * blocks_per_cu, tiles); int it2 = (int)((tiles + ig - 1) / ig);
-        report("topk, interleaved tiles", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false>), dim3(ig), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, (int64_t)0, it2, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr, (const uint64_t*)nullptr); }, g_reps));
+        report("topk, interleaved tiles", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false>), dim3(ig), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, (int64_t)0, it2, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr, (const uint64_t*)nullptr, PrevMerge{nullptr, 0, 0, nullptr}); }, g_reps));
         hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(kMergeBlock), 0, 0, d_lists, ig, g_topk, (int64_t)g_topk, (int64_t)0, g_topk, d_out, (int64_t*)nullptr, (float*)nullptr, (int64_t)0);
         std::vector<uint64_t> got2(g_topk); CK(hipMemcpy(got2.data(), d_out, 8 * g_topk, hipMemcpyDeviceToHost));
         printf("  interleaved result %s\n", got2 == g_ref ? "matches" : "DIFFERS");
-        report("topk contiguous (again)", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr, (const uint64_t*)nullptr); }, g_reps));
-        report("topk, interleaved tiles (again)", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false>), dim3(ig), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, (int64_t)0, it2, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr, (const uint64_t*)nullptr); }, g_reps));
+        report("topk contiguous (again)", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr, (const uint64_t*)nullptr, PrevMerge{nullptr, 0, 0, nullptr}); }, g_reps));
+        report("topk, interleaved tiles (again)", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false>), dim3(ig), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, (int64_t)0, it2, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr, (const uint64_t*)nullptr, PrevMerge{nullptr, 0, 0, nullptr}); }, g_reps));
     }
-    report("topk, preset threshold (floor)", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false, 4>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr, (const uint64_t*)nullptr); }, g_reps));
+    report("topk, preset threshold (floor)", T.run([&] { hipLaunchKernelGGL((scan_kernel<Cfg, false, false, 4>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, iters, (int64_t)0, g_qa, (int64_t)0, (int64_t)7919, g_topk, d_lists, (float*)nullptr, (const uint64_t*)nullptr, PrevMerge{nullptr, 0, 0, nullptr}); }, g_reps));
 }
 
 template <typename Cfg>
@@ -77,10 +77,10 @@ void run_multi(const char* label, int blocks_per_cu, int nq, const std::vector<f
     MultiQueryArg qa; memset(&qa, 0, sizeof qa);
     for (int q = 0; q < kMultiQueries; ++q) { qa.exclude[q] = 7919 + 1000 * q; for (int j = 0; j < 12; ++j) qa.q[q][j] = h[12 * (7919 + 1000 * q) + j]; }
     printf("-- multi %s: block %d x %d rows, minwaves %d, grid %d (%d/CU asked, occupancy API %d), queries %d\n", label, Cfg::kBlock, Cfg::kRowsPerThread, Cfg::kMinWaves, grid, blocks_per_cu, occ, nq);
-    float ms = T.run([&] { hipLaunchKernelGGL((scan_multi_kernel<Cfg>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, rpb, iters, (int64_t)0, qa, nq, 0, g_topk, d_lists, (const uint64_t*)nullptr); }, g_reps);
+    float ms = T.run([&] { hipLaunchKernelGGL((scan_multi_kernel<Cfg>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, rpb, rpb, iters, (int64_t)0, qa, nq, 0, g_topk, d_lists, (const uint64_t*)nullptr, PrevMerge{nullptr, 0, 0, nullptr}); }, g_reps);
     printf("  %-40s %8.3f us  %8.1f GB/s  %9.0f queries/s\n", "multi-query pass (no seed)", ms * 1e3, g_gb / (ms * 1e-3), nq / (ms * 1e-3));
     static uint64_t* d_seed = nullptr; if (!d_seed) CK(hipMalloc(&d_seed, 8 * 8 * 1024));
-    float ms1 = T.run([&] { hipLaunchKernelGGL((scan_multi_kernel<Cfg>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, (int64_t)Cfg::kTileRows, rpb, 1, (int64_t)0, qa, nq, 0, g_topk, d_lists, (const uint64_t*)nullptr); }, g_reps);
+    float ms1 = T.run([&] { hipLaunchKernelGGL((scan_multi_kernel<Cfg>), dim3(grid), dim3(Cfg::kBlock), 0, 0, d_feats, g_n, (int64_t)Cfg::kTileRows, rpb, 1, (int64_t)0, qa, nq, 0, g_topk, d_lists, (const uint64_t*)nullptr, PrevMerge{nullptr, 0, 0, nullptr}); }, g_reps);
     report("seed pass (first tile of every workgroup)", ms1);
     hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(kMergeBlock), 0, 0, d_lists, grid, g_topk, (int64_t)g_topk, (int64_t)grid * g_topk, g_topk, d_seed, (int64_t*)nullptr, (float*)nullptr, (int64_t)g_topk);
     CK(hipDeviceSynchronize());
