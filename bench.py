@@ -153,6 +153,8 @@ def main():
     if world > 1 or force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # RCCL's version banner goes to STDOUT at NCCL_DEBUG=VERSION/INFO; the contract is ONE JSON line there
+        os.environ["NCCL_DEBUG"] = os.environ.get("BENCH_NCCL_DEBUG", "WARN")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     n, topn = args.rows, args.topn
