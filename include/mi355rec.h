@@ -72,6 +72,8 @@ typedef struct {
     float last_merge_ms;       /* HIP-event time of the last timed merge      */
     float last_pass_ms;        /* HIP-event time of the batched path's passes (mean of pass 1 and pass 2) */
     int32_t batched_grid_blocks; /* workgroups of a batched pass (0 before the first batched call) */
+    float batched_margin;      /* error bound the fp16 pre-filter runs with: 1.0e-3 where the device keeps
+                                  fp16 subnormals (checked on first use), 1.5e-3 otherwise */
 } mi355rec_stats_t;
 
 /* Number of visible HIP devices (0 when there is none / no driver). */
@@ -192,7 +194,7 @@ int mi355rec_enqueue_batch_keys_dev(mi355rec_t* h, const float* queries_dev,
  * multi-query pass; 13 and more on shards of >= 65536 rows through the batched
  * path: two passes over the shard per chunk of up to 1024 queries, in which a
  * conservative fp16 pre-filter on the matrix cores (v_mfma_f32_32x32x16_f16 on
- * L2-normalised rows x queries, error bound 1.5e-3 derived in
+ * L2-normalised rows x queries, error bound 1.0e-3 derived in
  * csrc/batched.hip.h) selects a few hundred candidate rows per query that are
  * then scored with the exact fp32 chain — results stay bit-identical to the
  * single-query path.  Queries the bound cannot be claimed for (tiny / huge /

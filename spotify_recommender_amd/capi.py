@@ -38,6 +38,7 @@ class Stats(ctypes.Structure):
         ("last_merge_ms", c_float),
         ("last_pass_ms", c_float),
         ("batched_grid_blocks", c_int32),
+        ("batched_margin", c_float),
     ]
 
 

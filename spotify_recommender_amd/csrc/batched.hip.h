@@ -46,16 +46,20 @@
 // once and scored exactly against every query in the finalize step.
 //
 // Margin.  r^ = r / |r| and q^ = q / |q| in fp32 (relative error < 1e-6 each),
-// then x~ = fp16(x) with |x~ - x| <= 2^-11 |x| for normal results and <= 2^-14
-// absolute if a subnormal result were flushed.  The products of fp16 values are
-// exact in the MFMA's fp32 accumulator.  So
+// then x~ = fp16(x) with |x~ - x| <= 2^-11 |x| for normal results and <= 2^-25
+// absolute for subnormal ones (2^-14 if they were flushed to zero).  The products
+// of fp16 values are exact in the MFMA's fp32 accumulator.  So
 //   |sum r~_j q~_j - sum r^_j q^_j| <= (2^-10 + 2^-22) sum |r^_j q^_j|
-//                                      + 2^-14 (sum |r^_j| + sum |q^_j|)
-//                                   <= 9.77e-4 + 2 sqrt(12) 2^-14 = 1.40e-3
-// (Cauchy-Schwarz; the second term only if subnormals flush), plus < 6e-6 for the
-// normalisations, the 16-term fp32 accumulation and the reference chain's own
-// rounding.  kBqMargin = 1.5e-3.  tests/test_batched_margin.py checks the bound
-// on hostile data with a numpy model of exactly this arithmetic.
+//                                      + e_sub (sum |r^_j| + sum |q^_j|)
+// with sum |r^_j q^_j| <= |r^||q^| <= 1 + 2e-6 (Cauchy-Schwarz) and
+// sum |x_j| <= sqrt(12): 9.77e-4 + 2.1e-7 with subnormals kept, 9.77e-4 + 4.2e-4
+// if they flush; plus < 6e-6 for the normalisations, the 16-term fp32
+// accumulation and the reference chain's own rounding.  gfx950 keeps fp16
+// subnormals both in v_cvt_pk_f16_f32 and as MFMA operands (default float mode);
+// this is CHECKED on the device when the path is first used
+// (bq_selfcheck_kernel): kBqMargin = 1.0e-3 if they are kept, kBqMarginFlush =
+// 1.5e-3 otherwise.  tests/test_batched_margin.py checks both bounds on hostile
+// data with a numpy model of exactly this arithmetic.
 #pragma once
 
 #include "kernels.hip.h"
@@ -73,7 +77,8 @@ constexpr int kBqSpecialCap = 1024;          // special rows kept per chunk
 constexpr int kBqFinalBlock = 256;           // threads of the finalize workgroup
 constexpr int kBqFinalPerThread = (kBqCap + kBqSpecialCap) / kBqFinalBlock;
 constexpr int kBqPassBlock = 256;            // 4 waves, one per SIMD; 4-5 workgroups per CU
-constexpr float kBqMargin = 1.5e-3f;
+constexpr float kBqMargin = 1.0e-3f;         // fp16 subnormals kept (verified per device by bq_selfcheck_kernel)
+constexpr float kBqMarginFlush = 1.5e-3f;    // bound if they were flushed
 constexpr float kBqSlack = 4e-6f;            // fp16 hi/lo split of T' and the fused subtraction
 constexpr float kBqMinNorm2 = 1.01e-8f;      // |x| >= 1.005e-4 for rows and queries alike
 constexpr float kBqMaxNorm2 = 1e36f;
@@ -90,6 +95,25 @@ __device__ __forceinline__ uint32_t bq_pack_h2(float a, float b) {
     const float __attribute__((ext_vector_type(2))) f = {a, b};
     const bq_h2 h = __builtin_convertvector(f, bq_h2);   // v_cvt_pk_f16_f32, round to nearest even
     return __builtin_bit_cast(uint32_t, h);
+}
+
+// ---- does this device keep fp16 subnormals? ----------------------------------------
+// out[0] = MFMA(2^-20 (an fp16 subnormal) x 1.0), out[1] = fp16(3e-6) converted back:
+// both are non-zero iff neither the conversion nor the matrix core flushes.
+__global__ void bq_selfcheck_kernel(float* out) {
+    const int lane = threadIdx.x;
+    bq_h8 A = {0, 0, 0, 0, 0, 0, 0, 0}, B = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (lane < 32) {
+        A[0] = __builtin_bit_cast(_Float16, static_cast<unsigned short>(0x0010));   // 2^-20
+        B[0] = __builtin_bit_cast(_Float16, static_cast<unsigned short>(0x3c00));   // 1.0
+    }
+    const bq_f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const bq_f16v D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, zero, 0, 0, 0);
+    const uint32_t packed = bq_pack_h2(3.0e-6f * (1.0f + static_cast<float>(lane)), 0.0f);   // lane 0: 3e-6
+    if (lane == 0) {
+        out[0] = D[0];
+        out[1] = static_cast<float>(__builtin_bit_cast(bq_h2, packed)[0]);
+    }
 }
 
 // ---- queries -> B fragments -----------------------------------------------------
@@ -355,8 +379,8 @@ constexpr int kBqMaxPassGrid = 1280;          // 5 workgroups per CU on 256 CUs
 constexpr int kBqSelectKeys = kBqMaxPassGrid * kBqGroupsPerBlock / 64;   // group maxima per lane
 
 __global__ __launch_bounds__(kBqSelectBlock) void bq_select_kernel(
-    const float* __restrict__ gmax, int grid_pass1, int n_blocks, int topk, uint32_t* __restrict__ bfrag,
-    uint32_t* __restrict__ qflags, float* __restrict__ qthr) {
+    const float* __restrict__ gmax, int grid_pass1, int n_blocks, int topk, float margin,
+    uint32_t* __restrict__ bfrag, uint32_t* __restrict__ qflags, float* __restrict__ qthr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bq_smem[];
     float* s_vals = reinterpret_cast<float*>(bq_smem);                        // [2 * grid][9]
     int* s_hist = reinterpret_cast<int*>(s_vals + static_cast<size_t>(grid_pass1) * 2 * 9);  // [4][256]
@@ -404,7 +428,7 @@ __global__ __launch_bounds__(kBqSelectBlock) void bq_select_kernel(
             if (total >= need) {
                 const uint64_t kth = wave_select_threshold<kBqSelectKeys>(mine, need, true, 0, s_hist + wave * 256);
                 const float t = ordered_to_score(static_cast<uint32_t>(kth >> 32));
-                t_prime = t - 2.0f * kBqMargin - kBqSlack;
+                t_prime = t - 2.0f * margin - kBqSlack;
             }
             if (t_prime > 0.0f) {
                 thr_out = t_prime;

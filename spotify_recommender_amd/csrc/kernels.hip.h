@@ -1105,6 +1105,7 @@ __device__ __forceinline__ void multi_scan_group(
             // overflow are always re-scored exactly (see kApproxMaxNorm2)
             inv_norm[u] = nrm2 < kApproxMaxNorm2 ? __builtin_amdgcn_rsqf(nrm2) : __builtin_nanf("");
         }
+        // (unrolling this loop by 4 was measured: 156 us per 12-query pass instead of 130)
         for (int qi = 0; qi < n_queries; ++qi) {  // uniform trip count
             // three broadcast ds_read_b128; the .xy / .zw halves feed the packed FMAs directly
             const v4f qa = s_q[qi][0], qb = s_q[qi][1], qcv = s_q[qi][2];

@@ -97,6 +97,7 @@ struct mi355rec {
         int grid = 0;                 // workgroups of pass 1 (= groups / 2 of the threshold select)
         int grid2 = 0;                // workgroups of pass 2
         int occ1 = 0, occ2 = 0;
+        float margin = kBqMarginFlush; // error bound of the fp16 pre-filter (set by the device self-check)
         int step1 = 4;                // pass 1 looks at every step1-th tile (tuning knob MI355REC_BQ_STEP1)
         int qgrid = 0, qiters = 0;    // geometry of the queued exact scan
         uint32_t* bfrag = nullptr;    // [32][64][4]
@@ -584,6 +585,13 @@ int ensure_bq(mi355rec* h) {
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bq_select_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(sizeof(float) * grid * 2 * 9 + sizeof(int) * (kBqSelectBlock / 64) * 256)));
+    // the tighter bound is only claimed where fp16 subnormals are demonstrably kept
+    hipLaunchKernelGGL(bq_selfcheck_kernel, dim3(1), dim3(64), 0, h->stream, b.qnorm);
+    float chk[2] = {0.0f, 0.0f};
+    HIP_TRY(h, hipMemcpyAsync(chk, b.qnorm, sizeof chk, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const bool kept = chk[0] == 9.5367431640625e-07f && chk[1] > 2.9e-6f && chk[1] < 3.1e-6f;
+    b.margin = kept ? kBqMargin : kBqMarginFlush;
     b.ready = true;
     return MI355REC_OK;
 }
@@ -614,7 +622,7 @@ void launch_bq_passes(mi355rec* h, int topn, hipStream_t s) {
     hipLaunchKernelGGL((bq_pass_kernel<NB, false>), dim3(b.grid), dim3(kBqPassBlock), 0, s, h->d_feats, h->n, n_tiles,
                        step1, b.bfrag, b.gmax, b.cand_count, b.cand_rows, b.counters, b.special_rows);
     timing_end(h, h->ev_pass, h->n_pass_pairs, slot, s);
-    hipLaunchKernelGGL(bq_select_kernel, dim3(NB * 4), dim3(kBqSelectBlock), smem, s, b.gmax, b.grid, NB, topn, b.bfrag,
+    hipLaunchKernelGGL(bq_select_kernel, dim3(NB * 4), dim3(kBqSelectBlock), smem, s, b.gmax, b.grid, NB, topn, b.margin, b.bfrag,
                        b.qflags, b.qthr);
     slot = timing_begin(h, h->ev_pass, h->n_pass_pairs, h->pass_launches, s);
     hipLaunchKernelGGL((bq_pass_kernel<NB, true>), dim3(b.grid2), dim3(kBqPassBlock), 0, s, h->d_feats, h->n, n_tiles,
@@ -818,6 +826,7 @@ int mi355rec_stats(const mi355rec_t* hc, mi355rec_stats_t* out) {
     out->last_merge_ms = h->last_merge_ms;
     out->last_pass_ms = h->last_pass_ms;
     out->batched_grid_blocks = h->bq.ready ? h->bq.grid : 0;
+    out->batched_margin = h->bq.ready ? h->bq.margin : 0.0f;
     return MI355REC_OK;
 }
 

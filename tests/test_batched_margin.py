@@ -1,5 +1,5 @@
 """The error bound of the batched path's fp16 pre-filter (csrc/batched.hip.h,
-kBqMargin = 1.5e-3), checked on the CPU with a numpy model of exactly that
+kBqMargin = 1.0e-3 with fp16 subnormals kept, kBqMarginFlush = 1.5e-3), checked on the CPU with a numpy model of exactly that
 arithmetic against the oracle's exact scores:
 
     r^ = r * rsqrt(|r|^2), q^ = q / |q|         (fp32)
@@ -16,7 +16,7 @@ import pytest
 
 from oracle import oracle
 
-MARGIN = 1.5e-3
+MARGIN = {False: 1.0e-3, True: 1.5e-3}   # fp16 subnormals kept (gfx950, checked on the device) / flushed
 MIN_NORM2, MAX_NORM2 = 1.01e-8, 1e36
 
 
@@ -79,6 +79,6 @@ def test_prefilter_error_stays_inside_the_margin(flush):
             err = np.abs(approx - exact)[valid]
             if err.size:
                 worst = max(worst, float(err.max()))
-                assert err.max() < MARGIN, (name, flush, float(err.max()))
+                assert err.max() < MARGIN[flush], (name, flush, float(err.max()))
     # the bound is not vacuous: fp16 rounding of both operands really costs ~2^-11..2^-10
-    assert 1e-4 < worst < MARGIN, worst
+    assert 1e-4 < worst < MARGIN[flush], worst

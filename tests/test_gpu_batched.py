@@ -66,6 +66,8 @@ def test_uniform_catalogue_matches_oracle(Engine, batch, topn):
         idx, sc, counts = check_batch(eng, f, queries, excl, topn, f"uniform b{batch}", sample=sample)
         d = eng.batched_last_counters()
         assert d["queued_queries"] == 0 and d["special_rows"] == 0, d
+        # gfx950 keeps fp16 subnormals (device self-check on first use): the tight bound applies
+        assert abs(eng.stats().batched_margin - 1.0e-3) < 1e-9
         served = batch if batch <= 1024 else batch - 1024       # diagnostics cover the last chunk
         assert d["candidates_total"] >= served * min(topn, 1), d
         assert d["candidates_max"] <= 4096

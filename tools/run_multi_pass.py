@@ -30,6 +30,7 @@ def main():
     q = t[torch.from_numpy(rows).cuda()].cpu().numpy()
     keys = torch.zeros(args.queries * args.topn, dtype=torch.int64, device="cuda")
     with CosineEngine(t) as eng:
+        eng.set_batch_path(1)   # the exact multi-query passes (AUTO would send 72 queries down the batched path)
         for _ in range(args.reps):
             eng.enqueue_batch_keys(q, rows, args.topn, keys)
         for k in range(args.single):
