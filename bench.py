@@ -229,10 +229,12 @@ def main():
     for k in range(total_q, total_q + args.latency_queries):
         t1 = time.perf_counter()
         if sharded is None:
-            eng.enqueue_row_keys(q_rows[k], topn, out_keys)   # one query end to end: scan + its own merge
+            # one query end to end through the synchronous C-ABI call the C++ Recommender uses
+            # (mi355rec_query_row_topn: scan + merge, ids and scores in host memory on return)
+            res = eng.query_row_topn(q_rows[k], topn)
         else:
             step(k)
-        res = (out_keys if sharded is None else sharded.out_keys[:topn]).cpu()
+            res = sharded.out_keys[:topn].cpu()
         lat.append((time.perf_counter() - t1) * 1e3)
         host_idx = res
     lat.sort()
