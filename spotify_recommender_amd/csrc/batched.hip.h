@@ -152,15 +152,24 @@ __global__ __launch_bounds__(256) void bq_prepare_kernel(
 }
 
 // ---- the two passes ---------------------------------------------------------------
-// One wave = one 32-row tile at a time against all NB query blocks.  Lane l
-// (r = l & 31, h = l >> 5) loads floats [0,8) (h = 0) or [8,12) (h = 1) of row
-// tile*32 + r: exactly its share of the A operand, A[row r][k = 8h + j].  Tiles are
-// dealt round-robin over all waves of the grid, so the chip reads one moving window
-// of the matrix.  The B fragments (NB KiB) live in LDS and are read one
-// ds_read_b128 per MFMA, one block ahead: in registers they would cost 128 VGPRs and
-// leave two waves per SIMD, too few to cover the MFMA -> VALU latency of the
-// reduction (measured: 454 / 584 us per pass at 12.5 M rows x 1024 queries with B
-// in registers; tools/mfma_probe.hip has the issue-rate model).
+// One wave = 64 rows at a time (two 32-row MFMA tiles) against all NB query blocks.
+// Lane l loads ROW tile*64 + l whole (3 x dwordx4, every fetched line fully used), sums its
+// squares and normalises it in-lane, and packs it to six fp16 pairs p0..p5.  The A
+// operand wants lane l (r = l & 31, h = l >> 5) to hold A[row r][k = 8h + j]: k 0..7 of
+// row r in the lower half-wave, k 8..15 in the upper.  One v_permlane32_swap per
+// register builds BOTH tiles' operands at once: swap(p0, p4) leaves
+//   x' = [p0 of rows 0..31  | p4 of rows 0..31 ]  = register 0 of tile 0's operand
+//   y' = [p0 of rows 32..63 | p4 of rows 32..63]  = register 0 of tile 1's operand
+// likewise swap(p1, p5); swap(p2, ONE) and swap(p3, ZERO) put the constant threshold
+// multiplier (k = 12, 13 -> 1.0) and the zero padding into the upper halves.  Four swaps,
+// no selects, and the per-row work (norm, 12 multiplies, 6 conversions) is done once per
+// row instead of once per half-row as in the first version of this kernel.
+// Tiles are dealt round-robin over all waves of the grid, so the chip reads one moving
+// window of the matrix.  The B fragments (NB KiB) live in LDS: one ds_read_b128 feeds TWO
+// MFMAs; in registers they would cost 128 VGPRs and leave two waves per SIMD, too few to
+// cover the MFMA -> VALU latency of the reduction (measured: 454 / 584 us per pass at
+// 12.5 M rows x 1024 queries with B in registers; tools/mfma_probe.hip has the
+// issue-rate model).
 // C/D layout (cdna_hip_programming.md §3): lane holds column c = l & 31 (the query)
 // and rows (i & 3) + 8 (i >> 2) + 4 h for register i = 0..15.
 // Per MFMA (1024 outputs) the VALU does 8 three-operand integer maxima; with the
@@ -185,18 +194,18 @@ struct BqPassCfg {
     static constexpr int kMinBlocksPerCu = 4;   // waves per SIMD the register budget must allow
 };
 
-// kVariant (development A/B only, tools/bqbench.hip; 0 in the product): 1 = one VALU
-// operation per MFMA instead of the 8-operation reduction, 2 = no ds_read in the block
-// loop (every MFMA uses block 0's fragment), 3 = both, 4 = synthetic rows (no HBM reads).
+// kVariant (development A/B only, tools/bqbench.hip; 0 in the product): 4 = synthetic rows
+// (no HBM reads).
 template <int NB, bool kCollect, int kVariant = 0>
 __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu) void bq_pass_kernel(
     const float* __restrict__ feats, int64_t n, int64_t n_tiles, int tile_step, const uint32_t* __restrict__ bfrag,
     float* __restrict__ gmax /* [grid][NB][64] */, int* __restrict__ cand_count,
     uint32_t* __restrict__ cand_rows /* [query][kBqCap] */, int* __restrict__ counters,
     uint32_t* __restrict__ special_rows) {
-    // tile_step = 1: every 32-row tile.  tile_step = 2 (pass 1 only): every other tile —
-    // a threshold derived from ANY subset of the rows is a valid lower bound; from half of
-    // them it lets about twice as many candidates through and costs half a pass.
+    // n_tiles counts 64-row tiles.  tile_step = 1: every tile.  tile_step > 1 (pass 1 only):
+    // every tile_step-th tile — a threshold derived from ANY subset of the rows is a valid
+    // lower bound; from a quarter of them it lets about four times as many candidates
+    // through and costs a quarter of a pass.
     __shared__ uint4 s_b[NB][64];   // reused for the group maxima at the end of pass 1
     __shared__ uint2 s_stage[kCollect ? kBqPassBlock / 64 : 1][kCollect ? kBqStage : 1];   // (query, row) per wave
     uint2* const stage = s_stage[kCollect ? (threadIdx.x >> 6) : 0];
@@ -221,117 +230,128 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
     const float4* base = reinterpret_cast<const float4*>(feats);
 
     // rows past the end re-read the last row (cached) so the prefetch is unconditional
-    auto load_a = [&](int64_t tile) {
-        int64_t row = tile * 32 + r;
+    auto load_row3 = [&](int64_t tile, float4& a, float4& b, float4& c) {
+        int64_t row = tile * 64 + lane;
         row = row < n ? row : last_row;
-        return base[row * 3 + 2 * h];          // floats [0,4) or [8,12)
-    };
-    auto load_b = [&](int64_t tile) {
-        int64_t row = tile * 32 + r;
-        row = row < n ? row : last_row;
-        return base[row * 3 + 1];              // floats [4,8): used by the lower half only
+        const float4* p = base + row * 3;
+        a = p[0];
+        b = p[1];
+        c = p[2];
     };
 
-    float4 na = load_a(first), nb = load_b(first);
+    float4 na, nb, nc;
+    load_row3(first, na, nb, nc);
     for (int64_t tile = first; tile < n_tiles; tile += total_waves) {
-        float4 a = na, b = nb;
+        float4 a = na, b = nb, c = nc;
         if constexpr ((kVariant & 4) != 0) {   // A/B probe: no HBM traffic, synthetic rows
             const float t = static_cast<float>(tile & 1023) * 1e-3f + lane * 0.01f;
             a = make_float4(t, 0.3f, 0.5f, t * 0.5f);
             b = make_float4(0.1f, t, 0.7f, 0.2f);
+            c = make_float4(0.4f, 0.6f, t, 0.9f);
         } else {
-            na = load_a(tile + total_waves);
-            nb = load_b(tile + total_waves);
+            load_row3(tile + total_waves, na, nb, nc);
         }
 
-        const int64_t row = tile * 32 + r;
-        float ss = a.x * a.x;
-        ss = __builtin_fmaf(a.y, a.y, ss);
-        ss = __builtin_fmaf(a.z, a.z, ss);
-        ss = __builtin_fmaf(a.w, a.w, ss);
-        float sb = b.x * b.x;
-        sb = __builtin_fmaf(b.y, b.y, sb);
-        sb = __builtin_fmaf(b.z, b.z, sb);
-        sb = __builtin_fmaf(b.w, b.w, sb);
-        ss = h == 0 ? ss + sb : ss;
-        // lower-half sum + upper-half sum, in that order in both halves
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
-        const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        const int64_t row = tile * 64 + lane;
+        float tot = a.x * a.x;
+        tot = __builtin_fmaf(a.y, a.y, tot);
+        tot = __builtin_fmaf(a.z, a.z, tot);
+        tot = __builtin_fmaf(a.w, a.w, tot);
+        tot = __builtin_fmaf(b.x, b.x, tot);
+        tot = __builtin_fmaf(b.y, b.y, tot);
+        tot = __builtin_fmaf(b.z, b.z, tot);
+        tot = __builtin_fmaf(b.w, b.w, tot);
+        tot = __builtin_fmaf(c.x, c.x, tot);
+        tot = __builtin_fmaf(c.y, c.y, tot);
+        tot = __builtin_fmaf(c.z, c.z, tot);
+        tot = __builtin_fmaf(c.w, c.w, tot);
         const bool in_range = row < n;
         const bool valid = in_range && tot >= kBqMinNorm2 && tot <= kBqMaxNorm2;
         const float inv = valid ? __builtin_amdgcn_rsqf(tot) : 0.0f;
         if constexpr (kCollect) {
             // neither valid nor exactly zero: scored exactly against every query later
             const bool special = in_range && !valid && !(tot == 0.0f);
-            if (special && h == 0) {
+            if (special) {
                 const int pos = atomicAdd(&counters[0], 1);
                 if (pos < kBqSpecialCap) special_rows[pos] = static_cast<uint32_t>(row);
             }
         }
-        // zero (not NaN) for rows the bound is not claimed for: 0 * inf would poison D
-        const float e0 = valid ? a.x * inv : 0.0f, e1 = valid ? a.y * inv : 0.0f;
-        const float e2 = valid ? a.z * inv : 0.0f, e3 = valid ? a.w * inv : 0.0f;
-        const float e4 = valid ? b.x * inv : 0.0f, e5 = valid ? b.y * inv : 0.0f;
-        const float e6 = valid ? b.z * inv : 0.0f, e7 = valid ? b.w * inv : 0.0f;
-        uint4 aw;
-        aw.x = bq_pack_h2(e0, e1);
-        aw.y = bq_pack_h2(e2, e3);
-        // upper half: k = 12, 13 multiply the threshold slots of B by 1.0 (ALL rows, so a
-        // masked row yields D = -T' < 0), k = 14, 15 are zero
-        aw.z = h == 0 ? bq_pack_h2(e4, e5) : 0x3c003c00u;
-        aw.w = h == 0 ? bq_pack_h2(e6, e7) : 0u;
-        const bq_h8 A = __builtin_bit_cast(bq_h8, aw);
+        // zero (not NaN) for rows the bound is not claimed for: inf * 0 would poison D
+        uint32_t p0 = bq_pack_h2(a.x * inv, a.y * inv), p1 = bq_pack_h2(a.z * inv, a.w * inv);
+        uint32_t p2 = bq_pack_h2(b.x * inv, b.y * inv), p3 = bq_pack_h2(b.z * inv, b.w * inv);
+        uint32_t p4 = bq_pack_h2(c.x * inv, c.y * inv), p5 = bq_pack_h2(c.z * inv, c.w * inv);
+        p0 = valid ? p0 : 0u; p1 = valid ? p1 : 0u; p2 = valid ? p2 : 0u;
+        p3 = valid ? p3 : 0u; p4 = valid ? p4 : 0u; p5 = valid ? p5 : 0u;
+        // k = 12, 13 multiply the threshold slots of B by 1.0 for ALL rows (a masked row
+        // yields D = -T' < 0); k = 14, 15 are zero
+        const auto s0 = __builtin_amdgcn_permlane32_swap(p0, p4, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(p1, p5, false, false);
+        const auto s2 = __builtin_amdgcn_permlane32_swap(p2, 0x3c003c00u, false, false);
+        const auto s3 = __builtin_amdgcn_permlane32_swap(p3, 0u, false, false);
+        uint4 aw0, aw1;
+        aw0.x = s0[0]; aw0.y = s1[0]; aw0.z = s2[0]; aw0.w = s3[0];   // rows tile*64 +  0..31
+        aw1.x = s0[1]; aw1.y = s1[1]; aw1.z = s2[1]; aw1.w = s3[1];   // rows tile*64 + 32..63
+        const bq_h8 A[2] = {__builtin_bit_cast(bq_h8, aw0), __builtin_bit_cast(bq_h8, aw1)};
 
         const bq_f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f,
                               0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        // Two accumulator tiles: the MFMA of block blk + 1 is issued before block blk's
-        // 16 results are reduced, so the matrix pipe does not wait for the VALU tree.
-        // The reductions run on the BIT PATTERNS as signed integers (v_max3_i32): for
-        // the values that matter (>= 0) integer order is float order, negative floats
-        // are negative integers, and there is no NaN canonicalisation to pay for.
-        bq_f16v D[2];
-        uint4 bw[2];
+        // Two accumulator tiles alternate: MFMA number m + 1 (sub-tile (m+1) & 1 of block
+        // (m+1) >> 1) is issued before the 16 results of MFMA m are reduced, so the matrix
+        // pipe does not wait for the VALU tree.  The reductions run on the BIT PATTERNS as
+        // signed integers (v_max3_i32): for the values that matter (>= 0) integer order is
+        // float order, negative floats are negative integers, and there is no NaN
+        // canonicalisation to pay for.
         // the fragments are loop-invariant: without this the compiler hoists all NB
         // ds_reads out of the tile loop, back into 4 * NB registers (and spills them)
         asm volatile("" ::: "memory");
-        bw[0] = s_b[0][lane];
-        if (NB > 1) bw[1] = s_b[1][lane];
-        D[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, __builtin_bit_cast(bq_h8, bw[0]), zero, 0, 0, 0);
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) {
-            if (blk + 1 < NB) {
-                D[(blk + 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                    A, __builtin_bit_cast(bq_h8, bw[(kVariant & 2) ? 0 : ((blk + 1) & 1)]), zero, 0, 0, 0);
-                if (blk + 2 < NB && (kVariant & 2) == 0) bw[blk & 1] = s_b[blk + 2][lane];
-            }
-            const bq_f16v& d = D[blk & 1];
+        auto max3 = [](int x, int y, int z) { return max(max(x, y), z); };
+        // depth-3 tree over the 16 results of one MFMA: 7 operations -> (u0, u1)
+        auto tree = [&](const bq_f16v& d, int& u0, int& u1) {
             auto bits = [&](int i) { return static_cast<int>(__float_as_uint(d[i])); };
-            auto max3 = [](int x, int y, int z) { return max(max(x, y), z); };
-            if constexpr ((kVariant & 1) != 0 && !kCollect) {
-                mx[blk] = max(mx[blk], bits(0));
-                continue;
-            }
-            // depth-3 tree over the 16 results (8 operations, the last one folds the running maximum in)
             const int t0 = max3(bits(0), bits(1), bits(2));
             const int t1 = max3(bits(3), bits(4), bits(5));
             const int t2 = max3(bits(6), bits(7), bits(8));
             const int t3 = max3(bits(9), bits(10), bits(11));
             const int t4 = max3(bits(12), bits(13), bits(14));
-            const int u0 = max3(t0, t1, t2);
-            const int u1 = max3(t3, t4, bits(15));
-            if constexpr (!kCollect) {
-                mx[blk] = max3(mx[blk], u0, u1);
-            } else {
-                const int m = max(u0, u1);
-                if (__builtin_expect(__ballot(m >= 0) != 0ull, 0)) {   // some D >= +0: approx >= T'
-                    // Hits go to the wave's LDS staging buffer (ballot + prefix count, no atomics);
-                    // the global per-query counters are only touched when the buffer is flushed,
-                    // 64 entries per round trip.  A returning global atomic per hit kept each wave
-                    // waiting ~1.5 us about 160 times per pass (measured: 555 vs 485 us).
+            u0 = max3(t0, t1, t2);
+            u1 = max3(t3, t4, bits(15));
+        };
+        if constexpr (!kCollect) {
+            // pass 1: fully unrolled (the running maxima are a register array indexed by block)
+            bq_f16v D[2];
+            uint4 bw[2];
+            bw[0] = s_b[0][lane];
+            if (NB > 1) bw[1] = s_b[1][lane];
+            D[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw[0]), zero, 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 2 * NB; ++m) {
+                const int blk = m >> 1, sub = m & 1;
+                if (m + 1 < 2 * NB)
+                    D[(m + 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                        A[(m + 1) & 1], __builtin_bit_cast(bq_h8, bw[((m + 1) >> 1) & 1]), zero, 0, 0, 0);
+                // block blk's fragment register is free once its second MFMA has been issued
+                if (sub == 1 && blk + 2 < NB) bw[blk & 1] = s_b[blk + 2][lane];
+                int u0, u1;
+                tree(D[m & 1], u0, u1);
+                mx[blk] = max3(mx[blk], u0, u1);   // the 8th operation folds the running maximum in
+            }
+        } else {
+            // pass 2: the same pipeline as a ROLLED loop over pairs of blocks (4 MFMAs per
+            // iteration) — unrolled 2 * NB times, the rare hit path below would be
+            // instantiated 64 times and spill the hot loop.
+            // Hits go to the wave's LDS staging buffer (ballot + prefix count, no atomics); the
+            // global per-query counters are only touched when the buffer is flushed, 64 entries
+            // per round trip.  A returning global atomic per hit kept each wave waiting ~1.5 us
+            // about 160 times per pass (measured: 555 vs 485 us).
+            auto check = [&](const bq_f16v& d, int blk, int sub) {
+                int u0, u1;
+                tree(d, u0, u1);
+                const int mm = max(u0, u1);
+                if (__builtin_expect(__ballot(mm >= 0) != 0ull, 0)) {   // some D >= +0: approx >= T'
                     const uint32_t q = static_cast<uint32_t>(blk * 32 + r);
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        const bool hit = bits(i) >= 0;
+                        const bool hit = static_cast<int>(__float_as_uint(d[i])) >= 0;
                         const uint64_t who = __ballot(hit);
                         if (who) {   // wave-uniform
                             const int n_hit = __popcll(who);
@@ -341,12 +361,38 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
                             }
                             if (hit) {
                                 const int slot = staged + lanes_below(who);
-                                stage[slot] = make_uint2(q, static_cast<uint32_t>(tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h));
+                                // opaque on purpose: otherwise the compiler hoists all 32 row ids of a tile
+                                // out of this rare path into the tile prologue and spills them
+                                uint32_t row_lo = static_cast<uint32_t>(tile * 64) + static_cast<uint32_t>(sub * 32 + 4 * h);
+                                asm volatile("" : "+v"(row_lo));
+                                stage[slot] = make_uint2(q, row_lo + static_cast<uint32_t>((i & 3) + 8 * (i >> 2)));
                             }
                             staged += n_hit;
                         }
                     }
                 }
+            };
+            static_assert(NB % 2 == 0, "blocks are processed in pairs");
+            const uint4* sb = &s_b[0][0] + lane;
+            uint4 bw0 = sb[0], bw1 = sb[64];
+            bq_f16v D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);
+            bq_f16v D1;
+#pragma unroll 1
+            for (int bp = 0; bp < NB; bp += 2) {
+                // straight-line body: the fragment loads past the last block are clamped (they
+                // re-read the last fragment) and the MFMA issued for block NB is simply unused
+                const int nb0 = bp + 2 < NB ? bp + 2 : NB - 1;
+                const int nb1 = bp + 3 < NB ? bp + 3 : NB - 1;
+                D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);   // (bp, 1)
+                check(D0, bp, 0);
+                D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw1), zero, 0, 0, 0);   // (bp+1, 0)
+                bw0 = sb[nb0 * 64];
+                check(D1, bp, 1);
+                D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], __builtin_bit_cast(bq_h8, bw1), zero, 0, 0, 0);   // (bp+1, 1)
+                check(D0, bp + 1, 0);
+                D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);   // (bp+2, 0)
+                bw1 = sb[nb1 * 64];
+                check(D1, bp + 1, 1);
             }
         }
     }

@@ -618,8 +618,8 @@ void free_bq(mi355rec* h) {
 template <int NB>
 void launch_bq_passes(mi355rec* h, int topn, hipStream_t s) {
     auto& b = h->bq;
-    const int64_t n_tiles = (h->n + 31) / 32;
-    // pass 1 looks at every other tile once each wave still gets a few dozen of them
+    const int64_t n_tiles = (h->n + 63) / 64;   // a wave handles 64 rows (two 32-row MFMA tiles) at a time
+    // pass 1 looks at every step1-th tile once each wave still gets a couple of dozen of them
     int step1 = n_tiles >= static_cast<int64_t>(b.grid) * (kBqPassBlock / 64) * 16 ? b.step1 : 1;
     while (step1 > 1 && n_tiles < static_cast<int64_t>(b.grid) * (kBqPassBlock / 64) * 8 * step1) step1 /= 2;
     const size_t smem = sizeof(float) * b.grid * 2 * 9 + sizeof(int) * (kBqSelectBlock / 64) * 256;

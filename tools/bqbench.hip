@@ -51,8 +51,8 @@ int main(int argc, char** argv) {
     fill_kernel<<<64, 256>>>(queries, 1024 * 12, 7u);
     bq_prepare_kernel<<<4, 256>>>(queries, 1024, NB, bfrag, qnorm, qflags, cand_count, counters);
     CK(hipDeviceSynchronize());
-    const int64_t tiles = (n + 31) / 32;
-    const double mfmas_per_simd = double(tiles) * NB / 1024.0;
+    const int64_t tiles = (n + 63) / 64;
+    const double mfmas_per_simd = double(tiles) * 2 * NB / 1024.0;
     auto report = [&](const char* name, float ms) {
         printf("  %-52s %8.1f us   %6.2f ns per MFMA per SIMD\n", name, ms * 1e3, ms * 1e6 / mfmas_per_simd); fflush(stdout);
     };
