@@ -199,7 +199,7 @@ struct BqPassCfg {
 template <int NB, bool kCollect, int kVariant = 0>
 __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu) void bq_pass_kernel(
     const float* __restrict__ feats, int64_t n, int64_t n_tiles, int tile_step, const uint32_t* __restrict__ bfrag,
-    float* __restrict__ gmax /* [grid][NB][64] */, int* __restrict__ cand_count,
+    float* __restrict__ gmax /* [NB][8][2 * grid][4] */, int* __restrict__ cand_count,
     uint32_t* __restrict__ cand_rows /* [query][kBqCap] */, int* __restrict__ counters,
     uint32_t* __restrict__ special_rows) {
     // n_tiles counts 64-row tiles.  tile_step = 1: every tile.  tile_step > 1 (pass 1 only):
@@ -406,21 +406,29 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
 #pragma unroll
         for (int b = 0; b < NB; ++b) s_mx[(wave * NB + b) * 64 + lane] = __uint_as_float(static_cast<uint32_t>(mx[b]));
         __syncthreads();
+        // gmax layout [block][eighth of 4 queries][group][4]: the threshold select of one
+        // (block, eighth) then reads ONE contiguous run of groups x 16 bytes.
+        // group = half * gridDim.x + workgroup
         for (int i = threadIdx.x; i < NB * 64; i += kBqPassBlock) {
             float m = s_mx[i];
 #pragma unroll
             for (int w = 1; w < kBqPassBlock / 64; ++w) m = __builtin_fmaxf(m, s_mx[w * NB * 64 + i]);
-            gmax[static_cast<int64_t>(blockIdx.x) * NB * 64 + i] = m;
+            const int b = i >> 6, l = i & 63;
+            const int half = l >> 5, c = l & 31;
+            const int64_t group = static_cast<int64_t>(half) * gridDim.x + blockIdx.x;
+            const int64_t groups = 2ll * gridDim.x;
+            gmax[((static_cast<int64_t>(b) * 8 + (c >> 2)) * groups + group) * 4 + (c & 3)] = m;
         }
     }
 }
 
 // ---- per-query threshold ----------------------------------------------------------
-// One workgroup of 256 threads per (query block, quarter): the group maxima of its 8
-// queries ([grid][2 halves] values each) are staged in LDS, then wave w selects the
-// (topk+1)-th largest value for queries 2w and 2w + 1 of the quarter.
+// One workgroup of 256 threads per (query block, eighth): the group maxima of its 4
+// queries ([2 halves][grid] values each) are staged in LDS, then wave w selects the
+// (topk+1)-th largest value for query w of the eighth (256 workgroups per 1024 queries:
+// one round on a 256-CU part).
 constexpr int kBqSelectBlock = 256;
-constexpr int kBqSelectQueries = 8;           // queries per workgroup
+constexpr int kBqSelectQueries = 4;           // queries per workgroup
 constexpr int kBqMaxPassGrid = 1280;          // 5 workgroups per CU on 256 CUs
 constexpr int kBqSelectKeys = kBqMaxPassGrid * kBqGroupsPerBlock / 64;   // group maxima per lane
 
@@ -428,24 +436,21 @@ __global__ __launch_bounds__(kBqSelectBlock) void bq_select_kernel(
     const float* __restrict__ gmax, int grid_pass1, int n_blocks, int topk, float margin,
     uint32_t* __restrict__ bfrag, uint32_t* __restrict__ qflags, float* __restrict__ qthr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bq_smem[];
-    float* s_vals = reinterpret_cast<float*>(bq_smem);                        // [2 * grid][9]
-    int* s_hist = reinterpret_cast<int*>(s_vals + static_cast<size_t>(grid_pass1) * 2 * 9);  // [4][256]
+    float* s_vals = reinterpret_cast<float*>(bq_smem);                        // [2 * grid][5]
+    int* s_hist = reinterpret_cast<int*>(s_vals + static_cast<size_t>(grid_pass1) * 2 * 5);  // [4][256]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int blk = blockIdx.x >> 2;
-    const int quarter = blockIdx.x & 3;
+    const int blk = blockIdx.x >> 3;
+    const int part = blockIdx.x & 7;
     const int groups = grid_pass1 * kBqGroupsPerBlock;
-    // group gi = half * grid + workgroup; 8 consecutive floats (32 B) per group
-    for (int i = tid; i < groups * kBqSelectQueries; i += kBqSelectBlock) {
-        const int gi = i >> 3, j = i & 7;
-        const int half = gi >= grid_pass1 ? 1 : 0;
-        const int g = gi - half * grid_pass1;
-        s_vals[gi * 9 + j] = gmax[(static_cast<int64_t>(g) * n_blocks + blk) * 64 + half * 32 + quarter * 8 + j];
-    }
+    // group gi = half * grid + workgroup; this (block, quarter)'s values are one contiguous
+    // run of groups x 8 floats (pass 1 wrote them that way)
+    const float* mine_vals = gmax + (static_cast<int64_t>(blk) * 8 + part) * groups * kBqSelectQueries;
+    for (int i = tid; i < groups * kBqSelectQueries; i += kBqSelectBlock) s_vals[(i >> 2) * 5 + (i & 3)] = mine_vals[i];
     __syncthreads();
     for (int j = wave; j < kBqSelectQueries; j += kBqSelectBlock / 64) {
-        const int c = quarter * 8 + j;
+        const int c = part * kBqSelectQueries + j;
         const int q = blk * 32 + c;
         uint32_t flag = qflags[q];
         float thr_out = 0.0f;
@@ -455,10 +460,10 @@ __global__ __launch_bounds__(kBqSelectBlock) void bq_select_kernel(
             int positive = 0;
 #pragma unroll
             for (int u = 0; u < kBqSelectKeys; ++u) {
-                const int gi = lane + u * 64;   // consecutive lanes: stride 9 words, conflict-free
+                const int gi = lane + u * 64;   // consecutive lanes: stride 5 words, conflict-free
                 uint64_t key = 0ull;
                 if (gi < groups) {
-                    const float v = s_vals[gi * 9 + j];
+                    const float v = s_vals[gi * 5 + j];
                     if (v > 0.0f) {
                         key = (static_cast<uint64_t>(score_to_ordered(v)) << 32) | static_cast<uint32_t>(gi + 1);
                         ++positive;

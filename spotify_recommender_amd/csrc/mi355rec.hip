@@ -589,7 +589,7 @@ int ensure_bq(mi355rec* h) {
     }
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(bq_select_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   static_cast<int>(sizeof(float) * grid * 2 * 9 + sizeof(int) * (kBqSelectBlock / 64) * 256)));
+                                   static_cast<int>(sizeof(float) * grid * 2 * 5 + sizeof(int) * (kBqSelectBlock / 64) * 256)));
     // the tighter bound is only claimed where fp16 subnormals are demonstrably kept
     hipLaunchKernelGGL(bq_selfcheck_kernel, dim3(1), dim3(64), 0, h->stream, b.qnorm);
     float chk[2] = {0.0f, 0.0f};
@@ -622,12 +622,12 @@ void launch_bq_passes(mi355rec* h, int topn, hipStream_t s) {
     // pass 1 looks at every step1-th tile once each wave still gets a couple of dozen of them
     int step1 = n_tiles >= static_cast<int64_t>(b.grid) * (kBqPassBlock / 64) * 16 ? b.step1 : 1;
     while (step1 > 1 && n_tiles < static_cast<int64_t>(b.grid) * (kBqPassBlock / 64) * 8 * step1) step1 /= 2;
-    const size_t smem = sizeof(float) * b.grid * 2 * 9 + sizeof(int) * (kBqSelectBlock / 64) * 256;
+    const size_t smem = sizeof(float) * b.grid * 2 * 5 + sizeof(int) * (kBqSelectBlock / 64) * 256;
     int slot = timing_begin(h, h->ev_pass, h->n_pass_pairs, h->pass_launches, s);
     hipLaunchKernelGGL((bq_pass_kernel<NB, false>), dim3(b.grid), dim3(kBqPassBlock), 0, s, h->d_feats, h->n, n_tiles,
                        step1, b.bfrag, b.gmax, b.cand_count, b.cand_rows, b.counters, b.special_rows);
     timing_end(h, h->ev_pass, h->n_pass_pairs, slot, s);
-    hipLaunchKernelGGL(bq_select_kernel, dim3(NB * 4), dim3(kBqSelectBlock), smem, s, b.gmax, b.grid, NB, topn, b.margin, b.bfrag,
+    hipLaunchKernelGGL(bq_select_kernel, dim3(NB * 8), dim3(kBqSelectBlock), smem, s, b.gmax, b.grid, NB, topn, b.margin, b.bfrag,
                        b.qflags, b.qthr);
     slot = timing_begin(h, h->ev_pass, h->n_pass_pairs, h->pass_launches, s);
     hipLaunchKernelGGL((bq_pass_kernel<NB, true>), dim3(b.grid2), dim3(kBqPassBlock), 0, s, h->d_feats, h->n, n_tiles,
