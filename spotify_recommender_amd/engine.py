@@ -431,6 +431,58 @@ class ShardedEngine:
         self.local.enqueue_merge_keys(gathered, self.world, k, k, self.out_keys[:k],
                                       self.out_idx[:k], self.out_score[:k])
 
+    # -- windowed single queries: one all-gather per `window` queries ---------------
+    def enqueue_query_windowed(self, query, exclude_global: int, topn: int, window: int = 16) -> None:
+        """A stream of single queries on a sharded catalogue: every query is still one
+        full pass over every shard, but the exchange is amortised — the local merge of
+        query k rides in the scan launch of query k + 1 (streamed C-ABI calls) and the
+        per-rank key lists of `window` queries cross xGMI in ONE all-gather followed by ONE
+        batched merge launch.  Results appear in `self.window_keys / window_idx /
+        window_score` ([window, topn]) when a window closes (`flush_window`)."""
+        torch = self._torch
+        k, w = int(topn), int(window)
+        if k > self.max_topn:
+            raise ValueError(f"topn {topn} > max_topn {self.max_topn}")
+        if getattr(self, "_w_shape", None) != (w, k):
+            if getattr(self, "_w_count", 0):
+                self.flush_window()
+            dev = self.device
+            self._w_local = torch.zeros(w * k, dtype=torch.int64, device=dev)
+            self._w_gather = torch.zeros(self.world * w * k, dtype=torch.int64, device=dev)
+            self._w_keys = torch.zeros(w * k, dtype=torch.int64, device=dev)
+            self._w_idx = torch.full((w * k,), -1, dtype=torch.int64, device=dev)
+            self._w_score = torch.zeros(w * k, dtype=torch.float32, device=dev)
+            self._w_shape = (w, k)
+            self._w_count = 0
+        slot = self._w_count
+        self.local.enqueue_query_keys_streamed(query, exclude_global, k, self._w_local[slot * k:(slot + 1) * k])
+        self._w_count += 1
+        if self._w_count == w:
+            self.flush_window()
+
+    def flush_window(self) -> int:
+        """Closes the current window (possibly partial): flush the last local merge, ONE
+        all-gather, ONE batched merge.  Returns the number of queries in the window."""
+        cnt = getattr(self, "_w_count", 0)
+        if cnt == 0:
+            return 0
+        w, k = self._w_shape
+        need = cnt * k
+        self.local.enqueue_flush()
+        local = self._w_local[:need]
+        if self.world == 1 and not self.always_gather:
+            gathered = local
+        else:
+            gathered = self._w_gather[: self.world * need]
+            self._all_gather(gathered, local)
+        self.local.enqueue_merge_keys_batch(gathered, self.world, k, need, k, cnt, k, self._w_keys[:need],
+                                            self._w_idx[:need], self._w_score[:need])
+        self.window_keys = self._w_keys[:need].view(cnt, k)
+        self.window_idx = self._w_idx[:need].view(cnt, k)
+        self.window_score = self._w_score[:need].view(cnt, k)
+        self._w_count = 0
+        return cnt
+
     def enqueue_batch(self, queries, exclude_global, topn: int):
         """`batch` queries: local multi-query passes, ONE all-gather of batch*topn
         keys per rank, one merge launch (a workgroup per query).  Results in

@@ -43,6 +43,13 @@ class OracleShard:
         out[: len(keys)] = keys
         out_keys.copy_(torch.from_numpy(out.view(np.int64)))
 
+    # the streamed calls only differ in WHEN the device merge runs: same results
+    def enqueue_query_keys_streamed(self, query, exclude_global, topn, out_keys, stream=None):
+        self.enqueue_query_keys(query, exclude_global, topn, out_keys)
+
+    def enqueue_flush(self, stream=None):
+        pass
+
     def enqueue_batch_keys(self, queries, exclude_global, topn, out_keys, stream=None):
         q = np.asarray(queries, np.float32).reshape(-1, 12)
         for b in range(q.shape[0]):
@@ -104,6 +111,20 @@ def _worker(rank, world, port, n_rows, result_dir):
             ci, _ = oracle.topn_canonical(want, q, 10)
             assert eng.batch_idx[b].numpy().tolist() == ci.tolist(), (rank, q)
             out[f"batch_{q}"] = eng.batch_idx[b].numpy()
+        # windowed single queries: one all-gather per window of 4, a partial last window
+        qrows = [3, n_rows // 2, n_rows - 1, 17, 4242, 99]
+        got = []
+        for q in qrows:
+            eng.enqueue_query_windowed(f[q], q, 10, window=4)
+            if eng._w_count == 0:
+                got.extend(eng.window_idx.numpy().copy())
+        assert eng.flush_window() == 2
+        got.extend(eng.window_idx.numpy().copy())
+        assert eng.flush_window() == 0
+        for q, idx in zip(qrows, got):
+            ci, _ = oracle.topn_canonical(oracle.scores(f, f[q]), q, 10)
+            assert idx.tolist() == ci.tolist(), (rank, q)
+            out[f"window_{q}"] = idx
         np.savez(Path(result_dir) / f"rank{rank}.npz", **out)
     finally:
         dist.destroy_process_group()
