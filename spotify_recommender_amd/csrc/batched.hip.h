@@ -72,7 +72,7 @@ typedef float bq_f16v __attribute__((ext_vector_type(16)));
 
 constexpr int kBqMaxBlocks = 32;             // 32 queries per block -> 1024 queries per chunk
 constexpr int kBqMaxQueries = kBqMaxBlocks * 32;
-constexpr int kBqCap = 4096;                 // candidate rows kept per query
+constexpr int kBqCap = 2048;                 // candidate rows kept per query
 constexpr int kBqSpecialCap = 1024;          // special rows kept per chunk
 constexpr int kBqFinalBlock = 256;           // threads of the finalize workgroup
 constexpr int kBqFinalPerThread = (kBqCap + kBqSpecialCap) / kBqFinalBlock;

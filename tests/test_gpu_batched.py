@@ -70,7 +70,7 @@ def test_uniform_catalogue_matches_oracle(Engine, batch, topn):
         assert abs(eng.stats().batched_margin - 1.0e-3) < 1e-9
         served = batch if batch <= 1024 else batch - 1024       # diagnostics cover the last chunk
         assert d["candidates_total"] >= served * min(topn, 1), d
-        assert d["candidates_max"] <= 4096
+        assert d["candidates_max"] <= 2048
         # every list equals the single-query path, bit for bit
         for b in range(0, batch, 7):
             si, ss = eng.query_topn(queries[b], int(excl[b]), topn)
