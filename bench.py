@@ -412,7 +412,11 @@ def main():
             "p50_ms": round(lat[len(lat) // 2], 4) if lat else None,
             "p99_ms": round(lat[min(len(lat) - 1, int(len(lat) * 0.99))], 4) if lat else None,
             "roofline": {
-                "bound": "hbm", "kernel": "mi355::scan_kernel<true,false>" if world == 1 else "mi355::scan_kernel<false,false>",
+                "bound": "hbm",
+                "kernel": ("mi355::scan_kernel<ScanCfg<512,1,6,2>, true, false, 0, true> (query = catalogue row; the previous "
+                           "query's merge rides in its last workgroup)" if streamed else
+                           ("mi355::scan_kernel<ScanCfg<512,1,6,2>, true, false>" if world == 1 else
+                            "mi355::scan_kernel<ScanCfg<512,1,6,2>, false, false, 0, true>")),
                 "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None,
                 "traffic": traffic_bytes, "traffic_source": traffic_source,
