@@ -336,63 +336,69 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
                 mx[blk] = max3(mx[blk], u0, u1);   // the 8th operation folds the running maximum in
             }
         } else {
-            // pass 2: the same pipeline as a ROLLED loop over pairs of blocks (4 MFMAs per
-            // iteration) — unrolled 2 * NB times, the rare hit path below would be
-            // instantiated 64 times and spill the hot loop.
-            // Hits go to the wave's LDS staging buffer (ballot + prefix count, no atomics); the
+            // pass 2.  Hits go to the wave's LDS staging buffer (ballot + prefix count, no atomics); the
             // global per-query counters are only touched when the buffer is flushed, 64 entries
             // per round trip.  A returning global atomic per hit kept each wave waiting ~1.5 us
             // about 160 times per pass (measured: 555 vs 485 us).
-            auto check = [&](const bq_f16v& d, int blk, int sub) {
-                int u0, u1;
-                tree(d, u0, u1);
-                const int mm = max(u0, u1);
-                if (__builtin_expect(__ballot(mm >= 0) != 0ull, 0)) {   // some D >= +0: approx >= T'
-                    const uint32_t q = static_cast<uint32_t>(blk * 32 + r);
+            auto push_hits = [&](const bq_f16v& d, int blk, int sub) {
+                const uint32_t q = static_cast<uint32_t>(blk * 32 + r);
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const bool hit = static_cast<int>(__float_as_uint(d[i])) >= 0;
-                        const uint64_t who = __ballot(hit);
-                        if (who) {   // wave-uniform
-                            const int n_hit = __popcll(who);
-                            if (staged + n_hit > kBqStage) {
-                                bq_flush_stage(stage, staged, lane, cand_count, cand_rows);
-                                staged = 0;
-                            }
-                            if (hit) {
-                                const int slot = staged + lanes_below(who);
-                                // opaque on purpose: otherwise the compiler hoists all 32 row ids of a tile
-                                // out of this rare path into the tile prologue and spills them
-                                uint32_t row_lo = static_cast<uint32_t>(tile * 64) + static_cast<uint32_t>(sub * 32 + 4 * h);
-                                asm volatile("" : "+v"(row_lo));
-                                stage[slot] = make_uint2(q, row_lo + static_cast<uint32_t>((i & 3) + 8 * (i >> 2)));
-                            }
-                            staged += n_hit;
+                for (int i = 0; i < 16; ++i) {
+                    const bool hit = static_cast<int>(__float_as_uint(d[i])) >= 0;
+                    const uint64_t who = __ballot(hit);
+                    if (who) {   // wave-uniform
+                        const int n_hit = __popcll(who);
+                        if (staged + n_hit > kBqStage) {
+                            bq_flush_stage(stage, staged, lane, cand_count, cand_rows);
+                            staged = 0;
                         }
+                        if (hit) {
+                            const int slot = staged + lanes_below(who);
+                            // opaque on purpose: otherwise the compiler hoists all row ids of a tile
+                            // out of this rare path into the tile prologue and spills them
+                            uint32_t row_lo = static_cast<uint32_t>(tile * 64) + static_cast<uint32_t>(sub * 32 + 4 * h);
+                            asm volatile("" : "+v"(row_lo));
+                            stage[slot] = make_uint2(q, row_lo + static_cast<uint32_t>((i & 3) + 8 * (i >> 2)));
+                        }
+                        staged += n_hit;
                     }
                 }
             };
+            // ONE hit test per query block (both 32-row sub-tiles): 16 maxima + 1 compare + 1
+            // branch per two MFMAs
+            auto check2 = [&](const bq_f16v& da, const bq_f16v& db, int blk) {
+                int u0, u1, v0, v1;
+                tree(da, u0, u1);
+                tree(db, v0, v1);
+                const int mm = max(max3(u0, u1, v0), v1);
+                if (__builtin_expect(__ballot(mm >= 0) != 0ull, 0)) {   // some D >= +0: approx >= T'
+                    push_hits(da, blk, 0);
+                    push_hits(db, blk, 1);
+                }
+            };
+            // Four accumulator tiles: while block b's two tiles are reduced and tested, block
+            // b + 1's two MFMAs are in flight.  A ROLLED loop over pairs of blocks (unrolled
+            // 2 * NB times the rare hit path would be instantiated 64 times and spill the hot
+            // loop); straight-line body: the fragment loads past the last block are clamped
+            // and the two MFMAs issued for block NB are simply unused.
             static_assert(NB % 2 == 0, "blocks are processed in pairs");
             const uint4* sb = &s_b[0][0] + lane;
             uint4 bw0 = sb[0], bw1 = sb[64];
             bq_f16v D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);
-            bq_f16v D1;
+            bq_f16v D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);
+            bq_f16v D2, D3;
 #pragma unroll 1
             for (int bp = 0; bp < NB; bp += 2) {
-                // straight-line body: the fragment loads past the last block are clamped (they
-                // re-read the last fragment) and the MFMA issued for block NB is simply unused
                 const int nb0 = bp + 2 < NB ? bp + 2 : NB - 1;
                 const int nb1 = bp + 3 < NB ? bp + 3 : NB - 1;
-                D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);   // (bp, 1)
-                check(D0, bp, 0);
-                D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw1), zero, 0, 0, 0);   // (bp+1, 0)
+                D2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw1), zero, 0, 0, 0);   // block bp + 1
+                D3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], __builtin_bit_cast(bq_h8, bw1), zero, 0, 0, 0);
                 bw0 = sb[nb0 * 64];
-                check(D1, bp, 1);
-                D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], __builtin_bit_cast(bq_h8, bw1), zero, 0, 0, 0);   // (bp+1, 1)
-                check(D0, bp + 1, 0);
-                D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);   // (bp+2, 0)
+                check2(D0, D1, bp);
+                D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);   // block bp + 2
+                D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);
                 bw1 = sb[nb1 * 64];
-                check(D1, bp + 1, 1);
+                check2(D2, D3, bp + 1);
             }
         }
     }
