@@ -547,9 +547,20 @@ int enqueue_streamed(mi355rec* h, int64_t query_row, const float* query12, int64
 constexpr int64_t kBqMinRows = 65536;   // below this the launch count, not the arithmetic, decides
 constexpr int kBqMinBatch = 13;          // up to 12 queries are ONE multi-query pass
 
+void free_bq(mi355rec* h);
+
+int ensure_bq_alloc(mi355rec* h);
+
+// First batched call on a handle: allocate the path's scratch (all or nothing).
 int ensure_bq(mi355rec* h) {
+    if (h->bq.ready) return MI355REC_OK;
+    const int rc = ensure_bq_alloc(h);
+    if (rc != MI355REC_OK) free_bq(h);   // no half-allocated state survives a failure
+    return rc;
+}
+
+int ensure_bq_alloc(mi355rec* h) {
     auto& b = h->bq;
-    if (b.ready) return MI355REC_OK;
     // workgroups of a pass: what the 1024-query kernels can keep resident (LDS: 32 KiB of B
     // fragments per workgroup; registers: 4 resp. 5 waves per SIMD), the same for both passes
     int occ1 = 0, occ2 = 0;

@@ -226,3 +226,41 @@ def test_config5_shard_1024_queries_every_list(Engine, torch_cuda):
             rows, scores = unpack_keys(got[b])
             ex = int(excl[b]) - base if excl[b] >= 0 else -1
             assert_topn_matches(rows - base, scores, want, ex, topn, ref_idx=oracle.topn_heap(want, ex, topn))
+
+
+def test_batched_call_replays_from_a_hip_graph(Engine, torch_cuda):
+    """The asynchronous batched call allocates nothing and never synchronises after its
+    first use on a handle, so it can be captured into a hipGraph (here through torch's
+    CUDAGraph on a side stream) and replayed with new queries in the same device buffers."""
+    torch = torch_cuda
+    from spotify_recommender_amd.engine import unpack_keys
+    rng = np.random.default_rng(77)
+    n, batch, topn = 400_000, 200, 20
+    f = rng.random((n, 12), dtype=np.float32)
+    t = torch.from_numpy(f).cuda()
+    side = torch.cuda.Stream()
+    qd = torch.zeros((batch, 12), dtype=torch.float32, device="cuda")
+    ed = torch.full((batch,), -1, dtype=torch.int64, device="cuda")
+    keys = torch.zeros(batch * topn, dtype=torch.int64, device="cuda")
+    with Engine(t) as eng:
+        rows0 = rng.integers(0, n, size=batch)
+        qd.copy_(t[torch.from_numpy(rows0).cuda()])
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            eng.enqueue_batch_keys_dev(qd, ed, topn, keys)     # first call: allocates, on the capture stream
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            eng.enqueue_batch_keys_dev(qd, ed, topn, keys)
+        for trial in range(2):
+            rows = rng.integers(0, n, size=batch)
+            qd.copy_(t[torch.from_numpy(rows).cuda()])
+            ed.copy_(torch.from_numpy(rows.astype(np.int64)).cuda())
+            torch.cuda.synchronize()
+            graph.replay()
+            torch.cuda.synchronize()
+            got = keys.cpu().numpy().reshape(batch, topn)
+            for b in range(0, batch, 17):
+                want = oracle.scores(f, f[rows[b]])
+                r_, s_ = unpack_keys(got[b])
+                assert_topn_matches(r_, s_, want, int(rows[b]), topn, ref_idx=oracle.topn_heap(want, int(rows[b]), topn))
