@@ -79,8 +79,9 @@ def test_uniform_catalogue_matches_oracle(Engine, batch, topn):
 
 
 def test_hostile_distributions(Engine):
-    rng = np.random.default_rng(20261004)
-    for case in range(14):
+    import os
+    rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "20261004")))
+    for case in range(int(os.environ.get("BATCHED_FUZZ_CASES", "14"))):
         rows = int(rng.choice([70_000, 150_000, 400_000]))
         f = make_catalogue(rng, rows)
         batch = int(rng.integers(13, 120))
