@@ -370,10 +370,11 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
                 int u0, u1, v0, v1;
                 tree(da, u0, u1);
                 tree(db, v0, v1);
-                const int mm = max(max3(u0, u1, v0), v1);
-                if (__builtin_expect(__ballot(mm >= 0) != 0ull, 0)) {   // some D >= +0: approx >= T'
-                    push_hits(da, blk, 0);
-                    push_hits(db, blk, 1);
+                const int ma = max(u0, u1), mb = max(v0, v1);
+                if (__builtin_expect(__ballot(max(ma, mb) >= 0) != 0ull, 0)) {   // some D >= +0: approx >= T'
+                    // usually ONE of the two tiles holds the hit: skip the other's 16 ballots
+                    if (__ballot(ma >= 0)) push_hits(da, blk, 0);
+                    if (__ballot(mb >= 0)) push_hits(db, blk, 1);
                 }
             };
             // Four accumulator tiles: while block b's two tiles are reduced and tested, block
