@@ -74,6 +74,11 @@ typedef struct {
     int32_t batched_grid_blocks; /* workgroups of a batched pass (0 before the first batched call) */
     float batched_margin;      /* error bound the fp16 pre-filter runs with: 1.0e-3 where the device keeps
                                   fp16 subnormals (checked on first use), 1.5e-3 otherwise */
+    int64_t replica_bytes_per_query; /* algorithmic bytes of one pass over the fp16 replica: ceil(rows/2) * 48
+                                        (0 = the handle has no replica)                     */
+    int32_t replica_active;    /* 1 = single queries currently scan the replica (mi355rec_set_replica) */
+    int32_t replica_grid_blocks; /* resident workgroups of the replica scan                 */
+    float replica_build_ms;    /* device time of building the replica (once, at create)     */
 } mi355rec_stats_t;
 
 /* Number of visible HIP devices (0 when there is none / no driver). */
@@ -101,6 +106,32 @@ int mi355rec_create(const float* feats_host, int64_t n, int dim, int device,
  * the first query; ordering LATER writes to it is the caller's business. */
 int mi355rec_create_device(const float* feats_dev, int64_t n, int dim,
                            int device, int64_t row_base, mi355rec_t** out);
+
+/* THE fp16 REPLICA.  Next to the fp32 rows every handle keeps a second copy of
+ * its shard that is only good enough to rule rows OUT: each row L2-normalised
+ * and rounded to fp16, 24 B per row (+50 % device memory, built once inside
+ * create; csrc/replica.hip.h).  A single query then streams 24 B per row
+ * instead of 48: a row is skipped when its fp16 cosine is more than the derived
+ * error bound (1.5e-3) below what the top-N needs; every row that is not
+ * skipped is fetched from the fp32 matrix and scored by the reference's exact
+ * chain, so ids, order and score bits are those of the fp32 scan and of
+ * Recommender.cu:256-318.  Rows or queries the bound cannot be claimed for
+ * (zero / tiny / huge / non-finite norms) are always scored exactly.
+ *   AUTO (default): shards of >= 2 Mi rows scan the replica, smaller ones the
+ *                   fp32 rows (a query is launch-bound there either way);
+ *   OFF:            always the fp32 rows (the reference's own traffic, 48 B/row);
+ *   ON:             always the replica.
+ * The score vector (mi355rec_scores*), topn > 1024 and the multi-query /
+ * batched calls do not use it.  The environment variable MI355REC_REPLICA=0
+ * creates handles without one.
+ * A replica is a SNAPSHOT: if the caller overwrites a borrowed matrix
+ * (mi355rec_create_device) while the handle lives, it must call
+ * mi355rec_rebuild_replica before the next query (synchronous). */
+#define MI355REC_REPLICA_AUTO 0
+#define MI355REC_REPLICA_OFF 1
+#define MI355REC_REPLICA_ON 2
+int mi355rec_set_replica(mi355rec_t* h, int mode);
+int mi355rec_rebuild_replica(mi355rec_t* h);
 
 /* Replaces Recommender::~Recommender (Recommender.cu:86-98). */
 void mi355rec_destroy(mi355rec_t* h);

@@ -16,6 +16,7 @@ LIB_PATH = PKG / "libmi355rec.so"
 DIM = 12
 MAX_TOPN_FAST = 1024
 BATCH_AUTO, BATCH_MULTI, BATCH_MFMA = 0, 1, 2
+REPLICA_AUTO, REPLICA_OFF, REPLICA_ON = 0, 1, 2
 TRANSPORT_PEER, TRANSPORT_RCCL = 1, 2
 
 OK = 0
@@ -39,6 +40,10 @@ class Stats(ctypes.Structure):
         ("last_pass_ms", c_float),
         ("batched_grid_blocks", c_int32),
         ("batched_margin", c_float),
+        ("replica_bytes_per_query", c_int64),
+        ("replica_active", c_int32),
+        ("replica_grid_blocks", c_int32),
+        ("replica_build_ms", c_float),
     ]
 
 
@@ -64,6 +69,8 @@ SIGNATURES = {
     "mi355rec_enqueue_batch_keys": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mi355rec_enqueue_batch_keys_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mi355rec_set_batch_path": (c_int, [c_void_p, c_int]),
+    "mi355rec_set_replica": (c_int, [c_void_p, c_int]),
+    "mi355rec_rebuild_replica": (c_int, [c_void_p]),
     "mi355rec_batched_last_counters": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int64),
                                                POINTER(c_int32)]),
     "mi355rec_enqueue_merge_keys": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

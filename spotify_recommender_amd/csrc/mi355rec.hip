@@ -18,6 +18,7 @@
 
 #include "batched.hip.h"
 #include "kernels.hip.h"
+#include "replica.hip.h"
 
 using namespace mi355;
 
@@ -43,6 +44,8 @@ constexpr int kDirectResultSlots = 2048;   // results up to this many slots are 
 
 using ScanConfig = DefaultScanCfg;
 using MultiConfig = DefaultMultiCfg;
+using HalfConfig = DefaultHalfCfg;
+constexpr int64_t kHalfAutoMinRows = 2 * 1024 * 1024;   // below this a query is launch-bound either way
 constexpr int kScanBlock = ScanConfig::kBlock;
 constexpr int kScanTileRows = ScanConfig::kTileRows;
 
@@ -72,6 +75,16 @@ struct mi355rec {
     bool pending = false;               // a streamed query's lists wait for their merge
     int pending_buf = 0, pending_topn = 0;
     uint64_t* pending_out = nullptr;
+    // fp16 replica of the catalogue (replica.hip.h) and the geometry of the scan over it
+    uint4* d_half = nullptr;            // ((n + 1) / 2) pairs of rows x 48 B
+    uint32_t* d_half_seed = nullptr;    // kHalfSeedMaxGrid x 8 sample maxima of the query in flight
+    int hgrid = 0, hiters = 0;          // plain launch
+    int hsgrid = 0, hsiters = 0;        // streamed launch (one more workgroup is the merger)
+    int hseed_grid = 0;
+    int64_t hseed_stride = 0;
+    int replica_mode = 0;               // MI355REC_REPLICA_AUTO / _OFF / _ON
+    float replica_build_ms = 0.f;
+    int pending_lists = 0;              // lists of the streamed query that waits for its merge
     uint32_t* d_seed_vals = nullptr;    // kMultiChain x (mgrid * kSeedWaves) sample maxima
     uint64_t* d_seed_keys = nullptr;    // kMultiChain x kMultiMaxTopK: sample top-k per query of a multi-query chain
 
@@ -211,6 +224,52 @@ void plan_multi_grid(mi355rec* h, int blocks_per_cu) {
     h->mrows_per_block = stride;  // seed kernel only: distance between sampled regions
 }
 
+// Scan over the fp16 replica (replica.hip.h): tiles of 1024 rows dealt round-robin; the
+// seed kernel samples 1024 rows of up to 256 evenly spaced regions (>= 1024 rows apart, so
+// no row is sampled twice).
+void plan_half_grid(mi355rec* h) {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_half_kernel<HalfConfig, true, false>, HalfConfig::kBlock, 0) != hipSuccess || occ < 1) occ = 1;
+    if (occ > 3) occ = 3;
+    if (const char* e = std::getenv("MI355REC_EXP_HOCC")) {   // A/B experiment only
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 4) occ = v;
+    }
+    int64_t max_blocks = static_cast<int64_t>(h->cus) * occ;
+    if (max_blocks > kRideMaxLists) max_blocks = kRideMaxLists;
+    const int64_t tiles = (h->n + HalfConfig::kTileRows - 1) / HalfConfig::kTileRows;
+    h->hgrid = static_cast<int>(tiles < max_blocks ? tiles : max_blocks);
+    h->hiters = static_cast<int>((tiles + h->hgrid - 1) / h->hgrid);
+    h->hsgrid = h->hgrid > 1 ? h->hgrid - 1 : 1;
+    h->hsiters = static_cast<int>((tiles + h->hsgrid - 1) / h->hsgrid);
+    int64_t sg = h->n / HalfConfig::kTileRows;
+    if (sg > kHalfSeedMaxGrid) sg = kHalfSeedMaxGrid;
+    h->hseed_grid = static_cast<int>(sg);
+    h->hseed_stride = sg > 0 ? ((h->n / sg) & ~static_cast<int64_t>(1)) : 0;
+}
+
+// (Re)builds the replica from the fp32 rows on the handle's stream and waits for it.
+int build_replica(mi355rec* h) {
+    const int64_t n_padded = (h->n + 1) & ~static_cast<int64_t>(1);
+    if (!h->d_half) {
+        HIP_TRY(h, hipMalloc(&h->d_half, static_cast<size_t>(n_padded) * 24));
+        HIP_TRY(h, hipMalloc(&h->d_half_seed, sizeof(uint32_t) * kHalfSeedMaxGrid * kHalfSeedWaves));
+    }
+    hipEvent_t a = nullptr, b = nullptr;
+    const bool timed = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess;
+    if (timed) (void)hipEventRecord(a, h->stream);
+    hipLaunchKernelGGL(replica_build_kernel, dim3(static_cast<unsigned>((n_padded + 255) / 256)), dim3(256), 0, h->stream,
+                       h->d_feats, h->n, n_padded, reinterpret_cast<uint2*>(h->d_half));
+    if (timed) (void)hipEventRecord(b, h->stream);
+    const hipError_t e = hipStreamSynchronize(h->stream);
+    if (timed && e == hipSuccess) (void)hipEventElapsedTime(&h->replica_build_ms, a, b);
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    HIP_TRY(h, e);
+    HIP_TRY(h, hipGetLastError());
+    return MI355REC_OK;
+}
+
 int create_common(const float* feats, bool on_device, int64_t n, int dim, int device,
                   int64_t row_base, mi355rec_t** out) {
     if (out) *out = nullptr;
@@ -255,6 +314,7 @@ int create_common(const float* feats, bool on_device, int64_t n, int dim, int de
         if (e != hipSuccess || mocc < 1) mocc = 1;
         if (mocc > 4) mocc = 4;
         plan_multi_grid(h, mocc);
+        plan_half_grid(h);
     } else {
         h->grid = h->mgrid = 1;  // sizes the (unused) scratch; no scan is ever launched
     }
@@ -283,7 +343,7 @@ int create_common(const float* feats, bool on_device, int64_t n, int dim, int de
         h->d_feats = h->owned_feats;
     }
 
-    size_t list_words = static_cast<size_t>(h->grid) * kMaxTopK;
+    size_t list_words = static_cast<size_t>(h->grid > h->hgrid ? h->grid : h->hgrid) * kMaxTopK;
     const size_t multi_words = static_cast<size_t>(h->mgrid) * kMultiChain * kMultiMaxTopK;
     if (multi_words > list_words) list_words = multi_words;
     if ((e = hipMalloc(&h->d_block_lists, sizeof(uint64_t) * list_words)) != hipSuccess)
@@ -302,6 +362,17 @@ int create_common(const float* feats, bool on_device, int64_t n, int dim, int de
         // scan it half-written.  Later writes to it are the caller's to order.
         if ((e = hipDeviceSynchronize()) != hipSuccess)
             return cleanup(MI355REC_ERR_HIP, "hipDeviceSynchronize", e);
+    }
+    // The fp16 replica (+50 % device memory, one pass over the rows).  MI355REC_REPLICA=0
+    // in the environment keeps a handle fp32-only.
+    const char* renv = std::getenv("MI355REC_REPLICA");
+    if (n > 0 && !(renv && renv[0] == '0')) {
+        const int brc = build_replica(h);
+        if (brc != MI355REC_OK) {
+            const std::string msg = h->err;
+            mi355rec_destroy(h);
+            return fail(nullptr, brc, "%s", msg.c_str());
+        }
     }
 
     *out = h;
@@ -354,23 +425,60 @@ void timing_end(mi355rec* h, std::vector<hipEvent_t>& evs, int& pairs, int slot,
     pairs = slot + 1;
 }
 
+bool use_half(const mi355rec* h, const uint64_t* upper_dev) {
+    if (!h->d_half || upper_dev || h->replica_mode == MI355REC_REPLICA_OFF) return false;
+    return h->replica_mode == MI355REC_REPLICA_ON || h->n >= kHalfAutoMinRows;
+}
+
+// The sample that seeds the launch-wide cutoff of the next scan over the replica.
+void enqueue_half_seed(mi355rec* h, int64_t query_row, const QueryArg& qa, int64_t exclude_global, hipStream_t s) {
+    if (h->hseed_grid <= 0) return;
+    if (query_row >= 0) {
+        hipLaunchKernelGGL((seed_half_kernel<true>), dim3(h->hseed_grid), dim3(kHalfSeedBlock), 0, s, h->d_feats, h->d_half,
+                           h->n, h->hseed_stride, h->row_base, qa, query_row, exclude_global, h->d_half_seed);
+    } else {
+        hipLaunchKernelGGL((seed_half_kernel<false>), dim3(h->hseed_grid), dim3(kHalfSeedBlock), 0, s, h->d_feats, h->d_half,
+                           h->n, h->hseed_stride, h->row_base, qa, static_cast<int64_t>(0), exclude_global, h->d_half_seed);
+    }
+}
+
 // Enqueue the scan for one query.  query_row >= 0: query is that local row.
+// *n_lists = per-workgroup lists it leaves in d_block_lists.
 int enqueue_scan(mi355rec* h, int64_t query_row, const float* query12,
-                 int64_t exclude_global, int topn, const uint64_t* upper_dev, hipStream_t s) {
+                 int64_t exclude_global, int topn, const uint64_t* upper_dev, hipStream_t s, int* n_lists) {
     QueryArg qa;
     std::memset(&qa, 0, sizeof qa);
+    if (query_row < 0) std::memcpy(qa.q, query12, sizeof qa.q);
+    const PrevMerge none{nullptr, 0, 0, nullptr};
+    if (use_half(h, upper_dev)) {
+        *n_lists = h->hgrid;
+        enqueue_half_seed(h, query_row, qa, exclude_global, s);
+        const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, s);
+        if (query_row >= 0) {
+            hipLaunchKernelGGL((scan_half_kernel<HalfConfig, true, false>), dim3(h->hgrid), dim3(HalfConfig::kBlock), 0, s,
+                               h->d_feats, h->d_half, h->n, h->hiters, h->row_base, qa, query_row, exclude_global, topn,
+                               h->d_block_lists, h->d_half_seed, h->hseed_grid * kHalfSeedWaves, none);
+        } else {
+            hipLaunchKernelGGL((scan_half_kernel<HalfConfig, false, false>), dim3(h->hgrid), dim3(HalfConfig::kBlock), 0, s,
+                               h->d_feats, h->d_half, h->n, h->hiters, h->row_base, qa, static_cast<int64_t>(0), exclude_global,
+                               topn, h->d_block_lists, h->d_half_seed, h->hseed_grid * kHalfSeedWaves, none);
+        }
+        timing_end(h, h->ev_scan, h->n_scan_pairs, slot, s);
+        HIP_TRY(h, hipGetLastError());
+        return MI355REC_OK;
+    }
+    *n_lists = h->grid;
     const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, s);
     if (query_row >= 0) {
         hipLaunchKernelGGL((scan_kernel<ScanConfig, true, false>), dim3(h->grid), dim3(kScanBlock), 0, s,
                            h->d_feats, h->n, h->rows_per_block, h->iters, h->row_base, qa,
                            query_row, exclude_global, topn, h->d_block_lists,
-                           static_cast<float*>(nullptr), upper_dev, PrevMerge{nullptr, 0, 0, nullptr});
+                           static_cast<float*>(nullptr), upper_dev, none);
     } else {
-        std::memcpy(qa.q, query12, sizeof qa.q);
         hipLaunchKernelGGL((scan_kernel<ScanConfig, false, false>), dim3(h->grid), dim3(kScanBlock), 0, s,
                            h->d_feats, h->n, h->rows_per_block, h->iters, h->row_base, qa,
                            static_cast<int64_t>(0), exclude_global, topn, h->d_block_lists,
-                           static_cast<float*>(nullptr), upper_dev, PrevMerge{nullptr, 0, 0, nullptr});
+                           static_cast<float*>(nullptr), upper_dev, none);
     }
     timing_end(h, h->ev_scan, h->n_scan_pairs, slot, s);
     HIP_TRY(h, hipGetLastError());
@@ -469,9 +577,10 @@ int enqueue_query(mi355rec* h, int64_t query_row, const float* query12, int64_t 
     for (int done = 0; done < topn; done += kMaxTopK) {
         const int k = topn - done < kMaxTopK ? topn - done : kMaxTopK;
         const uint64_t* upper = done ? out_keys + done - 1 : nullptr;
-        int rc = enqueue_scan(h, query_row, query12, exclude_global, k, upper, s);
+        int lists = 0;
+        int rc = enqueue_scan(h, query_row, query12, exclude_global, k, upper, s, &lists);
         if (rc) return rc;
-        rc = enqueue_merge(h, h->d_block_lists, h->grid, k, k, out_keys + done,
+        rc = enqueue_merge(h, h->d_block_lists, lists, k, k, out_keys + done,
                            out_idx ? out_idx + done : nullptr, out_score ? out_score + done : nullptr, s);
         if (rc) return rc;
     }
@@ -494,16 +603,17 @@ int ensure_streamed(mi355rec* h) {
     if (tiles < g) g = static_cast<int>(tiles);
     h->sgrid = g;
     h->siters = static_cast<int>((tiles + g - 1) / g);
+    const int most = g > h->hsgrid ? g : h->hsgrid;
     for (int i = 0; i < 2; ++i)
-        HIP_TRY(h, hipMalloc(&h->d_stream_lists[i], sizeof(uint64_t) * static_cast<size_t>(g) * kMaxTopK));
+        HIP_TRY(h, hipMalloc(&h->d_stream_lists[i], sizeof(uint64_t) * static_cast<size_t>(most) * kMaxTopK));
     return MI355REC_OK;
 }
 
 int flush_streamed(mi355rec* h, hipStream_t s) {
     if (!h->pending) return MI355REC_OK;
     h->pending = false;
-    return enqueue_merge(h, h->d_stream_lists[h->pending_buf], h->sgrid, h->pending_topn, h->pending_topn, h->pending_out,
-                         nullptr, nullptr, s);
+    return enqueue_merge(h, h->d_stream_lists[h->pending_buf], h->pending_lists, h->pending_topn, h->pending_topn,
+                         h->pending_out, nullptr, nullptr, s);
 }
 
 int enqueue_streamed(mi355rec* h, int64_t query_row, const float* query12, int64_t exclude_global, int topn,
@@ -517,9 +627,32 @@ int enqueue_streamed(mi355rec* h, int64_t query_row, const float* query12, int64
         rc = flush_streamed(h, s);
         if (rc) return rc;
     }
-    if (h->pending) prev = PrevMerge{h->d_stream_lists[h->pending_buf], h->sgrid, h->pending_topn, h->pending_out};
+    if (h->pending) prev = PrevMerge{h->d_stream_lists[h->pending_buf], h->pending_lists, h->pending_topn, h->pending_out};
     QueryArg qa;
     std::memset(&qa, 0, sizeof qa);
+    if (use_half(h, nullptr)) {
+        if (query_row < 0) std::memcpy(qa.q, query12, sizeof qa.q);
+        enqueue_half_seed(h, query_row, qa, exclude_global, s);
+        const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, s);
+        if (query_row >= 0) {
+            hipLaunchKernelGGL((scan_half_kernel<HalfConfig, true, true>), dim3(h->hsgrid + 1), dim3(HalfConfig::kBlock), 0, s,
+                               h->d_feats, h->d_half, h->n, h->hsiters, h->row_base, qa, query_row, exclude_global, topn,
+                               h->d_stream_lists[buf], h->d_half_seed, h->hseed_grid * kHalfSeedWaves, prev);
+        } else {
+            hipLaunchKernelGGL((scan_half_kernel<HalfConfig, false, true>), dim3(h->hsgrid + 1), dim3(HalfConfig::kBlock), 0, s,
+                               h->d_feats, h->d_half, h->n, h->hsiters, h->row_base, qa, static_cast<int64_t>(0),
+                               exclude_global, topn, h->d_stream_lists[buf], h->d_half_seed, h->hseed_grid * kHalfSeedWaves,
+                               prev);
+        }
+        timing_end(h, h->ev_scan, h->n_scan_pairs, slot, s);
+        HIP_TRY(h, hipGetLastError());
+        h->pending = true;
+        h->pending_buf = buf;
+        h->pending_topn = topn;
+        h->pending_out = out_keys;
+        h->pending_lists = h->hsgrid;
+        return MI355REC_OK;
+    }
     const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, s);
     if (query_row >= 0) {
         hipLaunchKernelGGL((scan_kernel<ScanConfig, true, false, 0, true>), dim3(h->sgrid + 1), dim3(kScanBlock), 0, s,
@@ -539,6 +672,7 @@ int enqueue_streamed(mi355rec* h, int64_t query_row, const float* query12, int64
     h->pending_buf = buf;
     h->pending_topn = topn;
     h->pending_out = out_keys;
+    h->pending_lists = h->sgrid;
     return MI355REC_OK;
 }
 
@@ -781,6 +915,8 @@ void mi355rec_destroy(mi355rec_t* h) {
     if (h->d_stream_lists[1]) (void)hipFree(h->d_stream_lists[1]);
     if (h->d_seed_keys) (void)hipFree(h->d_seed_keys);
     if (h->d_seed_vals) (void)hipFree(h->d_seed_vals);
+    if (h->d_half) (void)hipFree(h->d_half);
+    if (h->d_half_seed) (void)hipFree(h->d_half_seed);
     if (h->d_keys) (void)hipFree(h->d_keys);
     if (h->d_idx) (void)hipFree(h->d_idx);
     if (h->d_score) (void)hipFree(h->d_score);
@@ -843,6 +979,10 @@ int mi355rec_stats(const mi355rec_t* hc, mi355rec_stats_t* out) {
     out->last_pass_ms = h->last_pass_ms;
     out->batched_grid_blocks = h->bq.ready ? h->bq.grid : 0;
     out->batched_margin = h->bq.ready ? h->bq.margin : 0.0f;
+    out->replica_bytes_per_query = h->d_half ? ((h->n + 1) / 2) * 48 : 0;
+    out->replica_active = use_half(h, nullptr) ? 1 : 0;
+    out->replica_grid_blocks = h->d_half ? h->hgrid : 0;
+    out->replica_build_ms = h->replica_build_ms;
     return MI355REC_OK;
 }
 
@@ -980,6 +1120,25 @@ int mi355rec_set_batch_path(mi355rec_t* h, int path) {
         return fail(h, MI355REC_ERR_INVALID_ARG, "unknown batch path %d", path);
     h->batch_path = path;
     return MI355REC_OK;
+}
+
+int mi355rec_set_replica(mi355rec_t* h, int mode) {
+    if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    if (mode != MI355REC_REPLICA_AUTO && mode != MI355REC_REPLICA_OFF && mode != MI355REC_REPLICA_ON)
+        return fail(h, MI355REC_ERR_INVALID_ARG, "unknown replica mode %d", mode);
+    if (mode == MI355REC_REPLICA_ON && !h->d_half && h->n > 0)
+        return fail(h, MI355REC_ERR_INVALID_ARG, "this handle was created without a replica (MI355REC_REPLICA=0)");
+    h->replica_mode = mode;
+    return MI355REC_OK;
+}
+
+int mi355rec_rebuild_replica(mi355rec_t* h) {
+    if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    if (h->n == 0) return MI355REC_OK;
+    DeviceGuard guard(h->device);
+    const int rc = sync_api_begin(h);
+    if (rc) return rc;
+    return build_replica(h);
 }
 
 int mi355rec_enqueue_merge_keys(mi355rec_t* h, const mi355rec_key_t* lists_dev, int n_lists,

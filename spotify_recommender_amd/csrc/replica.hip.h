@@ -1,0 +1,346 @@
+// replica.hip.h — the fp16 REPLICA of the catalogue and the single-query scan over it.
+//
+// The reference streams the N x 12 fp32 matrix once per query (Recommender.cu:184-254,
+// 48 B per row).  The contract per query is recommendByIndex's (Recommender.cu:275-318):
+// the exact fp32 cosine of calculateSimilaritiesCPU (:256-273) and the best topN rows.
+// A row can only be in that top-N if its score reaches the N-th best score T; almost no
+// row does.  So the engine keeps, next to the fp32 rows, a second copy that is only good
+// enough to RULE ROWS OUT: every row L2-normalised in fp32 and rounded to fp16 (24 B per
+// row, built once when the handle is created).  A query reads the 24 B replica; the few
+// rows per workgroup the replica cannot rule out are fetched from the fp32 matrix and
+// scored with the exact chain (cosine_score(), kernels.hip.h).  Every key that leaves the
+// kernel is therefore computed from the fp32 row by the reference's arithmetic: results
+// are bit-identical to the fp32 scan (scan_kernel) and to the oracle, at half the bytes.
+//
+// Bound (the batched path's, batched.hip.h "Margin"): for a VALID row and a VALID query
+//   |approx - exact| <= kHalfMargin,   approx = sum_j fp16(r^_j) * fp16(q^_j)
+// (fp16 products are exact in fp32, accumulated by fp32 FMAs).  kHalfMargin is the
+// flush-proof 1.5e-3, so nothing here depends on how a unit treats fp16 subnormals.
+// valid row:   |row|^2 in [kBqMinNorm2, kBqMaxNorm2]  (then |row||q| > 1e-8: no zero branch,
+//              and no fp32 sum overflows in any order)
+// zero row:    fma-summed |row|^2 == 0 -> the reference's |row|^2 is 0 as well, its score is
+//              exactly 0 against every valid query: the replica stores zeros (approx = 0).
+// other rows:  (tiny, huge, inf, NaN) the replica stores fp16 NaN: approx = NaN, and
+//              !(NaN < cutoff) sends the row to the exact chain every time.
+// valid query: |q| in [kBqMinNorm, kBqMaxNorm]; otherwise the pre-filter stays off for the
+//              whole launch (every row is fetched and scored exactly: slow, still right).
+//
+// Threshold.  Per-workgroup thresholds alone (a workgroup sees n / 512 rows) would send
+// ~k ln(rows/k) rows per workgroup to the exact chain, each a random 48 B fetch.  So one
+// small launch first looks at a spread sample of the replica (seed_half_kernel: one approx
+// maximum per 128-row wave tile, excluded row masked).  With v the topN-th largest of those
+// maxima, topN distinct rows have approx >= v, hence exact >= v - margin, hence the
+// catalogue's topN-th best is >= v - margin and every row of the true top-N has
+//   approx >= v - 2 margin  =: the launch-wide cutoff.
+// Each scanning workgroup selects v itself from the <= 2048 sample maxima (one radix select
+// while its first tiles are in flight).  Workgroup-local thresholds tighten the cutoff
+// further whenever a local list fills.
+#pragma once
+
+#include "batched.hip.h"
+
+namespace mi355 {
+
+constexpr float kHalfMargin = kBqMarginFlush;
+constexpr uint32_t kHalfNaN2 = 0x7e007e00u;   // two fp16 quiet NaNs
+constexpr int kHalfSeedBlock = 512;
+constexpr int kHalfSeedWaves = kHalfSeedBlock / 64;
+constexpr int kHalfSeedMaxGrid = 256;          // <= 2048 sample maxima
+constexpr int kHalfSeedPerThread = 4;          // x 512 threads of a scanning workgroup
+
+// ---- building the replica ---------------------------------------------------------
+// One thread per row; rows [n, n_padded) (n_padded even) are padding and hold NaN.
+__global__ __launch_bounds__(256) void replica_build_kernel(const float* __restrict__ feats, int64_t n, int64_t n_padded,
+                                                            uint2* __restrict__ half) {
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (row >= n_padded) return;
+    uint32_t p0 = kHalfNaN2, p1 = kHalfNaN2, p2 = kHalfNaN2, p3 = kHalfNaN2, p4 = kHalfNaN2, p5 = kHalfNaN2;
+    if (row < n) {
+        const float4* p = reinterpret_cast<const float4*>(feats) + row * 3;
+        const float4 a = p[0], b = p[1], c = p[2];
+        // the same normalisation as the batched passes (bq_pass_kernel), so one bound covers both
+        float tot = a.x * a.x;
+        tot = __builtin_fmaf(a.y, a.y, tot);
+        tot = __builtin_fmaf(a.z, a.z, tot);
+        tot = __builtin_fmaf(a.w, a.w, tot);
+        tot = __builtin_fmaf(b.x, b.x, tot);
+        tot = __builtin_fmaf(b.y, b.y, tot);
+        tot = __builtin_fmaf(b.z, b.z, tot);
+        tot = __builtin_fmaf(b.w, b.w, tot);
+        tot = __builtin_fmaf(c.x, c.x, tot);
+        tot = __builtin_fmaf(c.y, c.y, tot);
+        tot = __builtin_fmaf(c.z, c.z, tot);
+        tot = __builtin_fmaf(c.w, c.w, tot);
+        const bool valid = tot >= kBqMinNorm2 && tot <= kBqMaxNorm2;
+        if (valid) {
+            const float inv = __builtin_amdgcn_rsqf(tot);
+            p0 = bq_pack_h2(a.x * inv, a.y * inv); p1 = bq_pack_h2(a.z * inv, a.w * inv);
+            p2 = bq_pack_h2(b.x * inv, b.y * inv); p3 = bq_pack_h2(b.z * inv, b.w * inv);
+            p4 = bq_pack_h2(c.x * inv, c.y * inv); p5 = bq_pack_h2(c.z * inv, c.w * inv);
+        } else if (tot == 0.0f) {
+            p0 = p1 = p2 = p3 = p4 = p5 = 0u;
+        }
+    }
+    uint2* dst = half + row * 3;
+    dst[0] = make_uint2(p0, p1);
+    dst[1] = make_uint2(p2, p3);
+    dst[2] = make_uint2(p4, p5);
+}
+
+// ---- the query in fp16 --------------------------------------------------------------
+struct HalfQuery {
+    uint32_t h[6];   // fp16 pairs of q / |q| (wave-uniform: scalar registers)
+    bool ok;         // the bound may be claimed for this query
+};
+
+__device__ __forceinline__ HalfQuery half_query(const float (&q)[kDim], float qn) {
+    HalfQuery hq;
+    hq.ok = qn >= kBqMinNorm && qn <= kBqMaxNorm;   // false for NaN
+    const float inv = hq.ok ? 1.0f / qn : 0.0f;
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+        hq.h[p] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
+            static_cast<int>(hq.ok ? bq_pack_h2(q[2 * p] * inv, q[2 * p + 1] * inv) : 0u)));
+    return hq;
+}
+
+// sum_j fp16 * fp16 with fp32 FMAs (v_fma_mix_f32: the fp16 operands are converted exactly)
+__device__ __forceinline__ float half_dot(const uint32_t (&qh)[6], uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3,
+                                          uint32_t a4, uint32_t a5) {
+    const uint32_t a[6] = {a0, a1, a2, a3, a4, a5};
+    float acc = 0.0f;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+        const bq_h2 x = __builtin_bit_cast(bq_h2, a[p]);
+        const bq_h2 y = __builtin_bit_cast(bq_h2, qh[p]);
+        acc = __builtin_fmaf(static_cast<float>(x[0]), static_cast<float>(y[0]), acc);
+        acc = __builtin_fmaf(static_cast<float>(x[1]), static_cast<float>(y[1]), acc);
+    }
+    return acc;
+}
+
+// ---- the sample that seeds the launch-wide cutoff -------------------------------------
+// Workgroup b looks at the 1024 rows from row b * stride_rows on (stride_rows even): one
+// ordered-u32 approx maximum per wave (0 = nothing usable) -> seed_vals[b * 8 + wave].
+template <bool kQueryFromRow>
+__global__ __launch_bounds__(kHalfSeedBlock) void seed_half_kernel(
+    const float* __restrict__ feats, const uint4* __restrict__ half, int64_t n, int64_t stride_rows, int64_t row_base,
+    QueryArg qarg, int64_t query_row, int64_t exclude_global, uint32_t* __restrict__ seed_vals) {
+    float q[kDim];
+    if constexpr (kQueryFromRow) {
+        const float* qp = feats + query_row * kDim;
+#pragma unroll
+        for (int j = 0; j < kDim; ++j) q[j] = qp[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < kDim; ++j) q[j] = qarg.q[j];
+    }
+    const HalfQuery hq = half_query(q, query_norm(q));
+    const int tid = threadIdx.x;
+    const int64_t n_pairs = (n + 1) >> 1;
+    int64_t pair = (static_cast<int64_t>(blockIdx.x) * stride_rows >> 1) + tid;
+    const bool have = pair < n_pairs;
+    pair = have ? pair : n_pairs - 1;
+    const uint4* p = half + pair * 3;
+    const uint4 t0 = p[0], t1 = p[1], t2 = p[2];
+    const float a0 = half_dot(hq.h, t0.x, t0.y, t0.z, t0.w, t1.x, t1.y);
+    const float a1 = half_dot(hq.h, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w);
+    const int64_t r0 = pair * 2;
+    // NaN compares false: special rows never seed
+    const bool use0 = have && hq.ok && r0 < n && row_base + r0 != exclude_global && a0 >= -2.0f;
+    const bool use1 = have && hq.ok && r0 + 1 < n && row_base + r0 + 1 != exclude_global && a1 >= -2.0f;
+    uint32_t v = 0u;
+    if (use0) v = score_to_ordered(a0);
+    if (use1) {
+        const uint32_t w = score_to_ordered(a1);
+        v = w > v ? w : v;
+    }
+    v = wave_max_u32(v);
+    if ((tid & 63) == 0) seed_vals[blockIdx.x * kHalfSeedWaves + (tid >> 6)] = v;
+}
+
+// ---- the scan --------------------------------------------------------------------------
+// One lane = one PAIR of rows = 48 B of replica (3 x dwordx4, the fp32 scan's own load
+// pattern: every wave-level load covers a contiguous 3 KiB span).  Tiles of 2 * kBlock rows
+// are dealt round-robin over the scanning workgroups.
+template <int kBlockT, int kMinWavesT, int kDepthT>
+struct HalfCfg {
+    static constexpr int kBlock = kBlockT;
+    static constexpr int kMinWaves = kMinWavesT;
+    static constexpr int kDepth = kDepthT;
+    static constexpr int kTileRows = 2 * kBlockT;
+    static constexpr int kCandCap = kCandLimit + kTileRows;
+    static constexpr int kCandPerThread = (kCandCap + kBlockT - 1) / kBlockT;
+};
+using DefaultHalfCfg = HalfCfg<512, 4, 3>;
+
+template <typename Cfg>
+struct HalfScanSmemT {
+    uint64_t cand[Cfg::kCandCap];
+    SelectSmem sel;
+    int count;
+    int seeds;
+};
+template <typename Cfg>
+union HalfScanOrMergeSmem {
+    HalfScanSmemT<Cfg> scan;
+    MergeSmemT<Cfg::kBlock, kRideMaxLists, kRideSurvCap> merge;
+};
+
+struct HalfTile {
+    uint4 t0, t1, t2;
+};
+
+// kWithMerge: as scan_kernel's — the LAST workgroup merges the previous streamed query.
+template <typename Cfg, bool kQueryFromRow, bool kWithMerge>
+__global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_half_kernel(
+    const float* __restrict__ feats, const uint4* __restrict__ half, int64_t n, int iters, int64_t row_base,
+    QueryArg qarg, int64_t query_row, int64_t exclude_global, int topk, uint64_t* __restrict__ block_lists,
+    const uint32_t* __restrict__ seed_vals, int n_seed, PrevMerge prev) {
+    constexpr int kBlock = Cfg::kBlock;
+    constexpr int kTileRows = Cfg::kTileRows;
+    __shared__ typename std::conditional<kWithMerge, HalfScanOrMergeSmem<Cfg>, HalfScanSmemT<Cfg>>::type s_mem;
+    HalfScanSmemT<Cfg>* sm;
+    if constexpr (kWithMerge) {
+        if (blockIdx.x == gridDim.x - 1) {
+            if (prev.lists)
+                merge_body(s_mem.merge, prev.lists, prev.n_lists, prev.topk, static_cast<int64_t>(prev.topk),
+                           static_cast<int64_t>(0), prev.topk, prev.out_keys, static_cast<int64_t*>(nullptr),
+                           static_cast<float*>(nullptr), static_cast<int64_t>(0), static_cast<int64_t>(0),
+                           static_cast<int64_t>(0));
+            return;
+        }
+        sm = &s_mem.scan;
+    } else {
+        sm = &s_mem;
+    }
+    uint64_t* const s_cand = sm->cand;
+    SelectSmem& s_sel = sm->sel;
+    int& s_count = sm->count;
+
+    const unsigned bid = blockIdx.x;
+    const unsigned nblocks = kWithMerge ? gridDim.x - 1u : gridDim.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+
+    float q[kDim];
+    if constexpr (kQueryFromRow) {
+        const float* qp = feats + query_row * kDim;  // wave-uniform: scalar loads
+#pragma unroll
+        for (int j = 0; j < kDim; ++j) q[j] = qp[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < kDim; ++j) q[j] = qarg.q[j];
+    }
+    const float qn = query_norm(q);
+    const HalfQuery hq = half_query(q, qn);
+
+    const int64_t n_pairs = (n + 1) >> 1;
+    const int64_t last_pair = n_pairs - 1;
+    const int64_t pair_begin = static_cast<int64_t>(bid) * kBlock + tid;
+    const int64_t pair_stride = static_cast<int64_t>(nblocks) * kBlock;
+
+    auto load_tile = [&](HalfTile& dst, int it) {
+        int64_t pair = pair_begin + static_cast<int64_t>(it) * pair_stride;
+        pair = pair < n_pairs ? pair : last_pair;   // unconditional prefetch (see scan_kernel)
+        const uint4* p = half + pair * 3;
+        dst.t0 = p[0];
+        dst.t1 = p[1];
+        dst.t2 = p[2];
+    };
+
+    constexpr int kDepth = Cfg::kDepth;
+    HalfTile ring[kDepth];
+#pragma unroll
+    for (int d = 0; d < kDepth - 1; ++d) load_tile(ring[d], d);
+
+    // ---- launch-wide cutoff from the sample maxima (while the first tiles are in flight)
+    if (tid == 0) {
+        s_count = 0;
+        sm->seeds = 0;
+    }
+    __syncthreads();
+    const float neg_inf = -__builtin_inff();
+    float cutoff = neg_inf;   // -inf: everything is fetched and scored exactly
+    if (hq.ok && n_seed > 0) {   // uniform
+        uint64_t mine[kHalfSeedPerThread];
+        int have = 0;
+#pragma unroll
+        for (int r = 0; r < kHalfSeedPerThread; ++r) {
+            const int i = tid + r * kBlock;
+            const uint32_t v = i < n_seed ? seed_vals[i] : 0u;
+            mine[r] = v ? (static_cast<uint64_t>(v) << 32) | static_cast<uint32_t>(i + 1) : 0ull;
+            have += v != 0u;
+        }
+        const uint64_t b = __ballot(have != 0);   // cheap pre-reduction: most lanes hold values
+        (void)b;
+        if (have) atomicAdd(&sm->seeds, have);
+        __syncthreads();
+        if (sm->seeds >= topk) {   // uniform
+            const uint64_t t = block_select_threshold<kBlock, kHalfSeedPerThread>(mine, topk, true, 0, s_sel);
+            const float v = ordered_to_score(static_cast<uint32_t>(t >> 32));
+            cutoff = v - 2.0f * kHalfMargin - kBqSlack;
+        }
+    }
+    uint64_t thr = 0;
+    int compact_at = 2 * topk > 256 ? 2 * topk : 256;
+    if (compact_at > kCandLimit) compact_at = kCandLimit;
+
+    auto process_tile = [&](const HalfTile& t, int it) {
+        const int64_t pair = pair_begin + static_cast<int64_t>(it) * pair_stride;
+        const float a0 = half_dot(hq.h, t.t0.x, t.t0.y, t.t0.z, t.t0.w, t.t1.x, t.t1.y);
+        const float a1 = half_dot(hq.h, t.t1.z, t.t1.w, t.t2.x, t.t2.y, t.t2.z, t.t2.w);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t r = pair * 2 + u;
+            const bool in_range = pair < n_pairs && r < n;
+            const bool maybe = in_range && !((u ? a1 : a0) < cutoff);
+            if (__ballot(maybe)) {
+                // the fp32 row (lanes without a candidate re-read row 0: one cached line)
+                const Row row = load_row(feats, maybe ? r : static_cast<int64_t>(0));
+                const float s = cosine_score(q, qn, row);
+                const int64_t g = row_base + r;
+                uint64_t key = pack_key(s, static_cast<uint32_t>(g));
+                if (g == exclude_global) key = 0;
+                const bool pass = maybe && key > thr;
+                const uint64_t ballot = __ballot(pass);
+                if (ballot) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&s_count, __popcll(ballot));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    const int pos = base + lanes_below(ballot);
+                    if (pass) s_cand[pos] = key;
+                }
+            }
+        }
+        __syncthreads();
+        const int c = s_count;
+        __syncthreads();
+        if (c >= compact_at) {
+            const uint64_t local_thr = compact_candidates<kBlock, Cfg::kCandPerThread>(s_cand, &s_count, topk, false, s_sel);
+            if (local_thr > thr) {
+                thr = local_thr;
+                if (hq.ok) {
+                    const float local_cut = ordered_to_score(static_cast<uint32_t>(thr >> 32)) - kHalfMargin - kBqSlack;
+                    cutoff = local_cut > cutoff ? local_cut : cutoff;
+                }
+            }
+        }
+    };
+
+    for (int it = 0; it < iters; it += kDepth) {
+#pragma unroll
+        for (int sidx = 0; sidx < kDepth; ++sidx) {
+            load_tile(ring[(sidx + kDepth - 1) % kDepth], it + sidx + kDepth - 1);
+            if (it + sidx < iters) process_tile(ring[sidx], it + sidx);  // uniform
+        }
+    }
+
+    __syncthreads();
+    if (s_count > kRankDirectMax && s_count > topk)  // uniform
+        compact_candidates<kBlock, Cfg::kCandPerThread>(s_cand, &s_count, topk, true, s_sel);
+    __syncthreads();
+    block_rank_and_store<kBlock>(s_cand, s_count, block_lists + static_cast<int64_t>(bid) * topk, topk);
+}
+
+}  // namespace mi355

@@ -200,6 +200,14 @@ class CosineEngine:
         return {"special_rows": sp.value, "queued_queries": qd.value, "candidates_total": tot.value,
                 "candidates_max": mx.value}
 
+    def set_replica(self, mode: int) -> None:
+        """capi.REPLICA_AUTO / REPLICA_OFF (fp32 rows only) / REPLICA_ON: which copy single queries scan."""
+        capi.check(self._lib.mi355rec_set_replica(self._h, int(mode)), self._h)
+
+    def rebuild_replica(self) -> None:
+        """After overwriting a borrowed catalogue in place (synchronous)."""
+        capi.check(self._lib.mi355rec_rebuild_replica(self._h), self._h)
+
     def set_batch_path(self, path: int) -> None:
         """capi.BATCH_AUTO / BATCH_MULTI / BATCH_MFMA (tests, A/B measurements)."""
         capi.check(self._lib.mi355rec_set_batch_path(self._h, int(path)), self._h)

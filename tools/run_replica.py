@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""A/B driver for the single-query scan over the fp16 replica (csrc/replica.hip.h) against
+the fp32 scan: same queries through both, keys compared bit for bit, streamed step time of each.
+  python3 tools/run_replica.py --rows 10000000 --topn 100 --steps 300
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/x -- python3 tools/run_replica.py ...
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--topn", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--check", type=int, default=64, help="queries compared between the two paths")
+    ap.add_argument("--only", type=int, default=-1, help="time only this mode (1 fp32 rows, 2 replica)")
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    from spotify_recommender_amd import CosineEngine, capi
+    from spotify_recommender_amd.synth import synthetic_catalogue
+
+    t = synthetic_catalogue(args.rows, seed=12345)
+    rows = [(k * 7919 + 13) % args.rows for k in range(max(args.check, args.steps + 20))]
+    out = {"rows": args.rows, "topn": args.topn}
+    with CosineEngine(t) as eng:
+        st = eng.stats()
+        out["replica_build_ms"] = round(float(st.replica_build_ms), 3)
+        out["replica_grid_blocks"] = int(st.replica_grid_blocks)
+        keys = {m: torch.zeros((args.check, args.topn), dtype=torch.int64, device="cuda") for m in (1, 2)}
+        if args.only < 0:
+            for mode in (capi.REPLICA_OFF, capi.REPLICA_ON):
+                eng.set_replica(mode)
+                for i in range(args.check):
+                    eng.enqueue_row_keys(rows[i], args.topn, keys[mode][i])
+                torch.cuda.synchronize()
+            same = bool(torch.equal(keys[1], keys[2]))
+            out["keys_identical"] = same
+            if not same:
+                bad = (keys[1] != keys[2]).any(dim=1).nonzero().flatten().tolist()
+                out["first_bad_queries"] = bad[:8]
+            # streamed too
+            sk = torch.zeros((args.check, args.topn), dtype=torch.int64, device="cuda")
+            eng.set_replica(capi.REPLICA_ON)
+            for i in range(args.check):
+                eng.enqueue_row_keys_streamed(rows[i], args.topn, sk[i])
+            eng.enqueue_flush()
+            torch.cuda.synchronize()
+            out["streamed_identical"] = bool(torch.equal(sk, keys[1]))
+        ring = torch.zeros((64, args.topn), dtype=torch.int64, device="cuda")
+        for mode, name in ((capi.REPLICA_OFF, "fp32_rows"), (capi.REPLICA_ON, "replica")):
+            if args.only >= 0 and args.only != mode:
+                continue
+            eng.set_replica(mode)
+            for i in range(20):
+                eng.enqueue_row_keys_streamed(rows[i], args.topn, ring[i % 64])
+            eng.enqueue_flush()
+            torch.cuda.synchronize()
+            eng.set_timing(8)
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                eng.enqueue_row_keys_streamed(rows[20 + i], args.topn, ring[i % 64])
+            eng.enqueue_flush()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.steps
+            st = eng.stats()
+            eng.set_timing(0)
+            out[name] = {"us_per_step": round(dt * 1e6, 2), "queries_per_s": round(1.0 / dt, 1),
+                         "scan_kernel_us": round(float(st.last_scan_ms) * 1e3, 2)}
+            # one query alone, synchronous API
+            lat = []
+            for i in range(200):
+                t1 = time.perf_counter()
+                eng.query_row_topn(rows[i], args.topn)
+                lat.append(time.perf_counter() - t1)
+            lat.sort()
+            out[name]["p50_us"] = round(lat[len(lat) // 2] * 1e6, 1)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
