@@ -132,6 +132,10 @@ int mi355rec_create_device(const float* feats_dev, int64_t n, int dim,
 #define MI355REC_REPLICA_ON 2
 int mi355rec_set_replica(mi355rec_t* h, int mode);
 int mi355rec_rebuild_replica(mi355rec_t* h);
+/* Diagnostics, cumulative since create (synchronises the device): scans that
+ * went over the replica, and rows those scans fetched from the fp32 matrix for
+ * the exact chain.  Either pointer may be NULL. */
+int mi355rec_replica_counters(mi355rec_t* h, int64_t* scans, int64_t* rescored_rows);
 
 /* Replaces Recommender::~Recommender (Recommender.cu:86-98). */
 void mi355rec_destroy(mi355rec_t* h);

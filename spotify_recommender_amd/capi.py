@@ -71,6 +71,7 @@ SIGNATURES = {
     "mi355rec_set_batch_path": (c_int, [c_void_p, c_int]),
     "mi355rec_set_replica": (c_int, [c_void_p, c_int]),
     "mi355rec_rebuild_replica": (c_int, [c_void_p]),
+    "mi355rec_replica_counters": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64)]),
     "mi355rec_batched_last_counters": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int64),
                                                POINTER(c_int32)]),
     "mi355rec_enqueue_merge_keys": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

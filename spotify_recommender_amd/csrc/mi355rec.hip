@@ -78,6 +78,8 @@ struct mi355rec {
     // fp16 replica of the catalogue (replica.hip.h) and the geometry of the scan over it
     uint4* d_half = nullptr;            // ((n + 1) / 2) pairs of rows x 48 B
     uint32_t* d_half_seed = nullptr;    // kHalfSeedMaxGrid x 8 sample maxima of the query in flight
+    unsigned long long* d_half_rescored = nullptr;   // [kRideMaxLists] rows sent to the exact chain, per workgroup slot
+    int64_t half_scans = 0;             // replica scans enqueued since create
     int hgrid = 0, hiters = 0;          // plain launch
     int hsgrid = 0, hsiters = 0;        // streamed launch (one more workgroup is the merger)
     int hseed_grid = 0;
@@ -254,6 +256,8 @@ int build_replica(mi355rec* h) {
     if (!h->d_half) {
         HIP_TRY(h, hipMalloc(&h->d_half, static_cast<size_t>(n_padded) * 24));
         HIP_TRY(h, hipMalloc(&h->d_half_seed, sizeof(uint32_t) * kHalfSeedMaxGrid * kHalfSeedWaves));
+        HIP_TRY(h, hipMalloc(&h->d_half_rescored, sizeof(unsigned long long) * kRideMaxLists));
+        HIP_TRY(h, hipMemsetAsync(h->d_half_rescored, 0, sizeof(unsigned long long) * kRideMaxLists, h->stream));
     }
     hipEvent_t a = nullptr, b = nullptr;
     const bool timed = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess;
@@ -452,16 +456,17 @@ int enqueue_scan(mi355rec* h, int64_t query_row, const float* query12,
     const PrevMerge none{nullptr, 0, 0, nullptr};
     if (use_half(h, upper_dev)) {
         *n_lists = h->hgrid;
+        ++h->half_scans;
         enqueue_half_seed(h, query_row, qa, exclude_global, s);
         const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, s);
         if (query_row >= 0) {
             hipLaunchKernelGGL((scan_half_kernel<HalfConfig, true, false>), dim3(h->hgrid), dim3(HalfConfig::kBlock), 0, s,
                                h->d_feats, h->d_half, h->n, h->hiters, h->row_base, qa, query_row, exclude_global, topn,
-                               h->d_block_lists, h->d_half_seed, h->hseed_grid * kHalfSeedWaves, none);
+                               h->d_block_lists, h->d_half_seed, h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, none);
         } else {
             hipLaunchKernelGGL((scan_half_kernel<HalfConfig, false, false>), dim3(h->hgrid), dim3(HalfConfig::kBlock), 0, s,
                                h->d_feats, h->d_half, h->n, h->hiters, h->row_base, qa, static_cast<int64_t>(0), exclude_global,
-                               topn, h->d_block_lists, h->d_half_seed, h->hseed_grid * kHalfSeedWaves, none);
+                               topn, h->d_block_lists, h->d_half_seed, h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, none);
         }
         timing_end(h, h->ev_scan, h->n_scan_pairs, slot, s);
         HIP_TRY(h, hipGetLastError());
@@ -631,18 +636,19 @@ int enqueue_streamed(mi355rec* h, int64_t query_row, const float* query12, int64
     QueryArg qa;
     std::memset(&qa, 0, sizeof qa);
     if (use_half(h, nullptr)) {
+        ++h->half_scans;
         if (query_row < 0) std::memcpy(qa.q, query12, sizeof qa.q);
         enqueue_half_seed(h, query_row, qa, exclude_global, s);
         const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, s);
         if (query_row >= 0) {
             hipLaunchKernelGGL((scan_half_kernel<HalfConfig, true, true>), dim3(h->hsgrid + 1), dim3(HalfConfig::kBlock), 0, s,
                                h->d_feats, h->d_half, h->n, h->hsiters, h->row_base, qa, query_row, exclude_global, topn,
-                               h->d_stream_lists[buf], h->d_half_seed, h->hseed_grid * kHalfSeedWaves, prev);
+                               h->d_stream_lists[buf], h->d_half_seed, h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, prev);
         } else {
             hipLaunchKernelGGL((scan_half_kernel<HalfConfig, false, true>), dim3(h->hsgrid + 1), dim3(HalfConfig::kBlock), 0, s,
                                h->d_feats, h->d_half, h->n, h->hsiters, h->row_base, qa, static_cast<int64_t>(0),
                                exclude_global, topn, h->d_stream_lists[buf], h->d_half_seed, h->hseed_grid * kHalfSeedWaves,
-                               prev);
+                               h->d_half_rescored, prev);
         }
         timing_end(h, h->ev_scan, h->n_scan_pairs, slot, s);
         HIP_TRY(h, hipGetLastError());
@@ -917,6 +923,7 @@ void mi355rec_destroy(mi355rec_t* h) {
     if (h->d_seed_vals) (void)hipFree(h->d_seed_vals);
     if (h->d_half) (void)hipFree(h->d_half);
     if (h->d_half_seed) (void)hipFree(h->d_half_seed);
+    if (h->d_half_rescored) (void)hipFree(h->d_half_rescored);
     if (h->d_keys) (void)hipFree(h->d_keys);
     if (h->d_idx) (void)hipFree(h->d_idx);
     if (h->d_score) (void)hipFree(h->d_score);
@@ -1129,6 +1136,21 @@ int mi355rec_set_replica(mi355rec_t* h, int mode) {
     if (mode == MI355REC_REPLICA_ON && !h->d_half && h->n > 0)
         return fail(h, MI355REC_ERR_INVALID_ARG, "this handle was created without a replica (MI355REC_REPLICA=0)");
     h->replica_mode = mode;
+    return MI355REC_OK;
+}
+
+int mi355rec_replica_counters(mi355rec_t* h, int64_t* scans, int64_t* rescored_rows) {
+    if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    if (scans) *scans = h->half_scans;
+    if (rescored_rows) *rescored_rows = 0;
+    if (!h->d_half_rescored || !rescored_rows) return MI355REC_OK;
+    DeviceGuard guard(h->device);
+    std::vector<unsigned long long> slots(kRideMaxLists);
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(slots.data(), h->d_half_rescored, sizeof(unsigned long long) * kRideMaxLists, hipMemcpyDeviceToHost));
+    unsigned long long sum = 0;
+    for (unsigned long long v : slots) sum += v;
+    *rescored_rows = static_cast<int64_t>(sum);
     return MI355REC_OK;
 }
 

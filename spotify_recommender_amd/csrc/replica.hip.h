@@ -180,6 +180,7 @@ struct HalfScanSmemT {
     SelectSmem sel;
     int count;
     int seeds;
+    int rescored;
 };
 template <typename Cfg>
 union HalfScanOrMergeSmem {
@@ -196,9 +197,9 @@ template <typename Cfg, bool kQueryFromRow, bool kWithMerge>
 __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_half_kernel(
     const float* __restrict__ feats, const uint4* __restrict__ half, int64_t n, int iters, int64_t row_base,
     QueryArg qarg, int64_t query_row, int64_t exclude_global, int topk, uint64_t* __restrict__ block_lists,
-    const uint32_t* __restrict__ seed_vals, int n_seed, PrevMerge prev) {
+    const uint32_t* __restrict__ seed_vals, int n_seed, unsigned long long* __restrict__ rescored /* [scanning workgroups] */,
+    PrevMerge prev) {
     constexpr int kBlock = Cfg::kBlock;
-    constexpr int kTileRows = Cfg::kTileRows;
     __shared__ typename std::conditional<kWithMerge, HalfScanOrMergeSmem<Cfg>, HalfScanSmemT<Cfg>>::type s_mem;
     HalfScanSmemT<Cfg>* sm;
     if constexpr (kWithMerge) {
@@ -258,7 +259,9 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_half_kernel(
     if (tid == 0) {
         s_count = 0;
         sm->seeds = 0;
+        sm->rescored = 0;
     }
+    int n_rescored = 0;   // wave-uniform: rows this wave sent to the exact chain (diagnostics)
     __syncthreads();
     const float neg_inf = -__builtin_inff();
     float cutoff = neg_inf;   // -inf: everything is fetched and scored exactly
@@ -272,8 +275,6 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_half_kernel(
             mine[r] = v ? (static_cast<uint64_t>(v) << 32) | static_cast<uint32_t>(i + 1) : 0ull;
             have += v != 0u;
         }
-        const uint64_t b = __ballot(have != 0);   // cheap pre-reduction: most lanes hold values
-        (void)b;
         if (have) atomicAdd(&sm->seeds, have);
         __syncthreads();
         if (sm->seeds >= topk) {   // uniform
@@ -295,7 +296,9 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_half_kernel(
             const int64_t r = pair * 2 + u;
             const bool in_range = pair < n_pairs && r < n;
             const bool maybe = in_range && !((u ? a1 : a0) < cutoff);
-            if (__ballot(maybe)) {
+            const uint64_t any = __ballot(maybe);
+            if (any) {
+                n_rescored += __popcll(any);
                 // the fp32 row (lanes without a candidate re-read row 0: one cached line)
                 const Row row = load_row(feats, maybe ? r : static_cast<int64_t>(0));
                 const float s = cosine_score(q, qn, row);
@@ -336,7 +339,9 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_half_kernel(
         }
     }
 
+    if (lane == 0 && n_rescored) atomicAdd(&sm->rescored, n_rescored);
     __syncthreads();
+    if (tid == 0) rescored[bid] += static_cast<unsigned long long>(sm->rescored);   // launches of a handle are stream-ordered
     if (s_count > kRankDirectMax && s_count > topk)  // uniform
         compact_candidates<kBlock, Cfg::kCandPerThread>(s_cand, &s_count, topk, true, s_sel);
     __syncthreads();

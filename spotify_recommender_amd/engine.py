@@ -204,6 +204,12 @@ class CosineEngine:
         """capi.REPLICA_AUTO / REPLICA_OFF (fp32 rows only) / REPLICA_ON: which copy single queries scan."""
         capi.check(self._lib.mi355rec_set_replica(self._h, int(mode)), self._h)
 
+    def replica_counters(self) -> dict:
+        """Cumulative: scans over the replica and rows they sent to the exact fp32 chain (synchronises)."""
+        scans, rows = ctypes.c_int64(0), ctypes.c_int64(0)
+        capi.check(self._lib.mi355rec_replica_counters(self._h, ctypes.byref(scans), ctypes.byref(rows)), self._h)
+        return {"scans": int(scans.value), "rescored_rows": int(rows.value)}
+
     def rebuild_replica(self) -> None:
         """After overwriting a borrowed catalogue in place (synchronous)."""
         capi.check(self._lib.mi355rec_rebuild_replica(self._h), self._h)

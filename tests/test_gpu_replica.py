@@ -1,0 +1,280 @@
+"""The single-query scan over the fp16 replica (csrc/replica.hip.h) against the oracle and
+against the fp32 scan, through the C-ABI.
+
+The replica only rules rows OUT; every key that leaves the kernel is computed from the
+fp32 row by the exact chain, so the bar is the usual one: scores bit-exact, ids identical
+(tie-aware).  The diagnostics (rows sent to the exact chain) are asserted as well, so a
+build that silently re-scored everything — or nothing — would fail.
+
+The launch-wide cutoff comes from a sample: up to 256 regions of 1024 rows, spaced
+(n / regions) & ~1 rows apart; "in the sample" below means rows placed there.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.parity import assert_topn_matches
+from tests.test_batched_margin import catalogues
+
+pytestmark = pytest.mark.gpu
+
+ON, OFF = 2, 1
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.fixture(scope="module")
+def Engine(torch_cuda):
+    from spotify_recommender_amd.engine import CosineEngine
+    return CosineEngine
+
+
+def sample_rows(n):
+    regions = min(256, n // 1024)
+    stride = (n // regions) & ~1
+    return regions, stride
+
+
+def check_queries(eng, f, queries, excl, topns, label, rows=None):
+    """queries[i] (vector) or rows[i] (catalogue row as the query) through the replica scan vs the oracle."""
+    for i in range(len(excl)):
+        q = f[rows[i]] if rows is not None else queries[i]
+        want = oracle.scores(f, np.ascontiguousarray(q, dtype=np.float32), threads=0)
+        ex = int(excl[i])
+        for topn in topns:
+            if rows is not None:
+                idx, sc = eng.query_row_topn(int(rows[i]), topn)
+            else:
+                idx, sc = eng.query_topn(q, ex, topn)
+            try:
+                assert_topn_matches(idx, sc, want, ex, topn, ref_idx=oracle.topn_heap(want, ex, topn))
+            except AssertionError as e:
+                raise AssertionError(f"{label}: query {i} topn {topn}: {e}") from e
+
+
+def test_uniform_catalogue_and_the_rescored_share(Engine):
+    rng = np.random.default_rng(7)
+    n = 2_500_003                      # AUTO takes the replica from 2 Mi rows; odd: the last pair is half empty
+    f = rng.random((n, 12), dtype=np.float32)
+    rows = rng.integers(0, n, size=12)
+    rows[0], rows[1] = n - 1, 0
+    with Engine(f) as eng:
+        st = eng.stats()
+        assert st.replica_active == 1 and st.replica_bytes_per_query == (n + 1) // 2 * 48
+        before = eng.replica_counters()
+        check_queries(eng, f, None, rows, (1, 10, 100, 1000), "uniform 2.5 M", rows=rows)
+        after = eng.replica_counters()
+        scans = after["scans"] - before["scans"]
+        assert scans == 12 * 4
+        per_scan = (after["rescored_rows"] - before["rescored_rows"]) / scans
+        # the fast path really is one: a few thousand of 2.5 M rows go to the exact chain, not all and not none
+        assert 1 <= per_scan < 0.02 * n, per_scan
+        # the same queries over the fp32 rows: identical keys
+        import torch
+        k_on = torch.zeros((len(rows), 100), dtype=torch.int64, device="cuda")
+        k_off = torch.zeros_like(k_on)
+        for i, r in enumerate(rows):
+            eng.enqueue_row_keys(int(r), 100, k_on[i])
+        eng.set_replica(OFF)
+        assert eng.stats().replica_active == 0
+        for i, r in enumerate(rows):
+            eng.enqueue_row_keys(int(r), 100, k_off[i])
+        torch.cuda.synchronize()
+        assert torch.equal(k_on, k_off)
+        assert eng.replica_counters()["scans"] == after["scans"] + len(rows)
+
+
+def test_streamed_queries_over_the_replica(Engine, torch_cuda):
+    torch = torch_cuda
+    rng = np.random.default_rng(8)
+    n = 900_001
+    f = rng.random((n, 12), dtype=np.float32)
+    rows = rng.integers(0, n, size=9)
+    vecs = rng.random((4, 12), dtype=np.float32)
+    with Engine(f) as eng:
+        eng.set_replica(ON)
+        keys = torch.zeros((13, 100), dtype=torch.int64, device="cuda")
+        for i, r in enumerate(rows):
+            eng.enqueue_row_keys_streamed(int(r), 100, keys[i])
+        for j, v in enumerate(vecs):
+            eng.enqueue_query_keys_streamed(v, -1, 100, keys[9 + j])
+        eng.enqueue_flush()
+        torch.cuda.synchronize()
+        got = keys.cpu().numpy().view(np.uint64)
+        for i in range(13):
+            q = f[rows[i]] if i < 9 else vecs[i - 9]
+            ex = int(rows[i]) if i < 9 else -1
+            want = oracle.scores(f, q, threads=0)
+            idx = (~got[i] & np.uint64(0xffffffff)).astype(np.int64)
+            assert_topn_matches(idx, None, want, ex, 100, ref_idx=oracle.topn_heap(want, ex, 100))
+        # alternating with fp32-row queries in one stream: the riding merge takes either kind of list
+        eng.set_replica(OFF)
+        eng.enqueue_row_keys_streamed(int(rows[0]), 100, keys[0])
+        eng.set_replica(ON)
+        eng.enqueue_row_keys_streamed(int(rows[1]), 100, keys[1])
+        eng.set_replica(OFF)
+        eng.enqueue_row_keys_streamed(int(rows[2]), 100, keys[2])
+        eng.enqueue_flush()
+        torch.cuda.synchronize()
+        again = keys.cpu().numpy().view(np.uint64)
+        assert np.array_equal(again[:3], got[:3])
+
+
+@pytest.mark.parametrize("which", range(7))
+def test_hostile_value_ranges(Engine, which):
+    """The catalogues the error bound is checked on in tests/test_batched_margin.py (rounding
+    midpoints, subnormal tails after normalisation, rows at the validity edge, huge rows ...)."""
+    rng = np.random.default_rng(100 + which)
+    n = 400_003
+    name, f = list(catalogues(rng, n))[which]
+    f = np.ascontiguousarray(f, dtype=np.float32)
+    queries = np.stack([f[rng.integers(0, n)], f[rng.integers(0, n)] * np.float32(3), rng.random(12, dtype=np.float32),
+                        rng.normal(0, 1, 12).astype(np.float32), np.eye(12, dtype=np.float32)[3]])
+    with Engine(f) as eng:
+        eng.set_replica(ON)
+        check_queries(eng, f, queries, np.full(len(queries), -1), (1, 100, 1000), name)
+
+
+def test_special_rows_and_queries(Engine):
+    """NaN / inf / denormal / zero / overflowing rows inside and outside the sampled regions, and
+    queries the bound cannot be claimed for (zero, tiny, huge, NaN, inf): exact chain only."""
+    rng = np.random.default_rng(9)
+    n = 600_011
+    f = rng.random((n, 12), dtype=np.float32)
+    regions, stride = sample_rows(n)
+    sampled = np.array([b * stride + o for b in range(0, regions, 5) for o in (0, 1, 127, 128, 600, 1023)])
+    unsampled = np.array([b * stride + o for b in range(2, regions, 7) for o in (1024, 1500, stride - 1)])
+    vals = [np.nan, np.inf, -np.inf, 1e-42, 3e19, -3e19, 0.0]
+    for i, r in enumerate(np.concatenate([sampled, unsampled])):
+        f[r, rng.integers(0, 12)] = vals[i % len(vals)]
+    f[sampled[::4] + 2] = 0.0                        # exactly-zero rows
+    f[unsampled[::3] + 1] = np.float32(1e-42)        # rows whose squares underflow
+    f[sampled[::6] + 3] = np.float32(6e-5) * rng.random((len(sampled[::6]), 12), dtype=np.float32)   # around the validity edge
+    big = np.zeros(12, dtype=np.float32)
+    big[:3] = (3e19, 3e19, -3e19)
+    f[sampled[::9] + 4] = big
+    qrows = rng.choice(n, size=6, replace=False)
+    queries = f[qrows].copy()
+    excl = qrows.astype(np.int64)
+    extra = np.zeros((8, 12), dtype=np.float32)
+    extra[0, :3] = 1e19                              # exact = inf / inf = NaN -> clamped to 1.0 for the overflow rows
+    extra[1] = f[sampled[1]]                          # a component is inf
+    extra[2] = f[sampled[0]]                          # a component is NaN
+    extra[3] = 0.0
+    extra[4] = rng.random(12, dtype=np.float32) * np.float32(1e-5)    # below the validity edge
+    extra[5] = rng.random(12, dtype=np.float32) * np.float32(1e-4)    # straddles it
+    extra[6] = -rng.random(12, dtype=np.float32)      # every cosine negative
+    extra[7] = rng.normal(0, 1, 12).astype(np.float32) * np.float32(1e17)
+    queries = np.concatenate([queries, extra])
+    excl = np.concatenate([excl, np.full(8, -1)])
+    with Engine(f) as eng:
+        eng.set_replica(ON)
+        check_queries(eng, f, queries, excl, (1, 100), "special rows / queries")
+        # a zero row as the query (row index API): every score is 0, the order is by row index
+        z = int(sampled[0] + 2)
+        idx, sc = eng.query_row_topn(z, 50)
+        want = oracle.scores(f, f[z], threads=0)
+        assert_topn_matches(idx, sc, want, z, 50, ref_idx=oracle.topn_heap(want, z, 50))
+
+
+@pytest.mark.parametrize("descending", [False, True])
+def test_catalogue_ordered_by_similarity(Engine, descending):
+    """The sample sees the far end of an ordered catalogue only through its spread regions."""
+    rng = np.random.default_rng(10)
+    n = 700_003
+    t = np.linspace(0.0, 1.0, n, dtype=np.float32)
+    if descending:
+        t = t[::-1]
+    f = np.ones((n, 12), dtype=np.float32)
+    f[:, :6] = (0.1 + 0.9 * t)[:, None]
+    f[:, 6:] += rng.random((n, 6), dtype=np.float32) * np.float32(1e-3)
+    q = np.ones((4, 12), dtype=np.float32)
+    q[:, 6:] += rng.random((4, 6), dtype=np.float32) * np.float32(0.02)
+    with Engine(f) as eng:
+        eng.set_replica(ON)
+        check_queries(eng, f, q, np.full(4, -1), (1, 100, 1000), f"ordered desc={descending}")
+
+
+def test_duplicates_and_mass_ties_at_the_nth_score(Engine):
+    rng = np.random.default_rng(11)
+    n = 500_009
+    f = rng.random((n, 12), dtype=np.float32)
+    regions, stride = sample_rows(n)
+    qrow = int(rng.integers(0, n))
+    dup = np.concatenate([np.arange(0, regions, 3) * stride + 5, rng.choice(n, 150, replace=False)])
+    f[dup] = f[qrow]                                  # > topn exact duplicates of the query, many of them sampled
+    v = rng.random(12, dtype=np.float32) + np.float32(0.5)
+    tie_rows = rng.choice(np.setdiff1d(np.arange(n), dup), size=5000, replace=False)
+    f[tie_rows] = v[None, :] * (np.float32(2.0) ** rng.integers(-3, 4, size=5000)).astype(np.float32)[:, None]
+    better = rng.choice(np.setdiff1d(np.arange(n), np.concatenate([tie_rows, dup])), size=60, replace=False)
+    tie_query = v + rng.random(12, dtype=np.float32) * np.float32(0.05)
+    f[better] = tie_query[None, :] * (1 + rng.random((60, 12), dtype=np.float32) * np.float32(1e-3))
+    s = oracle.scores(f, tie_query, threads=0)
+    top = np.sort(s)[::-1]
+    assert top[99] == top[100], "construction: the 100th score must sit inside the tie run"
+    with Engine(f) as eng:
+        eng.set_replica(ON)
+        check_queries(eng, f, np.stack([tie_query, tie_query * np.float32(2)]), np.array([-1, -1]), (100, 1000), "mass ties")
+        check_queries(eng, f, None, np.array([qrow]), (1, 100, 300), "duplicates of the query", rows=np.array([qrow]))
+
+
+def test_small_and_ragged_shards(Engine):
+    """Fewer rows than one sampled region, fewer than topn, one row, row_base shards."""
+    rng = np.random.default_rng(12)
+    for n in (1, 2, 3, 777, 1023, 1024, 1025, 2049, 5000):
+        f = rng.random((n, 12), dtype=np.float32)
+        with Engine(f) as eng:
+            eng.set_replica(ON)
+            rows = np.unique(np.array([0, n - 1, n // 2]))
+            check_queries(eng, f, None, rows, (1, 10, 100), f"n={n}", rows=rows)
+    n = 300_000
+    f = rng.random((n, 12), dtype=np.float32)
+    lo = 123_457
+    with Engine(f[lo:], row_base=lo) as eng:          # a shard: keys carry global row ids
+        eng.set_replica(ON)
+        q = rng.random(12, dtype=np.float32)
+        idx, sc = eng.query_topn(q, lo + 5, 100)
+        want = oracle.scores(f, q, threads=0)
+        want[:lo] = -2.0                               # rows of other shards cannot appear
+        assert_topn_matches(idx, sc, want, lo + 5, 100)
+
+
+def test_rebuild_after_overwriting_a_borrowed_matrix(Engine, torch_cuda):
+    torch = torch_cuda
+    rng = np.random.default_rng(13)
+    n = 300_001
+    f0 = rng.random((n, 12), dtype=np.float32)
+    f1 = rng.random((n, 12), dtype=np.float32)
+    t = torch.from_numpy(f0).cuda()
+    with Engine(t) as eng:
+        eng.set_replica(ON)
+        check_queries(eng, f0, None, np.array([17]), (100,), "before", rows=np.array([17]))
+        t.copy_(torch.from_numpy(f1))
+        torch.cuda.synchronize()
+        eng.rebuild_replica()
+        check_queries(eng, f1, None, np.array([17]), (100,), "after the rebuild", rows=np.array([17]))
+
+
+def test_handle_without_a_replica(Engine):
+    rng = np.random.default_rng(14)
+    f = rng.random((50_000, 12), dtype=np.float32)
+    os.environ["MI355REC_REPLICA"] = "0"
+    try:
+        with Engine(f) as eng:
+            st = eng.stats()
+            assert st.replica_bytes_per_query == 0 and st.replica_active == 0
+            with pytest.raises(RuntimeError, match="without a replica"):
+                eng.set_replica(ON)
+            idx, sc = eng.query_row_topn(3, 10)
+            want = oracle.scores(f, f[3], threads=0)
+            assert_topn_matches(idx, sc, want, 3, 10)
+            assert eng.replica_counters() == {"scans": 0, "rescored_rows": 0}
+    finally:
+        del os.environ["MI355REC_REPLICA"]

@@ -48,6 +48,16 @@ def run_case(Engine, f, queries, excl, label, topns=(1, 100, 128), batches=(13, 
         for b in range(single):   # the single-query kernel on the same data
             idx, sc = eng.query_topn(queries[b], int(excl[b]), 100)
             assert_topn_matches(idx, sc, want[b], int(excl[b]), 100, ref_idx=oracle.topn_heap(want[b], int(excl[b]), 100))
+        # ... and the scan over the fp16 replica (csrc/replica.hip.h; forced on: AUTO starts at 2 Mi rows):
+        # its launch-wide cutoff also comes from a sample, of an approximation with a much wider margin
+        eng.set_replica(2)
+        for b in range(min(len(queries), 8)):
+            for topn in (1, 100, 1000):
+                idx, sc = eng.query_topn(queries[b], int(excl[b]), topn)
+                try:
+                    assert_topn_matches(idx, sc, want[b], int(excl[b]), topn, ref_idx=oracle.topn_heap(want[b], int(excl[b]), topn))
+                except AssertionError as e:
+                    raise AssertionError(f"{label}: replica scan, topn {topn} query {b}: {e}") from e
 
 
 def perturbed_ones(rng, count):
