@@ -59,11 +59,13 @@ def parse_args():
                     help="N > 1: single queries whose per-rank keys share one all-gather")
     ap.add_argument("--no-streamed", action="store_true",
                     help="merge every query in its own launch instead of inside the next query's scan launch")
+    ap.add_argument("--no-replica", action="store_true",
+                    help="scan the fp32 rows (48 B/row, the reference's own traffic) instead of the fp16 replica")
     ap.add_argument("--latency-queries", type=int, default=1000)
     return ap.parse_args()
 
 
-def pmc_traffic(rows_local: int):
+def pmc_traffic(rows_local: int, replica: bool = False):
     """HBM bytes per scan launch from the committed rocprofv3 PMC passes
     (profiles/*_pmc_hbm_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs
     of this same script, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950
@@ -72,8 +74,10 @@ def pmc_traffic(rows_local: int):
     try:
         files = sorted((ROOT / "profiles").glob("*_pmc_hbm_traffic.json"))
         data = json.loads(files[-1].read_text())
+        want = "scan_half_kernel" if replica else "scan_kernel"
+        alg = (rows_local + 1) // 2 * 48 if replica else rows_local * BYTES_PER_ROW
         for name, k in data["kernels"].items():
-            if "scan_kernel" in name and k.get("algorithmic_bytes_per_launch") == rows_local * BYTES_PER_ROW:
+            if want in name and k.get("algorithmic_bytes_per_launch") == alg:
                 return int(k["hbm_bytes_per_launch"]), f"profiles/{files[-1].name}"
     except Exception:
         pass
@@ -180,6 +184,10 @@ def main():
     torch.cuda.empty_cache()
 
     eng = CosineEngine(shard, row_base=lo)
+    from spotify_recommender_amd import capi
+    if args.no_replica:
+        eng.set_replica(capi.REPLICA_OFF)
+    replica = bool(eng.stats().replica_active)
     sharded = ShardedEngine(eng, max_topn=topn, always_gather=force_sharded) if (world > 1 or force_sharded) else None
     out_keys = torch.zeros(topn, dtype=torch.int64, device=dev)
 
@@ -249,9 +257,35 @@ def main():
         host_idx = res
     lat.sort()
 
+    # The same stream of single queries over the fp32 rows (the reference's own 48 B per row),
+    # outside the timed region: what the replica buys, measured in the same process.
+    fp32_rows = None
+    if replica and sharded is None and streamed:
+        eng.set_replica(capi.REPLICA_OFF)
+        for k in range(10):
+            step(k)
+        flush()
+        fence()
+        eng.set_timing(4)
+        t1 = time.perf_counter()
+        for k in range(10, 110):
+            step(k % total_q)
+        flush()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / 100
+        st32 = eng.stats()
+        eng.set_timing(False)
+        eng.set_replica(capi.REPLICA_AUTO)
+        k_ms = float(st32.last_scan_ms)
+        fp32_rows = {"kernel": "mi355::scan_kernel<ScanCfg<512,1,6,2>, true, false, 0, true>", "steps": 100,
+                     "ms_per_step": round(dt * 1e3, 5), "value": round(1.0 / dt, 1), "unit": "queries/s",
+                     "algorithmic_bytes_per_launch": (hi - lo) * BYTES_PER_ROW,
+                     "avg_kernel_ms": round(k_ms, 5),
+                     "achieved": round((hi - lo) * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
+                     "frac": round((hi - lo) * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if k_ms > 0 else None}
+
     # micro-batched throughput, outside the timed region:
     # 12 queries share one pass over the catalogue, seed/final merge launches shared by 36
-    from spotify_recommender_amd import capi
 
     def timed(fn, reps):
         fn()
@@ -390,9 +424,21 @@ def main():
     if rank == 0:
         qps = args.steps / elapsed
         scan_ms = float(st.last_scan_ms) if not args.no_kernel_events else 0.0
-        achieved = ((hi - lo) * BYTES_PER_ROW / (scan_ms * 1e-3) / 1e9) if scan_ms > 0 else None
-        cache_resident = (hi - lo) * BYTES_PER_ROW <= 256 * 2**20
-        traffic_bytes, traffic_source = pmc_traffic(hi - lo)
+        alg_bytes = int(st.replica_bytes_per_query) if replica else (hi - lo) * BYTES_PER_ROW
+        achieved = (alg_bytes / (scan_ms * 1e-3) / 1e9) if scan_ms > 0 else None
+        # a pass only finds its bytes in the 256 MiB Infinity Cache if the whole buffer survives one
+        # full pass of itself plus the fp32 fetches: half the cache is the most that can be hoped for
+        cache_resident = alg_bytes <= 128 * 2**20
+        traffic_bytes, traffic_source = pmc_traffic(hi - lo, replica)
+        if replica:
+            kernel_name = ("mi355::scan_half_kernel<HalfCfg<512,4,3>, true, " + ("true" if streamed else "false") + "> over the "
+                           "fp16 replica (24 B/row; rows it cannot rule out are fetched from the fp32 matrix and scored by "
+                           "the exact chain" + ("; the previous query's merge rides in its last workgroup)" if streamed else ")"))
+        else:
+            kernel_name = ("mi355::scan_kernel<ScanCfg<512,1,6,2>, true, false, 0, true> (query = catalogue row; the previous "
+                           "query's merge rides in its last workgroup)" if streamed else
+                           ("mi355::scan_kernel<ScanCfg<512,1,6,2>, true, false>" if world == 1 else
+                            "mi355::scan_kernel<ScanCfg<512,1,6,2>, false, false, 0, true>"))
         line = {
             "metric": "queries/sec, cosine top-100 over a 10M x 12 fp32 catalogue",
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
@@ -413,14 +459,13 @@ def main():
             "p99_ms": round(lat[min(len(lat) - 1, int(len(lat) * 0.99))], 4) if lat else None,
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("mi355::scan_kernel<ScanCfg<512,1,6,2>, true, false, 0, true> (query = catalogue row; the previous "
-                           "query's merge rides in its last workgroup)" if streamed else
-                           ("mi355::scan_kernel<ScanCfg<512,1,6,2>, true, false>" if world == 1 else
-                            "mi355::scan_kernel<ScanCfg<512,1,6,2>, false, false, 0, true>")),
+                "kernel": kernel_name,
                 "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None,
                 "traffic": traffic_bytes, "traffic_source": traffic_source,
-                "algorithmic_bytes_per_launch": (hi - lo) * BYTES_PER_ROW,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "bytes_per_row": 24 if replica else BYTES_PER_ROW,
+                "survey_bytes_per_row": BYTES_PER_ROW,
                 "avg_kernel_ms": round(scan_ms, 5) if scan_ms else None,
                 "merge_kernel_ms": round(float(st.last_merge_ms), 5),
                 "stream_probe_gbps": round(probe_gbps, 1) if probe_gbps else None,
@@ -428,6 +473,13 @@ def main():
                 "infinity_cache_resident": bool(cache_resident),
             },
         }
+        if replica:
+            rc = eng.replica_counters()
+            line["roofline"]["rescored_rows_per_query"] = round(rc["rescored_rows"] / max(1, rc["scans"]), 1)
+            line["roofline"]["note"] = ("achieved / frac are for the bytes this kernel streams (the 24 B/row fp16 replica); "
+                                        "SURVEY.md §8(d) prices a query at 48 B/row, i.e. the fp32 scan in `fp32_rows`")
+        if fp32_rows is not None:
+            line["fp32_rows"] = fp32_rows
         if micro is not None:
             line["microbatch"] = micro
         if batched is not None:

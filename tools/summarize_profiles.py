@@ -51,6 +51,9 @@ for k, d in out["kernels"].items():
     alg = None
     if "scan_kernel" in k or "stream_probe" in k or "scan_multi_kernel" in k:
         alg = rows * 48
+    elif "scan_half_kernel" in k:
+        alg = (rows + 1) // 2 * 48
+        d["note"] = "scan over the fp16 replica: 24 B per row + the fp32 rows it cannot rule out (a few thousand per query)"
     elif "bq_pass_kernel" in k:
         # pass 2 (<.., true, ..>) reads every row once; pass 1 every 4th 32-row tile
         alg = rows * 48 if ", true" in k else rows * 48 // 4
