@@ -172,7 +172,10 @@ struct HalfCfg {
     static constexpr int kCandCap = kCandLimit + kTileRows;
     static constexpr int kCandPerThread = (kCandCap + kBlockT - 1) / kBlockT;
 };
-using DefaultHalfCfg = HalfCfg<512, 4, 3>;
+#ifndef MI355_HALF_DEPTH
+#define MI355_HALF_DEPTH 2   // tiles in flight per lane (measured: 2, 3 and 4 are equally fast)
+#endif
+using DefaultHalfCfg = HalfCfg<512, 4, MI355_HALF_DEPTH>;
 
 template <typename Cfg>
 struct HalfScanSmemT {
@@ -287,33 +290,57 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_half_kernel(
     int compact_at = 2 * topk > 256 ? 2 * topk : 256;
     if (compact_at > kCandLimit) compact_at = kCandLimit;
 
+    // A row the replica cannot rule out costs one random 48 B fetch from the fp32 matrix.  The
+    // fetch is ISSUED when the row is found and CONSUMED one tile later (a one-entry pending slot
+    // per lane, the same distance as the replica prefetch), so its latency overlaps the next
+    // tile instead of stalling the wave.  A lane whose two rows both qualify scores the second
+    // one on the spot (rare outside the first tiles of a launch without a seed).
+    Row pend;
+    pend.a = pend.b = pend.c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    int64_t pend_r = 0;
+    bool pend_on = false;
+
+    auto append = [&](bool have, const Row& row, int64_t r) {
+        const float s = cosine_score(q, qn, row);
+        const int64_t g = row_base + r;
+        uint64_t key = pack_key(s, static_cast<uint32_t>(g));
+        if (g == exclude_global) key = 0;
+        const bool pass = have && key > thr;
+        const uint64_t ballot = __ballot(pass);
+        if (ballot) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_count, __popcll(ballot));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const int pos = base + lanes_below(ballot);
+            if (pass) s_cand[pos] = key;
+        }
+    };
+    auto consume = [&]() {
+        if (__ballot(pend_on)) append(pend_on, pend, pend_r);
+        pend_on = false;
+    };
+
     auto process_tile = [&](const HalfTile& t, int it) {
         const int64_t pair = pair_begin + static_cast<int64_t>(it) * pair_stride;
         const float a0 = half_dot(hq.h, t.t0.x, t.t0.y, t.t0.z, t.t0.w, t.t1.x, t.t1.y);
         const float a1 = half_dot(hq.h, t.t1.z, t.t1.w, t.t2.x, t.t2.y, t.t2.z, t.t2.w);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int64_t r = pair * 2 + u;
-            const bool in_range = pair < n_pairs && r < n;
-            const bool maybe = in_range && !((u ? a1 : a0) < cutoff);
-            const uint64_t any = __ballot(maybe);
-            if (any) {
-                n_rescored += __popcll(any);
-                // the fp32 row (lanes without a candidate re-read row 0: one cached line)
-                const Row row = load_row(feats, maybe ? r : static_cast<int64_t>(0));
-                const float s = cosine_score(q, qn, row);
-                const int64_t g = row_base + r;
-                uint64_t key = pack_key(s, static_cast<uint32_t>(g));
-                if (g == exclude_global) key = 0;
-                const bool pass = maybe && key > thr;
-                const uint64_t ballot = __ballot(pass);
-                if (ballot) {
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(&s_count, __popcll(ballot));
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    const int pos = base + lanes_below(ballot);
-                    if (pass) s_cand[pos] = key;
-                }
+        const int64_t r0 = pair * 2;
+        const bool maybe0 = pair < n_pairs && !(a0 < cutoff);              // r0 < n whenever the pair exists
+        const bool maybe1 = pair < n_pairs && r0 + 1 < n && !(a1 < cutoff);
+        consume();   // the rows fetched while the previous tile was scanned
+        const bool some = maybe0 || maybe1;
+        const uint64_t any = __ballot(some);
+        if (any) {
+            const bool both = maybe0 && maybe1;
+            const uint64_t two = __ballot(both);
+            n_rescored += __popcll(any) + __popcll(two);
+            // lanes without a candidate re-read row 0: one cached line
+            pend_r = maybe0 ? r0 : r0 + 1;
+            pend = load_row(feats, some ? pend_r : static_cast<int64_t>(0));
+            pend_on = some;
+            if (two) {
+                const Row second = load_row(feats, both ? r0 + 1 : static_cast<int64_t>(0));
+                append(both, second, r0 + 1);
             }
         }
         __syncthreads();
@@ -338,6 +365,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_half_kernel(
             if (it + sidx < iters) process_tile(ring[sidx], it + sidx);  // uniform
         }
     }
+    consume();   // the last tile's fetches
 
     if (lane == 0 && n_rescored) atomicAdd(&sm->rescored, n_rescored);
     __syncthreads();
