@@ -87,6 +87,10 @@ constexpr float kBqMaxNorm = 1e18f;
 constexpr int kBqGroupsPerBlock = 2;         // the two lane halves of a workgroup stay separate groups
 
 // per-query flags written by prepare / select, read by finalize
+// The fp16 replica of the catalogue (replica.hip.h) stores rows in exactly the form the A
+// operand wants (normalised, six fp16 pairs); rows the bound is not claimed for are all-NaN.
+constexpr uint32_t kBqNaN2 = 0x7e007e00u;   // two fp16 quiet NaNs
+
 constexpr uint32_t kBqFlagOk = 0u;
 constexpr uint32_t kBqFlagQueue = 1u;        // serve through the exact multi-query scan
 constexpr uint32_t kBqFlagPad = 2u;          // not a query (padding up to a multiple of 32)
@@ -196,12 +200,16 @@ struct BqPassCfg {
 
 // kVariant (development A/B only, tools/bqbench.hip; 0 in the product): 4 = synthetic rows
 // (no HBM reads).
-template <int NB, bool kCollect, int kVariant = 0>
+// kFromReplica: the rows come from the fp16 replica (24 B per row, already normalised and
+// packed: `half`, replica.hip.h) instead of the fp32 matrix — half the bytes and none of the
+// per-row norm / scale / convert work; the bound is the same because the replica is built
+// with this kernel's own arithmetic.
+template <int NB, bool kCollect, int kVariant = 0, bool kFromReplica = false>
 __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu) void bq_pass_kernel(
     const float* __restrict__ feats, int64_t n, int64_t n_tiles, int tile_step, const uint32_t* __restrict__ bfrag,
     float* __restrict__ gmax /* [NB][8][2 * grid][4] */, int* __restrict__ cand_count,
     uint32_t* __restrict__ cand_rows /* [query][kBqCap] */, int* __restrict__ counters,
-    uint32_t* __restrict__ special_rows) {
+    uint32_t* __restrict__ special_rows, const uint2* __restrict__ half = nullptr) {
     // n_tiles counts 64-row tiles.  tile_step = 1: every tile.  tile_step > 1 (pass 1 only):
     // every tile_step-th tile — a threshold derived from ANY subset of the rows is a valid
     // lower bound; from a quarter of them it lets about four times as many candidates
@@ -239,49 +247,79 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
         c = p[2];
     };
 
-    float4 na, nb, nc;
-    load_row3(first, na, nb, nc);
-    for (int64_t tile = first; tile < n_tiles; tile += total_waves) {
-        float4 a = na, b = nb, c = nc;
-        if constexpr ((kVariant & 4) != 0) {   // A/B probe: no HBM traffic, synthetic rows
-            const float t = static_cast<float>(tile & 1023) * 1e-3f + lane * 0.01f;
-            a = make_float4(t, 0.3f, 0.5f, t * 0.5f);
-            b = make_float4(0.1f, t, 0.7f, 0.2f);
-            c = make_float4(0.4f, 0.6f, t, 0.9f);
-        } else {
-            load_row3(tile + total_waves, na, nb, nc);
-        }
+    auto load_half3 = [&](int64_t tile, uint2& x, uint2& y, uint2& z) {
+        int64_t row = tile * 64 + lane;
+        row = row < n ? row : last_row;
+        const uint2* p = half + row * 3;
+        x = p[0];
+        y = p[1];
+        z = p[2];
+    };
 
+    float4 na, nb, nc;
+    uint2 nx, ny, nz;
+    if constexpr (kFromReplica) {
+        load_half3(first, nx, ny, nz);
+    } else {
+        load_row3(first, na, nb, nc);
+    }
+    for (int64_t tile = first; tile < n_tiles; tile += total_waves) {
         const int64_t row = tile * 64 + lane;
-        float tot = a.x * a.x;
-        tot = __builtin_fmaf(a.y, a.y, tot);
-        tot = __builtin_fmaf(a.z, a.z, tot);
-        tot = __builtin_fmaf(a.w, a.w, tot);
-        tot = __builtin_fmaf(b.x, b.x, tot);
-        tot = __builtin_fmaf(b.y, b.y, tot);
-        tot = __builtin_fmaf(b.z, b.z, tot);
-        tot = __builtin_fmaf(b.w, b.w, tot);
-        tot = __builtin_fmaf(c.x, c.x, tot);
-        tot = __builtin_fmaf(c.y, c.y, tot);
-        tot = __builtin_fmaf(c.z, c.z, tot);
-        tot = __builtin_fmaf(c.w, c.w, tot);
         const bool in_range = row < n;
-        const bool valid = in_range && tot >= kBqMinNorm2 && tot <= kBqMaxNorm2;
-        const float inv = valid ? __builtin_amdgcn_rsqf(tot) : 0.0f;
-        if constexpr (kCollect) {
-            // neither valid nor exactly zero: scored exactly against every query later
-            const bool special = in_range && !valid && !(tot == 0.0f);
-            if (special) {
-                const int pos = atomicAdd(&counters[0], 1);
-                if (pos < kBqSpecialCap) special_rows[pos] = static_cast<uint32_t>(row);
+        uint32_t p0, p1, p2, p3, p4, p5;
+        if constexpr (kFromReplica) {
+            const uint2 x = nx, y = ny, z = nz;
+            load_half3(tile + total_waves, nx, ny, nz);
+            const bool special = in_range && x.x == kBqNaN2;   // tiny / huge / inf / NaN row: exact chain only
+            if constexpr (kCollect) {
+                if (special) {
+                    const int pos = atomicAdd(&counters[0], 1);
+                    if (pos < kBqSpecialCap) special_rows[pos] = static_cast<uint32_t>(row);
+                }
             }
+            const bool keep = in_range && !special;
+            p0 = keep ? x.x : 0u; p1 = keep ? x.y : 0u; p2 = keep ? y.x : 0u;
+            p3 = keep ? y.y : 0u; p4 = keep ? z.x : 0u; p5 = keep ? z.y : 0u;
+        } else {
+            float4 a = na, b = nb, c = nc;
+            if constexpr ((kVariant & 4) != 0) {   // A/B probe: no HBM traffic, synthetic rows
+                const float t = static_cast<float>(tile & 1023) * 1e-3f + lane * 0.01f;
+                a = make_float4(t, 0.3f, 0.5f, t * 0.5f);
+                b = make_float4(0.1f, t, 0.7f, 0.2f);
+                c = make_float4(0.4f, 0.6f, t, 0.9f);
+            } else {
+                load_row3(tile + total_waves, na, nb, nc);
+            }
+
+            float tot = a.x * a.x;
+            tot = __builtin_fmaf(a.y, a.y, tot);
+            tot = __builtin_fmaf(a.z, a.z, tot);
+            tot = __builtin_fmaf(a.w, a.w, tot);
+            tot = __builtin_fmaf(b.x, b.x, tot);
+            tot = __builtin_fmaf(b.y, b.y, tot);
+            tot = __builtin_fmaf(b.z, b.z, tot);
+            tot = __builtin_fmaf(b.w, b.w, tot);
+            tot = __builtin_fmaf(c.x, c.x, tot);
+            tot = __builtin_fmaf(c.y, c.y, tot);
+            tot = __builtin_fmaf(c.z, c.z, tot);
+            tot = __builtin_fmaf(c.w, c.w, tot);
+            const bool valid = in_range && tot >= kBqMinNorm2 && tot <= kBqMaxNorm2;
+            const float inv = valid ? __builtin_amdgcn_rsqf(tot) : 0.0f;
+            if constexpr (kCollect) {
+                // neither valid nor exactly zero: scored exactly against every query later
+                const bool special = in_range && !valid && !(tot == 0.0f);
+                if (special) {
+                    const int pos = atomicAdd(&counters[0], 1);
+                    if (pos < kBqSpecialCap) special_rows[pos] = static_cast<uint32_t>(row);
+                }
+            }
+            // zero (not NaN) for rows the bound is not claimed for: inf * 0 would poison D
+            p0 = bq_pack_h2(a.x * inv, a.y * inv); p1 = bq_pack_h2(a.z * inv, a.w * inv);
+            p2 = bq_pack_h2(b.x * inv, b.y * inv); p3 = bq_pack_h2(b.z * inv, b.w * inv);
+            p4 = bq_pack_h2(c.x * inv, c.y * inv); p5 = bq_pack_h2(c.z * inv, c.w * inv);
+            p0 = valid ? p0 : 0u; p1 = valid ? p1 : 0u; p2 = valid ? p2 : 0u;
+            p3 = valid ? p3 : 0u; p4 = valid ? p4 : 0u; p5 = valid ? p5 : 0u;
         }
-        // zero (not NaN) for rows the bound is not claimed for: inf * 0 would poison D
-        uint32_t p0 = bq_pack_h2(a.x * inv, a.y * inv), p1 = bq_pack_h2(a.z * inv, a.w * inv);
-        uint32_t p2 = bq_pack_h2(b.x * inv, b.y * inv), p3 = bq_pack_h2(b.z * inv, b.w * inv);
-        uint32_t p4 = bq_pack_h2(c.x * inv, c.y * inv), p5 = bq_pack_h2(c.z * inv, c.w * inv);
-        p0 = valid ? p0 : 0u; p1 = valid ? p1 : 0u; p2 = valid ? p2 : 0u;
-        p3 = valid ? p3 : 0u; p4 = valid ? p4 : 0u; p5 = valid ? p5 : 0u;
         // k = 12, 13 multiply the threshold slots of B by 1.0 for ALL rows (a masked row
         // yields D = -T' < 0); k = 14, 15 are zero
         const auto s0 = __builtin_amdgcn_permlane32_swap(p0, p4, false, false);

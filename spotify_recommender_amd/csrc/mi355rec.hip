@@ -766,7 +766,7 @@ void free_bq(mi355rec* h) {
     b = mi355rec::Batched();
 }
 
-template <int NB>
+template <int NB, bool kFromReplica>
 void launch_bq_passes(mi355rec* h, int topn, hipStream_t s) {
     auto& b = h->bq;
     const int64_t n_tiles = (h->n + 63) / 64;   // a wave handles 64 rows (two 32-row MFMA tiles) at a time
@@ -774,16 +774,27 @@ void launch_bq_passes(mi355rec* h, int topn, hipStream_t s) {
     int step1 = n_tiles >= static_cast<int64_t>(b.grid) * (kBqPassBlock / 64) * 16 ? b.step1 : 1;
     while (step1 > 1 && n_tiles < static_cast<int64_t>(b.grid) * (kBqPassBlock / 64) * 8 * step1) step1 /= 2;
     const size_t smem = sizeof(float) * b.grid * 2 * 5 + sizeof(int) * (kBqSelectBlock / 64) * 256;
+    const uint2* half = reinterpret_cast<const uint2*>(h->d_half);
     int slot = timing_begin(h, h->ev_pass, h->n_pass_pairs, h->pass_launches, s);
-    hipLaunchKernelGGL((bq_pass_kernel<NB, false>), dim3(b.grid), dim3(kBqPassBlock), 0, s, h->d_feats, h->n, n_tiles,
-                       step1, b.bfrag, b.gmax, b.cand_count, b.cand_rows, b.counters, b.special_rows);
+    hipLaunchKernelGGL((bq_pass_kernel<NB, false, 0, kFromReplica>), dim3(b.grid), dim3(kBqPassBlock), 0, s, h->d_feats, h->n,
+                       n_tiles, step1, b.bfrag, b.gmax, b.cand_count, b.cand_rows, b.counters, b.special_rows, half);
     timing_end(h, h->ev_pass, h->n_pass_pairs, slot, s);
     hipLaunchKernelGGL(bq_select_kernel, dim3(NB * 8), dim3(kBqSelectBlock), smem, s, b.gmax, b.grid, NB, topn, b.margin, b.bfrag,
                        b.qflags, b.qthr);
     slot = timing_begin(h, h->ev_pass, h->n_pass_pairs, h->pass_launches, s);
-    hipLaunchKernelGGL((bq_pass_kernel<NB, true>), dim3(b.grid2), dim3(kBqPassBlock), 0, s, h->d_feats, h->n, n_tiles,
-                       1, b.bfrag, b.gmax, b.cand_count, b.cand_rows, b.counters, b.special_rows);
+    hipLaunchKernelGGL((bq_pass_kernel<NB, true, 0, kFromReplica>), dim3(b.grid2), dim3(kBqPassBlock), 0, s, h->d_feats, h->n,
+                       n_tiles, 1, b.bfrag, b.gmax, b.cand_count, b.cand_rows, b.counters, b.special_rows, half);
     timing_end(h, h->ev_pass, h->n_pass_pairs, slot, s);
+}
+
+template <int NB>
+void launch_bq_passes(mi355rec* h, int topn, hipStream_t s) {
+    // the passes read the fp16 replica when the handle has one (it holds their A operand ready-made)
+    if (h->d_half && h->replica_mode != MI355REC_REPLICA_OFF) {
+        launch_bq_passes<NB, true>(h, topn, s);
+    } else {
+        launch_bq_passes<NB, false>(h, topn, s);
+    }
 }
 
 // One chunk of up to kBqMaxQueries queries that are already in device memory.

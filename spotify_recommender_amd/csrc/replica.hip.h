@@ -42,7 +42,7 @@
 namespace mi355 {
 
 constexpr float kHalfMargin = kBqMarginFlush;
-constexpr uint32_t kHalfNaN2 = 0x7e007e00u;   // two fp16 quiet NaNs
+constexpr uint32_t kHalfNaN2 = kBqNaN2;        // two fp16 quiet NaNs: "always score this row exactly"
 constexpr int kHalfSeedBlock = 512;
 constexpr int kHalfSeedWaves = kHalfSeedBlock / 64;
 constexpr int kHalfSeedMaxGrid = 256;          // <= 2048 sample maxima

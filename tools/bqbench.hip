@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
         printf("  %-52s %8.1f us   %6.2f ns per MFMA per SIMD\n", name, ms * 1e3, ms * 1e6 / mfmas_per_simd); fflush(stdout);
     };
     printf("rows %lld, %d workgroups (%d per CU), %d query blocks\n", (long long)n, grid, per_cu, NB);
-#define PASS(COLLECT, VAR) [&] { hipLaunchKernelGGL((bq_pass_kernel<NB, COLLECT, VAR>), dim3(grid), dim3(kBqPassBlock), 0, 0, feats, n, tiles, 1, bfrag, gmax, cand_count, cand_rows, counters, special); }
+#define PASS(COLLECT, VAR) [&] { hipLaunchKernelGGL((bq_pass_kernel<NB, COLLECT, VAR>), dim3(grid), dim3(kBqPassBlock), 0, 0, feats, n, tiles, 1, bfrag, gmax, cand_count, cand_rows, counters, special, static_cast<const uint2*>(nullptr)); }
     report("pass 1 (group maxima), product", median_ms(PASS(false, 0), 7));
     report("pass 1, synthetic rows (no HBM reads)", median_ms(PASS(false, 4), 7));
     // pass 2 with thresholds nobody reaches (bfrag threshold slots are 0 -> D = dot >= 0 always hits):
