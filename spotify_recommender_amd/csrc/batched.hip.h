@@ -84,6 +84,13 @@ constexpr float kBqMinNorm2 = 1.01e-8f;      // |x| >= 1.005e-4 for rows and que
 constexpr float kBqMaxNorm2 = 1e36f;
 constexpr float kBqMinNorm = 1.005e-4f;
 constexpr float kBqMaxNorm = 1e18f;
+// Every query's candidate counter sits in its own 128-byte line: the counters of 32 queries in
+// ONE line made every returning atomic of a small batch queue up at one L2 channel (measured at
+// 10 M rows x 32 queries: ~20 k atomics in a burst as the waves drain, 37 of pass 2's 83 us).
+#ifndef MI355_BQ_COUNT_STRIDE
+#define MI355_BQ_COUNT_STRIDE 32
+#endif
+constexpr int kBqCountStride = MI355_BQ_COUNT_STRIDE;
 constexpr int kBqGroupsPerBlock = 2;         // the two lane halves of a workgroup stay separate groups
 
 // per-query flags written by prepare / select, read by finalize
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(256) void bq_prepare_kernel(
     *hi = make_uint4(bq_pack_h2(u[8], u[9]), bq_pack_h2(u[10], u[11]), 0u, 0u);
     qnorm[q] = qn;
     qflags[q] = ok ? kBqFlagOk : (real ? kBqFlagQueue : kBqFlagPad);
-    cand_count[q] = 0;
+    cand_count[q * kBqCountStride] = 0;
 }
 
 // ---- the two passes ---------------------------------------------------------------
@@ -188,7 +195,7 @@ __device__ __forceinline__ void bq_flush_stage(const uint2* stage, int staged, i
                                                uint32_t* __restrict__ cand_rows) {
     for (int e = lane; e < staged; e += 64) {
         const uint2 qr = stage[e];
-        const int pos = atomicAdd(&cand_count[qr.x], 1);
+        const int pos = atomicAdd(&cand_count[qr.x * kBqCountStride], 1);
         if (pos < kBqCap) cand_rows[static_cast<int64_t>(qr.x) * kBqCap + pos] = qr.y;
     }
 }
@@ -256,20 +263,53 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
         z = p[2];
     };
 
+    // With only a handful of query blocks a tile is a few hundred cycles of work, far less than
+    // a memory round trip, and one tile ahead per wave leaves the pass latency-bound (measured at
+    // 10 M rows x 32 queries: 83 us, 2.9 TB/s).  Registers that are the target of a load in
+    // flight cannot be rotated, and unrolling this loop would multiply the rare hit path, so for
+    // NB <= 8 the replica rows go through a per-wave LDS ring: every kPre-th iteration the wave
+    // parks the kPre tiles that have arrived in LDS and sends out the loads of the next kPre;
+    // the body reads its tile from LDS by a dynamic slot index.  Wave-private slots, no barrier.
+    constexpr bool kStaged = kFromReplica && NB <= 8;
+    constexpr int kPre = kStaged ? 4 : 1;
+    __shared__ uint2 s_rows[kStaged ? kBqPassBlock / 64 : 1][kStaged ? kPre : 1][3][kStaged ? 64 : 1];
     float4 na, nb, nc;
-    uint2 nx, ny, nz;
+    uint2 pre[kPre][3];
     if constexpr (kFromReplica) {
-        load_half3(first, nx, ny, nz);
+#pragma unroll
+        for (int d = 0; d < kPre; ++d) load_half3(first + d * total_waves, pre[d][0], pre[d][1], pre[d][2]);
     } else {
         load_row3(first, na, nb, nc);
     }
+    int slot = 0;   // wave-uniform: position of `tile` in its group of kPre
     for (int64_t tile = first; tile < n_tiles; tile += total_waves) {
         const int64_t row = tile * 64 + lane;
         const bool in_range = row < n;
         uint32_t p0, p1, p2, p3, p4, p5;
         if constexpr (kFromReplica) {
-            const uint2 x = nx, y = ny, z = nz;
-            load_half3(tile + total_waves, nx, ny, nz);
+            uint2 x, y, z;
+            if constexpr (kStaged) {
+                if (slot == 0) {
+#pragma unroll
+                    for (int d = 0; d < kPre; ++d) {
+                        s_rows[wave][d][0][lane] = pre[d][0];
+                        s_rows[wave][d][1][lane] = pre[d][1];
+                        s_rows[wave][d][2][lane] = pre[d][2];
+                    }
+#pragma unroll
+                    for (int d = 0; d < kPre; ++d)
+                        load_half3(tile + (kPre + d) * total_waves, pre[d][0], pre[d][1], pre[d][2]);
+                }
+                x = s_rows[wave][slot][0][lane];
+                y = s_rows[wave][slot][1][lane];
+                z = s_rows[wave][slot][2][lane];
+                slot = slot + 1 == kPre ? 0 : slot + 1;
+            } else {
+                x = pre[0][0];
+                y = pre[0][1];
+                z = pre[0][2];
+                load_half3(tile + total_waves, pre[0][0], pre[0][1], pre[0][2]);
+            }
             const bool special = in_range && x.x == kBqNaN2;   // tiny / huge / inf / NaN row: exact chain only
             if constexpr (kCollect) {
                 if (special) {
@@ -565,7 +605,7 @@ __global__ __launch_bounds__(kBqFinalBlock) void bq_finalize_kernel(
     __shared__ int s_n;
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
-    const int n_cand = cand_count[q];
+    const int n_cand = cand_count[q * kBqCountStride];
     const int n_special = counters[0];
     const bool served = qflags[q] == kBqFlagOk && n_cand <= kBqCap && n_special <= kBqSpecialCap;
     if (!served) {   // uniform

@@ -724,7 +724,7 @@ int ensure_bq_alloc(mi355rec* h) {
     HIP_TRY(h, hipMalloc(&b.qnorm, sizeof(float) * kBqMaxQueries));
     HIP_TRY(h, hipMalloc(&b.qthr, sizeof(float) * kBqMaxQueries));
     HIP_TRY(h, hipMalloc(&b.qflags, sizeof(uint32_t) * kBqMaxQueries));
-    HIP_TRY(h, hipMalloc(&b.cand_count, sizeof(int) * kBqMaxQueries));
+    HIP_TRY(h, hipMalloc(&b.cand_count, sizeof(int) * kBqMaxQueries * kBqCountStride));
     HIP_TRY(h, hipMalloc(&b.cand_rows, sizeof(uint32_t) * static_cast<size_t>(kBqMaxQueries) * kBqCap));
     HIP_TRY(h, hipMalloc(&b.counters, sizeof(int) * 4));
     HIP_TRY(h, hipMalloc(&b.special_rows, sizeof(uint32_t) * kBqSpecialCap));
@@ -1116,7 +1116,8 @@ int mi355rec_batched_last_counters(mi355rec_t* h, int32_t* special_rows, int32_t
     std::vector<int> cand(kBqMaxQueries);
     std::vector<uint32_t> flags(kBqMaxQueries);
     HIP_TRY(h, hipMemcpy(counters, h->bq.counters, sizeof counters, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(cand.data(), h->bq.cand_count, sizeof(int) * kBqMaxQueries, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy2D(cand.data(), sizeof(int), h->bq.cand_count, sizeof(int) * kBqCountStride, sizeof(int),
+                           kBqMaxQueries, hipMemcpyDeviceToHost));
     HIP_TRY(h, hipMemcpy(flags.data(), h->bq.qflags, sizeof(uint32_t) * kBqMaxQueries, hipMemcpyDeviceToHost));
     int64_t total = 0;
     int mx = 0;

@@ -8,7 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "batched.hip.h"
+#include "replica.hip.h"
 
 using namespace mi355;
 
@@ -38,11 +38,14 @@ template <class F> float median_ms(F&& f, int reps) {
 int main(int argc, char** argv) {
     const int64_t n = argc > 1 ? atoll(argv[1]) : 12500000;
     const int per_cu = argc > 2 ? atoi(argv[2]) : 4;
-    constexpr int NB = 32;
+#ifndef BQ_NB
+#define BQ_NB 32   // query blocks (compile with -DBQ_NB=2 for the small-batch kernels)
+#endif
+    constexpr int NB = BQ_NB;
     float *feats, *queries, *qnorm, *gmax; uint32_t *bfrag, *qflags, *cand_rows, *special; int *cand_count, *counters;
     CK(hipMalloc(&feats, n * 12 * sizeof(float)));
     CK(hipMalloc(&queries, 1024 * 12 * sizeof(float)));
-    CK(hipMalloc(&qnorm, 1024 * 4)); CK(hipMalloc(&qflags, 1024 * 4)); CK(hipMalloc(&cand_count, 1024 * 4));
+    CK(hipMalloc(&qnorm, 1024 * 4)); CK(hipMalloc(&qflags, 1024 * 4)); CK(hipMalloc(&cand_count, 1024 * 4 * kBqCountStride));
     CK(hipMalloc(&bfrag, NB * 64 * 16)); CK(hipMalloc(&counters, 16)); CK(hipMalloc(&special, kBqSpecialCap * 4));
     CK(hipMalloc(&cand_rows, (size_t)1024 * kBqCap * 4));
     const int grid = 256 * per_cu;
@@ -68,6 +71,14 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(bfrag, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
     report("pass 2 (no hits), product", median_ms(PASS(true, 0), 7));
     report("pass 2 (no hits), synthetic rows", median_ms(PASS(true, 4), 7));
+    // the same two passes reading the fp16 replica
+    uint2* half;
+    CK(hipMalloc(&half, (size_t)((n + 1) & ~1ll) * 24));
+    replica_build_kernel<<<(unsigned)((((n + 1) & ~1ll) + 255) / 256), 256>>>(feats, n, (n + 1) & ~1ll, half);
+    CK(hipDeviceSynchronize());
+#define PASSR(COLLECT) [&] { hipLaunchKernelGGL((bq_pass_kernel<NB, COLLECT, 0, true>), dim3(grid), dim3(kBqPassBlock), 0, 0, feats, n, tiles, 1, bfrag, gmax, cand_count, cand_rows, counters, special, static_cast<const uint2*>(half)); }
+    report("pass 2 (no hits), fp16 replica", median_ms(PASSR(true), 7));
+    report("pass 1 over every tile, fp16 replica", median_ms(PASSR(false), 7));
     // the same kernels on an all-zero catalogue and all-zero fragments (switching power)
     CK(hipMemset(feats, 0, n * 12 * sizeof(float)));
     report("pass 1, all-zero catalogue", median_ms(PASS(false, 0), 7));
