@@ -302,26 +302,34 @@ def main():
             dt = float(tt.item())
         return dt / reps
 
-    # micro-batched throughput, outside the timed region:
-    # 12 queries share one exact pass over the catalogue (mi355::scan_multi_kernel)
+    # micro-batched throughput, outside the timed region: a dozen queries
+    # per call.  With a replica such a call takes the batched matrix-core path (one block of <= 32
+    # queries); the exact 12-query pass (mi355::scan_multi_kernel) is timed beside it.
     micro = None
     if topn <= 128:
-        nb = 72   # two chains of 36 = six passes of 12 queries
-        b_rows = np.array(q_rows[:nb], dtype=np.int64)
-        b_keys = torch.zeros(nb * topn, dtype=torch.int64, device=dev)
-        eng.set_batch_path(capi.BATCH_MULTI)
+        def batch_leg(nb, calls, path):
+            b_rows = np.array(q_rows[:nb], dtype=np.int64)
+            b_keys = torch.zeros(nb * topn, dtype=torch.int64, device=dev)
+            eng.set_batch_path(path)
 
-        def batch_step():
-            if sharded is None:
-                eng.enqueue_batch_keys(q_vecs[:nb], b_rows, topn, b_keys)
-            else:
-                sharded.enqueue_batch(q_vecs[:nb], b_rows, topn)
+            def batch_step():
+                if sharded is None:
+                    eng.enqueue_batch_keys(q_vecs[:nb], b_rows, topn, b_keys)
+                else:
+                    sharded.enqueue_batch(q_vecs[:nb], b_rows, topn)
 
-        dt = timed(batch_step, 6)
-        micro = {"queries_per_pass": 12, "queries_per_call": nb, "value": round(nb / dt, 1),
-                 "unit": "queries/s", "ms_per_pass": round(dt / (nb / 12) * 1e3, 5),
-                 "note": "one exact scan of the (local) catalogue answers 12 queries (mi355::scan_multi_kernel); "
-                         + ("single GPU" if sharded is None else "one all-gather per 72-query call")}
+            dt = timed(batch_step, calls)
+            eng.set_batch_path(capi.BATCH_AUTO)
+            return dt, b_keys
+
+        nb = 12 if sharded is None else 72
+        dt, b_keys = batch_leg(nb, 30 if sharded is None else 6, capi.BATCH_AUTO)
+        micro = {"queries_per_call": nb, "value": round(nb / dt, 1), "unit": "queries/s",
+                 "ms_per_call": round(dt * 1e3, 5),
+                 "note": ("one call = one pass pair of the batched matrix-core path over the fp16 replica "
+                          "(mi355::bq_pass_kernel<2, .., true>: a block of <= 32 queries costs the same)" if replica else
+                          "one call = the path mi355rec_enqueue_batch_keys picks for this batch size; "
+                          + ("single GPU" if sharded is None else "one all-gather per call"))}
         if sharded is None:
             eng.enqueue_row_keys(q_rows[0], topn, out_keys)
         else:
@@ -330,7 +338,11 @@ def main():
         a, _ = unpack_keys((out_keys if sharded is None else sharded.out_keys[:topn]).cpu().numpy())
         b, _ = unpack_keys((b_keys[:topn] if sharded is None else sharded.batch_keys[0]).cpu().numpy())
         micro["matches_single_query_path"] = bool(a.tolist() == b.tolist())
-        eng.set_batch_path(capi.BATCH_AUTO)
+        if sharded is None:
+            dt, _ = batch_leg(72, 6, capi.BATCH_MULTI)   # two chains of 36 = six exact passes of 12 queries
+            micro["exact_multi_query_pass"] = {"queries_per_pass": 12, "queries_per_call": 72, "value": round(72 / dt, 1),
+                                               "unit": "queries/s", "ms_per_pass": round(dt / 6 * 1e3, 5),
+                                               "kernel": "mi355::scan_multi_kernel (fp32 rows, exact pre-filter)"}
 
     # the batched path of BASELINE configs[4] (csrc/batched.hip.h): `--batch` queries per call,
     # queries resident in HBM, fp16 matrix-core pre-filter + exact fp32 re-score

@@ -121,9 +121,11 @@ int mi355rec_create_device(const float* feats_dev, int64_t n, int dim,
  *                   fp32 rows (a query is launch-bound there either way);
  *   OFF:            always the fp32 rows (the reference's own traffic, 48 B/row);
  *   ON:             always the replica.
- * The score vector (mi355rec_scores*), topn > 1024 and the multi-query /
- * batched calls do not use it.  The environment variable MI355REC_REPLICA=0
- * creates handles without one.
+ * The batched matrix-core path reads its rows from the replica too (they are
+ * stored in exactly the form its MFMA operand wants) unless the mode is OFF.
+ * The score vector (mi355rec_scores*), rounds of topn > 1024 after the first
+ * and the exact multi-query pass always read the fp32 rows.  The environment
+ * variable MI355REC_REPLICA=0 creates handles without one.
  * A replica is a SNAPSHOT: if the caller overwrites a borrowed matrix
  * (mi355rec_create_device) while the handle lives, it must call
  * mi355rec_rebuild_replica before the next query (synchronous). */
@@ -208,11 +210,13 @@ int mi355rec_enqueue_query_keys_streamed(mi355rec_t* h, const float* query12,
 /* Merges the last streamed query (no-op when nothing is pending). */
 int mi355rec_enqueue_flush(mi355rec_t* h, void* stream);
 
-/* `batch` queries (batch x 12 floats, host; exclude_global may be NULL) in
- * multi-query passes: every pass streams the shard ONCE for up to 12 queries
- * (topn <= 128; larger topn falls back to one scan per query); 13 and more
- * queries take the batched matrix-core path (mi355rec_set_batch_path).  Writes
- * batch x topn packed keys (each row sorted descending, 0-padded). */
+/* `batch` queries (batch x 12 floats, host; exclude_global may be NULL).
+ * Three or more queries (13 or more on a handle without a replica) take the
+ * batched matrix-core path (mi355rec_set_batch_path); fewer — or shards below
+ * 65536 rows — go in exact multi-query passes: every pass streams the shard
+ * ONCE for up to 12 queries (topn <= 128; larger topn falls back to one scan
+ * per query).  Writes batch x topn packed keys (each row sorted descending,
+ * 0-padded). */
 int mi355rec_enqueue_batch_keys(mi355rec_t* h, const float* queries,
                                 const int64_t* exclude_global, int batch, int topn,
                                 mi355rec_key_t* out_keys_dev, void* stream);

@@ -685,7 +685,9 @@ int enqueue_streamed(mi355rec* h, int64_t query_row, const float* query12, int64
 // ---- batched path (batched.hip.h) -----------------------------------------------
 
 constexpr int64_t kBqMinRows = 65536;   // below this the launch count, not the arithmetic, decides
-constexpr int kBqMinBatch = 13;          // up to 12 queries are ONE multi-query pass
+constexpr int kBqMinBatch = 13;          // without a replica: up to 12 queries are ONE exact multi-query pass (141 us at 10 M rows)
+constexpr int kBqMinBatchReplica = 3;    // with one, the passes cost ~92 us for any chunk of <= 32 queries (two single
+                                         // replica scans cost 88): measured at 10 M rows, tools/run_batched.py
 
 void free_bq(mi355rec* h);
 
@@ -850,7 +852,8 @@ bool use_bq(const mi355rec* h, int batch, int topn) {
     if (topn > kMultiMaxTopK || h->n < 1) return false;
     if (h->batch_path == MI355REC_BATCH_MULTI) return false;
     if (h->batch_path == MI355REC_BATCH_MFMA) return true;
-    return batch >= kBqMinBatch && h->n >= kBqMinRows;
+    const bool replica = h->d_half && h->replica_mode != MI355REC_REPLICA_OFF;
+    return batch >= (replica ? kBqMinBatchReplica : kBqMinBatch) && h->n >= kBqMinRows;
 }
 
 int enqueue_bq_host(mi355rec* h, const float* queries, const int64_t* exclude, int batch, int topn,

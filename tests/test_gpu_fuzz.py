@@ -68,6 +68,7 @@ def test_randomised_parity():
             topn = int(rng.choice([1, 7, 100, 128]))
             qrows = rng.integers(0, rows, size=batch)
             excl = np.where(rng.random(batch) < 0.8, qrows, -1).astype(np.int64)
+            eng.set_batch_path(1 if case % 2 else 0)   # odd cases: the exact multi-query pass; even: AUTO
             idx, sc, counts = eng.query_batch_topn(f[qrows], excl, topn)
             for b in range(batch):
                 want = oracle.scores(f, f[qrows[b]])

@@ -156,9 +156,11 @@ def test_sums_that_overflow_in_one_order_only(Engine):
             for topn in (10, 100):
                 idx, sc = eng.query_topn(q, -1, topn)
                 assert_topn_matches(idx, sc, want, -1, topn, ref_idx=oracle.topn_heap(want, -1, topn))
-        idx, sc, counts = eng.query_batch_topn(queries, None, 100)
-        for b, want in enumerate(wants):
-            assert_topn_matches(idx[b][:counts[b]], sc[b][:counts[b]], want, -1, 100)
+        for path in (1, 0):   # the exact multi-query pass, then whatever AUTO picks
+            eng.set_batch_path(path)
+            idx, sc, counts = eng.query_batch_topn(queries, None, 100)
+            for b, want in enumerate(wants):
+                assert_topn_matches(idx[b][:counts[b]], sc[b][:counts[b]], want, -1, 100)
 
 
 def test_all_rows_identical_exercises_merge_fallback(Engine):
@@ -270,13 +272,15 @@ def test_batch_matches_single(Engine):
     f = rng.random((70_000, 12), dtype=np.float32)
     rows = [0, 999, 69_999, 12_345, 7]
     with Engine(f) as eng:
-        idx, sc, counts = eng.query_batch_topn(f[rows], rows, 25)
-        assert counts.tolist() == [25] * len(rows)
-        for b, r in enumerate(rows):
-            want = oracle.scores(f, f[r])
-            assert_topn_matches(idx[b], sc[b], want, r, 25, ref_idx=oracle.topn_heap(want, r, 25))
-            i1, s1 = eng.query_row_topn(r, 25)
-            assert i1.tolist() == idx[b].tolist()
+        for path in (1, 0):   # the exact multi-query pass, then whatever AUTO picks
+            eng.set_batch_path(path)
+            idx, sc, counts = eng.query_batch_topn(f[rows], rows, 25)
+            assert counts.tolist() == [25] * len(rows)
+            for b, r in enumerate(rows):
+                want = oracle.scores(f, f[r])
+                assert_topn_matches(idx[b], sc[b], want, r, 25, ref_idx=oracle.topn_heap(want, r, 25))
+                i1, s1 = eng.query_row_topn(r, 25)
+                assert i1.tolist() == idx[b].tolist()
 
 
 @pytest.mark.parametrize("rows", [5, 700, 70_000, 1_000_003])
@@ -290,7 +294,10 @@ def test_multi_query_pass_matches_single_queries(Engine, torch_cuda, rows):
         f[50:60] = f[3]                                   # ties with a query
     from spotify_recommender_amd.engine import unpack_keys
     with Engine(f) as eng:
-        for batch, topn in ((1, 10), (3, 5), (8, 100), (19, 128), (9, 1), (40, 16), (5, 200)):
+        # the exact multi-query passes (forced), then once more under AUTO (the batched
+        # matrix-core path from 3 queries up on shards of >= 65536 rows)
+        for path, (batch, topn) in [(p, bt) for p in (1, 0) for bt in ((1, 10), (3, 5), (8, 100), (19, 128), (9, 1), (40, 16), (5, 200))]:
+            eng.set_batch_path(path)
             qrows = rng.integers(0, rows, size=batch)
             qrows[0] = min(3, rows - 1)
             queries = f[qrows].copy()
@@ -323,15 +330,19 @@ def test_multi_query_pass_adversarial(Engine):
     queries = np.ones((8, 12), dtype=np.float32)
     queries[:, 6:] += np.linspace(0, 0.01, 8, dtype=np.float32)[:, None]
     with Engine(f) as eng:
-        idx, sc, counts = eng.query_batch_topn(queries, None, 100)
-        for b in range(8):
-            want = oracle.scores(f, queries[b])
-            assert_topn_matches(idx[b], sc[b], want, -1, 100, ref_idx=oracle.topn_heap(want, -1, 100))
+        for path in (1, 0):   # the exact multi-query pass, then whatever AUTO picks
+            eng.set_batch_path(path)
+            idx, sc, counts = eng.query_batch_topn(queries, None, 100)
+            for b in range(8):
+                want = oracle.scores(f, queries[b])
+                assert_topn_matches(idx[b], sc[b], want, -1, 100, ref_idx=oracle.topn_heap(want, -1, 100))
     same = np.tile(np.linspace(0.05, 0.95, 12, dtype=np.float32), (90_000, 1))
     with Engine(same) as eng:
-        idx, sc, counts = eng.query_batch_topn(same[:8], np.arange(8), 64)
-        for b in range(8):
-            assert idx[b].tolist() == [i for i in range(65) if i != b][:64]
+        for path in (1, 0):
+            eng.set_batch_path(path)
+            idx, sc, counts = eng.query_batch_topn(same[:8], np.arange(8), 64)
+            for b in range(8):
+                assert idx[b].tolist() == [i for i in range(65) if i != b][:64]
 
 
 def test_borrowed_device_matrix_and_row_base(Engine, torch_cuda):

@@ -37,14 +37,19 @@ def run_case(Engine, f, queries, excl, label, topns=(1, 100, 128), batches=(13, 
     excl = np.asarray(excl, dtype=np.int64)
     want = [oracle.scores(f, q, threads=0) for q in queries]
     with Engine(f) as eng:
-        for topn, batch in zip(topns, batches):
-            idx, sc, counts = eng.query_batch_topn(queries[:batch], excl[:batch], topn)
-            for b in range(batch):
-                try:
-                    assert_topn_matches(idx[b][:counts[b]], sc[b][:counts[b]], want[b], int(excl[b]), topn,
-                                        ref_idx=oracle.topn_heap(want[b], int(excl[b]), topn))
-                except AssertionError as e:
-                    raise AssertionError(f"{label}: batch {batch} topn {topn} query {b}: {e}") from e
+        # 1 = the exact multi-query passes with their sampled seed (what this file is about),
+        # 2 = the batched matrix-core path (what AUTO picks for these batch sizes)
+        for path in (1, 2):
+            eng.set_batch_path(path)
+            for topn, batch in zip(topns, batches):
+                idx, sc, counts = eng.query_batch_topn(queries[:batch], excl[:batch], topn)
+                for b in range(batch):
+                    try:
+                        assert_topn_matches(idx[b][:counts[b]], sc[b][:counts[b]], want[b], int(excl[b]), topn,
+                                            ref_idx=oracle.topn_heap(want[b], int(excl[b]), topn))
+                    except AssertionError as e:
+                        raise AssertionError(f"{label}: path {path} batch {batch} topn {topn} query {b}: {e}") from e
+        eng.set_batch_path(0)
         for b in range(single):   # the single-query kernel on the same data
             idx, sc = eng.query_topn(queries[b], int(excl[b]), 100)
             assert_topn_matches(idx, sc, want[b], int(excl[b]), 100, ref_idx=oracle.topn_heap(want[b], int(excl[b]), 100))
