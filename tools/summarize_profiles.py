@@ -55,8 +55,11 @@ for k, d in out["kernels"].items():
         alg = (rows + 1) // 2 * 48
         d["note"] = "scan over the fp16 replica: 24 B per row + the fp32 rows it cannot rule out (a few thousand per query)"
     elif "bq_pass_kernel" in k:
-        # pass 2 (<.., true, ..>) reads every row once; pass 1 every 4th 32-row tile
-        alg = rows * 48 if ", true" in k else rows * 48 // 4
+        # bq_pass_kernel<NB, kCollect, kVariant, kFromReplica>: pass 2 (kCollect) reads every row once, pass 1
+        # every 4th 64-row tile; 24 B per row from the fp16 replica, 48 B from the fp32 matrix
+        args = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
+        per_row = 24 if len(args) > 3 and args[3] == "true" else 48
+        alg = rows * per_row if args[1] == "true" else rows * per_row // 4
         d["note"] = "batched path: rows are read once per pass whatever the number of queries (<= 1024 per pass)"
     if alg is not None:
         d["algorithmic_bytes_per_launch"] = alg
