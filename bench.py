@@ -257,32 +257,44 @@ def main():
         host_idx = res
     lat.sort()
 
-    # The same stream of single queries over the fp32 rows (the reference's own 48 B per row),
-    # outside the timed region: what the replica buys, measured in the same process.
+    # The same stream of single queries over the fp32 rows (the reference's own 48 B per row,
+    # SURVEY.md §8(d)), same protocol — warm-up, K steps with the flush inside the timed region,
+    # kernel events — outside the headline's timed region: what the replica buys, measured in the
+    # same process, and a complete headline of its own for a reader who prices a query at 48 B/row.
     fp32_rows = None
     if replica and sharded is None and streamed:
         eng.set_replica(capi.REPLICA_OFF)
-        for k in range(10):
+        for k in range(args.warmup):
             step(k)
         flush()
         fence()
-        eng.set_timing(4)
+        eng.set_timing(stride)
         t1 = time.perf_counter()
-        for k in range(10, 110):
-            step(k % total_q)
+        for k in range(args.warmup, total_q):
+            step(k)
         flush()
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t1) / 100
+        dt = (time.perf_counter() - t1) / args.steps
         st32 = eng.stats()
         eng.set_timing(False)
+        lat32 = []
+        for k in range(total_q, total_q + min(200, args.latency_queries)):
+            t1 = time.perf_counter()
+            eng.query_row_topn(q_rows[k], topn)
+            lat32.append((time.perf_counter() - t1) * 1e3)
+        lat32.sort()
         eng.set_replica(capi.REPLICA_AUTO)
         k_ms = float(st32.last_scan_ms)
-        fp32_rows = {"kernel": "mi355::scan_kernel<ScanCfg<512,1,6,2>, true, false, 0, true>", "steps": 100,
-                     "ms_per_step": round(dt * 1e3, 5), "value": round(1.0 / dt, 1), "unit": "queries/s",
-                     "algorithmic_bytes_per_launch": (hi - lo) * BYTES_PER_ROW,
-                     "avg_kernel_ms": round(k_ms, 5),
-                     "achieved": round((hi - lo) * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
-                     "frac": round((hi - lo) * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if k_ms > 0 else None}
+        t32, src32 = pmc_traffic(hi - lo, False)
+        fp32_rows = {"kernel": "mi355::scan_kernel<ScanCfg<512,1,6,2>, true, false, 0, true>", "steps": args.steps,
+                     "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 5), "value": round(1.0 / dt, 2),
+                     "unit": "queries/s", "p50_ms": round(lat32[len(lat32) // 2], 4) if lat32 else None,
+                     "roofline": {"bound": "hbm", "algorithmic_bytes_per_launch": (hi - lo) * BYTES_PER_ROW,
+                                  "avg_kernel_ms": round(k_ms, 5),
+                                  "achieved": round((hi - lo) * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
+                                  "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": round((hi - lo) * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if k_ms > 0 else None,
+                                  "traffic": t32, "traffic_source": src32}}
 
     # micro-batched throughput, outside the timed region:
     # 12 queries share one pass over the catalogue, seed/final merge launches shared by 36
