@@ -455,7 +455,7 @@ def main():
         cache_resident = alg_bytes <= 128 * 2**20
         traffic_bytes, traffic_source = pmc_traffic(hi - lo, replica)
         if replica:
-            kernel_name = ("mi355::scan_half_kernel<HalfCfg<512,4,3>, true, " + ("true" if streamed else "false") + "> over the "
+            kernel_name = ("mi355::scan_half_kernel<HalfCfg<512,4,2>, true, " + ("true" if streamed else "false") + "> over the "
                            "fp16 replica (24 B/row; rows it cannot rule out are fetched from the fp32 matrix and scored by "
                            "the exact chain" + ("; the previous query's merge rides in its last workgroup)" if streamed else ")"))
         else:
