@@ -339,7 +339,8 @@ def main():
         micro = {"queries_per_call": nb, "value": round(nb / dt, 1), "unit": "queries/s",
                  "ms_per_call": round(dt * 1e3, 5),
                  "note": ("one call = one pass pair of the batched matrix-core path over the fp16 replica "
-                          "(mi355::bq_pass_kernel<2, .., true>: a block of <= 32 queries costs the same)" if replica else
+                          "(mi355::bq_pass_kernel<2, .., true>: a block of <= 32 queries costs the same)"
+                          if (replica and sharded is None) else
                           "one call = the path mi355rec_enqueue_batch_keys picks for this batch size; "
                           + ("single GPU" if sharded is None else "one all-gather per call"))}
         if sharded is None:
@@ -455,9 +456,10 @@ def main():
         cache_resident = alg_bytes <= 128 * 2**20
         traffic_bytes, traffic_source = pmc_traffic(hi - lo, replica)
         if replica:
-            kernel_name = ("mi355::scan_half_kernel<HalfCfg<512,4,2>, true, " + ("true" if streamed else "false") + "> over the "
+            targs = "true, true" if streamed else ("true, false" if sharded is None else "false, true")
+            kernel_name = ("mi355::scan_half_kernel<HalfCfg<512,4,2>, " + targs + "> over the "
                            "fp16 replica (24 B/row; rows it cannot rule out are fetched from the fp32 matrix and scored by "
-                           "the exact chain" + ("; the previous query's merge rides in its last workgroup)" if streamed else ")"))
+                           "the exact chain" + (")" if (sharded is None and not streamed) else "; the previous query's merge rides in its last workgroup)"))
         else:
             kernel_name = ("mi355::scan_kernel<ScanCfg<512,1,6,2>, true, false, 0, true> (query = catalogue row; the previous "
                            "query's merge rides in its last workgroup)" if streamed else
