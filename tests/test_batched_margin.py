@@ -82,3 +82,34 @@ def test_prefilter_error_stays_inside_the_margin(flush):
                 assert err.max() < MARGIN[flush], (name, flush, float(err.max()))
     # the bound is not vacuous: fp16 rounding of both operands really costs ~2^-11..2^-10
     assert 1e-4 < worst < MARGIN[flush], worst
+
+
+def test_sequential_fp32_accumulation_stays_inside_the_slack():
+    """The scan over the fp16 replica (csrc/replica.hip.h) accumulates the twelve exact fp16 x fp16
+    products with fp32 FMAs in index order instead of inside the matrix core.  Against the exactly
+    summed products that costs at most a few 1e-7 — far inside the 4e-6 of slack (kBqSlack) that the
+    cutoff leaves on top of the margin."""
+    rng = np.random.default_rng(5)
+    n = 40_000
+    worst = 0.0
+    for name, f in catalogues(rng, n):
+        q = f[rng.integers(0, n)]
+        rows = f.astype(np.float32)
+        n2 = np.zeros(n, np.float32)
+        for j in range(12):
+            n2 = n2 + rows[:, j] * rows[:, j]
+        valid = (n2 >= np.float32(MIN_NORM2)) & (n2 <= np.float32(MAX_NORM2))
+        inv = np.zeros_like(n2)
+        inv[valid] = (np.float32(1) / np.sqrt(n2[valid])).astype(np.float32)
+        rh = to_f16((rows * inv[:, None]).astype(np.float32), False)[valid]
+        qn = np.float32(np.sqrt(np.sum(q.astype(np.float32) ** 2, dtype=np.float32)))
+        if not (1.005e-4 <= qn <= 1e18):
+            continue
+        qh = to_f16((q.astype(np.float32) / qn).astype(np.float32), False)
+        exact_sum = rh @ qh                                   # float64: the products and their sum are exact enough
+        acc = np.zeros(len(rh), np.float32)
+        for j in range(12):                                   # v_fma_mix_f32: fl32(x * y + acc), the product exact
+            acc = (acc.astype(np.float64) + rh[:, j] * qh[j]).astype(np.float32)
+        if len(rh):
+            worst = max(worst, float(np.abs(acc.astype(np.float64) - exact_sum).max()))
+    assert worst < 1e-6, worst

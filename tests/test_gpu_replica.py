@@ -278,3 +278,62 @@ def test_handle_without_a_replica(Engine):
             assert eng.replica_counters() == {"scans": 0, "rescored_rows": 0}
     finally:
         del os.environ["MI355REC_REPLICA"]
+
+
+def test_replica_queries_replay_from_a_hip_graph(Engine, torch_cuda):
+    """Seed + scan + merge allocate nothing and never synchronise, so single queries over the
+    replica can be captured into a hipGraph (torch's CUDAGraph on a side stream) and replayed —
+    here with the same query rows over new catalogue bytes (borrowed matrix overwritten in place,
+    replica rebuilt)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(15)
+    n, topn = 500_000, 50
+    f = rng.random((n, 12), dtype=np.float32)
+    t = torch.from_numpy(f).cuda()
+    side = torch.cuda.Stream()
+    rows = [5, 123_456, n - 1]
+    keys = torch.zeros((len(rows), topn), dtype=torch.int64, device="cuda")
+    with Engine(t) as eng:
+        eng.set_replica(ON)
+        with torch.cuda.stream(side):
+            for i, r in enumerate(rows):
+                eng.enqueue_row_keys(r, topn, keys[i], stream=side)     # warm-up on the capture stream
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            for i, r in enumerate(rows):
+                eng.enqueue_row_keys(r, topn, keys[i], stream=side)
+        for trial in range(2):
+            if trial:
+                f = np.random.default_rng(16).random((n, 12), dtype=np.float32)
+                t.copy_(torch.from_numpy(f))
+                torch.cuda.synchronize()
+                eng.rebuild_replica()
+            keys.zero_()
+            torch.cuda.synchronize()
+            graph.replay()
+            torch.cuda.synchronize()
+            got = keys.cpu().numpy().view(np.uint64)
+            for i, r in enumerate(rows):
+                want = oracle.scores(f, f[r], threads=0)
+                idx = (~got[i] & np.uint64(0xffffffff)).astype(np.int64)
+                assert_topn_matches(idx, None, want, r, topn, ref_idx=oracle.topn_heap(want, r, topn))
+
+
+def test_sharded_node_with_replica_sized_shards():
+    """mi355rec_create_sharded over two VIRTUAL shards of > 2 Mi rows each: every shard's single
+    queries take the replica scan under AUTO, the peer-store merge sees the same keys."""
+    from spotify_recommender_amd.engine import NodeEngine
+    rng = np.random.default_rng(17)
+    n = 4_300_001
+    f = rng.random((n, 12), dtype=np.float32)
+    with NodeEngine(f, devices=[0, 0]) as node:
+        assert min(node.info()["shard_rows"]) >= 2 * 1024 * 1024
+        for row in (3, n // 2 + 1, n - 1):
+            idx, sc = node.query_row_topn(row, 100)
+            want = oracle.scores(f, f[row], threads=0)
+            assert_topn_matches(idx, sc, want, row, 100, ref_idx=oracle.topn_heap(want, row, 100))
+        q = rng.random(12, dtype=np.float32)
+        idx, sc = node.query_topn(q, -1, 10)
+        want = oracle.scores(f, q, threads=0)
+        assert_topn_matches(idx, sc, want, -1, 10, ref_idx=oracle.topn_heap(want, -1, 10))
