@@ -8,6 +8,7 @@
 #include "mi355rec.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -429,6 +430,36 @@ void timing_end(mi355rec* h, std::vector<hipEvent_t>& evs, int& pairs, int slot,
     pairs = slot + 1;
 }
 
+// The event pair of the next timed launch, NOT recorded: LAUNCH_TIMED hands it to the dispatch
+// itself (hipExtLaunchKernelGGL), so it stamps the kernel's own start and end — the same
+// interval rocprofv3 reports — instead of two extra stream commands around the launch (those
+// bracket the dispatch too: +3 us on a 40 us kernel).
+int timing_slot(mi355rec* h, std::vector<hipEvent_t>& evs, int& pairs, int& launches) {
+    if (!h->timing) return -1;
+    if ((launches++ % h->timing_stride) != 0) return -1;
+    if (pairs >= kTimingPairs) return -1;
+    if (static_cast<int>(evs.size()) < 2 * (pairs + 1)) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess) return -1;
+        if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return -1; }
+        evs.push_back(a);
+        evs.push_back(b);
+    }
+    return pairs;
+}
+
+#define LAUNCH_TIMED(h, evs, pairs, launches, kernel, grid, block, s, ...)                                  \
+    do {                                                                                                    \
+        const int slot_ = timing_slot((h), (evs), (pairs), (launches));                                     \
+        if (slot_ >= 0) {                                                                                   \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, s, (evs)[2 * slot_], (evs)[2 * slot_ + 1], 0,      \
+                                  __VA_ARGS__);                                                             \
+            (pairs) = slot_ + 1;                                                                            \
+        } else {                                                                                            \
+            hipLaunchKernelGGL(kernel, grid, block, 0, s, __VA_ARGS__);                                     \
+        }                                                                                                   \
+    } while (0)
+
 bool use_half(const mi355rec* h, const uint64_t* upper_dev) {
     if (!h->d_half || upper_dev || h->replica_mode == MI355REC_REPLICA_OFF) return false;
     return h->replica_mode == MI355REC_REPLICA_ON || h->n >= kHalfAutoMinRows;
@@ -458,34 +489,34 @@ int enqueue_scan(mi355rec* h, int64_t query_row, const float* query12,
         *n_lists = h->hgrid;
         ++h->half_scans;
         enqueue_half_seed(h, query_row, qa, exclude_global, s);
-        const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, s);
         if (query_row >= 0) {
-            hipLaunchKernelGGL((scan_half_kernel<HalfConfig, true, false>), dim3(h->hgrid), dim3(HalfConfig::kBlock), 0, s,
+            LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, true, false>),
+                         dim3(h->hgrid), dim3(HalfConfig::kBlock), s,
                                h->d_feats, h->d_half, h->n, h->hiters, h->row_base, qa, query_row, exclude_global, topn,
                                h->d_block_lists, h->d_half_seed, h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, none);
         } else {
-            hipLaunchKernelGGL((scan_half_kernel<HalfConfig, false, false>), dim3(h->hgrid), dim3(HalfConfig::kBlock), 0, s,
+            LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, false, false>),
+                         dim3(h->hgrid), dim3(HalfConfig::kBlock), s,
                                h->d_feats, h->d_half, h->n, h->hiters, h->row_base, qa, static_cast<int64_t>(0), exclude_global,
                                topn, h->d_block_lists, h->d_half_seed, h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, none);
         }
-        timing_end(h, h->ev_scan, h->n_scan_pairs, slot, s);
         HIP_TRY(h, hipGetLastError());
         return MI355REC_OK;
     }
     *n_lists = h->grid;
-    const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, s);
     if (query_row >= 0) {
-        hipLaunchKernelGGL((scan_kernel<ScanConfig, true, false>), dim3(h->grid), dim3(kScanBlock), 0, s,
+        LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_kernel<ScanConfig, true, false>),
+                     dim3(h->grid), dim3(kScanBlock), s,
                            h->d_feats, h->n, h->rows_per_block, h->iters, h->row_base, qa,
                            query_row, exclude_global, topn, h->d_block_lists,
                            static_cast<float*>(nullptr), upper_dev, none);
     } else {
-        hipLaunchKernelGGL((scan_kernel<ScanConfig, false, false>), dim3(h->grid), dim3(kScanBlock), 0, s,
+        LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_kernel<ScanConfig, false, false>),
+                     dim3(h->grid), dim3(kScanBlock), s,
                            h->d_feats, h->n, h->rows_per_block, h->iters, h->row_base, qa,
                            static_cast<int64_t>(0), exclude_global, topn, h->d_block_lists,
                            static_cast<float*>(nullptr), upper_dev, none);
     }
-    timing_end(h, h->ev_scan, h->n_scan_pairs, slot, s);
     HIP_TRY(h, hipGetLastError());
     return MI355REC_OK;
 }
@@ -540,12 +571,11 @@ int enqueue_multi(mi355rec* h, const float* queries, const int64_t* exclude, int
     }
     for (int g = 0; g < groups; ++g) {
         const int nq = count - g * kMultiQueries < kMultiQueries ? count - g * kMultiQueries : kMultiQueries;
-        const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, s);
-        hipLaunchKernelGGL((scan_multi_kernel<MultiConfig>), dim3(h->mgrid), dim3(MultiConfig::kBlock), 0, s,
+        LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_multi_kernel<MultiConfig>),
+                     dim3(h->mgrid), dim3(MultiConfig::kBlock), s,
                            h->d_feats, h->n, static_cast<int64_t>(0), static_cast<int64_t>(0), h->miters, h->row_base,
                            qa[g], nq, g * kMultiQueries, topn, h->d_block_lists,
                            seeded ? h->d_seed_keys : static_cast<const uint64_t*>(nullptr));
-        timing_end(h, h->ev_scan, h->n_scan_pairs, slot, s);
     }
     HIP_TRY(h, hipGetLastError());
     const int slot = timing_begin(h, h->ev_merge, h->n_merge_pairs, h->merge_launches, s);
@@ -639,18 +669,18 @@ int enqueue_streamed(mi355rec* h, int64_t query_row, const float* query12, int64
         ++h->half_scans;
         if (query_row < 0) std::memcpy(qa.q, query12, sizeof qa.q);
         enqueue_half_seed(h, query_row, qa, exclude_global, s);
-        const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, s);
         if (query_row >= 0) {
-            hipLaunchKernelGGL((scan_half_kernel<HalfConfig, true, true>), dim3(h->hsgrid + 1), dim3(HalfConfig::kBlock), 0, s,
+            LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, true, true>),
+                         dim3(h->hsgrid + 1), dim3(HalfConfig::kBlock), s,
                                h->d_feats, h->d_half, h->n, h->hsiters, h->row_base, qa, query_row, exclude_global, topn,
                                h->d_stream_lists[buf], h->d_half_seed, h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, prev);
         } else {
-            hipLaunchKernelGGL((scan_half_kernel<HalfConfig, false, true>), dim3(h->hsgrid + 1), dim3(HalfConfig::kBlock), 0, s,
+            LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, false, true>),
+                         dim3(h->hsgrid + 1), dim3(HalfConfig::kBlock), s,
                                h->d_feats, h->d_half, h->n, h->hsiters, h->row_base, qa, static_cast<int64_t>(0),
                                exclude_global, topn, h->d_stream_lists[buf], h->d_half_seed, h->hseed_grid * kHalfSeedWaves,
                                h->d_half_rescored, prev);
         }
-        timing_end(h, h->ev_scan, h->n_scan_pairs, slot, s);
         HIP_TRY(h, hipGetLastError());
         h->pending = true;
         h->pending_buf = buf;
@@ -659,20 +689,20 @@ int enqueue_streamed(mi355rec* h, int64_t query_row, const float* query12, int64
         h->pending_lists = h->hsgrid;
         return MI355REC_OK;
     }
-    const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, s);
     if (query_row >= 0) {
-        hipLaunchKernelGGL((scan_kernel<ScanConfig, true, false, 0, true>), dim3(h->sgrid + 1), dim3(kScanBlock), 0, s,
+        LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_kernel<ScanConfig, true, false, 0, true>),
+                     dim3(h->sgrid + 1), dim3(kScanBlock), s,
                            h->d_feats, h->n, static_cast<int64_t>(0), h->siters, h->row_base, qa, query_row,
                            exclude_global, topn, h->d_stream_lists[buf], static_cast<float*>(nullptr),
                            static_cast<const uint64_t*>(nullptr), prev);
     } else {
         std::memcpy(qa.q, query12, sizeof qa.q);
-        hipLaunchKernelGGL((scan_kernel<ScanConfig, false, false, 0, true>), dim3(h->sgrid + 1), dim3(kScanBlock), 0, s,
+        LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_kernel<ScanConfig, false, false, 0, true>),
+                     dim3(h->sgrid + 1), dim3(kScanBlock), s,
                            h->d_feats, h->n, static_cast<int64_t>(0), h->siters, h->row_base, qa, static_cast<int64_t>(0),
                            exclude_global, topn, h->d_stream_lists[buf], static_cast<float*>(nullptr),
                            static_cast<const uint64_t*>(nullptr), prev);
     }
-    timing_end(h, h->ev_scan, h->n_scan_pairs, slot, s);
     HIP_TRY(h, hipGetLastError());
     h->pending = true;
     h->pending_buf = buf;
@@ -1248,10 +1278,9 @@ int mi355rec_enqueue_stream_probe(mi355rec_t* h, uint32_t* sink_dev, void* strea
     if (h->n == 0) return MI355REC_OK;
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int slot = timing_begin(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, s);
-    hipLaunchKernelGGL(stream_probe_kernel, dim3(h->cus), dim3(kProbeBlock), 0, s,
+    LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, stream_probe_kernel,
+                 dim3(h->cus), dim3(kProbeBlock), s,
                        reinterpret_cast<const float4*>(h->d_feats), h->n * 3, sink_dev);
-    timing_end(h, h->ev_scan, h->n_scan_pairs, slot, s);
     HIP_TRY(h, hipGetLastError());
     return MI355REC_OK;
 }
