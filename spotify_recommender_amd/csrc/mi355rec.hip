@@ -492,13 +492,13 @@ int enqueue_scan(mi355rec* h, int64_t query_row, const float* query12,
         if (query_row >= 0) {
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, true, false>),
                          dim3(h->hgrid), dim3(HalfConfig::kBlock), s,
-                               h->d_feats, h->d_half, h->n, h->hiters, h->row_base, qa, query_row, exclude_global, topn,
-                               h->d_block_lists, h->d_half_seed, h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, none);
+                         h->d_feats, h->d_half, h->n, h->hiters, h->row_base, qa, query_row, exclude_global, topn,
+                         h->d_block_lists, h->d_half_seed, h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, none);
         } else {
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, false, false>),
                          dim3(h->hgrid), dim3(HalfConfig::kBlock), s,
-                               h->d_feats, h->d_half, h->n, h->hiters, h->row_base, qa, static_cast<int64_t>(0), exclude_global,
-                               topn, h->d_block_lists, h->d_half_seed, h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, none);
+                         h->d_feats, h->d_half, h->n, h->hiters, h->row_base, qa, static_cast<int64_t>(0), exclude_global,
+                         topn, h->d_block_lists, h->d_half_seed, h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, none);
         }
         HIP_TRY(h, hipGetLastError());
         return MI355REC_OK;
@@ -507,15 +507,15 @@ int enqueue_scan(mi355rec* h, int64_t query_row, const float* query12,
     if (query_row >= 0) {
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_kernel<ScanConfig, true, false>),
                      dim3(h->grid), dim3(kScanBlock), s,
-                           h->d_feats, h->n, h->rows_per_block, h->iters, h->row_base, qa,
-                           query_row, exclude_global, topn, h->d_block_lists,
-                           static_cast<float*>(nullptr), upper_dev, none);
+                     h->d_feats, h->n, h->rows_per_block, h->iters, h->row_base, qa,
+                     query_row, exclude_global, topn, h->d_block_lists,
+                     static_cast<float*>(nullptr), upper_dev, none);
     } else {
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_kernel<ScanConfig, false, false>),
                      dim3(h->grid), dim3(kScanBlock), s,
-                           h->d_feats, h->n, h->rows_per_block, h->iters, h->row_base, qa,
-                           static_cast<int64_t>(0), exclude_global, topn, h->d_block_lists,
-                           static_cast<float*>(nullptr), upper_dev, none);
+                     h->d_feats, h->n, h->rows_per_block, h->iters, h->row_base, qa,
+                     static_cast<int64_t>(0), exclude_global, topn, h->d_block_lists,
+                     static_cast<float*>(nullptr), upper_dev, none);
     }
     HIP_TRY(h, hipGetLastError());
     return MI355REC_OK;
@@ -573,9 +573,9 @@ int enqueue_multi(mi355rec* h, const float* queries, const int64_t* exclude, int
         const int nq = count - g * kMultiQueries < kMultiQueries ? count - g * kMultiQueries : kMultiQueries;
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_multi_kernel<MultiConfig>),
                      dim3(h->mgrid), dim3(MultiConfig::kBlock), s,
-                           h->d_feats, h->n, static_cast<int64_t>(0), static_cast<int64_t>(0), h->miters, h->row_base,
-                           qa[g], nq, g * kMultiQueries, topn, h->d_block_lists,
-                           seeded ? h->d_seed_keys : static_cast<const uint64_t*>(nullptr));
+                     h->d_feats, h->n, static_cast<int64_t>(0), static_cast<int64_t>(0), h->miters, h->row_base,
+                     qa[g], nq, g * kMultiQueries, topn, h->d_block_lists,
+                     seeded ? h->d_seed_keys : static_cast<const uint64_t*>(nullptr));
     }
     HIP_TRY(h, hipGetLastError());
     const int slot = timing_begin(h, h->ev_merge, h->n_merge_pairs, h->merge_launches, s);
@@ -672,14 +672,14 @@ int enqueue_streamed(mi355rec* h, int64_t query_row, const float* query12, int64
         if (query_row >= 0) {
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, true, true>),
                          dim3(h->hsgrid + 1), dim3(HalfConfig::kBlock), s,
-                               h->d_feats, h->d_half, h->n, h->hsiters, h->row_base, qa, query_row, exclude_global, topn,
-                               h->d_stream_lists[buf], h->d_half_seed, h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, prev);
+                         h->d_feats, h->d_half, h->n, h->hsiters, h->row_base, qa, query_row, exclude_global, topn,
+                         h->d_stream_lists[buf], h->d_half_seed, h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, prev);
         } else {
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, false, true>),
                          dim3(h->hsgrid + 1), dim3(HalfConfig::kBlock), s,
-                               h->d_feats, h->d_half, h->n, h->hsiters, h->row_base, qa, static_cast<int64_t>(0),
-                               exclude_global, topn, h->d_stream_lists[buf], h->d_half_seed, h->hseed_grid * kHalfSeedWaves,
-                               h->d_half_rescored, prev);
+                         h->d_feats, h->d_half, h->n, h->hsiters, h->row_base, qa, static_cast<int64_t>(0),
+                         exclude_global, topn, h->d_stream_lists[buf], h->d_half_seed, h->hseed_grid * kHalfSeedWaves,
+                         h->d_half_rescored, prev);
         }
         HIP_TRY(h, hipGetLastError());
         h->pending = true;
@@ -692,16 +692,16 @@ int enqueue_streamed(mi355rec* h, int64_t query_row, const float* query12, int64
     if (query_row >= 0) {
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_kernel<ScanConfig, true, false, 0, true>),
                      dim3(h->sgrid + 1), dim3(kScanBlock), s,
-                           h->d_feats, h->n, static_cast<int64_t>(0), h->siters, h->row_base, qa, query_row,
-                           exclude_global, topn, h->d_stream_lists[buf], static_cast<float*>(nullptr),
-                           static_cast<const uint64_t*>(nullptr), prev);
+                     h->d_feats, h->n, static_cast<int64_t>(0), h->siters, h->row_base, qa, query_row,
+                     exclude_global, topn, h->d_stream_lists[buf], static_cast<float*>(nullptr),
+                     static_cast<const uint64_t*>(nullptr), prev);
     } else {
         std::memcpy(qa.q, query12, sizeof qa.q);
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_kernel<ScanConfig, false, false, 0, true>),
                      dim3(h->sgrid + 1), dim3(kScanBlock), s,
-                           h->d_feats, h->n, static_cast<int64_t>(0), h->siters, h->row_base, qa, static_cast<int64_t>(0),
-                           exclude_global, topn, h->d_stream_lists[buf], static_cast<float*>(nullptr),
-                           static_cast<const uint64_t*>(nullptr), prev);
+                     h->d_feats, h->n, static_cast<int64_t>(0), h->siters, h->row_base, qa, static_cast<int64_t>(0),
+                     exclude_global, topn, h->d_stream_lists[buf], static_cast<float*>(nullptr),
+                     static_cast<const uint64_t*>(nullptr), prev);
     }
     HIP_TRY(h, hipGetLastError());
     h->pending = true;
@@ -1280,7 +1280,7 @@ int mi355rec_enqueue_stream_probe(mi355rec_t* h, uint32_t* sink_dev, void* strea
     hipStream_t s = static_cast<hipStream_t>(stream);
     LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, stream_probe_kernel,
                  dim3(h->cus), dim3(kProbeBlock), s,
-                       reinterpret_cast<const float4*>(h->d_feats), h->n * 3, sink_dev);
+                 reinterpret_cast<const float4*>(h->d_feats), h->n * 3, sink_dev);
     HIP_TRY(h, hipGetLastError());
     return MI355REC_OK;
 }
