@@ -140,6 +140,7 @@ struct mi355rec {
         bool slot_used[kSlots] = {false, false, false, false};
         int next_slot = 0;
         int launches = 0;                // chunks enqueued (stats)
+        int last_count = 0;              // queries of the last chunk (what the diagnostics cover)
     } bq;
     int batch_path = 0;               // MI355REC_BATCH_AUTO / _MULTI / _MFMA
 
@@ -757,6 +758,7 @@ int ensure_bq_alloc(mi355rec* h) {
     HIP_TRY(h, hipMalloc(&b.qthr, sizeof(float) * kBqMaxQueries));
     HIP_TRY(h, hipMalloc(&b.qflags, sizeof(uint32_t) * kBqMaxQueries));
     HIP_TRY(h, hipMalloc(&b.cand_count, sizeof(int) * kBqMaxQueries * kBqCountStride));
+    HIP_TRY(h, hipMemsetAsync(b.cand_count, 0, sizeof(int) * kBqMaxQueries * kBqCountStride, h->stream));
     HIP_TRY(h, hipMalloc(&b.cand_rows, sizeof(uint32_t) * static_cast<size_t>(kBqMaxQueries) * kBqCap));
     HIP_TRY(h, hipMalloc(&b.counters, sizeof(int) * 4));
     HIP_TRY(h, hipMalloc(&b.special_rows, sizeof(uint32_t) * kBqSpecialCap));
@@ -858,6 +860,7 @@ int enqueue_bq_chunk(mi355rec* h, const float* d_queries, const long long* d_exc
                        out_keys, out_idx, out_score, static_cast<int64_t>(topn));
     HIP_TRY(h, hipGetLastError());
     ++b.launches;
+    b.last_count = count;
     return MI355REC_OK;
 }
 
@@ -1154,8 +1157,8 @@ int mi355rec_batched_last_counters(mi355rec_t* h, int32_t* special_rows, int32_t
     HIP_TRY(h, hipMemcpy(flags.data(), h->bq.qflags, sizeof(uint32_t) * kBqMaxQueries, hipMemcpyDeviceToHost));
     int64_t total = 0;
     int mx = 0;
-    for (int q = 0; q < kBqMaxQueries; ++q) {
-        if (flags[q] != kBqFlagOk) continue;   // padding, or rows of an earlier, larger chunk
+    for (int q = 0; q < h->bq.last_count; ++q) {   // slots past the last chunk hold an earlier chunk's values, or nothing
+        if (flags[q] != kBqFlagOk) continue;       // queued to the exact scan
         total += cand[q];
         if (cand[q] > mx) mx = cand[q];
     }
