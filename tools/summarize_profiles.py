@@ -7,12 +7,19 @@ import collections
 import csv
 import glob
 import json
+import os
 import shutil
 import sys
 
+
+def newest(pattern):
+    """gpurun merges every run's files into the same directory: take the latest."""
+    return max(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+
+
 tag, trace_dir, fetch_dir, write_dir, bench_json = sys.argv[1:6]
 rows = int(sys.argv[6]) if len(sys.argv) > 6 else 10_000_000
-stats = glob.glob(f"{trace_dir}/**/*kernel_stats.csv", recursive=True)[0]
+stats = newest(f"{trace_dir}/**/*kernel_stats.csv")
 keep = []
 with open(stats) as f:
     rd = csv.DictReader(f)
@@ -34,7 +41,7 @@ out = {
     "kernels": {},
 }
 for name, d in (("FETCH_SIZE", fetch_dir), ("WRITE_SIZE", write_dir)):
-    f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
+    f = newest(f"{d}/**/*counter_collection.csv")
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "mi355::" in r["Kernel_Name"] and r["Counter_Name"] == name:
