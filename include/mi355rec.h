@@ -197,11 +197,17 @@ int mi355rec_enqueue_query_keys(mi355rec_t* h, const float* query12,
 /* STREAMED single queries: as mi355rec_enqueue_row_keys / _query_keys (topn <= 1024), but
  * the device merge of this query is deferred — it runs inside the scan launch of the NEXT
  * streamed query on this handle (one extra workgroup merges the previous query's
- * per-workgroup lists while the others scan), or in mi355rec_enqueue_flush.  The keys of
- * query k are therefore complete when the work enqueued by streamed call k + 1, or by
- * the flush, has completed; out_keys_dev must stay valid until then.  A stream of K
- * queries costs K scan launches + ONE merge launch instead of K + K, which removes the
- * ~10 us one-workgroup merge kernel from every step but the last. */
+ * per-workgroup lists while the others scan), or in mi355rec_enqueue_flush.  On a shard
+ * that scans its fp16 replica the stream additionally runs ONE CALL BEHIND: call k + 1
+ * LAUNCHES the scan of query k, and a few workgroups of that launch take the sample that
+ * seeds query k + 1's cutoff, so no query but the first needs a seed launch of its own
+ * (the launch goes to the stream of the call that issues it; the query vector is copied
+ * by the call that passes it).  The keys of query k are therefore complete when the work
+ * enqueued by streamed call k + 2 (k + 1 over the fp32 rows), or by the flush, has
+ * completed; out_keys_dev must stay valid until then — in practice: flush, then
+ * synchronise, then read.  A stream of K queries costs K scan launches + ONE merge launch
+ * (+ one seed launch) instead of 3 K, which removes the ~10 us one-workgroup merge kernel
+ * and the ~5 us seed kernel from every step. */
 int mi355rec_enqueue_row_keys_streamed(mi355rec_t* h, int64_t local_row, int topn,
                                        mi355rec_key_t* out_keys_dev, void* stream);
 int mi355rec_enqueue_query_keys_streamed(mi355rec_t* h, const float* query12,

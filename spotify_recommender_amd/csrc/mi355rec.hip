@@ -88,6 +88,21 @@ struct mi355rec {
     int replica_mode = 0;               // MI355REC_REPLICA_AUTO / _OFF / _ON
     float replica_build_ms = 0.f;
     int pending_lists = 0;              // lists of the streamed query that waits for its merge
+    // Streamed queries over the replica run ONE CALL BEHIND: query k is launched by call k + 1 (or
+    // by the flush), so that its launch can carry the sample of query k + 1 (seed riders) instead
+    // of a seed launch per query.
+    struct Stashed {
+        bool has = false;
+        int64_t row = -1;               // local row of the query, or -1: q holds the vector
+        float q[kDim] = {0};
+        int64_t exclude = -1;
+        int topn = 0;
+        uint64_t* out = nullptr;
+        int seed_buf = 0;               // which of d_stream_seed holds ITS sample maxima
+    } stashed;
+    uint32_t* d_stream_seed[2] = {nullptr, nullptr};
+    int hs_riders = 0;                  // seed riders of a streamed launch
+    int hs_scan = 0, hs_iters = 0;      // its scanners and their tiles
     uint32_t* d_seed_vals = nullptr;    // kMultiChain x (mgrid * kSeedWaves) sample maxima
     uint64_t* d_seed_keys = nullptr;    // kMultiChain x kMultiMaxTopK: sample top-k per query of a multi-query chain
 
@@ -250,6 +265,26 @@ void plan_half_grid(mi355rec* h) {
     if (sg > kHalfSeedMaxGrid) sg = kHalfSeedMaxGrid;
     h->hseed_grid = static_cast<int>(sg);
     h->hseed_stride = sg > 0 ? ((h->n / sg) & ~static_cast<int64_t>(1)) : 0;
+    // seed riders of a streamed launch: each takes four regions per memory round trip (~2 us) and
+    // should be done well before the scanners (~2.1 us per tile) are
+    h->hs_riders = 0;
+    h->hs_scan = h->hsgrid;
+    h->hs_iters = h->hsiters;
+    if (sg > 0 && h->hgrid >= 16) {
+        int rounds = static_cast<int>(h->hsiters * 2.1 / 12.0);
+        if (rounds < 1) rounds = 1;
+        int riders = static_cast<int>((sg + 4 * rounds - 1) / (4 * rounds));
+        if (riders > h->hgrid / 8) riders = h->hgrid / 8;
+        if (const char* e = std::getenv("MI355REC_EXP_RIDERS")) {   // A/B experiment only
+            const int v = std::atoi(e);
+            if (v >= 0 && v <= h->hgrid / 2) riders = v;
+        }
+        if (riders > 0) {
+            h->hs_riders = riders;
+            h->hs_scan = h->hgrid - 1 - riders;
+            h->hs_iters = static_cast<int>((tiles + h->hs_scan - 1) / h->hs_scan);
+        }
+    }
 }
 
 // (Re)builds the replica from the fp32 rows on the handle's stream and waits for it.
@@ -487,6 +522,8 @@ int enqueue_scan(mi355rec* h, int64_t query_row, const float* query12,
     if (query_row < 0) std::memcpy(qa.q, query12, sizeof qa.q);
     const PrevMerge none{nullptr, 0, 0, nullptr};
     if (use_half(h, upper_dev)) {
+        NextSeed no_next;
+        std::memset(&no_next, 0, sizeof no_next);
         *n_lists = h->hgrid;
         ++h->half_scans;
         enqueue_half_seed(h, query_row, qa, exclude_global, s);
@@ -494,12 +531,12 @@ int enqueue_scan(mi355rec* h, int64_t query_row, const float* query12,
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, true, false>),
                          dim3(h->hgrid), dim3(HalfConfig::kBlock), s,
                          h->d_feats, h->d_half, h->n, h->hiters, h->row_base, qa, query_row, exclude_global, topn,
-                         h->d_block_lists, h->d_half_seed, h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, none);
+                         h->d_block_lists, h->d_half_seed, h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next);
         } else {
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, false, false>),
                          dim3(h->hgrid), dim3(HalfConfig::kBlock), s,
                          h->d_feats, h->d_half, h->n, h->hiters, h->row_base, qa, static_cast<int64_t>(0), exclude_global,
-                         topn, h->d_block_lists, h->d_half_seed, h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, none);
+                         topn, h->d_block_lists, h->d_half_seed, h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next);
         }
         HIP_TRY(h, hipGetLastError());
         return MI355REC_OK;
@@ -642,54 +679,128 @@ int ensure_streamed(mi355rec* h) {
     const int most = g > h->hsgrid ? g : h->hsgrid;
     for (int i = 0; i < 2; ++i)
         HIP_TRY(h, hipMalloc(&h->d_stream_lists[i], sizeof(uint64_t) * static_cast<size_t>(most) * kMaxTopK));
+    if (h->d_half)
+        for (int i = 0; i < 2; ++i)
+            HIP_TRY(h, hipMalloc(&h->d_stream_seed[i], sizeof(uint32_t) * kHalfSeedMaxGrid * kHalfSeedWaves));
     return MI355REC_OK;
 }
 
+int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, int64_t next_row, const float* next_q,
+                   int64_t next_exclude, int next_buf);
+
 int flush_streamed(mi355rec* h, hipStream_t s) {
+    if (h->stashed.has) {
+        const int rc = launch_stashed(h, s, false, -1, nullptr, -1, 0);
+        if (rc) return rc;
+    }
     if (!h->pending) return MI355REC_OK;
     h->pending = false;
     return enqueue_merge(h, h->d_stream_lists[h->pending_buf], h->pending_lists, h->pending_topn, h->pending_topn,
                          h->pending_out, nullptr, nullptr, s);
 }
 
+// Launches the stashed streamed query over the replica: scanners + the riding merger of the query
+// before it + (with_next) the seed riders of the query after it.
+int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, int64_t next_row, const float* next_q,
+                   int64_t next_exclude, int next_buf) {
+    auto& st = h->stashed;
+    const int buf = h->pending ? 1 - h->pending_buf : 0;
+    PrevMerge prev{nullptr, 0, 0, nullptr};
+    if (h->pending) prev = PrevMerge{h->d_stream_lists[h->pending_buf], h->pending_lists, h->pending_topn, h->pending_out};
+    NextSeed next;
+    std::memset(&next, 0, sizeof next);
+    next.query_row = -1;
+    next.exclude_global = -1;
+    int scanners = h->hsgrid, iters = h->hsiters;
+    if (with_next && h->hs_riders > 0) {
+        next.query_row = next_row;
+        if (next_row < 0) std::memcpy(next.q, next_q, sizeof next.q);
+        next.exclude_global = next_exclude;
+        next.out = h->d_stream_seed[next_buf];
+        next.n_wgs = h->hs_riders;
+        next.regions = h->hseed_grid;
+        next.stride_rows = h->hseed_stride;
+        scanners = h->hs_scan;
+        iters = h->hs_iters;
+    }
+    QueryArg qa;
+    std::memset(&qa, 0, sizeof qa);
+    const int n_seed = h->hseed_grid * kHalfSeedWaves;
+    ++h->half_scans;
+    if (st.row >= 0) {
+        LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, true, true>),
+                     dim3(scanners + 1 + next.n_wgs), dim3(HalfConfig::kBlock), s,
+                     h->d_feats, h->d_half, h->n, iters, h->row_base, qa, st.row, st.exclude, st.topn,
+                     h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], n_seed, h->d_half_rescored, prev, next);
+    } else {
+        std::memcpy(qa.q, st.q, sizeof qa.q);
+        LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, false, true>),
+                     dim3(scanners + 1 + next.n_wgs), dim3(HalfConfig::kBlock), s,
+                     h->d_feats, h->d_half, h->n, iters, h->row_base, qa, static_cast<int64_t>(0), st.exclude, st.topn,
+                     h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], n_seed, h->d_half_rescored, prev, next);
+    }
+    HIP_TRY(h, hipGetLastError());
+    h->pending = true;
+    h->pending_buf = buf;
+    h->pending_topn = st.topn;
+    h->pending_out = st.out;
+    h->pending_lists = scanners;
+    st.has = false;
+    return MI355REC_OK;
+}
+
 int enqueue_streamed(mi355rec* h, int64_t query_row, const float* query12, int64_t exclude_global, int topn,
                      uint64_t* out_keys, hipStream_t s) {
     int rc = ensure_streamed(h);
     if (rc) return rc;
-    const int buf = h->pending ? 1 - h->pending_buf : 0;
-    PrevMerge prev{nullptr, 0, 0, nullptr};
     static const bool exp_nomerge = std::getenv("MI355REC_EXP_RIDE_NOMERGE") != nullptr;   // A/B experiment only
     if (h->pending && exp_nomerge) {
         rc = flush_streamed(h, s);
         if (rc) return rc;
     }
-    if (h->pending) prev = PrevMerge{h->d_stream_lists[h->pending_buf], h->pending_lists, h->pending_topn, h->pending_out};
     QueryArg qa;
     std::memset(&qa, 0, sizeof qa);
     if (use_half(h, nullptr)) {
-        ++h->half_scans;
-        if (query_row < 0) std::memcpy(qa.q, query12, sizeof qa.q);
-        enqueue_half_seed(h, query_row, qa, exclude_global, s);
-        if (query_row >= 0) {
-            LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, true, true>),
-                         dim3(h->hsgrid + 1), dim3(HalfConfig::kBlock), s,
-                         h->d_feats, h->d_half, h->n, h->hsiters, h->row_base, qa, query_row, exclude_global, topn,
-                         h->d_stream_lists[buf], h->d_half_seed, h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, prev);
-        } else {
-            LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, false, true>),
-                         dim3(h->hsgrid + 1), dim3(HalfConfig::kBlock), s,
-                         h->d_feats, h->d_half, h->n, h->hsiters, h->row_base, qa, static_cast<int64_t>(0),
-                         exclude_global, topn, h->d_stream_lists[buf], h->d_half_seed, h->hseed_grid * kHalfSeedWaves,
-                         h->d_half_rescored, prev);
+        // One call behind: the query of the PREVIOUS call is launched now, and its launch takes the
+        // sample of this one (seed riders).  The first query of a stream needs a seed launch of its own.
+        int seed_buf = 0;
+        bool sampled = false;
+        if (h->stashed.has) {
+            seed_buf = 1 - h->stashed.seed_buf;
+            sampled = h->hs_riders > 0;
+            rc = launch_stashed(h, s, sampled, query_row, query12, exclude_global, seed_buf);
+            if (rc) return rc;
         }
-        HIP_TRY(h, hipGetLastError());
-        h->pending = true;
-        h->pending_buf = buf;
-        h->pending_topn = topn;
-        h->pending_out = out_keys;
-        h->pending_lists = h->hsgrid;
+        if (!sampled && h->hseed_grid > 0) {   // first query of a stream, or a shard too small to spare riders
+            if (query_row < 0) std::memcpy(qa.q, query12, sizeof qa.q);
+            if (query_row >= 0) {
+                hipLaunchKernelGGL((seed_half_kernel<true>), dim3(h->hseed_grid), dim3(kHalfSeedBlock), 0, s, h->d_feats,
+                                   h->d_half, h->n, h->hseed_stride, h->row_base, qa, query_row, exclude_global,
+                                   h->d_stream_seed[seed_buf]);
+            } else {
+                hipLaunchKernelGGL((seed_half_kernel<false>), dim3(h->hseed_grid), dim3(kHalfSeedBlock), 0, s, h->d_feats,
+                                   h->d_half, h->n, h->hseed_stride, h->row_base, qa, static_cast<int64_t>(0),
+                                   exclude_global, h->d_stream_seed[seed_buf]);
+            }
+            HIP_TRY(h, hipGetLastError());
+        }
+        auto& st = h->stashed;
+        st.has = true;
+        st.row = query_row;
+        if (query_row < 0) std::memcpy(st.q, query12, sizeof st.q);
+        st.exclude = exclude_global;
+        st.topn = topn;
+        st.out = out_keys;
+        st.seed_buf = seed_buf;
         return MI355REC_OK;
     }
+    if (h->stashed.has) {   // the path changed under a stream (mi355rec_set_replica): the stashed query goes first
+        rc = launch_stashed(h, s, false, -1, nullptr, -1, 0);
+        if (rc) return rc;
+    }
+    const int buf = h->pending ? 1 - h->pending_buf : 0;
+    PrevMerge prev{nullptr, 0, 0, nullptr};
+    if (h->pending) prev = PrevMerge{h->d_stream_lists[h->pending_buf], h->pending_lists, h->pending_topn, h->pending_out};
     if (query_row >= 0) {
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_kernel<ScanConfig, true, false, 0, true>),
                      dim3(h->sgrid + 1), dim3(kScanBlock), s,
@@ -971,6 +1082,8 @@ void mi355rec_destroy(mi355rec_t* h) {
     if (h->d_half) (void)hipFree(h->d_half);
     if (h->d_half_seed) (void)hipFree(h->d_half_seed);
     if (h->d_half_rescored) (void)hipFree(h->d_half_rescored);
+    if (h->d_stream_seed[0]) (void)hipFree(h->d_stream_seed[0]);
+    if (h->d_stream_seed[1]) (void)hipFree(h->d_stream_seed[1]);
     if (h->d_keys) (void)hipFree(h->d_keys);
     if (h->d_idx) (void)hipFree(h->d_idx);
     if (h->d_score) (void)hipFree(h->d_score);

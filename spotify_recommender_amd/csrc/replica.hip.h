@@ -120,8 +120,48 @@ __device__ __forceinline__ float half_dot(const uint32_t (&qh)[6], uint32_t a0, 
 }
 
 // ---- the sample that seeds the launch-wide cutoff -------------------------------------
-// Workgroup b looks at the 1024 rows from row b * stride_rows on (stride_rows even): one
-// ordered-u32 approx maximum per wave (0 = nothing usable) -> seed_vals[b * 8 + wave].
+// A REGION is 1024 rows from row g * stride_rows on (stride_rows even and >= 1024, so no row is in
+// two regions): one ordered-u32 approx maximum per 128-row wave tile (0 = nothing usable) goes to
+// seed_vals[g * 8 + wave].  seed_region_load / seed_region_finish are the two halves of that, so a
+// caller can have the loads of several regions in flight before it reduces the first.
+struct SeedRegion {
+    uint4 t0, t1, t2;
+    int64_t pair;
+    bool have;
+};
+
+__device__ __forceinline__ SeedRegion seed_region_load(const uint4* __restrict__ half, int64_t n_pairs, int64_t stride_rows,
+                                                       int64_t g) {
+    SeedRegion s;
+    s.pair = ((g * stride_rows) >> 1) + threadIdx.x;
+    s.have = s.pair < n_pairs;
+    s.pair = s.have ? s.pair : n_pairs - 1;
+    const uint4* p = half + s.pair * 3;
+    s.t0 = p[0];
+    s.t1 = p[1];
+    s.t2 = p[2];
+    return s;
+}
+
+__device__ __forceinline__ void seed_region_finish(const SeedRegion& s, const HalfQuery& hq, int64_t n, int64_t row_base,
+                                                   int64_t exclude_global, uint32_t* __restrict__ seed_vals, int64_t g) {
+    const float a0 = half_dot(hq.h, s.t0.x, s.t0.y, s.t0.z, s.t0.w, s.t1.x, s.t1.y);
+    const float a1 = half_dot(hq.h, s.t1.z, s.t1.w, s.t2.x, s.t2.y, s.t2.z, s.t2.w);
+    const int64_t r0 = s.pair * 2;
+    // NaN compares false: special rows never seed
+    const bool use0 = s.have && hq.ok && r0 < n && row_base + r0 != exclude_global && a0 >= -2.0f;
+    const bool use1 = s.have && hq.ok && r0 + 1 < n && row_base + r0 + 1 != exclude_global && a1 >= -2.0f;
+    uint32_t v = 0u;
+    if (use0) v = score_to_ordered(a0);
+    if (use1) {
+        const uint32_t w = score_to_ordered(a1);
+        v = w > v ? w : v;
+    }
+    v = wave_max_u32(v);
+    if ((threadIdx.x & 63) == 0) seed_vals[g * kHalfSeedWaves + (threadIdx.x >> 6)] = v;
+}
+
+// One workgroup per region (single queries; the first query of a stream).
 template <bool kQueryFromRow>
 __global__ __launch_bounds__(kHalfSeedBlock) void seed_half_kernel(
     const float* __restrict__ feats, const uint4* __restrict__ half, int64_t n, int64_t stride_rows, int64_t row_base,
@@ -136,27 +176,52 @@ __global__ __launch_bounds__(kHalfSeedBlock) void seed_half_kernel(
         for (int j = 0; j < kDim; ++j) q[j] = qarg.q[j];
     }
     const HalfQuery hq = half_query(q, query_norm(q));
-    const int tid = threadIdx.x;
-    const int64_t n_pairs = (n + 1) >> 1;
-    int64_t pair = (static_cast<int64_t>(blockIdx.x) * stride_rows >> 1) + tid;
-    const bool have = pair < n_pairs;
-    pair = have ? pair : n_pairs - 1;
-    const uint4* p = half + pair * 3;
-    const uint4 t0 = p[0], t1 = p[1], t2 = p[2];
-    const float a0 = half_dot(hq.h, t0.x, t0.y, t0.z, t0.w, t1.x, t1.y);
-    const float a1 = half_dot(hq.h, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w);
-    const int64_t r0 = pair * 2;
-    // NaN compares false: special rows never seed
-    const bool use0 = have && hq.ok && r0 < n && row_base + r0 != exclude_global && a0 >= -2.0f;
-    const bool use1 = have && hq.ok && r0 + 1 < n && row_base + r0 + 1 != exclude_global && a1 >= -2.0f;
-    uint32_t v = 0u;
-    if (use0) v = score_to_ordered(a0);
-    if (use1) {
-        const uint32_t w = score_to_ordered(a1);
-        v = w > v ? w : v;
+    const SeedRegion s = seed_region_load(half, (n + 1) >> 1, stride_rows, blockIdx.x);
+    seed_region_finish(s, hq, n, row_base, exclude_global, seed_vals, blockIdx.x);
+}
+
+// In a STREAM of queries the sample of query k + 1 is taken by a few workgroups of query k's scan
+// launch instead of a launch of its own (scan_half_kernel<.., kWithMerge>: after the scanners and the
+// merger come next.n_wgs "seed riders").  They are resident from the start like everybody else — the
+// host launches that many scanners fewer — and each walks its share of the regions, four loads in
+// flight at a time.
+struct NextSeed {
+    float q[kDim];             // the next query (used when query_row < 0)
+    long long query_row;       // ... or its local row
+    long long exclude_global;
+    uint32_t* out;             // its sample maxima
+    int n_wgs;                 // seed riders in this launch (0 = none)
+    int regions;
+    long long stride_rows;
+};
+
+__device__ __forceinline__ void seed_rider(const float* __restrict__ feats, const uint4* __restrict__ half, int64_t n,
+                                           int64_t row_base, const NextSeed& next, int rider) {
+    float q[kDim];
+    if (next.query_row >= 0) {
+        const float* qp = feats + next.query_row * kDim;
+#pragma unroll
+        for (int j = 0; j < kDim; ++j) q[j] = qp[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < kDim; ++j) q[j] = next.q[j];
     }
-    v = wave_max_u32(v);
-    if ((tid & 63) == 0) seed_vals[blockIdx.x * kHalfSeedWaves + (tid >> 6)] = v;
+    const HalfQuery hq = half_query(q, query_norm(q));
+    const int64_t n_pairs = (n + 1) >> 1;
+    constexpr int kAhead = 4;
+    for (int g0 = rider; g0 < next.regions; g0 += kAhead * next.n_wgs) {
+        SeedRegion s[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const int g = g0 + u * next.n_wgs;
+            s[u] = seed_region_load(half, n_pairs, next.stride_rows, g < next.regions ? g : rider);
+        }
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const int g = g0 + u * next.n_wgs;
+            if (g < next.regions) seed_region_finish(s[u], hq, n, row_base, next.exclude_global, next.out, g);   // uniform
+        }
+    }
 }
 
 // ---- the scan --------------------------------------------------------------------------
@@ -195,27 +260,36 @@ struct HalfTile {
     uint4 t0, t1, t2;
 };
 
-// kWithMerge: as scan_kernel's — the LAST workgroup merges the previous streamed query.
+// kWithMerge (streamed queries): workgroups [0, S) scan, workgroup S merges the PREVIOUS streamed
+// query (as scan_kernel's riding merger), workgroups (S, gridDim) are seed riders for the NEXT one;
+// S = gridDim.x - 1 - next.n_wgs.
 template <typename Cfg, bool kQueryFromRow, bool kWithMerge>
 __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_half_kernel(
     const float* __restrict__ feats, const uint4* __restrict__ half, int64_t n, int iters, int64_t row_base,
     QueryArg qarg, int64_t query_row, int64_t exclude_global, int topk, uint64_t* __restrict__ block_lists,
     const uint32_t* __restrict__ seed_vals, int n_seed, unsigned long long* __restrict__ rescored /* [scanning workgroups] */,
-    PrevMerge prev) {
+    PrevMerge prev, NextSeed next) {
     constexpr int kBlock = Cfg::kBlock;
     __shared__ typename std::conditional<kWithMerge, HalfScanOrMergeSmem<Cfg>, HalfScanSmemT<Cfg>>::type s_mem;
     HalfScanSmemT<Cfg>* sm;
+    unsigned nblocks = gridDim.x;   // scanning workgroups
     if constexpr (kWithMerge) {
-        if (blockIdx.x == gridDim.x - 1) {
-            if (prev.lists)
-                merge_body(s_mem.merge, prev.lists, prev.n_lists, prev.topk, static_cast<int64_t>(prev.topk),
-                           static_cast<int64_t>(0), prev.topk, prev.out_keys, static_cast<int64_t*>(nullptr),
-                           static_cast<float*>(nullptr), static_cast<int64_t>(0), static_cast<int64_t>(0),
-                           static_cast<int64_t>(0));
+        nblocks = gridDim.x - 1u - static_cast<unsigned>(next.n_wgs);
+        if (blockIdx.x >= nblocks) {
+            if (blockIdx.x == nblocks) {
+                if (prev.lists)
+                    merge_body(s_mem.merge, prev.lists, prev.n_lists, prev.topk, static_cast<int64_t>(prev.topk),
+                               static_cast<int64_t>(0), prev.topk, prev.out_keys, static_cast<int64_t*>(nullptr),
+                               static_cast<float*>(nullptr), static_cast<int64_t>(0), static_cast<int64_t>(0),
+                               static_cast<int64_t>(0));
+            } else {
+                seed_rider(feats, half, n, row_base, next, static_cast<int>(blockIdx.x - nblocks - 1u));
+            }
             return;
         }
         sm = &s_mem.scan;
     } else {
+        (void)next;
         sm = &s_mem;
     }
     uint64_t* const s_cand = sm->cand;
@@ -223,7 +297,6 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_half_kernel(
     int& s_count = sm->count;
 
     const unsigned bid = blockIdx.x;
-    const unsigned nblocks = kWithMerge ? gridDim.x - 1u : gridDim.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
 

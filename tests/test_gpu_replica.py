@@ -337,3 +337,55 @@ def test_sharded_node_with_replica_sized_shards():
         idx, sc = node.query_topn(q, -1, 10)
         want = oracle.scores(f, q, threads=0)
         assert_topn_matches(idx, sc, want, -1, 10, ref_idx=oracle.topn_heap(want, -1, 10))
+
+
+@pytest.mark.parametrize("n", [777, 5000, 40_000, 700_001])
+def test_streams_run_one_call_behind(Engine, torch_cuda, n):
+    """Over the replica a streamed query is LAUNCHED by the next streamed call (whose sample rides in
+    that launch) or by the flush: streams of one query, mixed row / vector queries with different
+    topn, synchronous queries in between, a flush in the middle, shards too small to spare seed
+    riders (5000 rows) or to have a sample at all (777 rows)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(n)
+    f = rng.random((n, 12), dtype=np.float32)
+    with Engine(f) as eng:
+        eng.set_replica(ON)
+
+        def verify(keys, q, ex, topn):
+            got = keys.cpu().numpy().view(np.uint64)
+            want = oracle.scores(f, q, threads=0)
+            cnt = min(topn, n - (1 if ex >= 0 else 0))
+            idx = (~got[:cnt] & np.uint64(0xffffffff)).astype(np.int64)
+            assert_topn_matches(idx, None, want, ex, topn, ref_idx=oracle.topn_heap(want, ex, topn))
+            assert not got[cnt:].any()
+
+        # a stream of ONE query
+        k1 = torch.zeros(100, dtype=torch.int64, device="cuda")
+        eng.enqueue_row_keys_streamed(3, 100, k1)
+        eng.enqueue_flush()
+        torch.cuda.synchronize()
+        verify(k1, f[3], 3, 100)
+        eng.enqueue_flush()                                   # nothing pending: no-op
+        # mixed stream, a synchronous query and a flush in the middle
+        plan = [("row", int(rng.integers(0, n)), 10), ("vec", rng.random(12, dtype=np.float32), 100),
+                ("row", n - 1, 1000), ("row", 0, 1), ("vec", rng.random(12, dtype=np.float32), 64),
+                ("row", int(rng.integers(0, n)), 100), ("row", int(rng.integers(0, n)), 100)]
+        outs = [torch.zeros(t, dtype=torch.int64, device="cuda") for _, _, t in plan]
+        for i, (kind, q, topn) in enumerate(plan):
+            if kind == "row":
+                eng.enqueue_row_keys_streamed(q, topn, outs[i])
+            else:
+                eng.enqueue_query_keys_streamed(q, -1, topn, outs[i])
+            if i == 2:
+                idx, sc = eng.query_row_topn(5 % n, 20)      # synchronous, own scratch: the stream is untouched
+                want = oracle.scores(f, f[5 % n], threads=0)
+                assert_topn_matches(idx, sc, want, 5 % n, 20, ref_idx=oracle.topn_heap(want, 5 % n, 20))
+            if i == 4:
+                eng.enqueue_flush()
+        eng.enqueue_flush()
+        torch.cuda.synchronize()
+        for i, (kind, q, topn) in enumerate(plan):
+            if kind == "row":
+                verify(outs[i], f[q], q, topn)
+            else:
+                verify(outs[i], q, -1, topn)
