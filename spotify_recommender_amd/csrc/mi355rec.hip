@@ -46,6 +46,7 @@ constexpr int kDirectResultSlots = 2048;   // results up to this many slots are 
 using ScanConfig = DefaultScanCfg;
 using MultiConfig = DefaultMultiCfg;
 using HalfConfig = DefaultHalfCfg;
+constexpr int kRideTopnMax = 640;   // largest topN whose merge rides in the next fp32 scan launch
 constexpr int64_t kHalfAutoMinRows = 2 * 1024 * 1024;   // below this a query is launch-bound either way
 constexpr int kScanBlock = ScanConfig::kBlock;
 constexpr int kScanTileRows = ScanConfig::kTileRows;
@@ -796,6 +797,13 @@ int enqueue_streamed(mi355rec* h, int64_t query_row, const float* query12, int64
     }
     if (h->stashed.has) {   // the path changed under a stream (mi355rec_set_replica): the stashed query goes first
         rc = launch_stashed(h, s, false, -1, nullptr, -1, 0);
+        if (rc) return rc;
+    }
+    // The fp32 scan's riding merger keeps 2048 survivors; with ~770 lists and topN near 1000 about
+    // 2.2 topN keys survive its first cut, and an overflow drops into the exact radix select over all
+    // keys in global memory (correct, ~1 ms).  Such a query's merge gets its own launch instead.
+    if (h->pending && h->pending_topn > kRideTopnMax) {
+        rc = flush_streamed(h, s);
         if (rc) return rc;
     }
     const int buf = h->pending ? 1 - h->pending_buf : 0;

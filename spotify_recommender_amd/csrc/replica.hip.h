@@ -250,10 +250,15 @@ struct HalfScanSmemT {
     int seeds;
     int rescored;
 };
+// The riding merger of the replica scan keeps 4096 survivors (the fp32 scan's keeps 2048: its kernel
+// has neither the registers nor, at 3 workgroups per CU, the LDS for more).  With ~500 lists and topN
+// near 1000 the merge probes every list 4-5 keys deep and ~2.2 topN keys survive the first cut: a
+// 2048-slot buffer overflowed into the exact radix select over all keys in global memory (1 ms).
+constexpr int kHalfRideSurvCap = 4096;
 template <typename Cfg>
 union HalfScanOrMergeSmem {
     HalfScanSmemT<Cfg> scan;
-    MergeSmemT<Cfg::kBlock, kRideMaxLists, kRideSurvCap> merge;
+    MergeSmemT<Cfg::kBlock, kRideMaxLists, kHalfRideSurvCap> merge;
 };
 
 struct HalfTile {
