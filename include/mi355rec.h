@@ -117,7 +117,7 @@ int mi355rec_create_device(const float* feats_dev, int64_t n, int dim,
  * chain, so ids, order and score bits are those of the fp32 scan and of
  * Recommender.cu:256-318.  Rows or queries the bound cannot be claimed for
  * (zero / tiny / huge / non-finite norms) are always scored exactly.
- *   AUTO (default): shards of >= 2 Mi rows scan the replica, smaller ones the
+ *   AUTO (default): shards of >= 1 M rows scan the replica, smaller ones the
  *                   fp32 rows (a query is launch-bound there either way);
  *   OFF:            always the fp32 rows (the reference's own traffic, 48 B/row);
  *   ON:             always the replica.

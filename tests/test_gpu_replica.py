@@ -61,7 +61,7 @@ def check_queries(eng, f, queries, excl, topns, label, rows=None):
 
 def test_uniform_catalogue_and_the_rescored_share(Engine):
     rng = np.random.default_rng(7)
-    n = 2_500_003                      # AUTO takes the replica from 2 Mi rows; odd: the last pair is half empty
+    n = 2_500_003                      # AUTO takes the replica from 1 M rows; odd: the last pair is half empty
     f = rng.random((n, 12), dtype=np.float32)
     rows = rng.integers(0, n, size=12)
     rows[0], rows[1] = n - 1, 0
@@ -321,7 +321,7 @@ def test_replica_queries_replay_from_a_hip_graph(Engine, torch_cuda):
 
 
 def test_sharded_node_with_replica_sized_shards():
-    """mi355rec_create_sharded over two VIRTUAL shards of > 2 Mi rows each: every shard's single
+    """mi355rec_create_sharded over two VIRTUAL shards of > 2 M rows each: every shard's single
     queries take the replica scan under AUTO, the peer-store merge sees the same keys."""
     from spotify_recommender_amd.engine import NodeEngine
     rng = np.random.default_rng(17)

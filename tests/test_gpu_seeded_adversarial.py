@@ -53,7 +53,7 @@ def run_case(Engine, f, queries, excl, label, topns=(1, 100, 128), batches=(13, 
         for b in range(single):   # the single-query kernel on the same data
             idx, sc = eng.query_topn(queries[b], int(excl[b]), 100)
             assert_topn_matches(idx, sc, want[b], int(excl[b]), 100, ref_idx=oracle.topn_heap(want[b], int(excl[b]), 100))
-        # ... and the scan over the fp16 replica (csrc/replica.hip.h; forced on: AUTO starts at 2 Mi rows):
+        # ... and the scan over the fp16 replica (csrc/replica.hip.h; forced on: AUTO starts at 1 M rows):
         # its launch-wide cutoff also comes from a sample, of an approximation with a much wider margin
         eng.set_replica(2)
         for b in range(min(len(queries), 8)):
