@@ -265,3 +265,33 @@ def test_batched_call_replays_from_a_hip_graph(Engine, torch_cuda):
                 want = oracle.scores(f, f[rows[b]])
                 r_, s_ = unpack_keys(got[b])
                 assert_topn_matches(r_, s_, want, int(rows[b]), topn, ref_idx=oracle.topn_heap(want, int(rows[b]), topn))
+
+
+def test_fp32_sourced_passes_give_the_same_keys(Engine, torch_cuda):
+    """By default the passes read the fp16 replica; with the replica switched off they normalise and
+    convert the fp32 rows themselves.  Same arithmetic by construction: same candidates, same keys."""
+    torch = torch_cuda
+    rng = np.random.default_rng(91)
+    n, batch, topn = 500_003, 96, 50
+    f = rng.random((n, 12), dtype=np.float32)
+    f[::5000] *= np.float32(1e-7)                  # some rows the bound is not claimed for
+    f[7::9000] = 0.0
+    qrows = rng.integers(0, n, size=batch)
+    queries = f[qrows].copy()
+    excl = qrows.astype(np.int64)
+    keys = {}
+    cands = {}
+    with Engine(f) as eng:
+        mfma(eng)
+        for mode in (0, 1):                         # REPLICA_AUTO (replica-sourced), REPLICA_OFF (fp32-sourced)
+            eng.set_replica(mode)
+            k = torch.zeros(batch * topn, dtype=torch.int64, device="cuda")
+            eng.enqueue_batch_keys(queries, excl, topn, k)
+            torch.cuda.synchronize()
+            keys[mode] = k.cpu().numpy()
+            cands[mode] = eng.batched_last_counters()
+        assert np.array_equal(keys[0], keys[1])
+        assert cands[0] == cands[1], (cands[0], cands[1])
+        assert cands[0]["special_rows"] > 0
+        eng.set_replica(0)
+        check_batch(eng, f, queries, excl, topn, "replica-sourced", sample=range(0, batch, 11))
