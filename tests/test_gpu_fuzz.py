@@ -70,6 +70,25 @@ def test_randomised_parity():
             topn = int(rng.choice([1, 7, 100, 128]))
             qrows = rng.integers(0, rows, size=batch)
             excl = np.where(rng.random(batch) < 0.8, qrows, -1).astype(np.int64)
+            # a short stream of single queries (merge riding, over the replica one call behind): same keys as
+            # the synchronous path
+            s_topn = int(rng.choice([1, 10, 100, 700]))
+            s_rows = [int(r) for r in rng.integers(0, rows, size=3)]
+            s_keys = [torch.zeros(s_topn, dtype=torch.int64, device="cuda") for _ in s_rows]
+            for r, k in zip(s_rows, s_keys):
+                eng.enqueue_row_keys_streamed(r, s_topn, k)
+            eng.enqueue_flush()
+            torch.cuda.synchronize()
+            for r, k in zip(s_rows, s_keys):
+                want = oracle.scores(f, f[r])
+                got = k.cpu().numpy().view(np.uint64)
+                cnt = min(s_topn, rows - 1)
+                idx = (~got[:cnt] & np.uint64(0xffffffff)).astype(np.int64)
+                try:
+                    assert_topn_matches(idx, None, want, r, s_topn, ref_idx=oracle.topn_heap(want, r, s_topn))
+                    assert not got[cnt:].any()
+                except AssertionError as e:  # pragma: no cover
+                    raise AssertionError(f"case {case} streamed: rows {rows} q {r} topn {s_topn}: {e}") from e
             eng.set_batch_path(1 if case % 2 else 0)   # odd cases: the exact multi-query pass; even: AUTO
             idx, sc, counts = eng.query_batch_topn(f[qrows], excl, topn)
             for b in range(batch):
