@@ -224,7 +224,9 @@ def main():
         step(k)
     flush()
     fence()
-    stride = args.event_stride if args.event_stride > 0 else max(1, min(10, args.steps // 16))
+    # a timed launch costs ~6 us of stream time (start / stop signals around the dispatch): time every 10th
+    # launch of a long run, and at least ~7 launches of a short one (the driver's 20-step run: every 3rd)
+    stride = args.event_stride if args.event_stride > 0 else max(1, min(10, args.steps // 6))
     if not args.no_kernel_events:
         eng.set_timing(stride)  # HIP events around every k-th scan / merge launch
     t0 = time.perf_counter()
