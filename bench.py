@@ -224,9 +224,9 @@ def main():
         step(k)
     flush()
     fence()
-    # a timed launch costs ~6 us of stream time (start / stop signals around the dispatch): time every 10th
-    # launch of a long run, and at least ~7 launches of a short one (the driver's 20-step run: every 3rd)
-    stride = args.event_stride if args.event_stride > 0 else max(1, min(10, args.steps // 6))
+    # a timed launch costs ~6 us of stream time (start / stop signals around the dispatch): 16 timed launches
+    # in a long run (every 18th of the default 300), 4 in a short one (the driver's 20-step run: every 5th)
+    stride = args.event_stride if args.event_stride > 0 else max(1, args.steps // (16 if args.steps >= 64 else 4))
     if not args.no_kernel_events:
         eng.set_timing(stride)  # HIP events around every k-th scan / merge launch
     t0 = time.perf_counter()
