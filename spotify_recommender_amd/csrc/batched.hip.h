@@ -460,24 +460,32 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
             // 2 * NB times the rare hit path would be instantiated 64 times and spill the hot
             // loop); straight-line body: the fragment loads past the last block are clamped
             // and the two MFMAs issued for block NB are simply unused.
-            static_assert(NB % 2 == 0, "blocks are processed in pairs");
             const uint4* sb = &s_b[0][0] + lane;
-            uint4 bw0 = sb[0], bw1 = sb[64];
-            bq_f16v D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);
-            bq_f16v D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);
-            bq_f16v D2, D3;
+            if constexpr (NB == 1) {
+                // a single block of <= 32 queries (a micro-batch): two MFMAs per tile, one hit test
+                const uint4 bw0 = sb[0];
+                const bq_f16v D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);
+                const bq_f16v D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);
+                check2(D0, D1, 0);
+            } else {
+                static_assert(NB % 2 == 0, "blocks are processed in pairs");
+                uint4 bw0 = sb[0], bw1 = sb[64];
+                bq_f16v D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);
+                bq_f16v D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);
+                bq_f16v D2, D3;
 #pragma unroll 1
-            for (int bp = 0; bp < NB; bp += 2) {
-                const int nb0 = bp + 2 < NB ? bp + 2 : NB - 1;
-                const int nb1 = bp + 3 < NB ? bp + 3 : NB - 1;
-                D2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw1), zero, 0, 0, 0);   // block bp + 1
-                D3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], __builtin_bit_cast(bq_h8, bw1), zero, 0, 0, 0);
-                bw0 = sb[nb0 * 64];
-                check2(D0, D1, bp);
-                D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);   // block bp + 2
-                D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);
-                bw1 = sb[nb1 * 64];
-                check2(D2, D3, bp + 1);
+                for (int bp = 0; bp < NB; bp += 2) {
+                    const int nb0 = bp + 2 < NB ? bp + 2 : NB - 1;
+                    const int nb1 = bp + 3 < NB ? bp + 3 : NB - 1;
+                    D2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw1), zero, 0, 0, 0);   // block bp + 1
+                    D3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], __builtin_bit_cast(bq_h8, bw1), zero, 0, 0, 0);
+                    bw0 = sb[nb0 * 64];
+                    check2(D0, D1, bp);
+                    D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);   // block bp + 2
+                    D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);
+                    bw1 = sb[nb1 * 64];
+                    check2(D2, D3, bp + 1);
+                }
             }
         }
     }

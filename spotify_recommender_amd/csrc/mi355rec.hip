@@ -956,11 +956,12 @@ int enqueue_bq_chunk(mi355rec* h, const float* d_queries, const long long* d_exc
                      uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s) {
     auto& b = h->bq;
     const int blocks = (count + 31) / 32;
-    int nb = 2;
+    int nb = 1;
     while (nb < blocks) nb *= 2;
     hipLaunchKernelGGL(bq_prepare_kernel, dim3((nb * 32 + 255) / 256), dim3(256), 0, s, d_queries, count, nb, b.bfrag,
                        b.qnorm, b.qflags, b.cand_count, b.counters);
     switch (nb) {
+        case 1: launch_bq_passes<1>(h, topn, s); break;
         case 2: launch_bq_passes<2>(h, topn, s); break;
         case 4: launch_bq_passes<4>(h, topn, s); break;
         case 8: launch_bq_passes<8>(h, topn, s); break;
