@@ -62,7 +62,29 @@ def parse_args():
     ap.add_argument("--no-replica", action="store_true",
                     help="scan the fp32 rows (48 B/row, the reference's own traffic) instead of the fp16 replica")
     ap.add_argument("--latency-queries", type=int, default=1000)
+    ap.add_argument("--virtual-shards", type=int, default=0,
+                    help="drive the product's single-process row-sharded engine (mi355rec_create_sharded_on) with this "
+                         "many shards of ONE GPU: the multi-GPU orchestration rehearsed on a one-GPU box")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: resolve the launch mode, load the C-ABI library, print the plan as one JSON line")
+    ap.add_argument("--transport", choices=["auto", "peer", "rccl"], default="auto",
+                    help="N > 1, single process: how the per-shard key lists meet (default: peer stores where every "
+                         "device can map the first one's memory, else one grouped ncclAllGather)")
     return ap.parse_args()
+
+
+def workload_label(n: int, topn: int) -> str:
+    """Which BASELINE.json config a (rows, topn) pair is, if any."""
+    if n == 10_000_000 and topn == 100:
+        return "BASELINE configs[2], HBM-roofline run"
+    if n == 1_000_000 and topn == 10:
+        return "BASELINE configs[1]"
+    return "not a BASELINE config: same path, other size"
+
+
+def metric_label(n: int, topn: int) -> str:
+    rows = f"{n // 1_000_000}M" if n % 1_000_000 == 0 else str(n)
+    return f"queries/sec, cosine top-{topn} over a {rows} x 12 fp32 catalogue"
 
 
 def pmc_traffic(rows_local: int, replica: bool = False):
@@ -136,6 +158,218 @@ def cpu_baseline(feats_host, topn, query_rows):
     }
 
 
+def run_node(args, json_fd):
+    """`--gpus N` launched plainly (or `--virtual-shards G`): ONE process drives every shard through the
+    product's row-sharded C-ABI handle (mi355rec_create_sharded / _on, csrc/sharded.hip) — the engine the
+    C++ Recommender uses in place of the reference's cudaSetDevice(0) (Recommender.cu:124).  A step is one
+    query = one streamed scan launch on EVERY shard; the per-shard key lists of `--window` queries share one
+    exchange (peer stores or one grouped ncclAllGather) and one batched merge whose results land in host
+    memory.  The flush of the last window and the wait for the last result are inside the timed region."""
+    import numpy as np
+    import torch
+
+    from spotify_recommender_amd import capi
+    from spotify_recommender_amd.engine import CosineEngine, NodeEngine
+    from spotify_recommender_amd.synth import synthetic_catalogue
+
+    virtual = args.virtual_shards > 1
+    g = args.virtual_shards if virtual else args.gpus
+    visible = torch.cuda.device_count()
+    if not virtual and visible < g:
+        raise SystemExit(f"--gpus {g} but only {visible} device(s) visible (use --virtual-shards {g} to rehearse on one)")
+    devices = [0] * g if virtual else list(range(g))
+    n, topn = args.rows, args.topn
+    total_q = args.warmup + args.steps
+    q_rows = [(k * 7919) % n for k in range(total_q + args.latency_queries)]
+    dev0 = torch.device("cuda", 0)
+    full = synthetic_catalogue(n, seed=args.seed, device=dev0)
+    feats_host = full.cpu().numpy()
+    if not virtual:
+        del full
+        torch.cuda.empty_cache()
+
+    node = NodeEngine(feats_host, devices=devices)
+    info = node.info()
+    node.set_window(args.window)
+    if args.transport == "rccl":
+        node.set_transport(capi.TRANSPORT_RCCL)
+    elif args.transport == "peer":
+        node.set_transport(capi.TRANSPORT_PEER)
+    if args.no_replica:
+        node.set_replica(capi.REPLICA_OFF)
+    transport = node.info()["transport"]
+
+    def sync_all():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    def stream(lo_k, hi_k):
+        t = -1
+        for k in range(lo_k, hi_k):
+            t = node.enqueue_row(q_rows[k], topn)
+        node.enqueue_flush()
+        return node.wait(t, topn)
+
+    def timed_stream():
+        stream(0, args.warmup)
+        sync_all()
+        stride = args.event_stride if args.event_stride > 0 else max(1, args.steps // (16 if args.steps >= 64 else 4))
+        if not args.no_kernel_events:
+            node.set_timing(stride)
+        st0 = node.stream_stats()
+        t0 = time.perf_counter()
+        last = stream(args.warmup, total_q)
+        sync_all()
+        dt = time.perf_counter() - t0
+        st1 = node.stream_stats()
+        shard_ms = [float(node.shard_stats(r).last_scan_ms) for r in range(g) if info["shard_rows"][r] > 0]
+        node.set_timing(0)
+        host_us = (st1["host_ns"] - st0["host_ns"]) / max(1, st1["queries"] - st0["queries"]) / 1e3
+        return dt, last, shard_ms, host_us, st1["exchanges"] - st0["exchanges"]
+
+    elapsed, last_result, shard_ms, host_us, exchanges = timed_stream()
+    replica = bool(node.shard_stats(0).replica_active)
+    rows_local = max(info["shard_rows"])
+
+    # one query alone, end to end, through the synchronous call the C++ Recommender makes
+    lat = []
+    for k in range(total_q, total_q + args.latency_queries):
+        t1 = time.perf_counter()
+        node.query_row_topn(q_rows[k], topn)
+        lat.append((time.perf_counter() - t1) * 1e3)
+    lat.sort()
+
+    # the same stream over the fp32 rows (SURVEY.md §8(d)'s 48 B per row), for the survey-priced roofline
+    fp32_rows = None
+    if replica:
+        node.set_replica(capi.REPLICA_OFF)
+        dt32, _, ms32, host32, _ = timed_stream()
+        node.set_replica(capi.REPLICA_AUTO)
+        k_ms = sum(ms32) / len(ms32) if ms32 else 0.0
+        fp32_rows = {"ms_per_step": round(dt32 / args.steps * 1e3, 5), "value": round(args.steps / dt32, 2), "unit": "queries/s",
+                     "host_enqueue_us_per_query": round(host32, 2),
+                     "roofline": {"bound": "hbm", "algorithmic_bytes_per_launch": rows_local * BYTES_PER_ROW,
+                                  "avg_kernel_ms": round(k_ms, 5),
+                                  "achieved": round(rows_local * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
+                                  "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": round(rows_local * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if k_ms > 0 else None}}
+
+    # the other transport, same stream (real placements only: RCCL wants one device per shard)
+    other = None
+    if not virtual and g > 1:
+        try:
+            node.set_transport(capi.TRANSPORT_RCCL if transport == capi.TRANSPORT_PEER else capi.TRANSPORT_PEER)
+            dt2, _, _, host2, ex2 = timed_stream()
+            other = {"transport": "rccl" if transport == capi.TRANSPORT_PEER else "peer", "value": round(args.steps / dt2, 2),
+                     "unit": "queries/s", "ms_per_step": round(dt2 / args.steps * 1e3, 5), "exchanges": ex2,
+                     "host_enqueue_us_per_query": round(host2, 2)}
+        except capi.Mi355Error as e:
+            other = {"unavailable": str(e)}
+        node.set_transport(transport)
+
+    # virtual shards: the whole catalogue through ONE single-device handle on the same GPU, same stream of
+    # queries — the difference is what the orchestration (G launches per query, exchange, second merge) costs
+    single = None
+    if virtual:
+        eng = CosineEngine(full)
+        if args.no_replica:
+            eng.set_replica(capi.REPLICA_OFF)
+        ring = [torch.zeros(topn, dtype=torch.int64, device=dev0) for _ in range(4)]
+        for k in range(args.warmup):
+            eng.enqueue_row_keys_streamed(q_rows[k], topn, ring[k % 4])
+        eng.enqueue_flush()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(args.warmup, total_q):
+            eng.enqueue_row_keys_streamed(q_rows[k], topn, ring[k % 4])
+        eng.enqueue_flush()
+        torch.cuda.synchronize()
+        sdt = (time.perf_counter() - t1) / args.steps
+        lat1 = []
+        for k in range(total_q, total_q + min(200, args.latency_queries)):
+            t1 = time.perf_counter()
+            eng.query_row_topn(q_rows[k], topn)
+            lat1.append((time.perf_counter() - t1) * 1e3)
+        lat1.sort()
+        eng.close()
+        single = {"ms_per_step": round(sdt * 1e3, 5), "value": round(1.0 / sdt, 2), "p50_ms": round(lat1[len(lat1) // 2], 4) if lat1 else None,
+                  "orchestration_ms_per_query": round(elapsed / args.steps * 1e3 - sdt * 1e3, 5),
+                  "note": "the same 10 M-row stream through one mi355rec handle on the same GPU; orchestration = sharded step - this"}
+
+    # results of the run against the oracle (checker only): the last streamed query of the timed region,
+    # plus a few through the synchronous call
+    from oracle import oracle
+    ok, checked = True, 0
+    rows_to_check = [(q_rows[total_q - 1], last_result)]
+    for k in (0, total_q // 2, total_q + args.latency_queries - 1):
+        rows_to_check.append((q_rows[k], node.query_row_topn(q_rows[k], topn)))
+    for row, (idx, sc) in rows_to_check:
+        want = oracle.scores(feats_host, feats_host[row], threads=0)
+        ci, cs = oracle.topn_canonical(want, row, topn)
+        ok = ok and idx.tolist() == ci.tolist() and bool(np.array_equal(sc, cs + np.float32(0)))
+        checked += 1
+
+    k_ms = sum(shard_ms) / len(shard_ms) if shard_ms else 0.0
+    alg = (rows_local + 1) // 2 * 48 if replica else rows_local * BYTES_PER_ROW
+    achieved = alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
+    traffic_bytes, traffic_source = pmc_traffic(rows_local, replica)
+    line = {
+        "metric": metric_label(n, topn), "value": round(args.steps / elapsed, 2), "unit": "queries/s",
+        "n_gpus": 1 if virtual else g, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": ("f32 (every score is the exact fp32 chain; a 24 B/row fp16 replica only rules rows out)" if replica else "f32"),
+        "data": "synthetic",
+        "config": {
+            "workload": f"{n} synthetic tracks x 12 fp32 features, top-{topn}, row-sharded over "
+                        + (f"{g} VIRTUAL shards of one MI355X (orchestration rehearsal)" if virtual else f"{g} MI355X")
+                        + (" (BASELINE configs[3])" if (n == 10_000_000 and topn == 100) else ""),
+            "engine": "ONE process, the product's C-ABI: mi355rec_create_sharded" + ("_on" if virtual else "") + " (csrc/sharded.hip)",
+            "rows": n, "topn": topn, "shards": g, "virtual_shards": virtual, "devices": devices,
+            "rows_per_shard": rows_local, "queries_per_step": 1,
+            "transport": "peer" if transport == capi.TRANSPORT_PEER else "rccl",
+            "rccl_ranks": g if (transport == capi.TRANSPORT_RCCL or (other is not None and other.get("transport") == "rccl"
+                                                                    and "value" in other)) else None,
+            "window": args.window, "exchanges_in_timed_region": exchanges,
+            "rows_by_pointer": node.rows_by_pointer(), "note": node.note(),
+            "merge": "per shard inside the next query's scan launch (streamed); one exchange + one batched merge per window; "
+                     "last window flushed and its result awaited inside the timed region",
+            "seed": args.seed, "generator": "torch.rand(seed) uniform[0,1) on device 0, sharded from host memory",
+        },
+        "p50_ms": round(lat[len(lat) // 2], 4) if lat else None,
+        "p99_ms": round(lat[min(len(lat) - 1, int(len(lat) * 0.99))], 4) if lat else None,
+        "roofline": {
+            "bound": "hbm", "per": "shard launch (mean over shards)",
+            "kernel": ("mi355::scan_half_kernel<HalfCfg<512,4,2>, true, true> (24 B/row fp16 replica)" if replica
+                       else "mi355::scan_kernel<ScanCfg<512,1,6,2>, true, false, 0, true> (48 B/row)"),
+            "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None,
+            "traffic": traffic_bytes, "traffic_source": traffic_source,
+            "algorithmic_bytes_per_launch": alg, "bytes_per_row": 24 if replica else BYTES_PER_ROW,
+            "survey_bytes_per_row": BYTES_PER_ROW, "avg_kernel_ms": round(k_ms, 5) if k_ms else None,
+            "kernel_ms_per_shard": [round(m, 5) for m in shard_ms],
+            "infinity_cache_resident": bool(alg <= 128 * 2**20),
+        },
+        "host": {"enqueue_us_per_query": round(host_us, 2), "launches_per_query": g,
+                 "note": "wall time of the enqueue/flush calls on the one host thread (all shards), per query"},
+        "verified_against_oracle": bool(ok), "verified_queries": checked,
+    }
+    if fp32_rows is not None:
+        line["fp32_rows"] = fp32_rows
+        line["roofline"]["survey_frac"] = fp32_rows["roofline"]["frac"]
+        line["roofline"]["survey_achieved"] = fp32_rows["roofline"]["achieved"]
+    elif not replica:
+        line["roofline"]["survey_frac"] = line["roofline"]["frac"]
+        line["roofline"]["survey_achieved"] = line["roofline"]["achieved"]
+    if other is not None:
+        line["other_transport"] = other
+    if single is not None:
+        line["single_engine_same_gpu"] = single
+    node.close()
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(line) + "\n").encode())
+
+
 def main():
     args = parse_args()
     # The contract is ONE JSON line on stdout.  RCCL prints its version banner (and warnings)
@@ -155,9 +389,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        from spotify_recommender_amd import capi
+        capi.lib()   # the product library loads and exports every declared symbol
+        mode = ("node: one process, mi355rec_create_sharded over %d %s" % (
+                    args.virtual_shards if args.virtual_shards > 1 else args.gpus,
+                    "virtual shards of device 0" if args.virtual_shards > 1 else "devices")
+                if (world == 1 and (args.gpus > 1 or args.virtual_shards > 1)) else
+                ("rank: one process per GPU over torch.distributed (RCCL), WORLD_SIZE=%d" % world if world > 1 else
+                 "single: one mi355rec handle on device 0"))
+        os.write(json_fd, (json.dumps({"dry_run": True, "mode": mode, "metric": metric_label(args.rows, args.topn),
+                                       "rows": args.rows, "topn": args.topn, "gpus": args.gpus,
+                                       "devices_visible": torch.cuda.device_count()}) + "\n").encode())
+        return
+    if world == 1 and (args.gpus > 1 or args.virtual_shards > 1):
+        # Launched plainly: ONE process drives every GPU through the product's C-ABI
+        # (mi355rec_create_sharded: what the C++ Recommender uses).  Under torch.distributed.run
+        # (WORLD_SIZE = N) the one-process-per-GPU path below runs instead.
+        return run_node(args, json_fd)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -238,6 +488,8 @@ def main():
     fence()
     st = eng.stats()  # averages the HIP events recorded inside the timed region
     eng.set_timing(False)
+    # what the timed stream itself produced for its last two queries (checked against the oracle below)
+    timed_tail = [(q_rows[k], ring[k % 4].clone()) for k in (total_q - 2, total_q - 1)] if streamed and args.steps >= 2 else []
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -401,17 +653,18 @@ def main():
             "queries_per_call": bq, "value": round(bq / dt, 1),
             "unit": "queries/s", "ms_per_call": round(dt * 1e3, 4), "rows_per_gpu": rows_local,
             "roofline": {
-                "bound": "compute", "kernel": "mi355::bq_pass_kernel (pass 1 + pass 2)",
-                "algorithmic_flops_per_call_per_gpu": flops,
-                "achieved": round(flops / dt / 1e12, 1), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(flops / dt / 1e12 / FP32_PEAK_TFLOPS, 3),
-                "note": "24 flop per (row, query) pair against the fp32 peak (SURVEY.md §8(d)); the pre-filter runs "
-                        "in fp16 on the matrix cores, so the fraction may exceed 1 — the exact fp32 chain only "
-                        "touches the candidates",
-                "mfma": {"issued_tflops": round(mfma_flops / dt / 1e12, 1), "peak": FP16_MFMA_PEAK_TFLOPS,
-                         "frac": round(mfma_flops / dt / 1e12 / FP16_MFMA_PEAK_TFLOPS, 3),
-                         "avg_pass_kernel_ms": round(pass_ms, 4),
-                         "binding_unit": "VALU issue: 8 v_max3_i32 per MFMA (1024 outputs) + chip power (DESIGN.md §4.6)"},
+                "bound": "mfma", "kernel": "mi355::bq_pass_kernel (pass 1 + pass 2), v_mfma_f32_32x32x16_f16",
+                "issued_mfma_flops_per_call_per_gpu": mfma_flops,
+                "achieved": round(mfma_flops / dt / 1e12, 1), "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(mfma_flops / dt / 1e12 / FP16_MFMA_PEAK_TFLOPS, 3),
+                "avg_pass_kernel_ms": round(pass_ms, 4),
+                "binding_unit": "VALU issue: 8 v_max3_i32 per MFMA (1024 outputs) + chip power (DESIGN.md §4.6)",
+                "note": "the pre-filter runs on the fp16 matrix cores, so its roofline is the dense fp16 MFMA peak and "
+                        "`achieved` counts the MFMA flops really issued (2*32*32*16 each, pass 1 on every 4th tile)",
+                "survey_priced": {"algorithmic_flops_per_call_per_gpu": flops, "tflops": round(flops / dt / 1e12, 1),
+                                  "fp32_peak": FP32_PEAK_TFLOPS, "ratio": round(flops / dt / 1e12 / FP32_PEAK_TFLOPS, 3),
+                                  "note": "SURVEY.md §8(d)'s 24 flop per (row, query) pair against the fp32 peak: NOT a "
+                                          "roofline fraction (> 1 because the exact fp32 chain only touches the candidates)"},
             },
             "candidates_per_query": round(diag["candidates_total"] / max(1, min(bq, 1024) - diag["queued_queries"]), 1),
             "queued_to_exact_scan": diag["queued_queries"], "special_rows": diag["special_rows"],
@@ -468,15 +721,17 @@ def main():
                            ("mi355::scan_kernel<ScanCfg<512,1,6,2>, true, false>" if world == 1 else
                             "mi355::scan_kernel<ScanCfg<512,1,6,2>, false, false, 0, true>"))
         line = {
-            "metric": "queries/sec, cosine top-100 over a 10M x 12 fp32 catalogue",
+            "metric": metric_label(n, topn),
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": ("f32 (every score is the exact fp32 chain; a 24 B/row fp16 replica only rules rows out)" if replica
+                      else "f32"), "data": "synthetic",
             "config": {
                 "workload": f"{n} synthetic tracks x 12 fp32 features, top-{topn}, "
-                            + ("1 MI355X (BASELINE configs[2], HBM-roofline run)" if world == 1 else
-                               f"row-sharded across {world} MI355X, one all-gather of {topn} keys/rank (configs[3])"),
+                            + (f"1 MI355X ({workload_label(n, topn)})" if world == 1 else
+                               f"row-sharded across {world} MI355X, one process per GPU, one all-gather of {topn} keys/rank "
+                               + ("(BASELINE configs[3])" if (n == 10_000_000 and topn == 100) else "")),
                 "rows": n, "topn": topn, "rows_per_gpu": hi - lo, "queries_per_step": 1,
                 "merge": ("inside the next query's scan launch (streamed), last one flushed in the timed region"
                           if streamed else ("own launch per query" if sharded is None else
@@ -513,6 +768,13 @@ def main():
                                                                "note": "480 MB-equivalent per query; the kernel moves 0.50x of that"}
         if fp32_rows is not None:
             line["fp32_rows"] = fp32_rows
+            # SURVEY.md §8(d) prices a query at 48 B/row: that is the fp32 scan's roofline, measured in this run
+            line["roofline"]["survey_frac"] = fp32_rows["roofline"]["frac"]
+            line["roofline"]["survey_achieved"] = fp32_rows["roofline"]["achieved"]
+            line["roofline"]["survey_kernel"] = "mi355::scan_kernel over the fp32 rows (48 B/row): the `fp32_rows` object"
+        elif not replica:
+            line["roofline"]["survey_frac"] = line["roofline"]["frac"]
+            line["roofline"]["survey_achieved"] = line["roofline"]["achieved"]
         if micro is not None:
             line["microbatch"] = micro
         if batched is not None:
@@ -523,13 +785,25 @@ def main():
             from oracle import oracle
             ok = True
             checked = 0
-            for k in (0, total_q // 2, total_q + args.latency_queries - 1):
+            for k in (0, total_q // 3, total_q // 2, total_q + args.latency_queries - 1):
                 eng.enqueue_row_keys(q_rows[k], topn, out_keys)
                 torch.cuda.synchronize()
                 rows_got, sc_got = unpack_keys(out_keys.cpu().numpy())
                 want = oracle.scores(feats_host, feats_host[q_rows[k]], threads=0)
                 ci, cs = oracle.topn_canonical(want, q_rows[k], topn)
                 ok = ok and rows_got.tolist() == ci.tolist() and bool(np.array_equal(sc_got, cs + np.float32(0)))
+                checked += 1
+            for row, keys_t in timed_tail:      # results of the TIMED stream (merge riding in the next scan launch)
+                rows_got, sc_got = unpack_keys(keys_t.cpu().numpy())
+                want = oracle.scores(feats_host, feats_host[row], threads=0)
+                ci, cs = oracle.topn_canonical(want, row, topn)
+                ok = ok and rows_got.tolist() == ci.tolist() and bool(np.array_equal(sc_got, cs + np.float32(0)))
+                checked += 1
+            if host_idx is not None and sharded is None:   # the last synchronous latency query (ids + scores on the host)
+                row = q_rows[total_q + args.latency_queries - 1]
+                want = oracle.scores(feats_host, feats_host[row], threads=0)
+                ci, cs = oracle.topn_canonical(want, row, topn)
+                ok = ok and host_idx[0].tolist() == ci.tolist() and bool(np.array_equal(host_idx[1], cs + np.float32(0)))
                 checked += 1
             if batched is not None:
                 for k in (1, args.batch // 2):

@@ -6,7 +6,9 @@
 #define DATAMANAGER_H
 
 #include <cstdint>
+#include <fstream>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -44,6 +46,8 @@ public:
         std::vector<std::string> trackNames;
         std::vector<uint64_t> recordOffsets;    // byte offset of song i in the file
         std::map<int, std::string> genreMap;
+        // readSong's file handle, opened on first use and kept (one open per catalogue, not per printed song)
+        mutable std::shared_ptr<std::ifstream> reader;
         size_t size() const { return trackIds.size(); }
     };
     static bool loadCatalogue(const std::string& binaryPath, Catalogue& out);

@@ -216,6 +216,22 @@ int mi355rec_enqueue_query_keys_streamed(mi355rec_t* h, const float* query12,
 /* Merges the last streamed query (no-op when nothing is pending). */
 int mi355rec_enqueue_flush(mi355rec_t* h, void* stream);
 
+/* Queries whose 12 floats ALREADY LIVE in memory this device can read: a resident
+ * row of this handle, a row of ANOTHER shard on another GPU of the node (through
+ * the peer mapping: how the row-sharded engine below hands a catalogue row to every
+ * shard without a host round trip), a staged vector in mapped host memory.  The
+ * kernels fetch them with scalar loads when they start; the 48 bytes must not
+ * change until the query has completed.  mi355rec_row_ptr returns where a resident
+ * row lives (valid for the lifetime of the handle).  Otherwise as
+ * mi355rec_enqueue_query_keys / _query_keys_streamed; out_idx_dev / out_score_dev
+ * may be NULL. */
+int mi355rec_row_ptr(mi355rec_t* h, int64_t local_row, const float** out_dev);
+int mi355rec_enqueue_ptr_keys(mi355rec_t* h, const float* query12_dev, int64_t exclude_global, int topn,
+                              mi355rec_key_t* out_keys_dev, int64_t* out_idx_dev, float* out_score_dev,
+                              void* stream);
+int mi355rec_enqueue_ptr_keys_streamed(mi355rec_t* h, const float* query12_dev, int64_t exclude_global,
+                                       int topn, mi355rec_key_t* out_keys_dev, void* stream);
+
 /* `batch` queries (batch x 12 floats, host; exclude_global may be NULL).
  * Three or more queries (13 or more on a handle without a replica) take the
  * batched matrix-core path (mi355rec_set_batch_path); fewer — or shards below
@@ -319,9 +335,11 @@ int mi355rec_fetch_row(mi355rec_t* h, int64_t local_row, float* out12_host);
  *       them — no collective, no copy launch.  Default when peer access exists.
  *   MI355REC_TRANSPORT_RCCL  one grouped ncclAllGather per call (ncclCommInitAll,
  *       ncclGroupStart/End); librccl is opened on first use of this transport.
- * All calls are synchronous (results in host memory on return); one host thread
- * at a time per handle.  topn > 1024 is served exactly but slowly (per-shard
- * rounds, the G sorted key lists merged on the host). */
+ * The mi355rec_sharded_query_* calls are synchronous (results in host memory on
+ * return); the STREAM calls further down only enqueue.  One host thread at a time
+ * per handle.  topn > 1024 is served exactly but slowly (per-shard rounds, the G
+ * sorted key lists merged on the host).  With ONE shard the synchronous calls go
+ * straight to that shard's single-device handle (no exchange, no second merge). */
 typedef struct mi355rec_sharded mi355rec_sharded_t;
 
 #define MI355REC_MAX_SHARDS 64
@@ -349,6 +367,20 @@ int mi355rec_sharded_set_transport(mi355rec_sharded_t* h, int transport);
 int mi355rec_sharded_info(const mi355rec_sharded_t* h, int* n_shards, int* transport,
                           int64_t* rows, int* devices_out, int64_t* shard_rows_out);
 
+/* Per-shard diagnostics: mi355rec_set_timing on every shard's engine, and the
+ * mi355rec_stats of one shard (kernel event times, grid geometry, replica state). */
+int mi355rec_sharded_set_timing(mi355rec_sharded_t* h, int enabled);
+int mi355rec_sharded_shard_stats(const mi355rec_sharded_t* h, int shard, mi355rec_stats_t* out);
+/* mi355rec_set_replica on every shard (AUTO / OFF / ON); flushes an open stream window first. */
+int mi355rec_sharded_set_replica(mi355rec_sharded_t* h, int mode);
+
+/* 1 when queries by row are read by every shard straight from the owning shard's
+ * memory (all-pairs peer access, verified against the by-value path when the handle
+ * was created), 0 when the row is fetched to the host once per query.  The note says
+ * why a fast path was switched off ("" when none was). */
+int mi355rec_sharded_rows_by_pointer(const mi355rec_sharded_t* h);
+const char* mi355rec_sharded_note(const mi355rec_sharded_t* h);
+
 /* Same contracts as mi355rec_query_row_topn / _query_topn / _query_batch_topn /
  * _scores_row, with GLOBAL row indices. */
 int mi355rec_sharded_query_row_topn(mi355rec_sharded_t* h, int64_t global_row, int topn,
@@ -359,6 +391,43 @@ int mi355rec_sharded_query_batch_topn(mi355rec_sharded_t* h, const float* querie
                                       const int64_t* exclude_global, int topn, int64_t* out_idx,
                                       float* out_score, int* out_count);
 int mi355rec_sharded_scores_row(mi355rec_sharded_t* h, int64_t global_row, float* out_host);
+
+/* ---- a STREAM of single queries on the row-sharded catalogue (asynchronous) ------
+ * What a serving loop uses (and `bench.py --gpus N`): every call only ENQUEUES —
+ * one streamed scan launch per shard (mi355rec_enqueue_*_keys_streamed: the local
+ * merge of query k rides in the scan launch of query k + 1) — and returns a TICKET.
+ * The per-shard key lists of `window` consecutive queries cross xGMI in ONE exchange
+ * (peer stores straight into the first device's gather buffer + one event per shard,
+ * or one grouped ncclAllGather) followed by ONE batched merge launch on the first
+ * device, whose results (global row ids + scores) the merge kernel stores straight
+ * into pinned host memory.  No call but mi355rec_sharded_wait synchronises, nothing
+ * is allocated after the first call with a given (topn, window).
+ *
+ *   enqueue_row / enqueue_query   -> *ticket (consecutive within a window; a flush
+ *                                    rounds the next ticket up to a window boundary)
+ *   enqueue_flush                 -> closes the open window now (drains the per-shard
+ *                                    pipelines: call it when the burst is over)
+ *   wait(ticket, ...)             -> blocks until that ticket's window has been merged
+ *                                    and copies its result out (flushes first if the
+ *                                    window is still open)
+ * A window's results stay readable until 3 further windows have been opened
+ * (a ring of 4); waiting for an older ticket is MI355REC_ERR_INVALID_ARG.
+ * A query by ROW is read by every shard from the owning shard's memory through the
+ * peer mapping (mi355rec_enqueue_ptr_keys_streamed) — no 48-byte round trip through
+ * the host; where some pair of devices has no peer access the row is fetched once
+ * (mi355rec_fetch_row) and passed by value.  topn <= 1024, window in [1, 64]. */
+int mi355rec_sharded_set_window(mi355rec_sharded_t* h, int window);   /* default 16; flushes an open window */
+int mi355rec_sharded_enqueue_row(mi355rec_sharded_t* h, int64_t global_row, int topn, int64_t* ticket);
+int mi355rec_sharded_enqueue_query(mi355rec_sharded_t* h, const float* query12, int64_t exclude_global,
+                                   int topn, int64_t* ticket);
+int mi355rec_sharded_enqueue_flush(mi355rec_sharded_t* h);
+int mi355rec_sharded_wait(mi355rec_sharded_t* h, int64_t ticket, int64_t* out_idx, float* out_score,
+                          int* out_count);
+/* Host-side cost accounting of the stream (cumulative since create): queries
+ * enqueued, exchanges issued, and the wall-clock nanoseconds the enqueue / flush
+ * calls themselves took on the host thread.  Any pointer may be NULL. */
+int mi355rec_sharded_stream_stats(const mi355rec_sharded_t* h, int64_t* queries, int64_t* exchanges,
+                                  int64_t* host_ns);
 
 /* ---- key helpers (host side, no device needed) --------------------------- */
 mi355rec_key_t mi355rec_pack_key(float score, int64_t global_row);

@@ -91,6 +91,20 @@ SIGNATURES = {
     "mi355rec_sharded_query_topn": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, POINTER(c_int)]),
     "mi355rec_sharded_query_batch_topn": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "mi355rec_sharded_scores_row": (c_int, [c_void_p, c_int64, c_void_p]),
+    "mi355rec_row_ptr": (c_int, [c_void_p, c_int64, POINTER(c_void_p)]),
+    "mi355rec_enqueue_ptr_keys": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mi355rec_enqueue_ptr_keys_streamed": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "mi355rec_sharded_set_timing": (c_int, [c_void_p, c_int]),
+    "mi355rec_sharded_shard_stats": (c_int, [c_void_p, c_int, POINTER(Stats)]),
+    "mi355rec_sharded_set_replica": (c_int, [c_void_p, c_int]),
+    "mi355rec_sharded_rows_by_pointer": (c_int, [c_void_p]),
+    "mi355rec_sharded_note": (c_char_p, [c_void_p]),
+    "mi355rec_sharded_set_window": (c_int, [c_void_p, c_int]),
+    "mi355rec_sharded_enqueue_row": (c_int, [c_void_p, c_int64, c_int, POINTER(c_int64)]),
+    "mi355rec_sharded_enqueue_query": (c_int, [c_void_p, c_void_p, c_int64, c_int, POINTER(c_int64)]),
+    "mi355rec_sharded_enqueue_flush": (c_int, [c_void_p]),
+    "mi355rec_sharded_wait": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, POINTER(c_int)]),
+    "mi355rec_sharded_stream_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     "mi355rec_pack_key": (c_uint64, [c_float, c_int64]),
     "mi355rec_key_score": (c_float, [c_uint64]),
     "mi355rec_key_row": (c_int64, [c_uint64]),

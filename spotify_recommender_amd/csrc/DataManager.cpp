@@ -385,8 +385,10 @@ bool DataManager::loadCatalogue(const std::string& binaryPath, Catalogue& out) {
 
 bool DataManager::readSong(const Catalogue& catalogue, size_t index, Song& out) {
     if (index >= catalogue.recordOffsets.size()) return false;
-    std::ifstream in(catalogue.path, std::ios::binary);
+    if (!catalogue.reader) catalogue.reader = std::make_shared<std::ifstream>(catalogue.path, std::ios::binary);
+    std::ifstream& in = *catalogue.reader;
     if (!in.is_open()) return false;
+    in.clear();
     in.seekg(static_cast<std::streamoff>(catalogue.recordOffsets[index]));
     out.deserialize(in);
     return static_cast<bool>(in);

@@ -119,9 +119,13 @@ bool startEngine(Recommender::Impl* impl, const float* matrix, size_t n) {
     mi355rec_sharded_info(impl->engine, &impl->numDevices, nullptr, nullptr, nullptr, nullptr);
     impl->gpuEnabled = true;
     impl->initialized = true;
-    std::cout << "Successfully initialized with " << impl->numSongs << " songs on GPU";
-    if (impl->numDevices > 1) std::cout << " (row-sharded over " << impl->numDevices << " devices)";
-    std::cout << std::endl;
+    // the reference's stdout line, byte for byte (Recommender.cu:172); the placement note goes to stderr
+    std::cout << "Successfully initialized with " << impl->numSongs << " songs on GPU" << std::endl;
+    if (impl->numDevices > 1) {
+        std::cerr << "[mi355rec] catalogue row-sharded over " << impl->numDevices << " devices" << std::endl;
+        const char* note = mi355rec_sharded_note(impl->engine);
+        if (note && note[0]) std::cerr << "[mi355rec] " << note << std::endl;
+    }
     return true;
 }
 

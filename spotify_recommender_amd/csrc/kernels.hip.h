@@ -689,7 +689,7 @@ union ScanOrMergeSmem {
 template <typename Cfg, bool kQueryFromRow, bool kScoresOnly, int kDebug = 0, bool kWithMerge = false>
 __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
     const float* __restrict__ feats, int64_t n, int64_t rows_per_block, int iters,
-    int64_t row_base, QueryArg qarg, int64_t query_row, int64_t exclude_global,
+    int64_t row_base, QueryArg qarg, const float* __restrict__ query_ptr, int64_t exclude_global,
     int topk, uint64_t* __restrict__ block_lists, float* __restrict__ scores_out,
     const uint64_t* __restrict__ upper_ptr, PrevMerge prev) {
     constexpr int kBlock = Cfg::kBlock;
@@ -733,9 +733,10 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
 
     float q[kDim];
     if constexpr (kQueryFromRow) {
-        const float* qp = feats + query_row * kDim;  // wave-uniform: scalar loads
+        // 12 floats anywhere this device can read: a resident row of this shard, a row of
+        // ANOTHER shard through the peer mapping (sharded.hip), a staged vector.  Wave-uniform: scalar loads.
 #pragma unroll
-        for (int j = 0; j < kDim; ++j) q[j] = qp[j];
+        for (int j = 0; j < kDim; ++j) q[j] = query_ptr[j];
     } else {
 #pragma unroll
         for (int j = 0; j < kDim; ++j) q[j] = qarg.q[j];

@@ -47,10 +47,12 @@ using ScanConfig = DefaultScanCfg;
 using MultiConfig = DefaultMultiCfg;
 using HalfConfig = DefaultHalfCfg;
 constexpr int kRideTopnMax = 640;   // largest topN whose merge rides in the next fp32 scan launch
+constexpr int64_t kReplicaMinRows = 65536;      // smaller shards are created without a replica (built on demand by set_replica(ON))
 constexpr int64_t kHalfAutoMinRows = 1000000;   // below this a query is launch-bound either way (measured: 11.8 vs
                                                 // 13.5 us per streamed query at 1 M rows, equal at 300 k)
 constexpr int kScanBlock = ScanConfig::kBlock;
 constexpr int kScanTileRows = ScanConfig::kTileRows;
+const float* const kNoQueryPtr = nullptr;   // kernel argument of the variants that take the query by value
 
 }  // namespace
 
@@ -75,6 +77,7 @@ struct mi355rec {
     // the scan launch of query k + 1; two more list buffers alternate
     uint64_t* d_stream_lists[2] = {nullptr, nullptr};
     int sgrid = 0, siters = 0;          // scanning workgroups of a streamed launch (one slot is the merger's)
+    bool streamed_ready = false;        // both list buffers exist
     bool pending = false;               // a streamed query's lists wait for their merge
     int pending_buf = 0, pending_topn = 0;
     uint64_t* pending_out = nullptr;
@@ -88,6 +91,7 @@ struct mi355rec {
     int hseed_grid = 0;
     int64_t hseed_stride = 0;
     int replica_mode = 0;               // MI355REC_REPLICA_AUTO / _OFF / _ON
+    bool replica_allowed = true;        // false: created under MI355REC_REPLICA=0
     float replica_build_ms = 0.f;
     int pending_lists = 0;              // lists of the streamed query that waits for its merge
     // Streamed queries over the replica run ONE CALL BEHIND: query k is launched by call k + 1 (or
@@ -95,7 +99,7 @@ struct mi355rec {
     // of a seed launch per query.
     struct Stashed {
         bool has = false;
-        int64_t row = -1;               // local row of the query, or -1: q holds the vector
+        const float* qptr = nullptr;    // where the query's 12 floats live on a device, or null: q holds the vector
         float q[kDim] = {0};
         int64_t exclude = -1;
         int topn = 0;
@@ -252,10 +256,12 @@ void plan_half_grid(mi355rec* h) {
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_half_kernel<HalfConfig, true, false>, HalfConfig::kBlock, 0) != hipSuccess || occ < 1) occ = 1;
     if (occ > 3) occ = 3;
-    if (const char* e = std::getenv("MI355REC_EXP_HOCC")) {   // A/B experiment only
+#ifdef MI355REC_EXPERIMENTS   // A/B builds of tools/ only: the product reads no tuning knob from the environment
+    if (const char* e = std::getenv("MI355REC_EXP_HOCC")) {
         const int v = std::atoi(e);
         if (v >= 1 && v <= 4) occ = v;
     }
+#endif
     int64_t max_blocks = static_cast<int64_t>(h->cus) * occ;
     if (max_blocks > kRideMaxLists) max_blocks = kRideMaxLists;
     const int64_t tiles = (h->n + HalfConfig::kTileRows - 1) / HalfConfig::kTileRows;
@@ -277,10 +283,12 @@ void plan_half_grid(mi355rec* h) {
         if (rounds < 1) rounds = 1;
         int riders = static_cast<int>((sg + 4 * rounds - 1) / (4 * rounds));
         if (riders > h->hgrid / 8) riders = h->hgrid / 8;
-        if (const char* e = std::getenv("MI355REC_EXP_RIDERS")) {   // A/B experiment only
+#ifdef MI355REC_EXPERIMENTS
+        if (const char* e = std::getenv("MI355REC_EXP_RIDERS")) {
             const int v = std::atoi(e);
             if (v >= 0 && v <= h->hgrid / 2) riders = v;
         }
+#endif
         if (riders > 0) {
             h->hs_riders = riders;
             h->hs_scan = h->hgrid - 1 - riders;
@@ -289,14 +297,46 @@ void plan_half_grid(mi355rec* h) {
     }
 }
 
-// (Re)builds the replica from the fp32 rows on the handle's stream and waits for it.
+void free_replica(mi355rec* h) {
+    void* bufs[] = {h->d_half, h->d_half_seed, h->d_half_rescored, h->d_stream_seed[0], h->d_stream_seed[1]};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    h->d_half = nullptr;
+    h->d_half_seed = nullptr;
+    h->d_half_rescored = nullptr;
+    h->d_stream_seed[0] = h->d_stream_seed[1] = nullptr;
+}
+
+int alloc_replica(mi355rec* h, int64_t n_padded) {
+    HIP_TRY(h, hipMalloc(&h->d_half, static_cast<size_t>(n_padded) * 24));
+    HIP_TRY(h, hipMalloc(&h->d_half_seed, sizeof(uint32_t) * kHalfSeedMaxGrid * kHalfSeedWaves));
+    HIP_TRY(h, hipMalloc(&h->d_half_rescored, sizeof(unsigned long long) * kRideMaxLists));
+    // the sample buffers of STREAMED queries belong to the replica: whoever has d_half has them
+    for (int i = 0; i < 2; ++i)
+        HIP_TRY(h, hipMalloc(&h->d_stream_seed[i], sizeof(uint32_t) * kHalfSeedMaxGrid * kHalfSeedWaves));
+    HIP_TRY(h, hipMemsetAsync(h->d_half_rescored, 0, sizeof(unsigned long long) * kRideMaxLists, h->stream));
+    return MI355REC_OK;
+}
+
+// (Re)builds the replica from the fp32 rows on the handle's stream and waits for it.  All or
+// nothing: after a failure the handle has NO replica (d_half and everything keyed on it is null)
+// and keeps serving from the fp32 rows.
+int build_replica_inner(mi355rec* h);
 int build_replica(mi355rec* h) {
+    const int rc = build_replica_inner(h);
+    if (rc != MI355REC_OK) {
+        (void)hipStreamSynchronize(h->stream);
+        free_replica(h);
+        if (h->replica_mode == MI355REC_REPLICA_ON) h->replica_mode = MI355REC_REPLICA_AUTO;
+    }
+    return rc;
+}
+
+int build_replica_inner(mi355rec* h) {
     const int64_t n_padded = (h->n + 1) & ~static_cast<int64_t>(1);
     if (!h->d_half) {
-        HIP_TRY(h, hipMalloc(&h->d_half, static_cast<size_t>(n_padded) * 24));
-        HIP_TRY(h, hipMalloc(&h->d_half_seed, sizeof(uint32_t) * kHalfSeedMaxGrid * kHalfSeedWaves));
-        HIP_TRY(h, hipMalloc(&h->d_half_rescored, sizeof(unsigned long long) * kRideMaxLists));
-        HIP_TRY(h, hipMemsetAsync(h->d_half_rescored, 0, sizeof(unsigned long long) * kRideMaxLists, h->stream));
+        const int rc = alloc_replica(h, n_padded);
+        if (rc != MI355REC_OK) return rc;
     }
     hipEvent_t a = nullptr, b = nullptr;
     const bool timed = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess;
@@ -408,13 +448,16 @@ int create_common(const float* feats, bool on_device, int64_t n, int dim, int de
     }
     // The fp16 replica (+50 % device memory, one pass over the rows).  MI355REC_REPLICA=0
     // in the environment keeps a handle fp32-only.
+    // Shards below kReplicaMinRows get none: no AUTO path reads it there (single queries switch over at 1 M
+    // rows, batches at 65536); mi355rec_set_replica(ON) builds it on demand.  If the +50 % cannot be had the
+    // handle degrades to fp32-only (same results, 48 B/row) and says so in mi355rec_last_error.
     const char* renv = std::getenv("MI355REC_REPLICA");
-    if (n > 0 && !(renv && renv[0] == '0')) {
+    h->replica_allowed = !(renv && renv[0] == '0');
+    if (n >= kReplicaMinRows && h->replica_allowed) {
         const int brc = build_replica(h);
         if (brc != MI355REC_OK) {
-            const std::string msg = h->err;
-            mi355rec_destroy(h);
-            return fail(nullptr, brc, "%s", msg.c_str());
+            (void)hipGetLastError();
+            h->err = "fp16 replica not built (" + h->err + "): this handle serves from the fp32 rows only";
         }
     }
 
@@ -504,57 +547,59 @@ bool use_half(const mi355rec* h, const uint64_t* upper_dev) {
 }
 
 // The sample that seeds the launch-wide cutoff of the next scan over the replica.
-void enqueue_half_seed(mi355rec* h, int64_t query_row, const QueryArg& qa, int64_t exclude_global, hipStream_t s) {
+void enqueue_half_seed(mi355rec* h, const float* qptr, const QueryArg& qa, int64_t exclude_global, uint32_t* seed_out,
+                       hipStream_t s) {
     if (h->hseed_grid <= 0) return;
-    if (query_row >= 0) {
+    if (qptr) {
         hipLaunchKernelGGL((seed_half_kernel<true>), dim3(h->hseed_grid), dim3(kHalfSeedBlock), 0, s, h->d_feats, h->d_half,
-                           h->n, h->hseed_stride, h->row_base, qa, query_row, exclude_global, h->d_half_seed);
+                           h->n, h->hseed_stride, h->row_base, qa, qptr, exclude_global, seed_out);
     } else {
         hipLaunchKernelGGL((seed_half_kernel<false>), dim3(h->hseed_grid), dim3(kHalfSeedBlock), 0, s, h->d_feats, h->d_half,
-                           h->n, h->hseed_stride, h->row_base, qa, static_cast<int64_t>(0), exclude_global, h->d_half_seed);
+                           h->n, h->hseed_stride, h->row_base, qa, kNoQueryPtr, exclude_global, seed_out);
     }
 }
 
-// Enqueue the scan for one query.  query_row >= 0: query is that local row.
+// Enqueue the scan for one query.  qptr != null: the kernel reads the query's 12 floats from there
+// (a resident row, or any other device-readable address).
 // *n_lists = per-workgroup lists it leaves in d_block_lists.
-int enqueue_scan(mi355rec* h, int64_t query_row, const float* query12,
+int enqueue_scan(mi355rec* h, const float* qptr, const float* query12,
                  int64_t exclude_global, int topn, const uint64_t* upper_dev, hipStream_t s, int* n_lists) {
     QueryArg qa;
     std::memset(&qa, 0, sizeof qa);
-    if (query_row < 0) std::memcpy(qa.q, query12, sizeof qa.q);
+    if (!qptr) std::memcpy(qa.q, query12, sizeof qa.q);
     const PrevMerge none{nullptr, 0, 0, nullptr};
     if (use_half(h, upper_dev)) {
         NextSeed no_next;
         std::memset(&no_next, 0, sizeof no_next);
         *n_lists = h->hgrid;
         ++h->half_scans;
-        enqueue_half_seed(h, query_row, qa, exclude_global, s);
-        if (query_row >= 0) {
+        enqueue_half_seed(h, qptr, qa, exclude_global, h->d_half_seed, s);
+        if (qptr) {
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, true, false>),
                          dim3(h->hgrid), dim3(HalfConfig::kBlock), s,
-                         h->d_feats, h->d_half, h->n, h->hiters, h->row_base, qa, query_row, exclude_global, topn,
+                         h->d_feats, h->d_half, h->n, h->hiters, h->row_base, qa, qptr, exclude_global, topn,
                          h->d_block_lists, h->d_half_seed, h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next);
         } else {
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, false, false>),
                          dim3(h->hgrid), dim3(HalfConfig::kBlock), s,
-                         h->d_feats, h->d_half, h->n, h->hiters, h->row_base, qa, static_cast<int64_t>(0), exclude_global,
+                         h->d_feats, h->d_half, h->n, h->hiters, h->row_base, qa, kNoQueryPtr, exclude_global,
                          topn, h->d_block_lists, h->d_half_seed, h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next);
         }
         HIP_TRY(h, hipGetLastError());
         return MI355REC_OK;
     }
     *n_lists = h->grid;
-    if (query_row >= 0) {
+    if (qptr) {
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_kernel<ScanConfig, true, false>),
                      dim3(h->grid), dim3(kScanBlock), s,
                      h->d_feats, h->n, h->rows_per_block, h->iters, h->row_base, qa,
-                     query_row, exclude_global, topn, h->d_block_lists,
+                     qptr, exclude_global, topn, h->d_block_lists,
                      static_cast<float*>(nullptr), upper_dev, none);
     } else {
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_kernel<ScanConfig, false, false>),
                      dim3(h->grid), dim3(kScanBlock), s,
                      h->d_feats, h->n, h->rows_per_block, h->iters, h->row_base, qa,
-                     static_cast<int64_t>(0), exclude_global, topn, h->d_block_lists,
+                     kNoQueryPtr, exclude_global, topn, h->d_block_lists,
                      static_cast<float*>(nullptr), upper_dev, none);
     }
     HIP_TRY(h, hipGetLastError());
@@ -637,7 +682,7 @@ int check_topn(mi355rec* h, int topn, bool allow_rounds) {
 // One query end to end on stream `s`: scan + merge, in rounds of kMaxTopK when
 // topn is larger (round r only sees keys below the last key of round r-1, read
 // from device memory, so the rounds are enqueued back to back without a sync).
-int enqueue_query(mi355rec* h, int64_t query_row, const float* query12, int64_t exclude_global,
+int enqueue_query(mi355rec* h, const float* qptr, const float* query12, int64_t exclude_global,
                   int topn_asked, uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s) {
     // A shard of n rows has at most n results (the reference's heap never grows
     // past N-1, Recommender.cu:300): run only the rounds that can produce keys and
@@ -653,7 +698,7 @@ int enqueue_query(mi355rec* h, int64_t query_row, const float* query12, int64_t 
         const int k = topn - done < kMaxTopK ? topn - done : kMaxTopK;
         const uint64_t* upper = done ? out_keys + done - 1 : nullptr;
         int lists = 0;
-        int rc = enqueue_scan(h, query_row, query12, exclude_global, k, upper, s, &lists);
+        int rc = enqueue_scan(h, qptr, query12, exclude_global, k, upper, s, &lists);
         if (rc) return rc;
         rc = enqueue_merge(h, h->d_block_lists, lists, k, k, out_keys + done,
                            out_idx ? out_idx + done : nullptr, out_score ? out_score + done : nullptr, s);
@@ -666,33 +711,46 @@ int enqueue_query(mi355rec* h, int64_t query_row, const float* query12, int64_t 
 // scan(k+1) and merge(k) share one launch: workgroup 0 merges the previous query's lists,
 // the others scan.  One scanning workgroup fewer than the plain scan uses, so the launch
 // still fits the chip in one wave of workgroups.
+int ensure_streamed_alloc(mi355rec* h);
 int ensure_streamed(mi355rec* h) {
-    if (h->d_stream_lists[0]) return MI355REC_OK;
+    if (h->streamed_ready) return MI355REC_OK;
+    const int rc = ensure_streamed_alloc(h);
+    if (rc != MI355REC_OK) {   // all or nothing: no half-allocated state survives a failure
+        for (int i = 0; i < 2; ++i) {
+            if (h->d_stream_lists[i]) (void)hipFree(h->d_stream_lists[i]);
+            h->d_stream_lists[i] = nullptr;
+        }
+        return rc;
+    }
+    h->streamed_ready = true;
+    return MI355REC_OK;
+}
+
+int ensure_streamed_alloc(mi355rec* h) {
     const int64_t tiles = (h->n + kScanTileRows - 1) / kScanTileRows;
     int g = h->grid > 1 ? h->grid - 1 : 1;
     if (g > kRideMaxLists - 1) g = kRideMaxLists - 1;
-    if (const char* e = std::getenv("MI355REC_EXP_SGRID")) {   // A/B experiment only
+#ifdef MI355REC_EXPERIMENTS
+    if (const char* e = std::getenv("MI355REC_EXP_SGRID")) {
         const int v = std::atoi(e);
         if (v >= 1 && v < g) g = v;
     }
+#endif
     if (tiles < g) g = static_cast<int>(tiles);
     h->sgrid = g;
     h->siters = static_cast<int>((tiles + g - 1) / g);
     const int most = g > h->hsgrid ? g : h->hsgrid;
     for (int i = 0; i < 2; ++i)
         HIP_TRY(h, hipMalloc(&h->d_stream_lists[i], sizeof(uint64_t) * static_cast<size_t>(most) * kMaxTopK));
-    if (h->d_half)
-        for (int i = 0; i < 2; ++i)
-            HIP_TRY(h, hipMalloc(&h->d_stream_seed[i], sizeof(uint32_t) * kHalfSeedMaxGrid * kHalfSeedWaves));
     return MI355REC_OK;
 }
 
-int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, int64_t next_row, const float* next_q,
+int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, const float* next_ptr, const float* next_q,
                    int64_t next_exclude, int next_buf);
 
 int flush_streamed(mi355rec* h, hipStream_t s) {
     if (h->stashed.has) {
-        const int rc = launch_stashed(h, s, false, -1, nullptr, -1, 0);
+        const int rc = launch_stashed(h, s, false, nullptr, nullptr, -1, 0);
         if (rc) return rc;
     }
     if (!h->pending) return MI355REC_OK;
@@ -703,7 +761,7 @@ int flush_streamed(mi355rec* h, hipStream_t s) {
 
 // Launches the stashed streamed query over the replica: scanners + the riding merger of the query
 // before it + (with_next) the seed riders of the query after it.
-int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, int64_t next_row, const float* next_q,
+int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, const float* next_ptr, const float* next_q,
                    int64_t next_exclude, int next_buf) {
     auto& st = h->stashed;
     const int buf = h->pending ? 1 - h->pending_buf : 0;
@@ -711,12 +769,12 @@ int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, int64_t next_row,
     if (h->pending) prev = PrevMerge{h->d_stream_lists[h->pending_buf], h->pending_lists, h->pending_topn, h->pending_out};
     NextSeed next;
     std::memset(&next, 0, sizeof next);
-    next.query_row = -1;
+    next.query_ptr = nullptr;
     next.exclude_global = -1;
     int scanners = h->hsgrid, iters = h->hsiters;
     if (with_next && h->hs_riders > 0) {
-        next.query_row = next_row;
-        if (next_row < 0) std::memcpy(next.q, next_q, sizeof next.q);
+        next.query_ptr = next_ptr;
+        if (!next_ptr) std::memcpy(next.q, next_q, sizeof next.q);
         next.exclude_global = next_exclude;
         next.out = h->d_stream_seed[next_buf];
         next.n_wgs = h->hs_riders;
@@ -729,16 +787,16 @@ int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, int64_t next_row,
     std::memset(&qa, 0, sizeof qa);
     const int n_seed = h->hseed_grid * kHalfSeedWaves;
     ++h->half_scans;
-    if (st.row >= 0) {
+    if (st.qptr) {
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, true, true>),
                      dim3(scanners + 1 + next.n_wgs), dim3(HalfConfig::kBlock), s,
-                     h->d_feats, h->d_half, h->n, iters, h->row_base, qa, st.row, st.exclude, st.topn,
+                     h->d_feats, h->d_half, h->n, iters, h->row_base, qa, st.qptr, st.exclude, st.topn,
                      h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], n_seed, h->d_half_rescored, prev, next);
     } else {
         std::memcpy(qa.q, st.q, sizeof qa.q);
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, false, true>),
                      dim3(scanners + 1 + next.n_wgs), dim3(HalfConfig::kBlock), s,
-                     h->d_feats, h->d_half, h->n, iters, h->row_base, qa, static_cast<int64_t>(0), st.exclude, st.topn,
+                     h->d_feats, h->d_half, h->n, iters, h->row_base, qa, kNoQueryPtr, st.exclude, st.topn,
                      h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], n_seed, h->d_half_rescored, prev, next);
     }
     HIP_TRY(h, hipGetLastError());
@@ -751,15 +809,17 @@ int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, int64_t next_row,
     return MI355REC_OK;
 }
 
-int enqueue_streamed(mi355rec* h, int64_t query_row, const float* query12, int64_t exclude_global, int topn,
+int enqueue_streamed(mi355rec* h, const float* qptr, const float* query12, int64_t exclude_global, int topn,
                      uint64_t* out_keys, hipStream_t s) {
     int rc = ensure_streamed(h);
     if (rc) return rc;
-    static const bool exp_nomerge = std::getenv("MI355REC_EXP_RIDE_NOMERGE") != nullptr;   // A/B experiment only
+#ifdef MI355REC_EXPERIMENTS
+    static const bool exp_nomerge = std::getenv("MI355REC_EXP_RIDE_NOMERGE") != nullptr;
     if (h->pending && exp_nomerge) {
         rc = flush_streamed(h, s);
         if (rc) return rc;
     }
+#endif
     QueryArg qa;
     std::memset(&qa, 0, sizeof qa);
     if (use_half(h, nullptr)) {
@@ -770,26 +830,18 @@ int enqueue_streamed(mi355rec* h, int64_t query_row, const float* query12, int64
         if (h->stashed.has) {
             seed_buf = 1 - h->stashed.seed_buf;
             sampled = h->hs_riders > 0;
-            rc = launch_stashed(h, s, sampled, query_row, query12, exclude_global, seed_buf);
+            rc = launch_stashed(h, s, sampled, qptr, query12, exclude_global, seed_buf);
             if (rc) return rc;
         }
         if (!sampled && h->hseed_grid > 0) {   // first query of a stream, or a shard too small to spare riders
-            if (query_row < 0) std::memcpy(qa.q, query12, sizeof qa.q);
-            if (query_row >= 0) {
-                hipLaunchKernelGGL((seed_half_kernel<true>), dim3(h->hseed_grid), dim3(kHalfSeedBlock), 0, s, h->d_feats,
-                                   h->d_half, h->n, h->hseed_stride, h->row_base, qa, query_row, exclude_global,
-                                   h->d_stream_seed[seed_buf]);
-            } else {
-                hipLaunchKernelGGL((seed_half_kernel<false>), dim3(h->hseed_grid), dim3(kHalfSeedBlock), 0, s, h->d_feats,
-                                   h->d_half, h->n, h->hseed_stride, h->row_base, qa, static_cast<int64_t>(0),
-                                   exclude_global, h->d_stream_seed[seed_buf]);
-            }
+            if (!qptr) std::memcpy(qa.q, query12, sizeof qa.q);
+            enqueue_half_seed(h, qptr, qa, exclude_global, h->d_stream_seed[seed_buf], s);
             HIP_TRY(h, hipGetLastError());
         }
         auto& st = h->stashed;
         st.has = true;
-        st.row = query_row;
-        if (query_row < 0) std::memcpy(st.q, query12, sizeof st.q);
+        st.qptr = qptr;
+        if (!qptr) std::memcpy(st.q, query12, sizeof st.q);
         st.exclude = exclude_global;
         st.topn = topn;
         st.out = out_keys;
@@ -797,7 +849,7 @@ int enqueue_streamed(mi355rec* h, int64_t query_row, const float* query12, int64
         return MI355REC_OK;
     }
     if (h->stashed.has) {   // the path changed under a stream (mi355rec_set_replica): the stashed query goes first
-        rc = launch_stashed(h, s, false, -1, nullptr, -1, 0);
+        rc = launch_stashed(h, s, false, nullptr, nullptr, -1, 0);
         if (rc) return rc;
     }
     // The fp32 scan's riding merger keeps 2048 survivors; with ~770 lists and topN near 1000 about
@@ -810,17 +862,17 @@ int enqueue_streamed(mi355rec* h, int64_t query_row, const float* query12, int64
     const int buf = h->pending ? 1 - h->pending_buf : 0;
     PrevMerge prev{nullptr, 0, 0, nullptr};
     if (h->pending) prev = PrevMerge{h->d_stream_lists[h->pending_buf], h->pending_lists, h->pending_topn, h->pending_out};
-    if (query_row >= 0) {
+    if (qptr) {
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_kernel<ScanConfig, true, false, 0, true>),
                      dim3(h->sgrid + 1), dim3(kScanBlock), s,
-                     h->d_feats, h->n, static_cast<int64_t>(0), h->siters, h->row_base, qa, query_row,
+                     h->d_feats, h->n, static_cast<int64_t>(0), h->siters, h->row_base, qa, qptr,
                      exclude_global, topn, h->d_stream_lists[buf], static_cast<float*>(nullptr),
                      static_cast<const uint64_t*>(nullptr), prev);
     } else {
         std::memcpy(qa.q, query12, sizeof qa.q);
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_kernel<ScanConfig, false, false, 0, true>),
                      dim3(h->sgrid + 1), dim3(kScanBlock), s,
-                     h->d_feats, h->n, static_cast<int64_t>(0), h->siters, h->row_base, qa, static_cast<int64_t>(0),
+                     h->d_feats, h->n, static_cast<int64_t>(0), h->siters, h->row_base, qa, kNoQueryPtr,
                      exclude_global, topn, h->d_stream_lists[buf], static_cast<float*>(nullptr),
                      static_cast<const uint64_t*>(nullptr), prev);
     }
@@ -865,10 +917,12 @@ int ensure_bq_alloc(mi355rec* h) {
     if (grid > kBqMaxPassGrid) grid = kBqMaxPassGrid;
     b.grid = grid;
     b.grid2 = h->cus * b.occ2;
+#ifdef MI355REC_EXPERIMENTS
     if (const char* e = std::getenv("MI355REC_BQ_STEP1")) {
         const int v = std::atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8) b.step1 = v;
     }
+#endif
     b.qgrid = h->cus < kMergeMaxLists ? h->cus : kMergeMaxLists;
     const int64_t tiles = (h->n + MultiConfig::kTileRows - 1) / MultiConfig::kTileRows;
     if (tiles < b.qgrid) b.qgrid = static_cast<int>(tiles);
@@ -1045,7 +1099,7 @@ int enqueue_batch(mi355rec* h, const float* queries, const int64_t* exclude_glob
     }
     for (int b = 0; b < batch; ++b) {
         const size_t off = static_cast<size_t>(b) * topn;
-        const int rc = enqueue_query(h, -1, queries + static_cast<size_t>(b) * kDim,
+        const int rc = enqueue_query(h, nullptr, queries + static_cast<size_t>(b) * kDim,
                                      exclude_global ? exclude_global[b] : -1, topn, out_keys + off,
                                      out_idx ? out_idx + off : nullptr, out_score ? out_score + off : nullptr, s);
         if (rc) return rc;
@@ -1089,11 +1143,7 @@ void mi355rec_destroy(mi355rec_t* h) {
     if (h->d_stream_lists[1]) (void)hipFree(h->d_stream_lists[1]);
     if (h->d_seed_keys) (void)hipFree(h->d_seed_keys);
     if (h->d_seed_vals) (void)hipFree(h->d_seed_vals);
-    if (h->d_half) (void)hipFree(h->d_half);
-    if (h->d_half_seed) (void)hipFree(h->d_half_seed);
-    if (h->d_half_rescored) (void)hipFree(h->d_half_rescored);
-    if (h->d_stream_seed[0]) (void)hipFree(h->d_stream_seed[0]);
-    if (h->d_stream_seed[1]) (void)hipFree(h->d_stream_seed[1]);
+    free_replica(h);
     if (h->d_keys) (void)hipFree(h->d_keys);
     if (h->d_idx) (void)hipFree(h->d_idx);
     if (h->d_score) (void)hipFree(h->d_score);
@@ -1175,8 +1225,8 @@ int mi355rec_enqueue_row_keys(mi355rec_t* h, int64_t local_row, int topn,
     DeviceGuard guard(h->device);
     rc = order_stream(h, static_cast<hipStream_t>(stream));
     if (rc) return rc;
-    return enqueue_query(h, local_row, nullptr, h->row_base + local_row, topn, out_keys_dev, nullptr, nullptr,
-                         static_cast<hipStream_t>(stream));
+    return enqueue_query(h, h->d_feats + local_row * kDim, nullptr, h->row_base + local_row, topn, out_keys_dev, nullptr,
+                         nullptr, static_cast<hipStream_t>(stream));
 }
 
 int mi355rec_enqueue_query_keys(mi355rec_t* h, const float* query12, int64_t exclude_global,
@@ -1187,7 +1237,7 @@ int mi355rec_enqueue_query_keys(mi355rec_t* h, const float* query12, int64_t exc
     DeviceGuard guard(h->device);
     rc = order_stream(h, static_cast<hipStream_t>(stream));
     if (rc) return rc;
-    return enqueue_query(h, -1, query12, exclude_global, topn, out_keys_dev, nullptr, nullptr,
+    return enqueue_query(h, nullptr, query12, exclude_global, topn, out_keys_dev, nullptr, nullptr,
                          static_cast<hipStream_t>(stream));
 }
 
@@ -1202,20 +1252,62 @@ int mi355rec_enqueue_row_keys_streamed(mi355rec_t* h, int64_t local_row, int top
     hipStream_t s = static_cast<hipStream_t>(stream);
     rc = order_stream(h, s);
     if (rc) return rc;
-    return enqueue_streamed(h, local_row, nullptr, h->row_base + local_row, topn, out_keys_dev, s);
+    return enqueue_streamed(h, h->d_feats + local_row * kDim, nullptr, h->row_base + local_row, topn, out_keys_dev, s);
 }
 
 int mi355rec_enqueue_query_keys_streamed(mi355rec_t* h, const float* query12, int64_t exclude_global, int topn,
                                          mi355rec_key_t* out_keys_dev, void* stream) {
     if (!h || !out_keys_dev || !query12) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
-    if (h->n < 1) return fail(h, MI355REC_ERR_INVALID_ARG, "empty shard: use mi355rec_enqueue_query_keys");
     int rc = check_topn(h, topn, false);
     if (rc) return rc;
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     rc = order_stream(h, s);
     if (rc) return rc;
-    return enqueue_streamed(h, -1, query12, exclude_global, topn, out_keys_dev, s);
+    if (h->n < 1) {   // an EMPTY shard answers with an all-empty list at once (it still takes part in the merge)
+        HIP_TRY(h, hipMemsetAsync(out_keys_dev, 0, sizeof(uint64_t) * static_cast<size_t>(topn), s));
+        return MI355REC_OK;
+    }
+    return enqueue_streamed(h, nullptr, query12, exclude_global, topn, out_keys_dev, s);
+}
+
+// ---- queries whose 12 floats already live in device-readable memory -----------------
+
+int mi355rec_row_ptr(mi355rec_t* h, int64_t local_row, const float** out_dev) {
+    if (!h || !out_dev) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (local_row < 0 || local_row >= h->n)
+        return fail(h, MI355REC_ERR_INVALID_ARG, "Invalid song index: %lld", (long long)local_row);
+    *out_dev = h->d_feats + local_row * kDim;
+    return MI355REC_OK;
+}
+
+int mi355rec_enqueue_ptr_keys(mi355rec_t* h, const float* query12_dev, int64_t exclude_global, int topn,
+                              mi355rec_key_t* out_keys_dev, int64_t* out_idx_dev, float* out_score_dev, void* stream) {
+    if (!h || !out_keys_dev || !query12_dev) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    int rc = check_topn(h, topn, true);
+    if (rc) return rc;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = order_stream(h, s);
+    if (rc) return rc;
+    return enqueue_query(h, h->n > 0 ? query12_dev : nullptr, query12_dev, exclude_global, topn, out_keys_dev, out_idx_dev,
+                         out_score_dev, s);
+}
+
+int mi355rec_enqueue_ptr_keys_streamed(mi355rec_t* h, const float* query12_dev, int64_t exclude_global, int topn,
+                                       mi355rec_key_t* out_keys_dev, void* stream) {
+    if (!h || !out_keys_dev || !query12_dev) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    int rc = check_topn(h, topn, false);
+    if (rc) return rc;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = order_stream(h, s);
+    if (rc) return rc;
+    if (h->n < 1) {
+        HIP_TRY(h, hipMemsetAsync(out_keys_dev, 0, sizeof(uint64_t) * static_cast<size_t>(topn), s));
+        return MI355REC_OK;
+    }
+    return enqueue_streamed(h, query12_dev, nullptr, exclude_global, topn, out_keys_dev, s);
 }
 
 int mi355rec_enqueue_flush(mi355rec_t* h, void* stream) {
@@ -1304,8 +1396,13 @@ int mi355rec_set_replica(mi355rec_t* h, int mode) {
     if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
     if (mode != MI355REC_REPLICA_AUTO && mode != MI355REC_REPLICA_OFF && mode != MI355REC_REPLICA_ON)
         return fail(h, MI355REC_ERR_INVALID_ARG, "unknown replica mode %d", mode);
-    if (mode == MI355REC_REPLICA_ON && !h->d_half && h->n > 0)
-        return fail(h, MI355REC_ERR_INVALID_ARG, "this handle was created without a replica (MI355REC_REPLICA=0)");
+    if (mode == MI355REC_REPLICA_ON && !h->d_half && h->n > 0) {
+        if (!h->replica_allowed)
+            return fail(h, MI355REC_ERR_INVALID_ARG, "this handle was created without a replica (MI355REC_REPLICA=0)");
+        // a small shard (or one whose replica could not be allocated at create): build it now
+        const int rc = mi355rec_rebuild_replica(h);
+        if (rc) return rc;
+    }
     h->replica_mode = mode;
     return MI355REC_OK;
 }
@@ -1328,8 +1425,14 @@ int mi355rec_replica_counters(mi355rec_t* h, int64_t* scans, int64_t* rescored_r
 int mi355rec_rebuild_replica(mi355rec_t* h) {
     if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
     if (h->n == 0) return MI355REC_OK;
+    if (!h->replica_allowed)
+        return fail(h, MI355REC_ERR_INVALID_ARG, "this handle was created without a replica (MI355REC_REPLICA=0)");
     DeviceGuard guard(h->device);
-    const int rc = sync_api_begin(h);
+    int rc = sync_api_begin(h);
+    if (rc) return rc;
+    // A stashed streamed query carries a sample taken from the OLD replica, and the pending one's
+    // lists wait for their merge: both are completed first (on the handle's own stream).
+    rc = flush_streamed(h, h->stream);
     if (rc) return rc;
     return build_replica(h);
 }
@@ -1385,13 +1488,13 @@ int mi355rec_enqueue_scores(mi355rec_t* h, int64_t local_row, const float* query
     std::memset(&qa, 0, sizeof qa);
     if (local_row >= 0) {
         hipLaunchKernelGGL((scan_kernel<ScanConfig, true, true>), dim3(h->grid), dim3(kScanBlock), 0, s, h->d_feats,
-                           h->n, h->rows_per_block, h->iters, h->row_base, qa, local_row,
+                           h->n, h->rows_per_block, h->iters, h->row_base, qa, h->d_feats + local_row * kDim,
                            static_cast<int64_t>(-1), 1, static_cast<uint64_t*>(nullptr), out_scores_dev,
                            static_cast<const uint64_t*>(nullptr), PrevMerge{nullptr, 0, 0, nullptr});
     } else {
         std::memcpy(qa.q, query12, sizeof qa.q);
         hipLaunchKernelGGL((scan_kernel<ScanConfig, false, true>), dim3(h->grid), dim3(kScanBlock), 0, s, h->d_feats,
-                           h->n, h->rows_per_block, h->iters, h->row_base, qa, static_cast<int64_t>(0),
+                           h->n, h->rows_per_block, h->iters, h->row_base, qa, kNoQueryPtr,
                            static_cast<int64_t>(-1), 1, static_cast<uint64_t*>(nullptr), out_scores_dev,
                            static_cast<const uint64_t*>(nullptr), PrevMerge{nullptr, 0, 0, nullptr});
     }
@@ -1512,7 +1615,7 @@ int mi355rec_query_row_topn(mi355rec_t* h, int64_t local_row, int topn, int64_t*
     // Small results go straight into the pinned host buffers from the merge kernel
     // (zero-copy stores over PCIe: no D2H copy launches on the latency path).
     const bool direct = eff <= kDirectResultSlots;
-    rc = enqueue_query(h, local_row, nullptr, h->row_base + local_row, eff, h->d_keys, direct ? h->hd_idx : h->d_idx,
+    rc = enqueue_query(h, h->d_feats + local_row * kDim, nullptr, h->row_base + local_row, eff, h->d_keys, direct ? h->hd_idx : h->d_idx,
                        direct ? h->hd_score : h->d_score, h->stream);
     if (rc) return rc;
     if (!direct) {

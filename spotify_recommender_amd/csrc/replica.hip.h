@@ -165,12 +165,11 @@ __device__ __forceinline__ void seed_region_finish(const SeedRegion& s, const Ha
 template <bool kQueryFromRow>
 __global__ __launch_bounds__(kHalfSeedBlock) void seed_half_kernel(
     const float* __restrict__ feats, const uint4* __restrict__ half, int64_t n, int64_t stride_rows, int64_t row_base,
-    QueryArg qarg, int64_t query_row, int64_t exclude_global, uint32_t* __restrict__ seed_vals) {
+    QueryArg qarg, const float* __restrict__ query_ptr, int64_t exclude_global, uint32_t* __restrict__ seed_vals) {
     float q[kDim];
     if constexpr (kQueryFromRow) {
-        const float* qp = feats + query_row * kDim;
 #pragma unroll
-        for (int j = 0; j < kDim; ++j) q[j] = qp[j];
+        for (int j = 0; j < kDim; ++j) q[j] = query_ptr[j];
     } else {
 #pragma unroll
         for (int j = 0; j < kDim; ++j) q[j] = qarg.q[j];
@@ -186,8 +185,8 @@ __global__ __launch_bounds__(kHalfSeedBlock) void seed_half_kernel(
 // host launches that many scanners fewer — and each walks its share of the regions, four loads in
 // flight at a time.
 struct NextSeed {
-    float q[kDim];             // the next query (used when query_row < 0)
-    long long query_row;       // ... or its local row
+    float q[kDim];             // the next query (used when query_ptr is null)
+    const float* query_ptr;    // ... or where its 12 floats live (a resident row, possibly of another shard)
     long long exclude_global;
     uint32_t* out;             // its sample maxima
     int n_wgs;                 // seed riders in this launch (0 = none)
@@ -198,10 +197,9 @@ struct NextSeed {
 __device__ __forceinline__ void seed_rider(const float* __restrict__ feats, const uint4* __restrict__ half, int64_t n,
                                            int64_t row_base, const NextSeed& next, int rider) {
     float q[kDim];
-    if (next.query_row >= 0) {
-        const float* qp = feats + next.query_row * kDim;
+    if (next.query_ptr) {
 #pragma unroll
-        for (int j = 0; j < kDim; ++j) q[j] = qp[j];
+        for (int j = 0; j < kDim; ++j) q[j] = next.query_ptr[j];
     } else {
 #pragma unroll
         for (int j = 0; j < kDim; ++j) q[j] = next.q[j];
@@ -271,7 +269,7 @@ struct HalfTile {
 template <typename Cfg, bool kQueryFromRow, bool kWithMerge>
 __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_half_kernel(
     const float* __restrict__ feats, const uint4* __restrict__ half, int64_t n, int iters, int64_t row_base,
-    QueryArg qarg, int64_t query_row, int64_t exclude_global, int topk, uint64_t* __restrict__ block_lists,
+    QueryArg qarg, const float* __restrict__ query_ptr, int64_t exclude_global, int topk, uint64_t* __restrict__ block_lists,
     const uint32_t* __restrict__ seed_vals, int n_seed, unsigned long long* __restrict__ rescored /* [scanning workgroups] */,
     PrevMerge prev, NextSeed next) {
     constexpr int kBlock = Cfg::kBlock;
@@ -307,9 +305,8 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_half_kernel(
 
     float q[kDim];
     if constexpr (kQueryFromRow) {
-        const float* qp = feats + query_row * kDim;  // wave-uniform: scalar loads
 #pragma unroll
-        for (int j = 0; j < kDim; ++j) q[j] = qp[j];
+        for (int j = 0; j < kDim; ++j) q[j] = query_ptr[j];  // wave-uniform: scalar loads
     } else {
 #pragma unroll
         for (int j = 0; j < kDim; ++j) q[j] = qarg.q[j];

@@ -19,10 +19,23 @@
 //         north_star names).  librccl is opened lazily, only for this transport.
 // This layer is host orchestration over the single-device C-ABI and the HIP
 // runtime: it launches no kernel of its own.
+//
+// Two ways in:
+//   * synchronous calls (mi355rec_sharded_query_*): what Recommender::recommendByIndex
+//     maps to.  One shard -> straight to that shard's handle.  More: scan + local merge per
+//     shard, exchange, merge on the first device straight into mapped host memory, ONE
+//     host wait (the first device's stream; everything it depends on is ordered by events).
+//   * the STREAM (mi355rec_sharded_enqueue_* / _flush / _wait): a serving loop.  One streamed
+//     scan launch per shard per query, one exchange + one batched merge per WINDOW of
+//     queries, tickets instead of host waits.
+// A query by ROW never comes back to the host: every shard's kernels read its 48 bytes from
+// the owning shard's memory through the peer mapping (checked once at create time against
+// the by-value path; without all-pairs peer access the row is fetched once per query).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -84,7 +97,26 @@ struct Shard {
     mi355rec_key_t* local_keys = nullptr;   // RCCL transport: send buffer on the shard's device
     mi355rec_key_t* gathered = nullptr;     // RCCL transport: receive buffer on the shard's device
     ncclComm_t comm = nullptr;
+    // the stream of single queries (RCCL transport): [kStreamDepth][window][topn] send,
+    // [kStreamDepth][shards][window][topn] receive
+    mi355rec_key_t* s_local = nullptr;
+    mi355rec_key_t* s_gathered = nullptr;
 };
+
+constexpr int kStreamDepth = 4;     // windows whose results are kept (ring)
+constexpr int kStreamLag = 2;       // the keys of streamed query k are complete, in stream order, behind call k + 2
+constexpr int kMaxWindow = 64;
+
+struct Window {
+    hipEvent_t merged = nullptr;    // first device: this window's batched merge has run (results are in host memory)
+    int64_t abs = -1;               // which window of the stream the ring entry holds (-1: none)
+    int count = 0;                  // queries in it
+    bool issued = false;            // its exchange + merge have been enqueued
+};
+
+int64_t now_ns() {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 }  // namespace
 
@@ -99,9 +131,27 @@ struct mi355rec_sharded {
     mi355rec_key_t* d_keys = nullptr;   // merged results on devices[0]
     int64_t* d_idx = nullptr;
     float* d_score = nullptr;
-    int64_t* h_idx = nullptr;           // pinned
+    int64_t* h_idx = nullptr;           // pinned + mapped: the final merge stores its results here itself
     float* h_score = nullptr;
-    hipEvent_t merged = nullptr;        // device 0 has consumed the gather buffer
+    int64_t* hd_idx = nullptr;          // their device-side addresses
+    float* hd_score = nullptr;
+    bool peer_rows = true;              // every shard's device can read every other shard's rows
+    std::string note;                   // why a fast path was switched off at create time (diagnostics)
+
+    // ---- the stream of single queries -------------------------------------------------
+    int s_topn = 0;                     // geometry the stream buffers were allocated for (0: none yet)
+    int s_window = 16;
+    int s_alloc_window = 0;
+    mi355rec_key_t* s_gather0 = nullptr;   // first device: [kStreamDepth][shards][window][topn] (PEER transport)
+    mi355rec_key_t* s_keys = nullptr;      // first device: [kStreamDepth][window][topn] merged keys
+    int64_t* s_hidx = nullptr;             // pinned + mapped: [kStreamDepth][window][topn]
+    float* s_hscore = nullptr;
+    int64_t* s_hdidx = nullptr;
+    float* s_hdscore = nullptr;
+    Window win[kStreamDepth];
+    int64_t next_ticket = 0;            // tickets handed out so far (window-aligned after a flush)
+    int64_t issued_upto = 0;            // every ticket below has had its window's exchange enqueued
+    int64_t st_queries = 0, st_exchanges = 0, st_host_ns = 0;
     std::string err;
 };
 
@@ -160,8 +210,10 @@ int ensure_capacity(mi355rec_sharded* h, size_t keys_per_shard) {
     S_HIP(h, hipMalloc(&h->d_keys, sizeof(mi355rec_key_t) * cap));
     S_HIP(h, hipMalloc(&h->d_idx, sizeof(int64_t) * cap));
     S_HIP(h, hipMalloc(&h->d_score, sizeof(float) * cap));
-    S_HIP(h, hipHostMalloc(&h->h_idx, sizeof(int64_t) * cap, hipHostMallocDefault));
-    S_HIP(h, hipHostMalloc(&h->h_score, sizeof(float) * cap, hipHostMallocDefault));
+    S_HIP(h, hipHostMalloc(&h->h_idx, sizeof(int64_t) * cap, hipHostMallocMapped));
+    S_HIP(h, hipHostMalloc(&h->h_score, sizeof(float) * cap, hipHostMallocMapped));
+    S_HIP(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->hd_idx), h->h_idx, 0));
+    S_HIP(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->hd_score), h->h_score, 0));
     for (Shard& s : h->shards) {
         S_HIP(h, hipSetDevice(s.device));
         S_HIP(h, hipDeviceSynchronize());
@@ -197,9 +249,52 @@ int ensure_rccl(mi355rec_sharded* h) {
     return MI355REC_OK;
 }
 
-// `count` queries (host vectors) -> merged results in h->d_keys / d_idx / d_score on
-// devices[0] and, after the final sync, in the pinned host mirrors.
-int run_queries(mi355rec_sharded* h, const float* queries, const int64_t* exclude, int count, int topn) {
+// The exchange + final merge of `count` queries whose per-shard key lists ([shard][query][key],
+// `stride` keys from one shard's block to the next) are being produced on the shards' streams:
+// PEER: lists already land in `peer_lists` on the first device; one event per shard orders the
+// merge behind them.  RCCL: ONE grouped all-gather of `stride` keys per shard from send_of(r)
+// into recv_of(r).  Results go to out_keys (device) and out_idx / out_score (device-visible
+// addresses; mapped host memory on the hot paths).
+template <typename SendOf, typename RecvOf>
+int exchange_and_merge(mi355rec_sharded* h, bool rccl, const mi355rec_key_t* peer_lists, SendOf send_of, RecvOf recv_of,
+                       size_t stride, int count, int topn, mi355rec_key_t* out_keys, int64_t* out_idx, float* out_score) {
+    const int g = static_cast<int>(h->shards.size());
+    Shard& root = h->shards[0];
+    const mi355rec_key_t* lists = peer_lists;
+    if (rccl) {
+        ncclResult_t nrc = g_rccl.GroupStart();
+        for (int r = 0; r < g && nrc == 0; ++r) {
+            Shard& s = h->shards[r];
+            nrc = g_rccl.AllGather(send_of(r), recv_of(r), stride, kNcclUint64, s.comm, s.stream);
+        }
+        const ncclResult_t erc = g_rccl.GroupEnd();
+        if (nrc != 0 || erc != 0)
+            return sfail(h, MI355REC_ERR_HIP, "ncclAllGather: %s",
+                         g_rccl.GetErrorString ? g_rccl.GetErrorString(nrc ? nrc : erc) : "error");
+        lists = recv_of(0);   // the collective is ordered on root.stream already
+    } else {
+        for (int r = 1; r < g; ++r) {
+            Shard& s = h->shards[r];
+            S_HIP(h, hipSetDevice(s.device));
+            S_HIP(h, hipEventRecord(s.done, s.stream));
+        }
+        S_HIP(h, hipSetDevice(root.device));
+        for (int r = 1; r < g; ++r) S_HIP(h, hipStreamWaitEvent(root.stream, h->shards[r].done, 0));
+    }
+    S_HIP(h, hipSetDevice(root.device));
+    // list l of query b starts at b * topn + l * stride
+    S_ENG(h, root, mi355rec_enqueue_merge_keys_batch(root.engine, lists, g, topn, static_cast<int64_t>(stride),
+                                                     static_cast<int64_t>(topn), count, topn, out_keys, out_idx, out_score,
+                                                     root.stream));
+    return MI355REC_OK;
+}
+
+// `count` queries (host vectors; or, with count == 1, `qptr` = where the query's 12 floats live
+// in device memory every shard can read) -> merged results in the pinned host mirrors.
+// ONE host wait: the first device's stream.  Its merge waited (events / the collective) for
+// everything the other shards did for this call, and their streams order the next call's
+// writes behind this call's reads, so nothing else needs draining.
+int run_queries(mi355rec_sharded* h, const float* queries, const float* qptr, const int64_t* exclude, int count, int topn) {
     const int g = static_cast<int>(h->shards.size());
     const size_t per_shard = static_cast<size_t>(count) * topn;
     int rc = ensure_capacity(h, per_shard);
@@ -213,49 +308,27 @@ int run_queries(mi355rec_sharded* h, const float* queries, const int64_t* exclud
         Shard& s = h->shards[r];
         S_HIP(h, hipSetDevice(s.device));
         mi355rec_key_t* dst = rccl ? s.local_keys : h->gather0 + static_cast<size_t>(r) * per_shard;
-        if (count == 1) {
+        if (qptr) {
+            S_ENG(h, s, mi355rec_enqueue_ptr_keys(s.engine, qptr, exclude ? exclude[0] : -1, topn, dst, nullptr, nullptr, s.stream));
+        } else if (count == 1) {
             S_ENG(h, s, mi355rec_enqueue_query_keys(s.engine, queries, exclude ? exclude[0] : -1, topn, dst, s.stream));
         } else {
             S_ENG(h, s, mi355rec_enqueue_batch_keys(s.engine, queries, exclude, count, topn, dst, s.stream));
         }
     }
+    // results up to a few thousand slots are stored by the merge kernel straight into mapped host
+    // memory (no copy launches on the latency path); larger ones come back in two copies
+    const bool direct = per_shard <= 4096;
+    rc = exchange_and_merge(
+        h, rccl, h->gather0, [&](int r) { return h->shards[r].local_keys; }, [&](int r) { return h->shards[r].gathered; },
+        per_shard, count, topn, h->d_keys, direct ? h->hd_idx : h->d_idx, direct ? h->hd_score : h->d_score);
+    if (rc) return rc;
     Shard& root = h->shards[0];
-    const mi355rec_key_t* lists = h->gather0;
-    if (rccl) {
-        // ONE grouped all-gather: every device receives [shard][query][key]
-        ncclResult_t nrc = g_rccl.GroupStart();
-        for (int r = 0; r < g && nrc == 0; ++r) {
-            Shard& s = h->shards[r];
-            nrc = g_rccl.AllGather(s.local_keys, s.gathered, per_shard, kNcclUint64, s.comm, s.stream);
-        }
-        const ncclResult_t erc = g_rccl.GroupEnd();
-        if (nrc != 0 || erc != 0)
-            return sfail(h, MI355REC_ERR_HIP, "ncclAllGather: %s",
-                         g_rccl.GetErrorString ? g_rccl.GetErrorString(nrc ? nrc : erc) : "error");
-        lists = root.gathered;   // the collective is ordered on root.stream already
-    } else {
-        for (int r = 1; r < g; ++r) {
-            Shard& s = h->shards[r];
-            S_HIP(h, hipSetDevice(s.device));
-            S_HIP(h, hipEventRecord(s.done, s.stream));
-        }
-        S_HIP(h, hipSetDevice(root.device));
-        for (int r = 1; r < g; ++r) S_HIP(h, hipStreamWaitEvent(root.stream, h->shards[r].done, 0));
+    if (!direct) {
+        S_HIP(h, hipMemcpyAsync(h->h_idx, h->d_idx, per_shard * sizeof(int64_t), hipMemcpyDeviceToHost, root.stream));
+        S_HIP(h, hipMemcpyAsync(h->h_score, h->d_score, per_shard * sizeof(float), hipMemcpyDeviceToHost, root.stream));
     }
-    S_HIP(h, hipSetDevice(root.device));
-    // [shard][query][key]: list l of query b starts at b * topn + l * per_shard
-    S_ENG(h, root, mi355rec_enqueue_merge_keys_batch(root.engine, lists, g, topn, static_cast<int64_t>(per_shard),
-                                                     static_cast<int64_t>(topn), count, topn, h->d_keys, h->d_idx,
-                                                     h->d_score, root.stream));
-    S_HIP(h, hipMemcpyAsync(h->h_idx, h->d_idx, per_shard * sizeof(int64_t), hipMemcpyDeviceToHost, root.stream));
-    S_HIP(h, hipMemcpyAsync(h->h_score, h->d_score, per_shard * sizeof(float), hipMemcpyDeviceToHost, root.stream));
     S_HIP(h, hipStreamSynchronize(root.stream));
-    // the calls are synchronous, so nothing of the next call can overtake this merge;
-    // the other shards' streams are drained too before their buffers are reused
-    for (int r = 1; r < g; ++r) {
-        S_HIP(h, hipSetDevice(h->shards[r].device));
-        S_HIP(h, hipStreamSynchronize(h->shards[r].stream));
-    }
     return MI355REC_OK;
 }
 
@@ -295,21 +368,22 @@ int run_queries_large(mi355rec_sharded* h, const float* queries, const int64_t* 
     return MI355REC_OK;
 }
 
-void copy_out(const mi355rec_sharded* h, int count, int eff, int topn, int64_t* out_idx, float* out_score, int* out_count) {
+void copy_rows(const int64_t* src_i, const float* src_s, int count, int eff, int topn, int64_t* out_idx, float* out_score,
+               int* out_count) {
     for (int b = 0; b < count; ++b) {
-        const int64_t* src_i = h->h_idx + static_cast<size_t>(b) * eff;
-        const float* src_s = h->h_score + static_cast<size_t>(b) * eff;
+        const int64_t* si = src_i + static_cast<size_t>(b) * eff;
+        const float* ss = src_s + static_cast<size_t>(b) * eff;
         int64_t* dst_i = out_idx + static_cast<size_t>(b) * topn;
-        std::memcpy(dst_i, src_i, sizeof(int64_t) * eff);
+        std::memcpy(dst_i, si, sizeof(int64_t) * eff);
         for (int i = eff; i < topn; ++i) dst_i[i] = -1;
         if (out_score) {
             float* dst_s = out_score + static_cast<size_t>(b) * topn;
-            std::memcpy(dst_s, src_s, sizeof(float) * eff);
+            std::memcpy(dst_s, ss, sizeof(float) * eff);
             for (int i = eff; i < topn; ++i) dst_s[i] = 0.0f;
         }
         if (out_count) {
             int c = 0;
-            while (c < eff && src_i[c] >= 0) ++c;
+            while (c < eff && si[c] >= 0) ++c;
             out_count[b] = c;
         }
     }
@@ -320,6 +394,193 @@ struct DeviceRestore {
     DeviceRestore() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
     ~DeviceRestore() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
+
+const Shard* owner_of(const mi355rec_sharded* h, int64_t global_row) {
+    for (const Shard& s : h->shards)
+        if (global_row >= s.lo && global_row < s.hi) return &s;
+    return nullptr;
+}
+
+// Where the 12 floats of a catalogue row live, for kernels on ANY shard's device; null when
+// the row has to travel by value (no all-pairs peer access): then *q_host receives it.
+int locate_row(mi355rec_sharded* h, int64_t global_row, const float** qptr, float* q_host) {
+    const Shard* own = owner_of(h, global_row);
+    if (!own) return sfail(h, MI355REC_ERR_INVALID_ARG, "Invalid song index: %lld", (long long)global_row);
+    *qptr = nullptr;
+    if (h->peer_rows) {
+        const int rc = mi355rec_row_ptr(own->engine, global_row - own->lo, qptr);
+        if (rc != MI355REC_OK) return sfail(h, rc, "shard on device %d: %s", own->device, mi355rec_last_error(own->engine));
+        return MI355REC_OK;
+    }
+    const int rc = mi355rec_fetch_row(own->engine, global_row - own->lo, q_host);
+    if (rc != MI355REC_OK) return sfail(h, rc, "shard on device %d: %s", own->device, mi355rec_last_error(own->engine));
+    return MI355REC_OK;
+}
+
+// ---- the stream of single queries ------------------------------------------------------
+
+void free_stream(mi355rec_sharded* h) {
+    if (h->shards.empty()) return;
+    for (Shard& s : h->shards) {
+        if (hipSetDevice(s.device) != hipSuccess) continue;
+        if (s.s_local) (void)hipFree(s.s_local);
+        if (s.s_gathered) (void)hipFree(s.s_gathered);
+        s.s_local = s.s_gathered = nullptr;
+    }
+    if (hipSetDevice(h->shards[0].device) == hipSuccess) {
+        if (h->s_gather0) (void)hipFree(h->s_gather0);
+        if (h->s_keys) (void)hipFree(h->s_keys);
+        if (h->s_hidx) (void)hipHostFree(h->s_hidx);
+        if (h->s_hscore) (void)hipHostFree(h->s_hscore);
+    }
+    h->s_gather0 = h->s_keys = nullptr;
+    h->s_hidx = nullptr;
+    h->s_hscore = nullptr;
+    h->s_topn = 0;
+    h->s_alloc_window = 0;
+}
+
+int stream_alloc(mi355rec_sharded* h, int topn) {
+    const int g = static_cast<int>(h->shards.size());
+    const size_t wk = static_cast<size_t>(h->s_window) * topn;   // keys of one shard in one window
+    S_HIP(h, hipSetDevice(h->shards[0].device));
+    S_HIP(h, hipMalloc(&h->s_gather0, sizeof(mi355rec_key_t) * kStreamDepth * g * wk));
+    S_HIP(h, hipMalloc(&h->s_keys, sizeof(mi355rec_key_t) * kStreamDepth * wk));
+    S_HIP(h, hipHostMalloc(&h->s_hidx, sizeof(int64_t) * kStreamDepth * wk, hipHostMallocMapped));
+    S_HIP(h, hipHostMalloc(&h->s_hscore, sizeof(float) * kStreamDepth * wk, hipHostMallocMapped));
+    S_HIP(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->s_hdidx), h->s_hidx, 0));
+    S_HIP(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->s_hdscore), h->s_hscore, 0));
+    for (Shard& s : h->shards) {
+        S_HIP(h, hipSetDevice(s.device));
+        S_HIP(h, hipMalloc(&s.s_local, sizeof(mi355rec_key_t) * kStreamDepth * wk));
+        S_HIP(h, hipMalloc(&s.s_gathered, sizeof(mi355rec_key_t) * kStreamDepth * g * wk));
+    }
+    h->s_topn = topn;
+    h->s_alloc_window = h->s_window;
+    return MI355REC_OK;
+}
+
+int stream_flush(mi355rec_sharded* h);
+
+// Buffers for (topn, window); a change of geometry closes the stream first.  All or nothing.
+int ensure_stream(mi355rec_sharded* h, int topn) {
+    if (h->s_topn == topn && h->s_alloc_window == h->s_window) return MI355REC_OK;
+    if (h->s_topn) {
+        int rc = stream_flush(h);
+        if (rc) return rc;
+        for (Shard& s : h->shards) {
+            S_HIP(h, hipSetDevice(s.device));
+            S_HIP(h, hipStreamSynchronize(s.stream));
+        }
+        free_stream(h);
+    }
+    for (Window& w : h->win) {
+        w.abs = -1;
+        w.count = 0;
+        w.issued = false;
+    }
+    // tickets keep growing across a change of geometry, window-aligned in the new one
+    h->next_ticket = (h->next_ticket + h->s_window - 1) / h->s_window * h->s_window;
+    h->issued_upto = h->next_ticket;
+    const int rc = stream_alloc(h, topn);
+    if (rc != MI355REC_OK) free_stream(h);
+    return rc;
+}
+
+// Enqueues the exchange + batched merge of ring entry `w` (its `count` queries are complete on
+// every shard's stream, in stream order).
+int stream_issue(mi355rec_sharded* h, int w) {
+    Window& win = h->win[w];
+    const int g = static_cast<int>(h->shards.size());
+    const int topn = h->s_topn;
+    const size_t wk = static_cast<size_t>(h->s_window) * topn;
+    const bool rccl = h->transport == MI355REC_TRANSPORT_RCCL;
+    const int rc = exchange_and_merge(
+        h, rccl, h->s_gather0 + static_cast<size_t>(w) * g * wk,
+        [&](int r) { return h->shards[r].s_local + static_cast<size_t>(w) * wk; },
+        [&](int r) { return h->shards[r].s_gathered + static_cast<size_t>(w) * g * wk; }, wk, win.count, topn,
+        h->s_keys + static_cast<size_t>(w) * wk, h->s_hdidx + static_cast<size_t>(w) * wk, h->s_hdscore + static_cast<size_t>(w) * wk);
+    if (rc) return rc;
+    S_HIP(h, hipEventRecord(win.merged, h->shards[0].stream));
+    win.issued = true;
+    ++h->st_exchanges;
+    return MI355REC_OK;
+}
+
+// Windows that have become complete (every query of theirs is at least kStreamLag calls old) get
+// their exchange now; `all`: whatever is open as well (the caller has drained the shard pipelines).
+int stream_issue_ready(mi355rec_sharded* h, bool all) {
+    const int W = h->s_window;
+    while (h->issued_upto < h->next_ticket) {
+        const int64_t first = h->issued_upto;
+        const int64_t end = first + W;   // windows are ticket-aligned
+        if (!all && end + kStreamLag > h->next_ticket) break;
+        const int w = static_cast<int>((first / W) % kStreamDepth);
+        const int rc = stream_issue(h, w);
+        if (rc) return rc;
+        h->issued_upto = end < h->next_ticket || !all ? end : h->next_ticket;
+    }
+    return MI355REC_OK;
+}
+
+int stream_flush(mi355rec_sharded* h) {
+    if (!h->s_topn || h->issued_upto >= h->next_ticket) return MI355REC_OK;
+    for (Shard& s : h->shards) {
+        S_HIP(h, hipSetDevice(s.device));
+        S_ENG(h, s, mi355rec_enqueue_flush(s.engine, s.stream));
+    }
+    const int rc = stream_issue_ready(h, true);
+    if (rc) return rc;
+    const int W = h->s_window;
+    h->next_ticket = (h->next_ticket + W - 1) / W * W;   // the next query opens a new window
+    h->issued_upto = h->next_ticket;
+    return MI355REC_OK;
+}
+
+int stream_enqueue(mi355rec_sharded* h, const float* qptr, const float* query12, int64_t exclude_global, int topn,
+                   int64_t* ticket) {
+    if (topn <= 0 || topn > MI355REC_MAX_TOPN_FAST)
+        return sfail(h, MI355REC_ERR_INVALID_ARG, "topn must be in [1, %d] for streamed queries, got %d", MI355REC_MAX_TOPN_FAST, topn);
+    const int64_t t0 = now_ns();
+    int rc = ensure_stream(h, topn);
+    if (rc) return rc;
+    const bool rccl = h->transport == MI355REC_TRANSPORT_RCCL;
+    if (rccl && (rc = ensure_rccl(h)) != MI355REC_OK) return rc;
+    const int g = static_cast<int>(h->shards.size());
+    const int W = h->s_window;
+    const int64_t t = h->next_ticket;
+    const int64_t abs = t / W;
+    const int w = static_cast<int>(abs % kStreamDepth);
+    const int slot = static_cast<int>(t % W);
+    Window& win = h->win[w];
+    if (slot == 0) {
+        // The ring entry's previous window (kStreamDepth windows ago) must be done on the device before
+        // any shard writes into its buffers again: host back-pressure, normally long satisfied.
+        if (win.abs >= 0 && win.issued) S_HIP(h, hipEventSynchronize(win.merged));
+        win.abs = abs;
+        win.count = 0;
+        win.issued = false;
+    }
+    const size_t wk = static_cast<size_t>(W) * topn;
+    for (int r = 0; r < g; ++r) {
+        Shard& s = h->shards[r];
+        S_HIP(h, hipSetDevice(s.device));
+        mi355rec_key_t* dst = rccl ? s.s_local + static_cast<size_t>(w) * wk + static_cast<size_t>(slot) * topn
+                                   : h->s_gather0 + (static_cast<size_t>(w) * g + r) * wk + static_cast<size_t>(slot) * topn;
+        if (qptr) {
+            S_ENG(h, s, mi355rec_enqueue_ptr_keys_streamed(s.engine, qptr, exclude_global, topn, dst, s.stream));
+        } else {
+            S_ENG(h, s, mi355rec_enqueue_query_keys_streamed(s.engine, query12, exclude_global, topn, dst, s.stream));
+        }
+    }
+    ++win.count;
+    ++h->next_ticket;
+    ++h->st_queries;
+    if (ticket) *ticket = t;
+    rc = stream_issue_ready(h, false);
+    h->st_host_ns += now_ns() - t0;
+    return rc;
+}
 
 }  // namespace
 
@@ -335,6 +596,10 @@ void mi355rec_sharded_destroy(mi355rec_sharded_t* h) {
     for (Shard& s : h->shards) {
         if (hipSetDevice(s.device) != hipSuccess) continue;
         if (s.stream) (void)hipStreamSynchronize(s.stream);
+    }
+    free_stream(h);
+    for (Shard& s : h->shards) {
+        if (hipSetDevice(s.device) != hipSuccess) continue;
         if (s.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(s.comm);
         if (s.engine) mi355rec_destroy(s.engine);
         if (s.local_keys) (void)hipFree(s.local_keys);
@@ -349,7 +614,8 @@ void mi355rec_sharded_destroy(mi355rec_sharded_t* h) {
         if (h->d_score) (void)hipFree(h->d_score);
         if (h->h_idx) (void)hipHostFree(h->h_idx);
         if (h->h_score) (void)hipHostFree(h->h_score);
-        if (h->merged) (void)hipEventDestroy(h->merged);
+        for (Window& w : h->win)
+            if (w.merged) (void)hipEventDestroy(w.merged);
     }
     delete h;
 }
@@ -391,21 +657,60 @@ int mi355rec_create_sharded_on(const float* feats_host, int64_t n, int dim, cons
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess)
             return bail(sfail(nullptr, MI355REC_ERR_HIP, "stream / event creation on device %d failed", s.device));
-        // peer stores into the root's gather buffer need the root's memory mapped here
-        if (s.device != root) {
+    }
+    // Peer mappings.  Stores into the first device's gather buffers need ITS memory mapped on every
+    // other device (PEER transport); queries by row need every device's rows mapped on every other.
+    for (int a = 0; a < n_shards; ++a) {
+        for (int b = 0; b < n_shards; ++b) {
+            const int da = devices[a], db = devices[b];
+            if (da == db) continue;
+            bool ok = false;
             int can = 0;
-            if (hipDeviceCanAccessPeer(&can, s.device, root) != hipSuccess || !can) {
-                h->peer_ok = false;
-            } else {
-                const hipError_t e = hipDeviceEnablePeerAccess(root, 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) h->peer_ok = false;
-                (void)hipGetLastError();
+            if (hipSetDevice(da) == hipSuccess && hipDeviceCanAccessPeer(&can, da, db) == hipSuccess && can) {
+                const hipError_t e = hipDeviceEnablePeerAccess(db, 0);
+                ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+            }
+            (void)hipGetLastError();
+            if (!ok) {
+                h->peer_rows = false;
+                if (db == root) h->peer_ok = false;
             }
         }
     }
-    if (hipSetDevice(root) != hipSuccess || hipEventCreateWithFlags(&h->merged, hipEventDisableTiming) != hipSuccess)
-        return bail(sfail(nullptr, MI355REC_ERR_HIP, "event creation on device %d failed", root));
+    if (hipSetDevice(root) != hipSuccess) return bail(sfail(nullptr, MI355REC_ERR_HIP, "hipSetDevice(%d) failed", root));
+    for (Window& w : h->win)
+        if (hipEventCreateWithFlags(&w.merged, hipEventDisableTiming) != hipSuccess)
+            return bail(sfail(nullptr, MI355REC_ERR_HIP, "event creation on device %d failed", root));
     h->transport = h->peer_ok ? MI355REC_TRANSPORT_PEER : MI355REC_TRANSPORT_RCCL;
+
+    // Queries by row through the peer mapping have to give the by-value path's keys: one query
+    // per shard boundary, checked here, once, on real multi-device placements (a mismatch or an
+    // error switches the pointer path off for this handle; mi355rec_sharded_info's note says so).
+    bool distinct = false;
+    for (int r = 1; r < n_shards; ++r) distinct = distinct || devices[r] != devices[0];
+    if (distinct && h->peer_rows && n >= 2) {
+        const int topn = n - 1 < 16 ? static_cast<int>(n - 1) : 16;
+        std::vector<int64_t> i_ptr(topn), i_val(topn);
+        std::vector<float> s_ptr(topn), s_val(topn);
+        for (int r = 0; r < n_shards && h->peer_rows; ++r) {
+            const Shard& s = h->shards[r];
+            if (s.hi == s.lo) continue;
+            const int64_t row = s.hi - 1;
+            int c0 = 0, c1 = 0;
+            int rc = mi355rec_sharded_query_row_topn(h, row, topn, i_ptr.data(), s_ptr.data(), &c0);
+            h->peer_rows = false;
+            const int rc2 = mi355rec_sharded_query_row_topn(h, row, topn, i_val.data(), s_val.data(), &c1);
+            h->peer_rows = true;
+            if (rc2 != MI355REC_OK) return bail(sfail(nullptr, rc2, "self-check query failed: %s", h->err.c_str()));
+            if (rc != MI355REC_OK || c0 != c1 || i_ptr != i_val ||
+                std::memcmp(s_ptr.data(), s_val.data(), sizeof(float) * topn) != 0) {
+                h->peer_rows = false;
+                h->note = "queries by row travel by value: reading a row through the peer mapping did not reproduce the by-value result";
+            }
+        }
+    } else if (!h->peer_rows) {
+        h->note = "queries by row travel by value: no all-pairs peer access between the shards' devices";
+    }
     *out = h;
     return MI355REC_OK;
 }
@@ -433,6 +738,11 @@ int mi355rec_sharded_set_transport(mi355rec_sharded_t* h, int transport) {
     } else if (transport != MI355REC_TRANSPORT_RCCL) {
         return sfail(h, MI355REC_ERR_INVALID_ARG, "unknown transport %d", transport);
     }
+    if (transport != h->transport) {   // an open stream window is closed under the transport it was filled with
+        DeviceRestore restore;
+        const int rc = stream_flush(h);
+        if (rc) return rc;
+    }
     h->transport = transport;
     return MI355REC_OK;
 }
@@ -450,19 +760,54 @@ int mi355rec_sharded_info(const mi355rec_sharded_t* h, int* n_shards, int* trans
     return MI355REC_OK;
 }
 
+const char* mi355rec_sharded_note(const mi355rec_sharded_t* h) { return h ? h->note.c_str() : ""; }
+
+int mi355rec_sharded_set_timing(mi355rec_sharded_t* h, int enabled) {
+    if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    for (Shard& s : h->shards) S_ENG(h, s, mi355rec_set_timing(s.engine, enabled));
+    return MI355REC_OK;
+}
+
+int mi355rec_sharded_shard_stats(const mi355rec_sharded_t* hc, int shard, mi355rec_stats_t* out) {
+    mi355rec_sharded_t* h = const_cast<mi355rec_sharded_t*>(hc);
+    if (!h || !out) return sfail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (shard < 0 || shard >= static_cast<int>(h->shards.size())) return sfail(h, MI355REC_ERR_INVALID_ARG, "no shard %d", shard);
+    const Shard& s = h->shards[shard];
+    S_ENG(h, s, mi355rec_stats(s.engine, out));
+    return MI355REC_OK;
+}
+
+int mi355rec_sharded_set_replica(mi355rec_sharded_t* h, int mode) {
+    if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    DeviceRestore restore;
+    const int rc = stream_flush(h);
+    if (rc) return rc;
+    for (Shard& s : h->shards) {
+        if (s.hi == s.lo) continue;
+        S_ENG(h, s, mi355rec_set_replica(s.engine, mode));
+    }
+    return MI355REC_OK;
+}
+
+int mi355rec_sharded_rows_by_pointer(const mi355rec_sharded_t* h) { return h && h->peer_rows ? 1 : 0; }
+
 int mi355rec_sharded_query_batch_topn(mi355rec_sharded_t* h, const float* queries, int batch,
                                       const int64_t* exclude_global, int topn, int64_t* out_idx, float* out_score,
                                       int* out_count) {
     if (!h || !queries || !out_idx) return sfail(h, MI355REC_ERR_INVALID_ARG, "null argument");
     if (batch < 1) return sfail(h, MI355REC_ERR_INVALID_ARG, "batch must be positive");
     if (topn <= 0) return sfail(h, MI355REC_ERR_INVALID_ARG, "topn must be positive, got %d", topn);
+    if (h->shards.size() == 1) {   // one shard: its own handle is the whole engine (row_base 0)
+        const int rc = mi355rec_query_batch_topn(h->shards[0].engine, queries, batch, exclude_global, topn, out_idx, out_score, out_count);
+        return rc == MI355REC_OK ? rc : sfail(h, rc, "%s", mi355rec_last_error(h->shards[0].engine));
+    }
     // lists are at most n long
     const int eff = static_cast<int64_t>(topn) < h->n ? topn : static_cast<int>(h->n);
     DeviceRestore restore;
     if (eff > MI355REC_MAX_TOPN_FAST) return run_queries_large(h, queries, exclude_global, batch, eff, topn, out_idx, out_score, out_count);
-    const int rc = run_queries(h, queries, exclude_global, batch, eff);
+    const int rc = run_queries(h, queries, nullptr, exclude_global, batch, eff);
     if (rc) return rc;
-    copy_out(h, batch, eff, topn, out_idx, out_score, out_count);
+    copy_rows(h->h_idx, h->h_score, batch, eff, topn, out_idx, out_score, out_count);
     return MI355REC_OK;
 }
 
@@ -476,18 +821,29 @@ int mi355rec_sharded_query_row_topn(mi355rec_sharded_t* h, int64_t global_row, i
     if (!h || !out_idx) return sfail(h, MI355REC_ERR_INVALID_ARG, "null argument");
     if (global_row < 0 || global_row >= h->n)
         return sfail(h, MI355REC_ERR_INVALID_ARG, "Invalid song index: %lld", (long long)global_row);
-    // the query vector lives on the shard that owns the row: 48 bytes come back to the host
-    // and go to every shard as kernel arguments (no collective needed)
+    if (topn <= 0) return sfail(h, MI355REC_ERR_INVALID_ARG, "topn must be positive, got %d", topn);
+    if (h->shards.size() == 1) {   // what Recommender::recommendByIndex costs on a one-GPU box: exactly mi355rec_query_row_topn
+        const int rc = mi355rec_query_row_topn(h->shards[0].engine, global_row, topn, out_idx, out_score, out_count);
+        return rc == MI355REC_OK ? rc : sfail(h, rc, "%s", mi355rec_last_error(h->shards[0].engine));
+    }
     DeviceRestore restore;
     float q[MI355REC_DIM];
-    for (const Shard& s : h->shards) {
-        if (global_row >= s.lo && global_row < s.hi) {
-            const int rc = mi355rec_fetch_row(s.engine, global_row - s.lo, q);
-            if (rc != MI355REC_OK) return sfail(h, rc, "shard on device %d: %s", s.device, mi355rec_last_error(s.engine));
-            break;
+    const float* qptr = nullptr;
+    int rc = locate_row(h, global_row, &qptr, q);
+    if (rc) return rc;
+    const int eff = static_cast<int64_t>(topn) < h->n ? topn : static_cast<int>(h->n);
+    if (eff > MI355REC_MAX_TOPN_FAST) {
+        if (qptr) {   // cold path: by value
+            const Shard* own = owner_of(h, global_row);
+            rc = mi355rec_fetch_row(own->engine, global_row - own->lo, q);
+            if (rc != MI355REC_OK) return sfail(h, rc, "shard on device %d: %s", own->device, mi355rec_last_error(own->engine));
         }
+        return run_queries_large(h, q, &global_row, 1, eff, topn, out_idx, out_score, out_count);
     }
-    return mi355rec_sharded_query_batch_topn(h, q, 1, &global_row, topn, out_idx, out_score, out_count);
+    rc = run_queries(h, q, qptr, &global_row, 1, eff);
+    if (rc) return rc;
+    copy_rows(h->h_idx, h->h_score, 1, eff, topn, out_idx, out_score, out_count);
+    return MI355REC_OK;
 }
 
 int mi355rec_sharded_scores_row(mi355rec_sharded_t* h, int64_t global_row, float* out_host) {
@@ -496,18 +852,100 @@ int mi355rec_sharded_scores_row(mi355rec_sharded_t* h, int64_t global_row, float
         return sfail(h, MI355REC_ERR_INVALID_ARG, "Invalid song index: %lld", (long long)global_row);
     DeviceRestore restore;
     float q[MI355REC_DIM];
-    for (const Shard& s : h->shards) {
-        if (global_row >= s.lo && global_row < s.hi) {
-            const int rc = mi355rec_fetch_row(s.engine, global_row - s.lo, q);
-            if (rc != MI355REC_OK) return sfail(h, rc, "shard on device %d: %s", s.device, mi355rec_last_error(s.engine));
-            break;
-        }
-    }
+    const Shard* own = owner_of(h, global_row);
+    int rc = mi355rec_fetch_row(own->engine, global_row - own->lo, q);
+    if (rc != MI355REC_OK) return sfail(h, rc, "shard on device %d: %s", own->device, mi355rec_last_error(own->engine));
     for (const Shard& s : h->shards) {
         if (s.hi == s.lo) continue;
-        const int rc = mi355rec_scores(s.engine, q, out_host + s.lo);
+        rc = mi355rec_scores(s.engine, q, out_host + s.lo);
         if (rc != MI355REC_OK) return sfail(h, rc, "shard on device %d: %s", s.device, mi355rec_last_error(s.engine));
     }
+    return MI355REC_OK;
+}
+
+// ---- the stream ---------------------------------------------------------------------------
+
+int mi355rec_sharded_set_window(mi355rec_sharded_t* h, int window) {
+    if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    if (window < 1 || window > kMaxWindow) return sfail(h, MI355REC_ERR_INVALID_ARG, "window must be in [1, %d], got %d", kMaxWindow, window);
+    if (window == h->s_window) return MI355REC_OK;
+    DeviceRestore restore;
+    const int rc = stream_flush(h);   // the open window is closed in the old geometry
+    if (rc) return rc;
+    // buffers are re-made by the next enqueue (ensure_stream sees s_alloc_window != s_window)
+    h->next_ticket = (h->next_ticket + window - 1) / window * window;
+    h->issued_upto = h->next_ticket;
+    for (Shard& s : h->shards) {
+        S_HIP(h, hipSetDevice(s.device));
+        S_HIP(h, hipStreamSynchronize(s.stream));
+    }
+    free_stream(h);
+    for (Window& w : h->win) {
+        w.abs = -1;
+        w.count = 0;
+        w.issued = false;
+    }
+    h->s_window = window;
+    return MI355REC_OK;
+}
+
+int mi355rec_sharded_enqueue_query(mi355rec_sharded_t* h, const float* query12, int64_t exclude_global, int topn,
+                                   int64_t* ticket) {
+    if (!h || !query12) return sfail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    DeviceRestore restore;
+    return stream_enqueue(h, nullptr, query12, exclude_global, topn, ticket);
+}
+
+int mi355rec_sharded_enqueue_row(mi355rec_sharded_t* h, int64_t global_row, int topn, int64_t* ticket) {
+    if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    if (global_row < 0 || global_row >= h->n)
+        return sfail(h, MI355REC_ERR_INVALID_ARG, "Invalid song index: %lld", (long long)global_row);
+    DeviceRestore restore;
+    float q[MI355REC_DIM];
+    const float* qptr = nullptr;
+    const int rc = locate_row(h, global_row, &qptr, q);
+    if (rc) return rc;
+    return stream_enqueue(h, qptr, q, global_row, topn, ticket);
+}
+
+int mi355rec_sharded_enqueue_flush(mi355rec_sharded_t* h) {
+    if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    DeviceRestore restore;
+    const int64_t t0 = now_ns();
+    const int rc = stream_flush(h);
+    h->st_host_ns += now_ns() - t0;
+    return rc;
+}
+
+int mi355rec_sharded_wait(mi355rec_sharded_t* h, int64_t ticket, int64_t* out_idx, float* out_score, int* out_count) {
+    if (!h || !out_idx) return sfail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (!h->s_topn || ticket < 0 || ticket >= h->next_ticket)
+        return sfail(h, MI355REC_ERR_INVALID_ARG, "ticket %lld was never handed out", (long long)ticket);
+    DeviceRestore restore;
+    const int W = h->s_window;
+    const int64_t abs = ticket / W;
+    const int w = static_cast<int>(abs % kStreamDepth);
+    const int slot = static_cast<int>(ticket % W);
+    Window& win = h->win[w];
+    if (win.abs != abs || slot >= win.count)
+        return sfail(h, MI355REC_ERR_INVALID_ARG, "the results of ticket %lld are no longer kept (ring of %d windows of %d)",
+                     (long long)ticket, kStreamDepth, W);
+    if (!win.issued) {   // its window is still open (or waits for the lag): close it now
+        const int rc = stream_flush(h);
+        if (rc) return rc;
+    }
+    S_HIP(h, hipEventSynchronize(win.merged));
+    const int topn = h->s_topn;
+    const size_t off = (static_cast<size_t>(w) * W + slot) * topn;
+    copy_rows(h->s_hidx + off, h->s_hscore + off, 1, topn, topn, out_idx, out_score, out_count);
+    return MI355REC_OK;
+}
+
+int mi355rec_sharded_stream_stats(const mi355rec_sharded_t* h, int64_t* queries, int64_t* exchanges, int64_t* host_ns) {
+    if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    if (queries) *queries = h->st_queries;
+    if (exchanges) *exchanges = h->st_exchanges;
+    if (host_ns) *host_ns = h->st_host_ns;
     return MI355REC_OK;
 }
 

@@ -355,6 +355,55 @@ class NodeEngine:
         self._check(self._lib.mi355rec_sharded_scores_row(self._h, int(global_row), out.ctypes.data_as(ctypes.c_void_p)))
         return out
 
+    # -- the stream of single queries (asynchronous; tickets) ---------------------------
+    def set_window(self, window: int) -> None:
+        self._check(self._lib.mi355rec_sharded_set_window(self._h, int(window)))
+
+    def enqueue_row(self, global_row: int, topn: int) -> int:
+        t = ctypes.c_int64(-1)
+        self._check(self._lib.mi355rec_sharded_enqueue_row(self._h, int(global_row), int(topn), ctypes.byref(t)))
+        return int(t.value)
+
+    def enqueue_query(self, query, exclude_global: int, topn: int) -> int:
+        q = _np_f32(query).reshape(capi.DIM)
+        t = ctypes.c_int64(-1)
+        self._check(self._lib.mi355rec_sharded_enqueue_query(self._h, q.ctypes.data_as(ctypes.c_void_p), int(exclude_global),
+                                                            int(topn), ctypes.byref(t)))
+        return int(t.value)
+
+    def enqueue_flush(self) -> None:
+        self._check(self._lib.mi355rec_sharded_enqueue_flush(self._h))
+
+    def wait(self, ticket: int, topn: int) -> Tuple[np.ndarray, np.ndarray]:
+        idx = np.empty(int(topn), dtype=np.int64)
+        score = np.empty(int(topn), dtype=np.float32)
+        count = ctypes.c_int(0)
+        self._check(self._lib.mi355rec_sharded_wait(self._h, int(ticket), idx.ctypes.data_as(ctypes.c_void_p),
+                                                   score.ctypes.data_as(ctypes.c_void_p), ctypes.byref(count)))
+        return idx[:count.value].copy(), score[:count.value].copy()
+
+    def stream_stats(self) -> dict:
+        q, e, ns = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        self._check(self._lib.mi355rec_sharded_stream_stats(self._h, ctypes.byref(q), ctypes.byref(e), ctypes.byref(ns)))
+        return {"queries": int(q.value), "exchanges": int(e.value), "host_ns": int(ns.value)}
+
+    def set_timing(self, enabled) -> None:
+        self._check(self._lib.mi355rec_sharded_set_timing(self._h, int(enabled)))
+
+    def shard_stats(self, shard: int) -> capi.Stats:
+        st = capi.Stats()
+        self._check(self._lib.mi355rec_sharded_shard_stats(self._h, int(shard), ctypes.byref(st)))
+        return st
+
+    def set_replica(self, mode: int) -> None:
+        self._check(self._lib.mi355rec_sharded_set_replica(self._h, int(mode)))
+
+    def rows_by_pointer(self) -> bool:
+        return bool(self._lib.mi355rec_sharded_rows_by_pointer(self._h))
+
+    def note(self) -> str:
+        return (self._lib.mi355rec_sharded_note(self._h) or b"").decode("utf-8", "replace")
+
 
 # ---- packed keys on the host (pure bit manipulation, mirrors kernels.hip.h) ----
 

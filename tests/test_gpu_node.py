@@ -115,3 +115,105 @@ def test_rccl_transport_issues_a_real_all_gather(Node):
         for b, row in enumerate(qrows):
             want = oracle.scores(f, f[row])
             assert_topn_matches(idx[b][:counts[b]], sc[b][:counts[b]], want, int(row), 10)
+
+
+# ---- the asynchronous stream on the sharded handle (tickets, windows) ------------------------
+
+@pytest.mark.parametrize("shards,window,n", [(1, 16, 300_007), (3, 4, 300_007), (8, 16, 400_003), (2, 1, 100_001),
+                                             (2, 5, 2_400_001)])   # the last: shards that scan their fp16 replica
+def test_streamed_queries_on_the_sharded_handle(Node, shards, window, n):
+    """enqueue_row / enqueue_query only enqueue (one streamed launch per shard), the key lists of a
+    WINDOW of queries share one exchange + one batched merge; results by ticket, compared with the
+    oracle.  Partial windows, waits that have to close the window themselves, vectors and rows mixed."""
+    rng = np.random.default_rng(100 + shards)
+    f = rng.random((n, 12), dtype=np.float32)
+    f[n - 3] = f[11]                                  # a duplicate of a query row in the last shard
+    topn = 50
+    with Node(f, devices=[0] * shards) as node:
+        assert node.rows_by_pointer() and node.note() == ""
+        node.set_window(window)
+        qrows = [11, n - 1, n // 2] + rng.integers(0, n, size=2 * window + 3).tolist()
+        for chunk in range(0, len(qrows), 2 * window):        # at most 2 windows in flight: all results still kept
+            part = qrows[chunk:chunk + 2 * window]
+            tickets = [node.enqueue_row(r, topn) for r in part]
+            vec = rng.random(12, dtype=np.float32)
+            tv = node.enqueue_query(vec, 5, topn)
+            assert tickets == sorted(tickets) and tv > tickets[-1]
+            for t, r in zip(tickets, part):                    # the first wait closes whatever is open
+                idx, sc = node.wait(t, topn)
+                want = oracle.scores(f, f[r])
+                assert_topn_matches(idx, sc, want, r, topn, ref_idx=oracle.topn_heap(want, r, topn))
+            idx, sc = node.wait(tv, topn)
+            want = oracle.scores(f, vec)
+            assert_topn_matches(idx, sc, want, 5, topn)
+        st = node.stream_stats()
+        assert st["queries"] == len(qrows) + (len(qrows) + 2 * window - 1) // (2 * window) and st["exchanges"] >= 1
+        # the synchronous calls still work in between, and give the same answer as the stream
+        a_idx, a_sc = node.query_row_topn(11, topn)
+        t = node.enqueue_row(11, topn)
+        b_idx, b_sc = node.wait(t, topn)
+        assert a_idx.tolist() == b_idx.tolist() and np.array_equal(a_sc.view(np.uint32), b_sc.view(np.uint32))
+
+
+def test_stream_ring_and_bad_tickets(Node):
+    from spotify_recommender_amd import capi
+    rng = np.random.default_rng(21)
+    n = 120_000
+    f = rng.random((n, 12), dtype=np.float32)
+    with Node(f, devices=[0, 0]) as node:
+        node.set_window(2)
+        with pytest.raises(capi.Mi355Error):
+            node.wait(0, 10)                                    # nothing was ever enqueued
+        tickets = [node.enqueue_row(int(r), 10) for r in range(0, 24)]     # 12 windows of 2: a ring of 4 is kept
+        node.enqueue_flush()
+        with pytest.raises(capi.Mi355Error, match="no longer kept"):
+            node.wait(tickets[0], 10)
+        for r in (20, 21, 22, 23):
+            idx, sc = node.wait(tickets[r], 10)
+            want = oracle.scores(f, f[r])
+            assert_topn_matches(idx, sc, want, r, 10, ref_idx=oracle.topn_heap(want, r, 10))
+        with pytest.raises(capi.Mi355Error):
+            node.wait(10_000, 10)
+        with pytest.raises(capi.Mi355Error):
+            node.enqueue_row(n, 10)
+        with pytest.raises(capi.Mi355Error):
+            node.enqueue_row(0, 2000)                           # streamed queries: topn <= 1024
+        with pytest.raises(capi.Mi355Error):
+            node.set_window(0)
+        # a change of topn re-makes the buffers; tickets keep growing
+        t = node.enqueue_row(7, 33)
+        assert t > tickets[-1]
+        idx, sc = node.wait(t, 33)
+        want = oracle.scores(f, f[7])
+        assert_topn_matches(idx, sc, want, 7, 33, ref_idx=oracle.topn_heap(want, 7, 33))
+
+
+def test_stream_with_more_shards_than_rows(Node):
+    rng = np.random.default_rng(22)
+    f = rng.random((5, 12), dtype=np.float32)
+    with Node(f, devices=[0] * 8) as node:                      # three shards are empty: they answer with empty lists
+        node.set_window(3)
+        tickets = [node.enqueue_row(r, 10) for r in range(5)]
+        for r, t in enumerate(tickets):
+            idx, sc = node.wait(t, 10)
+            want = oracle.scores(f, f[r])
+            assert_topn_matches(idx, sc, want, r, 10)
+
+
+def test_stream_over_the_rccl_transport(Node):
+    """One shard per device (one rank on this box): the window's keys go through a real grouped
+    ncclAllGather on the shard's stream, then the batched merge."""
+    from spotify_recommender_amd import capi
+    rng = np.random.default_rng(23)
+    n = 200_000
+    f = rng.random((n, 12), dtype=np.float32)
+    with Node(f, n_devices=1) as node:
+        node.set_transport(capi.TRANSPORT_RCCL)
+        node.set_window(4)
+        rows = rng.integers(0, n, size=10).tolist()
+        tickets = [node.enqueue_row(r, 20) for r in rows]
+        node.enqueue_flush()
+        for r, t in list(zip(rows, tickets))[-8:]:
+            idx, sc = node.wait(t, 20)
+            want = oracle.scores(f, f[r])
+            assert_topn_matches(idx, sc, want, r, 20, ref_idx=oracle.topn_heap(want, r, 20))

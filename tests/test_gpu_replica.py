@@ -389,3 +389,39 @@ def test_streams_run_one_call_behind(Engine, torch_cuda, n):
                 verify(outs[i], f[q], q, topn)
             else:
                 verify(outs[i], q, -1, topn)
+
+
+def test_replica_built_on_demand_under_a_running_stream(Engine, torch_cuda):
+    """A shard below 65536 rows is created WITHOUT a replica (no AUTO path would read it).  Streamed
+    queries over the fp32 rows, then set_replica(ON) — which builds the replica and everything keyed on
+    it (the sample buffers of streamed queries included) — then more streamed queries, a rebuild in the
+    middle of the stream (it completes the stashed and the pending query first), a flush: every key
+    list against the oracle.  (the lazily allocated scratch must be all-or-nothing.)"""
+    torch = torch_cuda
+    from spotify_recommender_amd.engine import unpack_keys
+    rng = np.random.default_rng(31)
+    n, topn = 40_000, 20
+    f = rng.random((n, 12), dtype=np.float32)
+    rows = rng.integers(0, n, size=14).tolist()
+    keys = torch.zeros((len(rows), topn), dtype=torch.int64, device="cuda")
+    with Engine(f) as eng:
+        st = eng.stats()
+        assert st.replica_bytes_per_query == 0 and st.replica_active == 0
+        for i in range(0, 4):
+            eng.enqueue_row_keys_streamed(rows[i], topn, keys[i])           # fp32 rows, merge riding
+        eng.set_replica(ON)                                                   # builds it now (flushes the stream first)
+        st = eng.stats()
+        assert st.replica_bytes_per_query == (n + 1) // 2 * 48 and st.replica_active == 1
+        for i in range(4, 9):
+            eng.enqueue_row_keys_streamed(rows[i], topn, keys[i])           # replica scan, one call behind
+        eng.rebuild_replica()                                                 # completes the stashed + pending query first
+        for i in range(9, 14):
+            eng.enqueue_query_keys_streamed(f[rows[i]], rows[i], topn, keys[i])
+        eng.enqueue_flush()
+        torch.cuda.synchronize()
+        got = keys.cpu().numpy()
+        for i, r in enumerate(rows):
+            want = oracle.scores(f, f[r], threads=0)
+            idx, sc = unpack_keys(got[i])
+            assert_topn_matches(idx, sc, want, r, topn, ref_idx=oracle.topn_heap(want, r, topn))
+        assert eng.replica_counters()["scans"] == 10

@@ -28,7 +28,7 @@ def main():
     from spotify_recommender_amd.synth import synthetic_catalogue
 
     t = synthetic_catalogue(args.rows, seed=12345)
-    rows = [(k * 7919 + 13) % args.rows for k in range(max(args.check, args.steps + 20))]
+    rows = [(k * 7919 + 13) % args.rows for k in range(max(args.check, args.steps + 20, 200))]   # 200: the latency loop below
     out = {"rows": args.rows, "topn": args.topn}
     with CosineEngine(t) as eng:
         st = eng.stats()
