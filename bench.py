@@ -191,6 +191,10 @@ def run_node(args, json_fd):
     node = NodeEngine(feats_host, devices=devices)
     info = node.info()
     node.set_window(args.window)
+    # `value` is measured with one streamed scan launch per shard per QUERY (each query its own pass over
+    # every shard: the N = 1 line's step, sharded); the same stream with BATCHED windows (a window of
+    # queries = one multi-query pass per shard) is reported beside it as `batched_windows`.
+    node.set_window_mode(False)
     if args.transport == "rccl":
         node.set_transport(capi.TRANSPORT_RCCL)
     elif args.transport == "peer":
@@ -254,6 +258,24 @@ def run_node(args, json_fd):
                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                   "frac": round(rows_local * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if k_ms > 0 else None}}
 
+    # the same stream with batched windows: a window of queries is ONE multi-query pass per shard
+    batched_windows = None
+    if topn <= 128 and args.window >= 2:
+        node.set_window_mode(True)
+        dtb, lastb, msb, hostb, exb = timed_stream()
+        node.set_window_mode(False)
+        kb = sum(msb) / len(msb) if msb else 0.0
+        alg_b = (rows_local + 1) // 2 * 48
+        batched_windows = {
+            "value": round(args.steps / dtb, 2), "unit": "queries/s", "ms_per_step": round(dtb / args.steps * 1e3, 5),
+            "queries_per_pass": min(args.window, 32), "launches_per_shard_per_window": 3 * ((args.window + 31) // 32),
+            "host_enqueue_us_per_query": round(hostb, 2), "exchanges": exb,
+            "kernel": "mi355::scan_half_multi_kernel (fp16 matrix-core pre-filter over the 24 B/row replica, up to 32 queries per pass)",
+            "avg_pass_kernel_ms": round(kb, 5),
+            "pass_gbps": round(alg_b / (kb * 1e-3) / 1e9, 1) if kb > 0 else None,
+            "note": "throughput mode: a query starts when its window closes; results identical (tests/test_gpu_node.py)"}
+        last_batched = lastb
+
     # the other transport, same stream (real placements only: RCCL wants one device per shard)
     other = None
     if not virtual and g > 1:
@@ -301,6 +323,8 @@ def run_node(args, json_fd):
     from oracle import oracle
     ok, checked = True, 0
     rows_to_check = [(q_rows[total_q - 1], last_result)]
+    if batched_windows is not None:
+        rows_to_check.append((q_rows[total_q - 1], last_batched))
     for k in (0, total_q // 2, total_q + args.latency_queries - 1):
         rows_to_check.append((q_rows[k], node.query_row_topn(q_rows[k], topn)))
     for row, (idx, sc) in rows_to_check:
@@ -330,7 +354,7 @@ def run_node(args, json_fd):
             "transport": "peer" if transport == capi.TRANSPORT_PEER else "rccl",
             "rccl_ranks": g if (transport == capi.TRANSPORT_RCCL or (other is not None and other.get("transport") == "rccl"
                                                                     and "value" in other)) else None,
-            "window": args.window, "exchanges_in_timed_region": exchanges,
+            "window": args.window, "window_mode": "streamed: one scan launch per shard per query", "exchanges_in_timed_region": exchanges,
             "rows_by_pointer": node.rows_by_pointer(), "note": node.note(),
             "merge": "per shard inside the next query's scan launch (streamed); one exchange + one batched merge per window; "
                      "last window flushed and its result awaited inside the timed region",
@@ -361,6 +385,8 @@ def run_node(args, json_fd):
     elif not replica:
         line["roofline"]["survey_frac"] = line["roofline"]["frac"]
         line["roofline"]["survey_achieved"] = line["roofline"]["achieved"]
+    if batched_windows is not None:
+        line["batched_windows"] = batched_windows
     if other is not None:
         line["other_transport"] = other
     if single is not None:
@@ -592,11 +618,31 @@ def main():
         dt, b_keys = batch_leg(nb, 30 if sharded is None else 6, capi.BATCH_AUTO)
         micro = {"queries_per_call": nb, "value": round(nb / dt, 1), "unit": "queries/s",
                  "ms_per_call": round(dt * 1e3, 5),
-                 "note": ("one call = one pass pair of the batched matrix-core path over the fp16 replica "
-                          "(mi355::bq_pass_kernel<2, .., true>: a block of <= 32 queries costs the same)"
+                 "note": ("one call = ONE multi-query pass over the fp16 replica (mi355::scan_half_multi_kernel: sample launch + "
+                          "24 B/row pass with an fp16 matrix-core pre-filter for up to 32 queries + one merge launch)"
                           if (replica and sharded is None) else
                           "one call = the path mi355rec_enqueue_batch_keys picks for this batch size; "
                           + ("single GPU" if sharded is None else "one all-gather per call"))}
+        if replica and sharded is None:
+            st_m = None
+            eng.set_timing(1)
+            dt12, _ = batch_leg(12, 20, capi.BATCH_AUTO)
+            st_m = eng.stats()
+            eng.set_timing(False)
+            k_ms = float(st_m.last_scan_ms)
+            alg12 = int(st_m.replica_bytes_per_query)
+            micro["roofline"] = {"bound": "hbm", "kernel": "mi355::scan_half_multi_kernel (up to 32 queries per 24 B/row pass)",
+                                 "algorithmic_bytes_per_launch": alg12, "avg_kernel_ms": round(k_ms, 5),
+                                 "achieved": round(alg12 / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None, "peak": HBM_PEAK_GBPS,
+                                 "unit": "GB/s", "frac": round(alg12 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if k_ms > 0 else None,
+                                 "merge_kernel_ms": round(float(st_m.last_merge_ms), 5)}
+            dt2, _ = batch_leg(2, 30, capi.BATCH_AUTO)
+            micro["two_queries"] = {"ms_per_call": round(dt2 * 1e3, 5), "value": round(2 / dt2, 1), "unit": "queries/s"}
+            dt32, _ = batch_leg(32, 20, capi.BATCH_AUTO)
+            micro["thirty_two_queries"] = {"ms_per_call": round(dt32 * 1e3, 5), "value": round(32 / dt32, 1), "unit": "queries/s"}
+            dtm, _ = batch_leg(12, 20, capi.BATCH_MFMA)
+            micro["matrix_core_path_12"] = {"ms_per_call": round(dtm * 1e3, 5), "value": round(12 / dtm, 1), "unit": "queries/s",
+                                            "note": "the same 12 queries forced through the batched fp16-MFMA path (round 2's route)"}
         if sharded is None:
             eng.enqueue_row_keys(q_rows[0], topn, out_keys)
         else:

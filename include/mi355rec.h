@@ -233,15 +233,29 @@ int mi355rec_enqueue_ptr_keys_streamed(mi355rec_t* h, const float* query12_dev, 
                                        int topn, mi355rec_key_t* out_keys_dev, void* stream);
 
 /* `batch` queries (batch x 12 floats, host; exclude_global may be NULL).
- * Three or more queries (13 or more on a handle without a replica) take the
- * batched matrix-core path (mi355rec_set_batch_path); fewer — or shards below
- * 65536 rows — go in exact multi-query passes: every pass streams the shard
- * ONCE for up to 12 queries (topn <= 128; larger topn falls back to one scan
- * per query).  Writes batch x topn packed keys (each row sorted descending,
+ * On a shard with a replica (>= 65536 rows, topn <= 128) 2 ... 16 queries go in
+ * ONE multi-query pass over the fp16 replica (csrc/replica_multi.hip.h: fp16
+ * matrix-core pre-filter for up to 32 queries per 24 B/row pass, candidates
+ * resolved by the exact chain in the same launch), 17 and more take the two-pass
+ * batched matrix-core path (mi355rec_set_batch_path forces either); without a
+ * replica up to 12 queries — or any batch on a shard below 65536 rows — go in
+ * exact multi-query passes over the fp32 rows (12 queries per pass; topn > 128
+ * falls back to one scan per query).  Writes batch x topn packed keys (each row sorted descending,
  * 0-padded). */
 int mi355rec_enqueue_batch_keys(mi355rec_t* h, const float* queries,
                                 const int64_t* exclude_global, int batch, int topn,
                                 mi355rec_key_t* out_keys_dev, void* stream);
+
+/* A batch whose queries are vectors (queries[i*12 ..], host) and / or POINTERS to 12 floats in
+ * device-readable memory (query_ptrs_dev[i] != NULL wins; either array may be NULL when the other
+ * covers every query): what a window of the row-sharded stream hands to every shard.  With a
+ * replica (mi355rec_batch_pointers_ok: shard of >= 65536 rows, topn <= 128, sample large enough)
+ * the batch goes in multi-query passes over the replica, up to 32 queries per pass
+ * (csrc/replica_multi.hip.h); otherwise one scan per query.  topn <= 1024. */
+int mi355rec_batch_pointers_ok(const mi355rec_t* h, int topn);
+int mi355rec_enqueue_batch_mixed_keys(mi355rec_t* h, const float* queries, const float* const* query_ptrs_dev,
+                                      const int64_t* exclude_global, int batch, int topn,
+                                      mi355rec_key_t* out_keys_dev, void* stream);
 
 /* The same for queries that are ALREADY in device memory (batch x 12 floats;
  * exclude_global_dev = batch int64 global row ids or NULL): always the batched
@@ -266,6 +280,7 @@ int mi355rec_enqueue_batch_keys_dev(mi355rec_t* h, const float* queries_dev,
 #define MI355REC_BATCH_AUTO 0
 #define MI355REC_BATCH_MULTI 1
 #define MI355REC_BATCH_MFMA 2
+#define MI355REC_BATCH_HALF 3   /* multi-query passes over the fp16 replica (12 queries per pass) whatever the count */
 int mi355rec_set_batch_path(mi355rec_t* h, int path);
 
 /* Diagnostics of the LAST chunk (<= 1024 queries) the batched path served on
@@ -417,6 +432,14 @@ int mi355rec_sharded_scores_row(mi355rec_sharded_t* h, int64_t global_row, float
  * the host; where some pair of devices has no peer access the row is fetched once
  * (mi355rec_fetch_row) and passed by value.  topn <= 1024, window in [1, 64]. */
 int mi355rec_sharded_set_window(mi355rec_sharded_t* h, int window);   /* default 16; flushes an open window */
+/* How a window runs on the shards.  batched = 1 (default): where every shard can take a batch in
+ * multi-query passes over its fp16 replica (shards of >= 65536 rows, topn <= 128, window >= 2:
+ * mi355rec_batch_pointers_ok) the queries of a window are collected on the host and reach every shard
+ * in ONE mi355rec_enqueue_batch_mixed_keys call when the window closes — three launches per shard per
+ * WINDOW and one pass over the shard per 32 queries, at the price that a query only starts when its
+ * window closes (or at the flush).  batched = 0, or shards that cannot: one streamed scan launch per
+ * shard per QUERY, as described above. */
+int mi355rec_sharded_set_window_mode(mi355rec_sharded_t* h, int batched);
 int mi355rec_sharded_enqueue_row(mi355rec_sharded_t* h, int64_t global_row, int topn, int64_t* ticket);
 int mi355rec_sharded_enqueue_query(mi355rec_sharded_t* h, const float* query12, int64_t exclude_global,
                                    int topn, int64_t* ticket);

@@ -15,7 +15,7 @@ LIB_PATH = PKG / "libmi355rec.so"
 
 DIM = 12
 MAX_TOPN_FAST = 1024
-BATCH_AUTO, BATCH_MULTI, BATCH_MFMA = 0, 1, 2
+BATCH_AUTO, BATCH_MULTI, BATCH_MFMA, BATCH_HALF = 0, 1, 2, 3
 REPLICA_AUTO, REPLICA_OFF, REPLICA_ON = 0, 1, 2
 TRANSPORT_PEER, TRANSPORT_RCCL = 1, 2
 
@@ -67,6 +67,8 @@ SIGNATURES = {
     "mi355rec_enqueue_query_keys_streamed": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "mi355rec_enqueue_flush": (c_int, [c_void_p, c_void_p]),
     "mi355rec_enqueue_batch_keys": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "mi355rec_batch_pointers_ok": (c_int, [c_void_p, c_int]),
+    "mi355rec_enqueue_batch_mixed_keys": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mi355rec_enqueue_batch_keys_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mi355rec_set_batch_path": (c_int, [c_void_p, c_int]),
     "mi355rec_set_replica": (c_int, [c_void_p, c_int]),
@@ -100,6 +102,7 @@ SIGNATURES = {
     "mi355rec_sharded_rows_by_pointer": (c_int, [c_void_p]),
     "mi355rec_sharded_note": (c_char_p, [c_void_p]),
     "mi355rec_sharded_set_window": (c_int, [c_void_p, c_int]),
+    "mi355rec_sharded_set_window_mode": (c_int, [c_void_p, c_int]),
     "mi355rec_sharded_enqueue_row": (c_int, [c_void_p, c_int64, c_int, POINTER(c_int64)]),
     "mi355rec_sharded_enqueue_query": (c_int, [c_void_p, c_void_p, c_int64, c_int, POINTER(c_int64)]),
     "mi355rec_sharded_enqueue_flush": (c_int, [c_void_p]),

@@ -989,6 +989,36 @@ __device__ inline uint64_t wave_compact(uint64_t* cand, int* count, int topk, bo
     return t - 1ull;
 }
 
+// The same with the count kept in a (wave-uniform) REGISTER.  A count that lane 0 stores to LDS and
+// the other lanes load back right away is a data race as far as the compiler is concerned (each lane
+// is a thread: it may keep using the value it loaded before) — callers that compact between two
+// workgroup barriers can use wave_compact; a wave that compacts in the middle of its own work must
+// carry the count itself.
+template <int kKeys>
+__device__ inline uint64_t wave_compact_reg(uint64_t* cand, int& c, int topk, bool exact, int* hist) {
+    const int lane = threadIdx.x & 63;
+    if (c <= topk) return 0ull;   // uniform
+    uint64_t mine[kKeys];
+#pragma unroll
+    for (int r = 0; r < kKeys; ++r) {
+        const int i = lane + r * 64;
+        mine[r] = i < c ? cand[i] : 0ull;
+    }
+    int slack = topk / 4;
+    if (slack < 16) slack = 16;
+    const uint64_t t = wave_select_threshold<kKeys>(mine, topk, exact, slack, hist);
+    int base = 0;
+#pragma unroll
+    for (int r = 0; r < kKeys; ++r) {
+        const bool keep = mine[r] >= t;  // t >= 1, so empty slots drop out
+        const uint64_t b = __ballot(keep);
+        if (keep) cand[base + lanes_below(b)] = mine[r];
+        base += __popcll(b);
+    }
+    c = base;
+    return t - 1ull;
+}
+
 // Wave-level ranking of c <= kRankDirectMax unique keys into dst (descending, best topk).
 __device__ inline void wave_rank_and_store(const uint64_t* keys, int c, uint64_t* dst, int topk) {
     const int lane = threadIdx.x & 63;

@@ -20,6 +20,7 @@
 #include "batched.hip.h"
 #include "kernels.hip.h"
 #include "replica.hip.h"
+#include "replica_multi.hip.h"
 
 using namespace mi355;
 
@@ -84,6 +85,7 @@ struct mi355rec {
     // fp16 replica of the catalogue (replica.hip.h) and the geometry of the scan over it
     uint4* d_half = nullptr;            // ((n + 1) / 2) pairs of rows x 48 B
     uint32_t* d_half_seed = nullptr;    // kHalfSeedMaxGrid x 8 sample maxima of the query in flight
+    uint32_t* d_half_mseed = nullptr;   // kHmQueries x that: the sample of a multi-query pass over the replica
     unsigned long long* d_half_rescored = nullptr;   // [kRideMaxLists] rows sent to the exact chain, per workgroup slot
     int64_t half_scans = 0;             // replica scans enqueued since create
     int hgrid = 0, hiters = 0;          // plain launch
@@ -298,11 +300,12 @@ void plan_half_grid(mi355rec* h) {
 }
 
 void free_replica(mi355rec* h) {
-    void* bufs[] = {h->d_half, h->d_half_seed, h->d_half_rescored, h->d_stream_seed[0], h->d_stream_seed[1]};
+    void* bufs[] = {h->d_half, h->d_half_seed, h->d_half_mseed, h->d_half_rescored, h->d_stream_seed[0], h->d_stream_seed[1]};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     h->d_half = nullptr;
     h->d_half_seed = nullptr;
+    h->d_half_mseed = nullptr;
     h->d_half_rescored = nullptr;
     h->d_stream_seed[0] = h->d_stream_seed[1] = nullptr;
 }
@@ -310,6 +313,7 @@ void free_replica(mi355rec* h) {
 int alloc_replica(mi355rec* h, int64_t n_padded) {
     HIP_TRY(h, hipMalloc(&h->d_half, static_cast<size_t>(n_padded) * 24));
     HIP_TRY(h, hipMalloc(&h->d_half_seed, sizeof(uint32_t) * kHalfSeedMaxGrid * kHalfSeedWaves));
+    HIP_TRY(h, hipMalloc(&h->d_half_mseed, sizeof(uint32_t) * kHmQueries * kHalfSeedMaxGrid * kHalfSeedWaves));
     HIP_TRY(h, hipMalloc(&h->d_half_rescored, sizeof(unsigned long long) * kRideMaxLists));
     // the sample buffers of STREAMED queries belong to the replica: whoever has d_half has them
     for (int i = 0; i < 2; ++i)
@@ -427,7 +431,7 @@ int create_common(const float* feats, bool on_device, int64_t n, int dim, int de
     }
 
     size_t list_words = static_cast<size_t>(h->grid > h->hgrid ? h->grid : h->hgrid) * kMaxTopK;
-    const size_t multi_words = static_cast<size_t>(h->mgrid) * kMultiChain * kMultiMaxTopK;
+    const size_t multi_words = static_cast<size_t>(h->mgrid > h->hgrid ? h->mgrid : h->hgrid) * kMultiChain * kMultiMaxTopK;
     if (multi_words > list_words) list_words = multi_words;
     if ((e = hipMalloc(&h->d_block_lists, sizeof(uint64_t) * list_words)) != hipSuccess)
         return cleanup(MI355REC_ERR_OUT_OF_MEMORY, "hipMalloc(block lists)", e);
@@ -671,6 +675,49 @@ int enqueue_multi(mi355rec* h, const float* queries, const int64_t* exclude, int
     return MI355REC_OK;
 }
 
+// Multi-query passes over the fp16 replica (replica_multi.hip.h): per group of up to kHmQueries
+// queries ONE sample launch + ONE pass over the 24 B/row replica, then one merge launch with a
+// workgroup per query for the whole chain.  queries[i] by value, or qptrs[i] != null: where its 12
+// floats live in device-readable memory.  topn <= kMultiMaxTopK, count <= kMultiChain.
+bool half_multi_ok(const mi355rec* h, int topn) {
+    return h->d_half && h->replica_mode != MI355REC_REPLICA_OFF && topn <= kMultiMaxTopK && h->hseed_grid > 0 &&
+           h->hseed_grid * kHalfSeedWaves >= topn;
+}
+
+int enqueue_half_multi(mi355rec* h, const float* queries, const float* const* qptrs, const int64_t* exclude, int count,
+                       int topn, uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s) {
+    const int n_seed = h->hseed_grid * kHalfSeedWaves;
+    for (int g0 = 0; g0 < count; g0 += kHmQueries) {
+        const int nq = count - g0 < kHmQueries ? count - g0 : kHmQueries;
+        HalfMultiArg arg;
+        std::memset(&arg, 0, sizeof arg);
+        for (int q = 0; q < kHmQueries; ++q) {
+            arg.exclude[q] = -1;
+            if (q >= nq) continue;
+            if (qptrs && qptrs[g0 + q]) {
+                arg.qptr[q] = qptrs[g0 + q];
+            } else if (queries) {
+                std::memcpy(arg.q[q], queries + static_cast<size_t>(g0 + q) * kDim, sizeof(float) * kDim);
+            }
+            if (exclude) arg.exclude[q] = exclude[g0 + q];
+        }
+        hipLaunchKernelGGL(seed_half_multi_kernel, dim3(h->hseed_grid), dim3(kHalfSeedBlock), 0, s, h->d_half, h->n,
+                           h->hseed_stride, h->row_base, arg, nq, h->d_half_mseed);
+        ++h->half_scans;
+        LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, scan_half_multi_kernel, dim3(h->hgrid), dim3(kHmBlock), s,
+                     h->d_feats, h->d_half, h->n, h->row_base, arg, nq, g0, topn, h->d_block_lists,
+                     h->d_half_mseed, n_seed, h->d_half_rescored);
+    }
+    HIP_TRY(h, hipGetLastError());
+    const int slot = timing_begin(h, h->ev_merge, h->n_merge_pairs, h->merge_launches, s);
+    hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(kMergeBlock), 0, s, h->d_block_lists, h->hgrid, topn,
+                       static_cast<int64_t>(topn), static_cast<int64_t>(h->hgrid) * topn, topn, out_keys, out_idx, out_score,
+                       static_cast<int64_t>(topn));
+    timing_end(h, h->ev_merge, h->n_merge_pairs, slot, s);
+    HIP_TRY(h, hipGetLastError());
+    return MI355REC_OK;
+}
+
 int check_topn(mi355rec* h, int topn, bool allow_rounds) {
     if (topn <= 0)
         return fail(h, MI355REC_ERR_INVALID_ARG, "topn must be positive, got %d", topn);
@@ -889,6 +936,8 @@ int enqueue_streamed(mi355rec* h, const float* qptr, const float* query12, int64
 
 constexpr int64_t kBqMinRows = 65536;   // below this the launch count, not the arithmetic, decides
 constexpr int kBqMinBatch = 13;          // without a replica: up to 12 queries are ONE exact multi-query pass (141 us at 10 M rows)
+constexpr int kHmAutoMax = 16;           // up to here a batch goes in ONE multi-query pass over the replica (measured at 10 M
+                                         // rows x top-100: 71 / 82 / 88 us per call for 2 / 12 / 16 queries, the matrix-core path 88)
 constexpr int kBqMinBatchReplica = 3;    // with one, the passes cost ~92 us for any chunk of <= 32 queries (two single
                                          // replica scans cost 88): measured at 10 M rows, tools/run_batched.py
 
@@ -1058,7 +1107,7 @@ int stage_queries(mi355rec* h, const float* queries, const int64_t* exclude, int
 
 bool use_bq(const mi355rec* h, int batch, int topn) {
     if (topn > kMultiMaxTopK || h->n < 1) return false;
-    if (h->batch_path == MI355REC_BATCH_MULTI) return false;
+    if (h->batch_path == MI355REC_BATCH_MULTI || h->batch_path == MI355REC_BATCH_HALF) return false;
     if (h->batch_path == MI355REC_BATCH_MFMA) return true;
     const bool replica = h->d_half && h->replica_mode != MI355REC_REPLICA_OFF;
     return batch >= (replica ? kBqMinBatchReplica : kBqMinBatch) && h->n >= kBqMinRows;
@@ -1084,6 +1133,22 @@ int enqueue_bq_host(mi355rec* h, const float* queries, const int64_t* exclude, i
 // kMultiMaxTopK), otherwise one scan per query.  Outputs are batch x topn.
 int enqueue_batch(mi355rec* h, const float* queries, const int64_t* exclude_global, int batch, int topn,
                   uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s) {
+    // 2 ... kHmAutoMax queries on a shard with a replica: multi-query passes over the replica (24 B/row,
+    // one pass per 12 queries); more: the matrix-core path (two passes whatever the count up to 1024)
+    const bool half_multi = half_multi_ok(h, topn) && h->n >= kBqMinRows &&
+                            (h->batch_path == MI355REC_BATCH_HALF ||
+                             (h->batch_path == MI355REC_BATCH_AUTO && batch >= 2 && batch <= kHmAutoMax));
+    if (half_multi) {
+        for (int b = 0; b < batch; b += kMultiChain) {
+            const int count = batch - b < kMultiChain ? batch - b : kMultiChain;
+            const size_t off = static_cast<size_t>(b) * topn;
+            const int rc = enqueue_half_multi(h, queries + static_cast<size_t>(b) * kDim, nullptr,
+                                              exclude_global ? exclude_global + b : nullptr, count, topn, out_keys + off,
+                                              out_idx ? out_idx + off : nullptr, out_score ? out_score + off : nullptr, s);
+            if (rc) return rc;
+        }
+        return MI355REC_OK;
+    }
     if (use_bq(h, batch, topn))
         return enqueue_bq_host(h, queries, exclude_global, batch, topn, out_keys, out_idx, out_score, s);
     if (batch > 1 && topn <= kMultiMaxTopK && h->n > 0) {
@@ -1271,6 +1336,49 @@ int mi355rec_enqueue_query_keys_streamed(mi355rec_t* h, const float* query12, in
     return enqueue_streamed(h, nullptr, query12, exclude_global, topn, out_keys_dev, s);
 }
 
+// ---- a batch whose queries are partly vectors, partly pointers (the sharded engine's windows) ----
+
+int mi355rec_batch_pointers_ok(const mi355rec_t* h, int topn) {
+    return h && h->n >= kBqMinRows && half_multi_ok(h, topn) ? 1 : 0;
+}
+
+int mi355rec_enqueue_batch_mixed_keys(mi355rec_t* h, const float* queries, const float* const* query_ptrs_dev,
+                                      const int64_t* exclude_global, int batch, int topn, mi355rec_key_t* out_keys_dev,
+                                      void* stream) {
+    if (!h || !out_keys_dev || (!queries && !query_ptrs_dev)) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (batch < 1) return fail(h, MI355REC_ERR_INVALID_ARG, "batch must be positive");
+    int rc = check_topn(h, topn, false);
+    if (rc) return rc;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = order_stream(h, s);
+    if (rc) return rc;
+    if (h->n < 1) {   // an empty shard answers with all-empty lists
+        HIP_TRY(h, hipMemsetAsync(out_keys_dev, 0, sizeof(uint64_t) * static_cast<size_t>(batch) * topn, s));
+        return MI355REC_OK;
+    }
+    if (batch >= 2 && mi355rec_batch_pointers_ok(h, topn) && h->batch_path != MI355REC_BATCH_MULTI) {
+        for (int b = 0; b < batch; b += kMultiChain) {
+            const int count = batch - b < kMultiChain ? batch - b : kMultiChain;
+            rc = enqueue_half_multi(h, queries ? queries + static_cast<size_t>(b) * kDim : nullptr,
+                                    query_ptrs_dev ? query_ptrs_dev + b : nullptr, exclude_global ? exclude_global + b : nullptr,
+                                    count, topn, out_keys_dev + static_cast<size_t>(b) * topn, nullptr, nullptr, s);
+            if (rc) return rc;
+        }
+        return MI355REC_OK;
+    }
+    // no multi-query pass over a replica here: one scan per query, either kind of query
+    for (int b = 0; b < batch; ++b) {
+        const float* ptr = query_ptrs_dev ? query_ptrs_dev[b] : nullptr;
+        if (!ptr && !queries) return fail(h, MI355REC_ERR_INVALID_ARG, "query %d has neither a vector nor a pointer", b);
+        rc = enqueue_query(h, ptr, queries ? queries + static_cast<size_t>(b) * kDim : nullptr,
+                           exclude_global ? exclude_global[b] : -1, topn, out_keys_dev + static_cast<size_t>(b) * topn, nullptr,
+                           nullptr, s);
+        if (rc) return rc;
+    }
+    return MI355REC_OK;
+}
+
 // ---- queries whose 12 floats already live in device-readable memory -----------------
 
 int mi355rec_row_ptr(mi355rec_t* h, int64_t local_row, const float** out_dev) {
@@ -1386,7 +1494,7 @@ int mi355rec_batched_last_counters(mi355rec_t* h, int32_t* special_rows, int32_t
 
 int mi355rec_set_batch_path(mi355rec_t* h, int path) {
     if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
-    if (path != MI355REC_BATCH_AUTO && path != MI355REC_BATCH_MULTI && path != MI355REC_BATCH_MFMA)
+    if (path != MI355REC_BATCH_AUTO && path != MI355REC_BATCH_MULTI && path != MI355REC_BATCH_MFMA && path != MI355REC_BATCH_HALF)
         return fail(h, MI355REC_ERR_INVALID_ARG, "unknown batch path %d", path);
     h->batch_path = path;
     return MI355REC_OK;

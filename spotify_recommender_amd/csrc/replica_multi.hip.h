@@ -1,0 +1,521 @@
+// replica_multi.hip.h — ONE pass over the fp16 replica for 2 ... 32 queries.
+//
+// The missing middle between one query (scan_half_kernel, replica.hip.h: 24 B per row, 12
+// v_fma_mix_f32 per row) and the two-pass matrix-core path for hundreds of queries (batched.hip.h).
+// Per query the contract is recommendByIndex's (Recommender.cu:275-318): every key that leaves the
+// kernel is the exact fp32 chain of calculateSimilaritiesCPU (:256-273, cosine_score()) on the fp32
+// row; the replica only rules rows OUT (bound and special rows: replica.hip.h's header).
+//
+// Why the matrix core.  The first version of this kernel evaluated the fp16 dot products on the
+// vector ALU: 24 v_fma_mix_f32 per lane (= pair of rows) per query.  Measured at 10 M rows x 12
+// queries: 118 us, ~8 cycles per v_fma_mix_f32 — instruction-bound at 3x the HBM time.  One
+// v_mfma_f32_32x32x16_f16 multiplies 32 rows x 32 queries in the 32 cycles the vector ALU needs for
+// FOUR fma_mix, so the pass is HBM-bound again for up to 32 queries (batched.hip.h's operand
+// layout, its threshold-in-the-K-slots trick and its max3 hit test are reused):
+//   A (rows)     lane = one PAIR of rows = 48 B of replica (scan_half_kernel's load pattern); the even
+//                and the odd rows of 64 lanes become two 32-row tiles each by v_permlane32_swap;
+//                k = 12, 13 carry 1.0, k = 14, 15 zero.
+//   B (queries)  column c = query c: its L2-normalised fp16 pairs in k = 0..11, and -T' (the query's
+//                approx cutoff, fp16 hi + lo) in k = 12, 13 — so D = approx - T' comes out of the matrix
+//                core and a row is a candidate iff D's sign bit is clear.  The fragment lives in LDS
+//                (1 KiB) and is re-read every step: the cutoffs tighten while the pass runs.
+// A candidate (query, row) is only NOTED in the hot loop (a per-wave staging buffer in LDS).  When a
+// wave's buffer fills — and once at the end — the wave RESOLVES it: one candidate per lane, the
+// fp32 row fetched (random 48 B), scored with cosine_score(), and the keys that beat the query's
+// current threshold are appended to the workgroup's key list of that query under a per-query spin
+// lock in LDS (a wave-level append of <= 64 keys; a full list is cut back to topk by the wave-level
+// radix select, which raises the threshold and with it the cutoff in the B fragment).  No workgroup
+// barrier in the hot loop, nothing that can overflow: hostile data (no usable sample, mass ties,
+// catalogues of special rows) only makes the resolves frequent.  With a seeded cutoff a wave notes
+// ~20 candidates in a whole launch and resolves once, at the end.
+//
+// Cutoff.  seed_half_multi_kernel takes the sample of replica.hip.h (1024 rows of up to 256 evenly
+// spaced regions, one approx maximum per 128-row wave tile) for every query of the group.  Each
+// scanning workgroup derives the launch-wide cutoff itself, per query, by one wave: lanes keep the
+// four largest of their 32 sample maxima and the topk-th largest v of those 256 values is found by
+// bisection on ballots (topk <= 128 = kMultiMaxTopK).  The 256 values are maxima of 256 DIFFERENT
+// wave tiles, so topk distinct rows have approx >= v, exact >= v - margin, and every row of the true
+// top-k has approx >= v - 2 margin - slack =: T' — the single-query scan's bound with a v that is at
+// most the exact topk-th of all 2048 maxima (equal unless a lane holds five of the top-k): valid.
+#pragma once
+
+#include "replica.hip.h"
+
+namespace mi355 {
+
+constexpr int kHmQueries = 32;                     // queries per pass: the columns of one MFMA tile
+constexpr int kHmBlock = 512;
+constexpr int kHmWaves = kHmBlock / 64;
+#ifndef MI355_HM_CHUNKS
+#define MI355_HM_CHUNKS 2
+#endif
+constexpr int kHmChunks = MI355_HM_CHUNKS;         // 128-row chunks (one pair load per lane) a wave handles per step
+constexpr int kHmStepRows = 128 * kHmChunks;
+constexpr int kHmStage = 128;                      // staged (query, row) candidates per wave
+constexpr int kHmPrivate = 4;                      // keys per (wave, query) kept in the wave's own list before the shared one is touched
+constexpr int kHmKeyCap = 192;                     // kept keys per query and workgroup
+constexpr int kHmKeysPerLane = kHmKeyCap / 64;
+static_assert(kMultiMaxTopK + 64 <= kHmKeyCap, "a wave-level append of 64 keys always fits after an exact compaction");
+
+struct HalfMultiArg {
+    float q[kHmQueries][kDim];            // query i by value (used when qptr[i] is null)
+    const float* qptr[kHmQueries];        // ... or where its 12 floats live (a resident row, possibly of another shard)
+    long long exclude[kHmQueries];        // global row to skip, -1 = none
+};
+
+__device__ __forceinline__ void hm_load_query(const HalfMultiArg& arg, int i, float (&q)[kDim]) {
+    if (arg.qptr[i]) {
+#pragma unroll
+        for (int j = 0; j < kDim; ++j) q[j] = arg.qptr[i][j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < kDim; ++j) q[j] = arg.q[i][j];
+    }
+}
+
+// ---- the sample: [query][region * 8 + wave] ordered-u32 approx maxima -----------------------------
+__global__ __launch_bounds__(kHalfSeedBlock) void seed_half_multi_kernel(
+    const uint4* __restrict__ half, int64_t n, int64_t stride_rows, int64_t row_base, HalfMultiArg arg, int n_queries,
+    uint32_t* __restrict__ seed_vals /* [query][gridDim.x * kHalfSeedWaves] */) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_h[kHmQueries][8];   // six fp16 pairs + ok flag per query
+    __shared__ long long s_excl[kHmQueries];
+    const int tid = threadIdx.x;
+    if (tid < n_queries) {
+        float q[kDim];
+        hm_load_query(arg, tid, q);
+        const float qn = query_norm(q);
+        const bool ok = qn >= kBqMinNorm && qn <= kBqMaxNorm;
+        const float inv = ok ? 1.0f / qn : 0.0f;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) s_h[tid][p] = ok ? bq_pack_h2(q[2 * p] * inv, q[2 * p + 1] * inv) : 0u;
+        s_h[tid][6] = ok ? 1u : 0u;
+        s_excl[tid] = arg.exclude[tid];
+    }
+    __syncthreads();
+    const SeedRegion s = seed_region_load(half, (n + 1) >> 1, stride_rows, blockIdx.x);
+    const int64_t r0 = s.pair * 2;
+    const int64_t per_query = static_cast<int64_t>(gridDim.x) * kHalfSeedWaves;
+    for (int qi = 0; qi < n_queries; ++qi) {
+        const uint4 h03 = *reinterpret_cast<const uint4*>(&s_h[qi][0]);
+        const uint4 h47 = *reinterpret_cast<const uint4*>(&s_h[qi][4]);
+        const uint32_t qh[6] = {h03.x, h03.y, h03.z, h03.w, h47.x, h47.y};
+        const bool ok = h47.z != 0u;
+        const float a0 = half_dot(qh, s.t0.x, s.t0.y, s.t0.z, s.t0.w, s.t1.x, s.t1.y);
+        const float a1 = half_dot(qh, s.t1.z, s.t1.w, s.t2.x, s.t2.y, s.t2.z, s.t2.w);
+        const long long excl = s_excl[qi];
+        // NaN compares false: special rows never seed
+        const bool use0 = s.have && ok && r0 < n && row_base + r0 != excl && a0 >= -2.0f;
+        const bool use1 = s.have && ok && r0 + 1 < n && row_base + r0 + 1 != excl && a1 >= -2.0f;
+        uint32_t v = 0u;
+        if (use0) v = score_to_ordered(a0);
+        if (use1) {
+            const uint32_t w = score_to_ordered(a1);
+            v = w > v ? w : v;
+        }
+        v = wave_max_u32(v);
+        if ((tid & 63) == 0) seed_vals[qi * per_query + static_cast<int64_t>(blockIdx.x) * kHalfSeedWaves + (tid >> 6)] = v;
+    }
+}
+
+// ---- shared memory of one scanning workgroup ---------------------------------------------------------
+struct alignas(16) HalfMultiSmem {
+    uint4 bfrag[64];                            // the B operand: lane c: k 0..7 of query c; lane 32 + c: k 8..11, -T' (hi, lo), 0
+    uint64_t keys[kHmQueries][kHmKeyCap];       // exact keys kept so far, per query (guarded by lock[q])
+    uint2 stage[kHmWaves][kHmStage];            // (query, local row) candidates noted by each wave
+    uint64_t pkeys[kHmWaves][kHmQueries][kHmPrivate];   // each wave's own first few keys per query: appended without a lock
+    int pcount[kHmWaves][kHmQueries];           // (may count past kHmPrivate: the surplus went to the shared list)
+    int hist[kHmWaves][256];                    // scratch of the wave-level radix select
+    float qf[kHmQueries][kDim];                 // the fp32 queries of the exact chain
+    float qn[kHmQueries];
+    float cut[kHmQueries];                      // the cutoff currently in the B fragment (-inf: every row is a candidate)
+    unsigned long long thr[kHmQueries];         // a key must be > thr to be kept (only ever rises)
+    long long excl[kHmQueries];
+    int nkeys[kHmQueries];
+    int lock[kHmQueries];
+    uint32_t ok[kHmQueries];
+    int rescored;
+};
+
+// -T' as the fp16 pair (hi, lo) of the B fragment's threshold slots.  T' = -inf ("every row is a
+// candidate") becomes +inf: D = approx + inf = +inf, sign bit clear.
+__device__ __forceinline__ uint32_t hm_threshold_slots(float cut) {
+    if (!(cut > -3.0e38f)) return 0x00007c00u;   // (hi, lo) = (+inf, 0)
+    const _Float16 hh = static_cast<_Float16>(-cut);
+    const float hi = static_cast<float>(hh);
+    return bq_pack_h2(hi, -cut - hi);
+}
+
+// The launch-wide cutoff of one query from its sample maxima, by one wave (see the header).
+__device__ __forceinline__ float hm_seed_cutoff(const uint32_t* __restrict__ vals, int n_seed, int topk) {
+    const int lane = threadIdx.x & 63;
+    // all of the lane's (up to 32) sample maxima are requested before the first is looked at
+    constexpr int kPer = kHalfSeedMaxGrid * kHalfSeedWaves / 64;
+    uint32_t mine[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int i = lane + 64 * j;
+        mine[j] = i < n_seed ? vals[i] : 0u;
+    }
+    uint32_t m1 = 0u, m2 = 0u, m3 = 0u, m4 = 0u;   // the lane's four largest (an insertion network per value)
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        uint32_t v = mine[j], t;
+        t = v < m1 ? v : m1; m1 = v > m1 ? v : m1; v = t;
+        t = v < m2 ? v : m2; m2 = v > m2 ? v : m2; v = t;
+        t = v < m3 ? v : m3; m3 = v > m3 ? v : m3; v = t;
+        m4 = v > m4 ? v : m4;
+    }
+    // the largest v with |{values >= v}| >= topk, by bisection (uniform: ballots and scalar counts)
+    uint32_t lo = 0u, hi = 0xffffffffu;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1) + ((hi - lo) & 1u);   // ceil of the midpoint: > lo
+        const int c = __popcll(__ballot(m1 >= mid)) + __popcll(__ballot(m2 >= mid)) + __popcll(__ballot(m3 >= mid)) +
+                      __popcll(__ballot(m4 >= mid));
+        if (c >= topk) lo = mid; else hi = mid - 1u;
+    }
+    if (lo == 0u) return -__builtin_inff();   // fewer than topk usable maxima: no seed
+    return ordered_to_score(lo) - 2.0f * kHalfMargin - kBqSlack;
+}
+
+// Per-query spin lock in LDS, taken by a whole wave (lane 0 spins; the holder is another wave of the
+// workgroup, which never waits for anything while it holds the lock).
+__device__ __forceinline__ void hm_lock(int* lock) {
+    if ((threadIdx.x & 63) == 0) {
+        while (atomicCAS(lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ void hm_unlock(int* lock) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((threadIdx.x & 63) == 0) atomicExch(lock, 0);
+}
+
+// Wave-level append to query q0's key list (q0 wave-uniform): the lanes with `mine` hold one exact key each.
+// Under the query's lock: the kept keys are cut back to topk when the new ones would not fit (or pile up),
+// which raises the query's threshold and, through the B fragment, its cutoff.
+__device__ __forceinline__ void hm_append_locked(HalfMultiSmem& sm, int q0, bool mine, uint64_t key, int topk) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    // an append of up to 64 keys must fit behind the kept ones: exact cut when topk is large
+    const bool exact_cut = topk + 32 + 64 > kHmKeyCap;
+    hm_lock(&sm.lock[q0]);
+    int nk = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sm.nkeys[q0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    uint64_t t = __hip_atomic_load(&sm.thr[q0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint64_t t_before = t;
+    bool keep = mine && key > t;
+    uint64_t mk = __ballot(keep);
+    if (mk) {
+        if (nk + __popcll(mk) > kHmKeyCap) {   // uniform: cut the kept keys back first
+            const uint64_t tn = wave_compact_reg<kHmKeysPerLane>(sm.keys[q0], nk, topk, exact_cut, sm.hist[wave]);
+            t = tn > t ? tn : t;
+            keep = mine && key > t;
+            mk = __ballot(keep);
+        }
+        if (keep) sm.keys[q0][nk + lanes_below(mk)] = key;
+        nk += __popcll(mk);
+        if (nk > topk + 32) {   // uniform: tighten the threshold for what is still to come
+            const uint64_t tn = wave_compact_reg<kHmKeysPerLane>(sm.keys[q0], nk, topk, exact_cut, sm.hist[wave]);
+            t = tn > t ? tn : t;
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&sm.nkeys[q0], nk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (t > t_before) {
+                __hip_atomic_store(&sm.thr[q0], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (sm.ok[q0]) {
+                    const float local_cut = ordered_to_score(static_cast<uint32_t>(t >> 32)) - kHalfMargin - kBqSlack;
+                    if (local_cut > sm.cut[q0]) {
+                        sm.cut[q0] = local_cut;
+                        reinterpret_cast<uint32_t*>(&sm.bfrag[32 + q0])[2] = hm_threshold_slots(local_cut);
+                    }
+                }
+            }
+        }
+    }
+    hm_unlock(&sm.lock[q0]);
+}
+
+// The wave's staged candidates -> exact keys -> the workgroup's per-query key lists.
+__device__ __forceinline__ void hm_resolve_stage(HalfMultiSmem& sm, int staged, const float* __restrict__ feats, int64_t row_base,
+                                                 int topk) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint2* stage = sm.stage[wave];
+    for (int e0 = 0; e0 < staged; e0 += 64) {
+        const bool have = e0 + lane < staged;
+        const uint2 e = have ? stage[e0 + lane] : make_uint2(0u, 0u);
+        const int q = static_cast<int>(e.x);
+        const Row r = load_row(feats, static_cast<int64_t>(e.y));   // idle lanes re-read row 0: one cached line
+        float qv[kDim];
+#pragma unroll
+        for (int j = 0; j < kDim; ++j) qv[j] = sm.qf[q][j];
+        const float s = cosine_score(qv, sm.qn[q], r);
+        const int64_t g = row_base + e.y;
+        uint64_t key = pack_key(s, static_cast<uint32_t>(g));
+        if (g == sm.excl[q]) key = 0;
+        // the threshold only ever rises: a stale value lets a key through to the locked check, nothing more
+        const uint64_t seen = __hip_atomic_load(&sm.thr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        bool pass = have && key > seen;
+        // first the wave's own list of that query: no other wave touches it, so no lock — one LDS atomic per key
+        if (pass) {
+            const int slot = atomicAdd(&sm.pcount[wave][q], 1);
+            if (slot < kHmPrivate) {
+                sm.pkeys[wave][q][slot] = key;
+                pass = false;
+            }
+        }
+        uint64_t rem = __ballot(pass);
+        while (rem) {   // uniform, rare: the keys that did not fit there, one query at a time, to the shared list
+            const int src = __ffsll(static_cast<long long>(rem)) - 1;
+            const int q0 = __builtin_amdgcn_readlane(q, src);
+            const bool mine = pass && q == q0;
+            rem &= ~__ballot(mine);
+            hm_append_locked(sm, q0, mine, key, topk);
+        }
+    }
+}
+
+// A step whose candidates did not fit the staging buffer (hostile data: no usable cutoff, special rows
+// everywhere): every (row, query) pair of the step through the exact chain, no pre-filter.
+__device__ __forceinline__ void hm_exact_step(HalfMultiSmem& sm, const float* __restrict__ feats, int64_t n, int64_t row_base,
+                                              int64_t first_row, int n_queries, int topk) {
+    const int lane = threadIdx.x & 63;
+    for (int u = 0; u < kHmStepRows / 64; ++u) {
+        const int64_t row = first_row + u * 64 + lane;
+        const bool have = row < n;
+        const Row r = load_row(feats, have ? row : static_cast<int64_t>(0));
+        for (int q0 = 0; q0 < n_queries; ++q0) {
+            float qv[kDim];
+#pragma unroll
+            for (int j = 0; j < kDim; ++j) qv[j] = sm.qf[q0][j];
+            const float s = cosine_score(qv, sm.qn[q0], r);
+            const int64_t g = row_base + row;
+            uint64_t key = pack_key(s, static_cast<uint32_t>(g));
+            if (g == sm.excl[q0]) key = 0;
+            const uint64_t seen = __hip_atomic_load(&sm.thr[q0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const bool pass = have && key > seen;
+            if (__ballot(pass)) hm_append_locked(sm, q0, pass, key, topk);
+        }
+    }
+}
+
+// block_lists[(slot0 + query) * gridDim.x + workgroup][topk], each list sorted descending, 0-padded.
+__global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
+    const float* __restrict__ feats, const uint4* __restrict__ half, int64_t n, int64_t row_base, HalfMultiArg arg, int n_queries,
+    int slot0, int topk, uint64_t* __restrict__ block_lists, const uint32_t* __restrict__ seed_vals,
+    int n_seed /* sample maxima per query, 0 = none */, unsigned long long* __restrict__ rescored /* [workgroups] */) {
+    __shared__ HalfMultiSmem sm;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int hh = lane >> 5;
+    const unsigned bid = blockIdx.x;
+    const unsigned nblocks = gridDim.x;
+
+    const int64_t n_pairs = (n + 1) >> 1;
+    const int64_t last_pair = n_pairs - 1;
+    const int64_t n_steps = (n_pairs + 64 * kHmChunks - 1) / (64 * kHmChunks);
+    const int64_t total_waves = static_cast<int64_t>(nblocks) * kHmWaves;
+    int64_t step = static_cast<int64_t>(bid) * kHmWaves + wave;   // consecutive steps to consecutive waves: one moving window
+    auto load_chunk = [&](HalfTile& dst, int64_t st, int u) {
+        int64_t pair = (st * kHmChunks + u) * 64 + lane;
+        pair = pair < n_pairs ? pair : last_pair;   // unconditional prefetch (see scan_kernel)
+        const uint4* p = half + pair * 3;
+        dst.t0 = p[0];
+        dst.t1 = p[1];
+        dst.t2 = p[2];
+    };
+    HalfTile T[kHmChunks];
+#pragma unroll
+    for (int u = 0; u < kHmChunks; ++u) load_chunk(T[u], step, u);
+
+    // ---- per-query state and the B fragment; the cutoffs from the sample while the first loads are in flight
+    if (tid < kHmQueries) {
+        float q[kDim];
+        if (tid < n_queries) {
+            hm_load_query(arg, tid, q);
+        } else {
+#pragma unroll
+            for (int j = 0; j < kDim; ++j) q[j] = 0.0f;
+        }
+        const float qn = query_norm(q);
+        const bool ok = tid < n_queries && qn >= kBqMinNorm && qn <= kBqMaxNorm;   // false for NaN
+        const float inv = ok ? 1.0f / qn : 0.0f;
+        uint32_t hp[6];
+#pragma unroll
+        for (int p = 0; p < 6; ++p) hp[p] = ok ? bq_pack_h2(q[2 * p] * inv, q[2 * p + 1] * inv) : 0u;
+        sm.bfrag[tid] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+        // a real query starts with "every row is a candidate"; a padding column can never hit (-65504)
+        sm.bfrag[32 + tid] = make_uint4(hp[4], hp[5], tid < n_queries ? 0x00007c00u : 0x0000fbffu, 0u);
+#pragma unroll
+        for (int j = 0; j < kDim; ++j) sm.qf[tid][j] = q[j];
+        sm.qn[tid] = qn;
+        sm.cut[tid] = -__builtin_inff();
+        sm.thr[tid] = 0ull;
+        sm.excl[tid] = tid < n_queries ? arg.exclude[tid] : -1ll;
+        sm.nkeys[tid] = 0;
+        sm.lock[tid] = 0;
+#pragma unroll
+        for (int w = 0; w < kHmWaves; ++w) sm.pcount[w][tid] = 0;
+        sm.ok[tid] = ok ? 1u : 0u;
+    }
+    if (tid == 0) sm.rescored = 0;
+    __syncthreads();
+    if (n_seed > 0) {
+        for (int qi = wave; qi < n_queries; qi += kHmWaves) {
+            if (sm.ok[qi]) {   // uniform
+                const float cut = hm_seed_cutoff(seed_vals + static_cast<int64_t>(qi) * n_seed, n_seed, topk);
+                if (lane == 0) {
+                    sm.cut[qi] = cut;
+                    reinterpret_cast<uint32_t*>(&sm.bfrag[32 + qi])[2] = hm_threshold_slots(cut);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    int staged = 0;       // wave-uniform
+    int n_rescored = 0;   // wave-uniform (diagnostics)
+    uint2* const stage = sm.stage[wave];
+
+    const bq_f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    auto max3 = [](int x, int y, int z) { return max(max(x, y), z); };
+    auto tree = [&](const bq_f16v& d) {   // max over the 16 results of one MFMA, on the bit patterns (batched.hip.h)
+        auto bits = [&](int i) { return static_cast<int>(__float_as_uint(d[i])); };
+        const int t0 = max3(bits(0), bits(1), bits(2));
+        const int t1 = max3(bits(3), bits(4), bits(5));
+        const int t2 = max3(bits(6), bits(7), bits(8));
+        const int t3 = max3(bits(9), bits(10), bits(11));
+        const int t4 = max3(bits(12), bits(13), bits(14));
+        return max(max3(t0, t1, t2), max3(t3, t4, bits(15)));
+    };
+    // D layout: lane holds column c = lane & 31 (the query) and, in register i, the row that lane
+    // (i & 3) + 8 (i >> 2) + 4 (lane >> 5) of the tile's 32 lanes loaded.  `first_row` = row of the tile's
+    // lane 0, rows of consecutive lanes are 2 apart (a lane holds a pair).
+    const uint32_t n32 = static_cast<uint32_t>(n);   // n <= 2^32 - 2 (mi355rec_create)
+    bool overflow = false;   // wave-uniform: this step's candidates did not fit the staging buffer
+    auto push_hits = [&](const bq_f16v& d, uint32_t first_row, int lane0, uint64_t special) {
+        auto bits = [&](int i) { return static_cast<int>(__float_as_uint(d[i])); };
+#pragma unroll
+        for (int g4 = 0; g4 < 16; g4 += 4) {
+            // four registers at a time first: a tile that holds a hit usually holds one
+            if (!__ballot(max(max(bits(g4), bits(g4 + 1)), max(bits(g4 + 2), bits(g4 + 3))) >= 0)) continue;   // wave-uniform
+#pragma unroll
+            for (int i = g4; i < g4 + 4; ++i) {
+                if (__ballot(bits(i) >= 0)) {   // wave-uniform, rare
+                    // opaque on purpose: otherwise the compiler hoists the row ids of all 16 registers out of
+                    // this rare path into the tile prologue and spills them
+                    uint32_t lr = 4u * static_cast<uint32_t>(hh);
+                    asm volatile("" : "+v"(lr));
+                    lr += static_cast<uint32_t>((i & 3) + 8 * (i >> 2));   // the lane of the tile that loaded the row
+                    const uint32_t row = first_row + 2u * lr;
+                    // out-of-range rows and special rows were zeroed in A (D = -T'): never through this path
+                    const bool hit = bits(i) >= 0 && row < n32 && !((special >> (lane0 + lr)) & 1ull);
+                    const uint64_t who = __ballot(hit);
+                    if (who) {
+                        const int n_hit = __popcll(who);
+                        if (staged + n_hit > kHmStage) {
+                            overflow = true;   // the whole step is redone through the exact chain (hm_exact_step)
+                        } else {
+                            if (hit) stage[staged + lanes_below(who)] = make_uint2(static_cast<uint32_t>(lane & 31), row);
+                            staged += n_hit;
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    for (; step < n_steps; step += total_waves) {
+        const int staged_before = staged;
+        // the fragment is re-read every step (its cutoffs tighten); the barrier keeps the compiler from hoisting it
+        asm volatile("" ::: "memory");
+        const uint4 bw = sm.bfrag[lane];
+        const bq_h8 B = __builtin_bit_cast(bq_h8, bw);
+#pragma unroll
+        for (int u = 0; u < kHmChunks; ++u) {
+            const HalfTile& t = T[u];
+            const uint32_t chunk_row = static_cast<uint32_t>((step * kHmChunks + u) * 128);   // row of lane 0's first row
+#pragma unroll
+            for (int S = 0; S < 2; ++S) {   // the lanes' even rows, then their odd rows
+                uint32_t p0 = S ? t.t1.z : t.t0.x, p1 = S ? t.t1.w : t.t0.y, p2 = S ? t.t2.x : t.t0.z;
+                uint32_t p3 = S ? t.t2.y : t.t0.w, p4 = S ? t.t2.z : t.t1.x, p5 = S ? t.t2.w : t.t1.y;
+                const uint32_t row = chunk_row + 2u * lane + S;
+                const bool in_range = row < n32;
+                const bool is_special = in_range && p0 == kBqNaN2;   // tiny / huge / inf / NaN row: exact chain for every query
+                const bool keep = in_range && !is_special;
+                p0 = keep ? p0 : 0u; p1 = keep ? p1 : 0u; p2 = keep ? p2 : 0u;
+                p3 = keep ? p3 : 0u; p4 = keep ? p4 : 0u; p5 = keep ? p5 : 0u;
+                const uint64_t special = __ballot(is_special);
+                if (special) {   // uniform, rare: one candidate per (special row, query)
+                    uint64_t sp = special;
+                    while (sp) {
+                        const int src = __ffsll(static_cast<long long>(sp)) - 1;
+                        sp &= sp - 1ull;
+                        if (staged + n_queries > kHmStage) {
+                            overflow = true;
+                        } else {
+                            if (lane < n_queries) stage[staged + lane] = make_uint2(static_cast<uint32_t>(lane), chunk_row + 2u * src + S);
+                            staged += n_queries;
+                        }
+                    }
+                }
+                // k = 12, 13 multiply the threshold slots of B by 1.0 for ALL rows; k = 14, 15 are zero
+                const auto s0 = __builtin_amdgcn_permlane32_swap(p0, p4, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(p1, p5, false, false);
+                const auto s2 = __builtin_amdgcn_permlane32_swap(p2, 0x3c003c00u, false, false);
+                const auto s3 = __builtin_amdgcn_permlane32_swap(p3, 0u, false, false);
+                uint4 aw0, aw1;
+                aw0.x = s0[0]; aw0.y = s1[0]; aw0.z = s2[0]; aw0.w = s3[0];   // the rows of lanes  0..31
+                aw1.x = s0[1]; aw1.y = s1[1]; aw1.z = s2[1]; aw1.w = s3[1];   // the rows of lanes 32..63
+                const bq_f16v D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(bq_h8, aw0), B, zero, 0, 0, 0);
+                const bq_f16v D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(bq_h8, aw1), B, zero, 0, 0, 0);
+                const int ma = tree(D0), mb = tree(D1);
+                if (__builtin_expect(__ballot(max(ma, mb) >= 0) != 0ull, 0)) {   // some D >= +0: approx >= T'
+                    if (__ballot(ma >= 0)) push_hits(D0, chunk_row + S, 0, special);
+                    if (__ballot(mb >= 0)) push_hits(D1, chunk_row + 64u + S, 32, special);
+                }
+            }
+            load_chunk(T[u], step + total_waves, u);   // this chunk's registers are free again: the next step's rows
+        }
+        // The buffer is drained when it is half full, so that only a step with more than 128 candidates of
+        // its own can overflow it; such a step forgets what it noted and goes through the exact chain whole.
+        if (__builtin_expect(overflow || staged >= kHmStage / 2, 0)) {   // uniform, rare
+            if (overflow) staged = staged_before;
+            hm_resolve_stage(sm, staged, feats, row_base, topk);
+            n_rescored += staged;
+            staged = 0;
+            if (overflow) {
+                hm_exact_step(sm, feats, n, row_base, step * kHmStepRows, n_queries, topk);
+                n_rescored += kHmStepRows * n_queries;
+                overflow = false;
+            }
+        }
+    }
+    hm_resolve_stage(sm, staged, feats, row_base, topk);
+    n_rescored += staged;
+    if (lane == 0) atomicAdd(&sm.rescored, n_rescored);
+    __syncthreads();
+    if (tid == 0) rescored[bid] += static_cast<unsigned long long>(sm.rescored);   // launches of a handle are stream-ordered
+
+    // ---- every query's best topk of this workgroup, sorted, one wave per query
+    static_assert(kHmWaves * kHmPrivate <= 64, "one lane per private key in the final gather");
+    for (int qi = wave; qi < n_queries; qi += kHmWaves) {
+        int c = __builtin_amdgcn_readfirstlane(sm.nkeys[qi]);   // final: written before the barrier
+        if (c + kHmWaves * kHmPrivate > kHmKeyCap) wave_compact_reg<kHmKeysPerLane>(sm.keys[qi], c, topk, true, sm.hist[wave]);
+        {   // the waves' own lists join the shared one
+            const int w = lane / kHmPrivate, e = lane % kHmPrivate;
+            const bool have = w < kHmWaves && e < sm.pcount[w][qi];   // a count past kHmPrivate: the list is full
+            const uint64_t key = have ? sm.pkeys[w][qi][e] : 0ull;
+            const bool keep = have && key > sm.thr[qi];
+            const uint64_t mk = __ballot(keep);
+            if (keep) sm.keys[qi][c + lanes_below(mk)] = key;
+            c += __popcll(mk);
+        }
+        if (c > topk) wave_compact_reg<kHmKeysPerLane>(sm.keys[qi], c, topk, true, sm.hist[wave]);
+        uint64_t* dst = block_lists + (static_cast<int64_t>(slot0 + qi) * nblocks + bid) * topk;
+        wave_rank_and_store(sm.keys[qi], c, dst, topk);
+    }
+}
+
+}  // namespace mi355

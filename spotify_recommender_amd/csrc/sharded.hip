@@ -136,6 +136,7 @@ struct mi355rec_sharded {
     int64_t* hd_idx = nullptr;          // their device-side addresses
     float* hd_score = nullptr;
     bool peer_rows = true;              // every shard's device can read every other shard's rows
+    bool batched_windows = true;        // mi355rec_sharded_set_window_mode
     std::string note;                   // why a fast path was switched off at create time (diagnostics)
 
     // ---- the stream of single queries -------------------------------------------------
@@ -149,6 +150,14 @@ struct mi355rec_sharded {
     int64_t* s_hdidx = nullptr;
     float* s_hdscore = nullptr;
     Window win[kStreamDepth];
+    // BATCHED windows: where every shard can take a window of queries in multi-query passes over its
+    // replica (mi355rec_batch_pointers_ok), the queries of a window are only collected on the host and go
+    // to every shard in ONE mi355rec_enqueue_batch_mixed_keys call when the window closes: 3 launches per
+    // shard per window instead of one per query, and one pass over the shard per 32 queries.
+    bool s_batched = false;
+    std::vector<float> w_q;             // [kStreamDepth][window][12]
+    std::vector<const float*> w_ptr;    // [kStreamDepth][window]
+    std::vector<int64_t> w_excl;
     int64_t next_ticket = 0;            // tickets handed out so far (window-aligned after a flush)
     int64_t issued_upto = 0;            // every ticket below has had its window's exchange enqueued
     int64_t st_queries = 0, st_exchanges = 0, st_host_ns = 0;
@@ -457,6 +466,13 @@ int stream_alloc(mi355rec_sharded* h, int topn) {
     }
     h->s_topn = topn;
     h->s_alloc_window = h->s_window;
+    h->s_batched = h->s_window >= 2 && h->batched_windows;
+    for (const Shard& s : h->shards)
+        if (s.hi > s.lo && !mi355rec_batch_pointers_ok(s.engine, topn)) h->s_batched = false;
+    const size_t slots = static_cast<size_t>(kStreamDepth) * h->s_window;
+    h->w_q.assign(slots * MI355REC_DIM, 0.0f);
+    h->w_ptr.assign(slots, nullptr);
+    h->w_excl.assign(slots, -1);
     return MI355REC_OK;
 }
 
@@ -523,8 +539,19 @@ int stream_issue_ready(mi355rec_sharded* h, bool all) {
     return MI355REC_OK;
 }
 
+int stream_issue_batched(mi355rec_sharded* h, int w);
+
 int stream_flush(mi355rec_sharded* h) {
     if (!h->s_topn || h->issued_upto >= h->next_ticket) return MI355REC_OK;
+    if (h->s_batched) {   // the open window goes out as it is
+        const int W = h->s_window;
+        const int w = static_cast<int>((h->issued_upto / W) % kStreamDepth);
+        const int rc = stream_issue_batched(h, w);
+        if (rc) return rc;
+        h->next_ticket = (h->next_ticket + W - 1) / W * W;
+        h->issued_upto = h->next_ticket;
+        return MI355REC_OK;
+    }
     for (Shard& s : h->shards) {
         S_HIP(h, hipSetDevice(s.device));
         S_ENG(h, s, mi355rec_enqueue_flush(s.engine, s.stream));
@@ -535,6 +562,29 @@ int stream_flush(mi355rec_sharded* h) {
     h->next_ticket = (h->next_ticket + W - 1) / W * W;   // the next query opens a new window
     h->issued_upto = h->next_ticket;
     return MI355REC_OK;
+}
+
+// A collected window goes to every shard in ONE call (multi-query passes over the replica), then its
+// exchange + merge follow at once: nothing of it is left in any pipeline.
+int stream_issue_batched(mi355rec_sharded* h, int w) {
+    Window& win = h->win[w];
+    if (win.count == 0 || win.issued) return MI355REC_OK;
+    const int g = static_cast<int>(h->shards.size());
+    const int W = h->s_window, topn = h->s_topn;
+    const size_t wk = static_cast<size_t>(W) * topn;
+    const bool rccl = h->transport == MI355REC_TRANSPORT_RCCL;
+    const size_t at = static_cast<size_t>(w) * W;
+    bool any_ptr = false, any_vec = false;
+    for (int i = 0; i < win.count; ++i) (h->w_ptr[at + i] ? any_ptr : any_vec) = true;
+    for (int r = 0; r < g; ++r) {
+        Shard& s = h->shards[r];
+        S_HIP(h, hipSetDevice(s.device));
+        mi355rec_key_t* dst = rccl ? s.s_local + static_cast<size_t>(w) * wk : h->s_gather0 + (static_cast<size_t>(w) * g + r) * wk;
+        S_ENG(h, s, mi355rec_enqueue_batch_mixed_keys(s.engine, any_vec ? &h->w_q[at * MI355REC_DIM] : nullptr,
+                                                      any_ptr ? &h->w_ptr[at] : nullptr, &h->w_excl[at], win.count, topn, dst,
+                                                      s.stream));
+    }
+    return stream_issue(h, w);
 }
 
 int stream_enqueue(mi355rec_sharded* h, const float* qptr, const float* query12, int64_t exclude_global, int topn,
@@ -562,6 +612,22 @@ int stream_enqueue(mi355rec_sharded* h, const float* qptr, const float* query12,
         win.issued = false;
     }
     const size_t wk = static_cast<size_t>(W) * topn;
+    if (h->s_batched) {
+        const size_t at = static_cast<size_t>(w) * W + slot;
+        h->w_ptr[at] = qptr;
+        if (!qptr) std::memcpy(&h->w_q[at * MI355REC_DIM], query12, sizeof(float) * MI355REC_DIM);
+        h->w_excl[at] = exclude_global;
+        ++win.count;
+        ++h->next_ticket;
+        ++h->st_queries;
+        if (ticket) *ticket = t;
+        if (slot == W - 1) {
+            rc = stream_issue_batched(h, w);
+            h->issued_upto = h->next_ticket;
+        }
+        h->st_host_ns += now_ns() - t0;
+        return rc;
+    }
     for (int r = 0; r < g; ++r) {
         Shard& s = h->shards[r];
         S_HIP(h, hipSetDevice(s.device));
@@ -886,6 +952,26 @@ int mi355rec_sharded_set_window(mi355rec_sharded_t* h, int window) {
         w.issued = false;
     }
     h->s_window = window;
+    return MI355REC_OK;
+}
+
+int mi355rec_sharded_set_window_mode(mi355rec_sharded_t* h, int batched) {
+    if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    if ((batched != 0) == h->batched_windows) return MI355REC_OK;
+    DeviceRestore restore;
+    const int rc = stream_flush(h);
+    if (rc) return rc;
+    for (Shard& s : h->shards) {
+        S_HIP(h, hipSetDevice(s.device));
+        S_HIP(h, hipStreamSynchronize(s.stream));
+    }
+    free_stream(h);   // the next enqueue re-makes the buffers and decides the mode again
+    for (Window& w : h->win) {
+        w.abs = -1;
+        w.count = 0;
+        w.issued = false;
+    }
+    h->batched_windows = batched != 0;
     return MI355REC_OK;
 }
 

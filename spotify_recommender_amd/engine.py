@@ -359,6 +359,9 @@ class NodeEngine:
     def set_window(self, window: int) -> None:
         self._check(self._lib.mi355rec_sharded_set_window(self._h, int(window)))
 
+    def set_window_mode(self, batched: bool) -> None:
+        self._check(self._lib.mi355rec_sharded_set_window_mode(self._h, 1 if batched else 0))
+
     def enqueue_row(self, global_row: int, topn: int) -> int:
         t = ctypes.c_int64(-1)
         self._check(self._lib.mi355rec_sharded_enqueue_row(self._h, int(global_row), int(topn), ctypes.byref(t)))

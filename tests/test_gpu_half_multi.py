@@ -1,0 +1,255 @@
+"""Multi-query passes over the fp16 replica (csrc/replica_multi.hip.h, mi355::scan_half_multi_kernel):
+2 ... 32 queries share ONE 24 B/row pass (fp16 matrix-core pre-filter, candidates resolved in the same
+launch); every key is still the exact fp32 chain on the fp32 row.
+Through the C-ABI (mi355rec_query_batch_topn / _enqueue_batch_keys with MI355REC_BATCH_HALF forced, and
+under AUTO where up to 16 queries on a shard with a replica take this path), against the oracle:
+scores bit-exact, ids tie-aware, keys identical to the single-query path.
+
+The hostile cases are the replica scan's own (tests/test_gpu_replica.py): value ranges of the error
+bound's model, special rows and queries, ordered catalogues, duplicates and mass ties (candidate lists
+that fill at every tile boundary and are resolved on the spot), tiny shards.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.parity import assert_topn_matches
+from tests.test_batched_margin import catalogues
+
+pytestmark = pytest.mark.gpu
+
+HALF, AUTO, ON = 3, 0, 2
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.fixture(scope="module")
+def Engine(torch_cuda):
+    from spotify_recommender_amd.engine import CosineEngine
+    return CosineEngine
+
+
+def passes_of(batch):
+    """Passes over the replica one call makes: chains of 36 queries, 32 queries per pass."""
+    total = 0
+    while batch > 0:
+        chain = min(batch, 36)
+        total += (chain + 31) // 32
+        batch -= chain
+    return total
+
+
+def check_batch(eng, f, queries, excl, topn, label, path=HALF, torch=None):
+    eng.set_batch_path(path)
+    queries = np.ascontiguousarray(queries, dtype=np.float32)
+    idx, sc, counts = eng.query_batch_topn(queries, excl, topn)
+    for b in range(len(queries)):
+        want = oracle.scores(f, queries[b], threads=0)
+        ex = int(excl[b]) if excl is not None else -1
+        try:
+            assert_topn_matches(idx[b][:counts[b]], sc[b][:counts[b]], want, ex, topn, ref_idx=oracle.topn_heap(want, ex, topn))
+        except AssertionError as e:
+            raise AssertionError(f"{label}: query {b} of {len(queries)}, topn {topn}: {e}") from e
+    return idx, sc, counts
+
+
+@pytest.mark.parametrize("n", [70_001, 300_001, 2_500_003])
+def test_batches_match_the_oracle_and_the_single_query_path(Engine, torch_cuda, n):
+    torch = torch_cuda
+    from spotify_recommender_amd.engine import unpack_keys
+    rng = np.random.default_rng(n)
+    f = rng.random((n, 12), dtype=np.float32)
+    f[50:60] = f[3]                                        # ties with a query
+    f[n - 2] = f[3]
+    with Engine(f) as eng:
+        assert eng.stats().replica_bytes_per_query > 0
+        before = eng.replica_counters()
+        passes = 0
+        for batch, topn in ((2, 100), (5, 10), (12, 100), (32, 128), (36, 1), (70, 16), (7, 100)):
+            qrows = rng.integers(0, n, size=batch)
+            qrows[0] = 3
+            queries = f[qrows].copy()
+            excl = qrows.astype(np.int64)
+            if batch > 2:
+                queries[2] = rng.random(12, dtype=np.float32)     # an external query, nothing excluded
+                excl[2] = -1
+            idx, sc, counts = check_batch(eng, f, queries, excl, topn, f"n={n}")
+            passes += passes_of(batch)
+            # the asynchronous entry: packed keys, identical to one single-query scan each
+            keys = torch.zeros(batch * topn, dtype=torch.int64, device="cuda")
+            eng.enqueue_batch_keys(queries, excl, topn, keys)
+            passes += passes_of(batch)
+            single = torch.zeros(topn, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            keys = keys.cpu().numpy().reshape(batch, topn)
+            for b in (0, batch // 2, batch - 1):
+                k_rows, k_sc = unpack_keys(keys[b])
+                assert k_rows.tolist() == idx[b][:counts[b]].tolist()
+                eng.enqueue_query_keys(queries[b], int(excl[b]), topn, single)
+                torch.cuda.synchronize()
+                assert np.array_equal(single.cpu().numpy(), keys[b]), (batch, topn, b)
+        after = eng.replica_counters()
+        # every pass went over the replica, and sent a few thousand rows per query to the exact chain — not all, not none
+        extra_single = 3 * 7 if n >= 1_000_000 else 0       # the single-query checks scan the replica too from 1 M rows up
+        assert after["scans"] - before["scans"] == passes + extra_single
+        per_pass = (after["rescored_rows"] - before["rescored_rows"]) / (after["scans"] - before["scans"])
+        assert 1 <= per_pass < 0.05 * n * 32, per_pass
+
+
+def test_up_to_16_queries_take_this_path_under_auto(Engine):
+    rng = np.random.default_rng(5)
+    n = 400_000
+    f = rng.random((n, 12), dtype=np.float32)
+    rows = rng.integers(0, n, size=32)
+    with Engine(f) as eng:
+        for batch in (2, 12, 16):
+            before = eng.replica_counters()["scans"]
+            check_batch(eng, f, f[rows[:batch]], rows[:batch].astype(np.int64), 100, "auto", path=AUTO)
+            assert eng.replica_counters()["scans"] == before + 1      # ONE pass over the replica
+        # 17 and more queries: the two-pass matrix-core path (no replica SCAN is counted)
+        before = eng.replica_counters()["scans"]
+        rows13 = rng.integers(0, n, size=17)
+        check_batch(eng, f, f[rows13], rows13.astype(np.int64), 100, "auto 17", path=AUTO)
+        assert eng.replica_counters()["scans"] == before
+        assert eng.batched_last_counters()["queued_queries"] == 0
+
+
+@pytest.mark.parametrize("which", range(7))
+def test_hostile_value_ranges(Engine, which):
+    rng = np.random.default_rng(200 + which)
+    n = 400_003
+    name, f = list(catalogues(rng, n))[which]
+    f = np.ascontiguousarray(f, dtype=np.float32)
+    queries = np.stack([f[rng.integers(0, n)], f[rng.integers(0, n)] * np.float32(3), rng.random(12, dtype=np.float32),
+                        rng.normal(0, 1, 12).astype(np.float32), np.eye(12, dtype=np.float32)[3],
+                        f[rng.integers(0, n)], -f[rng.integers(0, n)]])
+    with Engine(f) as eng:
+        for topn in (1, 100, 128):
+            check_batch(eng, f, queries, None, topn, name)
+
+
+def test_special_rows_and_queries(Engine):
+    """NaN / inf / denormal / zero / overflowing rows inside and outside the sampled regions, and queries the
+    bound cannot be claimed for (zero, tiny, huge, NaN, inf) in the SAME pass as ordinary ones."""
+    rng = np.random.default_rng(9)
+    n = 600_011
+    f = rng.random((n, 12), dtype=np.float32)
+    regions = min(256, n // 1024)
+    stride = (n // regions) & ~1
+    sampled = np.array([b * stride + o for b in range(0, regions, 5) for o in (0, 1, 127, 128, 600, 1023)])
+    unsampled = np.array([b * stride + o for b in range(2, regions, 7) for o in (1024, 1500, stride - 1)])
+    vals = [np.nan, np.inf, -np.inf, 1e-42, 3e19, -3e19, 0.0]
+    for i, r in enumerate(np.concatenate([sampled, unsampled])):
+        f[r, rng.integers(0, 12)] = vals[i % len(vals)]
+    f[sampled[::4] + 2] = 0.0
+    f[unsampled[::3] + 1] = np.float32(1e-42)
+    f[sampled[::6] + 3] = np.float32(6e-5) * rng.random((len(sampled[::6]), 12), dtype=np.float32)
+    big = np.zeros(12, dtype=np.float32)
+    big[:3] = (3e19, 3e19, -3e19)
+    f[sampled[::9] + 4] = big
+    qrows = rng.choice(n, size=4, replace=False)
+    extra = np.zeros((8, 12), dtype=np.float32)
+    extra[0, :3] = 1e19
+    extra[1] = f[sampled[1]]
+    extra[2] = f[sampled[0]]
+    extra[3] = 0.0
+    extra[4] = rng.random(12, dtype=np.float32) * np.float32(1e-5)
+    extra[5] = rng.random(12, dtype=np.float32) * np.float32(1e-4)
+    extra[6] = -rng.random(12, dtype=np.float32)
+    extra[7] = rng.normal(0, 1, 12).astype(np.float32) * np.float32(1e17)
+    queries = np.concatenate([f[qrows], extra])
+    excl = np.concatenate([qrows.astype(np.int64), np.full(8, -1)])
+    with Engine(f) as eng:
+        for topn in (1, 100):
+            check_batch(eng, f, queries, excl, topn, "special rows / queries")
+        z = int(sampled[0] + 2)                                 # a zero row as a query: every score 0, order by row index
+        check_batch(eng, f, np.stack([f[z], f[7]]), np.array([z, 7]), 50, "zero-row query")
+
+
+@pytest.mark.parametrize("descending", [False, True])
+def test_catalogue_ordered_by_similarity(Engine, descending):
+    rng = np.random.default_rng(10)
+    n = 700_003
+    t = np.linspace(0.0, 1.0, n, dtype=np.float32)
+    if descending:
+        t = t[::-1]
+    f = np.ones((n, 12), dtype=np.float32)
+    f[:, :6] = (0.1 + 0.9 * t)[:, None]
+    f[:, 6:] += rng.random((n, 6), dtype=np.float32) * np.float32(1e-3)
+    q = np.ones((8, 12), dtype=np.float32)
+    q[:, 6:] += rng.random((8, 6), dtype=np.float32) * np.float32(0.02)
+    with Engine(f) as eng:
+        for topn in (1, 100):
+            check_batch(eng, f, q, None, topn, f"ordered desc={descending}")
+
+
+def test_duplicates_mass_ties_and_identical_catalogues(Engine):
+    rng = np.random.default_rng(11)
+    n = 500_009
+    f = rng.random((n, 12), dtype=np.float32)
+    regions = min(256, n // 1024)
+    stride = (n // regions) & ~1
+    qrow = int(rng.integers(0, n))
+    dup = np.concatenate([np.arange(0, regions, 3) * stride + 5, rng.choice(n, 150, replace=False)])
+    f[dup] = f[qrow]                                          # > topn exact duplicates of a query, many of them sampled
+    v = rng.random(12, dtype=np.float32) + np.float32(0.5)
+    tie_rows = rng.choice(np.setdiff1d(np.arange(n), dup), size=5000, replace=False)
+    f[tie_rows] = v[None, :] * (np.float32(2.0) ** rng.integers(-3, 4, size=5000)).astype(np.float32)[:, None]
+    better = rng.choice(np.setdiff1d(np.arange(n), np.concatenate([tie_rows, dup])), size=60, replace=False)
+    tie_query = v + rng.random(12, dtype=np.float32) * np.float32(0.05)
+    f[better] = tie_query[None, :] * (1 + rng.random((60, 12), dtype=np.float32) * np.float32(1e-3))
+    queries = np.stack([tie_query, tie_query * np.float32(2), f[qrow], f[17], v])
+    excl = np.array([-1, -1, qrow, 17, -1])
+    with Engine(f) as eng:
+        for topn in (100, 128, 7):
+            check_batch(eng, f, queries, excl, topn, "mass ties / duplicates")
+    # every row identical: every row ties with every other for every query, every list fills at every tile
+    same = np.tile(np.linspace(0.05, 0.95, 12, dtype=np.float32), (90_000, 1))
+    with Engine(same) as eng:
+        eng.set_batch_path(HALF)
+        idx, sc, counts = eng.query_batch_topn(same[:8], np.arange(8), 64)
+        for b in range(8):
+            assert idx[b].tolist() == [i for i in range(65) if i != b][:64]
+    # ascending scores for every query: the local thresholds keep rising, compaction after compaction
+    n = 120_000
+    t = np.linspace(0.0, 1.0, n, dtype=np.float32)[:, None]
+    f = np.ones((n, 12), dtype=np.float32)
+    f[:, :6] = 1.0 - 0.9 * (1.0 - t)
+    queries = np.ones((32, 12), dtype=np.float32)
+    queries[:, 6:] += np.linspace(0, 0.01, 32, dtype=np.float32)[:, None]
+    with Engine(f) as eng:
+        check_batch(eng, f, queries, None, 100, "ascending")
+
+
+def test_small_shards_row_base_and_fallbacks(Engine):
+    rng = np.random.default_rng(12)
+    # below 65536 rows the path is not taken even when forced (no seedable sample worth a launch): same results
+    for n in (3, 777, 5000, 66_000):
+        f = rng.random((n, 12), dtype=np.float32)
+        with Engine(f) as eng:
+            rows = np.unique(np.array([0, n - 1, n // 2]))
+            check_batch(eng, f, f[rows], rows.astype(np.int64), 10, f"n={n}")
+    n = 300_000
+    f = rng.random((n, 12), dtype=np.float32)
+    lo = 123_457
+    with Engine(f[lo:], row_base=lo) as eng:                  # a shard: keys carry global row ids
+        eng.set_batch_path(HALF)
+        q = rng.random((4, 12), dtype=np.float32)
+        idx, sc, counts = eng.query_batch_topn(q, np.array([lo + 5, -1, lo, n - 1]), 100)
+        for b, ex in enumerate((lo + 5, -1, lo, n - 1)):
+            want = oracle.scores(f, q[b], threads=0)
+            want[:lo] = -2.0
+            assert_topn_matches(idx[b], sc[b], want, ex, 100)
+    # replica switched off: the exact multi-query pass serves the batch
+    f = rng.random((200_000, 12), dtype=np.float32)
+    with Engine(f) as eng:
+        eng.set_replica(1)
+        before = eng.replica_counters()["scans"]
+        rows = rng.integers(0, 200_000, size=6)
+        check_batch(eng, f, f[rows], rows.astype(np.int64), 20, "replica off")
+        assert eng.replica_counters()["scans"] == before

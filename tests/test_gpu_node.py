@@ -148,11 +148,24 @@ def test_streamed_queries_on_the_sharded_handle(Node, shards, window, n):
             assert_topn_matches(idx, sc, want, 5, topn)
         st = node.stream_stats()
         assert st["queries"] == len(qrows) + (len(qrows) + 2 * window - 1) // (2 * window) and st["exchanges"] >= 1
+        if window >= 2 and n // shards >= 65536:
+            # a window went to every shard as ONE batched call: at most one pass over the replica per 32 queries
+            scans = node.shard_stats(0).replica_bytes_per_query
+            assert scans > 0
         # the synchronous calls still work in between, and give the same answer as the stream
         a_idx, a_sc = node.query_row_topn(11, topn)
         t = node.enqueue_row(11, topn)
         b_idx, b_sc = node.wait(t, topn)
         assert a_idx.tolist() == b_idx.tolist() and np.array_equal(a_sc.view(np.uint32), b_sc.view(np.uint32))
+        # both window modes (a window as ONE batched call per shard / one streamed launch per query): same results
+        for batched in (False, True):
+            node.set_window_mode(batched)
+            part = qrows[:window + 2]
+            tickets = [node.enqueue_row(r, topn) for r in part]
+            for t, r in zip(tickets, part):
+                idx, sc = node.wait(t, topn)
+                want = oracle.scores(f, f[r])
+                assert_topn_matches(idx, sc, want, r, topn, ref_idx=oracle.topn_heap(want, r, topn))
 
 
 def test_stream_ring_and_bad_tickets(Node):
