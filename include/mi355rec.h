@@ -246,6 +246,17 @@ int mi355rec_enqueue_batch_keys(mi355rec_t* h, const float* queries,
                                 const int64_t* exclude_global, int batch, int topn,
                                 mi355rec_key_t* out_keys_dev, void* stream);
 
+/* A STREAM OF BATCHES: as mi355rec_enqueue_batch_keys, deferred like the streamed single queries.  On a
+ * shard with a replica (>= 65536 rows, topn <= 128) the stream runs one call behind: call k + 1 LAUNCHES
+ * batch k (groups of up to 32 queries), and that one launch carries, beside its scanners, a merging
+ * workgroup per query of batch k - 1 and a few workgroups that take the sample of batch k + 1 — K batches
+ * cost K launches + one sample launch at the head + one merge launch at the tail (mi355rec_enqueue_flush)
+ * instead of 3 K.  The keys of a batch are complete when the work of the SECOND streamed batch call after it,
+ * or of the flush, has completed; out_keys_dev (batch x topn) must stay valid until then.  Elsewhere the
+ * batch is served at once.  Streams of single queries and of batches on one handle close each other. */
+int mi355rec_enqueue_batch_keys_streamed(mi355rec_t* h, const float* queries, const int64_t* exclude_global,
+                                         int batch, int topn, mi355rec_key_t* out_keys_dev, void* stream);
+
 /* A batch whose queries are vectors (queries[i*12 ..], host) and / or POINTERS to 12 floats in
  * device-readable memory (query_ptrs_dev[i] != NULL wins; either array may be NULL when the other
  * covers every query): what a window of the row-sharded stream hands to every shard.  With a

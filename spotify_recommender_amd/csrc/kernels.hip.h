@@ -1358,6 +1358,22 @@ __global__ __launch_bounds__(kMergeBlock) void merge_kernel(
                out_score_base, out_query_stride, blockIdx.x, blockIdx.x);
 }
 
+// The same merge for a caller that WAITS ON THE HOST (mi355rec_query_row_topn): out_idx / out_score are
+// device-visible addresses of pinned host memory, and after them the workgroup stores `done_value` to
+// *done_word (pinned host memory as well), so the host can poll one word instead of going through
+// hipStreamSynchronize's completion path (~3 us of a 60 us query).
+__global__ __launch_bounds__(kMergeBlock) void merge_notify_kernel(
+    const uint64_t* __restrict__ lists_base, int n_lists, int list_len, int64_t list_stride, int topk,
+    uint64_t* __restrict__ out_keys_base, int64_t* __restrict__ out_idx_base, float* __restrict__ out_score_base,
+    uint32_t* done_word, uint32_t done_value) {
+    __shared__ MergeSmemT<kMergeBlock, kMergeMaxLists, kMergeSurvCap> sm;
+    merge_body(sm, lists_base, n_lists, list_len, list_stride, static_cast<int64_t>(0), topk, out_keys_base, out_idx_base,
+               out_score_base, static_cast<int64_t>(0), static_cast<int64_t>(0), static_cast<int64_t>(0));
+    __threadfence_system();   // every thread: its result stores are ordered before ...
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(done_word, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... the word
+}
+
 // Merge of the lists written by scan_multi_queued_kernel: workgroup b serves the b-th
 // queued query (if there is one) and writes to that query's output row.
 __global__ __launch_bounds__(kMergeBlock) void merge_queued_kernel(

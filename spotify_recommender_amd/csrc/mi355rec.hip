@@ -111,6 +111,22 @@ struct mi355rec {
     uint32_t* d_stream_seed[2] = {nullptr, nullptr};
     int hs_riders = 0;                  // seed riders of a streamed launch
     int hs_scan = 0, hs_iters = 0;      // its scanners and their tiles
+    // a STREAM of batches over the replica (mi355rec_enqueue_batch_keys_streamed)
+    bool mstream_ready = false;
+    uint64_t* d_mstream_lists[2] = {nullptr, nullptr};   // [kHmQueries][hgrid][kMultiMaxTopK], alternating
+    uint32_t* d_mstream_seed[2] = {nullptr, nullptr};    // [kHmQueries][regions * 8] sample maxima, alternating
+    struct MStash {
+        bool has = false;
+        HalfMultiArg arg;
+        int nq = 0, topn = 0;
+        uint64_t* out = nullptr;
+        int seed_buf = 0;
+    } mstash;
+    struct MPending {
+        bool has = false;
+        int buf = 0, nq = 0, topn = 0, n_lists = 0;
+        uint64_t* out = nullptr;
+    } mpending;
     uint32_t* d_seed_vals = nullptr;    // kMultiChain x (mgrid * kSeedWaves) sample maxima
     uint64_t* d_seed_keys = nullptr;    // kMultiChain x kMultiMaxTopK: sample top-k per query of a multi-query chain
 
@@ -131,6 +147,9 @@ struct mi355rec {
     float* h_score = nullptr;   // pinned, mapped
     int64_t* hd_idx = nullptr;  // device-side addresses of the two pinned buffers: small results are
     float* hd_score = nullptr;  // written there by the merge kernel itself (no D2H copy launch)
+    uint32_t* h_done = nullptr;   // pinned, mapped: the completion word of a synchronous single query
+    uint32_t* hd_done = nullptr;
+    uint32_t done_seq = 0;
     float* d_scores_full = nullptr;
 
     // batched path (batched.hip.h): allocated by the first batched call
@@ -489,6 +508,11 @@ int ensure_slots(mi355rec* h, size_t slots) {
     HIP_TRY(h, hipHostMalloc(&h->h_score, cap * sizeof(float), hipHostMallocMapped));
     HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->hd_idx), h->h_idx, 0));
     HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->hd_score), h->h_score, 0));
+    if (!h->h_done) {
+        HIP_TRY(h, hipHostMalloc(&h->h_done, sizeof(uint32_t), hipHostMallocMapped));
+        *h->h_done = 0u;
+        HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->hd_done), h->h_done, 0));
+    }
     h->slot_cap = cap;
     return MI355REC_OK;
 }
@@ -611,11 +635,16 @@ int enqueue_scan(mi355rec* h, const float* qptr, const float* query12,
 }
 
 int enqueue_merge(mi355rec* h, const uint64_t* lists, int n_lists, int list_len, int topn,
-                  uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s) {
+                  uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s, uint32_t notify = 0) {
     const int slot = timing_begin(h, h->ev_merge, h->n_merge_pairs, h->merge_launches, s);
-    hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(kMergeBlock), 0, s, lists, n_lists, list_len,
-                       static_cast<int64_t>(list_len), static_cast<int64_t>(0), topn, out_keys, out_idx, out_score,
-                       static_cast<int64_t>(0));
+    if (notify) {   // the host polls h->h_done for this value (mi355rec_query_row_topn)
+        hipLaunchKernelGGL(merge_notify_kernel, dim3(1), dim3(kMergeBlock), 0, s, lists, n_lists, list_len,
+                           static_cast<int64_t>(list_len), topn, out_keys, out_idx, out_score, h->hd_done, notify);
+    } else {
+        hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(kMergeBlock), 0, s, lists, n_lists, list_len,
+                           static_cast<int64_t>(list_len), static_cast<int64_t>(0), topn, out_keys, out_idx, out_score,
+                           static_cast<int64_t>(0));
+    }
     timing_end(h, h->ev_merge, h->n_merge_pairs, slot, s);
     HIP_TRY(h, hipGetLastError());
     return MI355REC_OK;
@@ -684,29 +713,36 @@ bool half_multi_ok(const mi355rec* h, int topn) {
            h->hseed_grid * kHalfSeedWaves >= topn;
 }
 
+void fill_half_multi_arg(HalfMultiArg& arg, const float* queries, const float* const* qptrs, const int64_t* exclude, int g0,
+                         int nq) {
+    std::memset(&arg, 0, sizeof arg);
+    for (int q = 0; q < kHmQueries; ++q) {
+        arg.exclude[q] = -1;
+        if (q >= nq) continue;
+        if (qptrs && qptrs[g0 + q]) {
+            hm_set_pointer(arg, q, qptrs[g0 + q]);
+        } else if (queries) {
+            std::memcpy(arg.q[q], queries + static_cast<size_t>(g0 + q) * kDim, sizeof(float) * kDim);
+        }
+        if (exclude) arg.exclude[q] = exclude[g0 + q];
+    }
+}
+
 int enqueue_half_multi(mi355rec* h, const float* queries, const float* const* qptrs, const int64_t* exclude, int count,
                        int topn, uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s) {
     const int n_seed = h->hseed_grid * kHalfSeedWaves;
+    HmRide no_ride;
+    std::memset(&no_ride, 0, sizeof no_ride);
+    HalfMultiArg arg;
     for (int g0 = 0; g0 < count; g0 += kHmQueries) {
         const int nq = count - g0 < kHmQueries ? count - g0 : kHmQueries;
-        HalfMultiArg arg;
-        std::memset(&arg, 0, sizeof arg);
-        for (int q = 0; q < kHmQueries; ++q) {
-            arg.exclude[q] = -1;
-            if (q >= nq) continue;
-            if (qptrs && qptrs[g0 + q]) {
-                arg.qptr[q] = qptrs[g0 + q];
-            } else if (queries) {
-                std::memcpy(arg.q[q], queries + static_cast<size_t>(g0 + q) * kDim, sizeof(float) * kDim);
-            }
-            if (exclude) arg.exclude[q] = exclude[g0 + q];
-        }
-        hipLaunchKernelGGL(seed_half_multi_kernel, dim3(h->hseed_grid), dim3(kHalfSeedBlock), 0, s, h->d_half, h->n,
-                           h->hseed_stride, h->row_base, arg, nq, h->d_half_mseed);
+        fill_half_multi_arg(arg, queries, qptrs, exclude, g0, nq);
+        hipLaunchKernelGGL(seed_half_multi_kernel, dim3(h->hseed_grid), dim3(kHmBlock), 0, s, h->d_half, h->n, h->hseed_stride,
+                           arg, nq, h->d_half_mseed);
         ++h->half_scans;
-        LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, scan_half_multi_kernel, dim3(h->hgrid), dim3(kHmBlock), s,
-                     h->d_feats, h->d_half, h->n, h->row_base, arg, nq, g0, topn, h->d_block_lists,
-                     h->d_half_mseed, n_seed, h->d_half_rescored);
+        LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<false>), dim3(h->hgrid),
+                     dim3(kHmBlock), s, h->d_feats, h->d_half, h->n, h->row_base, arg, nq, g0, topn, h->d_block_lists,
+                     h->d_half_mseed, n_seed, h->d_half_rescored, no_ride, arg);
     }
     HIP_TRY(h, hipGetLastError());
     const int slot = timing_begin(h, h->ev_merge, h->n_merge_pairs, h->merge_launches, s);
@@ -715,6 +751,120 @@ int enqueue_half_multi(mi355rec* h, const float* queries, const float* const* qp
                        static_cast<int64_t>(topn));
     timing_end(h, h->ev_merge, h->n_merge_pairs, slot, s);
     HIP_TRY(h, hipGetLastError());
+    return MI355REC_OK;
+}
+
+// ---- a STREAM of batches over the replica (mi355rec_enqueue_batch_keys_streamed) ---------------------
+// The single-query stream's scheme (enqueue_streamed), one level up: the stream runs one call behind —
+// call k + 1 LAUNCHES batch k — and that launch carries, beside its scanners, one merging workgroup per
+// query of batch k - 1 and a few seed riders that take the sample of batch k + 1.  A stream of K batches
+// costs K launches + one sample launch at its head + one merge launch at its tail (the flush).
+constexpr int kHmRiders = 16;   // seed riders of a streamed launch: 16 regions each, one memory round trip per region
+
+int ensure_mstream(mi355rec* h) {
+    if (h->mstream_ready) return MI355REC_OK;
+    const size_t list_bytes = sizeof(uint64_t) * static_cast<size_t>(kHmQueries) * h->hgrid * kMultiMaxTopK;
+    const size_t seed_bytes = sizeof(uint32_t) * static_cast<size_t>(kHmQueries) * kHalfSeedMaxGrid * kHalfSeedWaves;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipMalloc(&h->d_mstream_lists[i], list_bytes);
+        if (e == hipSuccess) e = hipMalloc(&h->d_mstream_seed[i], seed_bytes);
+    }
+    if (e != hipSuccess) {   // all or nothing
+        for (int i = 0; i < 2; ++i) {
+            if (h->d_mstream_lists[i]) (void)hipFree(h->d_mstream_lists[i]);
+            if (h->d_mstream_seed[i]) (void)hipFree(h->d_mstream_seed[i]);
+            h->d_mstream_lists[i] = nullptr;
+            h->d_mstream_seed[i] = nullptr;
+        }
+        return fail(h, e == hipErrorOutOfMemory ? MI355REC_ERR_OUT_OF_MEMORY : MI355REC_ERR_HIP, "hipMalloc(batch stream): %s",
+                    hipGetErrorString(e));
+    }
+    h->mstream_ready = true;
+    return MI355REC_OK;
+}
+
+// Launches the stashed batch: scanners + the mergers of the batch before it + (next != null) the seed
+// riders of the batch after it.
+int launch_mstash(mi355rec* h, hipStream_t s, const HalfMultiArg* next, int next_nq, int next_buf) {
+    auto& st = h->mstash;
+    const int buf = h->mpending.has ? 1 - h->mpending.buf : 0;
+    HmRide ride;
+    std::memset(&ride, 0, sizeof ride);
+    if (h->mpending.has) {
+        ride.prev_lists = h->d_mstream_lists[h->mpending.buf];
+        ride.prev_out = h->mpending.out;
+        ride.prev_queries = h->mpending.nq;
+        ride.prev_n_lists = h->mpending.n_lists;
+        ride.prev_topk = h->mpending.topn;
+    }
+    if (next) {
+        ride.seed_wgs = kHmRiders < h->hseed_grid ? kHmRiders : h->hseed_grid;
+        ride.next_queries = next_nq;
+        ride.regions = h->hseed_grid;
+        ride.stride_rows = h->hseed_stride;
+        ride.next_seed_vals = h->d_mstream_seed[next_buf];
+    }
+    // the launch stays within one resident wave of workgroups: the riders and mergers take scanner slots
+    int scanners = h->hgrid - ride.prev_queries - ride.seed_wgs;
+    if (scanners < 1) scanners = 1;
+    ++h->half_scans;
+    LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<true>),
+                 dim3(scanners + ride.prev_queries + ride.seed_wgs), dim3(kHmBlock), s, h->d_feats, h->d_half, h->n, h->row_base,
+                 st.arg, st.nq, 0, st.topn, h->d_mstream_lists[buf], h->d_mstream_seed[st.seed_buf],
+                 h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, ride, next ? *next : st.arg);
+    HIP_TRY(h, hipGetLastError());
+    h->mpending.has = true;
+    h->mpending.buf = buf;
+    h->mpending.nq = st.nq;
+    h->mpending.topn = st.topn;
+    h->mpending.n_lists = scanners;
+    h->mpending.out = st.out;
+    st.has = false;
+    return MI355REC_OK;
+}
+
+int flush_mstream(mi355rec* h, hipStream_t s) {
+    if (h->mstash.has) {
+        const int rc = launch_mstash(h, s, nullptr, 0, 0);
+        if (rc) return rc;
+    }
+    if (!h->mpending.has) return MI355REC_OK;
+    const auto& p = h->mpending;
+    const int slot = timing_begin(h, h->ev_merge, h->n_merge_pairs, h->merge_launches, s);
+    hipLaunchKernelGGL(merge_kernel, dim3(p.nq), dim3(kMergeBlock), 0, s, h->d_mstream_lists[p.buf], p.n_lists, p.topn,
+                       static_cast<int64_t>(p.topn), static_cast<int64_t>(p.n_lists) * p.topn, p.topn, p.out,
+                       static_cast<int64_t*>(nullptr), static_cast<float*>(nullptr), static_cast<int64_t>(p.topn));
+    timing_end(h, h->ev_merge, h->n_merge_pairs, slot, s);
+    HIP_TRY(h, hipGetLastError());
+    h->mpending.has = false;
+    return MI355REC_OK;
+}
+
+// One batch of <= kHmQueries queries joins the stream.
+int enqueue_mstream(mi355rec* h, const float* queries, const float* const* qptrs, const int64_t* exclude, int g0, int nq, int topn,
+                    uint64_t* out_keys, hipStream_t s) {
+    int rc = ensure_mstream(h);
+    if (rc) return rc;
+    HalfMultiArg arg;
+    fill_half_multi_arg(arg, queries, qptrs, exclude, g0, nq);
+    int seed_buf = 0;
+    if (h->mstash.has) {
+        seed_buf = 1 - h->mstash.seed_buf;
+        rc = launch_mstash(h, s, &arg, nq, seed_buf);   // its riders take THIS batch's sample
+        if (rc) return rc;
+    } else {   // the head of a stream: a sample launch of its own
+        hipLaunchKernelGGL(seed_half_multi_kernel, dim3(h->hseed_grid), dim3(kHmBlock), 0, s, h->d_half, h->n, h->hseed_stride,
+                           arg, nq, h->d_mstream_seed[seed_buf]);
+        HIP_TRY(h, hipGetLastError());
+    }
+    auto& st = h->mstash;
+    st.has = true;
+    st.arg = arg;
+    st.nq = nq;
+    st.topn = topn;
+    st.out = out_keys;
+    st.seed_buf = seed_buf;
     return MI355REC_OK;
 }
 
@@ -730,7 +880,7 @@ int check_topn(mi355rec* h, int topn, bool allow_rounds) {
 // topn is larger (round r only sees keys below the last key of round r-1, read
 // from device memory, so the rounds are enqueued back to back without a sync).
 int enqueue_query(mi355rec* h, const float* qptr, const float* query12, int64_t exclude_global,
-                  int topn_asked, uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s) {
+                  int topn_asked, uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s, uint32_t notify = 0) {
     // A shard of n rows has at most n results (the reference's heap never grows
     // past N-1, Recommender.cu:300): run only the rounds that can produce keys and
     // pad the rest, so an absurd topn costs a memset, not topn/1024 catalogue scans.
@@ -747,11 +897,29 @@ int enqueue_query(mi355rec* h, const float* qptr, const float* query12, int64_t 
         int lists = 0;
         int rc = enqueue_scan(h, qptr, query12, exclude_global, k, upper, s, &lists);
         if (rc) return rc;
+        // (a notifying merge is only asked for single-round queries: it is the last launch of the call)
         rc = enqueue_merge(h, h->d_block_lists, lists, k, k, out_keys + done,
-                           out_idx ? out_idx + done : nullptr, out_score ? out_score + done : nullptr, s);
+                           out_idx ? out_idx + done : nullptr, out_score ? out_score + done : nullptr, s, notify);
         if (rc) return rc;
     }
     return MI355REC_OK;
+}
+
+// Waits for the completion word of a notifying merge (a relaxed spin on pinned host memory); the stream
+// is asked now and then so that a failed launch cannot hang the caller.
+int wait_done(mi355rec* h, uint32_t want) {
+    for (uint64_t spins = 1;; ++spins) {
+        if (__atomic_load_n(h->h_done, __ATOMIC_ACQUIRE) == want) return MI355REC_OK;
+        __builtin_ia32_pause();
+        if ((spins & 0x3ffff) == 0) {   // every ~1 ms
+            const hipError_t e = hipStreamQuery(h->stream);
+            if (e == hipSuccess) {
+                if (__atomic_load_n(h->h_done, __ATOMIC_ACQUIRE) == want) return MI355REC_OK;
+                return fail(h, MI355REC_ERR_HIP, "the query's stream drained without its completion word");
+            }
+            if (e != hipErrorNotReady) return fail(h, MI355REC_ERR_HIP, "hipStreamQuery: %s", hipGetErrorString(e));
+        }
+    }
 }
 
 // ---- streamed single queries -------------------------------------------------------
@@ -856,9 +1024,13 @@ int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, const float* next
     return MI355REC_OK;
 }
 
+int flush_mstream(mi355rec* h, hipStream_t s);
+
 int enqueue_streamed(mi355rec* h, const float* qptr, const float* query12, int64_t exclude_global, int topn,
                      uint64_t* out_keys, hipStream_t s) {
     int rc = ensure_streamed(h);
+    if (rc) return rc;
+    rc = flush_mstream(h, s);   // a stream of BATCHES on this handle is closed first
     if (rc) return rc;
 #ifdef MI355REC_EXPERIMENTS
     static const bool exp_nomerge = std::getenv("MI355REC_EXP_RIDE_NOMERGE") != nullptr;
@@ -1201,6 +1373,10 @@ void mi355rec_destroy(mi355rec_t* h) {
     for (hipEvent_t e : h->ev_scan) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev_merge) (void)hipEventDestroy(e);
     free_bq(h);
+    for (int i = 0; i < 2; ++i) {
+        if (h->d_mstream_lists[i]) (void)hipFree(h->d_mstream_lists[i]);
+        if (h->d_mstream_seed[i]) (void)hipFree(h->d_mstream_seed[i]);
+    }
     for (hipEvent_t e : h->ev_pass) (void)hipEventDestroy(e);
     if (h->owned_feats) (void)hipFree(h->owned_feats);
     if (h->d_block_lists) (void)hipFree(h->d_block_lists);
@@ -1215,6 +1391,7 @@ void mi355rec_destroy(mi355rec_t* h) {
     if (h->d_scores_full) (void)hipFree(h->d_scores_full);
     if (h->h_idx) (void)hipHostFree(h->h_idx);
     if (h->h_score) (void)hipHostFree(h->h_score);
+    if (h->h_done) (void)hipHostFree(h->h_done);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->order_ev) (void)hipEventDestroy(h->order_ev);
     delete h;
@@ -1336,6 +1513,31 @@ int mi355rec_enqueue_query_keys_streamed(mi355rec_t* h, const float* query12, in
     return enqueue_streamed(h, nullptr, query12, exclude_global, topn, out_keys_dev, s);
 }
 
+int mi355rec_enqueue_batch_keys_streamed(mi355rec_t* h, const float* queries, const int64_t* exclude_global, int batch,
+                                         int topn, mi355rec_key_t* out_keys_dev, void* stream) {
+    if (!h || !queries || !out_keys_dev) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (batch < 1) return fail(h, MI355REC_ERR_INVALID_ARG, "batch must be positive");
+    int rc = check_topn(h, topn, true);
+    if (rc) return rc;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = order_stream(h, s);
+    if (rc) return rc;
+    if (!(h->n >= kBqMinRows && half_multi_ok(h, topn)) || h->batch_path == MI355REC_BATCH_MULTI ||
+        h->batch_path == MI355REC_BATCH_MFMA) {
+        // nothing to stream on: the batch is served at once (complete in stream order behind this call)
+        return enqueue_batch(h, queries, exclude_global, batch, topn, out_keys_dev, nullptr, nullptr, s);
+    }
+    rc = flush_streamed(h, s);   // a stream of SINGLE queries on this handle is closed first
+    if (rc) return rc;
+    for (int g0 = 0; g0 < batch; g0 += kHmQueries) {
+        const int nq = batch - g0 < kHmQueries ? batch - g0 : kHmQueries;
+        rc = enqueue_mstream(h, queries, nullptr, exclude_global, g0, nq, topn, out_keys_dev + static_cast<size_t>(g0) * topn, s);
+        if (rc) return rc;
+    }
+    return MI355REC_OK;
+}
+
 // ---- a batch whose queries are partly vectors, partly pointers (the sharded engine's windows) ----
 
 int mi355rec_batch_pointers_ok(const mi355rec_t* h, int topn) {
@@ -1422,9 +1624,11 @@ int mi355rec_enqueue_flush(mi355rec_t* h, void* stream) {
     if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int rc = order_stream(h, s);
+    int rc = order_stream(h, s);
     if (rc) return rc;
-    return flush_streamed(h, s);
+    rc = flush_streamed(h, s);
+    if (rc) return rc;
+    return flush_mstream(h, s);
 }
 
 int mi355rec_enqueue_batch_keys(mi355rec_t* h, const float* queries, const int64_t* exclude_global,
@@ -1541,6 +1745,8 @@ int mi355rec_rebuild_replica(mi355rec_t* h) {
     // A stashed streamed query carries a sample taken from the OLD replica, and the pending one's
     // lists wait for their merge: both are completed first (on the handle's own stream).
     rc = flush_streamed(h, h->stream);
+    if (rc) return rc;
+    rc = flush_mstream(h, h->stream);
     if (rc) return rc;
     return build_replica(h);
 }
@@ -1723,14 +1929,23 @@ int mi355rec_query_row_topn(mi355rec_t* h, int64_t local_row, int topn, int64_t*
     // Small results go straight into the pinned host buffers from the merge kernel
     // (zero-copy stores over PCIe: no D2H copy launches on the latency path).
     const bool direct = eff <= kDirectResultSlots;
+    // one round (eff <= 1024): the merge kernel stores the results AND a completion word in pinned host
+    // memory; the host spins on the word
+    const bool notify = direct && eff <= kMaxTopK && eff > 0;
+    const uint32_t want = notify ? (++h->done_seq ? h->done_seq : ++h->done_seq) : 0u;   // never 0
     rc = enqueue_query(h, h->d_feats + local_row * kDim, nullptr, h->row_base + local_row, eff, h->d_keys, direct ? h->hd_idx : h->d_idx,
-                       direct ? h->hd_score : h->d_score, h->stream);
+                       direct ? h->hd_score : h->d_score, h->stream, want);
     if (rc) return rc;
     if (!direct) {
         HIP_TRY(h, hipMemcpyAsync(h->h_idx, h->d_idx, eff * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipMemcpyAsync(h->h_score, h->d_score, eff * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     }
-    HIP_TRY(h, hipStreamSynchronize(h->stream));   // (polling hipStreamQuery instead was measured: no faster)
+    if (notify) {
+        rc = wait_done(h, want);
+        if (rc) return rc;
+    } else {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
     int c = 0;
     while (c < eff && h->h_idx[c] >= 0) ++c;
     std::memcpy(out_idx, h->h_idx, static_cast<size_t>(eff) * sizeof(int64_t));

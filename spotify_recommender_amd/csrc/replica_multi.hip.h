@@ -58,63 +58,159 @@ constexpr int kHmKeysPerLane = kHmKeyCap / 64;
 static_assert(kMultiMaxTopK + 64 <= kHmKeyCap, "a wave-level append of 64 keys always fits after an exact compaction");
 
 struct HalfMultiArg {
-    float q[kHmQueries][kDim];            // query i by value (used when qptr[i] is null)
-    const float* qptr[kHmQueries];        // ... or where its 12 floats live (a resident row, possibly of another shard)
+    float q[kHmQueries][kDim];            // query i by value — or, when bit i of ptr_mask is set, q[i][0..1] hold a POINTER to
+                                          // its 12 floats (a resident row, possibly of another shard): 48 B per query either way,
+                                          // so that two batches (this one and the next one's sample) fit one kernel's arguments
     long long exclude[kHmQueries];        // global row to skip, -1 = none
+    uint32_t ptr_mask;
+    uint32_t pad;
 };
 
+__host__ __device__ inline void hm_set_pointer(HalfMultiArg& arg, int i, const float* p) {
+    union { const float* p; float f[2]; } u;
+    u.p = p;
+    arg.q[i][0] = u.f[0];
+    arg.q[i][1] = u.f[1];
+    arg.ptr_mask |= 1u << i;
+}
+
 __device__ __forceinline__ void hm_load_query(const HalfMultiArg& arg, int i, float (&q)[kDim]) {
-    if (arg.qptr[i]) {
+    if ((arg.ptr_mask >> i) & 1u) {
+        union { const float* p; float f[2]; } u;
+        u.f[0] = arg.q[i][0];
+        u.f[1] = arg.q[i][1];
 #pragma unroll
-        for (int j = 0; j < kDim; ++j) q[j] = arg.qptr[i][j];
+        for (int j = 0; j < kDim; ++j) q[j] = u.p[j];
     } else {
 #pragma unroll
         for (int j = 0; j < kDim; ++j) q[j] = arg.q[i][j];
     }
 }
 
-// ---- the sample: [query][region * 8 + wave] ordered-u32 approx maxima -----------------------------
-__global__ __launch_bounds__(kHalfSeedBlock) void seed_half_multi_kernel(
-    const uint4* __restrict__ half, int64_t n, int64_t stride_rows, int64_t row_base, HalfMultiArg arg, int n_queries,
-    uint32_t* __restrict__ seed_vals /* [query][gridDim.x * kHalfSeedWaves] */) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_h[kHmQueries][8];   // six fp16 pairs + ok flag per query
-    __shared__ long long s_excl[kHmQueries];
-    const int tid = threadIdx.x;
-    if (tid < n_queries) {
-        float q[kDim];
-        hm_load_query(arg, tid, q);
-        const float qn = query_norm(q);
-        const bool ok = qn >= kBqMinNorm && qn <= kBqMaxNorm;
-        const float inv = ok ? 1.0f / qn : 0.0f;
+// The B operand of one batch in LDS (64 lanes x 4 dwords): lane c: k 0..7 of query c; lane 32 + c: k 8..11, the
+// threshold slots, 0.  `slots`: what real queries start with in k = 12, 13 (0 for the sample: D = approx; +inf
+// for the scan: every row is a candidate until a cutoff is known); a padding column can never hit (-65504).
+// Called by threads 0..31; returns the query (for the caller's own bookkeeping).
+__device__ __forceinline__ bool hm_build_fragment(const HalfMultiArg& arg, int n_queries, int c, uint32_t slots, uint4* bfrag,
+                                                  float (&q)[kDim], float& qn) {
+    if (c < n_queries) {
+        hm_load_query(arg, c, q);
+    } else {
 #pragma unroll
-        for (int p = 0; p < 6; ++p) s_h[tid][p] = ok ? bq_pack_h2(q[2 * p] * inv, q[2 * p + 1] * inv) : 0u;
-        s_h[tid][6] = ok ? 1u : 0u;
-        s_excl[tid] = arg.exclude[tid];
+        for (int j = 0; j < kDim; ++j) q[j] = 0.0f;
+    }
+    qn = query_norm(q);
+    const bool ok = c < n_queries && qn >= kBqMinNorm && qn <= kBqMaxNorm;   // false for NaN
+    const float inv = ok ? 1.0f / qn : 0.0f;
+    uint32_t hp[6];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) hp[p] = ok ? bq_pack_h2(q[2 * p] * inv, q[2 * p + 1] * inv) : 0u;
+    bfrag[c] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+    bfrag[32 + c] = make_uint4(hp[4], hp[5], c < n_queries ? slots : 0x0000fbffu, 0u);
+    return ok;
+}
+
+// The two 32-row A operands of one row set of a chunk (a lane's even rows, S = 0, or its odd rows, S = 1);
+// rows that are out of range or special are zeroed (their D is then -T', resp. 0 in the sample) and reported.
+struct HmTiles {
+    bq_h8 a0, a1;          // the rows of lanes 0..31, of lanes 32..63
+    uint64_t special;      // lanes whose row is special (tiny / huge / inf / NaN: exact chain for every query)
+};
+
+__device__ __forceinline__ HmTiles hm_make_tiles(const HalfTile& t, int S, uint32_t chunk_row, uint32_t n32) {
+    const int lane = threadIdx.x & 63;
+    uint32_t p0 = S ? t.t1.z : t.t0.x, p1 = S ? t.t1.w : t.t0.y, p2 = S ? t.t2.x : t.t0.z;
+    uint32_t p3 = S ? t.t2.y : t.t0.w, p4 = S ? t.t2.z : t.t1.x, p5 = S ? t.t2.w : t.t1.y;
+    const uint32_t row = chunk_row + 2u * lane + S;
+    const bool in_range = row < n32;
+    const bool is_special = in_range && p0 == kBqNaN2;
+    const bool keep = in_range && !is_special;
+    p0 = keep ? p0 : 0u; p1 = keep ? p1 : 0u; p2 = keep ? p2 : 0u;
+    p3 = keep ? p3 : 0u; p4 = keep ? p4 : 0u; p5 = keep ? p5 : 0u;
+    // k = 12, 13 multiply the threshold slots of B by 1.0 for ALL rows; k = 14, 15 are zero
+    const auto s0 = __builtin_amdgcn_permlane32_swap(p0, p4, false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(p1, p5, false, false);
+    const auto s2 = __builtin_amdgcn_permlane32_swap(p2, 0x3c003c00u, false, false);
+    const auto s3 = __builtin_amdgcn_permlane32_swap(p3, 0u, false, false);
+    uint4 aw0, aw1;
+    aw0.x = s0[0]; aw0.y = s1[0]; aw0.z = s2[0]; aw0.w = s3[0];
+    aw1.x = s0[1]; aw1.y = s1[1]; aw1.z = s2[1]; aw1.w = s3[1];
+    HmTiles r;
+    r.a0 = __builtin_bit_cast(bq_h8, aw0);
+    r.a1 = __builtin_bit_cast(bq_h8, aw1);
+    r.special = __ballot(is_special);
+    return r;
+}
+
+__device__ __forceinline__ int hm_tile_max(const bq_f16v& d) {   // max over the 16 results of one MFMA, on the bit patterns
+    auto bits = [&](int i) { return static_cast<int>(__float_as_uint(d[i])); };
+    auto max3 = [](int x, int y, int z) { return max(max(x, y), z); };
+    const int t0 = max3(bits(0), bits(1), bits(2));
+    const int t1 = max3(bits(3), bits(4), bits(5));
+    const int t2 = max3(bits(6), bits(7), bits(8));
+    const int t3 = max3(bits(9), bits(10), bits(11));
+    const int t4 = max3(bits(12), bits(13), bits(14));
+    return max(max3(t0, t1, t2), max3(t3, t4, bits(15)));
+}
+
+// ---- the sample: [query][region * 8 + wave] ordered-u32 approx maxima -----------------------------
+// The sample of replica.hip.h — 1024 rows of up to 256 evenly spaced regions, one maximum per 128-row wave
+// tile — for every query of a batch at once, on the matrix core: one wave = one 128-row chunk = four MFMAs
+// against the batch's B fragment with ZERO threshold slots (D = approx), a max over the 64 results a lane
+// holds for its query column, the two half-waves combined.  Masked rows (special, past the end) contribute an
+// approx of exactly 0 and the query's own row is not masked at all, so only POSITIVE maxima are published
+// (0 = nothing usable) and the cutoff is taken from the (topk + 1)-th largest: topk + 1 tiles with a
+// positive maximum >= v hold topk + 1 distinct genuine rows with approx >= v, at least topk of them not the
+// excluded one.  Workgroup `first`, `first + every`, ... of the regions; called by all 512 threads.
+__device__ __forceinline__ void hm_sample_regions(const uint4* __restrict__ half, int64_t n, int64_t stride_rows, int regions,
+                                                  int first, int every, const uint4* bfrag, int n_queries,
+                                                  uint32_t* __restrict__ seed_vals) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t n_pairs = (n + 1) >> 1;
+    const uint32_t n32 = static_cast<uint32_t>(n);
+    const bq_h8 B = __builtin_bit_cast(bq_h8, bfrag[lane]);
+    const bq_f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const int64_t per_query = static_cast<int64_t>(regions) * kHalfSeedWaves;
+    auto load = [&](HalfTile& t, int g) {
+        int64_t pair = ((static_cast<int64_t>(g) * stride_rows) >> 1) + wave * 64 + lane;
+        pair = pair < n_pairs ? pair : n_pairs - 1;
+        const uint4* p = half + pair * 3;
+        t.t0 = p[0];
+        t.t1 = p[1];
+        t.t2 = p[2];
+    };
+    HalfTile t;
+    if (first < regions) load(t, first);
+    for (int g = first; g < regions; g += every) {
+        const HalfTile cur = t;
+        if (g + every < regions) load(t, g + every);   // the next region's rows are on their way while this one is reduced
+        const uint32_t chunk_row = static_cast<uint32_t>(((static_cast<int64_t>(g) * stride_rows) & ~1ll) + wave * 128);
+        int m = static_cast<int>(0x80000000u);
+#pragma unroll
+        for (int S = 0; S < 2; ++S) {
+            const HmTiles a = hm_make_tiles(cur, S, chunk_row, n32);
+            const bq_f16v D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.a0, B, zero, 0, 0, 0);
+            const bq_f16v D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.a1, B, zero, 0, 0, 0);
+            m = max(m, max(hm_tile_max(D0), hm_tile_max(D1)));
+        }
+        m = max(m, __shfl_xor(m, 32));   // lanes c and 32 + c hold the two row halves of query c
+        // a positive float's bits are a positive int; its ordered image sets the top bit
+        const uint32_t v = m > 0 ? (static_cast<uint32_t>(m) | 0x80000000u) : 0u;
+        if (lane < n_queries) seed_vals[lane * per_query + static_cast<int64_t>(g) * kHalfSeedWaves + wave] = v;
+    }
+}
+
+__global__ __launch_bounds__(kHmBlock) void seed_half_multi_kernel(
+    const uint4* __restrict__ half, int64_t n, int64_t stride_rows, HalfMultiArg arg, int n_queries,
+    uint32_t* __restrict__ seed_vals /* [query][gridDim.x * kHalfSeedWaves] */) {
+    __shared__ uint4 s_b[64];
+    if (threadIdx.x < kHmQueries) {
+        float q[kDim], qn;
+        hm_build_fragment(arg, n_queries, threadIdx.x, 0u, s_b, q, qn);
     }
     __syncthreads();
-    const SeedRegion s = seed_region_load(half, (n + 1) >> 1, stride_rows, blockIdx.x);
-    const int64_t r0 = s.pair * 2;
-    const int64_t per_query = static_cast<int64_t>(gridDim.x) * kHalfSeedWaves;
-    for (int qi = 0; qi < n_queries; ++qi) {
-        const uint4 h03 = *reinterpret_cast<const uint4*>(&s_h[qi][0]);
-        const uint4 h47 = *reinterpret_cast<const uint4*>(&s_h[qi][4]);
-        const uint32_t qh[6] = {h03.x, h03.y, h03.z, h03.w, h47.x, h47.y};
-        const bool ok = h47.z != 0u;
-        const float a0 = half_dot(qh, s.t0.x, s.t0.y, s.t0.z, s.t0.w, s.t1.x, s.t1.y);
-        const float a1 = half_dot(qh, s.t1.z, s.t1.w, s.t2.x, s.t2.y, s.t2.z, s.t2.w);
-        const long long excl = s_excl[qi];
-        // NaN compares false: special rows never seed
-        const bool use0 = s.have && ok && r0 < n && row_base + r0 != excl && a0 >= -2.0f;
-        const bool use1 = s.have && ok && r0 + 1 < n && row_base + r0 + 1 != excl && a1 >= -2.0f;
-        uint32_t v = 0u;
-        if (use0) v = score_to_ordered(a0);
-        if (use1) {
-            const uint32_t w = score_to_ordered(a1);
-            v = w > v ? w : v;
-        }
-        v = wave_max_u32(v);
-        if ((tid & 63) == 0) seed_vals[qi * per_query + static_cast<int64_t>(blockIdx.x) * kHalfSeedWaves + (tid >> 6)] = v;
-    }
+    hm_sample_regions(half, n, stride_rows, gridDim.x, blockIdx.x, gridDim.x, s_b, n_queries, seed_vals);
 }
 
 // ---- shared memory of one scanning workgroup ---------------------------------------------------------
@@ -173,7 +269,7 @@ __device__ __forceinline__ float hm_seed_cutoff(const uint32_t* __restrict__ val
                       __popcll(__ballot(m4 >= mid));
         if (c >= topk) lo = mid; else hi = mid - 1u;
     }
-    if (lo == 0u) return -__builtin_inff();   // fewer than topk usable maxima: no seed
+    if (lo == 0u) return -__builtin_inff();   // fewer than `topk` usable (positive) maxima: no seed
     return ordered_to_score(lo) - 2.0f * kHalfMargin - kBqSlack;
 }
 
@@ -299,18 +395,72 @@ __device__ __forceinline__ void hm_exact_step(HalfMultiSmem& sm, const float* __
     }
 }
 
-// block_lists[(slot0 + query) * gridDim.x + workgroup][topk], each list sorted descending, 0-padded.
+// What else a launch of a STREAM of batches carries beside the scanners (mi355rec_enqueue_batch_keys_streamed):
+// one merging workgroup per query of the PREVIOUS batch (merge_body over that batch's per-workgroup lists, as
+// scan_half_kernel's riding merger) and a few "seed riders" that take the sample of the NEXT batch.
+struct HmRide {
+    const uint64_t* prev_lists;   // [prev_queries][prev_n_lists][prev_topk]
+    uint64_t* prev_out;           // [prev_queries][prev_topk]
+    int prev_queries;             // merging workgroups in this launch (0 = none)
+    int prev_n_lists;
+    int prev_topk;
+    int seed_wgs;                 // seed riders in this launch (0 = none)
+    int next_queries;
+    int regions;
+    long long stride_rows;
+    uint32_t* next_seed_vals;     // [next_queries][regions * 8]
+};
+
+template <bool kRide>
+union HmSmemU {
+    HalfMultiSmem scan;
+    MergeSmemT<kHmBlock, kRideMaxLists, kHalfRideSurvCap> merge;
+};
+
+// block_lists[(slot0 + query) * S + workgroup][topk], each list sorted descending, 0-padded; S = the scanning
+// workgroups = gridDim.x - ride.prev_queries - ride.seed_wgs.
+template <bool kRide>
 __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
     const float* __restrict__ feats, const uint4* __restrict__ half, int64_t n, int64_t row_base, HalfMultiArg arg, int n_queries,
     int slot0, int topk, uint64_t* __restrict__ block_lists, const uint32_t* __restrict__ seed_vals,
-    int n_seed /* sample maxima per query, 0 = none */, unsigned long long* __restrict__ rescored /* [workgroups] */) {
-    __shared__ HalfMultiSmem sm;
+    int n_seed /* sample maxima per query, 0 = none */, unsigned long long* __restrict__ rescored /* [workgroups] */,
+    HmRide ride, HalfMultiArg next) {
+    __shared__ typename std::conditional<kRide, HmSmemU<true>, HalfMultiSmem>::type s_mem;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int hh = lane >> 5;
     const unsigned bid = blockIdx.x;
-    const unsigned nblocks = gridDim.x;
+    unsigned nblocks = gridDim.x;   // scanning workgroups
+    HalfMultiSmem* smp;
+    if constexpr (kRide) {
+        nblocks = gridDim.x - static_cast<unsigned>(ride.prev_queries) - static_cast<unsigned>(ride.seed_wgs);
+        if (bid >= nblocks) {
+            const int extra = static_cast<int>(bid - nblocks);
+            if (extra < ride.prev_queries) {   // the merger of one query of the previous batch
+                merge_body(s_mem.merge, ride.prev_lists, ride.prev_n_lists, ride.prev_topk, static_cast<int64_t>(ride.prev_topk),
+                           static_cast<int64_t>(ride.prev_n_lists) * ride.prev_topk, ride.prev_topk, ride.prev_out,
+                           static_cast<int64_t*>(nullptr), static_cast<float*>(nullptr), static_cast<int64_t>(ride.prev_topk),
+                           static_cast<int64_t>(extra), static_cast<int64_t>(extra));
+            } else {                           // a seed rider: its share of the next batch's sample
+                uint4* const fb = s_mem.scan.bfrag;
+                if (tid < kHmQueries) {
+                    float q[kDim], qn;
+                    hm_build_fragment(next, ride.next_queries, tid, 0u, fb, q, qn);
+                }
+                __syncthreads();
+                hm_sample_regions(half, n, ride.stride_rows, ride.regions, extra - ride.prev_queries, ride.seed_wgs, fb,
+                                  ride.next_queries, ride.next_seed_vals);
+            }
+            return;
+        }
+        smp = &s_mem.scan;
+    } else {
+        (void)ride;
+        (void)next;
+        smp = &s_mem;
+    }
+    HalfMultiSmem& sm = *smp;
 
     const int64_t n_pairs = (n + 1) >> 1;
     const int64_t last_pair = n_pairs - 1;
@@ -331,22 +481,9 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
 
     // ---- per-query state and the B fragment; the cutoffs from the sample while the first loads are in flight
     if (tid < kHmQueries) {
-        float q[kDim];
-        if (tid < n_queries) {
-            hm_load_query(arg, tid, q);
-        } else {
-#pragma unroll
-            for (int j = 0; j < kDim; ++j) q[j] = 0.0f;
-        }
-        const float qn = query_norm(q);
-        const bool ok = tid < n_queries && qn >= kBqMinNorm && qn <= kBqMaxNorm;   // false for NaN
-        const float inv = ok ? 1.0f / qn : 0.0f;
-        uint32_t hp[6];
-#pragma unroll
-        for (int p = 0; p < 6; ++p) hp[p] = ok ? bq_pack_h2(q[2 * p] * inv, q[2 * p + 1] * inv) : 0u;
-        sm.bfrag[tid] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
-        // a real query starts with "every row is a candidate"; a padding column can never hit (-65504)
-        sm.bfrag[32 + tid] = make_uint4(hp[4], hp[5], tid < n_queries ? 0x00007c00u : 0x0000fbffu, 0u);
+        float q[kDim], qn;
+        // a real query starts with "every row is a candidate" (+inf in the threshold slots)
+        const bool ok = hm_build_fragment(arg, n_queries, tid, 0x00007c00u, sm.bfrag, q, qn);
 #pragma unroll
         for (int j = 0; j < kDim; ++j) sm.qf[tid][j] = q[j];
         sm.qn[tid] = qn;
@@ -364,7 +501,8 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
     if (n_seed > 0) {
         for (int qi = wave; qi < n_queries; qi += kHmWaves) {
             if (sm.ok[qi]) {   // uniform
-                const float cut = hm_seed_cutoff(seed_vals + static_cast<int64_t>(qi) * n_seed, n_seed, topk);
+                // the (topk + 1)-th largest: the query's own row may be among the sampled ones (hm_sample_regions)
+                const float cut = hm_seed_cutoff(seed_vals + static_cast<int64_t>(qi) * n_seed, n_seed, topk + 1);
                 if (lane == 0) {
                     sm.cut[qi] = cut;
                     reinterpret_cast<uint32_t*>(&sm.bfrag[32 + qi])[2] = hm_threshold_slots(cut);
@@ -379,21 +517,11 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
     uint2* const stage = sm.stage[wave];
 
     const bq_f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    auto max3 = [](int x, int y, int z) { return max(max(x, y), z); };
-    auto tree = [&](const bq_f16v& d) {   // max over the 16 results of one MFMA, on the bit patterns (batched.hip.h)
-        auto bits = [&](int i) { return static_cast<int>(__float_as_uint(d[i])); };
-        const int t0 = max3(bits(0), bits(1), bits(2));
-        const int t1 = max3(bits(3), bits(4), bits(5));
-        const int t2 = max3(bits(6), bits(7), bits(8));
-        const int t3 = max3(bits(9), bits(10), bits(11));
-        const int t4 = max3(bits(12), bits(13), bits(14));
-        return max(max3(t0, t1, t2), max3(t3, t4, bits(15)));
-    };
+    const uint32_t n32 = static_cast<uint32_t>(n);   // n <= 2^32 - 2 (mi355rec_create)
+    bool overflow = false;   // wave-uniform: this step's candidates did not fit the staging buffer
     // D layout: lane holds column c = lane & 31 (the query) and, in register i, the row that lane
     // (i & 3) + 8 (i >> 2) + 4 (lane >> 5) of the tile's 32 lanes loaded.  `first_row` = row of the tile's
     // lane 0, rows of consecutive lanes are 2 apart (a lane holds a pair).
-    const uint32_t n32 = static_cast<uint32_t>(n);   // n <= 2^32 - 2 (mi355rec_create)
-    bool overflow = false;   // wave-uniform: this step's candidates did not fit the staging buffer
     auto push_hits = [&](const bq_f16v& d, uint32_t first_row, int lane0, uint64_t special) {
         auto bits = [&](int i) { return static_cast<int>(__float_as_uint(d[i])); };
 #pragma unroll
@@ -434,21 +562,12 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
         const bq_h8 B = __builtin_bit_cast(bq_h8, bw);
 #pragma unroll
         for (int u = 0; u < kHmChunks; ++u) {
-            const HalfTile& t = T[u];
             const uint32_t chunk_row = static_cast<uint32_t>((step * kHmChunks + u) * 128);   // row of lane 0's first row
 #pragma unroll
             for (int S = 0; S < 2; ++S) {   // the lanes' even rows, then their odd rows
-                uint32_t p0 = S ? t.t1.z : t.t0.x, p1 = S ? t.t1.w : t.t0.y, p2 = S ? t.t2.x : t.t0.z;
-                uint32_t p3 = S ? t.t2.y : t.t0.w, p4 = S ? t.t2.z : t.t1.x, p5 = S ? t.t2.w : t.t1.y;
-                const uint32_t row = chunk_row + 2u * lane + S;
-                const bool in_range = row < n32;
-                const bool is_special = in_range && p0 == kBqNaN2;   // tiny / huge / inf / NaN row: exact chain for every query
-                const bool keep = in_range && !is_special;
-                p0 = keep ? p0 : 0u; p1 = keep ? p1 : 0u; p2 = keep ? p2 : 0u;
-                p3 = keep ? p3 : 0u; p4 = keep ? p4 : 0u; p5 = keep ? p5 : 0u;
-                const uint64_t special = __ballot(is_special);
-                if (special) {   // uniform, rare: one candidate per (special row, query)
-                    uint64_t sp = special;
+                const HmTiles a = hm_make_tiles(T[u], S, chunk_row, n32);
+                if (a.special) {   // uniform, rare: one candidate per (special row, query)
+                    uint64_t sp = a.special;
                     while (sp) {
                         const int src = __ffsll(static_cast<long long>(sp)) - 1;
                         sp &= sp - 1ull;
@@ -460,25 +579,17 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
                         }
                     }
                 }
-                // k = 12, 13 multiply the threshold slots of B by 1.0 for ALL rows; k = 14, 15 are zero
-                const auto s0 = __builtin_amdgcn_permlane32_swap(p0, p4, false, false);
-                const auto s1 = __builtin_amdgcn_permlane32_swap(p1, p5, false, false);
-                const auto s2 = __builtin_amdgcn_permlane32_swap(p2, 0x3c003c00u, false, false);
-                const auto s3 = __builtin_amdgcn_permlane32_swap(p3, 0u, false, false);
-                uint4 aw0, aw1;
-                aw0.x = s0[0]; aw0.y = s1[0]; aw0.z = s2[0]; aw0.w = s3[0];   // the rows of lanes  0..31
-                aw1.x = s0[1]; aw1.y = s1[1]; aw1.z = s2[1]; aw1.w = s3[1];   // the rows of lanes 32..63
-                const bq_f16v D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(bq_h8, aw0), B, zero, 0, 0, 0);
-                const bq_f16v D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(bq_h8, aw1), B, zero, 0, 0, 0);
-                const int ma = tree(D0), mb = tree(D1);
+                const bq_f16v D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.a0, B, zero, 0, 0, 0);
+                const bq_f16v D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.a1, B, zero, 0, 0, 0);
+                const int ma = hm_tile_max(D0), mb = hm_tile_max(D1);
                 if (__builtin_expect(__ballot(max(ma, mb) >= 0) != 0ull, 0)) {   // some D >= +0: approx >= T'
-                    if (__ballot(ma >= 0)) push_hits(D0, chunk_row + S, 0, special);
-                    if (__ballot(mb >= 0)) push_hits(D1, chunk_row + 64u + S, 32, special);
+                    if (__ballot(ma >= 0)) push_hits(D0, chunk_row + S, 0, a.special);
+                    if (__ballot(mb >= 0)) push_hits(D1, chunk_row + 64u + S, 32, a.special);
                 }
             }
             load_chunk(T[u], step + total_waves, u);   // this chunk's registers are free again: the next step's rows
         }
-        // The buffer is drained when it is half full, so that only a step with more than 128 candidates of
+        // The buffer is drained when it is half full, so that only a step with more than 64 candidates of
         // its own can overflow it; such a step forgets what it noted and goes through the exact chain whole.
         if (__builtin_expect(overflow || staged >= kHmStage / 2, 0)) {   // uniform, rare
             if (overflow) staged = staged_before;

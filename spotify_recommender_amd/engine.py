@@ -182,6 +182,17 @@ class CosineEngine:
             excl.ctypes.data_as(ctypes.c_void_p) if excl is not None else None, q.shape[0], int(topn),
             ctypes.c_void_p(out_keys.data_ptr()), self._stream_ptr(stream)), self._h)
 
+    def enqueue_batch_keys_streamed(self, queries, exclude_global, topn: int, out_keys, stream=None) -> None:
+        """A stream of batches: complete after the second streamed batch call behind it, or after enqueue_flush."""
+        q = _np_f32(queries).reshape(-1, capi.DIM)
+        excl = None
+        if exclude_global is not None:
+            excl = np.ascontiguousarray(np.asarray(exclude_global, dtype=np.int64).reshape(q.shape[0]))
+        capi.check(self._lib.mi355rec_enqueue_batch_keys_streamed(
+            self._h, q.ctypes.data_as(ctypes.c_void_p),
+            excl.ctypes.data_as(ctypes.c_void_p) if excl is not None else None, q.shape[0], int(topn),
+            ctypes.c_void_p(out_keys.data_ptr()), self._stream_ptr(stream)), self._h)
+
     def enqueue_batch_keys_dev(self, queries_dev, exclude_dev, topn: int, out_keys, stream=None) -> None:
         """Batched matrix-core path over queries already in device memory
         (float32 [batch, 12] tensor; exclude_dev int64 [batch] tensor or None)."""

@@ -253,3 +253,70 @@ def test_small_shards_row_base_and_fallbacks(Engine):
         rows = rng.integers(0, 200_000, size=6)
         check_batch(eng, f, f[rows], rows.astype(np.int64), 20, "replica off")
         assert eng.replica_counters()["scans"] == before
+
+
+def test_a_stream_of_batches(Engine, torch_cuda):
+    """mi355rec_enqueue_batch_keys_streamed: call k + 1 launches batch k together with the mergers of batch
+    k - 1 and the seed riders of batch k + 1; the flush closes the stream.  Batches of every size (more than
+    32 queries = several groups), different topn in one stream, single streamed queries in between (the two
+    kinds of stream close each other), a rebuild of the replica in the middle: every key list vs the oracle."""
+    torch = torch_cuda
+    from spotify_recommender_amd.engine import unpack_keys
+    rng = np.random.default_rng(77)
+    n = 1_200_001
+    f = rng.random((n, 12), dtype=np.float32)
+    f[70:75] = f[9]
+    plan = [(12, 100), (32, 100), (1, 10), (40, 16), (7, 128), (2, 100), (12, 100), (12, 100)]
+    outs, meta = [], []
+    with Engine(f) as eng:
+        for step, (batch, topn) in enumerate(plan):
+            qrows = rng.integers(0, n, size=batch)
+            qrows[0] = 9
+            queries = f[qrows].copy()
+            excl = qrows.astype(np.int64)
+            if batch > 2:
+                queries[1] = rng.random(12, dtype=np.float32)
+                excl[1] = -1
+            keys = torch.zeros(batch * topn, dtype=torch.int64, device="cuda")
+            eng.enqueue_batch_keys_streamed(queries, excl, topn, keys)
+            outs.append(keys)
+            meta.append((queries, excl, topn))
+            if step == 3:      # a streamed SINGLE query in the middle: closes the batch stream, and is closed by the next batch
+                single = torch.zeros(50, dtype=torch.int64, device="cuda")
+                eng.enqueue_row_keys_streamed(123, 50, single)
+            if step == 5:
+                eng.rebuild_replica()          # completes everything that is in flight first
+        eng.enqueue_flush()
+        torch.cuda.synchronize()
+        for keys, (queries, excl, topn) in zip(outs, meta):
+            got = keys.cpu().numpy().reshape(len(queries), topn)
+            for b in range(len(queries)):
+                want = oracle.scores(f, queries[b], threads=0)
+                idx, sc = unpack_keys(got[b])
+                assert_topn_matches(idx, sc, want, int(excl[b]), topn, ref_idx=oracle.topn_heap(want, int(excl[b]), topn))
+        want = oracle.scores(f, f[123], threads=0)
+        idx, sc = unpack_keys(single.cpu().numpy())
+        assert_topn_matches(idx, sc, want, 123, 50, ref_idx=oracle.topn_heap(want, 123, 50))
+        # a flush with nothing pending is a no-op; a stream of one batch works
+        eng.enqueue_flush()
+        keys = torch.zeros(3 * 20, dtype=torch.int64, device="cuda")
+        eng.enqueue_batch_keys_streamed(f[[5, 6, 7]], np.array([5, 6, 7]), 20, keys)
+        eng.enqueue_flush()
+        torch.cuda.synchronize()
+        got = keys.cpu().numpy().reshape(3, 20)
+        for b, r in enumerate((5, 6, 7)):
+            want = oracle.scores(f, f[r], threads=0)
+            idx, sc = unpack_keys(got[b])
+            assert_topn_matches(idx, sc, want, r, 20, ref_idx=oracle.topn_heap(want, r, 20))
+    # a shard without a replica: the streamed entry serves the batch at once
+    small = rng.random((30_000, 12), dtype=np.float32)
+    with Engine(small) as eng:
+        keys = torch.zeros(4 * 10, dtype=torch.int64, device="cuda")
+        eng.enqueue_batch_keys_streamed(small[[1, 2, 3, 4]], np.array([1, 2, 3, 4]), 10, keys)
+        eng.enqueue_flush()
+        torch.cuda.synchronize()
+        got = keys.cpu().numpy().reshape(4, 10)
+        for b, r in enumerate((1, 2, 3, 4)):
+            want = oracle.scores(small, small[r], threads=0)
+            idx, sc = unpack_keys(got[b])
+            assert_topn_matches(idx, sc, want, r, 10, ref_idx=oracle.topn_heap(want, r, 10))

@@ -1,0 +1,65 @@
+"""The drop-in boundary, kept true by a test: the REFERENCE's own main.cpp — the sole caller of the
+interface this build replaces (main.cpp:59-82: Recommender::initialize / recommend / recommendByName,
+DataManager::preprocessData / loadData, Song) — compiles against include/ and links against
+Recommender.cpp + DataManager.cpp + libmi355rec.so with exactly the command INTEGRATION.md §A gives.
+
+Build container only: skipped where /root/reference does not exist (the GPU box).  The reference file is
+copied to a pytest temp directory for the compile (quoted includes look next to the including file first,
+and next to the original lie the reference's own headers); nothing of it is ever stored in the repository.  Without a GPU the binary's query
+modes fail loudly (no CPU fallback), which is what the second half checks."""
+import shutil
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+REF_MAIN = Path("/root/reference/main.cpp")
+PKG = ROOT / "spotify_recommender_amd"
+
+pytestmark = pytest.mark.skipif(not REF_MAIN.exists(), reason="the reference tree is only present in the build container")
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory, engine_lib):
+    d = tmp_path_factory.mktemp("refmain")
+    out = d / "recommender_ref_main"
+    main_cpp = d / "main.cpp"
+    shutil.copyfile(REF_MAIN, main_cpp)
+    # INTEGRATION.md §A, verbatim up to the paths
+    cmd = ["g++", "-std=c++17", "-O2", f"-I{ROOT / 'include'}", str(main_cpp),
+           str(PKG / "csrc" / "Recommender.cpp"), str(PKG / "csrc" / "DataManager.cpp"),
+           f"-L{PKG}", "-lmi355rec", f"-Wl,-rpath,{PKG}", "-fopenmp", "-o", str(out)]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, "the reference's main.cpp no longer builds against include/:\n" + p.stderr[-3000:]
+    return str(out)
+
+
+def test_only_the_repo_headers_are_used(tmp_path):
+    """-H lists every header the translation unit opens: the three project headers must be the repo's."""
+    main_cpp = tmp_path / "main.cpp"
+    shutil.copyfile(REF_MAIN, main_cpp)
+    p = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-H", f"-I{ROOT / 'include'}", str(main_cpp)],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    opened = [l.lstrip(". ").strip() for l in p.stderr.splitlines() if l.startswith(".")]
+    for name in ("Song.h", "DataManager.h", "Recommender.h"):
+        hits = [h for h in opened if h.endswith("/" + name)]
+        assert hits and all(h.startswith(str(ROOT / "include")) for h in hits), (name, hits)
+
+
+def test_reference_main_runs_against_the_library(exe, golden_dir, tmp_path):
+    # usage path
+    p = subprocess.run([exe], capture_output=True, text=True, cwd=tmp_path)
+    assert p.returncode == 1 and "--preprocess" in (p.stdout + p.stderr)
+    # --preprocess goes through OUR DataManager and writes the byte-identical songs_data.bin
+    p = subprocess.run([exe, "--preprocess", str(golden_dir / "sample_songs.csv")], capture_output=True, text=True, cwd=tmp_path)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert (tmp_path / "songs_data.bin").read_bytes() == (golden_dir / "sample_songs_data.bin").read_bytes()
+    # a query: with a GPU it answers; without one it fails loudly (documented deviation: no CPU fallback)
+    p = subprocess.run([exe, "--id", "dupA", "-n", "10"], capture_output=True, text=True, cwd=tmp_path)
+    import torch
+    if torch.cuda.is_available():
+        assert p.returncode == 0 and "Top 3" in p.stdout, p.stdout + p.stderr
+    else:
+        assert p.returncode == 1 and "no CPU fallback" in p.stderr, p.stdout + p.stderr

@@ -31,3 +31,23 @@ with CosineEngine(t) as eng:
             a = eng.replica_counters()
             print(f"topn {topn} nq {nb}: {dt*1e6:.1f} us/call, scan kernel {st.last_scan_ms*1e3:.1f} us, merge {st.last_merge_ms*1e3:.1f} us, "
                   f"rescored/pass {(a['rescored_rows']-b['rescored_rows'])/20:.0f} = {(a['rescored_rows']-b['rescored_rows'])/20/nb:.0f} per query", flush=True)
+
+    # a stream of batches: launches per batch 1 (+ head sample, tail merge)
+    for topn in (100, 10):
+        for nb in (2, 12, 32):
+            ring = [torch.zeros(nb * topn, dtype=torch.int64, device="cuda") for _ in range(4)]
+            ex = np.array(rows[:nb], dtype=np.int64)
+            for k in range(6):
+                eng.enqueue_batch_keys_streamed(q[:nb], ex, topn, ring[k % 4])
+            eng.enqueue_flush()
+            torch.cuda.synchronize()
+            eng.set_timing(1)
+            t0 = time.perf_counter()
+            for k in range(40):
+                eng.enqueue_batch_keys_streamed(q[:nb], ex, topn, ring[k % 4])
+            eng.enqueue_flush()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 40
+            st = eng.stats()
+            eng.set_timing(0)
+            print(f"STREAMED topn {topn} nq {nb}: {dt*1e6:.1f} us/call = {nb/dt:.0f} q/s, scan kernel {st.last_scan_ms*1e3:.1f} us", flush=True)
