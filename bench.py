@@ -599,50 +599,66 @@ def main():
     # queries); the exact 12-query pass (mi355::scan_multi_kernel) is timed beside it.
     micro = None
     if topn <= 128:
-        def batch_leg(nb, calls, path):
+        def batch_leg(nb, calls, path, streamed_batches=False):
             b_rows = np.array(q_rows[:nb], dtype=np.int64)
-            b_keys = torch.zeros(nb * topn, dtype=torch.int64, device=dev)
+            rings = [torch.zeros(nb * topn, dtype=torch.int64, device=dev) for _ in range(4)]
             eng.set_batch_path(path)
+            state = {"k": 0}
 
             def batch_step():
+                b_keys = rings[state["k"] % 4]
+                state["k"] += 1
                 if sharded is None:
-                    eng.enqueue_batch_keys(q_vecs[:nb], b_rows, topn, b_keys)
+                    if streamed_batches:
+                        eng.enqueue_batch_keys_streamed(q_vecs[:nb], b_rows, topn, b_keys)
+                    else:
+                        eng.enqueue_batch_keys(q_vecs[:nb], b_rows, topn, b_keys)
                 else:
                     sharded.enqueue_batch(q_vecs[:nb], b_rows, topn)
 
-            dt = timed(batch_step, calls)
+            # the flush of a stream of batches is inside the timed region
+            def run():
+                for _ in range(calls):
+                    batch_step()
+                if streamed_batches:
+                    eng.enqueue_flush()
+
+            dt = timed(run, 1) / calls
             eng.set_batch_path(capi.BATCH_AUTO)
-            return dt, b_keys
+            return dt, rings[(state["k"] - 1) % 4]
 
         nb = 12 if sharded is None else 72
-        dt, b_keys = batch_leg(nb, 30 if sharded is None else 6, capi.BATCH_AUTO)
+        stream_ok = replica and sharded is None
+        dt, b_keys = batch_leg(nb, 30 if sharded is None else 6, capi.BATCH_AUTO, stream_ok)
         micro = {"queries_per_call": nb, "value": round(nb / dt, 1), "unit": "queries/s",
                  "ms_per_call": round(dt * 1e3, 5),
-                 "note": ("one call = ONE multi-query pass over the fp16 replica (mi355::scan_half_multi_kernel: sample launch + "
-                          "24 B/row pass with an fp16 matrix-core pre-filter for up to 32 queries + one merge launch)"
-                          if (replica and sharded is None) else
+                 "note": ("a STREAM of 12-query batches (mi355rec_enqueue_batch_keys_streamed, the flush inside the timed "
+                          "region): one launch per batch = one 24 B/row pass over the fp16 replica with an fp16 matrix-core "
+                          "pre-filter (mi355::scan_half_multi_kernel<true>), the previous batch's merges and the next batch's "
+                          "sample riding in it"
+                          if stream_ok else
                           "one call = the path mi355rec_enqueue_batch_keys picks for this batch size; "
                           + ("single GPU" if sharded is None else "one all-gather per call"))}
-        if replica and sharded is None:
-            st_m = None
+        if stream_ok:
             eng.set_timing(1)
-            dt12, _ = batch_leg(12, 20, capi.BATCH_AUTO)
+            dt12, _ = batch_leg(12, 20, capi.BATCH_AUTO, True)
             st_m = eng.stats()
             eng.set_timing(False)
             k_ms = float(st_m.last_scan_ms)
             alg12 = int(st_m.replica_bytes_per_query)
-            micro["roofline"] = {"bound": "hbm", "kernel": "mi355::scan_half_multi_kernel (up to 32 queries per 24 B/row pass)",
+            micro["roofline"] = {"bound": "hbm", "kernel": "mi355::scan_half_multi_kernel<true> (up to 32 queries per 24 B/row pass)",
                                  "algorithmic_bytes_per_launch": alg12, "avg_kernel_ms": round(k_ms, 5),
                                  "achieved": round(alg12 / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None, "peak": HBM_PEAK_GBPS,
-                                 "unit": "GB/s", "frac": round(alg12 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if k_ms > 0 else None,
-                                 "merge_kernel_ms": round(float(st_m.last_merge_ms), 5)}
-            dt2, _ = batch_leg(2, 30, capi.BATCH_AUTO)
-            micro["two_queries"] = {"ms_per_call": round(dt2 * 1e3, 5), "value": round(2 / dt2, 1), "unit": "queries/s"}
-            dt32, _ = batch_leg(32, 20, capi.BATCH_AUTO)
-            micro["thirty_two_queries"] = {"ms_per_call": round(dt32 * 1e3, 5), "value": round(32 / dt32, 1), "unit": "queries/s"}
-            dtm, _ = batch_leg(12, 20, capi.BATCH_MFMA)
-            micro["matrix_core_path_12"] = {"ms_per_call": round(dtm * 1e3, 5), "value": round(12 / dtm, 1), "unit": "queries/s",
-                                            "note": "the same 12 queries forced through the batched fp16-MFMA path (round 2's route)"}
+                                 "unit": "GB/s", "frac": round(alg12 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if k_ms > 0 else None}
+            for name, nq in (("two_queries", 2), ("thirty_two_queries", 32)):
+                d, _ = batch_leg(nq, 20, capi.BATCH_AUTO, True)
+                micro[name] = {"ms_per_call": round(d * 1e3, 5), "value": round(nq / d, 1), "unit": "queries/s"}
+            d, _ = batch_leg(12, 20, capi.BATCH_AUTO, False)
+            micro["single_call_12"] = {"ms_per_call": round(d * 1e3, 5), "value": round(12 / d, 1), "unit": "queries/s",
+                                       "note": "one batch alone (mi355rec_enqueue_batch_keys): sample launch + pass + merge launch"}
+            d, _ = batch_leg(12, 20, capi.BATCH_MFMA, False)
+            micro["two_pass_matrix_core_path_12"] = {"ms_per_call": round(d * 1e3, 5), "value": round(12 / d, 1), "unit": "queries/s",
+                                                     "note": "the same 12 queries forced through the two-pass batched path (round 2's route)"}
         if sharded is None:
             eng.enqueue_row_keys(q_rows[0], topn, out_keys)
         else:

@@ -267,6 +267,10 @@ int mi355rec_batch_pointers_ok(const mi355rec_t* h, int topn);
 int mi355rec_enqueue_batch_mixed_keys(mi355rec_t* h, const float* queries, const float* const* query_ptrs_dev,
                                       const int64_t* exclude_global, int batch, int topn,
                                       mi355rec_key_t* out_keys_dev, void* stream);
+/* ... and as a stream of batches (mi355rec_enqueue_batch_keys_streamed's deferred completion). */
+int mi355rec_enqueue_batch_mixed_keys_streamed(mi355rec_t* h, const float* queries, const float* const* query_ptrs_dev,
+                                               const int64_t* exclude_global, int batch, int topn,
+                                               mi355rec_key_t* out_keys_dev, void* stream);
 
 /* The same for queries that are ALREADY in device memory (batch x 12 floats;
  * exclude_global_dev = batch int64 global row ids or NULL): always the batched

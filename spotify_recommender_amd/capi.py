@@ -70,6 +70,7 @@ SIGNATURES = {
     "mi355rec_enqueue_batch_keys_streamed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mi355rec_batch_pointers_ok": (c_int, [c_void_p, c_int]),
     "mi355rec_enqueue_batch_mixed_keys": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "mi355rec_enqueue_batch_mixed_keys_streamed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mi355rec_enqueue_batch_keys_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mi355rec_set_batch_path": (c_int, [c_void_p, c_int]),
     "mi355rec_set_replica": (c_int, [c_void_p, c_int]),

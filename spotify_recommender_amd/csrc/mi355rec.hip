@@ -1515,24 +1515,33 @@ int mi355rec_enqueue_query_keys_streamed(mi355rec_t* h, const float* query12, in
 
 int mi355rec_enqueue_batch_keys_streamed(mi355rec_t* h, const float* queries, const int64_t* exclude_global, int batch,
                                          int topn, mi355rec_key_t* out_keys_dev, void* stream) {
-    if (!h || !queries || !out_keys_dev) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (!queries) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    return mi355rec_enqueue_batch_mixed_keys_streamed(h, queries, nullptr, exclude_global, batch, topn, out_keys_dev, stream);
+}
+
+int mi355rec_enqueue_batch_mixed_keys_streamed(mi355rec_t* h, const float* queries, const float* const* query_ptrs_dev,
+                                               const int64_t* exclude_global, int batch, int topn,
+                                               mi355rec_key_t* out_keys_dev, void* stream) {
+    if (!h || !out_keys_dev || (!queries && !query_ptrs_dev)) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
     if (batch < 1) return fail(h, MI355REC_ERR_INVALID_ARG, "batch must be positive");
-    int rc = check_topn(h, topn, true);
+    const bool streamable = h->n >= kBqMinRows && half_multi_ok(h, topn) && h->batch_path != MI355REC_BATCH_MULTI &&
+                            h->batch_path != MI355REC_BATCH_MFMA;
+    if (!streamable) {
+        // nothing to stream on: the batch is served at once (complete in stream order behind this call)
+        if (query_ptrs_dev) return mi355rec_enqueue_batch_mixed_keys(h, queries, query_ptrs_dev, exclude_global, batch, topn, out_keys_dev, stream);
+        return mi355rec_enqueue_batch_keys(h, queries, exclude_global, batch, topn, out_keys_dev, stream);
+    }
+    int rc = check_topn(h, topn, false);
     if (rc) return rc;
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     rc = order_stream(h, s);
     if (rc) return rc;
-    if (!(h->n >= kBqMinRows && half_multi_ok(h, topn)) || h->batch_path == MI355REC_BATCH_MULTI ||
-        h->batch_path == MI355REC_BATCH_MFMA) {
-        // nothing to stream on: the batch is served at once (complete in stream order behind this call)
-        return enqueue_batch(h, queries, exclude_global, batch, topn, out_keys_dev, nullptr, nullptr, s);
-    }
     rc = flush_streamed(h, s);   // a stream of SINGLE queries on this handle is closed first
     if (rc) return rc;
     for (int g0 = 0; g0 < batch; g0 += kHmQueries) {
         const int nq = batch - g0 < kHmQueries ? batch - g0 : kHmQueries;
-        rc = enqueue_mstream(h, queries, nullptr, exclude_global, g0, nq, topn, out_keys_dev + static_cast<size_t>(g0) * topn, s);
+        rc = enqueue_mstream(h, queries, query_ptrs_dev, exclude_global, g0, nq, topn, out_keys_dev + static_cast<size_t>(g0) * topn, s);
         if (rc) return rc;
     }
     return MI355REC_OK;

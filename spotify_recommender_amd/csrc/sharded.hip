@@ -28,6 +28,13 @@
 //   * the STREAM (mi355rec_sharded_enqueue_* / _flush / _wait): a serving loop.  One streamed
 //     scan launch per shard per query, one exchange + one batched merge per WINDOW of
 //     queries, tickets instead of host waits.
+// Host threads.  With more than one shard every shard has a WORKER thread that owns its device context,
+// its stream and its single-device handle: the caller's thread only posts small task records (a
+// single-producer ring per worker) and the workers issue the HIP launches in parallel — one launch per
+// shard per query costs the caller ~0.1 us instead of G x ~5 us, and a synchronous query on G GPUs pays
+// one shard's launch chain, not G of them.  Cross-shard ordering stays on the device (one event per shard,
+// or the collective); the only host-side hand-off is "shard r has RECORDED its event" before the first
+// device's worker makes its stream wait for it.  With one shard there are no threads at all.
 // A query by ROW never comes back to the host: every shard's kernels read its 48 bytes from
 // the owning shard's memory through the peer mapping (checked once at create time against
 // the by-value path; without all-pairs peer access the row is fetched once per query).
@@ -35,7 +42,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -47,6 +59,7 @@
 namespace {
 
 thread_local std::string g_sharded_error;
+thread_local bool t_worker_thread = false;   // a worker reports through its Worker record, never through the handle's string
 
 // ---- the few RCCL entry points, resolved at run time -------------------------------
 typedef struct ncclComm* ncclComm_t;
@@ -103,6 +116,56 @@ struct Shard {
     mi355rec_key_t* s_gathered = nullptr;
 };
 
+// ---- one unit of work for a shard's worker (plain data: copied into the worker's ring) --------------------
+enum TaskKind {
+    kTaskStreamQuery,   // one streamed scan launch: query by pointer or by value -> dst
+    kTaskSyncQuery,     // scan + local merge now (one query, or `count` of them as a batch) -> dst
+    kTaskBatch,         // a window: `count` queries (vectors and / or pointers) as a streamed batch -> dst
+    kTaskFlush,         // mi355rec_enqueue_flush on the shard's engine
+    kTaskPublish,       // PEER: record the shard's `done` event, then publish `seq` to the host
+    kTaskAllGather,     // RCCL: this shard's ncclAllGather
+    kTaskMerge,         // first device: wait for the other shards' events (PEER), merge the gathered lists
+};
+
+struct Task {
+    int kind = 0;
+    const float* qptr = nullptr;          // a query by pointer (device-readable memory)
+    float q[MI355REC_DIM] = {0};          // ... or by value
+    bool by_value = false;
+    const float* queries = nullptr;       // a batch by value (host memory that stays valid until the task has run)
+    const float* const* qptrs = nullptr;
+    const int64_t* excls = nullptr;
+    int64_t excl = -1;
+    int count = 1, topn = 0;
+    mi355rec_key_t* dst = nullptr;
+    bool flush_after = false;             // kTaskBatch: drain the engine's pipeline right behind it
+    uint64_t seq = 0;                     // exchange number (publish / merge)
+    const mi355rec_key_t* send = nullptr; // all-gather
+    mi355rec_key_t* recv = nullptr;
+    size_t stride = 0;
+    const mi355rec_key_t* lists = nullptr;   // merge
+    mi355rec_key_t* out_keys = nullptr;
+    int64_t* out_idx = nullptr;
+    float* out_score = nullptr;
+    hipEvent_t record_after = nullptr;    // merge: recorded on the stream behind it (a window's `merged`)
+    bool copy_back = false;               // merge: results too large for mapped stores: two copies to h_idx / h_score
+};
+
+struct Worker {
+    static constexpr uint64_t kCap = 2048;
+    std::thread th;
+    std::vector<Task> ring;
+    std::atomic<uint64_t> head{0};        // tasks posted
+    std::atomic<uint64_t> tail{0};        // tasks done
+    std::atomic<bool> sleeping{false};
+    std::atomic<bool> stop{false};
+    std::atomic<uint64_t> published{0};   // the exchange number the shard's `done` event was last recorded for
+    std::atomic<int> err{0};              // first failure of a task (sticky); err_msg is written before it
+    std::string err_msg;
+    std::mutex mu;
+    std::condition_variable cv;
+};
+
 constexpr int kStreamDepth = 4;     // windows whose results are kept (ring)
 constexpr int kStreamLag = 2;       // the keys of streamed query k are complete, in stream order, behind call k + 2
 constexpr int kMaxWindow = 64;
@@ -111,8 +174,11 @@ struct Window {
     hipEvent_t merged = nullptr;    // first device: this window's batched merge has run (results are in host memory)
     int64_t abs = -1;               // which window of the stream the ring entry holds (-1: none)
     int count = 0;                  // queries in it
-    bool issued = false;            // its exchange + merge have been enqueued
+    bool handed = false;            // batched windows: the shards have received it (one streamed batch call each)
+    bool issued = false;            // its exchange + merge have been enqueued (posted to the first device's worker)
+    uint64_t merge_task = 0;        // ... as that worker's task number: `merged` is recorded once it has run
 };
+constexpr int kWindowLag = 2;       // a streamed batch is complete, in stream order, behind the second batch call after it
 
 int64_t now_ns() {
     return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -137,6 +203,8 @@ struct mi355rec_sharded {
     float* hd_score = nullptr;
     bool peer_rows = true;              // every shard's device can read every other shard's rows
     bool batched_windows = true;        // mi355rec_sharded_set_window_mode
+    std::vector<std::unique_ptr<Worker>> workers;   // one per shard when there are several shards, none otherwise
+    uint64_t exchange_seq = 0;
     std::string note;                   // why a fast path was switched off at create time (diagnostics)
 
     // ---- the stream of single queries -------------------------------------------------
@@ -172,7 +240,7 @@ int sfail(mi355rec_sharded* h, int code, const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (h) h->err = buf;
+    if (h && !t_worker_thread) h->err = buf;
     g_sharded_error = buf;
     return code;
 }
@@ -199,8 +267,14 @@ void bounds(int64_t n, int g, int r, int64_t& lo, int64_t& hi) {
     hi = lo + per + (r < rem ? 1 : 0);
 }
 
+int drain_workers(mi355rec_sharded* h);
+
 int ensure_capacity(mi355rec_sharded* h, size_t keys_per_shard) {
     if (keys_per_shard <= h->cap) return MI355REC_OK;
+    {
+        const int rc = drain_workers(h);   // buffers are about to be replaced
+        if (rc) return rc;
+    }
     size_t cap = h->cap ? h->cap : 1024;
     while (cap < keys_per_shard) cap *= 2;
     const int g = static_cast<int>(h->shards.size());
@@ -239,6 +313,10 @@ int ensure_capacity(mi355rec_sharded* h, size_t keys_per_shard) {
 
 int ensure_rccl(mi355rec_sharded* h) {
     if (h->rccl_ready) return MI355REC_OK;
+    {
+        const int rc = drain_workers(h);
+        if (rc) return rc;
+    }
     std::string why;
     if (!g_rccl.load(why)) return sfail(h, MI355REC_ERR_HIP, "%s", why.c_str());
     const int g = static_cast<int>(h->shards.size());
@@ -258,49 +336,224 @@ int ensure_rccl(mi355rec_sharded* h) {
     return MI355REC_OK;
 }
 
+// ---- tasks: what a shard's worker (or, with one shard, the caller itself) executes ------------------
+
+int run_task(mi355rec_sharded* h, int r, const Task& t) {
+    Shard& s = h->shards[r];
+    const int g = static_cast<int>(h->shards.size());
+    switch (t.kind) {
+        case kTaskStreamQuery:
+            if (t.by_value) {
+                S_ENG(h, s, mi355rec_enqueue_query_keys_streamed(s.engine, t.q, t.excl, t.topn, t.dst, s.stream));
+            } else {
+                S_ENG(h, s, mi355rec_enqueue_ptr_keys_streamed(s.engine, t.qptr, t.excl, t.topn, t.dst, s.stream));
+            }
+            return MI355REC_OK;
+        case kTaskSyncQuery:
+            if (t.count > 1) {
+                S_ENG(h, s, mi355rec_enqueue_batch_keys(s.engine, t.queries, t.excls, t.count, t.topn, t.dst, s.stream));
+            } else if (t.by_value) {
+                S_ENG(h, s, mi355rec_enqueue_query_keys(s.engine, t.q, t.excl, t.topn, t.dst, s.stream));
+            } else {
+                S_ENG(h, s, mi355rec_enqueue_ptr_keys(s.engine, t.qptr, t.excl, t.topn, t.dst, nullptr, nullptr, s.stream));
+            }
+            return MI355REC_OK;
+        case kTaskBatch:
+            S_ENG(h, s, mi355rec_enqueue_batch_mixed_keys_streamed(s.engine, t.queries, t.qptrs, t.excls, t.count, t.topn, t.dst, s.stream));
+            if (t.flush_after) S_ENG(h, s, mi355rec_enqueue_flush(s.engine, s.stream));
+            return MI355REC_OK;
+        case kTaskFlush:
+            S_ENG(h, s, mi355rec_enqueue_flush(s.engine, s.stream));
+            return MI355REC_OK;
+        case kTaskPublish:
+            S_HIP(h, hipEventRecord(s.done, s.stream));
+            h->workers[r]->published.store(t.seq, std::memory_order_release);   // (several shards: there are workers)
+            return MI355REC_OK;
+        case kTaskAllGather: {
+            const ncclResult_t nrc = g_rccl.AllGather(t.send, t.recv, t.stride, kNcclUint64, s.comm, s.stream);
+            if (nrc != 0)
+                return sfail(h, MI355REC_ERR_HIP, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(nrc) : "error");
+            return MI355REC_OK;
+        }
+        case kTaskMerge: {
+            if (t.seq != 0) {   // PEER transport (0: the collective has ordered the streams)
+                // the other shards' events must have been RECORDED (on the host) before this stream can be told to
+                // wait for them; their workers publish the exchange number right behind the record
+                for (int o = 1; o < g; ++o) {
+                    Shard& other = h->shards[o];
+                    for (uint64_t spins = 0; h->workers[o]->published.load(std::memory_order_acquire) < t.seq; ++spins) {
+                        if (h->workers[o]->err.load(std::memory_order_acquire) != 0)
+                            return sfail(h, MI355REC_ERR_HIP, "shard on device %d failed before its keys were in place", other.device);
+                        if ((spins & 63) == 63) std::this_thread::yield(); else __builtin_ia32_pause();
+                    }
+                    S_HIP(h, hipStreamWaitEvent(s.stream, other.done, 0));
+                }
+            }
+            // list l of query b starts at b * topn + l * stride
+            S_ENG(h, s, mi355rec_enqueue_merge_keys_batch(s.engine, t.lists, g, t.topn, static_cast<int64_t>(t.stride),
+                                                          static_cast<int64_t>(t.topn), t.count, t.topn, t.out_keys, t.out_idx,
+                                                          t.out_score, s.stream));
+            if (t.copy_back) {
+                const size_t cnt = static_cast<size_t>(t.count) * t.topn;
+                S_HIP(h, hipMemcpyAsync(h->h_idx, h->d_idx, cnt * sizeof(int64_t), hipMemcpyDeviceToHost, s.stream));
+                S_HIP(h, hipMemcpyAsync(h->h_score, h->d_score, cnt * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+            }
+            if (t.record_after) S_HIP(h, hipEventRecord(t.record_after, s.stream));
+            return MI355REC_OK;
+        }
+    }
+    return sfail(h, MI355REC_ERR_INVALID_ARG, "unknown task %d", t.kind);
+}
+
+void worker_main(mi355rec_sharded* h, int r) {
+    Worker& w = *h->workers[r];
+    t_worker_thread = true;
+    (void)hipSetDevice(h->shards[r].device);
+    uint64_t next = 0;
+    for (;;) {
+        int idle = 0;
+        while (w.head.load(std::memory_order_acquire) == next) {
+            if (w.stop.load(std::memory_order_acquire)) return;
+            if (++idle < 400000) {
+                __builtin_ia32_pause();
+            } else {   // nothing for a few milliseconds: sleep until a task is posted (a wake-up costs tens of microseconds,
+                       // which a lone query right after a burst should not pay)
+                std::unique_lock<std::mutex> lk(w.mu);
+                w.sleeping.store(true, std::memory_order_seq_cst);
+                if (w.head.load(std::memory_order_seq_cst) == next && !w.stop.load(std::memory_order_seq_cst))
+                    w.cv.wait_for(lk, std::chrono::milliseconds(5));
+                w.sleeping.store(false, std::memory_order_seq_cst);
+                idle = 0;
+            }
+        }
+        const Task& t = w.ring[next % Worker::kCap];
+        if (w.err.load(std::memory_order_relaxed) == 0) {   // after a failure the remaining tasks are dropped
+            const int rc = run_task(h, r, t);
+            if (rc != MI355REC_OK) {
+                w.err_msg = g_sharded_error;   // sfail wrote the worker thread's copy
+                w.err.store(rc, std::memory_order_release);
+            }
+        } else if (t.kind == kTaskPublish) {
+            w.published.store(t.seq, std::memory_order_release);   // nobody must wait for a dead shard forever
+        }
+        ++next;
+        w.tail.store(next, std::memory_order_release);
+    }
+}
+
+// Hands a task to shard r: posted to its worker, or run here when there are no workers.  Returns the task's
+// number on that worker (0 without workers) through *id.
+int post(mi355rec_sharded* h, int r, const Task& t, uint64_t* id = nullptr) {
+    if (h->workers.empty()) {
+        S_HIP(h, hipSetDevice(h->shards[r].device));
+        if (id) *id = 0;
+        return run_task(h, r, t);
+    }
+    Worker& w = *h->workers[r];
+    const uint64_t at = w.head.load(std::memory_order_relaxed);
+    while (at - w.tail.load(std::memory_order_acquire) >= Worker::kCap) __builtin_ia32_pause();   // ring full: the worker is behind
+    w.ring[at % Worker::kCap] = t;
+    w.head.store(at + 1, std::memory_order_seq_cst);
+    if (w.sleeping.load(std::memory_order_seq_cst)) {
+        std::lock_guard<std::mutex> lk(w.mu);
+        w.cv.notify_one();
+    }
+    if (id) *id = at + 1;
+    return MI355REC_OK;
+}
+
+// First failure any worker has met (sticky: the handle is unusable afterwards, as after a HIP error).
+int worker_error(mi355rec_sharded* h) {
+    for (size_t r = 0; r < h->workers.size(); ++r) {
+        const int rc = h->workers[r]->err.load(std::memory_order_acquire);
+        if (rc != 0) return sfail(h, rc, "%s", h->workers[r]->err_msg.c_str());
+    }
+    return MI355REC_OK;
+}
+
+// Waits until shard r's worker has run its first `id` tasks (all of them when id == 0).
+int wait_worker(mi355rec_sharded* h, int r, uint64_t id = 0) {
+    if (h->workers.empty()) return MI355REC_OK;
+    Worker& w = *h->workers[r];
+    const uint64_t want = id ? id : w.head.load(std::memory_order_relaxed);
+    for (uint64_t spins = 0; w.tail.load(std::memory_order_acquire) < want; ++spins) {
+        if ((spins & 1023) == 1023) std::this_thread::yield(); else __builtin_ia32_pause();
+    }
+    return worker_error(h);
+}
+
+// Every worker idle: what anything that touches the engines from the caller's thread does first.
+int drain_workers(mi355rec_sharded* h) {
+    for (size_t r = 0; r < h->workers.size(); ++r) {
+        const int rc = wait_worker(h, static_cast<int>(r));
+        if (rc) return rc;
+    }
+    return MI355REC_OK;
+}
+
+void stop_workers(mi355rec_sharded* h) {
+    for (auto& w : h->workers) {
+        w->stop.store(true, std::memory_order_seq_cst);
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->cv.notify_one();
+        }
+        if (w->th.joinable()) w->th.join();
+    }
+    h->workers.clear();
+}
+
 // The exchange + final merge of `count` queries whose per-shard key lists ([shard][query][key],
 // `stride` keys from one shard's block to the next) are being produced on the shards' streams:
 // PEER: lists already land in `peer_lists` on the first device; one event per shard orders the
-// merge behind them.  RCCL: ONE grouped all-gather of `stride` keys per shard from send_of(r)
-// into recv_of(r).  Results go to out_keys (device) and out_idx / out_score (device-visible
-// addresses; mapped host memory on the hot paths).
+// merge behind them.  RCCL: one ncclAllGather of `stride` keys per shard from send_of(r) into
+// recv_of(r), each issued by its shard's worker.  Results go to out_keys (device) and out_idx /
+// out_score (device-visible addresses; mapped host memory on the hot paths).  Returns the merge's
+// task number on the first device's worker through *merge_task.
 template <typename SendOf, typename RecvOf>
 int exchange_and_merge(mi355rec_sharded* h, bool rccl, const mi355rec_key_t* peer_lists, SendOf send_of, RecvOf recv_of,
-                       size_t stride, int count, int topn, mi355rec_key_t* out_keys, int64_t* out_idx, float* out_score) {
+                       size_t stride, int count, int topn, mi355rec_key_t* out_keys, int64_t* out_idx, float* out_score,
+                       hipEvent_t record_after, bool copy_back, uint64_t* merge_task) {
     const int g = static_cast<int>(h->shards.size());
-    Shard& root = h->shards[0];
-    const mi355rec_key_t* lists = peer_lists;
+    const uint64_t seq = ++h->exchange_seq;
+    Task m;
+    m.kind = kTaskMerge;
+    m.seq = rccl ? 0 : seq;   // 0: nothing to wait for on the host (the collective orders the streams)
+    m.stride = stride;
+    m.count = count;
+    m.topn = topn;
+    m.out_keys = out_keys;
+    m.out_idx = out_idx;
+    m.out_score = out_score;
+    m.record_after = record_after;
+    m.copy_back = copy_back;
     if (rccl) {
-        ncclResult_t nrc = g_rccl.GroupStart();
-        for (int r = 0; r < g && nrc == 0; ++r) {
-            Shard& s = h->shards[r];
-            nrc = g_rccl.AllGather(send_of(r), recv_of(r), stride, kNcclUint64, s.comm, s.stream);
+        for (int r = 0; r < g; ++r) {   // every rank's call from its own thread (one rank: from here)
+            Task a;
+            a.kind = kTaskAllGather;
+            a.send = send_of(r);
+            a.recv = recv_of(r);
+            a.stride = stride;
+            const int rc = post(h, r, a);
+            if (rc) return rc;
         }
-        const ncclResult_t erc = g_rccl.GroupEnd();
-        if (nrc != 0 || erc != 0)
-            return sfail(h, MI355REC_ERR_HIP, "ncclAllGather: %s",
-                         g_rccl.GetErrorString ? g_rccl.GetErrorString(nrc ? nrc : erc) : "error");
-        lists = recv_of(0);   // the collective is ordered on root.stream already
+        m.lists = recv_of(0);   // the collective is ordered on the first device's stream already
     } else {
         for (int r = 1; r < g; ++r) {
-            Shard& s = h->shards[r];
-            S_HIP(h, hipSetDevice(s.device));
-            S_HIP(h, hipEventRecord(s.done, s.stream));
+            Task pb;
+            pb.kind = kTaskPublish;
+            pb.seq = seq;
+            const int rc = post(h, r, pb);
+            if (rc) return rc;
         }
-        S_HIP(h, hipSetDevice(root.device));
-        for (int r = 1; r < g; ++r) S_HIP(h, hipStreamWaitEvent(root.stream, h->shards[r].done, 0));
+        m.lists = peer_lists;
     }
-    S_HIP(h, hipSetDevice(root.device));
-    // list l of query b starts at b * topn + l * stride
-    S_ENG(h, root, mi355rec_enqueue_merge_keys_batch(root.engine, lists, g, topn, static_cast<int64_t>(stride),
-                                                     static_cast<int64_t>(topn), count, topn, out_keys, out_idx, out_score,
-                                                     root.stream));
-    return MI355REC_OK;
+    return post(h, 0, m, merge_task);
 }
 
 // `count` queries (host vectors; or, with count == 1, `qptr` = where the query's 12 floats live
 // in device memory every shard can read) -> merged results in the pinned host mirrors.
-// ONE host wait: the first device's stream.  Its merge waited (events / the collective) for
+// ONE device wait: the first device's stream.  Its merge waited (events / the collective) for
 // everything the other shards did for this call, and their streams order the next call's
 // writes behind this call's reads, so nothing else needs draining.
 int run_queries(mi355rec_sharded* h, const float* queries, const float* qptr, const int64_t* exclude, int count, int topn) {
@@ -315,30 +568,38 @@ int run_queries(mi355rec_sharded* h, const float* queries, const float* qptr, co
     // device 0's gather buffer (peer stores) or in the shard's send buffer (RCCL)
     for (int r = 0; r < g; ++r) {
         Shard& s = h->shards[r];
-        S_HIP(h, hipSetDevice(s.device));
-        mi355rec_key_t* dst = rccl ? s.local_keys : h->gather0 + static_cast<size_t>(r) * per_shard;
+        Task t;
+        t.kind = kTaskSyncQuery;
+        t.count = count;
+        t.topn = topn;
+        t.dst = rccl ? s.local_keys : h->gather0 + static_cast<size_t>(r) * per_shard;
+        t.excl = exclude ? exclude[0] : -1;
+        t.excls = exclude;
+        t.queries = queries;
         if (qptr) {
-            S_ENG(h, s, mi355rec_enqueue_ptr_keys(s.engine, qptr, exclude ? exclude[0] : -1, topn, dst, nullptr, nullptr, s.stream));
+            t.qptr = qptr;
         } else if (count == 1) {
-            S_ENG(h, s, mi355rec_enqueue_query_keys(s.engine, queries, exclude ? exclude[0] : -1, topn, dst, s.stream));
-        } else {
-            S_ENG(h, s, mi355rec_enqueue_batch_keys(s.engine, queries, exclude, count, topn, dst, s.stream));
+            t.by_value = true;
+            std::memcpy(t.q, queries, sizeof t.q);
         }
+        rc = post(h, r, t);
+        if (rc) return rc;
     }
     // results up to a few thousand slots are stored by the merge kernel straight into mapped host
     // memory (no copy launches on the latency path); larger ones come back in two copies
     const bool direct = per_shard <= 4096;
+    uint64_t merge_task = 0;
     rc = exchange_and_merge(
         h, rccl, h->gather0, [&](int r) { return h->shards[r].local_keys; }, [&](int r) { return h->shards[r].gathered; },
-        per_shard, count, topn, h->d_keys, direct ? h->hd_idx : h->d_idx, direct ? h->hd_score : h->d_score);
+        per_shard, count, topn, h->d_keys, direct ? h->hd_idx : h->d_idx, direct ? h->hd_score : h->d_score, nullptr, !direct,
+        &merge_task);
+    if (rc) return rc;
+    rc = wait_worker(h, 0, merge_task);   // the merge has been ENQUEUED on the first device's stream ...
     if (rc) return rc;
     Shard& root = h->shards[0];
-    if (!direct) {
-        S_HIP(h, hipMemcpyAsync(h->h_idx, h->d_idx, per_shard * sizeof(int64_t), hipMemcpyDeviceToHost, root.stream));
-        S_HIP(h, hipMemcpyAsync(h->h_score, h->d_score, per_shard * sizeof(float), hipMemcpyDeviceToHost, root.stream));
-    }
-    S_HIP(h, hipStreamSynchronize(root.stream));
-    return MI355REC_OK;
+    S_HIP(h, hipSetDevice(root.device));
+    S_HIP(h, hipStreamSynchronize(root.stream));   // ... and now it has run
+    return worker_error(h);
 }
 
 // topn above the single-launch merge limit (the CLI's `-n 5000`): every shard serves the
@@ -348,7 +609,9 @@ int run_queries(mi355rec_sharded* h, const float* queries, const float* qptr, co
 int run_queries_large(mi355rec_sharded* h, const float* queries, const int64_t* exclude, int count, int eff, int topn,
                       int64_t* out_idx, float* out_score, int* out_count) {
     const int g = static_cast<int>(h->shards.size());
-    int rc = ensure_capacity(h, static_cast<size_t>(eff));
+    int rc = drain_workers(h);   // cold path: the caller's thread drives every shard itself
+    if (rc) return rc;
+    rc = ensure_capacity(h, static_cast<size_t>(eff));
     if (rc) return rc;
     std::vector<mi355rec_key_t> all(static_cast<size_t>(g) * eff);
     for (int b = 0; b < count; ++b) {
@@ -484,6 +747,8 @@ int ensure_stream(mi355rec_sharded* h, int topn) {
     if (h->s_topn) {
         int rc = stream_flush(h);
         if (rc) return rc;
+        rc = drain_workers(h);
+        if (rc) return rc;
         for (Shard& s : h->shards) {
             S_HIP(h, hipSetDevice(s.device));
             S_HIP(h, hipStreamSynchronize(s.stream));
@@ -493,6 +758,7 @@ int ensure_stream(mi355rec_sharded* h, int topn) {
     for (Window& w : h->win) {
         w.abs = -1;
         w.count = 0;
+        w.handed = false;
         w.issued = false;
     }
     // tickets keep growing across a change of geometry, window-aligned in the new one
@@ -515,9 +781,9 @@ int stream_issue(mi355rec_sharded* h, int w) {
         h, rccl, h->s_gather0 + static_cast<size_t>(w) * g * wk,
         [&](int r) { return h->shards[r].s_local + static_cast<size_t>(w) * wk; },
         [&](int r) { return h->shards[r].s_gathered + static_cast<size_t>(w) * g * wk; }, wk, win.count, topn,
-        h->s_keys + static_cast<size_t>(w) * wk, h->s_hdidx + static_cast<size_t>(w) * wk, h->s_hdscore + static_cast<size_t>(w) * wk);
+        h->s_keys + static_cast<size_t>(w) * wk, h->s_hdidx + static_cast<size_t>(w) * wk, h->s_hdscore + static_cast<size_t>(w) * wk,
+        win.merged, false, &win.merge_task);
     if (rc) return rc;
-    S_HIP(h, hipEventRecord(win.merged, h->shards[0].stream));
     win.issued = true;
     ++h->st_exchanges;
     return MI355REC_OK;
@@ -539,22 +805,26 @@ int stream_issue_ready(mi355rec_sharded* h, bool all) {
     return MI355REC_OK;
 }
 
-int stream_issue_batched(mi355rec_sharded* h, int w);
+int stream_issue_batched(mi355rec_sharded* h, int w, bool close_all);
 
 int stream_flush(mi355rec_sharded* h) {
     if (!h->s_topn || h->issued_upto >= h->next_ticket) return MI355REC_OK;
-    if (h->s_batched) {   // the open window goes out as it is
+    if (h->s_batched) {   // the open window goes out as it is, the shards' pipelines are drained, every exchange issued
         const int W = h->s_window;
-        const int w = static_cast<int>((h->issued_upto / W) % kStreamDepth);
-        const int rc = stream_issue_batched(h, w);
+        const int64_t last = (h->next_ticket - 1) / W;   // the newest window that holds a query
+        Window& win = h->win[static_cast<int>(last % kStreamDepth)];
+        if (win.abs != last) return sfail(h, MI355REC_ERR_HIP, "stream bookkeeping: window %lld is not in the ring", (long long)last);
+        const int rc = stream_issue_batched(h, static_cast<int>(last % kStreamDepth), true);
         if (rc) return rc;
         h->next_ticket = (h->next_ticket + W - 1) / W * W;
         h->issued_upto = h->next_ticket;
         return MI355REC_OK;
     }
-    for (Shard& s : h->shards) {
-        S_HIP(h, hipSetDevice(s.device));
-        S_ENG(h, s, mi355rec_enqueue_flush(s.engine, s.stream));
+    for (int r = 0; r < static_cast<int>(h->shards.size()); ++r) {
+        Task t;
+        t.kind = kTaskFlush;
+        const int prc = post(h, r, t);
+        if (prc) return prc;
     }
     const int rc = stream_issue_ready(h, true);
     if (rc) return rc;
@@ -564,9 +834,10 @@ int stream_flush(mi355rec_sharded* h) {
     return MI355REC_OK;
 }
 
-// A collected window goes to every shard in ONE call (multi-query passes over the replica), then its
-// exchange + merge follow at once: nothing of it is left in any pipeline.
-int stream_issue_batched(mi355rec_sharded* h, int w) {
+// A collected window goes to every shard in ONE call: a streamed batch (multi-query passes over the replica
+// whose merge rides in the shard's next launch), so its keys are complete kWindowLag windows later — or at
+// the flush, which drains the shards' pipelines.  `close_all`: issue the exchange of every window handed out.
+int stream_issue_batched(mi355rec_sharded* h, int w, bool close_all) {
     Window& win = h->win[w];
     if (win.count == 0 || win.issued) return MI355REC_OK;
     const int g = static_cast<int>(h->shards.size());
@@ -578,13 +849,35 @@ int stream_issue_batched(mi355rec_sharded* h, int w) {
     for (int i = 0; i < win.count; ++i) (h->w_ptr[at + i] ? any_ptr : any_vec) = true;
     for (int r = 0; r < g; ++r) {
         Shard& s = h->shards[r];
-        S_HIP(h, hipSetDevice(s.device));
-        mi355rec_key_t* dst = rccl ? s.s_local + static_cast<size_t>(w) * wk : h->s_gather0 + (static_cast<size_t>(w) * g + r) * wk;
-        S_ENG(h, s, mi355rec_enqueue_batch_mixed_keys(s.engine, any_vec ? &h->w_q[at * MI355REC_DIM] : nullptr,
-                                                      any_ptr ? &h->w_ptr[at] : nullptr, &h->w_excl[at], win.count, topn, dst,
-                                                      s.stream));
+        Task t;
+        if (!win.handed) {
+            t.kind = kTaskBatch;
+            t.queries = any_vec ? &h->w_q[at * MI355REC_DIM] : nullptr;   // the ring entry stays untouched until its window
+            t.qptrs = any_ptr ? &h->w_ptr[at] : nullptr;                   // has been merged (back-pressure in stream_enqueue)
+            t.excls = &h->w_excl[at];
+            t.count = win.count;
+            t.topn = topn;
+            t.dst = rccl ? s.s_local + static_cast<size_t>(w) * wk : h->s_gather0 + (static_cast<size_t>(w) * g + r) * wk;
+            t.flush_after = close_all;
+        } else if (close_all) {
+            t.kind = kTaskFlush;
+        } else {
+            continue;
+        }
+        const int prc = post(h, r, t);
+        if (prc) return prc;
     }
-    return stream_issue(h, w);
+    win.handed = true;
+    // exchanges, oldest first: everything at least kWindowLag windows old — or everything, behind a flush
+    for (int64_t a = win.abs - (kStreamDepth - 1); a <= win.abs; ++a) {
+        if (a < 0) continue;
+        Window& old = h->win[static_cast<int>(a % kStreamDepth)];
+        if (old.abs != a || !old.handed || old.issued) continue;
+        if (!close_all && a + kWindowLag > win.abs) continue;
+        const int rc = stream_issue(h, static_cast<int>(a % kStreamDepth));
+        if (rc) return rc;
+    }
+    return MI355REC_OK;
 }
 
 int stream_enqueue(mi355rec_sharded* h, const float* qptr, const float* query12, int64_t exclude_global, int topn,
@@ -606,9 +899,14 @@ int stream_enqueue(mi355rec_sharded* h, const float* qptr, const float* query12,
     if (slot == 0) {
         // The ring entry's previous window (kStreamDepth windows ago) must be done on the device before
         // any shard writes into its buffers again: host back-pressure, normally long satisfied.
-        if (win.abs >= 0 && win.issued) S_HIP(h, hipEventSynchronize(win.merged));
+        if (win.abs >= 0 && win.issued) {
+            rc = wait_worker(h, 0, win.merge_task);   // its `merged` event has been recorded ...
+            if (rc) return rc;
+            S_HIP(h, hipEventSynchronize(win.merged));   // ... and has happened
+        }
         win.abs = abs;
         win.count = 0;
+        win.handed = false;
         win.issued = false;
     }
     const size_t wk = static_cast<size_t>(W) * topn;
@@ -621,23 +919,26 @@ int stream_enqueue(mi355rec_sharded* h, const float* qptr, const float* query12,
         ++h->next_ticket;
         ++h->st_queries;
         if (ticket) *ticket = t;
-        if (slot == W - 1) {
-            rc = stream_issue_batched(h, w);
-            h->issued_upto = h->next_ticket;
-        }
+        if (slot == W - 1) rc = stream_issue_batched(h, w, false);
         h->st_host_ns += now_ns() - t0;
         return rc;
     }
     for (int r = 0; r < g; ++r) {
         Shard& s = h->shards[r];
-        S_HIP(h, hipSetDevice(s.device));
-        mi355rec_key_t* dst = rccl ? s.s_local + static_cast<size_t>(w) * wk + static_cast<size_t>(slot) * topn
-                                   : h->s_gather0 + (static_cast<size_t>(w) * g + r) * wk + static_cast<size_t>(slot) * topn;
+        Task t;
+        t.kind = kTaskStreamQuery;
+        t.topn = topn;
+        t.excl = exclude_global;
+        t.dst = rccl ? s.s_local + static_cast<size_t>(w) * wk + static_cast<size_t>(slot) * topn
+                     : h->s_gather0 + (static_cast<size_t>(w) * g + r) * wk + static_cast<size_t>(slot) * topn;
         if (qptr) {
-            S_ENG(h, s, mi355rec_enqueue_ptr_keys_streamed(s.engine, qptr, exclude_global, topn, dst, s.stream));
+            t.qptr = qptr;
         } else {
-            S_ENG(h, s, mi355rec_enqueue_query_keys_streamed(s.engine, query12, exclude_global, topn, dst, s.stream));
+            t.by_value = true;
+            std::memcpy(t.q, query12, sizeof t.q);
         }
+        rc = post(h, r, t);
+        if (rc) return rc;
     }
     ++win.count;
     ++h->next_ticket;
@@ -659,6 +960,7 @@ const char* mi355rec_sharded_last_error(const mi355rec_sharded_t* h) {
 void mi355rec_sharded_destroy(mi355rec_sharded_t* h) {
     if (!h) return;
     DeviceRestore restore;
+    stop_workers(h);   // they finish what has been posted first
     for (Shard& s : h->shards) {
         if (hipSetDevice(s.device) != hipSuccess) continue;
         if (s.stream) (void)hipStreamSynchronize(s.stream);
@@ -749,6 +1051,14 @@ int mi355rec_create_sharded_on(const float* feats_host, int64_t n, int dim, cons
             return bail(sfail(nullptr, MI355REC_ERR_HIP, "event creation on device %d failed", root));
     h->transport = h->peer_ok ? MI355REC_TRANSPORT_PEER : MI355REC_TRANSPORT_RCCL;
 
+    if (n_shards > 1) {   // one worker per shard (none for a single shard: its calls are made by the caller)
+        for (int r = 0; r < n_shards; ++r) {
+            h->workers.emplace_back(new Worker());
+            h->workers.back()->ring.resize(Worker::kCap);
+        }
+        for (int r = 0; r < n_shards; ++r) h->workers[r]->th = std::thread(worker_main, h, r);
+    }
+
     // Queries by row through the peer mapping have to give the by-value path's keys: one query
     // per shard boundary, checked here, once, on real multi-device placements (a mismatch or an
     // error switches the pointer path off for this handle; mi355rec_sharded_info's note says so).
@@ -806,7 +1116,9 @@ int mi355rec_sharded_set_transport(mi355rec_sharded_t* h, int transport) {
     }
     if (transport != h->transport) {   // an open stream window is closed under the transport it was filled with
         DeviceRestore restore;
-        const int rc = stream_flush(h);
+        int rc = stream_flush(h);
+        if (rc) return rc;
+        rc = drain_workers(h);
         if (rc) return rc;
     }
     h->transport = transport;
@@ -830,6 +1142,8 @@ const char* mi355rec_sharded_note(const mi355rec_sharded_t* h) { return h ? h->n
 
 int mi355rec_sharded_set_timing(mi355rec_sharded_t* h, int enabled) {
     if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    const int drc = drain_workers(h);
+    if (drc) return drc;
     for (Shard& s : h->shards) S_ENG(h, s, mi355rec_set_timing(s.engine, enabled));
     return MI355REC_OK;
 }
@@ -838,6 +1152,8 @@ int mi355rec_sharded_shard_stats(const mi355rec_sharded_t* hc, int shard, mi355r
     mi355rec_sharded_t* h = const_cast<mi355rec_sharded_t*>(hc);
     if (!h || !out) return sfail(h, MI355REC_ERR_INVALID_ARG, "null argument");
     if (shard < 0 || shard >= static_cast<int>(h->shards.size())) return sfail(h, MI355REC_ERR_INVALID_ARG, "no shard %d", shard);
+    const int drc = drain_workers(h);
+    if (drc) return drc;
     const Shard& s = h->shards[shard];
     S_ENG(h, s, mi355rec_stats(s.engine, out));
     return MI355REC_OK;
@@ -846,7 +1162,9 @@ int mi355rec_sharded_shard_stats(const mi355rec_sharded_t* hc, int shard, mi355r
 int mi355rec_sharded_set_replica(mi355rec_sharded_t* h, int mode) {
     if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
     DeviceRestore restore;
-    const int rc = stream_flush(h);
+    int rc = stream_flush(h);
+    if (rc) return rc;
+    rc = drain_workers(h);
     if (rc) return rc;
     for (Shard& s : h->shards) {
         if (s.hi == s.lo) continue;
@@ -919,7 +1237,9 @@ int mi355rec_sharded_scores_row(mi355rec_sharded_t* h, int64_t global_row, float
     DeviceRestore restore;
     float q[MI355REC_DIM];
     const Shard* own = owner_of(h, global_row);
-    int rc = mi355rec_fetch_row(own->engine, global_row - own->lo, q);
+    int rc = drain_workers(h);   // cold path: the caller's thread drives every shard itself
+    if (rc) return rc;
+    rc = mi355rec_fetch_row(own->engine, global_row - own->lo, q);
     if (rc != MI355REC_OK) return sfail(h, rc, "shard on device %d: %s", own->device, mi355rec_last_error(own->engine));
     for (const Shard& s : h->shards) {
         if (s.hi == s.lo) continue;
@@ -936,7 +1256,9 @@ int mi355rec_sharded_set_window(mi355rec_sharded_t* h, int window) {
     if (window < 1 || window > kMaxWindow) return sfail(h, MI355REC_ERR_INVALID_ARG, "window must be in [1, %d], got %d", kMaxWindow, window);
     if (window == h->s_window) return MI355REC_OK;
     DeviceRestore restore;
-    const int rc = stream_flush(h);   // the open window is closed in the old geometry
+    int rc = stream_flush(h);   // the open window is closed in the old geometry
+    if (rc) return rc;
+    rc = drain_workers(h);
     if (rc) return rc;
     // buffers are re-made by the next enqueue (ensure_stream sees s_alloc_window != s_window)
     h->next_ticket = (h->next_ticket + window - 1) / window * window;
@@ -949,6 +1271,7 @@ int mi355rec_sharded_set_window(mi355rec_sharded_t* h, int window) {
     for (Window& w : h->win) {
         w.abs = -1;
         w.count = 0;
+        w.handed = false;
         w.issued = false;
     }
     h->s_window = window;
@@ -959,7 +1282,9 @@ int mi355rec_sharded_set_window_mode(mi355rec_sharded_t* h, int batched) {
     if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
     if ((batched != 0) == h->batched_windows) return MI355REC_OK;
     DeviceRestore restore;
-    const int rc = stream_flush(h);
+    int rc = stream_flush(h);
+    if (rc) return rc;
+    rc = drain_workers(h);
     if (rc) return rc;
     for (Shard& s : h->shards) {
         S_HIP(h, hipSetDevice(s.device));
@@ -969,6 +1294,7 @@ int mi355rec_sharded_set_window_mode(mi355rec_sharded_t* h, int batched) {
     for (Window& w : h->win) {
         w.abs = -1;
         w.count = 0;
+        w.handed = false;
         w.issued = false;
     }
     h->batched_windows = batched != 0;
@@ -1020,7 +1346,11 @@ int mi355rec_sharded_wait(mi355rec_sharded_t* h, int64_t ticket, int64_t* out_id
         const int rc = stream_flush(h);
         if (rc) return rc;
     }
-    S_HIP(h, hipEventSynchronize(win.merged));
+    {
+        const int rc = wait_worker(h, 0, win.merge_task);   // the merge has been enqueued and `merged` recorded ...
+        if (rc) return rc;
+    }
+    S_HIP(h, hipEventSynchronize(win.merged));                // ... and the results are in host memory
     const int topn = h->s_topn;
     const size_t off = (static_cast<size_t>(w) * W + slot) * topn;
     copy_rows(h->s_hidx + off, h->s_hscore + off, 1, topn, topn, out_idx, out_score, out_count);

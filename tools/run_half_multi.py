@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Driver for the multi-query pass over the fp16 replica (csrc/replica_multi.hip.h): single calls and streams of
+batches of 1 ... 32 queries, with the kernel's event time and the rows it sent to the exact chain.
+  python3 tools/run_half_multi.py --rows 10000000 --topn 100
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/x -- python3 tools/run_half_multi.py --only-stream 12
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--topn", type=int, default=100)
+    ap.add_argument("--calls", type=int, default=40)
+    ap.add_argument("--only-stream", type=int, default=0, help="only a stream of batches of this many queries (profiling)")
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    from spotify_recommender_amd import CosineEngine, capi
+    from spotify_recommender_amd.synth import synthetic_catalogue
+
+    n, topn = args.rows, args.topn
+    t = synthetic_catalogue(n, seed=12345)
+    rows = [(k * 7919) % n for k in range(64)]
+    q = t[torch.tensor(rows, device="cuda")].cpu().numpy()
+    out = {"rows": n, "topn": topn, "single_calls": [], "streams": []}
+    with CosineEngine(t) as eng:
+        eng.set_batch_path(capi.BATCH_HALF)
+        sizes = (1, 2, 4, 8, 12, 16, 24, 32) if not args.only_stream else ()
+        for nb in sizes:
+            keys = torch.zeros(nb * topn, dtype=torch.int64, device="cuda")
+            ex = np.array(rows[:nb], dtype=np.int64)
+            eng.enqueue_batch_keys(q[:nb], ex, topn, keys)
+            torch.cuda.synchronize()
+            b = eng.replica_counters()
+            eng.set_timing(1)
+            t0 = time.perf_counter()
+            for _ in range(args.calls):
+                eng.enqueue_batch_keys(q[:nb], ex, topn, keys)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.calls
+            st = eng.stats()
+            eng.set_timing(0)
+            a = eng.replica_counters()
+            out["single_calls"].append({"queries": nb, "us_per_call": round(dt * 1e6, 1), "queries_per_s": round(nb / dt),
+                                        "pass_kernel_us": round(st.last_scan_ms * 1e3, 1), "merge_kernel_us": round(st.last_merge_ms * 1e3, 1),
+                                        "rows_to_exact_chain_per_query": round((a["rescored_rows"] - b["rescored_rows"]) / args.calls / nb)})
+        for nb in ((2, 12, 32) if not args.only_stream else (args.only_stream,)):
+            ring = [torch.zeros(nb * topn, dtype=torch.int64, device="cuda") for _ in range(4)]
+            ex = np.array(rows[:nb], dtype=np.int64)
+            for k in range(6):
+                eng.enqueue_batch_keys_streamed(q[:nb], ex, topn, ring[k % 4])
+            eng.enqueue_flush()
+            torch.cuda.synchronize()
+            eng.set_timing(1)
+            t0 = time.perf_counter()
+            for k in range(args.calls):
+                eng.enqueue_batch_keys_streamed(q[:nb], ex, topn, ring[k % 4])
+            eng.enqueue_flush()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.calls
+            st = eng.stats()
+            eng.set_timing(0)
+            out["streams"].append({"queries": nb, "us_per_call": round(dt * 1e6, 1), "queries_per_s": round(nb / dt),
+                                   "launch_kernel_us": round(st.last_scan_ms * 1e3, 1)})
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -58,6 +58,9 @@ for k, d in out["kernels"].items():
     alg = None
     if "scan_kernel" in k or "stream_probe" in k or "scan_multi_kernel" in k:
         alg = rows * 48
+    elif "scan_half_multi_kernel" in k:
+        alg = (rows + 1) // 2 * 48
+        d["note"] = "multi-query pass over the fp16 replica (24 B per row whatever the number of queries, <= 32) + the fp32 rows of its candidates"
     elif "scan_half_kernel" in k:
         alg = (rows + 1) // 2 * 48
         d["note"] = "scan over the fp16 replica: 24 B per row + the fp32 rows it cannot rule out (a few thousand per query)"
