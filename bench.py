@@ -500,6 +500,7 @@ def main():
         step(k)
     flush()
     fence()
+    rc_before = eng.replica_counters() if replica else None
     # a timed launch costs ~6 us of stream time (start / stop signals around the dispatch): 16 timed launches
     # in a long run (every 18th of the default 300), 4 in a short one (the driver's 20-step run: every 5th)
     stride = args.event_stride if args.event_stride > 0 else max(1, args.steps // (16 if args.steps >= 64 else 4))
@@ -514,6 +515,7 @@ def main():
     fence()
     st = eng.stats()  # averages the HIP events recorded inside the timed region
     eng.set_timing(False)
+    rc_after = eng.replica_counters() if replica else None
     # what the timed stream itself produced for its last two queries (checked against the oracle below)
     timed_tail = [(q_rows[k], ring[k % 4].clone()) for k in (total_q - 2, total_q - 1)] if streamed and args.steps >= 2 else []
     if world > 1:
@@ -819,8 +821,9 @@ def main():
             },
         }
         if replica:
-            rc = eng.replica_counters()
-            line["roofline"]["rescored_rows_per_query"] = round(rc["rescored_rows"] / max(1, rc["scans"]), 1)
+            # rows the timed stream itself sent to the exact chain (counters read right before and after it)
+            line["roofline"]["rescored_rows_per_query"] = round(
+                (rc_after["rescored_rows"] - rc_before["rescored_rows"]) / max(1, rc_after["scans"] - rc_before["scans"]), 1)
             line["roofline"]["note"] = ("achieved / frac are for the bytes this kernel streams (the 24 B/row fp16 replica); "
                                         "SURVEY.md §8(d) prices a query at 48 B/row, i.e. the fp32 scan in `fp32_rows`")
             if scan_ms > 0:
