@@ -824,6 +824,7 @@ def main():
             # rows the timed stream itself sent to the exact chain (counters read right before and after it)
             line["roofline"]["rescored_rows_per_query"] = round(
                 (rc_after["rescored_rows"] - rc_before["rescored_rows"]) / max(1, rc_after["scans"] - rc_before["scans"]), 1)
+            line["roofline"]["prefilter_margin"] = round(float(st.replica_margin_single), 6)
             line["roofline"]["note"] = ("achieved / frac are for the bytes this kernel streams (the 24 B/row fp16 replica); "
                                         "SURVEY.md §8(d) prices a query at 48 B/row, i.e. the fp32 scan in `fp32_rows`")
             if scan_ms > 0:

@@ -79,6 +79,9 @@ typedef struct {
     int32_t replica_active;    /* 1 = single queries currently scan the replica (mi355rec_set_replica) */
     int32_t replica_grid_blocks; /* resident workgroups of the replica scan                 */
     float replica_build_ms;    /* device time of building the replica (once, at create)     */
+    float replica_margin_single; /* error bound the replica pre-filters claim on this device: 1.0e-3 where the unit  */
+    float replica_margin_multi;  /* demonstrably keeps fp16 subnormals (checked when the replica is built), else 1.5e-3:
+                                    v_fma_mix_f32 (single-query scan) / the matrix core (multi-query pass)             */
 } mi355rec_stats_t;
 
 /* Number of visible HIP devices (0 when there is none / no driver). */

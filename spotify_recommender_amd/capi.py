@@ -44,6 +44,8 @@ class Stats(ctypes.Structure):
         ("replica_active", c_int32),
         ("replica_grid_blocks", c_int32),
         ("replica_build_ms", c_float),
+        ("replica_margin_single", c_float),
+        ("replica_margin_multi", c_float),
     ]
 
 

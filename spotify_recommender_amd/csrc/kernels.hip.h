@@ -52,6 +52,7 @@ constexpr int kMergeHeadsPerThread = kMergeMaxLists / kMergeBlock;
 
 struct QueryArg {
     float q[kDim];
+    float margin;   // error bound of the fp16 pre-filter the launch may claim (replica scans only; set by the host)
 };
 
 // ---- packed keys -----------------------------------------------------------

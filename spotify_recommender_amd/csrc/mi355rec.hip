@@ -95,6 +95,8 @@ struct mi355rec {
     int replica_mode = 0;               // MI355REC_REPLICA_AUTO / _OFF / _ON
     bool replica_allowed = true;        // false: created under MI355REC_REPLICA=0
     float replica_build_ms = 0.f;
+    float margin_mix = kBqMarginFlush;   // error bound the single-query replica scan may claim (v_fma_mix_f32) ...
+    float margin_mfma = kBqMarginFlush;  // ... and the multi-query pass (matrix core): 1.0e-3 where the device check passes
     int pending_lists = 0;              // lists of the streamed query that waits for its merge
     // Streamed queries over the replica run ONE CALL BEHIND: query k is launched by call k + 1 (or
     // by the flush), so that its launch can carry the sample of query k + 1 (seed riders) instead
@@ -373,6 +375,15 @@ int build_replica_inner(mi355rec* h) {
     if (b) (void)hipEventDestroy(b);
     HIP_TRY(h, e);
     HIP_TRY(h, hipGetLastError());
+    // which error bound the pre-filters may claim on this device (replica.hip.h, half_selfcheck_kernel)
+    float* scratch = reinterpret_cast<float*>(h->d_half_seed);
+    hipLaunchKernelGGL(half_selfcheck_kernel, dim3(1), dim3(64), 0, h->stream, scratch);
+    float chk[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    HIP_TRY(h, hipMemcpyAsync(chk, scratch, sizeof chk, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const bool cvt_kept = chk[1] > 2.9e-6f && chk[1] < 3.1e-6f;
+    h->margin_mfma = (cvt_kept && chk[0] == 9.5367431640625e-07f) ? kBqMargin : kBqMarginFlush;
+    h->margin_mix = (cvt_kept && chk[2] == 9.5367431640625e-07f && chk[3] == 9.5367431640625e-07f) ? kBqMargin : kBqMarginFlush;
     return MI355REC_OK;
 }
 
@@ -594,6 +605,7 @@ int enqueue_scan(mi355rec* h, const float* qptr, const float* query12,
                  int64_t exclude_global, int topn, const uint64_t* upper_dev, hipStream_t s, int* n_lists) {
     QueryArg qa;
     std::memset(&qa, 0, sizeof qa);
+    qa.margin = h->margin_mix;
     if (!qptr) std::memcpy(qa.q, query12, sizeof qa.q);
     const PrevMerge none{nullptr, 0, 0, nullptr};
     if (use_half(h, upper_dev)) {
@@ -713,9 +725,10 @@ bool half_multi_ok(const mi355rec* h, int topn) {
            h->hseed_grid * kHalfSeedWaves >= topn;
 }
 
-void fill_half_multi_arg(HalfMultiArg& arg, const float* queries, const float* const* qptrs, const int64_t* exclude, int g0,
-                         int nq) {
+void fill_half_multi_arg(HalfMultiArg& arg, float margin, const float* queries, const float* const* qptrs, const int64_t* exclude,
+                         int g0, int nq) {
     std::memset(&arg, 0, sizeof arg);
+    arg.margin = margin;
     for (int q = 0; q < kHmQueries; ++q) {
         arg.exclude[q] = -1;
         if (q >= nq) continue;
@@ -736,7 +749,7 @@ int enqueue_half_multi(mi355rec* h, const float* queries, const float* const* qp
     HalfMultiArg arg;
     for (int g0 = 0; g0 < count; g0 += kHmQueries) {
         const int nq = count - g0 < kHmQueries ? count - g0 : kHmQueries;
-        fill_half_multi_arg(arg, queries, qptrs, exclude, g0, nq);
+        fill_half_multi_arg(arg, h->margin_mfma, queries, qptrs, exclude, g0, nq);
         hipLaunchKernelGGL(seed_half_multi_kernel, dim3(h->hseed_grid), dim3(kHmBlock), 0, s, h->d_half, h->n, h->hseed_stride,
                            arg, nq, h->d_half_mseed);
         ++h->half_scans;
@@ -847,7 +860,7 @@ int enqueue_mstream(mi355rec* h, const float* queries, const float* const* qptrs
     int rc = ensure_mstream(h);
     if (rc) return rc;
     HalfMultiArg arg;
-    fill_half_multi_arg(arg, queries, qptrs, exclude, g0, nq);
+    fill_half_multi_arg(arg, h->margin_mfma, queries, qptrs, exclude, g0, nq);
     int seed_buf = 0;
     if (h->mstash.has) {
         seed_buf = 1 - h->mstash.seed_buf;
@@ -1000,6 +1013,7 @@ int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, const float* next
     }
     QueryArg qa;
     std::memset(&qa, 0, sizeof qa);
+    qa.margin = h->margin_mix;
     const int n_seed = h->hseed_grid * kHalfSeedWaves;
     ++h->half_scans;
     if (st.qptr) {
@@ -1041,6 +1055,7 @@ int enqueue_streamed(mi355rec* h, const float* qptr, const float* query12, int64
 #endif
     QueryArg qa;
     std::memset(&qa, 0, sizeof qa);
+    qa.margin = h->margin_mix;
     if (use_half(h, nullptr)) {
         // One call behind: the query of the PREVIOUS call is launched now, and its launch takes the
         // sample of this one (seed riders).  The first query of a stream needs a seed launch of its own.
@@ -1452,6 +1467,8 @@ int mi355rec_stats(const mi355rec_t* hc, mi355rec_stats_t* out) {
     out->replica_active = use_half(h, nullptr) ? 1 : 0;
     out->replica_grid_blocks = h->d_half ? h->hgrid : 0;
     out->replica_build_ms = h->replica_build_ms;
+    out->replica_margin_single = h->d_half ? h->margin_mix : 0.0f;
+    out->replica_margin_multi = h->d_half ? h->margin_mfma : 0.0f;
     return MI355REC_OK;
 }
 
@@ -1809,6 +1826,7 @@ int mi355rec_enqueue_scores(mi355rec_t* h, int64_t local_row, const float* query
     if (rc) return rc;
     QueryArg qa;
     std::memset(&qa, 0, sizeof qa);
+    qa.margin = h->margin_mix;
     if (local_row >= 0) {
         hipLaunchKernelGGL((scan_kernel<ScanConfig, true, true>), dim3(h->grid), dim3(kScanBlock), 0, s, h->d_feats,
                            h->n, h->rows_per_block, h->iters, h->row_base, qa, h->d_feats + local_row * kDim,

@@ -41,7 +41,7 @@
 
 namespace mi355 {
 
-constexpr float kHalfMargin = kBqMarginFlush;
+constexpr float kHalfMargin = kBqMarginFlush;   // what a launch claims unless the device check below allows the tighter bound
 constexpr uint32_t kHalfNaN2 = kBqNaN2;        // two fp16 quiet NaNs: "always score this row exactly"
 constexpr int kHalfSeedBlock = 512;
 constexpr int kHalfSeedWaves = kHalfSeedBlock / 64;
@@ -117,6 +117,37 @@ __device__ __forceinline__ float half_dot(const uint32_t (&qh)[6], uint32_t a0, 
         acc = __builtin_fmaf(static_cast<float>(x[1]), static_cast<float>(y[1]), acc);
     }
     return acc;
+}
+
+// ---- does this device keep fp16 subnormals where the replica's arithmetic meets them? ---------------
+// The bound is 1.0e-3 (kBqMargin) when they are kept and 1.5e-3 (kBqMarginFlush) when a unit flushes them
+// (batched.hip.h, "Margin").  Three places matter: v_cvt_pk_f16_f32 when the replica is built (out[1]: fp16(3e-6)
+// converted back), v_fma_mix_f32's fp16 operands in the single-query scan (out[2], out[3]: a subnormal on the row
+// side, on the query side, times 1.0) and the matrix core in the multi-query pass (out[0], as bq_selfcheck_kernel).
+// One wave; the host compares with the exact values.
+__global__ void half_selfcheck_kernel(float* out) {
+    const int lane = threadIdx.x;
+    bq_h8 A = {0, 0, 0, 0, 0, 0, 0, 0}, B = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (lane < 32) {
+        A[0] = __builtin_bit_cast(_Float16, static_cast<unsigned short>(0x0010));   // 2^-20, an fp16 subnormal
+        B[0] = __builtin_bit_cast(_Float16, static_cast<unsigned short>(0x3c00));   // 1.0
+    }
+    const bq_f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const bq_f16v D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, zero, 0, 0, 0);
+    const uint32_t packed = bq_pack_h2(3.0e-6f * (1.0f + static_cast<float>(lane)), 0.0f);   // lane 0: 3e-6
+    // opaque operands: the compiler must not fold the products
+    uint32_t sub = 0x00000010u, one = 0x00003c00u;
+    asm volatile("" : "+v"(sub), "+v"(one));
+    const uint32_t qs[6] = {one, 0u, 0u, 0u, 0u, 0u};
+    const uint32_t qz[6] = {sub, 0u, 0u, 0u, 0u, 0u};
+    const float row_side = half_dot(qs, sub, 0u, 0u, 0u, 0u, 0u);
+    const float query_side = half_dot(qz, one, 0u, 0u, 0u, 0u, 0u);
+    if (lane == 0) {
+        out[0] = D[0];
+        out[1] = static_cast<float>(__builtin_bit_cast(bq_h2, packed)[0]);
+        out[2] = row_side;
+        out[3] = query_side;
+    }
 }
 
 // ---- the sample that seeds the launch-wide cutoff -------------------------------------
@@ -358,7 +389,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_half_kernel(
         if (sm->seeds >= topk) {   // uniform
             const uint64_t t = block_select_threshold<kBlock, kHalfSeedPerThread>(mine, topk, true, 0, s_sel);
             const float v = ordered_to_score(static_cast<uint32_t>(t >> 32));
-            cutoff = v - 2.0f * kHalfMargin - kBqSlack;
+            cutoff = v - 2.0f * qarg.margin - kBqSlack;
         }
     }
     uint64_t thr = 0;
@@ -426,7 +457,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_half_kernel(
             if (local_thr > thr) {
                 thr = local_thr;
                 if (hq.ok) {
-                    const float local_cut = ordered_to_score(static_cast<uint32_t>(thr >> 32)) - kHalfMargin - kBqSlack;
+                    const float local_cut = ordered_to_score(static_cast<uint32_t>(thr >> 32)) - qarg.margin - kBqSlack;
                     cutoff = local_cut > cutoff ? local_cut : cutoff;
                 }
             }

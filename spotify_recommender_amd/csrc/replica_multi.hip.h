@@ -63,7 +63,7 @@ struct HalfMultiArg {
                                           // so that two batches (this one and the next one's sample) fit one kernel's arguments
     long long exclude[kHmQueries];        // global row to skip, -1 = none
     uint32_t ptr_mask;
-    uint32_t pad;
+    float margin;                         // error bound the pre-filter may claim on this device (set by the host)
 };
 
 __host__ __device__ inline void hm_set_pointer(HalfMultiArg& arg, int i, const float* p) {
@@ -230,6 +230,7 @@ struct alignas(16) HalfMultiSmem {
     int lock[kHmQueries];
     uint32_t ok[kHmQueries];
     int rescored;
+    float margin;                               // the error bound this launch claims (HalfMultiArg::margin)
 };
 
 // -T' as the fp16 pair (hi, lo) of the B fragment's threshold slots.  T' = -inf ("every row is a
@@ -242,7 +243,7 @@ __device__ __forceinline__ uint32_t hm_threshold_slots(float cut) {
 }
 
 // The launch-wide cutoff of one query from its sample maxima, by one wave (see the header).
-__device__ __forceinline__ float hm_seed_cutoff(const uint32_t* __restrict__ vals, int n_seed, int topk) {
+__device__ __forceinline__ float hm_seed_cutoff(const uint32_t* __restrict__ vals, int n_seed, int topk, float margin) {
     const int lane = threadIdx.x & 63;
     // all of the lane's (up to 32) sample maxima are requested before the first is looked at
     constexpr int kPer = kHalfSeedMaxGrid * kHalfSeedWaves / 64;
@@ -270,7 +271,7 @@ __device__ __forceinline__ float hm_seed_cutoff(const uint32_t* __restrict__ val
         if (c >= topk) lo = mid; else hi = mid - 1u;
     }
     if (lo == 0u) return -__builtin_inff();   // fewer than `topk` usable (positive) maxima: no seed
-    return ordered_to_score(lo) - 2.0f * kHalfMargin - kBqSlack;
+    return ordered_to_score(lo) - 2.0f * margin - kBqSlack;
 }
 
 // Per-query spin lock in LDS, taken by a whole wave (lane 0 spins; the holder is another wave of the
@@ -291,6 +292,7 @@ __device__ __forceinline__ void hm_unlock(int* lock) {
 // Under the query's lock: the kept keys are cut back to topk when the new ones would not fit (or pile up),
 // which raises the query's threshold and, through the B fragment, its cutoff.
 __device__ __forceinline__ void hm_append_locked(HalfMultiSmem& sm, int q0, bool mine, uint64_t key, int topk) {
+    const float margin = sm.margin;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     // an append of up to 64 keys must fit behind the kept ones: exact cut when topk is large
@@ -319,7 +321,7 @@ __device__ __forceinline__ void hm_append_locked(HalfMultiSmem& sm, int q0, bool
             if (t > t_before) {
                 __hip_atomic_store(&sm.thr[q0], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (sm.ok[q0]) {
-                    const float local_cut = ordered_to_score(static_cast<uint32_t>(t >> 32)) - kHalfMargin - kBqSlack;
+                    const float local_cut = ordered_to_score(static_cast<uint32_t>(t >> 32)) - margin - kBqSlack;
                     if (local_cut > sm.cut[q0]) {
                         sm.cut[q0] = local_cut;
                         reinterpret_cast<uint32_t*>(&sm.bfrag[32 + q0])[2] = hm_threshold_slots(local_cut);
@@ -496,13 +498,16 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
         for (int w = 0; w < kHmWaves; ++w) sm.pcount[w][tid] = 0;
         sm.ok[tid] = ok ? 1u : 0u;
     }
-    if (tid == 0) sm.rescored = 0;
+    if (tid == 0) {
+        sm.rescored = 0;
+        sm.margin = arg.margin;
+    }
     __syncthreads();
     if (n_seed > 0) {
         for (int qi = wave; qi < n_queries; qi += kHmWaves) {
             if (sm.ok[qi]) {   // uniform
                 // the (topk + 1)-th largest: the query's own row may be among the sampled ones (hm_sample_regions)
-                const float cut = hm_seed_cutoff(seed_vals + static_cast<int64_t>(qi) * n_seed, n_seed, topk + 1);
+                const float cut = hm_seed_cutoff(seed_vals + static_cast<int64_t>(qi) * n_seed, n_seed, topk + 1, arg.margin);
                 if (lane == 0) {
                     sm.cut[qi] = cut;
                     reinterpret_cast<uint32_t*>(&sm.bfrag[32 + qi])[2] = hm_threshold_slots(cut);

@@ -32,6 +32,8 @@ def main():
     q = t[torch.tensor(rows, device="cuda")].cpu().numpy()
     out = {"rows": n, "topn": topn, "single_calls": [], "streams": []}
     with CosineEngine(t) as eng:
+        st0 = eng.stats()
+        out["margin_single"], out["margin_multi"] = round(float(st0.replica_margin_single), 6), round(float(st0.replica_margin_multi), 6)
         eng.set_batch_path(capi.BATCH_HALF)
         sizes = (1, 2, 4, 8, 12, 16, 24, 32) if not args.only_stream else ()
         for nb in sizes:
