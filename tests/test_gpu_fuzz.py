@@ -121,3 +121,83 @@ def test_two_handles_on_two_streams_share_one_matrix():
             want = oracle.scores(f, f[r])
             ci, _ = oracle.topn_canonical(want, r, 50)
             assert unpack_keys(got[i])[0].tolist() == ci.tolist()
+
+
+def test_randomised_multi_query_and_sharded_streams():
+    """The round-3 paths under the same hostile catalogues: the multi-query pass over the fp16 replica
+    (forced: MI355REC_BATCH_HALF), streams of batches (merge + next sample riding in the launch), and the
+    row-sharded stream with worker threads in both window modes — random shard counts, windows, batch sizes
+    and topn, special values included; every result against the oracle."""
+    import torch
+    assert torch.cuda.is_available()
+    from spotify_recommender_amd.engine import CosineEngine, NodeEngine, unpack_keys
+    cases = int(os.environ.get("FUZZ_CASES2", "14"))
+    rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "20261004")))
+    for case in range(cases):
+        rows = int(rng.choice([66_000, 90_000, 150_000, 400_000, 1_100_000], p=[.2, .25, .25, .2, .1]))
+        f = make_catalogue(rng, rows)
+        topn = int(rng.choice([1, 5, 50, 100, 128]))
+        # ---- one handle: forced multi-query passes, then a stream of batches
+        with CosineEngine(f) as eng:
+            eng.set_batch_path(3)
+            batch = int(rng.integers(2, 45))
+            qrows = rng.integers(0, rows, size=batch)
+            queries = f[qrows].copy()
+            excl = np.where(rng.random(batch) < 0.8, qrows, -1).astype(np.int64)
+            if batch > 3:
+                queries[3] = rng.normal(0, 1, 12).astype(np.float32)
+                excl[3] = -1
+            idx, sc, counts = eng.query_batch_topn(queries, excl, topn)
+            for b in range(batch):
+                want = oracle.scores(f, queries[b])
+                try:
+                    assert_topn_matches(idx[b][:counts[b]], sc[b][:counts[b]], want, int(excl[b]), topn)
+                except AssertionError as e:  # pragma: no cover
+                    raise AssertionError(f"case {case} multi-query pass: rows {rows} batch {batch} b {b} topn {topn}: {e}") from e
+            eng.set_batch_path(0)
+            outs = []
+            for _ in range(4):
+                nb = int(rng.integers(1, 34))
+                br = rng.integers(0, rows, size=nb)
+                keys = torch.zeros(nb * topn, dtype=torch.int64, device="cuda")
+                eng.enqueue_batch_keys_streamed(f[br], br.astype(np.int64), topn, keys)
+                outs.append((br, keys))
+            eng.enqueue_flush()
+            torch.cuda.synchronize()
+            for br, keys in outs:
+                got = keys.cpu().numpy().reshape(len(br), topn)
+                for b, r in enumerate(br):
+                    want = oracle.scores(f, f[r])
+                    i2, s2 = unpack_keys(got[b])
+                    try:
+                        assert_topn_matches(i2, s2, want, int(r), topn)
+                    except AssertionError as e:  # pragma: no cover
+                        raise AssertionError(f"case {case} stream of batches: rows {rows} q {r} topn {topn}: {e}") from e
+        # ---- the sharded stream, both window modes
+        shards = int(rng.choice([1, 2, 3, 5]))
+        window = int(rng.choice([1, 3, 8, 16, 40]))
+        with NodeEngine(f, devices=[0] * shards) as node:
+            node.set_window(window)
+            for batched in (True, False):
+                node.set_window_mode(batched)
+                nq = int(rng.integers(1, 2 * window + 3))
+                qr = rng.integers(0, rows, size=nq).tolist()
+                tickets = [node.enqueue_row(r, topn) for r in qr]
+                vec = rng.random(12, dtype=np.float32)
+                tv = node.enqueue_query(vec, -1, topn)
+                if rng.random() < 0.5:
+                    node.enqueue_flush()
+                keep = qr[-2 * window:] if window > 1 else qr[-2:]          # what the ring of 4 windows certainly still holds
+                for t, r in list(zip(tickets, qr))[-len(keep):]:
+                    i3, s3 = node.wait(t, topn)
+                    want = oracle.scores(f, f[r])
+                    try:
+                        assert_topn_matches(i3, s3, want, r, topn)
+                    except AssertionError as e:  # pragma: no cover
+                        raise AssertionError(f"case {case} sharded stream: rows {rows} shards {shards} window {window} batched {batched} q {r}: {e}") from e
+                i3, s3 = node.wait(tv, topn)
+                assert_topn_matches(i3, s3, oracle.scores(f, vec), -1, topn)
+            # and one synchronous query through the workers
+            r = int(rng.integers(0, rows))
+            i4, s4 = node.query_row_topn(r, topn)
+            assert_topn_matches(i4, s4, oracle.scores(f, f[r]), r, topn)
