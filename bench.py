@@ -59,8 +59,10 @@ def parse_args():
                     help="N > 1: single queries whose per-rank keys share one all-gather")
     ap.add_argument("--no-streamed", action="store_true",
                     help="merge every query in its own launch instead of inside the next query's scan launch")
+    ap.add_argument("--replica-fp16", action="store_true",
+                    help="A/B: single queries scan the 24 B/row fp16 replica instead of the 12 B/row 8-bit one")
     ap.add_argument("--no-replica", action="store_true",
-                    help="scan the fp32 rows (48 B/row, the reference's own traffic) instead of the fp16 replica")
+                    help="scan the fp32 rows (48 B/row, the reference's own traffic) instead of a replica")
     ap.add_argument("--latency-queries", type=int, default=1000)
     ap.add_argument("--virtual-shards", type=int, default=0,
                     help="drive the product's single-process row-sharded engine (mi355rec_create_sharded_on) with this "
@@ -87,7 +89,23 @@ def metric_label(n: int, topn: int) -> str:
     return f"queries/sec, cosine top-{topn} over a {rows} x 12 fp32 catalogue"
 
 
-def pmc_traffic(rows_local: int, replica: bool = False):
+def replica_desc(st):
+    """What a single query streams, from the handle's stats: (bytes per row, algorithmic bytes per launch,
+    kernel, its name in the PMC file, dtype label, short replica label)."""
+    rb = int(st.replica_single_row_bytes) if st.replica_active else 0
+    if rb == 12:
+        return (12, int(st.replica_single_bytes_per_query), "mi355::scan_q8_kernel<Q8Cfg<512,4,2>, {targs}>",
+                "scan_q8_kernel", "f32 (every score is the exact fp32 chain; a 12 B/row 8-bit replica only rules rows out)",
+                "8-bit replica (12 B/row")
+    if rb == 24:
+        return (24, int(st.replica_single_bytes_per_query), "mi355::scan_half_kernel<HalfCfg<512,4,2>, {targs}>",
+                "scan_half_kernel", "f32 (every score is the exact fp32 chain; a 24 B/row fp16 replica only rules rows out)",
+                "fp16 replica (24 B/row")
+    return (BYTES_PER_ROW, int(st.bytes_per_query), "mi355::scan_kernel<ScanCfg<512,1,6,2>, {targs}, 0, true>",
+            "scan_kernel", "f32", "fp32 rows (48 B/row")
+
+
+def pmc_traffic(alg: int, want: str):
     """HBM bytes per scan launch from the committed rocprofv3 PMC passes
     (profiles/*_pmc_hbm_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs
     of this same script, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950
@@ -96,8 +114,6 @@ def pmc_traffic(rows_local: int, replica: bool = False):
     try:
         files = sorted((ROOT / "profiles").glob("*_pmc_hbm_traffic.json"))
         data = json.loads(files[-1].read_text())
-        want = "scan_half_kernel" if replica else "scan_kernel"
-        alg = (rows_local + 1) // 2 * 48 if replica else rows_local * BYTES_PER_ROW
         for name, k in data["kernels"].items():
             if want in name and k.get("algorithmic_bytes_per_launch") == alg:
                 return int(k["hbm_bytes_per_launch"]), f"profiles/{files[-1].name}"
@@ -199,8 +215,11 @@ def run_node(args, json_fd):
         node.set_transport(capi.TRANSPORT_RCCL)
     elif args.transport == "peer":
         node.set_transport(capi.TRANSPORT_PEER)
+    replica_mode = capi.REPLICA_FP16 if args.replica_fp16 else capi.REPLICA_AUTO
     if args.no_replica:
         node.set_replica(capi.REPLICA_OFF)
+    elif args.replica_fp16:
+        node.set_replica(replica_mode)
     transport = node.info()["transport"]
 
     def sync_all():
@@ -232,7 +251,8 @@ def run_node(args, json_fd):
         return dt, last, shard_ms, host_us, st1["exchanges"] - st0["exchanges"]
 
     elapsed, last_result, shard_ms, host_us, exchanges = timed_stream()
-    replica = bool(node.shard_stats(0).replica_active)
+    st_headline = node.shard_stats(0)   # which copy of the rows the headline's queries scan
+    replica = bool(st_headline.replica_active)
     rows_local = max(info["shard_rows"])
 
     # one query alone, end to end, through the synchronous call the C++ Recommender makes
@@ -248,7 +268,7 @@ def run_node(args, json_fd):
     if replica:
         node.set_replica(capi.REPLICA_OFF)
         dt32, _, ms32, host32, _ = timed_stream()
-        node.set_replica(capi.REPLICA_AUTO)
+        node.set_replica(replica_mode)
         k_ms = sum(ms32) / len(ms32) if ms32 else 0.0
         fp32_rows = {"ms_per_step": round(dt32 / args.steps * 1e3, 5), "value": round(args.steps / dt32, 2), "unit": "queries/s",
                      "host_enqueue_us_per_query": round(host32, 2),
@@ -334,15 +354,16 @@ def run_node(args, json_fd):
         checked += 1
 
     k_ms = sum(shard_ms) / len(shard_ms) if shard_ms else 0.0
-    alg = (rows_local + 1) // 2 * 48 if replica else rows_local * BYTES_PER_ROW
+    row_bytes, alg, kernel_label, kernel_name, dtype_label, replica_label = replica_desc(st_headline)
+    kernel_label = kernel_label.format(targs="true, true") + f" ({replica_label})"
     achieved = alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
-    traffic_bytes, traffic_source = pmc_traffic(rows_local, replica)
+    traffic_bytes, traffic_source = pmc_traffic(alg, kernel_name)
     line = {
         "metric": metric_label(n, topn), "value": round(args.steps / elapsed, 2), "unit": "queries/s",
         "n_gpus": 1 if virtual else g, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None,
-        "dtype": ("f32 (every score is the exact fp32 chain; a 24 B/row fp16 replica only rules rows out)" if replica else "f32"),
+        "dtype": dtype_label,
         "data": "synthetic",
         "config": {
             "workload": f"{n} synthetic tracks x 12 fp32 features, top-{topn}, row-sharded over "
@@ -364,12 +385,11 @@ def run_node(args, json_fd):
         "p99_ms": round(lat[min(len(lat) - 1, int(len(lat) * 0.99))], 4) if lat else None,
         "roofline": {
             "bound": "hbm", "per": "shard launch (mean over shards)",
-            "kernel": ("mi355::scan_half_kernel<HalfCfg<512,4,2>, true, true> (24 B/row fp16 replica)" if replica
-                       else "mi355::scan_kernel<ScanCfg<512,1,6,2>, true, false, 0, true> (48 B/row)"),
+            "kernel": kernel_label,
             "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None,
             "traffic": traffic_bytes, "traffic_source": traffic_source,
-            "algorithmic_bytes_per_launch": alg, "bytes_per_row": 24 if replica else BYTES_PER_ROW,
+            "algorithmic_bytes_per_launch": alg, "bytes_per_row": row_bytes,
             "survey_bytes_per_row": BYTES_PER_ROW, "avg_kernel_ms": round(k_ms, 5) if k_ms else None,
             "kernel_ms_per_shard": [round(m, 5) for m in shard_ms],
             "infinity_cache_resident": bool(alg <= 128 * 2**20),
@@ -461,9 +481,13 @@ def main():
 
     eng = CosineEngine(shard, row_base=lo)
     from spotify_recommender_amd import capi
+    replica_mode = capi.REPLICA_FP16 if args.replica_fp16 else capi.REPLICA_AUTO
     if args.no_replica:
         eng.set_replica(capi.REPLICA_OFF)
-    replica = bool(eng.stats().replica_active)
+    elif args.replica_fp16:
+        eng.set_replica(replica_mode)
+    st_headline = eng.stats()       # which copy of the rows the headline's queries scan
+    replica = bool(st_headline.replica_active)
     sharded = ShardedEngine(eng, max_topn=topn, always_gather=force_sharded) if (world > 1 or force_sharded) else None
     out_keys = torch.zeros(topn, dtype=torch.int64, device=dev)
 
@@ -565,7 +589,7 @@ def main():
             eng.query_row_topn(q_rows[k], topn)
             lat32.append((time.perf_counter() - t1) * 1e3)
         lat32.sort()
-        eng.set_replica(capi.REPLICA_AUTO)
+        eng.set_replica(replica_mode)
         k_ms = float(st32.last_scan_ms)
         t32, src32 = pmc_traffic(hi - lo, False)
         fp32_rows = {"kernel": "mi355::scan_kernel<ScanCfg<512,1,6,2>, true, false, 0, true>", "steps": args.steps,
@@ -768,16 +792,16 @@ def main():
     if rank == 0:
         qps = args.steps / elapsed
         scan_ms = float(st.last_scan_ms) if not args.no_kernel_events else 0.0
-        alg_bytes = int(st.replica_bytes_per_query) if replica else (hi - lo) * BYTES_PER_ROW
+        row_bytes, alg_bytes, kernel_fmt, kernel_pmc, dtype_label, replica_label = replica_desc(st_headline)
         achieved = (alg_bytes / (scan_ms * 1e-3) / 1e9) if scan_ms > 0 else None
         # a pass only finds its bytes in the 256 MiB Infinity Cache if the whole buffer survives one
         # full pass of itself plus the fp32 fetches: half the cache is the most that can be hoped for
         cache_resident = alg_bytes <= 128 * 2**20
-        traffic_bytes, traffic_source = pmc_traffic(hi - lo, replica)
+        traffic_bytes, traffic_source = pmc_traffic(alg_bytes, kernel_pmc)
         if replica:
             targs = "true, true" if streamed else ("true, false" if sharded is None else "false, true")
-            kernel_name = ("mi355::scan_half_kernel<HalfCfg<512,4,2>, " + targs + "> over the "
-                           "fp16 replica (24 B/row; rows it cannot rule out are fetched from the fp32 matrix and scored by "
+            kernel_name = (kernel_fmt.format(targs=targs) + " over the "
+                           + replica_label + "; rows it cannot rule out are fetched from the fp32 matrix and scored by "
                            "the exact chain" + (")" if (sharded is None and not streamed) else "; the previous query's merge rides in its last workgroup)"))
         else:
             kernel_name = ("mi355::scan_kernel<ScanCfg<512,1,6,2>, true, false, 0, true> (query = catalogue row; the previous "
@@ -789,8 +813,7 @@ def main():
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": ("f32 (every score is the exact fp32 chain; a 24 B/row fp16 replica only rules rows out)" if replica
-                      else "f32"), "data": "synthetic",
+            "dtype": dtype_label, "data": "synthetic",
             "config": {
                 "workload": f"{n} synthetic tracks x 12 fp32 features, top-{topn}, "
                             + (f"1 MI355X ({workload_label(n, topn)})" if world == 1 else
@@ -811,7 +834,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None,
                 "traffic": traffic_bytes, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "bytes_per_row": 24 if replica else BYTES_PER_ROW,
+                "bytes_per_row": row_bytes,
                 "survey_bytes_per_row": BYTES_PER_ROW,
                 "avg_kernel_ms": round(scan_ms, 5) if scan_ms else None,
                 "merge_kernel_ms": round(float(st.last_merge_ms), 5),
@@ -824,14 +847,15 @@ def main():
             # rows the timed stream itself sent to the exact chain (counters read right before and after it)
             line["roofline"]["rescored_rows_per_query"] = round(
                 (rc_after["rescored_rows"] - rc_before["rescored_rows"]) / max(1, rc_after["scans"] - rc_before["scans"]), 1)
-            line["roofline"]["prefilter_margin"] = round(float(st.replica_margin_single), 6)
-            line["roofline"]["note"] = ("achieved / frac are for the bytes this kernel streams (the 24 B/row fp16 replica); "
+            line["roofline"]["prefilter_margin"] = ("per query: l1(q/|q|)/254 + 3e-5 (<= 0.0137)" if row_bytes == 12
+                                                    else round(float(st.replica_margin_single), 6))
+            line["roofline"]["note"] = ("achieved / frac are for the bytes this kernel streams (the " + replica_label + ")); "
                                         "SURVEY.md §8(d) prices a query at 48 B/row, i.e. the fp32 scan in `fp32_rows`")
             if scan_ms > 0:
                 # the same launch priced at the survey's 48 B/row: exceeds the HBM peak BECAUSE those bytes are not moved
                 eq = (hi - lo) * BYTES_PER_ROW / (scan_ms * 1e-3) / 1e9
                 line["roofline"]["at_survey_bytes_per_row"] = {"achieved": round(eq, 1), "frac": round(eq / HBM_PEAK_GBPS, 4),
-                                                               "note": "480 MB-equivalent per query; the kernel moves 0.50x of that"}
+                                                               "note": f"{(hi - lo) * BYTES_PER_ROW / 1e6:.0f} MB-equivalent per query; the kernel moves {row_bytes / BYTES_PER_ROW:.2f}x of that"}
         if fp32_rows is not None:
             line["fp32_rows"] = fp32_rows
             # SURVEY.md §8(d) prices a query at 48 B/row: that is the fp32 scan's roofline, measured in this run

@@ -81,7 +81,11 @@ typedef struct {
     float replica_build_ms;    /* device time of building the replica (once, at create)     */
     float replica_margin_single; /* error bound the replica pre-filters claim on this device: 1.0e-3 where the unit  */
     float replica_margin_multi;  /* demonstrably keeps fp16 subnormals (checked when the replica is built), else 1.5e-3:
-                                    v_fma_mix_f32 (single-query scan) / the matrix core (multi-query pass)             */
+                                    v_fma_mix_f32 (fp16 single-query scan) / the matrix core (multi-query pass)        */
+    int64_t replica_single_bytes_per_query; /* algorithmic bytes of one SINGLE-query scan over the replica it currently
+                                    uses: ceil(rows/4) * 48 over the 8-bit one, ceil(rows/2) * 48 over the fp16 one   */
+    int32_t replica_single_row_bytes; /* 12 (8-bit replica), 24 (fp16 replica, MI355REC_REPLICA_FP16) or 0 (no replica)  */
+    int32_t reserved0;
 } mi355rec_stats_t;
 
 /* Number of visible HIP devices (0 when there is none / no driver). */
@@ -123,7 +127,14 @@ int mi355rec_create_device(const float* feats_dev, int64_t n, int dim,
  *   AUTO (default): shards of >= 1 M rows scan the replica, smaller ones the
  *                   fp32 rows (a query is launch-bound there either way);
  *   OFF:            always the fp32 rows (the reference's own traffic, 48 B/row);
- *   ON:             always the replica.
+ *   ON:             always the replica;
+ *   FP16:           as ON, with single queries on the fp16 replica (see below).
+ * A handle with a replica holds two encodings of the normalised rows: fp16
+ * (24 B/row, csrc/replica.hip.h: what the multi-query and batched passes
+ * read, error bound 1.0e-3) and 8-bit (12 B/row, csrc/replica_q8.hip.h: what
+ * single queries scan; the query stays fp32, the bound is per query,
+ * l1(q/|q|)/254 + 3e-5 <= 0.0137).  Both are pre-filters in front of the same
+ * exact chain; MI355REC_REPLICA_FP16 exists for A/B measurements.
  * The batched matrix-core path reads its rows from the replica too (they are
  * stored in exactly the form its MFMA operand wants) unless the mode is OFF.
  * The score vector (mi355rec_scores*), rounds of topn > 1024 after the first
@@ -135,6 +146,7 @@ int mi355rec_create_device(const float* feats_dev, int64_t n, int dim,
 #define MI355REC_REPLICA_AUTO 0
 #define MI355REC_REPLICA_OFF 1
 #define MI355REC_REPLICA_ON 2
+#define MI355REC_REPLICA_FP16 3
 int mi355rec_set_replica(mi355rec_t* h, int mode);
 int mi355rec_rebuild_replica(mi355rec_t* h);
 /* Diagnostics, cumulative since create (synchronises the device): scans that

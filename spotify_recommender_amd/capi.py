@@ -16,7 +16,7 @@ LIB_PATH = PKG / "libmi355rec.so"
 DIM = 12
 MAX_TOPN_FAST = 1024
 BATCH_AUTO, BATCH_MULTI, BATCH_MFMA, BATCH_HALF = 0, 1, 2, 3
-REPLICA_AUTO, REPLICA_OFF, REPLICA_ON = 0, 1, 2
+REPLICA_AUTO, REPLICA_OFF, REPLICA_ON, REPLICA_FP16 = 0, 1, 2, 3
 TRANSPORT_PEER, TRANSPORT_RCCL = 1, 2
 
 OK = 0
@@ -46,6 +46,9 @@ class Stats(ctypes.Structure):
         ("replica_build_ms", c_float),
         ("replica_margin_single", c_float),
         ("replica_margin_multi", c_float),
+        ("replica_single_bytes_per_query", c_int64),
+        ("replica_single_row_bytes", c_int32),
+        ("reserved0", c_int32),
     ]
 
 

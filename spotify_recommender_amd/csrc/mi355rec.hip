@@ -21,6 +21,7 @@
 #include "kernels.hip.h"
 #include "replica.hip.h"
 #include "replica_multi.hip.h"
+#include "replica_q8.hip.h"
 
 using namespace mi355;
 
@@ -47,6 +48,7 @@ constexpr int kDirectResultSlots = 2048;   // results up to this many slots are 
 using ScanConfig = DefaultScanCfg;
 using MultiConfig = DefaultMultiCfg;
 using HalfConfig = DefaultHalfCfg;
+using Q8Config = DefaultQ8Cfg;
 constexpr int kRideTopnMax = 640;   // largest topN whose merge rides in the next fp32 scan launch
 constexpr int64_t kReplicaMinRows = 65536;      // smaller shards are created without a replica (built on demand by set_replica(ON))
 constexpr int64_t kHalfAutoMinRows = 1000000;   // below this a query is launch-bound either way (measured: 11.8 vs
@@ -54,6 +56,17 @@ constexpr int64_t kHalfAutoMinRows = 1000000;   // below this a query is launch-
 constexpr int kScanBlock = ScanConfig::kBlock;
 constexpr int kScanTileRows = ScanConfig::kTileRows;
 const float* const kNoQueryPtr = nullptr;   // kernel argument of the variants that take the query by value
+
+// Launch geometry of a single-query scan over a replica of the catalogue (fp16: replica.hip.h,
+// 8-bit: replica_q8.hip.h).
+struct ReplicaGeom {
+    int grid = 0, iters = 0;            // plain launch
+    int sgrid = 0, siters = 0;          // streamed launch without seed riders (one more workgroup is the merger)
+    int seed_grid = 0;                  // sampled regions ...
+    int64_t seed_stride = 0;            // ... and the rows between their starts
+    int riders = 0;                     // seed riders of a streamed launch
+    int r_scan = 0, r_iters = 0;        // its scanners and their tiles
+};
 
 }  // namespace
 
@@ -87,11 +100,11 @@ struct mi355rec {
     uint32_t* d_half_seed = nullptr;    // kHalfSeedMaxGrid x 8 sample maxima of the query in flight
     uint32_t* d_half_mseed = nullptr;   // kHmQueries x that: the sample of a multi-query pass over the replica
     unsigned long long* d_half_rescored = nullptr;   // [kRideMaxLists] rows sent to the exact chain, per workgroup slot
-    int64_t half_scans = 0;             // replica scans enqueued since create
-    int hgrid = 0, hiters = 0;          // plain launch
-    int hsgrid = 0, hsiters = 0;        // streamed launch (one more workgroup is the merger)
-    int hseed_grid = 0;
-    int64_t hseed_stride = 0;
+    int64_t half_scans = 0;             // replica scans enqueued since create ...
+    int64_t q8_scans = 0;               // ... of which over the 8-bit replica
+    ReplicaGeom hg;                     // geometry of the scan over the fp16 replica ...
+    uint4* d_q8 = nullptr;              // 8-bit replica (replica_q8.hip.h): ((n + 3) / 4) quads of rows x 48 B
+    ReplicaGeom qg;                     // ... and over the 8-bit one
     int replica_mode = 0;               // MI355REC_REPLICA_AUTO / _OFF / _ON
     bool replica_allowed = true;        // false: created under MI355REC_REPLICA=0
     float replica_build_ms = 0.f;
@@ -109,10 +122,9 @@ struct mi355rec {
         int topn = 0;
         uint64_t* out = nullptr;
         int seed_buf = 0;               // which of d_stream_seed holds ITS sample maxima
+        bool q8 = false;                // that sample was taken over the 8-bit replica, so its scan runs there
     } stashed;
     uint32_t* d_stream_seed[2] = {nullptr, nullptr};
-    int hs_riders = 0;                  // seed riders of a streamed launch
-    int hs_scan = 0, hs_iters = 0;      // its scanners and their tiles
     // a STREAM of batches over the replica (mi355rec_enqueue_batch_keys_streamed)
     bool mstream_ready = false;
     uint64_t* d_mstream_lists[2] = {nullptr, nullptr};   // [kHmQueries][hgrid][kMultiMaxTopK], alternating
@@ -272,59 +284,69 @@ void plan_multi_grid(mi355rec* h, int blocks_per_cu) {
     h->mrows_per_block = stride;  // seed kernel only: distance between sampled regions
 }
 
-// Scan over the fp16 replica (replica.hip.h): tiles of 1024 rows dealt round-robin; the
-// seed kernel samples 1024 rows of up to 256 evenly spaced regions (>= 1024 rows apart, so
-// no row is sampled twice).
+// Scan over a replica: tiles of `tile_rows` rows dealt round-robin; the seed kernel samples
+// `tile_rows` rows of up to 256 evenly spaced regions (>= tile_rows apart, so no row is sampled
+// twice; starts are multiples of `align` rows, the replica's packing unit).
+ReplicaGeom plan_replica(const mi355rec* h, int occ, int tile_rows, int align, double us_per_tile) {
+    ReplicaGeom g;
+    if (occ < 1) occ = 1;
+    if (occ > 3) occ = 3;
+    int64_t max_blocks = static_cast<int64_t>(h->cus) * occ;
+    if (max_blocks > kRideMaxLists) max_blocks = kRideMaxLists;
+    const int64_t tiles = (h->n + tile_rows - 1) / tile_rows;
+    g.grid = static_cast<int>(tiles < max_blocks ? tiles : max_blocks);
+    g.iters = static_cast<int>((tiles + g.grid - 1) / g.grid);
+    g.sgrid = g.grid > 1 ? g.grid - 1 : 1;
+    g.siters = static_cast<int>((tiles + g.sgrid - 1) / g.sgrid);
+    int64_t sg = h->n / tile_rows;
+    if (sg > kHalfSeedMaxGrid) sg = kHalfSeedMaxGrid;
+    g.seed_grid = static_cast<int>(sg);
+    g.seed_stride = sg > 0 ? (h->n / sg) / align * align : 0;
+    // seed riders of a streamed launch: each takes four regions per memory round trip (~2 us) and
+    // should be done well before the scanners (us_per_tile each) are
+    g.riders = 0;
+    g.r_scan = g.sgrid;
+    g.r_iters = g.siters;
+    if (sg > 0 && g.grid >= 16) {
+        int rounds = static_cast<int>(g.siters * us_per_tile / 12.0);
+        if (rounds < 1) rounds = 1;
+        int riders = static_cast<int>((sg + 4 * rounds - 1) / (4 * rounds));
+        if (riders > g.grid / 8) riders = g.grid / 8;
+#ifdef MI355REC_EXPERIMENTS   // A/B builds of tools/ only: the product reads no tuning knob from the environment
+        if (const char* e = std::getenv("MI355REC_EXP_RIDERS")) {
+            const int v = std::atoi(e);
+            if (v >= 0 && v <= g.grid / 2) riders = v;
+        }
+#endif
+        if (riders > 0) {
+            g.riders = riders;
+            g.r_scan = g.grid - 1 - riders;
+            g.r_iters = static_cast<int>((tiles + g.r_scan - 1) / g.r_scan);
+        }
+    }
+    return g;
+}
+
 void plan_half_grid(mi355rec* h) {
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_half_kernel<HalfConfig, true, false>, HalfConfig::kBlock, 0) != hipSuccess || occ < 1) occ = 1;
-    if (occ > 3) occ = 3;
-#ifdef MI355REC_EXPERIMENTS   // A/B builds of tools/ only: the product reads no tuning knob from the environment
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_half_kernel<HalfConfig, true, false>, HalfConfig::kBlock, 0) != hipSuccess) occ = 1;
+#ifdef MI355REC_EXPERIMENTS
     if (const char* e = std::getenv("MI355REC_EXP_HOCC")) {
         const int v = std::atoi(e);
         if (v >= 1 && v <= 4) occ = v;
     }
 #endif
-    int64_t max_blocks = static_cast<int64_t>(h->cus) * occ;
-    if (max_blocks > kRideMaxLists) max_blocks = kRideMaxLists;
-    const int64_t tiles = (h->n + HalfConfig::kTileRows - 1) / HalfConfig::kTileRows;
-    h->hgrid = static_cast<int>(tiles < max_blocks ? tiles : max_blocks);
-    h->hiters = static_cast<int>((tiles + h->hgrid - 1) / h->hgrid);
-    h->hsgrid = h->hgrid > 1 ? h->hgrid - 1 : 1;
-    h->hsiters = static_cast<int>((tiles + h->hsgrid - 1) / h->hsgrid);
-    int64_t sg = h->n / HalfConfig::kTileRows;
-    if (sg > kHalfSeedMaxGrid) sg = kHalfSeedMaxGrid;
-    h->hseed_grid = static_cast<int>(sg);
-    h->hseed_stride = sg > 0 ? ((h->n / sg) & ~static_cast<int64_t>(1)) : 0;
-    // seed riders of a streamed launch: each takes four regions per memory round trip (~2 us) and
-    // should be done well before the scanners (~2.1 us per tile) are
-    h->hs_riders = 0;
-    h->hs_scan = h->hsgrid;
-    h->hs_iters = h->hsiters;
-    if (sg > 0 && h->hgrid >= 16) {
-        int rounds = static_cast<int>(h->hsiters * 2.1 / 12.0);
-        if (rounds < 1) rounds = 1;
-        int riders = static_cast<int>((sg + 4 * rounds - 1) / (4 * rounds));
-        if (riders > h->hgrid / 8) riders = h->hgrid / 8;
-#ifdef MI355REC_EXPERIMENTS
-        if (const char* e = std::getenv("MI355REC_EXP_RIDERS")) {
-            const int v = std::atoi(e);
-            if (v >= 0 && v <= h->hgrid / 2) riders = v;
-        }
-#endif
-        if (riders > 0) {
-            h->hs_riders = riders;
-            h->hs_scan = h->hgrid - 1 - riders;
-            h->hs_iters = static_cast<int>((tiles + h->hs_scan - 1) / h->hs_scan);
-        }
-    }
+    h->hg = plan_replica(h, occ, HalfConfig::kTileRows, 2, 2.1);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_q8_kernel<Q8Config, true, false>, Q8Config::kBlock, 0) != hipSuccess) occ = 1;
+    h->qg = plan_replica(h, occ, Q8Config::kTileRows, 4, 2.1);
 }
 
 void free_replica(mi355rec* h) {
-    void* bufs[] = {h->d_half, h->d_half_seed, h->d_half_mseed, h->d_half_rescored, h->d_stream_seed[0], h->d_stream_seed[1]};
+    void* bufs[] = {h->d_half, h->d_q8, h->d_half_seed, h->d_half_mseed, h->d_half_rescored, h->d_stream_seed[0], h->d_stream_seed[1]};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     h->d_half = nullptr;
+    h->d_q8 = nullptr;
     h->d_half_seed = nullptr;
     h->d_half_mseed = nullptr;
     h->d_half_rescored = nullptr;
@@ -333,6 +355,7 @@ void free_replica(mi355rec* h) {
 
 int alloc_replica(mi355rec* h, int64_t n_padded) {
     HIP_TRY(h, hipMalloc(&h->d_half, static_cast<size_t>(n_padded) * 24));
+    HIP_TRY(h, hipMalloc(&h->d_q8, static_cast<size_t>((h->n + 3) / 4) * 48));
     HIP_TRY(h, hipMalloc(&h->d_half_seed, sizeof(uint32_t) * kHalfSeedMaxGrid * kHalfSeedWaves));
     HIP_TRY(h, hipMalloc(&h->d_half_mseed, sizeof(uint32_t) * kHmQueries * kHalfSeedMaxGrid * kHalfSeedWaves));
     HIP_TRY(h, hipMalloc(&h->d_half_rescored, sizeof(unsigned long long) * kRideMaxLists));
@@ -352,7 +375,7 @@ int build_replica(mi355rec* h) {
     if (rc != MI355REC_OK) {
         (void)hipStreamSynchronize(h->stream);
         free_replica(h);
-        if (h->replica_mode == MI355REC_REPLICA_ON) h->replica_mode = MI355REC_REPLICA_AUTO;
+        if (h->replica_mode == MI355REC_REPLICA_ON || h->replica_mode == MI355REC_REPLICA_FP16) h->replica_mode = MI355REC_REPLICA_AUTO;
     }
     return rc;
 }
@@ -368,6 +391,9 @@ int build_replica_inner(mi355rec* h) {
     if (timed) (void)hipEventRecord(a, h->stream);
     hipLaunchKernelGGL(replica_build_kernel, dim3(static_cast<unsigned>((n_padded + 255) / 256)), dim3(256), 0, h->stream,
                        h->d_feats, h->n, n_padded, reinterpret_cast<uint2*>(h->d_half));
+    const int64_t n_quads4 = (h->n + 3) / 4 * 4;
+    hipLaunchKernelGGL(q8_build_kernel, dim3(static_cast<unsigned>((n_quads4 + 255) / 256)), dim3(256), 0, h->stream,
+                       h->d_feats, h->n, n_quads4, reinterpret_cast<uint32_t*>(h->d_q8));
     if (timed) (void)hipEventRecord(b, h->stream);
     const hipError_t e = hipStreamSynchronize(h->stream);
     if (timed && e == hipSuccess) (void)hipEventElapsedTime(&h->replica_build_ms, a, b);
@@ -460,8 +486,10 @@ int create_common(const float* feats, bool on_device, int64_t n, int dim, int de
         h->d_feats = h->owned_feats;
     }
 
-    size_t list_words = static_cast<size_t>(h->grid > h->hgrid ? h->grid : h->hgrid) * kMaxTopK;
-    const size_t multi_words = static_cast<size_t>(h->mgrid > h->hgrid ? h->mgrid : h->hgrid) * kMultiChain * kMultiMaxTopK;
+    int single_lists = h->grid > h->hg.grid ? h->grid : h->hg.grid;
+    if (h->qg.grid > single_lists) single_lists = h->qg.grid;
+    size_t list_words = static_cast<size_t>(single_lists) * kMaxTopK;
+    const size_t multi_words = static_cast<size_t>(h->mgrid > h->hg.grid ? h->mgrid : h->hg.grid) * kMultiChain * kMultiMaxTopK;
     if (multi_words > list_words) list_words = multi_words;
     if ((e = hipMalloc(&h->d_block_lists, sizeof(uint64_t) * list_words)) != hipSuccess)
         return cleanup(MI355REC_ERR_OUT_OF_MEMORY, "hipMalloc(block lists)", e);
@@ -582,19 +610,33 @@ int timing_slot(mi355rec* h, std::vector<hipEvent_t>& evs, int& pairs, int& laun
 
 bool use_half(const mi355rec* h, const uint64_t* upper_dev) {
     if (!h->d_half || upper_dev || h->replica_mode == MI355REC_REPLICA_OFF) return false;
-    return h->replica_mode == MI355REC_REPLICA_ON || h->n >= kHalfAutoMinRows;
+    return h->replica_mode == MI355REC_REPLICA_ON || h->replica_mode == MI355REC_REPLICA_FP16 || h->n >= kHalfAutoMinRows;
 }
 
+// Single queries prefer the 8-bit replica (half the bytes per row); MI355REC_REPLICA_FP16 keeps them on the fp16 one.
+bool use_q8(const mi355rec* h) { return h->d_q8 && h->replica_mode != MI355REC_REPLICA_FP16; }
+
 // The sample that seeds the launch-wide cutoff of the next scan over the replica.
-void enqueue_half_seed(mi355rec* h, const float* qptr, const QueryArg& qa, int64_t exclude_global, uint32_t* seed_out,
+void enqueue_half_seed(mi355rec* h, bool q8, const float* qptr, const QueryArg& qa, int64_t exclude_global, uint32_t* seed_out,
                        hipStream_t s) {
-    if (h->hseed_grid <= 0) return;
+    if (q8) {
+        if (h->qg.seed_grid <= 0) return;
+        if (qptr) {
+            hipLaunchKernelGGL((seed_q8_kernel<true>), dim3(h->qg.seed_grid), dim3(kHalfSeedBlock), 0, s, h->d_q8, h->n,
+                               h->qg.seed_stride, h->row_base, qa, qptr, exclude_global, seed_out);
+        } else {
+            hipLaunchKernelGGL((seed_q8_kernel<false>), dim3(h->qg.seed_grid), dim3(kHalfSeedBlock), 0, s, h->d_q8, h->n,
+                               h->qg.seed_stride, h->row_base, qa, kNoQueryPtr, exclude_global, seed_out);
+        }
+        return;
+    }
+    if (h->hg.seed_grid <= 0) return;
     if (qptr) {
-        hipLaunchKernelGGL((seed_half_kernel<true>), dim3(h->hseed_grid), dim3(kHalfSeedBlock), 0, s, h->d_feats, h->d_half,
-                           h->n, h->hseed_stride, h->row_base, qa, qptr, exclude_global, seed_out);
+        hipLaunchKernelGGL((seed_half_kernel<true>), dim3(h->hg.seed_grid), dim3(kHalfSeedBlock), 0, s, h->d_feats, h->d_half,
+                           h->n, h->hg.seed_stride, h->row_base, qa, qptr, exclude_global, seed_out);
     } else {
-        hipLaunchKernelGGL((seed_half_kernel<false>), dim3(h->hseed_grid), dim3(kHalfSeedBlock), 0, s, h->d_feats, h->d_half,
-                           h->n, h->hseed_stride, h->row_base, qa, kNoQueryPtr, exclude_global, seed_out);
+        hipLaunchKernelGGL((seed_half_kernel<false>), dim3(h->hg.seed_grid), dim3(kHalfSeedBlock), 0, s, h->d_feats, h->d_half,
+                           h->n, h->hg.seed_stride, h->row_base, qa, kNoQueryPtr, exclude_global, seed_out);
     }
 }
 
@@ -611,19 +653,37 @@ int enqueue_scan(mi355rec* h, const float* qptr, const float* query12,
     if (use_half(h, upper_dev)) {
         NextSeed no_next;
         std::memset(&no_next, 0, sizeof no_next);
-        *n_lists = h->hgrid;
         ++h->half_scans;
-        enqueue_half_seed(h, qptr, qa, exclude_global, h->d_half_seed, s);
+        if (use_q8(h)) {
+            *n_lists = h->qg.grid;
+            ++h->q8_scans;
+            enqueue_half_seed(h, true, qptr, qa, exclude_global, h->d_half_seed, s);
+            if (qptr) {
+                LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, true, false>),
+                             dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
+                             h->d_feats, h->d_q8, h->n, h->qg.iters, h->row_base, qa, qptr, exclude_global, topn,
+                             h->d_block_lists, h->d_half_seed, h->qg.seed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next);
+            } else {
+                LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, false, false>),
+                             dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
+                             h->d_feats, h->d_q8, h->n, h->qg.iters, h->row_base, qa, kNoQueryPtr, exclude_global, topn,
+                             h->d_block_lists, h->d_half_seed, h->qg.seed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next);
+            }
+            HIP_TRY(h, hipGetLastError());
+            return MI355REC_OK;
+        }
+        *n_lists = h->hg.grid;
+        enqueue_half_seed(h, false, qptr, qa, exclude_global, h->d_half_seed, s);
         if (qptr) {
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, true, false>),
-                         dim3(h->hgrid), dim3(HalfConfig::kBlock), s,
-                         h->d_feats, h->d_half, h->n, h->hiters, h->row_base, qa, qptr, exclude_global, topn,
-                         h->d_block_lists, h->d_half_seed, h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next);
+                         dim3(h->hg.grid), dim3(HalfConfig::kBlock), s,
+                         h->d_feats, h->d_half, h->n, h->hg.iters, h->row_base, qa, qptr, exclude_global, topn,
+                         h->d_block_lists, h->d_half_seed, h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next);
         } else {
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, false, false>),
-                         dim3(h->hgrid), dim3(HalfConfig::kBlock), s,
-                         h->d_feats, h->d_half, h->n, h->hiters, h->row_base, qa, kNoQueryPtr, exclude_global,
-                         topn, h->d_block_lists, h->d_half_seed, h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next);
+                         dim3(h->hg.grid), dim3(HalfConfig::kBlock), s,
+                         h->d_feats, h->d_half, h->n, h->hg.iters, h->row_base, qa, kNoQueryPtr, exclude_global,
+                         topn, h->d_block_lists, h->d_half_seed, h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next);
         }
         HIP_TRY(h, hipGetLastError());
         return MI355REC_OK;
@@ -721,8 +781,8 @@ int enqueue_multi(mi355rec* h, const float* queries, const int64_t* exclude, int
 // workgroup per query for the whole chain.  queries[i] by value, or qptrs[i] != null: where its 12
 // floats live in device-readable memory.  topn <= kMultiMaxTopK, count <= kMultiChain.
 bool half_multi_ok(const mi355rec* h, int topn) {
-    return h->d_half && h->replica_mode != MI355REC_REPLICA_OFF && topn <= kMultiMaxTopK && h->hseed_grid > 0 &&
-           h->hseed_grid * kHalfSeedWaves >= topn;
+    return h->d_half && h->replica_mode != MI355REC_REPLICA_OFF && topn <= kMultiMaxTopK && h->hg.seed_grid > 0 &&
+           h->hg.seed_grid * kHalfSeedWaves >= topn;
 }
 
 void fill_half_multi_arg(HalfMultiArg& arg, float margin, const float* queries, const float* const* qptrs, const int64_t* exclude,
@@ -743,24 +803,24 @@ void fill_half_multi_arg(HalfMultiArg& arg, float margin, const float* queries, 
 
 int enqueue_half_multi(mi355rec* h, const float* queries, const float* const* qptrs, const int64_t* exclude, int count,
                        int topn, uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s) {
-    const int n_seed = h->hseed_grid * kHalfSeedWaves;
+    const int n_seed = h->hg.seed_grid * kHalfSeedWaves;
     HmRide no_ride;
     std::memset(&no_ride, 0, sizeof no_ride);
     HalfMultiArg arg;
     for (int g0 = 0; g0 < count; g0 += kHmQueries) {
         const int nq = count - g0 < kHmQueries ? count - g0 : kHmQueries;
         fill_half_multi_arg(arg, h->margin_mfma, queries, qptrs, exclude, g0, nq);
-        hipLaunchKernelGGL(seed_half_multi_kernel, dim3(h->hseed_grid), dim3(kHmBlock), 0, s, h->d_half, h->n, h->hseed_stride,
+        hipLaunchKernelGGL(seed_half_multi_kernel, dim3(h->hg.seed_grid), dim3(kHmBlock), 0, s, h->d_half, h->n, h->hg.seed_stride,
                            arg, nq, h->d_half_mseed);
         ++h->half_scans;
-        LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<false>), dim3(h->hgrid),
+        LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<false>), dim3(h->hg.grid),
                      dim3(kHmBlock), s, h->d_feats, h->d_half, h->n, h->row_base, arg, nq, g0, topn, h->d_block_lists,
                      h->d_half_mseed, n_seed, h->d_half_rescored, no_ride, arg);
     }
     HIP_TRY(h, hipGetLastError());
     const int slot = timing_begin(h, h->ev_merge, h->n_merge_pairs, h->merge_launches, s);
-    hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(kMergeBlock), 0, s, h->d_block_lists, h->hgrid, topn,
-                       static_cast<int64_t>(topn), static_cast<int64_t>(h->hgrid) * topn, topn, out_keys, out_idx, out_score,
+    hipLaunchKernelGGL(merge_kernel, dim3(count), dim3(kMergeBlock), 0, s, h->d_block_lists, h->hg.grid, topn,
+                       static_cast<int64_t>(topn), static_cast<int64_t>(h->hg.grid) * topn, topn, out_keys, out_idx, out_score,
                        static_cast<int64_t>(topn));
     timing_end(h, h->ev_merge, h->n_merge_pairs, slot, s);
     HIP_TRY(h, hipGetLastError());
@@ -776,7 +836,7 @@ constexpr int kHmRiders = 16;   // seed riders of a streamed launch: 16 regions 
 
 int ensure_mstream(mi355rec* h) {
     if (h->mstream_ready) return MI355REC_OK;
-    const size_t list_bytes = sizeof(uint64_t) * static_cast<size_t>(kHmQueries) * h->hgrid * kMultiMaxTopK;
+    const size_t list_bytes = sizeof(uint64_t) * static_cast<size_t>(kHmQueries) * h->hg.grid * kMultiMaxTopK;
     const size_t seed_bytes = sizeof(uint32_t) * static_cast<size_t>(kHmQueries) * kHalfSeedMaxGrid * kHalfSeedWaves;
     hipError_t e = hipSuccess;
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
@@ -812,20 +872,20 @@ int launch_mstash(mi355rec* h, hipStream_t s, const HalfMultiArg* next, int next
         ride.prev_topk = h->mpending.topn;
     }
     if (next) {
-        ride.seed_wgs = kHmRiders < h->hseed_grid ? kHmRiders : h->hseed_grid;
+        ride.seed_wgs = kHmRiders < h->hg.seed_grid ? kHmRiders : h->hg.seed_grid;
         ride.next_queries = next_nq;
-        ride.regions = h->hseed_grid;
-        ride.stride_rows = h->hseed_stride;
+        ride.regions = h->hg.seed_grid;
+        ride.stride_rows = h->hg.seed_stride;
         ride.next_seed_vals = h->d_mstream_seed[next_buf];
     }
     // the launch stays within one resident wave of workgroups: the riders and mergers take scanner slots
-    int scanners = h->hgrid - ride.prev_queries - ride.seed_wgs;
+    int scanners = h->hg.grid - ride.prev_queries - ride.seed_wgs;
     if (scanners < 1) scanners = 1;
     ++h->half_scans;
     LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<true>),
                  dim3(scanners + ride.prev_queries + ride.seed_wgs), dim3(kHmBlock), s, h->d_feats, h->d_half, h->n, h->row_base,
                  st.arg, st.nq, 0, st.topn, h->d_mstream_lists[buf], h->d_mstream_seed[st.seed_buf],
-                 h->hseed_grid * kHalfSeedWaves, h->d_half_rescored, ride, next ? *next : st.arg);
+                 h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, ride, next ? *next : st.arg);
     HIP_TRY(h, hipGetLastError());
     h->mpending.has = true;
     h->mpending.buf = buf;
@@ -867,7 +927,7 @@ int enqueue_mstream(mi355rec* h, const float* queries, const float* const* qptrs
         rc = launch_mstash(h, s, &arg, nq, seed_buf);   // its riders take THIS batch's sample
         if (rc) return rc;
     } else {   // the head of a stream: a sample launch of its own
-        hipLaunchKernelGGL(seed_half_multi_kernel, dim3(h->hseed_grid), dim3(kHmBlock), 0, s, h->d_half, h->n, h->hseed_stride,
+        hipLaunchKernelGGL(seed_half_multi_kernel, dim3(h->hg.seed_grid), dim3(kHmBlock), 0, s, h->d_half, h->n, h->hg.seed_stride,
                            arg, nq, h->d_mstream_seed[seed_buf]);
         HIP_TRY(h, hipGetLastError());
     }
@@ -967,7 +1027,8 @@ int ensure_streamed_alloc(mi355rec* h) {
     if (tiles < g) g = static_cast<int>(tiles);
     h->sgrid = g;
     h->siters = static_cast<int>((tiles + g - 1) / g);
-    const int most = g > h->hsgrid ? g : h->hsgrid;
+    int most = g > h->hg.sgrid ? g : h->hg.sgrid;
+    if (h->qg.sgrid > most) most = h->qg.sgrid;
     for (int i = 0; i < 2; ++i)
         HIP_TRY(h, hipMalloc(&h->d_stream_lists[i], sizeof(uint64_t) * static_cast<size_t>(most) * kMaxTopK));
     return MI355REC_OK;
@@ -999,24 +1060,39 @@ int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, const float* next
     std::memset(&next, 0, sizeof next);
     next.query_ptr = nullptr;
     next.exclude_global = -1;
-    int scanners = h->hsgrid, iters = h->hsiters;
-    if (with_next && h->hs_riders > 0) {
+    const ReplicaGeom& g = st.q8 ? h->qg : h->hg;
+    int scanners = g.sgrid, iters = g.siters;
+    if (with_next && g.riders > 0) {
         next.query_ptr = next_ptr;
         if (!next_ptr) std::memcpy(next.q, next_q, sizeof next.q);
         next.exclude_global = next_exclude;
         next.out = h->d_stream_seed[next_buf];
-        next.n_wgs = h->hs_riders;
-        next.regions = h->hseed_grid;
-        next.stride_rows = h->hseed_stride;
-        scanners = h->hs_scan;
-        iters = h->hs_iters;
+        next.n_wgs = g.riders;
+        next.regions = g.seed_grid;
+        next.stride_rows = g.seed_stride;
+        scanners = g.r_scan;
+        iters = g.r_iters;
     }
     QueryArg qa;
     std::memset(&qa, 0, sizeof qa);
     qa.margin = h->margin_mix;
-    const int n_seed = h->hseed_grid * kHalfSeedWaves;
+    const int n_seed = g.seed_grid * kHalfSeedWaves;
     ++h->half_scans;
-    if (st.qptr) {
+    if (st.q8) {
+        ++h->q8_scans;
+        if (st.qptr) {
+            LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, true, true>),
+                         dim3(scanners + 1 + next.n_wgs), dim3(Q8Config::kBlock), s,
+                         h->d_feats, h->d_q8, h->n, iters, h->row_base, qa, st.qptr, st.exclude, st.topn,
+                         h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], n_seed, h->d_half_rescored, prev, next);
+        } else {
+            std::memcpy(qa.q, st.q, sizeof qa.q);
+            LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, false, true>),
+                         dim3(scanners + 1 + next.n_wgs), dim3(Q8Config::kBlock), s,
+                         h->d_feats, h->d_q8, h->n, iters, h->row_base, qa, kNoQueryPtr, st.exclude, st.topn,
+                         h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], n_seed, h->d_half_rescored, prev, next);
+        }
+    } else if (st.qptr) {
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, true, true>),
                      dim3(scanners + 1 + next.n_wgs), dim3(HalfConfig::kBlock), s,
                      h->d_feats, h->d_half, h->n, iters, h->row_base, qa, st.qptr, st.exclude, st.topn,
@@ -1061,15 +1137,18 @@ int enqueue_streamed(mi355rec* h, const float* qptr, const float* query12, int64
         // sample of this one (seed riders).  The first query of a stream needs a seed launch of its own.
         int seed_buf = 0;
         bool sampled = false;
+        const bool q8 = use_q8(h);
         if (h->stashed.has) {
             seed_buf = 1 - h->stashed.seed_buf;
-            sampled = h->hs_riders > 0;
+            // the riders of a launch sample the replica that launch scans: a change of replica
+            // (mi355rec_set_replica) between two calls costs the next query a seed launch of its own
+            sampled = h->stashed.q8 == q8 && (q8 ? h->qg.riders : h->hg.riders) > 0;
             rc = launch_stashed(h, s, sampled, qptr, query12, exclude_global, seed_buf);
             if (rc) return rc;
         }
-        if (!sampled && h->hseed_grid > 0) {   // first query of a stream, or a shard too small to spare riders
+        if (!sampled && (q8 ? h->qg.seed_grid : h->hg.seed_grid) > 0) {   // first query of a stream, or a shard too small to spare riders
             if (!qptr) std::memcpy(qa.q, query12, sizeof qa.q);
-            enqueue_half_seed(h, qptr, qa, exclude_global, h->d_stream_seed[seed_buf], s);
+            enqueue_half_seed(h, q8, qptr, qa, exclude_global, h->d_stream_seed[seed_buf], s);
             HIP_TRY(h, hipGetLastError());
         }
         auto& st = h->stashed;
@@ -1080,6 +1159,7 @@ int enqueue_streamed(mi355rec* h, const float* qptr, const float* query12, int64
         st.topn = topn;
         st.out = out_keys;
         st.seed_buf = seed_buf;
+        st.q8 = q8;
         return MI355REC_OK;
     }
     if (h->stashed.has) {   // the path changed under a stream (mi355rec_set_replica): the stashed query goes first
@@ -1465,10 +1545,13 @@ int mi355rec_stats(const mi355rec_t* hc, mi355rec_stats_t* out) {
     out->batched_margin = h->bq.ready ? h->bq.margin : 0.0f;
     out->replica_bytes_per_query = h->d_half ? ((h->n + 1) / 2) * 48 : 0;
     out->replica_active = use_half(h, nullptr) ? 1 : 0;
-    out->replica_grid_blocks = h->d_half ? h->hgrid : 0;
+    out->replica_grid_blocks = h->d_half ? (use_q8(h) ? h->qg.grid : h->hg.grid) : 0;
     out->replica_build_ms = h->replica_build_ms;
     out->replica_margin_single = h->d_half ? h->margin_mix : 0.0f;
     out->replica_margin_multi = h->d_half ? h->margin_mfma : 0.0f;
+    out->replica_single_row_bytes = !h->d_half ? 0 : (use_q8(h) ? 12 : 24);
+    out->replica_single_bytes_per_query = !h->d_half ? 0 : (use_q8(h) ? ((h->n + 3) / 4) * 48 : ((h->n + 1) / 2) * 48);
+    out->reserved0 = 0;
     return MI355REC_OK;
 }
 
@@ -1732,9 +1815,9 @@ int mi355rec_set_batch_path(mi355rec_t* h, int path) {
 
 int mi355rec_set_replica(mi355rec_t* h, int mode) {
     if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
-    if (mode != MI355REC_REPLICA_AUTO && mode != MI355REC_REPLICA_OFF && mode != MI355REC_REPLICA_ON)
+    if (mode != MI355REC_REPLICA_AUTO && mode != MI355REC_REPLICA_OFF && mode != MI355REC_REPLICA_ON && mode != MI355REC_REPLICA_FP16)
         return fail(h, MI355REC_ERR_INVALID_ARG, "unknown replica mode %d", mode);
-    if (mode == MI355REC_REPLICA_ON && !h->d_half && h->n > 0) {
+    if ((mode == MI355REC_REPLICA_ON || mode == MI355REC_REPLICA_FP16) && !h->d_half && h->n > 0) {
         if (!h->replica_allowed)
             return fail(h, MI355REC_ERR_INVALID_ARG, "this handle was created without a replica (MI355REC_REPLICA=0)");
         // a small shard (or one whose replica could not be allocated at create): build it now

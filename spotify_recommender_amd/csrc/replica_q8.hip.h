@@ -1,0 +1,414 @@
+// replica_q8.hip.h — the 8-BIT replica of the catalogue and the single-query scan over it.
+//
+// replica.hip.h halves the bytes a query streams (24 B per row instead of the reference's 48,
+// Recommender.cu:184-254) with a copy that is only good enough to rule rows OUT.  The same idea one step
+// further: 12 B per row.  Each row is L2-normalised in fp32 and every component quantised to 8 bits,
+//     u_j = round(127 r^_j) + 128   in [1, 255],          |u_j - 128 - 127 r^_j| <= 1/2,
+// so that for a query q (normalised q^ = q / |q|, kept in fp32 — the query is NOT quantised)
+//     approx = sum_j q^_j (u_j - 128) / 127 ,        |approx - r^ . q^| <= l1(q^) / 254 ,   l1(q^) = sum |q^_j| <= sqrt(12).
+// The bound is PER QUERY (0.0137 at worst, ~0.012 for a typical query) and derived, not tuned: the
+// quantisation error of component j is at most 1/254 and enters the dot product multiplied by |q^_j|; the
+// fp32 evaluation adds < 2e-6, the normalisations and the reference chain's own rounding < 6e-6 (the
+// slack of batched.hip.h's derivation).  tests/test_q8_margin.py checks it on hostile data with a numpy
+// model of exactly this arithmetic.  Everything else is replica.hip.h's scheme, unchanged:
+//   * the contract per query is recommendByIndex's (Recommender.cu:275-318): every key that leaves the
+//     kernel is cosine_score() on the fp32 row (calculateSimilaritiesCPU, :256-273), bit for bit;
+//   * valid row: |row|^2 in [kBqMinNorm2, kBqMaxNorm2]; an exactly-zero row stores u = 128 everywhere
+//     (approx = 0 = its exact score); every other row (tiny, huge, inf, NaN) stores u = 0 — a byte no
+//     valid row contains — and is sent to the exact chain every time;
+//   * an invalid query (|q| outside [kBqMinNorm, kBqMaxNorm]) switches the pre-filter off for the launch;
+//   * the launch-wide cutoff comes from a spread sample: v = the topk-th largest of <= 2048 wave-tile
+//     maxima (here a wave tile is 256 rows: 5 % of the catalogue is sampled), cutoff = v - 2 margin - slack;
+//     workgroup-local thresholds tighten it whenever a local list fills.
+// With a margin ten times the fp16 replica's, ~0.3 % of the rows (20-35 k of 10 M at top-100) go to the
+// exact chain instead of 0.05 % — 2 MB of random 48 B fetches beside 120 MB of stream.
+//
+// One lane = FOUR rows = 48 B (3 x dwordx4: the same load pattern once more; row r of the lane is dwords
+// 3r .. 3r + 2), tiles of 4 * kBlock rows dealt round-robin over the scanning workgroups.  Per row 12
+// v_cvt_f32_ubyteN + 12 v_fmac_f32 (the query's 12 scaled components are scalar registers).
+#pragma once
+
+#include "replica.hip.h"
+
+namespace mi355 {
+
+constexpr float kQ8Step = 1.0f / 254.0f;     // half a quantisation step of a normalised component
+constexpr float kQ8Slack = 3e-5f;            // fp32 evaluation of the 12-term sum (terms up to 2, partial sums up to 7: < 6e-6),
+                                             // normalisations and the reference chain's own rounding (< 6e-6), with room to spare
+
+// ---- building the replica ---------------------------------------------------------------------------
+// One thread per row; rows [n, n_padded) (n_padded a multiple of 4) are padding and hold the special marker.
+__global__ __launch_bounds__(256) void q8_build_kernel(const float* __restrict__ feats, int64_t n, int64_t n_padded,
+                                                       uint32_t* __restrict__ q8) {
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (row >= n_padded) return;
+    uint32_t d0 = 0u, d1 = 0u, d2 = 0u;   // special
+    if (row < n) {
+        const float4* p = reinterpret_cast<const float4*>(feats) + row * 3;
+        const float4 a = p[0], b = p[1], c = p[2];
+        // the normalisation of the fp16 replica and of the batched passes (replica_build_kernel)
+        float tot = a.x * a.x;
+        tot = __builtin_fmaf(a.y, a.y, tot);
+        tot = __builtin_fmaf(a.z, a.z, tot);
+        tot = __builtin_fmaf(a.w, a.w, tot);
+        tot = __builtin_fmaf(b.x, b.x, tot);
+        tot = __builtin_fmaf(b.y, b.y, tot);
+        tot = __builtin_fmaf(b.z, b.z, tot);
+        tot = __builtin_fmaf(b.w, b.w, tot);
+        tot = __builtin_fmaf(c.x, c.x, tot);
+        tot = __builtin_fmaf(c.y, c.y, tot);
+        tot = __builtin_fmaf(c.z, c.z, tot);
+        tot = __builtin_fmaf(c.w, c.w, tot);
+        const bool valid = tot >= kBqMinNorm2 && tot <= kBqMaxNorm2;
+        if (valid || tot == 0.0f) {
+            const float inv = valid ? __builtin_amdgcn_rsqf(tot) * 127.0f : 0.0f;
+            auto q = [&](float x) {   // round to nearest; |x * inv| <= 127 (1 + 1e-6)
+                int k = static_cast<int>(__builtin_rintf(x * inv));
+                k = k > 127 ? 127 : (k < -127 ? -127 : k);
+                return static_cast<uint32_t>(k + 128);
+            };
+            d0 = q(a.x) | (q(a.y) << 8) | (q(a.z) << 16) | (q(a.w) << 24);
+            d1 = q(b.x) | (q(b.y) << 8) | (q(b.z) << 16) | (q(b.w) << 24);
+            d2 = q(c.x) | (q(c.y) << 8) | (q(c.z) << 16) | (q(c.w) << 24);
+        }
+    }
+    uint32_t* dst = q8 + row * 3;
+    dst[0] = d0;
+    dst[1] = d1;
+    dst[2] = d2;
+}
+
+// ---- the query ------------------------------------------------------------------------------------------
+struct Q8Query {
+    float s[kDim];   // q^_j / 127 (wave-uniform: scalar registers)
+    float c;         // 128 * sum_j s_j:   approx = sum_j s_j u_j - c
+    float margin;    // l1(q^) / 254 + slack
+    bool ok;         // the bound may be claimed for this query
+};
+
+__device__ __forceinline__ Q8Query q8_query(const float (&q)[kDim], float qn) {
+    Q8Query r;
+    r.ok = qn >= kBqMinNorm && qn <= kBqMaxNorm;   // false for NaN
+    const float inv = r.ok ? 1.0f / qn : 0.0f;
+    float sum = 0.0f, l1 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kDim; ++j) {
+        const float u = q[j] * inv;
+        r.s[j] = u * (1.0f / 127.0f);
+        sum += r.s[j];
+        l1 += __builtin_fabsf(u);
+    }
+    r.c = 128.0f * sum;
+    r.margin = l1 * kQ8Step * (1.0f + 1e-5f) + kQ8Slack;
+    return r;
+}
+
+// approx of one row (3 dwords); `special` = the row is sent to the exact chain whatever approx says
+__device__ __forceinline__ float q8_dot(const Q8Query& q, uint32_t d0, uint32_t d1, uint32_t d2, bool& special) {
+    special = (d0 & 0xffu) == 0u;
+    float acc = -q.c;
+    acc = __builtin_fmaf(static_cast<float>(d0 & 0xffu), q.s[0], acc);
+    acc = __builtin_fmaf(static_cast<float>((d0 >> 8) & 0xffu), q.s[1], acc);
+    acc = __builtin_fmaf(static_cast<float>((d0 >> 16) & 0xffu), q.s[2], acc);
+    acc = __builtin_fmaf(static_cast<float>(d0 >> 24), q.s[3], acc);
+    acc = __builtin_fmaf(static_cast<float>(d1 & 0xffu), q.s[4], acc);
+    acc = __builtin_fmaf(static_cast<float>((d1 >> 8) & 0xffu), q.s[5], acc);
+    acc = __builtin_fmaf(static_cast<float>((d1 >> 16) & 0xffu), q.s[6], acc);
+    acc = __builtin_fmaf(static_cast<float>(d1 >> 24), q.s[7], acc);
+    acc = __builtin_fmaf(static_cast<float>(d2 & 0xffu), q.s[8], acc);
+    acc = __builtin_fmaf(static_cast<float>((d2 >> 8) & 0xffu), q.s[9], acc);
+    acc = __builtin_fmaf(static_cast<float>((d2 >> 16) & 0xffu), q.s[10], acc);
+    acc = __builtin_fmaf(static_cast<float>(d2 >> 24), q.s[11], acc);
+    return acc;
+}
+
+__device__ __forceinline__ void q8_dot4(const Q8Query& q, const HalfTile& t, float (&a)[4], bool (&special)[4]) {
+    a[0] = q8_dot(q, t.t0.x, t.t0.y, t.t0.z, special[0]);
+    a[1] = q8_dot(q, t.t0.w, t.t1.x, t.t1.y, special[1]);
+    a[2] = q8_dot(q, t.t1.z, t.t1.w, t.t2.x, special[2]);
+    a[3] = q8_dot(q, t.t2.y, t.t2.z, t.t2.w, special[3]);
+}
+
+// ---- the sample that seeds the launch-wide cutoff ---------------------------------------------------------
+// A REGION is 2048 rows from row g * stride_rows on (stride_rows a multiple of 4 and >= 2048): one ordered-u32
+// approx maximum per 256-row wave tile (0 = nothing usable) goes to seed_vals[g * 8 + wave].
+struct Q8Region {
+    HalfTile t;
+    int64_t quad;
+    bool have;
+};
+
+__device__ __forceinline__ Q8Region q8_region_load(const uint4* __restrict__ q8, int64_t n_quads, int64_t stride_rows, int64_t g) {
+    Q8Region s;
+    s.quad = ((g * stride_rows) >> 2) + threadIdx.x;
+    s.have = s.quad < n_quads;
+    s.quad = s.have ? s.quad : n_quads - 1;
+    const uint4* p = q8 + s.quad * 3;
+    s.t.t0 = p[0];
+    s.t.t1 = p[1];
+    s.t.t2 = p[2];
+    return s;
+}
+
+__device__ __forceinline__ void q8_region_finish(const Q8Region& s, const Q8Query& q, int64_t n, int64_t row_base,
+                                                 int64_t exclude_global, uint32_t* __restrict__ seed_vals, int64_t g) {
+    float a[4];
+    bool special[4];
+    q8_dot4(q, s.t, a, special);
+    const int64_t r0 = s.quad * 4;
+    uint32_t v = 0u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const bool use = s.have && q.ok && !special[u] && r0 + u < n && row_base + r0 + u != exclude_global;
+        const uint32_t w = use ? score_to_ordered(a[u]) : 0u;
+        v = w > v ? w : v;
+    }
+    v = wave_max_u32(v);
+    if ((threadIdx.x & 63) == 0) seed_vals[g * kHalfSeedWaves + (threadIdx.x >> 6)] = v;
+}
+
+__device__ __forceinline__ void q8_load_query(const float* __restrict__ query_ptr, const float (&by_value)[kDim], float (&q)[kDim]) {
+    if (query_ptr) {
+#pragma unroll
+        for (int j = 0; j < kDim; ++j) q[j] = query_ptr[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < kDim; ++j) q[j] = by_value[j];
+    }
+}
+
+// One workgroup per region (single queries; the first query of a stream).
+template <bool kQueryFromRow>
+__global__ __launch_bounds__(kHalfSeedBlock) void seed_q8_kernel(
+    const uint4* __restrict__ q8, int64_t n, int64_t stride_rows, int64_t row_base, QueryArg qarg,
+    const float* __restrict__ query_ptr, int64_t exclude_global, uint32_t* __restrict__ seed_vals) {
+    float q[kDim];
+    q8_load_query(kQueryFromRow ? query_ptr : nullptr, qarg.q, q);
+    const Q8Query hq = q8_query(q, query_norm(q));
+    const Q8Region s = q8_region_load(q8, (n + 3) >> 2, stride_rows, blockIdx.x);
+    q8_region_finish(s, hq, n, row_base, exclude_global, seed_vals, blockIdx.x);
+}
+
+// The seed riders of a streamed launch (replica.hip.h, seed_rider): four regions per memory round trip.
+__device__ __forceinline__ void q8_seed_rider(const uint4* __restrict__ q8, int64_t n, int64_t row_base, const NextSeed& next,
+                                              int rider) {
+    float q[kDim];
+    q8_load_query(next.query_ptr, next.q, q);
+    const Q8Query hq = q8_query(q, query_norm(q));
+    const int64_t n_quads = (n + 3) >> 2;
+    constexpr int kAhead = 4;
+    for (int g0 = rider; g0 < next.regions; g0 += kAhead * next.n_wgs) {
+        Q8Region s[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const int g = g0 + u * next.n_wgs;
+            s[u] = q8_region_load(q8, n_quads, next.stride_rows, g < next.regions ? g : rider);
+        }
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const int g = g0 + u * next.n_wgs;
+            if (g < next.regions) q8_region_finish(s[u], hq, n, row_base, next.exclude_global, next.out, g);   // uniform
+        }
+    }
+}
+
+// ---- the scan ----------------------------------------------------------------------------------------------
+template <int kBlockT, int kMinWavesT, int kDepthT>
+struct Q8Cfg {
+    static constexpr int kBlock = kBlockT;
+    static constexpr int kMinWaves = kMinWavesT;
+    static constexpr int kDepth = kDepthT;
+    static constexpr int kTileRows = 4 * kBlockT;
+    static constexpr int kCandCap = kCandLimit + kTileRows;
+    static constexpr int kCandPerThread = (kCandCap + kBlockT - 1) / kBlockT;
+};
+using DefaultQ8Cfg = Q8Cfg<512, 4, 2>;
+
+// kWithMerge (streamed queries): workgroups [0, S) scan, workgroup S merges the PREVIOUS streamed query,
+// workgroups (S, gridDim) are seed riders for the NEXT one; S = gridDim.x - 1 - next.n_wgs (scan_half_kernel).
+template <typename Cfg, bool kQueryFromRow, bool kWithMerge>
+__global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
+    const float* __restrict__ feats, const uint4* __restrict__ q8, int64_t n, int iters, int64_t row_base,
+    QueryArg qarg, const float* __restrict__ query_ptr, int64_t exclude_global, int topk, uint64_t* __restrict__ block_lists,
+    const uint32_t* __restrict__ seed_vals, int n_seed, unsigned long long* __restrict__ rescored /* [scanning workgroups] */,
+    PrevMerge prev, NextSeed next) {
+    constexpr int kBlock = Cfg::kBlock;
+    __shared__ typename std::conditional<kWithMerge, HalfScanOrMergeSmem<Cfg>, HalfScanSmemT<Cfg>>::type s_mem;
+    HalfScanSmemT<Cfg>* sm;
+    unsigned nblocks = gridDim.x;   // scanning workgroups
+    if constexpr (kWithMerge) {
+        nblocks = gridDim.x - 1u - static_cast<unsigned>(next.n_wgs);
+        if (blockIdx.x >= nblocks) {
+            if (blockIdx.x == nblocks) {
+                if (prev.lists)
+                    merge_body(s_mem.merge, prev.lists, prev.n_lists, prev.topk, static_cast<int64_t>(prev.topk),
+                               static_cast<int64_t>(0), prev.topk, prev.out_keys, static_cast<int64_t*>(nullptr),
+                               static_cast<float*>(nullptr), static_cast<int64_t>(0), static_cast<int64_t>(0),
+                               static_cast<int64_t>(0));
+            } else {
+                q8_seed_rider(q8, n, row_base, next, static_cast<int>(blockIdx.x - nblocks - 1u));
+            }
+            return;
+        }
+        sm = &s_mem.scan;
+    } else {
+        (void)next;
+        sm = &s_mem;
+    }
+    uint64_t* const s_cand = sm->cand;
+    SelectSmem& s_sel = sm->sel;
+    int& s_count = sm->count;
+
+    const unsigned bid = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+
+    float q[kDim];
+    q8_load_query(kQueryFromRow ? query_ptr : nullptr, qarg.q, q);
+    const float qn = query_norm(q);
+    const Q8Query hq = q8_query(q, qn);
+
+    const int64_t n_quads = (n + 3) >> 2;
+    const int64_t last_quad = n_quads - 1;
+    const int64_t quad_begin = static_cast<int64_t>(bid) * kBlock + tid;
+    const int64_t quad_stride = static_cast<int64_t>(nblocks) * kBlock;
+
+    auto load_tile = [&](HalfTile& dst, int it) {
+        int64_t quad = quad_begin + static_cast<int64_t>(it) * quad_stride;
+        quad = quad < n_quads ? quad : last_quad;   // unconditional prefetch (see scan_kernel)
+        const uint4* p = q8 + quad * 3;
+        dst.t0 = p[0];
+        dst.t1 = p[1];
+        dst.t2 = p[2];
+    };
+
+    constexpr int kDepth = Cfg::kDepth;
+    HalfTile ring[kDepth];
+#pragma unroll
+    for (int d = 0; d < kDepth - 1; ++d) load_tile(ring[d], d);
+
+    // ---- launch-wide cutoff from the sample maxima (while the first tiles are in flight)
+    if (tid == 0) {
+        s_count = 0;
+        sm->seeds = 0;
+        sm->rescored = 0;
+    }
+    int n_rescored = 0;   // wave-uniform: rows this wave sent to the exact chain (diagnostics)
+    __syncthreads();
+    const float neg_inf = -__builtin_inff();
+    float cutoff = neg_inf;   // -inf: everything is fetched and scored exactly
+    if (hq.ok && n_seed > 0) {   // uniform
+        uint64_t mine[kHalfSeedPerThread];
+        int have = 0;
+#pragma unroll
+        for (int r = 0; r < kHalfSeedPerThread; ++r) {
+            const int i = tid + r * kBlock;
+            const uint32_t v = i < n_seed ? seed_vals[i] : 0u;
+            mine[r] = v ? (static_cast<uint64_t>(v) << 32) | static_cast<uint32_t>(i + 1) : 0ull;
+            have += v != 0u;
+        }
+        if (have) atomicAdd(&sm->seeds, have);
+        __syncthreads();
+        if (sm->seeds >= topk) {   // uniform
+            const uint64_t t = block_select_threshold<kBlock, kHalfSeedPerThread>(mine, topk, true, 0, s_sel);
+            const float v = ordered_to_score(static_cast<uint32_t>(t >> 32));
+            cutoff = v - 2.0f * hq.margin;   // (the margin carries its own slack)
+        }
+    }
+    uint64_t thr = 0;
+    int compact_at = 2 * topk > 256 ? 2 * topk : 256;
+    if (compact_at > kCandLimit) compact_at = kCandLimit;
+
+    // A row the replica cannot rule out costs one random 48 B fetch from the fp32 matrix, ISSUED when the
+    // row is found and CONSUMED one tile later (a one-entry pending slot per lane), so its latency overlaps
+    // the next tile.  A lane's second, third and fourth candidate of one tile are scored on the spot (rare).
+    Row pend;
+    pend.a = pend.b = pend.c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    int64_t pend_r = 0;
+    bool pend_on = false;
+
+    auto append = [&](bool have, const Row& row, int64_t r) {
+        const float s = cosine_score(q, qn, row);
+        const int64_t g = row_base + r;
+        uint64_t key = pack_key(s, static_cast<uint32_t>(g));
+        if (g == exclude_global) key = 0;
+        const bool pass = have && key > thr;
+        const uint64_t ballot = __ballot(pass);
+        if (ballot) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_count, __popcll(ballot));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const int pos = base + lanes_below(ballot);
+            if (pass) s_cand[pos] = key;
+        }
+    };
+    auto consume = [&]() {
+        if (__ballot(pend_on)) append(pend_on, pend, pend_r);
+        pend_on = false;
+    };
+
+    auto process_tile = [&](const HalfTile& t, int it) {
+        const int64_t quad = quad_begin + static_cast<int64_t>(it) * quad_stride;
+        const int64_t r0 = quad * 4;
+        float a[4];
+        bool special[4];
+        q8_dot4(hq, t, a, special);
+        uint32_t mask = 0u;   // which of the lane's four rows are candidates
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool maybe = quad < n_quads && r0 + u < n && (special[u] || !(a[u] < cutoff));
+            mask |= maybe ? (1u << u) : 0u;
+        }
+        consume();   // the rows fetched while the previous tile was scanned
+        const uint64_t any = __ballot(mask != 0u);
+        if (any) {
+            n_rescored += __popcll(any);
+            const int first = mask ? __builtin_ctz(mask) : 0;
+            // lanes without a candidate re-read row 0: one cached line
+            pend_r = r0 + first;
+            pend = load_row(feats, mask ? pend_r : static_cast<int64_t>(0));
+            pend_on = mask != 0u;
+            uint32_t rest = mask & (mask - 1u);   // the lane's further candidates, if any
+            while (__ballot(rest != 0u)) {         // uniform, rare
+                const int u = rest ? __builtin_ctz(rest) : 0;
+                const bool have = rest != 0u;
+                n_rescored += __popcll(__ballot(have));
+                const Row extra = load_row(feats, have ? r0 + u : static_cast<int64_t>(0));
+                append(have, extra, r0 + u);
+                rest &= rest - 1u;
+            }
+        }
+        __syncthreads();
+        const int c = s_count;
+        __syncthreads();
+        if (c >= compact_at) {
+            const uint64_t local_thr = compact_candidates<kBlock, Cfg::kCandPerThread>(s_cand, &s_count, topk, false, s_sel);
+            if (local_thr > thr) {
+                thr = local_thr;
+                if (hq.ok) {
+                    const float local_cut = ordered_to_score(static_cast<uint32_t>(thr >> 32)) - hq.margin;
+                    cutoff = local_cut > cutoff ? local_cut : cutoff;
+                }
+            }
+        }
+    };
+
+    for (int it = 0; it < iters; it += kDepth) {
+#pragma unroll
+        for (int sidx = 0; sidx < kDepth; ++sidx) {
+            load_tile(ring[(sidx + kDepth - 1) % kDepth], it + sidx + kDepth - 1);
+            if (it + sidx < iters) process_tile(ring[sidx], it + sidx);  // uniform
+        }
+    }
+    consume();   // the last tile's fetches
+
+    if (lane == 0 && n_rescored) atomicAdd(&sm->rescored, n_rescored);
+    __syncthreads();
+    if (tid == 0) rescored[bid] += static_cast<unsigned long long>(sm->rescored);   // launches of a handle are stream-ordered
+    if (s_count > kRankDirectMax && s_count > topk)  // uniform
+        compact_candidates<kBlock, Cfg::kCandPerThread>(s_cand, &s_count, topk, true, s_sel);
+    __syncthreads();
+    block_rank_and_store<kBlock>(s_cand, s_count, block_lists + static_cast<int64_t>(bid) * topk, topk);
+}
+
+}  // namespace mi355

@@ -53,8 +53,8 @@ def test_randomised_parity():
                               p=[.03, .03, .05, .05, .05, .05, .1, .1, .1, .14, .15, .1, .05]))
         f = make_catalogue(rng, rows)
         with CosineEngine(f) as eng:
-            # every third case: single queries over the fp16 replica (forced on: AUTO starts at 1 M rows)
-            eng.set_replica(2 if case % 3 == 0 else 0)
+            # single queries over the 8-bit replica / the fp16 one (forced on: AUTO starts at 1 M rows) / AUTO
+            eng.set_replica((2, 3, 0)[case % 3])
             for _ in range(3):
                 topn = int(rng.choice([1, 2, 10, 100, 128, 129, 1000, 1024, 1025, 2500]))
                 q = int(rng.integers(0, rows))

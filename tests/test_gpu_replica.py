@@ -1,13 +1,15 @@
-"""The single-query scan over the fp16 replica (csrc/replica.hip.h) against the oracle and
-against the fp32 scan, through the C-ABI.
+"""The single-query scans over the replicas — 8-bit (csrc/replica_q8.hip.h, the default) and fp16
+(csrc/replica.hip.h, MI355REC_REPLICA_FP16) — against the oracle and against the fp32 scan, through
+the C-ABI.  Every test runs once per replica.
 
 The replica only rules rows OUT; every key that leaves the kernel is computed from the
 fp32 row by the exact chain, so the bar is the usual one: scores bit-exact, ids identical
 (tie-aware).  The diagnostics (rows sent to the exact chain) are asserted as well, so a
 build that silently re-scored everything — or nothing — would fail.
 
-The launch-wide cutoff comes from a sample: up to 256 regions of 1024 rows, spaced
-(n / regions) & ~1 rows apart; "in the sample" below means rows placed there.
+The launch-wide cutoff comes from a sample: up to 256 regions of 1024 rows spaced
+(n / regions) & ~1 rows apart (fp16), of 2048 rows spaced (n / regions) & ~3 apart (8-bit);
+"in the sample" below means rows placed there.
 """
 import os
 
@@ -20,7 +22,15 @@ from tests.test_batched_margin import catalogues
 
 pytestmark = pytest.mark.gpu
 
-ON, OFF = 2, 1
+ON, OFF = 2, 1     # ON is rebound per test by replica_kind: 2 = ON (8-bit replica), 3 = FP16
+
+
+@pytest.fixture(autouse=True, params=[2, 3], ids=["q8", "fp16"])
+def replica_kind(request):
+    global ON
+    ON = request.param
+    yield request.param
+    ON = 2
 
 
 @pytest.fixture(scope="module")
@@ -37,9 +47,11 @@ def Engine(torch_cuda):
 
 
 def sample_rows(n):
-    regions = min(256, n // 1024)
-    stride = (n // regions) & ~1
-    return regions, stride
+    if ON == 3:
+        regions = min(256, n // 1024)
+        return regions, (n // regions) & ~1
+    regions = min(256, n // 2048)
+    return regions, (n // regions) & ~3
 
 
 def check_queries(eng, f, queries, excl, topns, label, rows=None):
@@ -66,8 +78,12 @@ def test_uniform_catalogue_and_the_rescored_share(Engine):
     rows = rng.integers(0, n, size=12)
     rows[0], rows[1] = n - 1, 0
     with Engine(f) as eng:
+        if ON == 3:
+            eng.set_replica(ON)
         st = eng.stats()
         assert st.replica_active == 1 and st.replica_bytes_per_query == (n + 1) // 2 * 48
+        assert st.replica_single_row_bytes == (24 if ON == 3 else 12)
+        assert st.replica_single_bytes_per_query == ((n + 1) // 2 * 48 if ON == 3 else (n + 3) // 4 * 48)
         before = eng.replica_counters()
         check_queries(eng, f, None, rows, (1, 10, 100, 1000), "uniform 2.5 M", rows=rows)
         after = eng.replica_counters()
@@ -150,7 +166,8 @@ def test_special_rows_and_queries(Engine):
     f = rng.random((n, 12), dtype=np.float32)
     regions, stride = sample_rows(n)
     sampled = np.array([b * stride + o for b in range(0, regions, 5) for o in (0, 1, 127, 128, 600, 1023)])
-    unsampled = np.array([b * stride + o for b in range(2, regions, 7) for o in (1024, 1500, stride - 1)])
+    R = 1024 if ON == 3 else 2048
+    unsampled = np.array([b * stride + o for b in range(2, regions, 7) for o in (R, R + 476, stride - 1)])
     vals = [np.nan, np.inf, -np.inf, 1e-42, 3e19, -3e19, 0.0]
     for i, r in enumerate(np.concatenate([sampled, unsampled])):
         f[r, rng.integers(0, 12)] = vals[i % len(vals)]

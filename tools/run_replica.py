@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""A/B driver for the single-query scan over the fp16 replica (csrc/replica.hip.h) against
-the fp32 scan: same queries through both, keys compared bit for bit, streamed step time of each.
+"""A/B driver for the single-query scans over the replicas (8-bit: csrc/replica_q8.hip.h, fp16:
+csrc/replica.hip.h) against the fp32 scan: same queries through all three, keys compared bit for bit,
+streamed step time, rows re-scored per query and lone-query latency of each.
   python3 tools/run_replica.py --rows 10000000 --topn 100 --steps 300
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/x -- python3 tools/run_replica.py ...
 """
@@ -20,7 +21,7 @@ def main():
     ap.add_argument("--topn", type=int, default=100)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--check", type=int, default=64, help="queries compared between the two paths")
-    ap.add_argument("--only", type=int, default=-1, help="time only this mode (1 fp32 rows, 2 replica)")
+    ap.add_argument("--only", type=int, default=-1, help="time only this mode (1 fp32 rows, 2 8-bit replica, 3 fp16 replica)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -34,28 +35,29 @@ def main():
         st = eng.stats()
         out["replica_build_ms"] = round(float(st.replica_build_ms), 3)
         out["replica_grid_blocks"] = int(st.replica_grid_blocks)
-        keys = {m: torch.zeros((args.check, args.topn), dtype=torch.int64, device="cuda") for m in (1, 2)}
+        keys = {m: torch.zeros((args.check, args.topn), dtype=torch.int64, device="cuda") for m in (1, 2, 3)}
         if args.only < 0:
-            for mode in (capi.REPLICA_OFF, capi.REPLICA_ON):
+            for mode in (capi.REPLICA_OFF, capi.REPLICA_ON, capi.REPLICA_FP16):
                 eng.set_replica(mode)
                 for i in range(args.check):
                     eng.enqueue_row_keys(rows[i], args.topn, keys[mode][i])
                 torch.cuda.synchronize()
-            same = bool(torch.equal(keys[1], keys[2]))
-            out["keys_identical"] = same
-            if not same:
-                bad = (keys[1] != keys[2]).any(dim=1).nonzero().flatten().tolist()
-                out["first_bad_queries"] = bad[:8]
-            # streamed too
-            sk = torch.zeros((args.check, args.topn), dtype=torch.int64, device="cuda")
-            eng.set_replica(capi.REPLICA_ON)
-            for i in range(args.check):
-                eng.enqueue_row_keys_streamed(rows[i], args.topn, sk[i])
-            eng.enqueue_flush()
-            torch.cuda.synchronize()
-            out["streamed_identical"] = bool(torch.equal(sk, keys[1]))
+            for mode, name in ((2, "q8"), (3, "fp16")):
+                same = bool(torch.equal(keys[1], keys[mode]))
+                out[f"keys_identical_{name}"] = same
+                if not same:
+                    bad = (keys[1] != keys[mode]).any(dim=1).nonzero().flatten().tolist()
+                    out[f"first_bad_queries_{name}"] = bad[:8]
+                # streamed too
+                sk = torch.zeros((args.check, args.topn), dtype=torch.int64, device="cuda")
+                eng.set_replica(mode)
+                for i in range(args.check):
+                    eng.enqueue_row_keys_streamed(rows[i], args.topn, sk[i])
+                eng.enqueue_flush()
+                torch.cuda.synchronize()
+                out[f"streamed_identical_{name}"] = bool(torch.equal(sk, keys[1]))
         ring = torch.zeros((64, args.topn), dtype=torch.int64, device="cuda")
-        for mode, name in ((capi.REPLICA_OFF, "fp32_rows"), (capi.REPLICA_ON, "replica")):
+        for mode, name in ((capi.REPLICA_OFF, "fp32_rows"), (capi.REPLICA_FP16, "replica_fp16"), (capi.REPLICA_ON, "replica_q8")):
             if args.only >= 0 and args.only != mode:
                 continue
             eng.set_replica(mode)
@@ -64,6 +66,7 @@ def main():
             eng.enqueue_flush()
             torch.cuda.synchronize()
             eng.set_timing(8)
+            c0 = eng.replica_counters()
             t0 = time.perf_counter()
             for i in range(args.steps):
                 eng.enqueue_row_keys_streamed(rows[20 + i], args.topn, ring[i % 64])
@@ -71,9 +74,12 @@ def main():
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / args.steps
             st = eng.stats()
+            c1 = eng.replica_counters()
             eng.set_timing(0)
             out[name] = {"us_per_step": round(dt * 1e6, 2), "queries_per_s": round(1.0 / dt, 1),
-                         "scan_kernel_us": round(float(st.last_scan_ms) * 1e3, 2)}
+                         "scan_kernel_us": round(float(st.last_scan_ms) * 1e3, 2),
+                         "rescored_per_query": round((c1["rescored_rows"] - c0["rescored_rows"]) / args.steps, 1),
+                         "grid_blocks": int(st.replica_grid_blocks)}
             # one query alone, synchronous API
             lat = []
             for i in range(200):
