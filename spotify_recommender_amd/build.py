@@ -23,7 +23,7 @@ HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc
 OFFLOAD_ARCH = "gfx950"
 
 ENGINE_SOURCES = [CSRC / "mi355rec.hip", CSRC / "sharded.hip"]
-ENGINE_DEPS = ENGINE_SOURCES + [CSRC / "kernels.hip.h", CSRC / "batched.hip.h", CSRC / "replica.hip.h", INCLUDE / "mi355rec.h"]
+ENGINE_DEPS = ENGINE_SOURCES + sorted(CSRC.glob("*.hip.h")) + [INCLUDE / "mi355rec.h"]
 
 # -ffp-contract=off: the parity contract is sequential multiply-then-add with no
 # FMA contraction (Recommender.cu:264-269 compiled by the reference Makefile:9).

@@ -123,8 +123,10 @@ struct mi355rec {
         uint64_t* out = nullptr;
         int seed_buf = 0;               // which of d_stream_seed holds ITS sample maxima
         bool q8 = false;                // that sample was taken over the 8-bit replica, so its scan runs there
+        bool cutoff_ready = false;      // ... by riders, whose last one left the launch-wide cutoff in d_stream_ctl
     } stashed;
     uint32_t* d_stream_seed[2] = {nullptr, nullptr};
+    SeedCtl* d_stream_ctl = nullptr;    // [2]: rider count and finished cutoff beside each of d_stream_seed (8-bit replica)
     // a STREAM of batches over the replica (mi355rec_enqueue_batch_keys_streamed)
     bool mstream_ready = false;
     uint64_t* d_mstream_lists[2] = {nullptr, nullptr};   // [kHmQueries][hgrid][kMultiMaxTopK], alternating
@@ -342,11 +344,12 @@ void plan_half_grid(mi355rec* h) {
 }
 
 void free_replica(mi355rec* h) {
-    void* bufs[] = {h->d_half, h->d_q8, h->d_half_seed, h->d_half_mseed, h->d_half_rescored, h->d_stream_seed[0], h->d_stream_seed[1]};
+    void* bufs[] = {h->d_half, h->d_q8, h->d_stream_ctl, h->d_half_seed, h->d_half_mseed, h->d_half_rescored, h->d_stream_seed[0], h->d_stream_seed[1]};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     h->d_half = nullptr;
     h->d_q8 = nullptr;
+    h->d_stream_ctl = nullptr;
     h->d_half_seed = nullptr;
     h->d_half_mseed = nullptr;
     h->d_half_rescored = nullptr;
@@ -363,6 +366,8 @@ int alloc_replica(mi355rec* h, int64_t n_padded) {
     for (int i = 0; i < 2; ++i)
         HIP_TRY(h, hipMalloc(&h->d_stream_seed[i], sizeof(uint32_t) * kHalfSeedMaxGrid * kHalfSeedWaves));
     HIP_TRY(h, hipMemsetAsync(h->d_half_rescored, 0, sizeof(unsigned long long) * kRideMaxLists, h->stream));
+    HIP_TRY(h, hipMalloc(&h->d_stream_ctl, sizeof(SeedCtl) * 2));
+    HIP_TRY(h, hipMemsetAsync(h->d_stream_ctl, 0, sizeof(SeedCtl) * 2, h->stream));
     return MI355REC_OK;
 }
 
@@ -616,6 +621,11 @@ bool use_half(const mi355rec* h, const uint64_t* upper_dev) {
 // Single queries prefer the 8-bit replica (half the bytes per row); MI355REC_REPLICA_FP16 keeps them on the fp16 one.
 bool use_q8(const mi355rec* h) { return h->d_q8 && h->replica_mode != MI355REC_REPLICA_FP16; }
 
+// Streamed launches over the 8-bit replica: the last seed rider out turns the sample into the next launch's
+// cutoff (saves a ~4 us select in every workgroup of that launch).  The riders then take sample + select
+// (~10 us) in all, so only where the scanners run longer than that.
+bool q8_hoists(const mi355rec* h) { return h->qg.riders > 0 && h->qg.r_iters >= 5; }
+
 // The sample that seeds the launch-wide cutoff of the next scan over the replica.
 void enqueue_half_seed(mi355rec* h, bool q8, const float* qptr, const QueryArg& qa, int64_t exclude_global, uint32_t* seed_out,
                        hipStream_t s) {
@@ -662,12 +672,14 @@ int enqueue_scan(mi355rec* h, const float* qptr, const float* query12,
                 LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, true, false>),
                              dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
                              h->d_feats, h->d_q8, h->n, h->qg.iters, h->row_base, qa, qptr, exclude_global, topn,
-                             h->d_block_lists, h->d_half_seed, h->qg.seed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next);
+                             h->d_block_lists, h->d_half_seed, h->qg.seed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next,
+                             static_cast<const float*>(nullptr));
             } else {
                 LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, false, false>),
                              dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
                              h->d_feats, h->d_q8, h->n, h->qg.iters, h->row_base, qa, kNoQueryPtr, exclude_global, topn,
-                             h->d_block_lists, h->d_half_seed, h->qg.seed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next);
+                             h->d_block_lists, h->d_half_seed, h->qg.seed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next,
+                             static_cast<const float*>(nullptr));
             }
             HIP_TRY(h, hipGetLastError());
             return MI355REC_OK;
@@ -1035,11 +1047,11 @@ int ensure_streamed_alloc(mi355rec* h) {
 }
 
 int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, const float* next_ptr, const float* next_q,
-                   int64_t next_exclude, int next_buf);
+                   int64_t next_exclude, int next_topn, int next_buf);
 
 int flush_streamed(mi355rec* h, hipStream_t s) {
     if (h->stashed.has) {
-        const int rc = launch_stashed(h, s, false, nullptr, nullptr, -1, 0);
+        const int rc = launch_stashed(h, s, false, nullptr, nullptr, -1, 0, 0);
         if (rc) return rc;
     }
     if (!h->pending) return MI355REC_OK;
@@ -1051,7 +1063,7 @@ int flush_streamed(mi355rec* h, hipStream_t s) {
 // Launches the stashed streamed query over the replica: scanners + the riding merger of the query
 // before it + (with_next) the seed riders of the query after it.
 int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, const float* next_ptr, const float* next_q,
-                   int64_t next_exclude, int next_buf) {
+                   int64_t next_exclude, int next_topn, int next_buf) {
     auto& st = h->stashed;
     const int buf = h->pending ? 1 - h->pending_buf : 0;
     PrevMerge prev{nullptr, 0, 0, nullptr};
@@ -1070,6 +1082,8 @@ int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, const float* next
         next.n_wgs = g.riders;
         next.regions = g.seed_grid;
         next.stride_rows = g.seed_stride;
+        next.ctl = (st.q8 && q8_hoists(h)) ? h->d_stream_ctl + next_buf : nullptr;
+        next.topk = next_topn;
         scanners = g.r_scan;
         iters = g.r_iters;
     }
@@ -1080,17 +1094,18 @@ int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, const float* next
     ++h->half_scans;
     if (st.q8) {
         ++h->q8_scans;
+        const float* ready = st.cutoff_ready ? &h->d_stream_ctl[st.seed_buf].cutoff : nullptr;
         if (st.qptr) {
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, true, true>),
                          dim3(scanners + 1 + next.n_wgs), dim3(Q8Config::kBlock), s,
                          h->d_feats, h->d_q8, h->n, iters, h->row_base, qa, st.qptr, st.exclude, st.topn,
-                         h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], n_seed, h->d_half_rescored, prev, next);
+                         h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], n_seed, h->d_half_rescored, prev, next, ready);
         } else {
             std::memcpy(qa.q, st.q, sizeof qa.q);
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, false, true>),
                          dim3(scanners + 1 + next.n_wgs), dim3(Q8Config::kBlock), s,
                          h->d_feats, h->d_q8, h->n, iters, h->row_base, qa, kNoQueryPtr, st.exclude, st.topn,
-                         h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], n_seed, h->d_half_rescored, prev, next);
+                         h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], n_seed, h->d_half_rescored, prev, next, ready);
         }
     } else if (st.qptr) {
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, true, true>),
@@ -1143,7 +1158,7 @@ int enqueue_streamed(mi355rec* h, const float* qptr, const float* query12, int64
             // the riders of a launch sample the replica that launch scans: a change of replica
             // (mi355rec_set_replica) between two calls costs the next query a seed launch of its own
             sampled = h->stashed.q8 == q8 && (q8 ? h->qg.riders : h->hg.riders) > 0;
-            rc = launch_stashed(h, s, sampled, qptr, query12, exclude_global, seed_buf);
+            rc = launch_stashed(h, s, sampled, qptr, query12, exclude_global, topn, seed_buf);
             if (rc) return rc;
         }
         if (!sampled && (q8 ? h->qg.seed_grid : h->hg.seed_grid) > 0) {   // first query of a stream, or a shard too small to spare riders
@@ -1160,10 +1175,11 @@ int enqueue_streamed(mi355rec* h, const float* qptr, const float* query12, int64
         st.out = out_keys;
         st.seed_buf = seed_buf;
         st.q8 = q8;
+        st.cutoff_ready = q8 && sampled && q8_hoists(h);
         return MI355REC_OK;
     }
     if (h->stashed.has) {   // the path changed under a stream (mi355rec_set_replica): the stashed query goes first
-        rc = launch_stashed(h, s, false, nullptr, nullptr, -1, 0);
+        rc = launch_stashed(h, s, false, nullptr, nullptr, -1, 0, 0);
         if (rc) return rc;
     }
     // The fp32 scan's riding merger keeps 2048 survivors; with ~770 lists and topN near 1000 about
@@ -1827,6 +1843,14 @@ int mi355rec_set_replica(mi355rec_t* h, int mode) {
     h->replica_mode = mode;
     return MI355REC_OK;
 }
+
+#ifdef MI355REC_PHASE_CLOCK   // tools/phase_clock.py builds only
+int mi355rec_debug_phase_clock(unsigned long long* out, int n_words) {
+    if (hipDeviceSynchronize() != hipSuccess) return MI355REC_ERR_HIP;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mi355::g_phase_clock), sizeof(unsigned long long) * n_words) == hipSuccess
+               ? MI355REC_OK : MI355REC_ERR_HIP;
+}
+#endif
 
 int mi355rec_replica_counters(mi355rec_t* h, int64_t* scans, int64_t* rescored_rows) {
     if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");

@@ -215,6 +215,11 @@ __global__ __launch_bounds__(kHalfSeedBlock) void seed_half_kernel(
 // merger come next.n_wgs "seed riders").  They are resident from the start like everybody else — the
 // host launches that many scanners fewer — and each walks its share of the regions, four loads in
 // flight at a time.
+struct SeedCtl {
+    unsigned done;    // riders that have stored their maxima (reset by the last one)
+    float cutoff;     // the next launch's launch-wide cutoff (-inf: none)
+};
+
 struct NextSeed {
     float q[kDim];             // the next query (used when query_ptr is null)
     const float* query_ptr;    // ... or where its 12 floats live (a resident row, possibly of another shard)
@@ -223,6 +228,10 @@ struct NextSeed {
     int n_wgs;                 // seed riders in this launch (0 = none)
     int regions;
     long long stride_rows;
+    // 8-bit replica only (replica_q8.hip.h): the rider that finishes LAST turns the sample into the next launch's
+    // cutoff, so that launch starts scanning at once instead of selecting in every workgroup
+    SeedCtl* ctl;
+    int topk;                  // of the next query
 };
 
 __device__ __forceinline__ void seed_rider(const float* __restrict__ feats, const uint4* __restrict__ half, int64_t n,

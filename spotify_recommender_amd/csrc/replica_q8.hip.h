@@ -164,7 +164,9 @@ __device__ __forceinline__ void q8_region_finish(const Q8Region& s, const Q8Quer
         v = w > v ? w : v;
     }
     v = wave_max_u32(v);
-    if ((threadIdx.x & 63) == 0) seed_vals[g * kHalfSeedWaves + (threadIdx.x >> 6)] = v;
+    // written THROUGH to device scope: a rider of the same launch may read it (scan_q8_kernel, last rider out)
+    if ((threadIdx.x & 63) == 0)
+        __hip_atomic_store(&seed_vals[g * kHalfSeedWaves + (threadIdx.x >> 6)], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ void q8_load_query(const float* __restrict__ query_ptr, const float (&by_value)[kDim], float (&q)[kDim]) {
@@ -190,8 +192,8 @@ __global__ __launch_bounds__(kHalfSeedBlock) void seed_q8_kernel(
 }
 
 // The seed riders of a streamed launch (replica.hip.h, seed_rider): four regions per memory round trip.
-__device__ __forceinline__ void q8_seed_rider(const uint4* __restrict__ q8, int64_t n, int64_t row_base, const NextSeed& next,
-                                              int rider) {
+__device__ __forceinline__ Q8Query q8_seed_rider(const uint4* __restrict__ q8, int64_t n, int64_t row_base, const NextSeed& next,
+                                                 int rider) {
     float q[kDim];
     q8_load_query(next.query_ptr, next.q, q);
     const Q8Query hq = q8_query(q, query_norm(q));
@@ -210,7 +212,52 @@ __device__ __forceinline__ void q8_seed_rider(const uint4* __restrict__ q8, int6
             if (g < next.regions) q8_region_finish(s[u], hq, n, row_base, next.exclude_global, next.out, g);   // uniform
         }
     }
+    return hq;
 }
+
+// The launch-wide cutoff from n_seed sample maxima (approximate scores, ordered; 0 = empty): a row whose
+// approximate score is below it cannot be among the best topk.  -inf when the sample cannot say.
+template <int kBlock, bool kSameLaunch = false>
+__device__ __forceinline__ float q8_cutoff_from_sample(const uint32_t* seed_vals, int n_seed, int topk,
+                                                       const Q8Query& hq, int* s_seeds /* zeroed */, SelectSmem& s_sel) {
+    const int tid = threadIdx.x;
+    float cutoff = -__builtin_inff();
+    if (hq.ok && n_seed > 0) {   // uniform
+        uint64_t mine[kHalfSeedPerThread];
+        int have = 0;
+#pragma unroll
+        for (int r = 0; r < kHalfSeedPerThread; ++r) {
+            const int i = tid + r * kBlock;
+            uint32_t v = 0u;
+            if (i < n_seed)   // kSameLaunch: written by other workgroups of THIS launch
+                v = kSameLaunch ? __hip_atomic_load(&seed_vals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : seed_vals[i];
+            mine[r] = v ? (static_cast<uint64_t>(v) << 32) | static_cast<uint32_t>(i + 1) : 0ull;
+            have += v != 0u;
+        }
+        if (have) atomicAdd(s_seeds, have);
+        __syncthreads();
+        if (*s_seeds >= topk) {   // uniform
+            // any T with at least topk maxima >= T will do: stopping a few keys early (<= topk/8 + 2 extra) saves
+            // most of the radix passes and moves the cutoff by a hair
+            const uint64_t t = block_select_threshold<kBlock, kHalfSeedPerThread>(mine, topk, false, topk / 8 + 2, s_sel);
+            const float v = ordered_to_score(static_cast<uint32_t>(t >> 32));
+            cutoff = v - 2.0f * hq.margin;   // (the margin carries its own slack)
+        }
+    }
+    return cutoff;
+}
+
+#ifdef MI355REC_PHASE_CLOCK   // tools/ builds only: where a launch spends its time (100 MHz wall clock, per workgroup)
+__device__ unsigned long long g_phase_clock[1024 * 8];
+#define MI355REC_PHASE(i)                                                                   \
+    do {                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) g_phase_clock[blockIdx.x * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define MI355REC_PHASE(i) \
+    do {                  \
+    } while (0)
+#endif
 
 // ---- the scan ----------------------------------------------------------------------------------------------
 template <int kBlockT, int kMinWavesT, int kDepthT>
@@ -226,16 +273,22 @@ using DefaultQ8Cfg = Q8Cfg<512, 4, 2>;
 
 // kWithMerge (streamed queries): workgroups [0, S) scan, workgroup S merges the PREVIOUS streamed query,
 // workgroups (S, gridDim) are seed riders for the NEXT one; S = gridDim.x - 1 - next.n_wgs (scan_half_kernel).
+//
+// Tiles are dealt round-robin.  Handing them out dynamically (ticket counters, the merger and the riders joining
+// once their job was done) was built and measured: every workgroup then finished within 2 us of the others
+// instead of 8 — and the launch took as long as before, because between prologue and last tile the launch
+// already moves its bytes at ~6.5 TB/s and early finishers only leave that bandwidth to the rest.
 template <typename Cfg, bool kQueryFromRow, bool kWithMerge>
 __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
     const float* __restrict__ feats, const uint4* __restrict__ q8, int64_t n, int iters, int64_t row_base,
     QueryArg qarg, const float* __restrict__ query_ptr, int64_t exclude_global, int topk, uint64_t* __restrict__ block_lists,
     const uint32_t* __restrict__ seed_vals, int n_seed, unsigned long long* __restrict__ rescored /* [scanning workgroups] */,
-    PrevMerge prev, NextSeed next) {
+    PrevMerge prev, NextSeed next, const float* __restrict__ cutoff_ready /* null: select from seed_vals here */) {
     constexpr int kBlock = Cfg::kBlock;
     __shared__ typename std::conditional<kWithMerge, HalfScanOrMergeSmem<Cfg>, HalfScanSmemT<Cfg>>::type s_mem;
     HalfScanSmemT<Cfg>* sm;
     unsigned nblocks = gridDim.x;   // scanning workgroups
+    MI355REC_PHASE(0);
     if constexpr (kWithMerge) {
         nblocks = gridDim.x - 1u - static_cast<unsigned>(next.n_wgs);
         if (blockIdx.x >= nblocks) {
@@ -246,8 +299,32 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
                                static_cast<float*>(nullptr), static_cast<int64_t>(0), static_cast<int64_t>(0),
                                static_cast<int64_t>(0));
             } else {
-                q8_seed_rider(q8, n, row_base, next, static_cast<int>(blockIdx.x - nblocks - 1u));
+                const Q8Query nq = q8_seed_rider(q8, n, row_base, next, static_cast<int>(blockIdx.x - nblocks - 1u));
+                // Last rider out turns the sample into the cutoff.  No device-wide fence: on this part a release /
+                // acquire pair at agent scope writes back and invalidates the whole L2 under the scanners (measured:
+                // the launch took 43 us instead of 28).  Instead the maxima are stored and loaded as device-scope
+                // atomics (write-through stores, L2-bypassing loads); each wave waits for its stores to complete
+                // (workgroup-scope release = s_waitcnt), one thread counts, and the last workgroup's loads are issued
+                // after its counter value came back.
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    s_mem.scan.seeds = 0;
+                    s_mem.scan.count = next.ctl && __hip_atomic_fetch_add(&next.ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                                                       static_cast<unsigned>(next.n_wgs) - 1u;
+                }
+                __syncthreads();
+                if (s_mem.scan.count) {   // uniform
+                    const float c = q8_cutoff_from_sample<kBlock, true>(next.out, next.regions * kHalfSeedWaves, next.topk, nq,
+                                                                        &s_mem.scan.seeds, s_mem.scan.sel);
+                    if (threadIdx.x == 0) {
+                        next.ctl->cutoff = c;
+                        next.ctl->done = 0u;
+                    }
+                }
             }
+            __syncthreads();
+            MI355REC_PHASE(5);
             return;
         }
         sm = &s_mem.scan;
@@ -267,6 +344,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
     q8_load_query(kQueryFromRow ? query_ptr : nullptr, qarg.q, q);
     const float qn = query_norm(q);
     const Q8Query hq = q8_query(q, qn);
+    if (hq.c != 0.0f || n >= 0) MI355REC_PHASE(1);   // (depends on the query: not hoisted above its load)
 
     const int64_t n_quads = (n + 3) >> 2;
     const int64_t last_quad = n_quads - 1;
@@ -287,7 +365,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
 #pragma unroll
     for (int d = 0; d < kDepth - 1; ++d) load_tile(ring[d], d);
 
-    // ---- launch-wide cutoff from the sample maxima (while the first tiles are in flight)
+    // ---- launch-wide cutoff (while the first tiles are in flight)
     if (tid == 0) {
         s_count = 0;
         sm->seeds = 0;
@@ -295,26 +373,13 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
     }
     int n_rescored = 0;   // wave-uniform: rows this wave sent to the exact chain (diagnostics)
     __syncthreads();
-    const float neg_inf = -__builtin_inff();
-    float cutoff = neg_inf;   // -inf: everything is fetched and scored exactly
-    if (hq.ok && n_seed > 0) {   // uniform
-        uint64_t mine[kHalfSeedPerThread];
-        int have = 0;
-#pragma unroll
-        for (int r = 0; r < kHalfSeedPerThread; ++r) {
-            const int i = tid + r * kBlock;
-            const uint32_t v = i < n_seed ? seed_vals[i] : 0u;
-            mine[r] = v ? (static_cast<uint64_t>(v) << 32) | static_cast<uint32_t>(i + 1) : 0ull;
-            have += v != 0u;
-        }
-        if (have) atomicAdd(&sm->seeds, have);
-        __syncthreads();
-        if (sm->seeds >= topk) {   // uniform
-            const uint64_t t = block_select_threshold<kBlock, kHalfSeedPerThread>(mine, topk, true, 0, s_sel);
-            const float v = ordered_to_score(static_cast<uint32_t>(t >> 32));
-            cutoff = v - 2.0f * hq.margin;   // (the margin carries its own slack)
-        }
+    float cutoff;
+    if (cutoff_ready) {   // uniform: the riders of the launch before this one left it
+        cutoff = *cutoff_ready;
+    } else {
+        cutoff = q8_cutoff_from_sample<kBlock>(seed_vals, n_seed, topk, hq, &sm->seeds, s_sel);
     }
+    MI355REC_PHASE(2);
     uint64_t thr = 0;
     int compact_at = 2 * topk > 256 ? 2 * topk : 256;
     if (compact_at > kCandLimit) compact_at = kCandLimit;
@@ -404,11 +469,14 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
 
     if (lane == 0 && n_rescored) atomicAdd(&sm->rescored, n_rescored);
     __syncthreads();
+    MI355REC_PHASE(3);
     if (tid == 0) rescored[bid] += static_cast<unsigned long long>(sm->rescored);   // launches of a handle are stream-ordered
     if (s_count > kRankDirectMax && s_count > topk)  // uniform
         compact_candidates<kBlock, Cfg::kCandPerThread>(s_cand, &s_count, topk, true, s_sel);
     __syncthreads();
     block_rank_and_store<kBlock>(s_cand, s_count, block_lists + static_cast<int64_t>(bid) * topk, topk);
+    __syncthreads();
+    MI355REC_PHASE(4);
 }
 
 }  // namespace mi355

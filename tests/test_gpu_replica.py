@@ -356,12 +356,13 @@ def test_sharded_node_with_replica_sized_shards():
         assert_topn_matches(idx, sc, want, -1, 10, ref_idx=oracle.topn_heap(want, -1, 10))
 
 
-@pytest.mark.parametrize("n", [777, 5000, 40_000, 700_001])
+@pytest.mark.parametrize("n", [777, 5000, 40_000, 700_001, 4_000_001])
 def test_streams_run_one_call_behind(Engine, torch_cuda, n):
     """Over the replica a streamed query is LAUNCHED by the next streamed call (whose sample rides in
     that launch) or by the flush: streams of one query, mixed row / vector queries with different
     topn, synchronous queries in between, a flush in the middle, shards too small to spare seed
-    riders (5000 rows) or to have a sample at all (777 rows)."""
+    riders (5000 rows) or to have a sample at all (777 rows), and one large enough (4 M rows) for the
+    8-bit scan's ticketed tiles and for the cutoff its last seed rider leaves for the next launch."""
     torch = torch_cuda
     rng = np.random.default_rng(n)
     f = rng.random((n, 12), dtype=np.float32)
@@ -442,3 +443,37 @@ def test_replica_built_on_demand_under_a_running_stream(Engine, torch_cuda):
             idx, sc = unpack_keys(got[i])
             assert_topn_matches(idx, sc, want, r, topn, ref_idx=oracle.topn_heap(want, r, topn))
         assert eng.replica_counters()["scans"] == 10
+
+
+@pytest.mark.parametrize("ordered", [False, True])
+def test_long_stream_over_a_large_shard(Engine, torch_cuda, ordered):
+    """60 streamed queries over 5 M rows (8-bit replica: tiles handed out by ticket, every workgroup a list,
+    cutoff from the previous launch's last seed rider), uniform and sorted by similarity to the queries'
+    neighbourhood (every best row in the last tiles): each key list against the oracle, and every row
+    scanned exactly once (a tile taken twice would show as a duplicate key, one dropped as a missing one)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(77 + ordered)
+    n = 5_000_003
+    f = rng.random((n, 12), dtype=np.float32)
+    if ordered:
+        t = np.sort(rng.random(n)).astype(np.float32)
+        f[:, :6] = (0.1 + 0.9 * t)[:, None]
+        f[:, 6:] = 1.0 + rng.random((n, 6), dtype=np.float32) * np.float32(1e-3)
+    qrows = rng.integers(0, n, size=60)
+    qrows[:4] = (0, n - 1, n - 2049, 2048)
+    topns = [int(t) for t in rng.choice([1, 10, 100, 1000], size=60)]
+    with Engine(f) as eng:
+        eng.set_replica(ON)
+        outs = [torch.zeros(t, dtype=torch.int64, device="cuda") for t in topns]
+        for i, r in enumerate(qrows):
+            eng.enqueue_row_keys_streamed(int(r), topns[i], outs[i])
+            if i == 30:
+                eng.enqueue_flush()
+        eng.enqueue_flush()
+        torch.cuda.synchronize()
+        for i, r in enumerate(qrows):
+            got = outs[i].cpu().numpy().view(np.uint64)
+            assert len(np.unique(got)) == len(got), f"query {i}: duplicate keys"
+            want = oracle.scores(f, f[r], threads=0)
+            idx = (~got & np.uint64(0xffffffff)).astype(np.int64)
+            assert_topn_matches(idx, None, want, int(r), topns[i], ref_idx=oracle.topn_heap(want, int(r), topns[i]))
