@@ -85,7 +85,8 @@ typedef struct {
     int64_t replica_single_bytes_per_query; /* algorithmic bytes of one SINGLE-query scan over the replica it currently
                                     uses: ceil(rows/4) * 48 over the 8-bit one, ceil(rows/2) * 48 over the fp16 one   */
     int32_t replica_single_row_bytes; /* 12 (8-bit replica), 24 (fp16 replica, MI355REC_REPLICA_FP16) or 0 (no replica)  */
-    int32_t reserved0;
+    int32_t lone_fused_queries; /* synchronous single queries served by ONE scan launch that also merged and raised the
+                                    completion word (8-bit replica, shards of >= 4 M rows), since create */
 } mi355rec_stats_t;
 
 /* Number of visible HIP devices (0 when there is none / no driver). */

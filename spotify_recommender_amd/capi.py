@@ -48,7 +48,7 @@ class Stats(ctypes.Structure):
         ("replica_margin_multi", c_float),
         ("replica_single_bytes_per_query", c_int64),
         ("replica_single_row_bytes", c_int32),
-        ("reserved0", c_int32),
+        ("lone_fused_queries", c_int32),
     ]
 
 

@@ -298,10 +298,21 @@ __device__ inline uint64_t block_select_threshold(const uint64_t (&mine)[kPerThr
 // the workgroup must call it (barriers inside).
 constexpr int kRankDirectMax = 384;   // callers cut larger survivor sets to exactly topk first (O(c) select)
 constexpr int kRankCountMax = 160;
-template <int kThreads>
+// kCoherent: the list is stored THROUGH to device scope (another workgroup of the same launch will read it:
+// lone_tail).
+template <bool kCoherent>
+__device__ __forceinline__ void st_key(uint64_t* p, uint64_t v) {
+    if constexpr (kCoherent) {
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *p = v;
+    }
+}
+
+template <int kThreads, bool kCoherent = false>
 __device__ inline void block_rank_and_store(uint64_t* s_keys, int c, uint64_t* dst, int topk) {
     for (int i = threadIdx.x; i < topk; i += kThreads) {
-        if (i >= c) dst[i] = 0ull;
+        if (i >= c) st_key<kCoherent>(&dst[i], 0ull);
     }
     if (c > kRankCountMax) {   // uniform
         int p2 = 256;
@@ -325,7 +336,7 @@ __device__ inline void block_rank_and_store(uint64_t* s_keys, int c, uint64_t* d
             }
         }
         const int n_out = c < topk ? c : topk;
-        for (int i = threadIdx.x; i < n_out; i += kThreads) dst[i] = s_keys[i];
+        for (int i = threadIdx.x; i < n_out; i += kThreads) st_key<kCoherent>(&dst[i], s_keys[i]);
         return;
     }
     for (int i = threadIdx.x; i < c; i += kThreads) {
@@ -339,7 +350,7 @@ __device__ inline void block_rank_and_store(uint64_t* s_keys, int c, uint64_t* d
                     (k4 > mine) + (k5 > mine) + (k6 > mine) + (k7 > mine);
         }
         for (; j < c; ++j) rank += (s_keys[j] > mine);
-        if (rank < topk) dst[rank] = mine;
+        if (rank < topk) st_key<kCoherent>(&dst[rank], mine);
     }
 }
 
@@ -388,8 +399,19 @@ __device__ inline uint64_t compact_candidates(uint64_t* s_cand, int* s_count, in
 // (adversarial input), an exact radix select over all keys in global memory
 // finds the topk-th key instead.
 
-template <int kThreads>
-__device__ inline uint64_t merge_global_radix_select(const uint64_t* __restrict__ lists,
+// Lists written by OTHER workgroups of the SAME launch (lone_tail below) are read past this XCD's L2, with
+// device-scope atomic loads; lists of an earlier launch with plain loads.
+template <bool kCoherent>
+__device__ __forceinline__ uint64_t ld_key(const uint64_t* p) {
+    if constexpr (kCoherent) {
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        return *p;
+    }
+}
+
+template <int kThreads, bool kCoherent = false>
+__device__ inline uint64_t merge_global_radix_select(const uint64_t* lists,
                                                      int64_t total, int list_len, int64_t list_stride,
                                                      int topk, int* s_hist, int* s_pair) {
     // returns the topk-th largest key (0 if fewer than topk non-zero keys)
@@ -400,7 +422,7 @@ __device__ inline uint64_t merge_global_radix_select(const uint64_t* __restrict_
         __syncthreads();
         const int shift = pass * 8;
         for (int64_t i = threadIdx.x; i < total; i += kThreads) {
-            const uint64_t k = lists[(i / list_len) * list_stride + (i % list_len)];
+            const uint64_t k = ld_key<kCoherent>(&lists[(i / list_len) * list_stride + (i % list_len)]);
             if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255], 1);
         }
         __syncthreads();
@@ -440,9 +462,9 @@ struct MergeSmemT {
     unsigned short active[kMaxLists];
 };
 
-template <int kThreads, int kMaxLists, int kSurvCap>
+template <bool kCoherent = false, int kThreads, int kMaxLists, int kSurvCap>
 __device__ __forceinline__ void merge_body(
-    MergeSmemT<kThreads, kMaxLists, kSurvCap>& sm, const uint64_t* __restrict__ lists_base, int n_lists, int list_len, int64_t list_stride,
+    MergeSmemT<kThreads, kMaxLists, kSurvCap>& sm, const uint64_t* lists_base, int n_lists, int list_len, int64_t list_stride,
     int64_t lists_query_stride, int topk, uint64_t* __restrict__ out_keys_base,
     int64_t* __restrict__ out_idx_base, float* __restrict__ out_score_base,
     int64_t out_query_stride, int64_t slot, int64_t out_slot) {
@@ -484,7 +506,7 @@ __device__ __forceinline__ void merge_body(
         // take every key in one load phase; the select / rank below does the rest.
         first = list_len;
         for (int64_t i = tid; i < total_keys; i += kThreads) {
-            const uint64_t k = lists[(i / list_len) * list_stride + (i % list_len)];
+            const uint64_t k = ld_key<kCoherent>(&lists[(i / list_len) * list_stride + (i % list_len)]);
             if (k) s_surv[atomicAdd(&s_count, 1)] = k;
         }
     } else if (probe == 1 && n_lists * kMergeFirst <= kThreads * kFirstPer) {
@@ -500,7 +522,7 @@ __device__ __forceinline__ void merge_body(
 #pragma unroll
         for (int u = 0; u < kFirstPer; ++u) {
             const int l = (u * kThreads + tid) / kMergeFirst;
-            k[u] = (l < n_lists && j < list_len) ? lists[static_cast<int64_t>(l) * list_stride + j] : 0ull;
+            k[u] = (l < n_lists && j < list_len) ? ld_key<kCoherent>(&lists[static_cast<int64_t>(l) * list_stride + j]) : 0ull;
         }
 #pragma unroll
         for (int u = 0; u < kFirstPer; ++u) {
@@ -533,7 +555,7 @@ __device__ __forceinline__ void merge_body(
 #pragma unroll
         for (int r = 0; r < kHeadsPer; ++r) {
             const int l = tid + r * kThreads;
-            heads[r] = l < n_lists ? lists[static_cast<int64_t>(l) * list_stride + (probe - 1)] : 0ull;
+            heads[r] = l < n_lists ? ld_key<kCoherent>(&lists[static_cast<int64_t>(l) * list_stride + (probe - 1)]) : 0ull;
             local_nonzero += heads[r] != 0ull;
             if (l < n_lists) s_active[l] = 0;
         }
@@ -564,7 +586,7 @@ __device__ __forceinline__ void merge_body(
                 const int l = t / kMergeChunk;
                 const int pos = first + round * kMergeChunk + (t % kMergeChunk);
                 const bool live = t < total && pos < list_len && s_active[l] == round;
-                k[u] = live ? lists[static_cast<int64_t>(l) * list_stride + pos] : 0ull;
+                k[u] = live ? ld_key<kCoherent>(&lists[static_cast<int64_t>(l) * list_stride + pos]) : 0ull;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -580,7 +602,7 @@ __device__ __forceinline__ void merge_body(
         for (int l = tid; l < n_lists; l += kThreads) {
             if (s_active[l] == round) {
                 const int last = first + (round + 1) * kMergeChunk - 1;
-                if (last < list_len && lists[static_cast<int64_t>(l) * list_stride + last] >= thr) {
+                if (last < list_len && ld_key<kCoherent>(&lists[static_cast<int64_t>(l) * list_stride + last]) >= thr) {
                     s_active[l] = static_cast<unsigned short>(round + 1);
                     s_more = 1;
                 }
@@ -592,13 +614,13 @@ __device__ __forceinline__ void merge_body(
     if (s_overflow) {
         // exact fallback: radix-select the topk-th key over everything
         const int64_t total = static_cast<int64_t>(n_lists) * list_len;
-        uint64_t kth = merge_global_radix_select<kThreads>(lists, total, list_len, list_stride, topk, s_sel.hist, s_pair);
+        uint64_t kth = merge_global_radix_select<kThreads, kCoherent>(lists, total, list_len, list_stride, topk, s_sel.hist, s_pair);
         if (kth == 0) kth = 1;
         if (tid == 0) s_count = 0;
         __syncthreads();
         for (int64_t i0 = 0; i0 < total; i0 += kThreads) {
             const int64_t i = i0 + tid;
-            const uint64_t k = (i < total) ? lists[(i / list_len) * list_stride + (i % list_len)] : 0ull;
+            const uint64_t k = (i < total) ? ld_key<kCoherent>(&lists[(i / list_len) * list_stride + (i % list_len)]) : 0ull;
             if (k >= kth) {
                 const int pos = atomicAdd(&s_count, 1);  // exactly topk keys when unique
                 if (pos < kSurvCap) s_surv[pos] = k;
@@ -642,6 +664,56 @@ __device__ __forceinline__ void merge_body(
             out_score_base[out_slot * out_query_stride + i] =
                 k ? ordered_to_score(static_cast<uint32_t>(k >> 32)) : 0.0f;
         }
+    }
+}
+
+// ---- one launch per lone query --------------------------------------------------
+// A caller that waits for ONE query on the host (mi355rec_query_row_topn, what Recommender::recommend sits on)
+// pays three launches: sample, scan, merge.  With a LoneTail (the scan over the 8-bit replica on shards of
+// >= 4 M rows; measured from C++: 46 us instead of 49 at 10 M rows, but 31 instead of 28 at 1 M, where the
+// separate 1024-thread merge kernel beats the last workgroup of the scan) the scan is the last one: every workgroup
+// stores its list through to device scope and counts itself out (two levels: eight group counters, then one, so
+// that no counter sees more than ~100 arrivals); the workgroup that finds itself last merges all lists — read
+// past its L2 — into the caller's buffers and, like merge_notify_kernel, raises the completion word the host
+// polls.  No fences under the scanners (see scan_q8_kernel's seed riders for what those cost) and no spinning:
+// every workgroup leaves after one atomic or two.
+struct LoneTail {
+    unsigned* counters;       // [9]: groups 0..7 (blockIdx % 8), then the count of finished groups; all zero between launches
+    uint64_t* out_keys;
+    int64_t* out_idx;         // may be device-visible pinned host memory
+    float* out_score;
+    uint32_t* done_word;      // null: no completion word
+    uint32_t done_value;
+};
+
+// Every thread of every workgroup calls this after block_rank_and_store<.., true>; `s_flag` is any LDS word the
+// caller can spare.  n_lists = gridDim.x lists of topk keys at `lists`.
+template <typename MergeSmem>
+__device__ __forceinline__ void lone_tail(MergeSmem& msm, int* s_flag, const uint64_t* lists, int topk, const LoneTail& lt) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's list stores have completed (s_waitcnt)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned groups = gridDim.x < 8u ? gridDim.x : 8u;
+        const unsigned g = blockIdx.x % groups;
+        const unsigned members = (gridDim.x - g + groups - 1u) / groups;
+        int last = 0;
+        if (__hip_atomic_fetch_add(&lt.counters[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
+            lt.counters[g] = 0u;   // (visible to the next launch)
+            last = __hip_atomic_fetch_add(&lt.counters[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1u;
+            if (last) lt.counters[8] = 0u;
+        }
+        *s_flag = last;
+    }
+    __syncthreads();
+    if (!*s_flag) return;   // uniform
+    __syncthreads();          // (the flag may live in the union the merge is about to use)
+    merge_body<true>(msm, lists, static_cast<int>(gridDim.x), topk, static_cast<int64_t>(topk), static_cast<int64_t>(0), topk,
+                     lt.out_keys, lt.out_idx, lt.out_score, static_cast<int64_t>(0), static_cast<int64_t>(0),
+                     static_cast<int64_t>(0));
+    if (lt.done_word) {   // uniform
+        __threadfence_system();   // every thread: its result stores are ordered before ...
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(lt.done_word, lt.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... the word
     }
 }
 

@@ -100,6 +100,8 @@ struct mi355rec {
     uint32_t* d_half_seed = nullptr;    // kHalfSeedMaxGrid x 8 sample maxima of the query in flight
     uint32_t* d_half_mseed = nullptr;   // kHmQueries x that: the sample of a multi-query pass over the replica
     unsigned long long* d_half_rescored = nullptr;   // [kRideMaxLists] rows sent to the exact chain, per workgroup slot
+    unsigned* d_lone_ctr = nullptr;     // [9] arrival counters of a lone query's launch (kernels.hip.h, LoneTail); zero between launches
+    int64_t lone_fused = 0;             // lone queries served by one launch (scan + merge + completion word)
     int64_t half_scans = 0;             // replica scans enqueued since create ...
     int64_t q8_scans = 0;               // ... of which over the 8-bit replica
     ReplicaGeom hg;                     // geometry of the scan over the fp16 replica ...
@@ -498,6 +500,8 @@ int create_common(const float* feats, bool on_device, int64_t n, int dim, int de
     if (multi_words > list_words) list_words = multi_words;
     if ((e = hipMalloc(&h->d_block_lists, sizeof(uint64_t) * list_words)) != hipSuccess)
         return cleanup(MI355REC_ERR_OUT_OF_MEMORY, "hipMalloc(block lists)", e);
+    if ((e = hipMalloc(&h->d_lone_ctr, sizeof(unsigned) * 16)) != hipSuccess || (e = hipMemset(h->d_lone_ctr, 0, sizeof(unsigned) * 16)) != hipSuccess)
+        return cleanup(MI355REC_ERR_OUT_OF_MEMORY, "hipMalloc(lone counters)", e);
     if ((e = hipMalloc(&h->d_seed_vals, sizeof(uint32_t) * kMultiChain * static_cast<size_t>(h->mgrid) * kSeedWaves)) != hipSuccess)
         return cleanup(MI355REC_ERR_OUT_OF_MEMORY, "hipMalloc(seed values)", e);
     if ((e = hipMalloc(&h->d_seed_keys, sizeof(uint64_t) * kMultiChain * kMultiMaxTopK)) != hipSuccess)
@@ -653,13 +657,19 @@ void enqueue_half_seed(mi355rec* h, bool q8, const float* qptr, const QueryArg& 
 // Enqueue the scan for one query.  qptr != null: the kernel reads the query's 12 floats from there
 // (a resident row, or any other device-readable address).
 // *n_lists = per-workgroup lists it leaves in d_block_lists.
+// lone != null (a lone query whose caller waits on the host): over the 8-bit replica of a large shard the launch
+// also merges its own lists into lone's buffers (kernels.hip.h, lone_tail) and *fused is set.
+constexpr int64_t kLoneFusedMinRows = 4000000;
 int enqueue_scan(mi355rec* h, const float* qptr, const float* query12,
-                 int64_t exclude_global, int topn, const uint64_t* upper_dev, hipStream_t s, int* n_lists) {
+                 int64_t exclude_global, int topn, const uint64_t* upper_dev, hipStream_t s, int* n_lists,
+                 const LoneTail* lone = nullptr, bool* fused = nullptr) {
     QueryArg qa;
     std::memset(&qa, 0, sizeof qa);
     qa.margin = h->margin_mix;
     if (!qptr) std::memcpy(qa.q, query12, sizeof qa.q);
     const PrevMerge none{nullptr, 0, 0, nullptr};
+    const LoneTail no_tail{nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+    if (fused) *fused = false;
     if (use_half(h, upper_dev)) {
         NextSeed no_next;
         std::memset(&no_next, 0, sizeof no_next);
@@ -668,18 +678,36 @@ int enqueue_scan(mi355rec* h, const float* qptr, const float* query12,
             *n_lists = h->qg.grid;
             ++h->q8_scans;
             enqueue_half_seed(h, true, qptr, qa, exclude_global, h->d_half_seed, s);
+            if (lone && h->n >= kLoneFusedMinRows) {
+                if (qptr) {
+                    LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, true, false, true>),
+                                 dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
+                                 h->d_feats, h->d_q8, h->n, h->qg.iters, h->row_base, qa, qptr, exclude_global, topn,
+                                 h->d_block_lists, h->d_half_seed, h->qg.seed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next,
+                                 static_cast<const float*>(nullptr), *lone);
+                } else {
+                    LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, false, false, true>),
+                                 dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
+                                 h->d_feats, h->d_q8, h->n, h->qg.iters, h->row_base, qa, kNoQueryPtr, exclude_global, topn,
+                                 h->d_block_lists, h->d_half_seed, h->qg.seed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next,
+                                 static_cast<const float*>(nullptr), *lone);
+                }
+                HIP_TRY(h, hipGetLastError());
+                *fused = true;
+                return MI355REC_OK;
+            }
             if (qptr) {
                 LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, true, false>),
                              dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
                              h->d_feats, h->d_q8, h->n, h->qg.iters, h->row_base, qa, qptr, exclude_global, topn,
                              h->d_block_lists, h->d_half_seed, h->qg.seed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next,
-                             static_cast<const float*>(nullptr));
+                             static_cast<const float*>(nullptr), no_tail);
             } else {
                 LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, false, false>),
                              dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
                              h->d_feats, h->d_q8, h->n, h->qg.iters, h->row_base, qa, kNoQueryPtr, exclude_global, topn,
                              h->d_block_lists, h->d_half_seed, h->qg.seed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next,
-                             static_cast<const float*>(nullptr));
+                             static_cast<const float*>(nullptr), no_tail);
             }
             HIP_TRY(h, hipGetLastError());
             return MI355REC_OK;
@@ -980,8 +1008,15 @@ int enqueue_query(mi355rec* h, const float* qptr, const float* query12, int64_t 
         const int k = topn - done < kMaxTopK ? topn - done : kMaxTopK;
         const uint64_t* upper = done ? out_keys + done - 1 : nullptr;
         int lists = 0;
-        int rc = enqueue_scan(h, qptr, query12, exclude_global, k, upper, s, &lists);
+        // a notifying query (single round, its caller polls the completion word): scan, merge and the word in ONE launch
+        LoneTail lone{h->d_lone_ctr, out_keys, out_idx, out_score, h->hd_done, notify};
+        bool fused = false;
+        int rc = enqueue_scan(h, qptr, query12, exclude_global, k, upper, s, &lists, (notify && h->d_lone_ctr) ? &lone : nullptr, &fused);
         if (rc) return rc;
+        if (fused) {
+            ++h->lone_fused;
+            continue;
+        }
         // (a notifying merge is only asked for single-round queries: it is the last launch of the call)
         rc = enqueue_merge(h, h->d_block_lists, lists, k, k, out_keys + done,
                            out_idx ? out_idx + done : nullptr, out_score ? out_score + done : nullptr, s, notify);
@@ -1099,13 +1134,15 @@ int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, const float* next
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, true, true>),
                          dim3(scanners + 1 + next.n_wgs), dim3(Q8Config::kBlock), s,
                          h->d_feats, h->d_q8, h->n, iters, h->row_base, qa, st.qptr, st.exclude, st.topn,
-                         h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], n_seed, h->d_half_rescored, prev, next, ready);
+                         h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], n_seed, h->d_half_rescored, prev, next, ready,
+                         LoneTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0u});
         } else {
             std::memcpy(qa.q, st.q, sizeof qa.q);
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, false, true>),
                          dim3(scanners + 1 + next.n_wgs), dim3(Q8Config::kBlock), s,
                          h->d_feats, h->d_q8, h->n, iters, h->row_base, qa, kNoQueryPtr, st.exclude, st.topn,
-                         h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], n_seed, h->d_half_rescored, prev, next, ready);
+                         h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], n_seed, h->d_half_rescored, prev, next, ready,
+                         LoneTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0u});
         }
     } else if (st.qptr) {
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, true, true>),
@@ -1491,6 +1528,7 @@ void mi355rec_destroy(mi355rec_t* h) {
     for (hipEvent_t e : h->ev_pass) (void)hipEventDestroy(e);
     if (h->owned_feats) (void)hipFree(h->owned_feats);
     if (h->d_block_lists) (void)hipFree(h->d_block_lists);
+    if (h->d_lone_ctr) (void)hipFree(h->d_lone_ctr);
     if (h->d_stream_lists[0]) (void)hipFree(h->d_stream_lists[0]);
     if (h->d_stream_lists[1]) (void)hipFree(h->d_stream_lists[1]);
     if (h->d_seed_keys) (void)hipFree(h->d_seed_keys);
@@ -1567,7 +1605,7 @@ int mi355rec_stats(const mi355rec_t* hc, mi355rec_stats_t* out) {
     out->replica_margin_multi = h->d_half ? h->margin_mfma : 0.0f;
     out->replica_single_row_bytes = !h->d_half ? 0 : (use_q8(h) ? 12 : 24);
     out->replica_single_bytes_per_query = !h->d_half ? 0 : (use_q8(h) ? ((h->n + 3) / 4) * 48 : ((h->n + 1) / 2) * 48);
-    out->reserved0 = 0;
+    out->lone_fused_queries = static_cast<int32_t>(h->lone_fused & 0x7fffffff);
     return MI355REC_OK;
 }
 

@@ -278,14 +278,20 @@ using DefaultQ8Cfg = Q8Cfg<512, 4, 2>;
 // once their job was done) was built and measured: every workgroup then finished within 2 us of the others
 // instead of 8 — and the launch took as long as before, because between prologue and last tile the launch
 // already moves its bytes at ~6.5 TB/s and early finishers only leave that bandwidth to the rest.
-template <typename Cfg, bool kQueryFromRow, bool kWithMerge>
+//
+// kLoneTail (a lone query whose caller waits on the host): the workgroup that finishes last merges the lists of
+// THIS launch into the caller's buffers and raises the completion word (kernels.hip.h, lone_tail).
+template <typename Cfg, bool kQueryFromRow, bool kWithMerge, bool kLoneTail = false>
 __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
     const float* __restrict__ feats, const uint4* __restrict__ q8, int64_t n, int iters, int64_t row_base,
     QueryArg qarg, const float* __restrict__ query_ptr, int64_t exclude_global, int topk, uint64_t* __restrict__ block_lists,
     const uint32_t* __restrict__ seed_vals, int n_seed, unsigned long long* __restrict__ rescored /* [scanning workgroups] */,
-    PrevMerge prev, NextSeed next, const float* __restrict__ cutoff_ready /* null: select from seed_vals here */) {
+    PrevMerge prev, NextSeed next, const float* __restrict__ cutoff_ready /* null: select from seed_vals here */,
+    LoneTail lone) {
     constexpr int kBlock = Cfg::kBlock;
-    __shared__ typename std::conditional<kWithMerge, HalfScanOrMergeSmem<Cfg>, HalfScanSmemT<Cfg>>::type s_mem;
+    static_assert(!(kWithMerge && kLoneTail), "a streamed query's merge rides in the next launch");
+    __shared__ typename std::conditional<kWithMerge || kLoneTail, HalfScanOrMergeSmem<Cfg>, HalfScanSmemT<Cfg>>::type s_mem;
+    __shared__ int s_lone_flag;
     HalfScanSmemT<Cfg>* sm;
     unsigned nblocks = gridDim.x;   // scanning workgroups
     MI355REC_PHASE(0);
@@ -328,8 +334,13 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
             return;
         }
         sm = &s_mem.scan;
+    } else if constexpr (kLoneTail) {
+        (void)next;
+        sm = &s_mem.scan;
     } else {
         (void)next;
+        (void)lone;
+        (void)s_lone_flag;
         sm = &s_mem;
     }
     uint64_t* const s_cand = sm->cand;
@@ -474,7 +485,8 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
     if (s_count > kRankDirectMax && s_count > topk)  // uniform
         compact_candidates<kBlock, Cfg::kCandPerThread>(s_cand, &s_count, topk, true, s_sel);
     __syncthreads();
-    block_rank_and_store<kBlock>(s_cand, s_count, block_lists + static_cast<int64_t>(bid) * topk, topk);
+    block_rank_and_store<kBlock, kLoneTail>(s_cand, s_count, block_lists + static_cast<int64_t>(bid) * topk, topk);
+    if constexpr (kLoneTail) lone_tail(s_mem.merge, &s_lone_flag, block_lists, topk, lone);
     __syncthreads();
     MI355REC_PHASE(4);
 }

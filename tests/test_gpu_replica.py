@@ -477,3 +477,11 @@ def test_long_stream_over_a_large_shard(Engine, torch_cuda, ordered):
             want = oracle.scores(f, f[r], threads=0)
             idx = (~got & np.uint64(0xffffffff)).astype(np.int64)
             assert_topn_matches(idx, None, want, int(r), topns[i], ref_idx=oracle.topn_heap(want, int(r), topns[i]))
+        # lone synchronous queries: over the 8-bit replica of a shard this size the scan launch merges its own
+        # lists and raises the completion word itself (one launch after the sample)
+        before = eng.stats().lone_fused_queries
+        for r, topn in ((int(qrows[0]), 1), (int(qrows[5]), 10), (int(qrows[6]), 100), (int(qrows[1]), 1000), (int(qrows[7]), 1024)):
+            idx, sc = eng.query_row_topn(r, topn)
+            want = oracle.scores(f, f[r], threads=0)
+            assert_topn_matches(idx, sc, want, r, topn, ref_idx=oracle.topn_heap(want, r, topn))
+        assert eng.stats().lone_fused_queries - before == (5 if ON == 2 else 0)
