@@ -629,19 +629,26 @@ bool use_q8(const mi355rec* h) { return h->d_q8 && h->replica_mode != MI355REC_R
 // cutoff (saves a ~4 us select in every workgroup of that launch).  The riders then take sample + select
 // (~10 us) in all, so only where the scanners run longer than that.
 bool q8_hoists(const mi355rec* h) { return h->qg.riders > 0 && h->qg.r_iters >= 5; }
+// The sample holds EXACT scores of its rows (one margin in the cutoff instead of two: a third of the candidates)
+// where the extra fetch per sampled wave is not on the launch's critical path.
+bool q8_exact_sample(const mi355rec* h) { return h->qg.iters >= 3; }
 
 // The sample that seeds the launch-wide cutoff of the next scan over the replica.
 void enqueue_half_seed(mi355rec* h, bool q8, const float* qptr, const QueryArg& qa, int64_t exclude_global, uint32_t* seed_out,
                        hipStream_t s) {
     if (q8) {
         if (h->qg.seed_grid <= 0) return;
-        if (qptr) {
-            hipLaunchKernelGGL((seed_q8_kernel<true>), dim3(h->qg.seed_grid), dim3(kHalfSeedBlock), 0, s, h->d_q8, h->n,
-                               h->qg.seed_stride, h->row_base, qa, qptr, exclude_global, seed_out);
+#define SEED_Q8(FROM_ROW, EXACT, QP)                                                                                       \
+    hipLaunchKernelGGL((seed_q8_kernel<FROM_ROW, EXACT>), dim3(h->qg.seed_grid), dim3(kHalfSeedBlock), 0, s, h->d_feats, h->d_q8, \
+                       h->n, h->qg.seed_stride, h->row_base, qa, QP, exclude_global, seed_out)
+        if (q8_exact_sample(h)) {
+            if (qptr) SEED_Q8(true, true, qptr);
+            else SEED_Q8(false, true, kNoQueryPtr);
         } else {
-            hipLaunchKernelGGL((seed_q8_kernel<false>), dim3(h->qg.seed_grid), dim3(kHalfSeedBlock), 0, s, h->d_q8, h->n,
-                               h->qg.seed_stride, h->row_base, qa, kNoQueryPtr, exclude_global, seed_out);
+            if (qptr) SEED_Q8(true, false, qptr);
+            else SEED_Q8(false, false, kNoQueryPtr);
         }
+#undef SEED_Q8
         return;
     }
     if (h->hg.seed_grid <= 0) return;
@@ -678,18 +685,19 @@ int enqueue_scan(mi355rec* h, const float* qptr, const float* query12,
             *n_lists = h->qg.grid;
             ++h->q8_scans;
             enqueue_half_seed(h, true, qptr, qa, exclude_global, h->d_half_seed, s);
+            const int q8_seeds = (q8_exact_sample(h) ? -1 : 1) * h->qg.seed_grid * kHalfSeedWaves;   // (negative: exact values)
             if (lone && h->n >= kLoneFusedMinRows) {
                 if (qptr) {
                     LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, true, false, true>),
                                  dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
                                  h->d_feats, h->d_q8, h->n, h->qg.iters, h->row_base, qa, qptr, exclude_global, topn,
-                                 h->d_block_lists, h->d_half_seed, h->qg.seed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next,
+                                 h->d_block_lists, h->d_half_seed, q8_seeds, h->d_half_rescored, none, no_next,
                                  static_cast<const float*>(nullptr), *lone);
                 } else {
                     LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, false, false, true>),
                                  dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
                                  h->d_feats, h->d_q8, h->n, h->qg.iters, h->row_base, qa, kNoQueryPtr, exclude_global, topn,
-                                 h->d_block_lists, h->d_half_seed, h->qg.seed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next,
+                                 h->d_block_lists, h->d_half_seed, q8_seeds, h->d_half_rescored, none, no_next,
                                  static_cast<const float*>(nullptr), *lone);
                 }
                 HIP_TRY(h, hipGetLastError());
@@ -700,13 +708,13 @@ int enqueue_scan(mi355rec* h, const float* qptr, const float* query12,
                 LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, true, false>),
                              dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
                              h->d_feats, h->d_q8, h->n, h->qg.iters, h->row_base, qa, qptr, exclude_global, topn,
-                             h->d_block_lists, h->d_half_seed, h->qg.seed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next,
+                             h->d_block_lists, h->d_half_seed, q8_seeds, h->d_half_rescored, none, no_next,
                              static_cast<const float*>(nullptr), no_tail);
             } else {
                 LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, false, false>),
                              dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
                              h->d_feats, h->d_q8, h->n, h->qg.iters, h->row_base, qa, kNoQueryPtr, exclude_global, topn,
-                             h->d_block_lists, h->d_half_seed, h->qg.seed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next,
+                             h->d_block_lists, h->d_half_seed, q8_seeds, h->d_half_rescored, none, no_next,
                              static_cast<const float*>(nullptr), no_tail);
             }
             HIP_TRY(h, hipGetLastError());
@@ -1119,6 +1127,7 @@ int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, const float* next
         next.stride_rows = g.seed_stride;
         next.ctl = (st.q8 && q8_hoists(h)) ? h->d_stream_ctl + next_buf : nullptr;
         next.topk = next_topn;
+        next.exact = st.q8 && q8_exact_sample(h);
         scanners = g.r_scan;
         iters = g.r_iters;
     }
@@ -1130,18 +1139,19 @@ int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, const float* next
     if (st.q8) {
         ++h->q8_scans;
         const float* ready = st.cutoff_ready ? &h->d_stream_ctl[st.seed_buf].cutoff : nullptr;
+        const int q8_seeds = q8_exact_sample(h) ? -n_seed : n_seed;   // (negative: exact values)
         if (st.qptr) {
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, true, true>),
                          dim3(scanners + 1 + next.n_wgs), dim3(Q8Config::kBlock), s,
                          h->d_feats, h->d_q8, h->n, iters, h->row_base, qa, st.qptr, st.exclude, st.topn,
-                         h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], n_seed, h->d_half_rescored, prev, next, ready,
+                         h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], q8_seeds, h->d_half_rescored, prev, next, ready,
                          LoneTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0u});
         } else {
             std::memcpy(qa.q, st.q, sizeof qa.q);
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, false, true>),
                          dim3(scanners + 1 + next.n_wgs), dim3(Q8Config::kBlock), s,
                          h->d_feats, h->d_q8, h->n, iters, h->row_base, qa, kNoQueryPtr, st.exclude, st.topn,
-                         h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], n_seed, h->d_half_rescored, prev, next, ready,
+                         h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], q8_seeds, h->d_half_rescored, prev, next, ready,
                          LoneTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0u});
         }
     } else if (st.qptr) {

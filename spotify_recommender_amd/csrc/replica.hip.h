@@ -232,6 +232,7 @@ struct NextSeed {
     // cutoff, so that launch starts scanning at once instead of selecting in every workgroup
     SeedCtl* ctl;
     int topk;                  // of the next query
+    int exact;                 // sample values are exact scores of the waves' best rows (one margin) or their approximate ones (two)
 };
 
 __device__ __forceinline__ void seed_rider(const float* __restrict__ feats, const uint4* __restrict__ half, int64_t n,

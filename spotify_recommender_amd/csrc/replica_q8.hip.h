@@ -150,20 +150,54 @@ __device__ __forceinline__ Q8Region q8_region_load(const uint4* __restrict__ q8,
     return s;
 }
 
-__device__ __forceinline__ void q8_region_finish(const Q8Region& s, const Q8Query& q, int64_t n, int64_t row_base,
-                                                 int64_t exclude_global, uint32_t* __restrict__ seed_vals, int64_t g) {
+// The sample value of one wave's 256 rows is the EXACT score of the row whose approximate score is the largest
+// (one 48 B fetch per wave, all lanes the same address): an exact score v of a real row needs only ONE margin in
+// the cutoff (approx < v - margin => exact < v), where the approximate maximum needed two.  At top-100 over
+// 10 M rows that is the difference between ~28 000 and ~10 000 rows sent to the exact chain per query.
+// (kExact = false keeps the approximate maximum and skips the fetch: small shards, where the riders' extra round
+// trip is on the critical path of the launch and a few hundred more candidates are not.)
+struct Q8Pick {
+    int64_t row;     // wave-uniform: local row of the wave's best usable row
+    uint32_t top;    // wave-uniform: its approximate score, ordered (0: no usable row)
+    bool any;        // wave-uniform
+};
+
+__device__ __forceinline__ Q8Pick q8_region_pick(const Q8Region& s, const Q8Query& q, int64_t n, int64_t row_base,
+                                                 int64_t exclude_global) {
     float a[4];
     bool special[4];
     q8_dot4(q, s.t, a, special);
     const int64_t r0 = s.quad * 4;
     uint32_t v = 0u;
+    int best = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const bool use = s.have && q.ok && !special[u] && r0 + u < n && row_base + r0 + u != exclude_global;
         const uint32_t w = use ? score_to_ordered(a[u]) : 0u;
+        best = w > v ? u : best;
         v = w > v ? w : v;
     }
-    v = wave_max_u32(v);
+    const uint32_t top = wave_max_u32(v);
+    const uint64_t holders = __ballot(v == top);   // never empty
+    const int lane = static_cast<int>(__builtin_ctzll(holders));
+    Q8Pick p;
+    p.top = top;
+    p.any = top != 0u;
+    const int64_t mine = r0 + best;
+    const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(mine)), lane));
+    const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(mine >> 32)), lane));
+    p.row = p.any ? static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo) : 0;
+    return p;
+}
+
+template <bool kExact>
+__device__ __forceinline__ void q8_region_store(const Q8Pick& p, const Row& row, const float (&q)[kDim], float qn,
+                                                uint32_t* __restrict__ seed_vals, int64_t g) {
+    uint32_t v = p.top;
+    if constexpr (kExact) {
+        const float exact = cosine_score(q, qn, row);
+        v = p.any ? score_to_ordered(exact) : 0u;
+    }
     // written THROUGH to device scope: a rider of the same launch may read it (scan_q8_kernel, last rider out)
     if ((threadIdx.x & 63) == 0)
         __hip_atomic_store(&seed_vals[g * kHalfSeedWaves + (threadIdx.x >> 6)], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -180,23 +214,29 @@ __device__ __forceinline__ void q8_load_query(const float* __restrict__ query_pt
 }
 
 // One workgroup per region (single queries; the first query of a stream).
-template <bool kQueryFromRow>
+template <bool kQueryFromRow, bool kExact>
 __global__ __launch_bounds__(kHalfSeedBlock) void seed_q8_kernel(
-    const uint4* __restrict__ q8, int64_t n, int64_t stride_rows, int64_t row_base, QueryArg qarg,
+    const float* __restrict__ feats, const uint4* __restrict__ q8, int64_t n, int64_t stride_rows, int64_t row_base, QueryArg qarg,
     const float* __restrict__ query_ptr, int64_t exclude_global, uint32_t* __restrict__ seed_vals) {
     float q[kDim];
     q8_load_query(kQueryFromRow ? query_ptr : nullptr, qarg.q, q);
-    const Q8Query hq = q8_query(q, query_norm(q));
+    const float qn = query_norm(q);
+    const Q8Query hq = q8_query(q, qn);
     const Q8Region s = q8_region_load(q8, (n + 3) >> 2, stride_rows, blockIdx.x);
-    q8_region_finish(s, hq, n, row_base, exclude_global, seed_vals, blockIdx.x);
+    const Q8Pick p = q8_region_pick(s, hq, n, row_base, exclude_global);
+    Row row;
+    row.a = row.b = row.c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if constexpr (kExact) row = load_row(feats, p.row);
+    q8_region_store<kExact>(p, row, q, qn, seed_vals, blockIdx.x);
 }
 
 // The seed riders of a streamed launch (replica.hip.h, seed_rider): four regions per memory round trip.
-__device__ __forceinline__ Q8Query q8_seed_rider(const uint4* __restrict__ q8, int64_t n, int64_t row_base, const NextSeed& next,
-                                                 int rider) {
+__device__ __forceinline__ Q8Query q8_seed_rider(const float* __restrict__ feats, const uint4* __restrict__ q8, int64_t n,
+                                                 int64_t row_base, const NextSeed& next, int rider) {
     float q[kDim];
     q8_load_query(next.query_ptr, next.q, q);
-    const Q8Query hq = q8_query(q, query_norm(q));
+    const float qn = query_norm(q);
+    const Q8Query hq = q8_query(q, qn);
     const int64_t n_quads = (n + 3) >> 2;
     constexpr int kAhead = 4;
     for (int g0 = rider; g0 < next.regions; g0 += kAhead * next.n_wgs) {
@@ -206,10 +246,26 @@ __device__ __forceinline__ Q8Query q8_seed_rider(const uint4* __restrict__ q8, i
             const int g = g0 + u * next.n_wgs;
             s[u] = q8_region_load(q8, n_quads, next.stride_rows, g < next.regions ? g : rider);
         }
+        Q8Pick pick[kAhead];
 #pragma unroll
-        for (int u = 0; u < kAhead; ++u) {
-            const int g = g0 + u * next.n_wgs;
-            if (g < next.regions) q8_region_finish(s[u], hq, n, row_base, next.exclude_global, next.out, g);   // uniform
+        for (int u = 0; u < kAhead; ++u) pick[u] = q8_region_pick(s[u], hq, n, row_base, next.exclude_global);
+        if (next.exact) {   // uniform: the four winners' rows, one more round trip with four fetches in flight
+            Row best[kAhead];
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) best[u] = load_row(feats, pick[u].row);
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                const int g = g0 + u * next.n_wgs;
+                if (g < next.regions) q8_region_store<true>(pick[u], best[u], q, qn, next.out, g);   // uniform
+            }
+        } else {
+            Row none;
+            none.a = none.b = none.c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                const int g = g0 + u * next.n_wgs;
+                if (g < next.regions) q8_region_store<false>(pick[u], none, q, qn, next.out, g);   // uniform
+            }
         }
     }
     return hq;
@@ -218,7 +274,7 @@ __device__ __forceinline__ Q8Query q8_seed_rider(const uint4* __restrict__ q8, i
 // The launch-wide cutoff from n_seed sample maxima (approximate scores, ordered; 0 = empty): a row whose
 // approximate score is below it cannot be among the best topk.  -inf when the sample cannot say.
 template <int kBlock, bool kSameLaunch = false>
-__device__ __forceinline__ float q8_cutoff_from_sample(const uint32_t* seed_vals, int n_seed, int topk,
+__device__ __forceinline__ float q8_cutoff_from_sample(const uint32_t* seed_vals, int n_seed, int topk, bool exact_values,
                                                        const Q8Query& hq, int* s_seeds /* zeroed */, SelectSmem& s_sel) {
     const int tid = threadIdx.x;
     float cutoff = -__builtin_inff();
@@ -241,7 +297,8 @@ __device__ __forceinline__ float q8_cutoff_from_sample(const uint32_t* seed_vals
             // most of the radix passes and moves the cutoff by a hair
             const uint64_t t = block_select_threshold<kBlock, kHalfSeedPerThread>(mine, topk, false, topk / 8 + 2, s_sel);
             const float v = ordered_to_score(static_cast<uint32_t>(t >> 32));
-            cutoff = v - 2.0f * hq.margin;   // (the margin carries its own slack)
+            // one margin below an EXACT score of a real row, two below an approximate one (the margin carries its own slack)
+            cutoff = exact_values ? v - hq.margin : v - 2.0f * hq.margin;
         }
     }
     return cutoff;
@@ -285,7 +342,8 @@ template <typename Cfg, bool kQueryFromRow, bool kWithMerge, bool kLoneTail = fa
 __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
     const float* __restrict__ feats, const uint4* __restrict__ q8, int64_t n, int iters, int64_t row_base,
     QueryArg qarg, const float* __restrict__ query_ptr, int64_t exclude_global, int topk, uint64_t* __restrict__ block_lists,
-    const uint32_t* __restrict__ seed_vals, int n_seed, unsigned long long* __restrict__ rescored /* [scanning workgroups] */,
+    const uint32_t* __restrict__ seed_vals, int n_seed /* negative: |n_seed| EXACT sample values */,
+    unsigned long long* __restrict__ rescored /* [scanning workgroups] */,
     PrevMerge prev, NextSeed next, const float* __restrict__ cutoff_ready /* null: select from seed_vals here */,
     LoneTail lone) {
     constexpr int kBlock = Cfg::kBlock;
@@ -305,7 +363,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
                                static_cast<float*>(nullptr), static_cast<int64_t>(0), static_cast<int64_t>(0),
                                static_cast<int64_t>(0));
             } else {
-                const Q8Query nq = q8_seed_rider(q8, n, row_base, next, static_cast<int>(blockIdx.x - nblocks - 1u));
+                const Q8Query nq = q8_seed_rider(feats, q8, n, row_base, next, static_cast<int>(blockIdx.x - nblocks - 1u));
                 // Last rider out turns the sample into the cutoff.  No device-wide fence: on this part a release /
                 // acquire pair at agent scope writes back and invalidates the whole L2 under the scanners (measured:
                 // the launch took 43 us instead of 28).  Instead the maxima are stored and loaded as device-scope
@@ -321,7 +379,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
                 }
                 __syncthreads();
                 if (s_mem.scan.count) {   // uniform
-                    const float c = q8_cutoff_from_sample<kBlock, true>(next.out, next.regions * kHalfSeedWaves, next.topk, nq,
+                    const float c = q8_cutoff_from_sample<kBlock, true>(next.out, next.regions * kHalfSeedWaves, next.topk, next.exact != 0, nq,
                                                                         &s_mem.scan.seeds, s_mem.scan.sel);
                     if (threadIdx.x == 0) {
                         next.ctl->cutoff = c;
@@ -388,7 +446,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
     if (cutoff_ready) {   // uniform: the riders of the launch before this one left it
         cutoff = *cutoff_ready;
     } else {
-        cutoff = q8_cutoff_from_sample<kBlock>(seed_vals, n_seed, topk, hq, &sm->seeds, s_sel);
+        cutoff = q8_cutoff_from_sample<kBlock>(seed_vals, n_seed < 0 ? -n_seed : n_seed, topk, n_seed < 0, hq, &sm->seeds, s_sel);
     }
     MI355REC_PHASE(2);
     uint64_t thr = 0;
