@@ -409,12 +409,6 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
 
-    float q[kDim];
-    q8_load_query(kQueryFromRow ? query_ptr : nullptr, qarg.q, q);
-    const float qn = query_norm(q);
-    const Q8Query hq = q8_query(q, qn);
-    if (hq.c != 0.0f || n >= 0) MI355REC_PHASE(1);   // (depends on the query: not hoisted above its load)
-
     const int64_t n_quads = (n + 3) >> 2;
     const int64_t last_quad = n_quads - 1;
     const int64_t quad_begin = static_cast<int64_t>(bid) * kBlock + tid;
@@ -429,10 +423,18 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
         dst.t2 = p[2];
     };
 
+    // everything the first tile needs is asked for at once: its 48 B per lane, the finished cutoff, the query
     constexpr int kDepth = Cfg::kDepth;
     HalfTile ring[kDepth];
 #pragma unroll
     for (int d = 0; d < kDepth - 1; ++d) load_tile(ring[d], d);
+    float cutoff_left = 0.0f;
+    if (cutoff_ready) cutoff_left = *cutoff_ready;   // uniform: the riders of the launch before this one left it
+    float q[kDim];
+    q8_load_query(kQueryFromRow ? query_ptr : nullptr, qarg.q, q);
+    const float qn = query_norm(q);
+    const Q8Query hq = q8_query(q, qn);
+    if (hq.c != 0.0f || n >= 0) MI355REC_PHASE(1);   // (depends on the query: not hoisted above its load)
 
     // ---- launch-wide cutoff (while the first tiles are in flight)
     if (tid == 0) {
@@ -443,8 +445,8 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
     int n_rescored = 0;   // wave-uniform: rows this wave sent to the exact chain (diagnostics)
     __syncthreads();
     float cutoff;
-    if (cutoff_ready) {   // uniform: the riders of the launch before this one left it
-        cutoff = *cutoff_ready;
+    if (cutoff_ready) {   // uniform
+        cutoff = cutoff_left;
     } else {
         cutoff = q8_cutoff_from_sample<kBlock>(seed_vals, n_seed < 0 ? -n_seed : n_seed, topk, n_seed < 0, hq, &sm->seeds, s_sel);
     }

@@ -58,6 +58,11 @@ for k, d in out["kernels"].items():
     alg = None
     if "scan_kernel" in k or "stream_probe" in k or "scan_multi_kernel" in k:
         alg = rows * 48
+    elif "scan_q8_kernel" in k:
+        alg = (rows + 3) // 4 * 48
+        d["note"] = ("scan over the 8-bit replica: 12 B per row + the fp32 rows it cannot rule out (~10 000 per query at top-100); "
+                     "a streamed launch also carries the seed riders' sample for the next query (256 regions x 2048 rows x 12 B = 6.3 MB) "
+                     "and the previous query's merge")
     elif "scan_half_multi_kernel" in k:
         alg = (rows + 1) // 2 * 48
         d["note"] = "multi-query pass over the fp16 replica (24 B per row whatever the number of queries, <= 32) + the fp32 rows of its candidates"
