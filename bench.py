@@ -114,9 +114,12 @@ def pmc_traffic(alg: int, want: str):
     try:
         files = sorted((ROOT / "profiles").glob("*_pmc_hbm_traffic.json"))
         data = json.loads(files[-1].read_text())
-        for name, k in data["kernels"].items():
-            if want in name and k.get("algorithmic_bytes_per_launch") == alg:
-                return int(k["hbm_bytes_per_launch"]), f"profiles/{files[-1].name}"
+        # several variants of a kernel may have been profiled (plain, streamed, lone): the one launched most often
+        # is the timed stream's
+        hits = [k for name, k in data["kernels"].items() if want in name and k.get("algorithmic_bytes_per_launch") == alg]
+        if hits:
+            k = max(hits, key=lambda e: e.get("FETCH_SIZE_launches", 0))
+            return int(k["hbm_bytes_per_launch"]), f"profiles/{files[-1].name}"
     except Exception:
         pass
     return None, None
