@@ -497,6 +497,26 @@ def test_full_size_10m_top100_properties(Engine, torch_cuda):
         got = eng.scores_row(q)
         want = oracle.scores(f, f[q], threads=0)
         assert np.array_equal(bits(got), bits(want))
+        # the three scans — fp32 rows, fp16 replica, 8-bit replica (the default at this size) — leave the same
+        # keys bit for bit, synchronously and as a stream (linearity of nothing, identity of everything)
+        from spotify_recommender_amd import capi
+        rows = query_rows(n, 12)
+        per_mode = {}
+        for mode in (capi.REPLICA_OFF, capi.REPLICA_FP16, capi.REPLICA_ON):
+            eng.set_replica(mode)
+            out = torch.zeros((2 * len(rows), 100), dtype=torch.int64, device="cuda")
+            for i, r in enumerate(rows):
+                eng.enqueue_row_keys(int(r), 100, out[i])
+            for i, r in enumerate(rows):
+                eng.enqueue_row_keys_streamed(int(r), 100, out[len(rows) + i])
+            eng.enqueue_flush()
+            torch.cuda.synchronize()
+            per_mode[mode] = out.cpu().numpy()
+            assert np.array_equal(per_mode[mode][:len(rows)], per_mode[mode][len(rows):])
+        assert np.array_equal(per_mode[capi.REPLICA_OFF], per_mode[capi.REPLICA_FP16])
+        assert np.array_equal(per_mode[capi.REPLICA_OFF], per_mode[capi.REPLICA_ON])
+        st = eng.stats()
+        assert st.replica_single_row_bytes == 12 and st.replica_single_bytes_per_query == n // 4 * 48
 
 
 def test_config5_shard_1024_query_batch(Engine, torch_cuda):
