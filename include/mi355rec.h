@@ -311,7 +311,10 @@ int mi355rec_enqueue_batch_keys_dev(mi355rec_t* h, const float* queries_dev,
 #define MI355REC_BATCH_AUTO 0
 #define MI355REC_BATCH_MULTI 1
 #define MI355REC_BATCH_MFMA 2
-#define MI355REC_BATCH_HALF 3   /* multi-query passes over the fp16 replica (12 queries per pass) whatever the count */
+#define MI355REC_BATCH_HALF 3   /* multi-query passes (<= 32 queries each) with rows from the fp16 replica, whatever the count */
+#define MI355REC_BATCH_Q8 4     /* the same passes with rows from the 8-bit replica (integer matrix core, candidates re-checked
+                                   against their fp16 rows): half the bytes, but 3.7 us per query of a pass instead of 0.85 —
+                                   AUTO takes it for passes of one or two queries only */
 int mi355rec_set_batch_path(mi355rec_t* h, int path);
 
 /* Diagnostics of the LAST chunk (<= 1024 queries) the batched path served on

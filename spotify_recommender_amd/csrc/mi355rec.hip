@@ -20,8 +20,8 @@
 #include "batched.hip.h"
 #include "kernels.hip.h"
 #include "replica.hip.h"
-#include "replica_multi.hip.h"
 #include "replica_q8.hip.h"
+#include "replica_multi.hip.h"
 
 using namespace mi355;
 
@@ -828,6 +828,15 @@ int enqueue_multi(mi355rec* h, const float* queries, const int64_t* exclude, int
 // queries ONE sample launch + ONE pass over the 24 B/row replica, then one merge launch with a
 // workgroup per query for the whole chain.  queries[i] by value, or qptrs[i] != null: where its 12
 // floats live in device-readable memory.  topn <= kMultiMaxTopK, count <= kMultiChain.
+// Which replica a multi-query pass streams.  The 8-bit front end (12 B/row, integer matrix core, fp16 re-check of
+// its candidates) moves half the bytes but its bound is 25x the fp16 one: ~1 % of the (row, query) pairs come
+// back as candidates, 3.7 us per query of a pass against 0.85 us (measured, 10 M rows: 1 query 36.9 vs 44.1 us,
+// 2: 41.9 vs 44.7, 12: 82 vs 53, 32: 152 vs 71).  So: passes of one or two queries, or when forced.
+bool multi_front_q8(const mi355rec* h, int nq) {
+    if (!use_q8(h) || h->batch_path == MI355REC_BATCH_HALF) return false;
+    return h->batch_path == MI355REC_BATCH_Q8 || nq <= 2;
+}
+
 bool half_multi_ok(const mi355rec* h, int topn) {
     return h->d_half && h->replica_mode != MI355REC_REPLICA_OFF && topn <= kMultiMaxTopK && h->hg.seed_grid > 0 &&
            h->hg.seed_grid * kHalfSeedWaves >= topn;
@@ -861,9 +870,16 @@ int enqueue_half_multi(mi355rec* h, const float* queries, const float* const* qp
         hipLaunchKernelGGL(seed_half_multi_kernel, dim3(h->hg.seed_grid), dim3(kHmBlock), 0, s, h->d_half, h->n, h->hg.seed_stride,
                            arg, nq, h->d_half_mseed);
         ++h->half_scans;
-        LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<false>), dim3(h->hg.grid),
-                     dim3(kHmBlock), s, h->d_feats, h->d_half, h->n, h->row_base, arg, nq, g0, topn, h->d_block_lists,
-                     h->d_half_mseed, n_seed, h->d_half_rescored, no_ride, arg);
+        if (multi_front_q8(h, nq)) {   // rows from the 8-bit replica through the integer matrix core (replica_multi.hip.h)
+            ++h->q8_scans;
+            LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<false, true>), dim3(h->hg.grid),
+                         dim3(kHmBlock), s, h->d_feats, h->d_half, reinterpret_cast<const uint32_t*>(h->d_q8), h->n, h->row_base, arg, nq,
+                         g0, topn, h->d_block_lists, h->d_half_mseed, n_seed, h->d_half_rescored, no_ride, arg);
+        } else {
+            LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<false, false>), dim3(h->hg.grid),
+                         dim3(kHmBlock), s, h->d_feats, h->d_half, static_cast<const uint32_t*>(nullptr), h->n, h->row_base, arg, nq,
+                         g0, topn, h->d_block_lists, h->d_half_mseed, n_seed, h->d_half_rescored, no_ride, arg);
+        }
     }
     HIP_TRY(h, hipGetLastError());
     const int slot = timing_begin(h, h->ev_merge, h->n_merge_pairs, h->merge_launches, s);
@@ -930,10 +946,20 @@ int launch_mstash(mi355rec* h, hipStream_t s, const HalfMultiArg* next, int next
     int scanners = h->hg.grid - ride.prev_queries - ride.seed_wgs;
     if (scanners < 1) scanners = 1;
     ++h->half_scans;
-    LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<true>),
-                 dim3(scanners + ride.prev_queries + ride.seed_wgs), dim3(kHmBlock), s, h->d_feats, h->d_half, h->n, h->row_base,
-                 st.arg, st.nq, 0, st.topn, h->d_mstream_lists[buf], h->d_mstream_seed[st.seed_buf],
-                 h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, ride, next ? *next : st.arg);
+    if (multi_front_q8(h, st.nq)) {
+        ++h->q8_scans;
+        LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<true, true>),
+                     dim3(scanners + ride.prev_queries + ride.seed_wgs), dim3(kHmBlock), s, h->d_feats, h->d_half,
+                     reinterpret_cast<const uint32_t*>(h->d_q8), h->n, h->row_base,
+                     st.arg, st.nq, 0, st.topn, h->d_mstream_lists[buf], h->d_mstream_seed[st.seed_buf],
+                     h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, ride, next ? *next : st.arg);
+    } else {
+        LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<true, false>),
+                     dim3(scanners + ride.prev_queries + ride.seed_wgs), dim3(kHmBlock), s, h->d_feats, h->d_half,
+                     static_cast<const uint32_t*>(nullptr), h->n, h->row_base,
+                     st.arg, st.nq, 0, st.topn, h->d_mstream_lists[buf], h->d_mstream_seed[st.seed_buf],
+                     h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, ride, next ? *next : st.arg);
+    }
     HIP_TRY(h, hipGetLastError());
     h->mpending.has = true;
     h->mpending.buf = buf;
@@ -1437,7 +1463,7 @@ int stage_queries(mi355rec* h, const float* queries, const int64_t* exclude, int
 
 bool use_bq(const mi355rec* h, int batch, int topn) {
     if (topn > kMultiMaxTopK || h->n < 1) return false;
-    if (h->batch_path == MI355REC_BATCH_MULTI || h->batch_path == MI355REC_BATCH_HALF) return false;
+    if (h->batch_path == MI355REC_BATCH_MULTI || h->batch_path == MI355REC_BATCH_HALF || h->batch_path == MI355REC_BATCH_Q8) return false;
     if (h->batch_path == MI355REC_BATCH_MFMA) return true;
     const bool replica = h->d_half && h->replica_mode != MI355REC_REPLICA_OFF;
     return batch >= (replica ? kBqMinBatchReplica : kBqMinBatch) && h->n >= kBqMinRows;
@@ -1466,7 +1492,7 @@ int enqueue_batch(mi355rec* h, const float* queries, const int64_t* exclude_glob
     // 2 ... kHmAutoMax queries on a shard with a replica: multi-query passes over the replica (24 B/row,
     // one pass per 12 queries); more: the matrix-core path (two passes whatever the count up to 1024)
     const bool half_multi = half_multi_ok(h, topn) && h->n >= kBqMinRows &&
-                            (h->batch_path == MI355REC_BATCH_HALF ||
+                            (h->batch_path == MI355REC_BATCH_HALF || h->batch_path == MI355REC_BATCH_Q8 ||
                              (h->batch_path == MI355REC_BATCH_AUTO && batch >= 2 && batch <= kHmAutoMax));
     if (half_multi) {
         for (int b = 0; b < batch; b += kMultiChain) {
@@ -1871,7 +1897,8 @@ int mi355rec_batched_last_counters(mi355rec_t* h, int32_t* special_rows, int32_t
 
 int mi355rec_set_batch_path(mi355rec_t* h, int path) {
     if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
-    if (path != MI355REC_BATCH_AUTO && path != MI355REC_BATCH_MULTI && path != MI355REC_BATCH_MFMA && path != MI355REC_BATCH_HALF)
+    if (path != MI355REC_BATCH_AUTO && path != MI355REC_BATCH_MULTI && path != MI355REC_BATCH_MFMA && path != MI355REC_BATCH_HALF &&
+        path != MI355REC_BATCH_Q8)
         return fail(h, MI355REC_ERR_INVALID_ARG, "unknown batch path %d", path);
     h->batch_path = path;
     return MI355REC_OK;

@@ -40,8 +40,15 @@
 #pragma once
 
 #include "replica.hip.h"
+#include "replica_q8.hip.h"
 
 namespace mi355 {
+
+typedef int hm_v4i __attribute__((ext_vector_type(4)));
+typedef int hm_v16i __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ float bq_h2f(uint32_t bits16) {
+    return static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(bits16)));
+}
 
 constexpr int kHmQueries = 32;                     // queries per pass: the columns of one MFMA tile
 constexpr int kHmBlock = 512;
@@ -231,6 +238,11 @@ struct alignas(16) HalfMultiSmem {
     uint32_t ok[kHmQueries];
     int rescored;
     float margin;                               // the error bound this launch claims (HalfMultiArg::margin)
+    // the 8-bit front end (scan_half_multi_kernel<.., true>): query c's B operand bytes — k 0..11 = round(127 q^_j),
+    // k 12..15 = the integer threshold (hm_q8_slots) — and the bound of its 8-bit approx
+    uint4 bfrag8[kHmQueries];
+    float m8[kHmQueries];
+    int q8;
 };
 
 // -T' as the fp16 pair (hi, lo) of the B fragment's threshold slots.  T' = -inf ("every row is a
@@ -240,6 +252,50 @@ __device__ __forceinline__ uint32_t hm_threshold_slots(float cut) {
     const _Float16 hh = static_cast<_Float16>(-cut);
     const float hi = static_cast<float>(hh);
     return bq_pack_h2(hi, -cut - hi);
+}
+
+// ---- the 8-bit front end ----------------------------------------------------------------------------------
+// Rows come from the 8-bit replica (replica_q8.hip.h: r_j = u_j - 128 in [-127, 127], |r_j / 127 - r^_j| <= 1/254),
+// the query is quantised the same way (qh_j = round(127 q^_j)), and v_mfma_i32_32x32x32_i8 forms
+//     D = sum_j r_j qh_j + 127 b12 + 127 b13 + b14 ,      approx8 = sum_j r_j qh_j / 127^2 ,
+// exactly, for 32 rows x 32 queries per instruction: a lane's 16 operand bytes are ITS row (12 bytes, sign bit
+// flipped) + the constants (127, 127, 1, 0), so the A operand is the load itself — no shuffles — and half the
+// bytes of the fp16 front end are streamed.  |approx8 - r^ . q^| <= (l1(r^) + l1(q^)) / 254 + 12 / 254^2 with
+// l1(r^) <= sqrt(12): m8(q) = (l1(q^) + 3.4642) / 254 + 2.2e-4 (<= 0.0276).  A row is out for query q if its exact
+// score is below L(q) = cut(q) + margin16 + slack (cut = the fp16 cutoff T' this kernel keeps anyway: L is the
+// exact lower bound of the top-k threshold it was derived from), so it is a candidate iff approx8 >= L - m8, i.e.
+// D >= 0 with 127 b12 + 127 b13 + b14 = -(floor((L - m8) 127^2) - 1).  That margin is 25x the fp16 one and lets
+// ~0.3 % of the (row, query) pairs through, so a candidate is first re-checked against its fp16 row (24 B, bound
+// margin16: hm_resolve_stage) and only what survives that takes the exact chain.
+__device__ __forceinline__ uint32_t hm_q8_slots(float t8) {   // t8 = L - m8; -inf: every row is a candidate
+    if (!(t8 > -3.0e38f)) return 0x00007f7fu;                 // (b12, b13, b14) = (127, 127, 0): +32258 > any |sum|
+    float xf = 1.0f - __builtin_floorf(t8 * 16129.0f);
+    xf = xf > 32258.0f ? 32258.0f : (xf < -32258.0f ? -32258.0f : xf);
+    const int x = static_cast<int>(xf);
+    const int s127 = x / 127;                                 // truncating: |x - 127 s127| < 127
+    const int rem = x - 127 * s127;
+    const int b12 = s127 / 2, b13 = s127 - b12;               // |s127| <= 254
+    return (static_cast<uint32_t>(b12) & 0xffu) | ((static_cast<uint32_t>(b13) & 0xffu) << 8) | ((static_cast<uint32_t>(rem) & 0xffu) << 16);
+}
+constexpr uint32_t kHmQ8NeverHit = 0x00008181u;               // (-127, -127, 0): -32258 < any sum
+constexpr uint32_t kHmQ8RowConst = 0x00017f7fu;               // the A operand's k 12..15: (127, 127, 1, 0)
+
+// Query c's operand bytes and bound (threads 0..31, beside hm_build_fragment).
+__device__ __forceinline__ void hm_build_fragment8(HalfMultiSmem& sm, int c, bool real, bool ok, const float (&q)[kDim], float qn) {
+    const float inv = ok ? 1.0f / qn : 0.0f;
+    uint32_t w[3] = {0u, 0u, 0u};
+    float l1 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kDim; ++j) {
+        const float u = q[j] * inv;
+        l1 += __builtin_fabsf(u);
+        int k = static_cast<int>(__builtin_rintf(u * 127.0f));
+        k = k > 127 ? 127 : (k < -127 ? -127 : k);
+        w[j >> 2] |= (static_cast<uint32_t>(k) & 0xffu) << (8 * (j & 3));
+    }
+    sm.m8[c] = (l1 + 3.4642f) * kQ8Step * (1.0f + 1e-5f) + 2.2e-4f;
+    // a real query starts with "every row is a candidate"; a padding column can never hit
+    sm.bfrag8[c] = make_uint4(w[0], w[1], w[2], real ? 0x00007f7fu : kHmQ8NeverHit);
 }
 
 // The launch-wide cutoff of one query from its sample maxima, by one wave (see the header).
@@ -325,6 +381,7 @@ __device__ __forceinline__ void hm_append_locked(HalfMultiSmem& sm, int q0, bool
                     if (local_cut > sm.cut[q0]) {
                         sm.cut[q0] = local_cut;
                         reinterpret_cast<uint32_t*>(&sm.bfrag[32 + q0])[2] = hm_threshold_slots(local_cut);
+                        if (sm.q8) reinterpret_cast<uint32_t*>(&sm.bfrag8[q0])[3] = hm_q8_slots(local_cut + margin + kBqSlack - sm.m8[q0]);
                     }
                 }
             }
@@ -333,17 +390,38 @@ __device__ __forceinline__ void hm_append_locked(HalfMultiSmem& sm, int q0, bool
     hm_unlock(&sm.lock[q0]);
 }
 
-// The wave's staged candidates -> exact keys -> the workgroup's per-query key lists.
-__device__ __forceinline__ void hm_resolve_stage(HalfMultiSmem& sm, int staged, const float* __restrict__ feats, int64_t row_base,
-                                                 int topk) {
+// The wave's staged candidates -> exact keys -> the workgroup's per-query key lists.  Returns the rows that took
+// the exact chain.  half16 != null (8-bit front end): a candidate is first re-checked against its row of the fp16
+// replica — approx16 < cut rules it out exactly as the fp16 front end would have — unless bit 31 of its query
+// word says that the row is special (exact chain, always).
+constexpr uint32_t kHmStageExact = 0x80000000u;
+__device__ __forceinline__ int hm_resolve_stage(HalfMultiSmem& sm, int staged, const float* __restrict__ feats, int64_t row_base,
+                                                int topk, const uint32_t* __restrict__ half16 = nullptr) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint2* stage = sm.stage[wave];
+    int n_exact = 0;
     for (int e0 = 0; e0 < staged; e0 += 64) {
-        const bool have = e0 + lane < staged;
+        bool have = e0 + lane < staged;
         const uint2 e = have ? stage[e0 + lane] : make_uint2(0u, 0u);
-        const int q = static_cast<int>(e.x);
-        const Row r = load_row(feats, static_cast<int64_t>(e.y));   // idle lanes re-read row 0: one cached line
+        const int q = static_cast<int>(e.x & ~kHmStageExact);
+        if (half16) {
+            const uint2* hp = reinterpret_cast<const uint2*>(half16 + static_cast<int64_t>(e.y) * 6);   // 24 B rows, 8 B aligned
+            const uint2 h0 = hp[0], h1 = hp[1], h2 = hp[2];
+            const float inv = sm.ok[q] ? 1.0f / sm.qn[q] : 0.0f;
+            float acc = 0.0f;
+            auto two = [&](uint32_t w, int j) {
+                acc = __builtin_fmaf(bq_h2f(w & 0xffffu), sm.qf[q][j] * inv, acc);
+                acc = __builtin_fmaf(bq_h2f(w >> 16), sm.qf[q][j + 1] * inv, acc);
+            };
+            two(h0.x, 0); two(h0.y, 2); two(h1.x, 4); two(h1.y, 6); two(h2.x, 8); two(h2.y, 10);
+            // NaN rows of the fp16 replica give acc = NaN: !(NaN < cut) keeps them; an invalid query has cut = -inf
+            const bool keep = (e.x & kHmStageExact) != 0u || h0.x == kBqNaN2 || !sm.ok[q] || !(acc < sm.cut[q]);
+            have = have && keep;
+            if (!__ballot(have)) continue;   // uniform
+        }
+        n_exact += __popcll(__ballot(have));
+        const Row r = load_row(feats, have ? static_cast<int64_t>(e.y) : static_cast<int64_t>(0));   // idle lanes re-read row 0: one cached line
         float qv[kDim];
 #pragma unroll
         for (int j = 0; j < kDim; ++j) qv[j] = sm.qf[q][j];
@@ -371,6 +449,7 @@ __device__ __forceinline__ void hm_resolve_stage(HalfMultiSmem& sm, int staged, 
             hm_append_locked(sm, q0, mine, key, topk);
         }
     }
+    return n_exact;
 }
 
 // A step whose candidates did not fit the staging buffer (hostile data: no usable cutoff, special rows
@@ -421,9 +500,13 @@ union HmSmemU {
 
 // block_lists[(slot0 + query) * S + workgroup][topk], each list sorted descending, 0-padded; S = the scanning
 // workgroups = gridDim.x - ride.prev_queries - ride.seed_wgs.
-template <bool kRide>
+// kQ8: the rows are streamed from the 8-bit replica `q8` (12 B per row) through the integer matrix core and a
+// candidate is re-checked against its fp16 row before the exact chain (see "the 8-bit front end" above); the
+// sample of the NEXT batch is still taken over the fp16 replica.
+template <bool kRide, bool kQ8 = false>
 __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
-    const float* __restrict__ feats, const uint4* __restrict__ half, int64_t n, int64_t row_base, HalfMultiArg arg, int n_queries,
+    const float* __restrict__ feats, const uint4* __restrict__ half, const uint32_t* __restrict__ q8, int64_t n, int64_t row_base,
+    HalfMultiArg arg, int n_queries,
     int slot0, int topk, uint64_t* __restrict__ block_lists, const uint32_t* __restrict__ seed_vals,
     int n_seed /* sample maxima per query, 0 = none */, unsigned long long* __restrict__ rescored /* [workgroups] */,
     HmRide ride, HalfMultiArg next) {
@@ -477,15 +560,35 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
         dst.t1 = p[1];
         dst.t2 = p[2];
     };
-    HalfTile T[kHmChunks];
+    // 8-bit front end: a step is the same kHmStepRows rows, as kHmGroups groups of 64 rows, one row (12 B) per lane
+    constexpr int kHmGroups = kHmStepRows / 64;
+    struct Row8 {
+        uint32_t d0, d1, d2;
+    };
+    auto load_group = [&](Row8& dst, int64_t st, int g) {
+        int64_t row = st * kHmStepRows + g * 64 + lane;
+        row = row < n ? row : n - 1;
+        const uint32_t* p = q8 + row * 3;
+        dst.d0 = p[0];
+        dst.d1 = p[1];
+        dst.d2 = p[2];
+    };
+    HalfTile T[kQ8 ? 1 : kHmChunks];
+    Row8 G[kQ8 ? kHmGroups : 1];
+    if constexpr (kQ8) {
 #pragma unroll
-    for (int u = 0; u < kHmChunks; ++u) load_chunk(T[u], step, u);
+        for (int g = 0; g < kHmGroups; ++g) load_group(G[g], step, g);
+    } else {
+#pragma unroll
+        for (int u = 0; u < kHmChunks; ++u) load_chunk(T[u], step, u);
+    }
 
     // ---- per-query state and the B fragment; the cutoffs from the sample while the first loads are in flight
     if (tid < kHmQueries) {
         float q[kDim], qn;
         // a real query starts with "every row is a candidate" (+inf in the threshold slots)
         const bool ok = hm_build_fragment(arg, n_queries, tid, 0x00007c00u, sm.bfrag, q, qn);
+        if constexpr (kQ8) hm_build_fragment8(sm, tid, tid < n_queries, ok, q, qn);
 #pragma unroll
         for (int j = 0; j < kDim; ++j) sm.qf[tid][j] = q[j];
         sm.qn[tid] = qn;
@@ -501,6 +604,7 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
     if (tid == 0) {
         sm.rescored = 0;
         sm.margin = arg.margin;
+        sm.q8 = kQ8 ? 1 : 0;
     }
     __syncthreads();
     if (n_seed > 0) {
@@ -511,6 +615,7 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
                 if (lane == 0) {
                     sm.cut[qi] = cut;
                     reinterpret_cast<uint32_t*>(&sm.bfrag[32 + qi])[2] = hm_threshold_slots(cut);
+                    if constexpr (kQ8) reinterpret_cast<uint32_t*>(&sm.bfrag8[qi])[3] = hm_q8_slots(cut + arg.margin + kBqSlack - sm.m8[qi]);
                 }
             }
         }
@@ -563,43 +668,115 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
         const int staged_before = staged;
         // the fragment is re-read every step (its cutoffs tighten); the barrier keeps the compiler from hoisting it
         asm volatile("" ::: "memory");
-        const uint4 bw = sm.bfrag[lane];
-        const bq_h8 B = __builtin_bit_cast(bq_h8, bw);
+        if constexpr (!kQ8) {
+            const uint4 bw = sm.bfrag[lane];
+            const bq_h8 B = __builtin_bit_cast(bq_h8, bw);
+    #pragma unroll
+            for (int u = 0; u < kHmChunks; ++u) {
+                const uint32_t chunk_row = static_cast<uint32_t>((step * kHmChunks + u) * 128);   // row of lane 0's first row
+    #pragma unroll
+                for (int S = 0; S < 2; ++S) {   // the lanes' even rows, then their odd rows
+                    const HmTiles a = hm_make_tiles(T[u], S, chunk_row, n32);
+                    if (a.special) {   // uniform, rare: one candidate per (special row, query)
+                        uint64_t sp = a.special;
+                        while (sp) {
+                            const int src = __ffsll(static_cast<long long>(sp)) - 1;
+                            sp &= sp - 1ull;
+                            if (staged + n_queries > kHmStage) {
+                                overflow = true;
+                            } else {
+                                if (lane < n_queries) stage[staged + lane] = make_uint2(static_cast<uint32_t>(lane), chunk_row + 2u * src + S);
+                                staged += n_queries;
+                            }
+                        }
+                    }
+                    const bq_f16v D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.a0, B, zero, 0, 0, 0);
+                    const bq_f16v D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.a1, B, zero, 0, 0, 0);
+                    const int ma = hm_tile_max(D0), mb = hm_tile_max(D1);
+                    if (__builtin_expect(__ballot(max(ma, mb) >= 0) != 0ull, 0)) {   // some D >= +0: approx >= T'
+                        if (__ballot(ma >= 0)) push_hits(D0, chunk_row + S, 0, a.special);
+                        if (__ballot(mb >= 0)) push_hits(D1, chunk_row + 64u + S, 32, a.special);
+                    }
+                }
+                load_chunk(T[u], step + total_waves, u);   // this chunk's registers are free again: the next step's rows
+            }
+        } else {
+            // every lane fetches its query column's 16 operand bytes; the two half-waves take turns as the K half that is live
+            const uint4 fw = sm.bfrag8[lane & 31];
+            const hm_v4i frag = {static_cast<int>(fw.x), static_cast<int>(fw.y), static_cast<int>(fw.z), static_cast<int>(fw.w)};
+            const hm_v4i none = {0, 0, 0, 0};
+            const hm_v4i B_lo = hh ? none : frag;   // k 0..15: the rows lanes 0..31 loaded
+            const hm_v4i B_hi = hh ? frag : none;   // k 16..31: the rows lanes 32..63 loaded
+            const hm_v16i zero_i = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int u = 0; u < kHmChunks; ++u) {
-            const uint32_t chunk_row = static_cast<uint32_t>((step * kHmChunks + u) * 128);   // row of lane 0's first row
-#pragma unroll
-            for (int S = 0; S < 2; ++S) {   // the lanes' even rows, then their odd rows
-                const HmTiles a = hm_make_tiles(T[u], S, chunk_row, n32);
-                if (a.special) {   // uniform, rare: one candidate per (special row, query)
-                    uint64_t sp = a.special;
+            for (int g = 0; g < kHmGroups; ++g) {
+                const uint32_t group_row = static_cast<uint32_t>(step * kHmStepRows + g * 64);   // row of lane 0
+                const bool in_range = group_row + static_cast<uint32_t>(lane) < n32;
+                const bool is_special = in_range && (G[g].d0 & 0xffu) == 0u;
+                const bool keep = in_range && !is_special;
+                // the lane's row IS its slice of the A operand: 12 bytes with the sign bit flipped (u - 128) + the constants
+                const hm_v4i A = {keep ? static_cast<int>(G[g].d0 ^ 0x80808080u) : 0, keep ? static_cast<int>(G[g].d1 ^ 0x80808080u) : 0,
+                                  keep ? static_cast<int>(G[g].d2 ^ 0x80808080u) : 0, static_cast<int>(kHmQ8RowConst)};
+                const uint64_t special = __ballot(is_special);
+                if (special) {   // uniform, rare: one candidate per (special row, query), straight to the exact chain
+                    uint64_t sp = special;
                     while (sp) {
                         const int src = __ffsll(static_cast<long long>(sp)) - 1;
                         sp &= sp - 1ull;
                         if (staged + n_queries > kHmStage) {
                             overflow = true;
                         } else {
-                            if (lane < n_queries) stage[staged + lane] = make_uint2(static_cast<uint32_t>(lane), chunk_row + 2u * src + S);
+                            if (lane < n_queries) stage[staged + lane] = make_uint2(static_cast<uint32_t>(lane) | kHmStageExact, group_row + src);
                             staged += n_queries;
                         }
                     }
                 }
-                const bq_f16v D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.a0, B, zero, 0, 0, 0);
-                const bq_f16v D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.a1, B, zero, 0, 0, 0);
-                const int ma = hm_tile_max(D0), mb = hm_tile_max(D1);
-                if (__builtin_expect(__ballot(max(ma, mb) >= 0) != 0ull, 0)) {   // some D >= +0: approx >= T'
-                    if (__ballot(ma >= 0)) push_hits(D0, chunk_row + S, 0, a.special);
-                    if (__ballot(mb >= 0)) push_hits(D1, chunk_row + 64u + S, 32, a.special);
+                const hm_v16i D0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B_lo, zero_i, 0, 0, 0);
+                const hm_v16i D1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B_hi, zero_i, 0, 0, 0);
+                load_group(G[g], step + total_waves, g);   // the registers are free again: the next step's rows
+                auto max16 = [](const hm_v16i& d) {
+                    auto max3 = [](int x, int y, int z) { return max(max(x, y), z); };
+                    return max(max3(max3(d[0], d[1], d[2]), max3(d[3], d[4], d[5]), max3(d[6], d[7], d[8])),
+                               max3(max3(d[9], d[10], d[11]), max3(d[12], d[13], d[14]), d[15]));
+                };
+                const int ma = max16(D0), mb = max16(D1);
+                if (__builtin_expect(__ballot(max(ma, mb) >= 0) != 0ull, 0)) {   // some D >= 0: approx8 >= L - m8
+                    auto push8 = [&](const hm_v16i& d, uint32_t first_row, int lane0) {
+#pragma unroll
+                        for (int g4 = 0; g4 < 16; g4 += 4) {
+                            if (!__ballot(max(max(d[g4], d[g4 + 1]), max(d[g4 + 2], d[g4 + 3])) >= 0)) continue;   // wave-uniform
+#pragma unroll
+                            for (int i = g4; i < g4 + 4; ++i) {
+                                if (__ballot(d[i] >= 0)) {   // wave-uniform
+                                    uint32_t lr = 4u * static_cast<uint32_t>(hh);
+                                    asm volatile("" : "+v"(lr));   // (see push_hits)
+                                    lr += static_cast<uint32_t>((i & 3) + 8 * (i >> 2));   // the lane of the tile that loaded the row
+                                    const uint32_t row = first_row + lr;
+                                    const bool hit = d[i] >= 0 && row < n32 && !((special >> (lane0 + lr)) & 1ull);
+                                    const uint64_t who = __ballot(hit);
+                                    if (who) {
+                                        const int n_hit = __popcll(who);
+                                        if (staged + n_hit > kHmStage) {
+                                            overflow = true;
+                                        } else {
+                                            if (hit) stage[staged + lanes_below(who)] = make_uint2(static_cast<uint32_t>(lane & 31), row);
+                                            staged += n_hit;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    };
+                    if (__ballot(ma >= 0)) push8(D0, group_row, 0);
+                    if (__ballot(mb >= 0)) push8(D1, group_row + 32u, 32);
                 }
             }
-            load_chunk(T[u], step + total_waves, u);   // this chunk's registers are free again: the next step's rows
         }
         // The buffer is drained when it is half full, so that only a step with more than 64 candidates of
         // its own can overflow it; such a step forgets what it noted and goes through the exact chain whole.
         if (__builtin_expect(overflow || staged >= kHmStage / 2, 0)) {   // uniform, rare
             if (overflow) staged = staged_before;
-            hm_resolve_stage(sm, staged, feats, row_base, topk);
-            n_rescored += staged;
+            n_rescored += hm_resolve_stage(sm, staged, feats, row_base, topk, kQ8 ? reinterpret_cast<const uint32_t*>(half) : nullptr);
             staged = 0;
             if (overflow) {
                 hm_exact_step(sm, feats, n, row_base, step * kHmStepRows, n_queries, topk);
@@ -608,8 +785,7 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
             }
         }
     }
-    hm_resolve_stage(sm, staged, feats, row_base, topk);
-    n_rescored += staged;
+    n_rescored += hm_resolve_stage(sm, staged, feats, row_base, topk, kQ8 ? reinterpret_cast<const uint32_t*>(half) : nullptr);
     if (lane == 0) atomicAdd(&sm.rescored, n_rescored);
     __syncthreads();
     if (tid == 0) rescored[bid] += static_cast<unsigned long long>(sm.rescored);   // launches of a handle are stream-ordered

@@ -139,7 +139,7 @@ def test_randomised_multi_query_and_sharded_streams():
         topn = int(rng.choice([1, 5, 50, 100, 128]))
         # ---- one handle: forced multi-query passes, then a stream of batches
         with CosineEngine(f) as eng:
-            eng.set_batch_path(3)
+            eng.set_batch_path(3 + case % 2)   # the multi-query pass forced, rows from the fp16 / the 8-bit replica
             batch = int(rng.integers(2, 45))
             qrows = rng.integers(0, rows, size=batch)
             queries = f[qrows].copy()

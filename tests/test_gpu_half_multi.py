@@ -1,6 +1,7 @@
-"""Multi-query passes over the fp16 replica (csrc/replica_multi.hip.h, mi355::scan_half_multi_kernel):
-2 ... 32 queries share ONE 24 B/row pass (fp16 matrix-core pre-filter, candidates resolved in the same
-launch); every key is still the exact fp32 chain on the fp32 row.
+"""Multi-query passes over the replicas (csrc/replica_multi.hip.h, mi355::scan_half_multi_kernel):
+2 ... 32 queries share ONE pass — 12 B/row through the integer matrix core with an fp16 re-check of the
+candidates, or 24 B/row through the fp16 matrix core — candidates resolved in the same launch; every key
+is still the exact fp32 chain on the fp32 row.
 Through the C-ABI (mi355rec_query_batch_topn / _enqueue_batch_keys with MI355REC_BATCH_HALF forced, and
 under AUTO where up to 16 queries on a shard with a replica take this path), against the oracle:
 scores bit-exact, ids tie-aware, keys identical to the single-query path.
@@ -28,10 +29,21 @@ def torch_cuda():
     return torch
 
 
-@pytest.fixture(scope="module")
-def Engine(torch_cuda):
+@pytest.fixture(params=["q8", "fp16"])
+def Engine(torch_cuda, request):
+    """Every test runs once per front end of the multi-query pass: rows streamed from the 8-bit replica through
+    the integer matrix core (MI355REC_BATCH_Q8; AUTO takes it for passes of one or two queries), or from the
+    fp16 replica (MI355REC_BATCH_HALF; AUTO's choice from three queries up)."""
     from spotify_recommender_amd.engine import CosineEngine
-    return CosineEngine
+
+    class FrontEnd(CosineEngine):
+        """HALF forced by a test means "the multi-query pass whatever the count": with this fixture's front end."""
+        front = 4 if request.param == "q8" else 3
+
+        def set_batch_path(self, path):
+            super().set_batch_path(self.front if path == HALF else path)
+
+    return FrontEnd
 
 
 def passes_of(batch):
@@ -95,7 +107,7 @@ def test_batches_match_the_oracle_and_the_single_query_path(Engine, torch_cuda, 
                 assert np.array_equal(single.cpu().numpy(), keys[b]), (batch, topn, b)
         after = eng.replica_counters()
         # every pass went over the replica, and sent a few thousand rows per query to the exact chain — not all, not none
-        extra_single = 3 * 7 if n >= 1_000_000 else 0       # the single-query checks scan the replica too from 1 M rows up
+        extra_single = 3 * 7 if eng.stats().replica_active else 0   # the single-query checks scan the replica too (AUTO: from 1 M rows up)
         assert after["scans"] - before["scans"] == passes + extra_single
         per_pass = (after["rescored_rows"] - before["rescored_rows"]) / (after["scans"] - before["scans"])
         assert 1 <= per_pass < 0.05 * n * 32, per_pass
@@ -269,6 +281,7 @@ def test_a_stream_of_batches(Engine, torch_cuda):
     plan = [(12, 100), (32, 100), (1, 10), (40, 16), (7, 128), (2, 100), (12, 100), (12, 100)]
     outs, meta = [], []
     with Engine(f) as eng:
+        eng.set_batch_path(HALF)       # this fixture's front end for every batch of the stream
         for step, (batch, topn) in enumerate(plan):
             qrows = rng.integers(0, n, size=batch)
             qrows[0] = 9

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Driver for the multi-query pass over the fp16 replica (csrc/replica_multi.hip.h): single calls and streams of
-batches of 1 ... 32 queries, with the kernel's event time and the rows it sent to the exact chain.
+"""Driver for the multi-query pass over the replicas (csrc/replica_multi.hip.h): single calls and streams of
+batches of 1 ... 32 queries, with the kernel's event time and the rows it sent to the exact chain; --fp16 for
+the fp16 front end.
   python3 tools/run_half_multi.py --rows 10000000 --topn 100
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/x -- python3 tools/run_half_multi.py --only-stream 12
 """
@@ -20,6 +21,7 @@ def main():
     ap.add_argument("--topn", type=int, default=100)
     ap.add_argument("--calls", type=int, default=40)
     ap.add_argument("--only-stream", type=int, default=0, help="only a stream of batches of this many queries (profiling)")
+    ap.add_argument("--fp16", action="store_true", help="rows from the fp16 replica (24 B/row: the default from three queries per pass up) instead of the 8-bit one")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -34,7 +36,8 @@ def main():
     with CosineEngine(t) as eng:
         st0 = eng.stats()
         out["margin_single"], out["margin_multi"] = round(float(st0.replica_margin_single), 6), round(float(st0.replica_margin_multi), 6)
-        eng.set_batch_path(capi.BATCH_HALF)
+        eng.set_batch_path(capi.BATCH_HALF if args.fp16 else capi.BATCH_Q8)
+        out["front_end"] = "fp16 replica, 24 B/row" if args.fp16 else "8-bit replica, 12 B/row, fp16 re-check of the candidates"
         sizes = (1, 2, 4, 8, 12, 16, 24, 32) if not args.only_stream else ()
         for nb in sizes:
             keys = torch.zeros(nb * topn, dtype=torch.int64, device="cuda")
