@@ -8,8 +8,8 @@
 //     approx = sum_j q^_j (u_j - 128) / 127 ,        |approx - r^ . q^| <= l1(q^) / 254 ,   l1(q^) = sum |q^_j| <= sqrt(12).
 // The bound is PER QUERY (0.0137 at worst, ~0.012 for a typical query) and derived, not tuned: the
 // quantisation error of component j is at most 1/254 and enters the dot product multiplied by |q^_j|; the
-// fp32 evaluation adds < 2e-6, the normalisations and the reference chain's own rounding < 6e-6 (the
-// slack of batched.hip.h's derivation).  tests/test_q8_margin.py checks it on hostile data with a numpy
+// fp32 evaluation of the 12-term sum, the normalisations and the reference chain's own rounding are covered by
+// kQ8Slack = 3e-5 (each < 6e-6).  tests/test_q8_margin.py checks it on hostile data with a numpy
 // model of exactly this arithmetic.  Everything else is replica.hip.h's scheme, unchanged:
 //   * the contract per query is recommendByIndex's (Recommender.cu:275-318): every key that leaves the
 //     kernel is cosine_score() on the fp32 row (calculateSimilaritiesCPU, :256-273), bit for bit;
@@ -17,11 +17,13 @@
 //     (approx = 0 = its exact score); every other row (tiny, huge, inf, NaN) stores u = 0 — a byte no
 //     valid row contains — and is sent to the exact chain every time;
 //   * an invalid query (|q| outside [kBqMinNorm, kBqMaxNorm]) switches the pre-filter off for the launch;
-//   * the launch-wide cutoff comes from a spread sample: v = the topk-th largest of <= 2048 wave-tile
-//     maxima (here a wave tile is 256 rows: 5 % of the catalogue is sampled), cutoff = v - 2 margin - slack;
-//     workgroup-local thresholds tighten it whenever a local list fills.
-// With a margin ten times the fp16 replica's, ~0.3 % of the rows (20-35 k of 10 M at top-100) go to the
-// exact chain instead of 0.05 % — 2 MB of random 48 B fetches beside 120 MB of stream.
+//   * the launch-wide cutoff comes from a spread sample of 256-row wave tiles (5 % of the catalogue): per tile the
+//     EXACT score of the row with the largest approx (q8_region_pick / q8_region_store); v = the topk-th largest of
+//     those <= 2048 exact scores, cutoff = v - margin (ONE margin: v is the exact score of a real row; shards too
+//     small to afford the extra fetch keep approximate sample values and two margins); workgroup-local thresholds
+//     tighten it whenever a local list fills.
+// With a margin twelve times the fp16 replica's, ~0.1 % of the rows (~9 000 of 10 M at top-100) go to the exact
+// chain instead of 0.05 % — 0.6 MB of random 48 B fetches beside 120 MB of stream.
 //
 // One lane = FOUR rows = 48 B (3 x dwordx4: the same load pattern once more; row r of the lane is dwords
 // 3r .. 3r + 2), tiles of 4 * kBlock rows dealt round-robin over the scanning workgroups.  Per row 12
