@@ -275,8 +275,24 @@ __device__ __forceinline__ Q8Query q8_seed_rider(const float* __restrict__ feats
 
 // The launch-wide cutoff from n_seed sample maxima (approximate scores, ordered; 0 = empty): a row whose
 // approximate score is below it cannot be among the best topk.  -inf when the sample cannot say.
+struct Q8Sample {
+    uint32_t v[kHalfSeedPerThread];   // this thread's share of the sample values (0 = empty)
+};
 template <int kBlock, bool kSameLaunch = false>
-__device__ __forceinline__ float q8_cutoff_from_sample(const uint32_t* seed_vals, int n_seed, int topk, bool exact_values,
+__device__ __forceinline__ Q8Sample q8_load_sample(const uint32_t* seed_vals, int n_seed) {
+    Q8Sample s;
+#pragma unroll
+    for (int r = 0; r < kHalfSeedPerThread; ++r) {
+        const int i = static_cast<int>(threadIdx.x) + r * kBlock;
+        s.v[r] = 0u;
+        if (i < n_seed)   // kSameLaunch: written by other workgroups of THIS launch
+            s.v[r] = kSameLaunch ? __hip_atomic_load(&seed_vals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : seed_vals[i];
+    }
+    return s;
+}
+
+template <int kBlock>
+__device__ __forceinline__ float q8_cutoff_from_sample(const Q8Sample& sample, int n_seed, int topk, bool exact_values,
                                                        const Q8Query& hq, int* s_seeds /* zeroed */, SelectSmem& s_sel) {
     const int tid = threadIdx.x;
     float cutoff = -__builtin_inff();
@@ -286,9 +302,7 @@ __device__ __forceinline__ float q8_cutoff_from_sample(const uint32_t* seed_vals
 #pragma unroll
         for (int r = 0; r < kHalfSeedPerThread; ++r) {
             const int i = tid + r * kBlock;
-            uint32_t v = 0u;
-            if (i < n_seed)   // kSameLaunch: written by other workgroups of THIS launch
-                v = kSameLaunch ? __hip_atomic_load(&seed_vals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : seed_vals[i];
+            const uint32_t v = sample.v[r];
             mine[r] = v ? (static_cast<uint64_t>(v) << 32) | static_cast<uint32_t>(i + 1) : 0ull;
             have += v != 0u;
         }
@@ -381,8 +395,9 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
                 }
                 __syncthreads();
                 if (s_mem.scan.count) {   // uniform
-                    const float c = q8_cutoff_from_sample<kBlock, true>(next.out, next.regions * kHalfSeedWaves, next.topk, next.exact != 0, nq,
-                                                                        &s_mem.scan.seeds, s_mem.scan.sel);
+                    const Q8Sample all = q8_load_sample<kBlock, true>(next.out, next.regions * kHalfSeedWaves);
+                    const float c = q8_cutoff_from_sample<kBlock>(all, next.regions * kHalfSeedWaves, next.topk, next.exact != 0, nq,
+                                                                  &s_mem.scan.seeds, s_mem.scan.sel);
                     if (threadIdx.x == 0) {
                         next.ctl->cutoff = c;
                         next.ctl->done = 0u;
@@ -431,7 +446,15 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
 #pragma unroll
     for (int d = 0; d < kDepth - 1; ++d) load_tile(ring[d], d);
     float cutoff_left = 0.0f;
-    if (cutoff_ready) cutoff_left = *cutoff_ready;   // uniform: the riders of the launch before this one left it
+    Q8Sample sample;
+#pragma unroll
+    for (int r = 0; r < kHalfSeedPerThread; ++r) sample.v[r] = 0u;
+    const int n_sample = n_seed < 0 ? -n_seed : n_seed;
+    if (cutoff_ready) {   // uniform: the riders of the launch before this one left it
+        cutoff_left = *cutoff_ready;
+    } else {              // ... or this workgroup selects it from the sample values itself: asked for now, used after the query
+        sample = q8_load_sample<kBlock>(seed_vals, n_sample);
+    }
     float q[kDim];
     q8_load_query(kQueryFromRow ? query_ptr : nullptr, qarg.q, q);
     const float qn = query_norm(q);
@@ -450,7 +473,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
     if (cutoff_ready) {   // uniform
         cutoff = cutoff_left;
     } else {
-        cutoff = q8_cutoff_from_sample<kBlock>(seed_vals, n_seed < 0 ? -n_seed : n_seed, topk, n_seed < 0, hq, &sm->seeds, s_sel);
+        cutoff = q8_cutoff_from_sample<kBlock>(sample, n_sample, topk, n_seed < 0, hq, &sm->seeds, s_sel);
     }
     MI355REC_PHASE(2);
     uint64_t thr = 0;
