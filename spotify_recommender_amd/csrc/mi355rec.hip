@@ -133,12 +133,15 @@ struct mi355rec {
     bool mstream_ready = false;
     uint64_t* d_mstream_lists[2] = {nullptr, nullptr};   // [kHmQueries][hgrid][kMultiMaxTopK], alternating
     uint32_t* d_mstream_seed[2] = {nullptr, nullptr};    // [kHmQueries][regions * 8] sample maxima, alternating
+    float* d_mstream_cuts = nullptr;    // [2][kHmQueries] cutoffs the last seed rider left for the batch whose sample it completed
+    SeedCtl* d_mstream_ctl = nullptr;   // [2] the riders' arrival counters
     struct MStash {
         bool has = false;
         HalfMultiArg arg;
         int nq = 0, topn = 0;
         uint64_t* out = nullptr;
         int seed_buf = 0;
+        bool cuts_ready = false;        // its cutoffs were selected by the riders that took its sample (d_mstream_cuts[seed_buf])
     } mstash;
     struct MPending {
         bool has = false;
@@ -874,11 +877,11 @@ int enqueue_half_multi(mi355rec* h, const float* queries, const float* const* qp
             ++h->q8_scans;
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<false, true>), dim3(h->hg.grid),
                          dim3(kHmBlock), s, h->d_feats, h->d_half, reinterpret_cast<const uint32_t*>(h->d_q8), h->n, h->row_base, arg, nq,
-                         g0, topn, h->d_block_lists, h->d_half_mseed, n_seed, h->d_half_rescored, no_ride, arg);
+                         g0, topn, h->d_block_lists, h->d_half_mseed, n_seed, h->d_half_rescored, no_ride, arg, static_cast<const float*>(nullptr));
         } else {
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<false, false>), dim3(h->hg.grid),
                          dim3(kHmBlock), s, h->d_feats, h->d_half, static_cast<const uint32_t*>(nullptr), h->n, h->row_base, arg, nq,
-                         g0, topn, h->d_block_lists, h->d_half_mseed, n_seed, h->d_half_rescored, no_ride, arg);
+                         g0, topn, h->d_block_lists, h->d_half_mseed, n_seed, h->d_half_rescored, no_ride, arg, static_cast<const float*>(nullptr));
         }
     }
     HIP_TRY(h, hipGetLastError());
@@ -907,7 +910,15 @@ int ensure_mstream(mi355rec* h) {
         e = hipMalloc(&h->d_mstream_lists[i], list_bytes);
         if (e == hipSuccess) e = hipMalloc(&h->d_mstream_seed[i], seed_bytes);
     }
+    if (e == hipSuccess) e = hipMalloc(&h->d_mstream_cuts, sizeof(float) * 2 * kHmQueries);
+    if (e == hipSuccess) e = hipMalloc(&h->d_mstream_ctl, sizeof(SeedCtl) * 2);
+    if (e == hipSuccess) e = hipMemsetAsync(h->d_mstream_ctl, 0, sizeof(SeedCtl) * 2, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {   // all or nothing
+        if (h->d_mstream_cuts) (void)hipFree(h->d_mstream_cuts);
+        if (h->d_mstream_ctl) (void)hipFree(h->d_mstream_ctl);
+        h->d_mstream_cuts = nullptr;
+        h->d_mstream_ctl = nullptr;
         for (int i = 0; i < 2; ++i) {
             if (h->d_mstream_lists[i]) (void)hipFree(h->d_mstream_lists[i]);
             if (h->d_mstream_seed[i]) (void)hipFree(h->d_mstream_seed[i]);
@@ -923,7 +934,7 @@ int ensure_mstream(mi355rec* h) {
 
 // Launches the stashed batch: scanners + the mergers of the batch before it + (next != null) the seed
 // riders of the batch after it.
-int launch_mstash(mi355rec* h, hipStream_t s, const HalfMultiArg* next, int next_nq, int next_buf) {
+int launch_mstash(mi355rec* h, hipStream_t s, const HalfMultiArg* next, int next_nq, int next_topn, int next_buf) {
     auto& st = h->mstash;
     const int buf = h->mpending.has ? 1 - h->mpending.buf : 0;
     HmRide ride;
@@ -941,7 +952,11 @@ int launch_mstash(mi355rec* h, hipStream_t s, const HalfMultiArg* next, int next
         ride.regions = h->hg.seed_grid;
         ride.stride_rows = h->hg.seed_stride;
         ride.next_seed_vals = h->d_mstream_seed[next_buf];
+        ride.next_ctl = h->d_mstream_ctl + next_buf;
+        ride.next_cuts = h->d_mstream_cuts + next_buf * kHmQueries;
+        ride.next_topk = next_topn;
     }
+    const float* cuts_ready = st.cuts_ready ? h->d_mstream_cuts + st.seed_buf * kHmQueries : nullptr;
     // the launch stays within one resident wave of workgroups: the riders and mergers take scanner slots
     int scanners = h->hg.grid - ride.prev_queries - ride.seed_wgs;
     if (scanners < 1) scanners = 1;
@@ -952,13 +967,13 @@ int launch_mstash(mi355rec* h, hipStream_t s, const HalfMultiArg* next, int next
                      dim3(scanners + ride.prev_queries + ride.seed_wgs), dim3(kHmBlock), s, h->d_feats, h->d_half,
                      reinterpret_cast<const uint32_t*>(h->d_q8), h->n, h->row_base,
                      st.arg, st.nq, 0, st.topn, h->d_mstream_lists[buf], h->d_mstream_seed[st.seed_buf],
-                     h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, ride, next ? *next : st.arg);
+                     h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, ride, next ? *next : st.arg, cuts_ready);
     } else {
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<true, false>),
                      dim3(scanners + ride.prev_queries + ride.seed_wgs), dim3(kHmBlock), s, h->d_feats, h->d_half,
                      static_cast<const uint32_t*>(nullptr), h->n, h->row_base,
                      st.arg, st.nq, 0, st.topn, h->d_mstream_lists[buf], h->d_mstream_seed[st.seed_buf],
-                     h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, ride, next ? *next : st.arg);
+                     h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, ride, next ? *next : st.arg, cuts_ready);
     }
     HIP_TRY(h, hipGetLastError());
     h->mpending.has = true;
@@ -973,7 +988,7 @@ int launch_mstash(mi355rec* h, hipStream_t s, const HalfMultiArg* next, int next
 
 int flush_mstream(mi355rec* h, hipStream_t s) {
     if (h->mstash.has) {
-        const int rc = launch_mstash(h, s, nullptr, 0, 0);
+        const int rc = launch_mstash(h, s, nullptr, 0, 0, 0);
         if (rc) return rc;
     }
     if (!h->mpending.has) return MI355REC_OK;
@@ -996,10 +1011,12 @@ int enqueue_mstream(mi355rec* h, const float* queries, const float* const* qptrs
     HalfMultiArg arg;
     fill_half_multi_arg(arg, h->margin_mfma, queries, qptrs, exclude, g0, nq);
     int seed_buf = 0;
+    bool cuts_ready = false;
     if (h->mstash.has) {
         seed_buf = 1 - h->mstash.seed_buf;
-        rc = launch_mstash(h, s, &arg, nq, seed_buf);   // its riders take THIS batch's sample
+        rc = launch_mstash(h, s, &arg, nq, topn, seed_buf);   // its riders take THIS batch's sample (and select its cutoffs)
         if (rc) return rc;
+        cuts_ready = h->hg.seed_grid > 0;   // (launch_mstash gave the launch seed riders)
     } else {   // the head of a stream: a sample launch of its own
         hipLaunchKernelGGL(seed_half_multi_kernel, dim3(h->hg.seed_grid), dim3(kHmBlock), 0, s, h->d_half, h->n, h->hg.seed_stride,
                            arg, nq, h->d_mstream_seed[seed_buf]);
@@ -1012,6 +1029,7 @@ int enqueue_mstream(mi355rec* h, const float* queries, const float* const* qptrs
     st.topn = topn;
     st.out = out_keys;
     st.seed_buf = seed_buf;
+    st.cuts_ready = cuts_ready;
     return MI355REC_OK;
 }
 
@@ -1561,6 +1579,8 @@ void mi355rec_destroy(mi355rec_t* h) {
         if (h->d_mstream_lists[i]) (void)hipFree(h->d_mstream_lists[i]);
         if (h->d_mstream_seed[i]) (void)hipFree(h->d_mstream_seed[i]);
     }
+    if (h->d_mstream_cuts) (void)hipFree(h->d_mstream_cuts);
+    if (h->d_mstream_ctl) (void)hipFree(h->d_mstream_ctl);
     for (hipEvent_t e : h->ev_pass) (void)hipEventDestroy(e);
     if (h->owned_feats) (void)hipFree(h->owned_feats);
     if (h->d_block_lists) (void)hipFree(h->d_block_lists);

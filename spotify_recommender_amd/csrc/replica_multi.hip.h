@@ -204,7 +204,10 @@ __device__ __forceinline__ void hm_sample_regions(const uint4* __restrict__ half
         m = max(m, __shfl_xor(m, 32));   // lanes c and 32 + c hold the two row halves of query c
         // a positive float's bits are a positive int; its ordered image sets the top bit
         const uint32_t v = m > 0 ? (static_cast<uint32_t>(m) | 0x80000000u) : 0u;
-        if (lane < n_queries) seed_vals[lane * per_query + static_cast<int64_t>(g) * kHalfSeedWaves + wave] = v;
+        // written THROUGH to device scope: the last seed rider of the same launch may read it (hoisted cutoffs)
+        if (lane < n_queries)
+            __hip_atomic_store(&seed_vals[lane * per_query + static_cast<int64_t>(g) * kHalfSeedWaves + wave], v, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -299,7 +302,8 @@ __device__ __forceinline__ void hm_build_fragment8(HalfMultiSmem& sm, int c, boo
 }
 
 // The launch-wide cutoff of one query from its sample maxima, by one wave (see the header).
-__device__ __forceinline__ float hm_seed_cutoff(const uint32_t* __restrict__ vals, int n_seed, int topk, float margin) {
+template <bool kSameLaunch = false>   // the values were written by other workgroups of THIS launch: read past the L2
+__device__ __forceinline__ float hm_seed_cutoff(const uint32_t* vals, int n_seed, int topk, float margin) {
     const int lane = threadIdx.x & 63;
     // all of the lane's (up to 32) sample maxima are requested before the first is looked at
     constexpr int kPer = kHalfSeedMaxGrid * kHalfSeedWaves / 64;
@@ -307,7 +311,8 @@ __device__ __forceinline__ float hm_seed_cutoff(const uint32_t* __restrict__ val
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
         const int i = lane + 64 * j;
-        mine[j] = i < n_seed ? vals[i] : 0u;
+        mine[j] = 0u;
+        if (i < n_seed) mine[j] = kSameLaunch ? __hip_atomic_load(&vals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : vals[i];
     }
     uint32_t m1 = 0u, m2 = 0u, m3 = 0u, m4 = 0u;   // the lane's four largest (an insertion network per value)
 #pragma unroll
@@ -490,6 +495,12 @@ struct HmRide {
     int regions;
     long long stride_rows;
     uint32_t* next_seed_vals;     // [next_queries][regions * 8]
+    // the seed rider that finishes LAST turns the sample into the next batch's cutoffs (replica_q8.hip.h's hand-off:
+    // write-through stores, a counter, L2-bypassing loads — no fence under the scanners), so that the next launch's
+    // scanners start with one load instead of a selection per query (2.5 us per round of eight queries)
+    SeedCtl* next_ctl;            // null: the next launch selects its cutoffs itself
+    float* next_cuts;             // [kHmQueries]
+    int next_topk;
 };
 
 template <bool kRide>
@@ -509,7 +520,7 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
     HalfMultiArg arg, int n_queries,
     int slot0, int topk, uint64_t* __restrict__ block_lists, const uint32_t* __restrict__ seed_vals,
     int n_seed /* sample maxima per query, 0 = none */, unsigned long long* __restrict__ rescored /* [workgroups] */,
-    HmRide ride, HalfMultiArg next) {
+    HmRide ride, HalfMultiArg next, const float* __restrict__ cuts_ready /* [n_queries] left by the launch before, or null */) {
     __shared__ typename std::conditional<kRide, HmSmemU<true>, HalfMultiSmem>::type s_mem;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -531,11 +542,30 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
                 uint4* const fb = s_mem.scan.bfrag;
                 if (tid < kHmQueries) {
                     float q[kDim], qn;
-                    hm_build_fragment(next, ride.next_queries, tid, 0u, fb, q, qn);
+                    s_mem.scan.ok[tid] = hm_build_fragment(next, ride.next_queries, tid, 0u, fb, q, qn) ? 1u : 0u;
                 }
                 __syncthreads();
                 hm_sample_regions(half, n, ride.stride_rows, ride.regions, extra - ride.prev_queries, ride.seed_wgs, fb,
                                   ride.next_queries, ride.next_seed_vals);
+                if (ride.next_ctl) {   // uniform: last rider out selects the next batch's cutoffs
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's sample stores have completed
+                    __syncthreads();
+                    if (tid == 0)
+                        s_mem.scan.rescored = __hip_atomic_fetch_add(&ride.next_ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                                              static_cast<unsigned>(ride.seed_wgs) - 1u;
+                    __syncthreads();
+                    if (s_mem.scan.rescored) {   // uniform
+                        const int n_next = ride.regions * kHalfSeedWaves;
+                        for (int qi = wave; qi < ride.next_queries; qi += kHmWaves) {
+                            // (a query the bound cannot be claimed for keeps "every row is a candidate")
+                            const float cut = s_mem.scan.ok[qi] ? hm_seed_cutoff<true>(ride.next_seed_vals + static_cast<int64_t>(qi) * n_next,
+                                                                                      n_next, ride.next_topk + 1, next.margin)
+                                                                : -__builtin_inff();
+                            if (lane == 0) ride.next_cuts[qi] = cut;
+                        }
+                        if (tid == 0) ride.next_ctl->done = 0u;
+                    }
+                }
             }
             return;
         }
@@ -607,7 +637,14 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
         sm.q8 = kQ8 ? 1 : 0;
     }
     __syncthreads();
-    if (n_seed > 0) {
+    if (cuts_ready) {   // uniform: the last seed rider of the launch before this one selected them
+        if (tid < n_queries && sm.ok[tid]) {
+            const float cut = cuts_ready[tid];
+            sm.cut[tid] = cut;
+            reinterpret_cast<uint32_t*>(&sm.bfrag[32 + tid])[2] = hm_threshold_slots(cut);
+            if constexpr (kQ8) reinterpret_cast<uint32_t*>(&sm.bfrag8[tid])[3] = hm_q8_slots(cut + arg.margin + kBqSlack - sm.m8[tid]);
+        }
+    } else if (n_seed > 0) {
         for (int qi = wave; qi < n_queries; qi += kHmWaves) {
             if (sm.ok[qi]) {   // uniform
                 // the (topk + 1)-th largest: the query's own row may be among the sampled ones (hm_sample_regions)
