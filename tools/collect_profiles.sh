@@ -14,12 +14,13 @@ SQ1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_W
 rocprofv3 --pmc $SQ1 --output-format csv -d $O/pmc_q8 -- python3 tools/run_replica.py --rows 10000000 --topn 100 --steps 120 --check 8 --only 2 > $O/pmc_q8.log 2>&1
 rocprofv3 --pmc $SQ1 --output-format csv -d $O/pmc_half -- python3 tools/run_replica.py --rows 10000000 --topn 100 --steps 120 --check 8 --only 3 > $O/pmc_half.log 2>&1
 python3 tools/run_replica.py --rows 10000000 --topn 100 --steps 300 > $O/replica_ab.json 2> $O/replica_ab.err
-python3 tools/run_half_multi.py > $O/half_multi.json 2> $O/half_multi.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_hm -- python3 tools/run_half_multi.py --only-stream 12 --calls 60 > $O/trace_hm.log 2>&1
-rocprofv3 --pmc $SQ1 --output-format csv -d $O/pmc_hm_a -- python3 tools/run_half_multi.py --only-stream 12 --calls 60 > $O/pmc_hm_a.log 2>&1
-rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_hm_b -- python3 tools/run_half_multi.py --only-stream 12 --calls 60 > $O/pmc_hm_b.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_hm_f -- python3 tools/run_half_multi.py --only-stream 12 --calls 60 > $O/pmc_hm_f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_hm_w -- python3 tools/run_half_multi.py --only-stream 12 --calls 60 > $O/pmc_hm_w.log 2>&1
+python3 tools/run_half_multi.py --fp16 > $O/half_multi.json 2> $O/half_multi.err
+python3 tools/run_half_multi.py > $O/half_multi_q8.json 2>> $O/half_multi.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_hm -- python3 tools/run_half_multi.py --fp16 --only-stream 12 --calls 60 > $O/trace_hm.log 2>&1
+rocprofv3 --pmc $SQ1 --output-format csv -d $O/pmc_hm_a -- python3 tools/run_half_multi.py --fp16 --only-stream 12 --calls 60 > $O/pmc_hm_a.log 2>&1
+rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_hm_b -- python3 tools/run_half_multi.py --fp16 --only-stream 12 --calls 60 > $O/pmc_hm_b.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_hm_f -- python3 tools/run_half_multi.py --fp16 --only-stream 12 --calls 60 > $O/pmc_hm_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_hm_w -- python3 tools/run_half_multi.py --fp16 --only-stream 12 --calls 60 > $O/pmc_hm_w.log 2>&1
 echo "kernel profiles done"
 python bench.py --virtual-shards 8 --no-cpu-baseline > $O/virtual8.json 2> $O/virtual8.err
 g++ -O2 -std=c++17 -Iinclude tools/latency.cpp spotify_recommender_amd/csrc/Recommender.cpp spotify_recommender_amd/csrc/DataManager.cpp \
