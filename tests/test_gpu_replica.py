@@ -485,3 +485,32 @@ def test_long_stream_over_a_large_shard(Engine, torch_cuda, ordered):
             want = oracle.scores(f, f[r], threads=0)
             assert_topn_matches(idx, sc, want, r, topn, ref_idx=oracle.topn_heap(want, r, topn))
         assert eng.stats().lone_fused_queries - before == (5 if ON == 2 else 0)
+
+
+def test_two_thousand_streamed_queries_key_for_key(Engine, torch_cuda):
+    """The hand-offs inside a launch (last seed rider -> the next launch's cutoff; sample values written through and
+    read past the L2) under many back-to-back launches: 2000 streamed queries with mixed topn over 4 M rows, restarted
+    every few hundred, every key list compared on the device with the same query over the fp32 rows (which use none
+    of those hand-offs).  A lost or stale cutoff would show as a missing key.  (tools/soak.py is the long version.)"""
+    torch = torch_cuda
+    rng = np.random.default_rng(2024 + ON)
+    n = 4_000_000
+    f = torch.rand((n, 12), generator=torch.Generator(device="cuda").manual_seed(5), device="cuda", dtype=torch.float32)
+    rows = rng.integers(0, n, size=2000)
+    topns = rng.choice([1, 10, 100, 100, 500, 1000], size=2000)
+    with Engine(f) as eng:
+        runs = {}
+        for mode in (OFF, ON):
+            eng.set_replica(mode)
+            outs = []
+            for i in range(len(rows)):
+                k = torch.zeros(int(topns[i]), dtype=torch.int64, device="cuda")
+                eng.enqueue_row_keys_streamed(int(rows[i]), int(topns[i]), k)
+                outs.append(k)
+                if i % 331 == 330:
+                    eng.enqueue_flush()
+            eng.enqueue_flush()
+            torch.cuda.synchronize()
+            runs[mode] = outs
+        bad = [i for i in range(len(rows)) if not torch.equal(runs[OFF][i], runs[ON][i])]
+        assert not bad, (len(bad), bad[:5])
