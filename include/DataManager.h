@@ -9,6 +9,7 @@
 #include <fstream>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -46,8 +47,14 @@ public:
         std::vector<std::string> trackNames;
         std::vector<uint64_t> recordOffsets;    // byte offset of song i in the file
         std::map<int, std::string> genreMap;
-        // readSong's file handle, opened on first use and kept (one open per catalogue, not per printed song)
-        mutable std::shared_ptr<std::ifstream> reader;
+        // readSong's file handle: created by loadCatalogue (shared by copies of the catalogue), opened on first use
+        // and kept (one open per catalogue, not per printed song); the mutex makes readSong safe to call from
+        // several threads, on one catalogue or on copies of it
+        struct Reader {
+            std::mutex lock;
+            std::ifstream in;
+        };
+        std::shared_ptr<Reader> reader;
         size_t size() const { return trackIds.size(); }
     };
     static bool loadCatalogue(const std::string& binaryPath, Catalogue& out);

@@ -486,6 +486,23 @@ int mi355rec_sharded_wait(mi355rec_sharded_t* h, int64_t ticket, int64_t* out_id
 int mi355rec_sharded_stream_stats(const mi355rec_sharded_t* h, int64_t* queries, int64_t* exchanges,
                                   int64_t* host_ns);
 
+/* TEST HOOK for the cross-workgroup hand-offs of the streamed scans (csrc/replica.hip.h, "hand-offs that fail
+ * safe": sample values and cutoffs carry the epoch of their query, arrival counters are never reset).  Simulates
+ * what a reader would see if the stores it depends on had not landed; results must stay those of the oracle —
+ * only slower.  flags (or-ed):
+ *   POISON          now (synchronises the device): every sample buffer and every left-behind cutoff of the handle is
+ *                   overwritten with the most hostile values an EARLIER query could have left (a perfect score, a
+ *                   cutoff of +1.0) under the epochs of the last queries;
+ *   DROP_STORES     the seed riders of the next streamed launch do not store the first half of their regions (the
+ *                   last rider then reads whatever was there before);
+ *   NO_LAST_RIDER   the next streamed launch is told a wrong arrival count, so none of its riders selects a cutoff
+ *                   (the following launch then finds whatever cutoff was there before).
+ * Never needed in production; tests/test_gpu_replica.py and tests/test_gpu_half_multi.py use it. */
+#define MI355REC_DEBUG_HANDOFF_POISON 1
+#define MI355REC_DEBUG_HANDOFF_DROP_STORES 2
+#define MI355REC_DEBUG_HANDOFF_NO_LAST_RIDER 4
+int mi355rec_debug_handoff(mi355rec_t* h, int flags);
+
 /* ---- key helpers (host side, no device needed) --------------------------- */
 mi355rec_key_t mi355rec_pack_key(float score, int64_t global_row);
 float mi355rec_key_score(mi355rec_key_t key);

@@ -18,6 +18,7 @@ MAX_TOPN_FAST = 1024
 BATCH_AUTO, BATCH_MULTI, BATCH_MFMA, BATCH_HALF, BATCH_Q8 = 0, 1, 2, 3, 4
 REPLICA_AUTO, REPLICA_OFF, REPLICA_ON, REPLICA_FP16 = 0, 1, 2, 3
 TRANSPORT_PEER, TRANSPORT_RCCL = 1, 2
+DEBUG_HANDOFF_POISON, DEBUG_HANDOFF_DROP_STORES, DEBUG_HANDOFF_NO_LAST_RIDER = 1, 2, 4
 
 OK = 0
 ERR_INVALID_ARG = -1
@@ -115,6 +116,7 @@ SIGNATURES = {
     "mi355rec_sharded_enqueue_flush": (c_int, [c_void_p]),
     "mi355rec_sharded_wait": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, POINTER(c_int)]),
     "mi355rec_sharded_stream_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
+    "mi355rec_debug_handoff": (c_int, [c_void_p, c_int]),
     "mi355rec_pack_key": (c_uint64, [c_float, c_int64]),
     "mi355rec_key_score": (c_float, [c_uint64]),
     "mi355rec_key_row": (c_int64, [c_uint64]),

@@ -375,6 +375,7 @@ bool DataManager::loadFeatureMatrix(const std::string& binaryPath, std::vector<f
 bool DataManager::loadCatalogue(const std::string& binaryPath, Catalogue& out) {
     std::cout << "Loading preprocessed data from: " << binaryPath << std::endl;
     out.path = binaryPath;
+    out.reader = std::make_shared<Catalogue::Reader>();   // opened by the first readSong
     if (!walkBinary(binaryPath, out.features, out.trackIds, out.trackNames, &out.recordOffsets, &out.genreMap)) {
         std::cerr << "Error: Could not read binary file: " << binaryPath << std::endl;
         return false;
@@ -385,11 +386,19 @@ bool DataManager::loadCatalogue(const std::string& binaryPath, Catalogue& out) {
 
 bool DataManager::readSong(const Catalogue& catalogue, size_t index, Song& out) {
     if (index >= catalogue.recordOffsets.size()) return false;
-    if (!catalogue.reader) catalogue.reader = std::make_shared<std::ifstream>(catalogue.path, std::ios::binary);
-    std::ifstream& in = *catalogue.reader;
-    if (!in.is_open()) return false;
-    in.clear();
-    in.seekg(static_cast<std::streamoff>(catalogue.recordOffsets[index]));
-    out.deserialize(in);
-    return static_cast<bool>(in);
+    if (!catalogue.reader) {   // a catalogue that did not come from loadCatalogue: a stream of this call's own
+        std::ifstream in(catalogue.path, std::ios::binary);
+        if (!in.is_open()) return false;
+        in.seekg(static_cast<std::streamoff>(catalogue.recordOffsets[index]));
+        out.deserialize(in);
+        return static_cast<bool>(in);
+    }
+    Catalogue::Reader& r = *catalogue.reader;
+    std::lock_guard<std::mutex> hold(r.lock);   // position and state of the shared stream belong to one caller at a time
+    if (!r.in.is_open()) r.in.open(catalogue.path, std::ios::binary);
+    if (!r.in.is_open()) return false;
+    r.in.clear();
+    r.in.seekg(static_cast<std::streamoff>(catalogue.recordOffsets[index]));
+    out.deserialize(r.in);
+    return static_cast<bool>(r.in);
 }

@@ -678,30 +678,38 @@ __device__ __forceinline__ void merge_body(
 // polls.  No fences under the scanners (see scan_q8_kernel's seed riders for what those cost) and no spinning:
 // every workgroup leaves after one atomic or two.
 struct LoneTail {
-    unsigned* counters;       // [9]: groups 0..7 (blockIdx % 8), then the count of finished groups; all zero between launches
+    unsigned* counters;       // [9]: groups 0..7 (blockIdx % 8), then the count of finished groups; counted up across launches, never reset
     uint64_t* out_keys;
     int64_t* out_idx;         // may be device-visible pinned host memory
     float* out_score;
     uint32_t* done_word;      // null: no completion word
     uint32_t done_value;
+    unsigned base[9];         // what each counter holds before this launch's arrivals (the host keeps the books: lone_tail_bases)
 };
+
+// The arrivals a launch of `grid` workgroups adds to counter g (g < 8), resp. to counter 8 (host and device agree on this).
+__host__ __device__ inline unsigned lone_tail_groups(unsigned grid) { return grid < 8u ? grid : 8u; }
+__host__ __device__ inline unsigned lone_tail_members(unsigned grid, unsigned g) {
+    const unsigned groups = lone_tail_groups(grid);
+    return g < groups ? (grid - g + groups - 1u) / groups : 0u;
+}
 
 // Every thread of every workgroup calls this after block_rank_and_store<.., true>; `s_flag` is any LDS word the
 // caller can spare.  n_lists = gridDim.x lists of topk keys at `lists`.
+// A workgroup is "last" only when the counter reaches exactly base + members: the counters are never reset, so no
+// missed or repeated reset can make two workgroups (or none of this launch's own) believe they are the last one;
+// a counter that does not add up leaves the completion word unwritten and the host call fails loudly (wait_done).
 template <typename MergeSmem>
 __device__ __forceinline__ void lone_tail(MergeSmem& msm, int* s_flag, const uint64_t* lists, int topk, const LoneTail& lt) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's list stores have completed (s_waitcnt)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through list stores have completed (a workgroup-scope fence does not wait for them)
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned groups = gridDim.x < 8u ? gridDim.x : 8u;
+        const unsigned groups = lone_tail_groups(gridDim.x);
         const unsigned g = blockIdx.x % groups;
-        const unsigned members = (gridDim.x - g + groups - 1u) / groups;
+        const unsigned members = lone_tail_members(gridDim.x, g);
         int last = 0;
-        if (__hip_atomic_fetch_add(&lt.counters[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
-            lt.counters[g] = 0u;   // (visible to the next launch)
-            last = __hip_atomic_fetch_add(&lt.counters[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1u;
-            if (last) lt.counters[8] = 0u;
-        }
+        if (__hip_atomic_fetch_add(&lt.counters[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == lt.base[g] + members)
+            last = __hip_atomic_fetch_add(&lt.counters[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == lt.base[8] + groups;
         *s_flag = last;
     }
     __syncthreads();

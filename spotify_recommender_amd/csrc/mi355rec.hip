@@ -97,8 +97,18 @@ struct mi355rec {
     uint64_t* pending_out = nullptr;
     // fp16 replica of the catalogue (replica.hip.h) and the geometry of the scan over it
     uint4* d_half = nullptr;            // ((n + 1) / 2) pairs of rows x 48 B
-    uint32_t* d_half_seed = nullptr;    // kHalfSeedMaxGrid x 8 sample maxima of the query in flight
-    uint32_t* d_half_mseed = nullptr;   // kHmQueries x that: the sample of a multi-query pass over the replica
+    // sample maxima: 8 bytes per entry — epoch-tagged values (8-bit scan, multi-query pass: replica.hip.h, "hand-offs
+    // that fail safe"); the fp16 single-query scan uses the same buffers as plain uint32_t[]
+    unsigned long long* d_half_seed = nullptr;    // kHalfSeedMaxGrid x 8 sample maxima of the query in flight
+    unsigned long long* d_half_mseed = nullptr;   // kHmQueries x that: the sample of a multi-query pass over the replica
+    uint32_t epoch_ctr = 0;             // the last epoch handed out (one per query / batch whose sample or cutoff crosses workgroups; never 0)
+    unsigned ctl_done[2] = {0u, 0u};    // what d_stream_ctl[i].done holds (the riders' arrival counters are never reset)
+    unsigned mctl_done[2] = {0u, 0u};   // ... and d_mstream_ctl[i].done
+    unsigned lone_base[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // ... and d_lone_ctr[0..8]
+    // test hooks (mi355rec_debug_handoff): the next rider launch drops the sample stores of regions below this one /
+    // is told a wrong arrival count, so that none of its riders is the last
+    int dbg_skip_regions = 0;
+    bool dbg_no_last = false;
     unsigned long long* d_half_rescored = nullptr;   // [kRideMaxLists] rows sent to the exact chain, per workgroup slot
     unsigned* d_lone_ctr = nullptr;     // [9] arrival counters of a lone query's launch (kernels.hip.h, LoneTail); zero between launches
     int64_t lone_fused = 0;             // lone queries served by one launch (scan + merge + completion word)
@@ -124,16 +134,17 @@ struct mi355rec {
         int topn = 0;
         uint64_t* out = nullptr;
         int seed_buf = 0;               // which of d_stream_seed holds ITS sample maxima
+        uint32_t epoch = 0;             // the tag of its sample values and of its cutoff
         bool q8 = false;                // that sample was taken over the 8-bit replica, so its scan runs there
         bool cutoff_ready = false;      // ... by riders, whose last one left the launch-wide cutoff in d_stream_ctl
     } stashed;
-    uint32_t* d_stream_seed[2] = {nullptr, nullptr};
+    unsigned long long* d_stream_seed[2] = {nullptr, nullptr};
     SeedCtl* d_stream_ctl = nullptr;    // [2]: rider count and finished cutoff beside each of d_stream_seed (8-bit replica)
     // a STREAM of batches over the replica (mi355rec_enqueue_batch_keys_streamed)
     bool mstream_ready = false;
     uint64_t* d_mstream_lists[2] = {nullptr, nullptr};   // [kHmQueries][hgrid][kMultiMaxTopK], alternating
-    uint32_t* d_mstream_seed[2] = {nullptr, nullptr};    // [kHmQueries][regions * 8] sample maxima, alternating
-    float* d_mstream_cuts = nullptr;    // [2][kHmQueries] cutoffs the last seed rider left for the batch whose sample it completed
+    unsigned long long* d_mstream_seed[2] = {nullptr, nullptr};    // [kHmQueries][regions * 8] tagged sample maxima, alternating
+    unsigned long long* d_mstream_cuts = nullptr;    // [2][kHmQueries] tagged cutoffs the last seed rider left for the batch whose sample it completed
     SeedCtl* d_mstream_ctl = nullptr;   // [2] the riders' arrival counters
     struct MStash {
         bool has = false;
@@ -141,6 +152,7 @@ struct mi355rec {
         int nq = 0, topn = 0;
         uint64_t* out = nullptr;
         int seed_buf = 0;
+        uint32_t epoch = 0;             // the tag of its sample values and of its cutoffs
         bool cuts_ready = false;        // its cutoffs were selected by the riders that took its sample (d_mstream_cuts[seed_buf])
     } mstash;
     struct MPending {
@@ -230,6 +242,13 @@ int fail(mi355rec* h, int code, const char* fmt, ...) {
     if (h) h->err = buf;
     g_last_error = buf;
     return code;
+}
+
+// One epoch per query / batch whose sample values or cutoff are handed from workgroup to workgroup (never 0: a
+// zeroed buffer holds no valid tag).
+uint32_t next_epoch(mi355rec* h) {
+    if (++h->epoch_ctr == 0u) ++h->epoch_ctr;
+    return h->epoch_ctr;
 }
 
 #define HIP_TRY(h, expr)                                                          \
@@ -364,15 +383,16 @@ void free_replica(mi355rec* h) {
 int alloc_replica(mi355rec* h, int64_t n_padded) {
     HIP_TRY(h, hipMalloc(&h->d_half, static_cast<size_t>(n_padded) * 24));
     HIP_TRY(h, hipMalloc(&h->d_q8, static_cast<size_t>((h->n + 3) / 4) * 48));
-    HIP_TRY(h, hipMalloc(&h->d_half_seed, sizeof(uint32_t) * kHalfSeedMaxGrid * kHalfSeedWaves));
-    HIP_TRY(h, hipMalloc(&h->d_half_mseed, sizeof(uint32_t) * kHmQueries * kHalfSeedMaxGrid * kHalfSeedWaves));
+    HIP_TRY(h, hipMalloc(&h->d_half_seed, sizeof(unsigned long long) * kHalfSeedMaxGrid * kHalfSeedWaves));
+    HIP_TRY(h, hipMalloc(&h->d_half_mseed, sizeof(unsigned long long) * kHmQueries * kHalfSeedMaxGrid * kHalfSeedWaves));
     HIP_TRY(h, hipMalloc(&h->d_half_rescored, sizeof(unsigned long long) * kRideMaxLists));
     // the sample buffers of STREAMED queries belong to the replica: whoever has d_half has them
     for (int i = 0; i < 2; ++i)
-        HIP_TRY(h, hipMalloc(&h->d_stream_seed[i], sizeof(uint32_t) * kHalfSeedMaxGrid * kHalfSeedWaves));
+        HIP_TRY(h, hipMalloc(&h->d_stream_seed[i], sizeof(unsigned long long) * kHalfSeedMaxGrid * kHalfSeedWaves));
     HIP_TRY(h, hipMemsetAsync(h->d_half_rescored, 0, sizeof(unsigned long long) * kRideMaxLists, h->stream));
     HIP_TRY(h, hipMalloc(&h->d_stream_ctl, sizeof(SeedCtl) * 2));
     HIP_TRY(h, hipMemsetAsync(h->d_stream_ctl, 0, sizeof(SeedCtl) * 2, h->stream));
+    h->ctl_done[0] = h->ctl_done[1] = 0u;
     return MI355REC_OK;
 }
 
@@ -412,7 +432,7 @@ int build_replica_inner(mi355rec* h) {
     HIP_TRY(h, e);
     HIP_TRY(h, hipGetLastError());
     // which error bound the pre-filters may claim on this device (replica.hip.h, half_selfcheck_kernel)
-    float* scratch = reinterpret_cast<float*>(h->d_half_seed);
+    float* scratch = reinterpret_cast<float*>(h->d_half_seed);   // (any scratch of >= 16 bytes will do)
     hipLaunchKernelGGL(half_selfcheck_kernel, dim3(1), dim3(64), 0, h->stream, scratch);
     float chk[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     HIP_TRY(h, hipMemcpyAsync(chk, scratch, sizeof chk, hipMemcpyDeviceToHost, h->stream));
@@ -637,13 +657,15 @@ bool q8_hoists(const mi355rec* h) { return h->qg.riders > 0 && h->qg.r_iters >= 
 bool q8_exact_sample(const mi355rec* h) { return h->qg.iters >= 3; }
 
 // The sample that seeds the launch-wide cutoff of the next scan over the replica.
-void enqueue_half_seed(mi355rec* h, bool q8, const float* qptr, const QueryArg& qa, int64_t exclude_global, uint32_t* seed_out,
-                       hipStream_t s) {
+// (8-bit replica: the values are tagged with `epoch`, which the scan that reads them is given as well)
+void enqueue_half_seed(mi355rec* h, bool q8, const float* qptr, const QueryArg& qa, int64_t exclude_global, unsigned long long* seed_buf,
+                       uint32_t epoch, hipStream_t s) {
+    uint32_t* const seed_out = reinterpret_cast<uint32_t*>(seed_buf);   // the fp16 scan's plain values
     if (q8) {
         if (h->qg.seed_grid <= 0) return;
 #define SEED_Q8(FROM_ROW, EXACT, QP)                                                                                       \
     hipLaunchKernelGGL((seed_q8_kernel<FROM_ROW, EXACT>), dim3(h->qg.seed_grid), dim3(kHalfSeedBlock), 0, s, h->d_feats, h->d_q8, \
-                       h->n, h->qg.seed_stride, h->row_base, qa, QP, exclude_global, seed_out)
+                       h->n, h->qg.seed_stride, h->row_base, qa, QP, exclude_global, seed_buf, epoch)
         if (q8_exact_sample(h)) {
             if (qptr) SEED_Q8(true, true, qptr);
             else SEED_Q8(false, true, kNoQueryPtr);
@@ -678,7 +700,7 @@ int enqueue_scan(mi355rec* h, const float* qptr, const float* query12,
     qa.margin = h->margin_mix;
     if (!qptr) std::memcpy(qa.q, query12, sizeof qa.q);
     const PrevMerge none{nullptr, 0, 0, nullptr};
-    const LoneTail no_tail{nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+    const LoneTail no_tail{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}};
     if (fused) *fused = false;
     if (use_half(h, upper_dev)) {
         NextSeed no_next;
@@ -687,21 +709,32 @@ int enqueue_scan(mi355rec* h, const float* qptr, const float* query12,
         if (use_q8(h)) {
             *n_lists = h->qg.grid;
             ++h->q8_scans;
-            enqueue_half_seed(h, true, qptr, qa, exclude_global, h->d_half_seed, s);
+            const uint32_t epoch = next_epoch(h);
+            enqueue_half_seed(h, true, qptr, qa, exclude_global, h->d_half_seed, epoch, s);
             const int q8_seeds = (q8_exact_sample(h) ? -1 : 1) * h->qg.seed_grid * kHalfSeedWaves;   // (negative: exact values)
+            const unsigned long long* const no_cutoff = nullptr;
             if (lone && h->n >= kLoneFusedMinRows) {
+                // the arrival counters of the launch's tail count up and are never reset: this launch starts from ...
+                LoneTail tail = *lone;
+                const unsigned grid = static_cast<unsigned>(h->qg.grid);
+                for (unsigned g = 0; g < 8u; ++g) {
+                    tail.base[g] = h->lone_base[g];
+                    h->lone_base[g] += lone_tail_members(grid, g);
+                }
+                tail.base[8] = h->lone_base[8];
+                h->lone_base[8] += lone_tail_groups(grid);
                 if (qptr) {
                     LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, true, false, true>),
                                  dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
                                  h->d_feats, h->d_q8, h->n, h->qg.iters, h->row_base, qa, qptr, exclude_global, topn,
                                  h->d_block_lists, h->d_half_seed, q8_seeds, h->d_half_rescored, none, no_next,
-                                 static_cast<const float*>(nullptr), *lone);
+                                 no_cutoff, tail, epoch);
                 } else {
                     LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, false, false, true>),
                                  dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
                                  h->d_feats, h->d_q8, h->n, h->qg.iters, h->row_base, qa, kNoQueryPtr, exclude_global, topn,
                                  h->d_block_lists, h->d_half_seed, q8_seeds, h->d_half_rescored, none, no_next,
-                                 static_cast<const float*>(nullptr), *lone);
+                                 no_cutoff, tail, epoch);
                 }
                 HIP_TRY(h, hipGetLastError());
                 *fused = true;
@@ -712,29 +745,30 @@ int enqueue_scan(mi355rec* h, const float* qptr, const float* query12,
                              dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
                              h->d_feats, h->d_q8, h->n, h->qg.iters, h->row_base, qa, qptr, exclude_global, topn,
                              h->d_block_lists, h->d_half_seed, q8_seeds, h->d_half_rescored, none, no_next,
-                             static_cast<const float*>(nullptr), no_tail);
+                             no_cutoff, no_tail, epoch);
             } else {
                 LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, false, false>),
                              dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
                              h->d_feats, h->d_q8, h->n, h->qg.iters, h->row_base, qa, kNoQueryPtr, exclude_global, topn,
                              h->d_block_lists, h->d_half_seed, q8_seeds, h->d_half_rescored, none, no_next,
-                             static_cast<const float*>(nullptr), no_tail);
+                             no_cutoff, no_tail, epoch);
             }
             HIP_TRY(h, hipGetLastError());
             return MI355REC_OK;
         }
         *n_lists = h->hg.grid;
-        enqueue_half_seed(h, false, qptr, qa, exclude_global, h->d_half_seed, s);
+        uint32_t* const half_seed = reinterpret_cast<uint32_t*>(h->d_half_seed);   // (the fp16 scan's plain sample values)
+        enqueue_half_seed(h, false, qptr, qa, exclude_global, h->d_half_seed, 0u, s);
         if (qptr) {
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, true, false>),
                          dim3(h->hg.grid), dim3(HalfConfig::kBlock), s,
                          h->d_feats, h->d_half, h->n, h->hg.iters, h->row_base, qa, qptr, exclude_global, topn,
-                         h->d_block_lists, h->d_half_seed, h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next);
+                         h->d_block_lists, half_seed, h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next);
         } else {
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, false, false>),
                          dim3(h->hg.grid), dim3(HalfConfig::kBlock), s,
                          h->d_feats, h->d_half, h->n, h->hg.iters, h->row_base, qa, kNoQueryPtr, exclude_global,
-                         topn, h->d_block_lists, h->d_half_seed, h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next);
+                         topn, h->d_block_lists, half_seed, h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, none, no_next);
         }
         HIP_TRY(h, hipGetLastError());
         return MI355REC_OK;
@@ -870,18 +904,20 @@ int enqueue_half_multi(mi355rec* h, const float* queries, const float* const* qp
     for (int g0 = 0; g0 < count; g0 += kHmQueries) {
         const int nq = count - g0 < kHmQueries ? count - g0 : kHmQueries;
         fill_half_multi_arg(arg, h->margin_mfma, queries, qptrs, exclude, g0, nq);
+        const uint32_t epoch = next_epoch(h);
+        const unsigned long long* const no_cuts = nullptr;
         hipLaunchKernelGGL(seed_half_multi_kernel, dim3(h->hg.seed_grid), dim3(kHmBlock), 0, s, h->d_half, h->n, h->hg.seed_stride,
-                           arg, nq, h->d_half_mseed);
+                           arg, nq, h->d_half_mseed, epoch);
         ++h->half_scans;
         if (multi_front_q8(h, nq)) {   // rows from the 8-bit replica through the integer matrix core (replica_multi.hip.h)
             ++h->q8_scans;
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<false, true>), dim3(h->hg.grid),
                          dim3(kHmBlock), s, h->d_feats, h->d_half, reinterpret_cast<const uint32_t*>(h->d_q8), h->n, h->row_base, arg, nq,
-                         g0, topn, h->d_block_lists, h->d_half_mseed, n_seed, h->d_half_rescored, no_ride, arg, static_cast<const float*>(nullptr));
+                         g0, topn, h->d_block_lists, h->d_half_mseed, n_seed, h->d_half_rescored, no_ride, arg, no_cuts, epoch);
         } else {
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<false, false>), dim3(h->hg.grid),
                          dim3(kHmBlock), s, h->d_feats, h->d_half, static_cast<const uint32_t*>(nullptr), h->n, h->row_base, arg, nq,
-                         g0, topn, h->d_block_lists, h->d_half_mseed, n_seed, h->d_half_rescored, no_ride, arg, static_cast<const float*>(nullptr));
+                         g0, topn, h->d_block_lists, h->d_half_mseed, n_seed, h->d_half_rescored, no_ride, arg, no_cuts, epoch);
         }
     }
     HIP_TRY(h, hipGetLastError());
@@ -904,13 +940,14 @@ constexpr int kHmRiders = 16;   // seed riders of a streamed launch: 16 regions 
 int ensure_mstream(mi355rec* h) {
     if (h->mstream_ready) return MI355REC_OK;
     const size_t list_bytes = sizeof(uint64_t) * static_cast<size_t>(kHmQueries) * h->hg.grid * kMultiMaxTopK;
-    const size_t seed_bytes = sizeof(uint32_t) * static_cast<size_t>(kHmQueries) * kHalfSeedMaxGrid * kHalfSeedWaves;
+    const size_t seed_bytes = sizeof(unsigned long long) * static_cast<size_t>(kHmQueries) * kHalfSeedMaxGrid * kHalfSeedWaves;
     hipError_t e = hipSuccess;
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
         e = hipMalloc(&h->d_mstream_lists[i], list_bytes);
         if (e == hipSuccess) e = hipMalloc(&h->d_mstream_seed[i], seed_bytes);
     }
-    if (e == hipSuccess) e = hipMalloc(&h->d_mstream_cuts, sizeof(float) * 2 * kHmQueries);
+    if (e == hipSuccess) e = hipMalloc(&h->d_mstream_cuts, sizeof(unsigned long long) * 2 * kHmQueries);
+    if (e == hipSuccess) e = hipMemsetAsync(h->d_mstream_cuts, 0, sizeof(unsigned long long) * 2 * kHmQueries, h->stream);
     if (e == hipSuccess) e = hipMalloc(&h->d_mstream_ctl, sizeof(SeedCtl) * 2);
     if (e == hipSuccess) e = hipMemsetAsync(h->d_mstream_ctl, 0, sizeof(SeedCtl) * 2, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -928,13 +965,14 @@ int ensure_mstream(mi355rec* h) {
         return fail(h, e == hipErrorOutOfMemory ? MI355REC_ERR_OUT_OF_MEMORY : MI355REC_ERR_HIP, "hipMalloc(batch stream): %s",
                     hipGetErrorString(e));
     }
+    h->mctl_done[0] = h->mctl_done[1] = 0u;
     h->mstream_ready = true;
     return MI355REC_OK;
 }
 
 // Launches the stashed batch: scanners + the mergers of the batch before it + (next != null) the seed
 // riders of the batch after it.
-int launch_mstash(mi355rec* h, hipStream_t s, const HalfMultiArg* next, int next_nq, int next_topn, int next_buf) {
+int launch_mstash(mi355rec* h, hipStream_t s, const HalfMultiArg* next, int next_nq, int next_topn, int next_buf, uint32_t next_epoch_tag) {
     auto& st = h->mstash;
     const int buf = h->mpending.has ? 1 - h->mpending.buf : 0;
     HmRide ride;
@@ -955,8 +993,15 @@ int launch_mstash(mi355rec* h, hipStream_t s, const HalfMultiArg* next, int next
         ride.next_ctl = h->d_mstream_ctl + next_buf;
         ride.next_cuts = h->d_mstream_cuts + next_buf * kHmQueries;
         ride.next_topk = next_topn;
+        ride.next_epoch = next_epoch_tag;
+        // the riders' arrival counter counts up and is never reset: this launch's riders start from ...
+        ride.done_base = h->mctl_done[next_buf] + (h->dbg_no_last ? 0x40000000u : 0u);
+        h->mctl_done[next_buf] += static_cast<unsigned>(ride.seed_wgs);
+        ride.debug_skip = h->dbg_skip_regions;
+        h->dbg_no_last = false;
+        h->dbg_skip_regions = 0;
     }
-    const float* cuts_ready = st.cuts_ready ? h->d_mstream_cuts + st.seed_buf * kHmQueries : nullptr;
+    const unsigned long long* cuts_ready = st.cuts_ready ? h->d_mstream_cuts + st.seed_buf * kHmQueries : nullptr;
     // the launch stays within one resident wave of workgroups: the riders and mergers take scanner slots
     int scanners = h->hg.grid - ride.prev_queries - ride.seed_wgs;
     if (scanners < 1) scanners = 1;
@@ -967,13 +1012,13 @@ int launch_mstash(mi355rec* h, hipStream_t s, const HalfMultiArg* next, int next
                      dim3(scanners + ride.prev_queries + ride.seed_wgs), dim3(kHmBlock), s, h->d_feats, h->d_half,
                      reinterpret_cast<const uint32_t*>(h->d_q8), h->n, h->row_base,
                      st.arg, st.nq, 0, st.topn, h->d_mstream_lists[buf], h->d_mstream_seed[st.seed_buf],
-                     h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, ride, next ? *next : st.arg, cuts_ready);
+                     h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, ride, next ? *next : st.arg, cuts_ready, st.epoch);
     } else {
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<true, false>),
                      dim3(scanners + ride.prev_queries + ride.seed_wgs), dim3(kHmBlock), s, h->d_feats, h->d_half,
                      static_cast<const uint32_t*>(nullptr), h->n, h->row_base,
                      st.arg, st.nq, 0, st.topn, h->d_mstream_lists[buf], h->d_mstream_seed[st.seed_buf],
-                     h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, ride, next ? *next : st.arg, cuts_ready);
+                     h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, ride, next ? *next : st.arg, cuts_ready, st.epoch);
     }
     HIP_TRY(h, hipGetLastError());
     h->mpending.has = true;
@@ -988,7 +1033,7 @@ int launch_mstash(mi355rec* h, hipStream_t s, const HalfMultiArg* next, int next
 
 int flush_mstream(mi355rec* h, hipStream_t s) {
     if (h->mstash.has) {
-        const int rc = launch_mstash(h, s, nullptr, 0, 0, 0);
+        const int rc = launch_mstash(h, s, nullptr, 0, 0, 0, 0u);
         if (rc) return rc;
     }
     if (!h->mpending.has) return MI355REC_OK;
@@ -1012,14 +1057,15 @@ int enqueue_mstream(mi355rec* h, const float* queries, const float* const* qptrs
     fill_half_multi_arg(arg, h->margin_mfma, queries, qptrs, exclude, g0, nq);
     int seed_buf = 0;
     bool cuts_ready = false;
+    const uint32_t epoch = next_epoch(h);   // the tag of this batch's sample values and cutoffs
     if (h->mstash.has) {
         seed_buf = 1 - h->mstash.seed_buf;
-        rc = launch_mstash(h, s, &arg, nq, topn, seed_buf);   // its riders take THIS batch's sample (and select its cutoffs)
+        rc = launch_mstash(h, s, &arg, nq, topn, seed_buf, epoch);   // its riders take THIS batch's sample (and select its cutoffs)
         if (rc) return rc;
         cuts_ready = h->hg.seed_grid > 0;   // (launch_mstash gave the launch seed riders)
     } else {   // the head of a stream: a sample launch of its own
         hipLaunchKernelGGL(seed_half_multi_kernel, dim3(h->hg.seed_grid), dim3(kHmBlock), 0, s, h->d_half, h->n, h->hg.seed_stride,
-                           arg, nq, h->d_mstream_seed[seed_buf]);
+                           arg, nq, h->d_mstream_seed[seed_buf], epoch);
         HIP_TRY(h, hipGetLastError());
     }
     auto& st = h->mstash;
@@ -1029,6 +1075,7 @@ int enqueue_mstream(mi355rec* h, const float* queries, const float* const* qptrs
     st.topn = topn;
     st.out = out_keys;
     st.seed_buf = seed_buf;
+    st.epoch = epoch;
     st.cuts_ready = cuts_ready;
     return MI355REC_OK;
 }
@@ -1061,7 +1108,7 @@ int enqueue_query(mi355rec* h, const float* qptr, const float* query12, int64_t 
         const uint64_t* upper = done ? out_keys + done - 1 : nullptr;
         int lists = 0;
         // a notifying query (single round, its caller polls the completion word): scan, merge and the word in ONE launch
-        LoneTail lone{h->d_lone_ctr, out_keys, out_idx, out_score, h->hd_done, notify};
+        LoneTail lone{h->d_lone_ctr, out_keys, out_idx, out_score, h->hd_done, notify, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}};   // (bases: enqueue_scan)
         bool fused = false;
         int rc = enqueue_scan(h, qptr, query12, exclude_global, k, upper, s, &lists, (notify && h->d_lone_ctr) ? &lone : nullptr, &fused);
         if (rc) return rc;
@@ -1134,11 +1181,11 @@ int ensure_streamed_alloc(mi355rec* h) {
 }
 
 int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, const float* next_ptr, const float* next_q,
-                   int64_t next_exclude, int next_topn, int next_buf);
+                   int64_t next_exclude, int next_topn, int next_buf, uint32_t next_epoch_tag);
 
 int flush_streamed(mi355rec* h, hipStream_t s) {
     if (h->stashed.has) {
-        const int rc = launch_stashed(h, s, false, nullptr, nullptr, -1, 0, 0);
+        const int rc = launch_stashed(h, s, false, nullptr, nullptr, -1, 0, 0, 0u);
         if (rc) return rc;
     }
     if (!h->pending) return MI355REC_OK;
@@ -1150,7 +1197,7 @@ int flush_streamed(mi355rec* h, hipStream_t s) {
 // Launches the stashed streamed query over the replica: scanners + the riding merger of the query
 // before it + (with_next) the seed riders of the query after it.
 int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, const float* next_ptr, const float* next_q,
-                   int64_t next_exclude, int next_topn, int next_buf) {
+                   int64_t next_exclude, int next_topn, int next_buf, uint32_t next_epoch_tag) {
     auto& st = h->stashed;
     const int buf = h->pending ? 1 - h->pending_buf : 0;
     PrevMerge prev{nullptr, 0, 0, nullptr};
@@ -1172,6 +1219,14 @@ int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, const float* next
         next.ctl = (st.q8 && q8_hoists(h)) ? h->d_stream_ctl + next_buf : nullptr;
         next.topk = next_topn;
         next.exact = st.q8 && q8_exact_sample(h);
+        next.epoch = next_epoch_tag;
+        if (next.ctl) {   // the riders' arrival counter counts up and is never reset: this launch's riders start from ...
+            next.done_base = h->ctl_done[next_buf] + (h->dbg_no_last ? 0x40000000u : 0u);
+            h->ctl_done[next_buf] += static_cast<unsigned>(g.riders);
+        }
+        next.debug_skip = h->dbg_skip_regions;
+        h->dbg_no_last = false;
+        h->dbg_skip_regions = 0;
         scanners = g.r_scan;
         iters = g.r_iters;
     }
@@ -1182,33 +1237,33 @@ int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, const float* next
     ++h->half_scans;
     if (st.q8) {
         ++h->q8_scans;
-        const float* ready = st.cutoff_ready ? &h->d_stream_ctl[st.seed_buf].cutoff : nullptr;
+        const unsigned long long* ready = st.cutoff_ready ? &h->d_stream_ctl[st.seed_buf].cutoff : nullptr;
         const int q8_seeds = q8_exact_sample(h) ? -n_seed : n_seed;   // (negative: exact values)
         if (st.qptr) {
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, true, true>),
                          dim3(scanners + 1 + next.n_wgs), dim3(Q8Config::kBlock), s,
                          h->d_feats, h->d_q8, h->n, iters, h->row_base, qa, st.qptr, st.exclude, st.topn,
                          h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], q8_seeds, h->d_half_rescored, prev, next, ready,
-                         LoneTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0u});
+                         LoneTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}}, st.epoch);
         } else {
             std::memcpy(qa.q, st.q, sizeof qa.q);
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, false, true>),
                          dim3(scanners + 1 + next.n_wgs), dim3(Q8Config::kBlock), s,
                          h->d_feats, h->d_q8, h->n, iters, h->row_base, qa, kNoQueryPtr, st.exclude, st.topn,
                          h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], q8_seeds, h->d_half_rescored, prev, next, ready,
-                         LoneTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0u});
+                         LoneTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}}, st.epoch);
         }
     } else if (st.qptr) {
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, true, true>),
                      dim3(scanners + 1 + next.n_wgs), dim3(HalfConfig::kBlock), s,
                      h->d_feats, h->d_half, h->n, iters, h->row_base, qa, st.qptr, st.exclude, st.topn,
-                     h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], n_seed, h->d_half_rescored, prev, next);
+                     h->d_stream_lists[buf], reinterpret_cast<uint32_t*>(h->d_stream_seed[st.seed_buf]), n_seed, h->d_half_rescored, prev, next);
     } else {
         std::memcpy(qa.q, st.q, sizeof qa.q);
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, false, true>),
                      dim3(scanners + 1 + next.n_wgs), dim3(HalfConfig::kBlock), s,
                      h->d_feats, h->d_half, h->n, iters, h->row_base, qa, kNoQueryPtr, st.exclude, st.topn,
-                     h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], n_seed, h->d_half_rescored, prev, next);
+                     h->d_stream_lists[buf], reinterpret_cast<uint32_t*>(h->d_stream_seed[st.seed_buf]), n_seed, h->d_half_rescored, prev, next);
     }
     HIP_TRY(h, hipGetLastError());
     h->pending = true;
@@ -1244,17 +1299,18 @@ int enqueue_streamed(mi355rec* h, const float* qptr, const float* query12, int64
         int seed_buf = 0;
         bool sampled = false;
         const bool q8 = use_q8(h);
+        const uint32_t epoch = next_epoch(h);   // the tag of this query's sample values and cutoff
         if (h->stashed.has) {
             seed_buf = 1 - h->stashed.seed_buf;
             // the riders of a launch sample the replica that launch scans: a change of replica
             // (mi355rec_set_replica) between two calls costs the next query a seed launch of its own
             sampled = h->stashed.q8 == q8 && (q8 ? h->qg.riders : h->hg.riders) > 0;
-            rc = launch_stashed(h, s, sampled, qptr, query12, exclude_global, topn, seed_buf);
+            rc = launch_stashed(h, s, sampled, qptr, query12, exclude_global, topn, seed_buf, epoch);
             if (rc) return rc;
         }
         if (!sampled && (q8 ? h->qg.seed_grid : h->hg.seed_grid) > 0) {   // first query of a stream, or a shard too small to spare riders
             if (!qptr) std::memcpy(qa.q, query12, sizeof qa.q);
-            enqueue_half_seed(h, q8, qptr, qa, exclude_global, h->d_stream_seed[seed_buf], s);
+            enqueue_half_seed(h, q8, qptr, qa, exclude_global, h->d_stream_seed[seed_buf], epoch, s);
             HIP_TRY(h, hipGetLastError());
         }
         auto& st = h->stashed;
@@ -1265,12 +1321,13 @@ int enqueue_streamed(mi355rec* h, const float* qptr, const float* query12, int64
         st.topn = topn;
         st.out = out_keys;
         st.seed_buf = seed_buf;
+        st.epoch = epoch;
         st.q8 = q8;
         st.cutoff_ready = q8 && sampled && q8_hoists(h);
         return MI355REC_OK;
     }
     if (h->stashed.has) {   // the path changed under a stream (mi355rec_set_replica): the stashed query goes first
-        rc = launch_stashed(h, s, false, nullptr, nullptr, -1, 0, 0);
+        rc = launch_stashed(h, s, false, nullptr, nullptr, -1, 0, 0, 0u);
         if (rc) return rc;
     }
     // The fp32 scan's riding merger keeps 2048 survivors; with ~770 lists and topN near 1000 about
@@ -1936,6 +1993,46 @@ int mi355rec_set_replica(mi355rec_t* h, int mode) {
         if (rc) return rc;
     }
     h->replica_mode = mode;
+    return MI355REC_OK;
+}
+
+// Test hook for the hand-offs that must fail safe (replica.hip.h): see include/mi355rec.h.
+int mi355rec_debug_handoff(mi355rec_t* h, int flags) {
+    if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    DeviceGuard guard(h->device);
+    if (flags & MI355REC_DEBUG_HANDOFF_POISON) {
+        HIP_TRY(h, hipDeviceSynchronize());
+        // what a reader would find if the stores it depends on had not landed: the values of EARLIER queries (the
+        // buffers alternate), here the most hostile ones — a perfect score under each of the last three epochs
+        const uint32_t one = score_to_ordered(1.0f);
+        const size_t per = static_cast<size_t>(kHalfSeedMaxGrid) * kHalfSeedWaves;
+        std::vector<unsigned long long> vals(per * kHmQueries);
+        for (size_t i = 0; i < vals.size(); ++i)
+            vals[i] = (static_cast<unsigned long long>(h->epoch_ctr - 1u - static_cast<uint32_t>(i % 3)) << 32) | one;
+        unsigned long long* single[] = {h->d_half_seed, h->d_stream_seed[0], h->d_stream_seed[1]};
+        for (unsigned long long* b : single)
+            if (b) HIP_TRY(h, hipMemcpy(b, vals.data(), sizeof(unsigned long long) * per, hipMemcpyHostToDevice));
+        unsigned long long* multi[] = {h->d_half_mseed, h->d_mstream_seed[0], h->d_mstream_seed[1]};
+        for (unsigned long long* b : multi)
+            if (b) HIP_TRY(h, hipMemcpy(b, vals.data(), sizeof(unsigned long long) * vals.size(), hipMemcpyHostToDevice));
+        // ... and a cutoff of +1.0 (it would rule out every row) under the epoch before the current one
+        unsigned int one_bits;
+        const float onef = 1.0f;
+        std::memcpy(&one_bits, &onef, sizeof one_bits);
+        const unsigned long long stale_cut = (static_cast<unsigned long long>(h->epoch_ctr - 1u) << 32) | one_bits;
+        if (h->d_stream_ctl) {
+            SeedCtl ctl[2];
+            HIP_TRY(h, hipMemcpy(ctl, h->d_stream_ctl, sizeof ctl, hipMemcpyDeviceToHost));
+            ctl[0].cutoff = ctl[1].cutoff = stale_cut;   // (the arrival counters stay what they are)
+            HIP_TRY(h, hipMemcpy(h->d_stream_ctl, ctl, sizeof ctl, hipMemcpyHostToDevice));
+        }
+        if (h->d_mstream_cuts) {
+            std::vector<unsigned long long> cuts(2 * kHmQueries, stale_cut);
+            HIP_TRY(h, hipMemcpy(h->d_mstream_cuts, cuts.data(), sizeof(unsigned long long) * cuts.size(), hipMemcpyHostToDevice));
+        }
+    }
+    if (flags & MI355REC_DEBUG_HANDOFF_DROP_STORES) h->dbg_skip_regions = kHalfSeedMaxGrid / 2;
+    if (flags & MI355REC_DEBUG_HANDOFF_NO_LAST_RIDER) h->dbg_no_last = true;
     return MI355REC_OK;
 }
 

@@ -215,16 +215,44 @@ __global__ __launch_bounds__(kHalfSeedBlock) void seed_half_kernel(
 // merger come next.n_wgs "seed riders").  They are resident from the start like everybody else — the
 // host launches that many scanners fewer — and each walks its share of the regions, four loads in
 // flight at a time.
+// HAND-OFFS THAT FAIL SAFE.  Two kinds of values cross workgroups outside the stream order of launches: the sample
+// values the seed riders of a launch leave for the rider that finishes last (same launch), and the cutoff that rider
+// leaves for the scanners of the next launch.  Both decide which rows a scan may skip, so a reader that picked up a
+// value of an EARLIER query (the buffers alternate) could place the cutoff above the true N-th score: a silently
+// wrong top-N.  Every such value therefore carries the EPOCH of the query it belongs to in its upper word, written
+// with the value by one 64-bit store; a reader that finds another epoch treats the value as absent — fewer sample
+// values, or no launch-wide cutoff at all, both of which only LOWER the cutoff (slower, never wrong).  The riders'
+// arrival counter counts up across launches and is never reset: the host tells each launch the count it starts
+// from, so a missed or repeated reset cannot make a rider believe it is the last one.
+// (tests/test_gpu_replica.py poisons the buffers and drops stores through mi355rec_debug_handoff to check this.)
+__device__ __forceinline__ unsigned long long tag_value(uint32_t epoch, uint32_t v) {
+    return (static_cast<unsigned long long>(epoch) << 32) | v;
+}
+__device__ __forceinline__ uint32_t untag_value(unsigned long long t, uint32_t epoch) {   // 0 = absent
+    return static_cast<uint32_t>(t >> 32) == epoch ? static_cast<uint32_t>(t) : 0u;
+}
+// A cutoff left by the riders of the launch before: the float's bits under its epoch; -inf (no launch-wide cutoff:
+// the workgroup-local thresholds take over) when the epoch is not the reader's.
+__device__ __forceinline__ float untag_cutoff(unsigned long long t, uint32_t epoch) {
+    return static_cast<uint32_t>(t >> 32) == epoch ? __uint_as_float(static_cast<uint32_t>(t)) : -__builtin_inff();
+}
+// Every wave's write-through stores have reached device scope before the workgroup counts itself out.  (A
+// workgroup-scope release fence does NOT wait for global stores on this target: the ISA showed
+// `s_waitcnt lgkmcnt(0); s_barrier` between the sc1 stores and the counter atomic.)
+__device__ __forceinline__ void wait_own_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 struct SeedCtl {
-    unsigned done;    // riders that have stored their maxima (reset by the last one)
-    float cutoff;     // the next launch's launch-wide cutoff (-inf: none)
+    unsigned done;               // riders that have stored their sample, counted up across launches, never reset
+    unsigned pad;
+    unsigned long long cutoff;   // tag_value(epoch, bits of the next launch's launch-wide cutoff)
 };
 
 struct NextSeed {
     float q[kDim];             // the next query (used when query_ptr is null)
     const float* query_ptr;    // ... or where its 12 floats live (a resident row, possibly of another shard)
     long long exclude_global;
-    uint32_t* out;             // its sample maxima
+    void* out;                 // its sample maxima: uint32_t[] (fp16 replica: read by the NEXT launch only) or
+                               // epoch-tagged unsigned long long[] (8-bit replica: read by the last rider of this launch)
     int n_wgs;                 // seed riders in this launch (0 = none)
     int regions;
     long long stride_rows;
@@ -233,6 +261,9 @@ struct NextSeed {
     SeedCtl* ctl;
     int topk;                  // of the next query
     int exact;                 // sample values are exact scores of the waves' best rows (one margin) or their approximate ones (two)
+    uint32_t epoch;            // of the next query: the tag of its sample values and of its cutoff
+    uint32_t done_base;        // ctl->done before this launch's riders arrive
+    int debug_skip;            // test hook (0 in the product): the riders do NOT store regions below this one
 };
 
 __device__ __forceinline__ void seed_rider(const float* __restrict__ feats, const uint4* __restrict__ half, int64_t n,
@@ -258,7 +289,8 @@ __device__ __forceinline__ void seed_rider(const float* __restrict__ feats, cons
 #pragma unroll
         for (int u = 0; u < kAhead; ++u) {
             const int g = g0 + u * next.n_wgs;
-            if (g < next.regions) seed_region_finish(s[u], hq, n, row_base, next.exclude_global, next.out, g);   // uniform
+            if (g < next.regions)   // uniform
+                seed_region_finish(s[u], hq, n, row_base, next.exclude_global, static_cast<uint32_t*>(next.out), g);
         }
     }
 }

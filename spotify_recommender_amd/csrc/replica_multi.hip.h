@@ -83,11 +83,17 @@ __host__ __device__ inline void hm_set_pointer(HalfMultiArg& arg, int i, const f
 
 __device__ __forceinline__ void hm_load_query(const HalfMultiArg& arg, int i, float (&q)[kDim]) {
     if ((arg.ptr_mask >> i) & 1u) {
-        union { const float* p; float f[2]; } u;
-        u.f[0] = arg.q[i][0];
-        u.f[1] = arg.q[i][1];
+        // The pointer's two words, put together in registers (a union here became an 8-byte stack slot that the
+        // backend never touched but still reserved: every dispatch of the kernel then set up scratch), and read
+        // through an explicitly GLOBAL pointer: with a generic one the compiler folds the two branches into one
+        // load through a phi of addresses, which forces the whole 1800-byte argument into scratch.
+        typedef const float __attribute__((address_space(1))) * global_floats;
+        const float lo = arg.q[i][0], hi = arg.q[i][1];
+        const uint64_t bits = static_cast<uint64_t>(__builtin_bit_cast(uint32_t, lo)) |
+                              (static_cast<uint64_t>(__builtin_bit_cast(uint32_t, hi)) << 32);
+        global_floats p = reinterpret_cast<global_floats>(bits);
 #pragma unroll
-        for (int j = 0; j < kDim; ++j) q[j] = u.p[j];
+        for (int j = 0; j < kDim; ++j) q[j] = p[j];
     } else {
 #pragma unroll
         for (int j = 0; j < kDim; ++j) q[j] = arg.q[i][j];
@@ -171,7 +177,7 @@ __device__ __forceinline__ int hm_tile_max(const bq_f16v& d) {   // max over the
 // excluded one.  Workgroup `first`, `first + every`, ... of the regions; called by all 512 threads.
 __device__ __forceinline__ void hm_sample_regions(const uint4* __restrict__ half, int64_t n, int64_t stride_rows, int regions,
                                                   int first, int every, const uint4* bfrag, int n_queries,
-                                                  uint32_t* __restrict__ seed_vals) {
+                                                  unsigned long long* __restrict__ seed_vals, uint32_t epoch, int debug_skip = 0) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t n_pairs = (n + 1) >> 1;
@@ -204,23 +210,24 @@ __device__ __forceinline__ void hm_sample_regions(const uint4* __restrict__ half
         m = max(m, __shfl_xor(m, 32));   // lanes c and 32 + c hold the two row halves of query c
         // a positive float's bits are a positive int; its ordered image sets the top bit
         const uint32_t v = m > 0 ? (static_cast<uint32_t>(m) | 0x80000000u) : 0u;
-        // written THROUGH to device scope: the last seed rider of the same launch may read it (hoisted cutoffs)
-        if (lane < n_queries)
-            __hip_atomic_store(&seed_vals[lane * per_query + static_cast<int64_t>(g) * kHalfSeedWaves + wave], v, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+        // written THROUGH to device scope, under the batch's epoch: the last seed rider of the same launch may read it
+        // (hoisted cutoffs; replica.hip.h, "hand-offs that fail safe")
+        if (lane < n_queries && g >= debug_skip)
+            __hip_atomic_store(&seed_vals[lane * per_query + static_cast<int64_t>(g) * kHalfSeedWaves + wave], tag_value(epoch, v),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 __global__ __launch_bounds__(kHmBlock) void seed_half_multi_kernel(
     const uint4* __restrict__ half, int64_t n, int64_t stride_rows, HalfMultiArg arg, int n_queries,
-    uint32_t* __restrict__ seed_vals /* [query][gridDim.x * kHalfSeedWaves] */) {
+    unsigned long long* __restrict__ seed_vals /* [query][gridDim.x * kHalfSeedWaves], tagged with `epoch` */, uint32_t epoch) {
     __shared__ uint4 s_b[64];
     if (threadIdx.x < kHmQueries) {
         float q[kDim], qn;
         hm_build_fragment(arg, n_queries, threadIdx.x, 0u, s_b, q, qn);
     }
     __syncthreads();
-    hm_sample_regions(half, n, stride_rows, gridDim.x, blockIdx.x, gridDim.x, s_b, n_queries, seed_vals);
+    hm_sample_regions(half, n, stride_rows, gridDim.x, blockIdx.x, gridDim.x, s_b, n_queries, seed_vals, epoch);
 }
 
 // ---- shared memory of one scanning workgroup ---------------------------------------------------------
@@ -302,26 +309,34 @@ __device__ __forceinline__ void hm_build_fragment8(HalfMultiSmem& sm, int c, boo
 }
 
 // The launch-wide cutoff of one query from its sample maxima, by one wave (see the header).
+// Values under another epoch than the reader's count as absent (replica.hip.h, "hand-offs that fail safe").
 template <bool kSameLaunch = false>   // the values were written by other workgroups of THIS launch: read past the L2
-__device__ __forceinline__ float hm_seed_cutoff(const uint32_t* vals, int n_seed, int topk, float margin) {
+__device__ __forceinline__ float hm_seed_cutoff(const unsigned long long* vals, int n_seed, int topk, float margin, uint32_t epoch) {
     const int lane = threadIdx.x & 63;
-    // all of the lane's (up to 32) sample maxima are requested before the first is looked at
+    // the lane's (up to 32) sample maxima, sixteen requests in flight at a time; each goes straight into the lane's
+    // four largest (an insertion network per value)
     constexpr int kPer = kHalfSeedMaxGrid * kHalfSeedWaves / 64;
-    uint32_t mine[kPer];
+    constexpr int kBurst = kPer < 16 ? kPer : 16;
+    static_assert(kPer % kBurst == 0, "whole bursts");
+    uint32_t m1 = 0u, m2 = 0u, m3 = 0u, m4 = 0u;
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        const int i = lane + 64 * j;
-        mine[j] = 0u;
-        if (i < n_seed) mine[j] = kSameLaunch ? __hip_atomic_load(&vals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : vals[i];
-    }
-    uint32_t m1 = 0u, m2 = 0u, m3 = 0u, m4 = 0u;   // the lane's four largest (an insertion network per value)
+    for (int j0 = 0; j0 < kPer; j0 += kBurst) {
+        // Unconditional loads (a conditional load per element made the compiler carry the burst as one 1024-bit
+        // register tuple and spill it); what lies past n_seed is masked below.  In bounds because every sample
+        // buffer is allocated for kHmQueries x kHalfSeedMaxGrid x kHalfSeedWaves entries whatever n_seed is.
+        const unsigned long long* const p = vals + lane + 64 * j0;
+        unsigned long long t[kBurst];
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        uint32_t v = mine[j], t;
-        t = v < m1 ? v : m1; m1 = v > m1 ? v : m1; v = t;
-        t = v < m2 ? v : m2; m2 = v > m2 ? v : m2; v = t;
-        t = v < m3 ? v : m3; m3 = v > m3 ? v : m3; v = t;
-        m4 = v > m4 ? v : m4;
+        for (int j = 0; j < kBurst; ++j)
+            t[j] = kSameLaunch ? __hip_atomic_load(&p[64 * j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p[64 * j];
+#pragma unroll
+        for (int j = 0; j < kBurst; ++j) {
+            uint32_t v = lane + 64 * (j0 + j) < n_seed ? untag_value(t[j], epoch) : 0u, w;
+            w = v < m1 ? v : m1; m1 = v > m1 ? v : m1; v = w;
+            w = v < m2 ? v : m2; m2 = v > m2 ? v : m2; v = w;
+            w = v < m3 ? v : m3; m3 = v > m3 ? v : m3; v = w;
+            m4 = v > m4 ? v : m4;
+        }
     }
     // the largest v with |{values >= v}| >= topk, by bisection (uniform: ballots and scalar counts)
     uint32_t lo = 0u, hi = 0xffffffffu;
@@ -494,13 +509,16 @@ struct HmRide {
     int next_queries;
     int regions;
     long long stride_rows;
-    uint32_t* next_seed_vals;     // [next_queries][regions * 8]
+    unsigned long long* next_seed_vals;   // [next_queries][regions * 8], tagged with next_epoch
     // the seed rider that finishes LAST turns the sample into the next batch's cutoffs (replica_q8.hip.h's hand-off:
     // write-through stores, a counter, L2-bypassing loads — no fence under the scanners), so that the next launch's
     // scanners start with one load instead of a selection per query (2.5 us per round of eight queries)
     SeedCtl* next_ctl;            // null: the next launch selects its cutoffs itself
-    float* next_cuts;             // [kHmQueries]
+    unsigned long long* next_cuts;   // [kHmQueries]: tag_value(next_epoch, bits of the cutoff)
     int next_topk;
+    uint32_t next_epoch;          // of the next batch: the tag of its sample values and of its cutoffs
+    uint32_t done_base;           // next_ctl->done before this launch's riders arrive (counted up, never reset)
+    int debug_skip;               // test hook (0 in the product): the riders do NOT store regions below this one
 };
 
 template <bool kRide>
@@ -518,9 +536,10 @@ template <bool kRide, bool kQ8 = false>
 __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
     const float* __restrict__ feats, const uint4* __restrict__ half, const uint32_t* __restrict__ q8, int64_t n, int64_t row_base,
     HalfMultiArg arg, int n_queries,
-    int slot0, int topk, uint64_t* __restrict__ block_lists, const uint32_t* __restrict__ seed_vals,
+    int slot0, int topk, uint64_t* __restrict__ block_lists, const unsigned long long* __restrict__ seed_vals /* tagged with `epoch` */,
     int n_seed /* sample maxima per query, 0 = none */, unsigned long long* __restrict__ rescored /* [workgroups] */,
-    HmRide ride, HalfMultiArg next, const float* __restrict__ cuts_ready /* [n_queries] left by the launch before, or null */) {
+    HmRide ride, HalfMultiArg next, const unsigned long long* __restrict__ cuts_ready /* [n_queries] tagged cutoffs left by the launch before, or null */,
+    uint32_t epoch /* of this batch */) {
     __shared__ typename std::conditional<kRide, HmSmemU<true>, HalfMultiSmem>::type s_mem;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -546,24 +565,23 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
                 }
                 __syncthreads();
                 hm_sample_regions(half, n, ride.stride_rows, ride.regions, extra - ride.prev_queries, ride.seed_wgs, fb,
-                                  ride.next_queries, ride.next_seed_vals);
+                                  ride.next_queries, ride.next_seed_vals, ride.next_epoch, ride.debug_skip);
                 if (ride.next_ctl) {   // uniform: last rider out selects the next batch's cutoffs
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's sample stores have completed
+                    wait_own_stores();   // this wave's write-through sample stores have completed
                     __syncthreads();
                     if (tid == 0)
-                        s_mem.scan.rescored = __hip_atomic_fetch_add(&ride.next_ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-                                              static_cast<unsigned>(ride.seed_wgs) - 1u;
+                        s_mem.scan.rescored = __hip_atomic_fetch_add(&ride.next_ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u ==
+                                              ride.done_base + static_cast<unsigned>(ride.seed_wgs);
                     __syncthreads();
                     if (s_mem.scan.rescored) {   // uniform
                         const int n_next = ride.regions * kHalfSeedWaves;
                         for (int qi = wave; qi < ride.next_queries; qi += kHmWaves) {
                             // (a query the bound cannot be claimed for keeps "every row is a candidate")
                             const float cut = s_mem.scan.ok[qi] ? hm_seed_cutoff<true>(ride.next_seed_vals + static_cast<int64_t>(qi) * n_next,
-                                                                                      n_next, ride.next_topk + 1, next.margin)
+                                                                                      n_next, ride.next_topk + 1, next.margin, ride.next_epoch)
                                                                 : -__builtin_inff();
-                            if (lane == 0) ride.next_cuts[qi] = cut;
+                            if (lane == 0) ride.next_cuts[qi] = tag_value(ride.next_epoch, __float_as_uint(cut));
                         }
-                        if (tid == 0) ride.next_ctl->done = 0u;
                     }
                 }
             }
@@ -639,7 +657,7 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
     __syncthreads();
     if (cuts_ready) {   // uniform: the last seed rider of the launch before this one selected them
         if (tid < n_queries && sm.ok[tid]) {
-            const float cut = cuts_ready[tid];
+            const float cut = untag_cutoff(cuts_ready[tid], epoch);   // another epoch: no launch-wide cutoff for this query
             sm.cut[tid] = cut;
             reinterpret_cast<uint32_t*>(&sm.bfrag[32 + tid])[2] = hm_threshold_slots(cut);
             if constexpr (kQ8) reinterpret_cast<uint32_t*>(&sm.bfrag8[tid])[3] = hm_q8_slots(cut + arg.margin + kBqSlack - sm.m8[tid]);
@@ -648,7 +666,7 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
         for (int qi = wave; qi < n_queries; qi += kHmWaves) {
             if (sm.ok[qi]) {   // uniform
                 // the (topk + 1)-th largest: the query's own row may be among the sampled ones (hm_sample_regions)
-                const float cut = hm_seed_cutoff(seed_vals + static_cast<int64_t>(qi) * n_seed, n_seed, topk + 1, arg.margin);
+                const float cut = hm_seed_cutoff(seed_vals + static_cast<int64_t>(qi) * n_seed, n_seed, topk + 1, arg.margin, epoch);
                 if (lane == 0) {
                     sm.cut[qi] = cut;
                     reinterpret_cast<uint32_t*>(&sm.bfrag[32 + qi])[2] = hm_threshold_slots(cut);

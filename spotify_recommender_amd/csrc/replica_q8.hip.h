@@ -194,15 +194,17 @@ __device__ __forceinline__ Q8Pick q8_region_pick(const Q8Region& s, const Q8Quer
 
 template <bool kExact>
 __device__ __forceinline__ void q8_region_store(const Q8Pick& p, const Row& row, const float (&q)[kDim], float qn,
-                                                uint32_t* __restrict__ seed_vals, int64_t g) {
+                                                unsigned long long* __restrict__ seed_vals, uint32_t epoch, int64_t g) {
     uint32_t v = p.top;
     if constexpr (kExact) {
         const float exact = cosine_score(q, qn, row);
         v = p.any ? score_to_ordered(exact) : 0u;
     }
-    // written THROUGH to device scope: a rider of the same launch may read it (scan_q8_kernel, last rider out)
+    // written THROUGH to device scope, under the query's epoch: a rider of the same launch may read it
+    // (scan_q8_kernel, last rider out; replica.hip.h, "hand-offs that fail safe")
     if ((threadIdx.x & 63) == 0)
-        __hip_atomic_store(&seed_vals[g * kHalfSeedWaves + (threadIdx.x >> 6)], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&seed_vals[g * kHalfSeedWaves + (threadIdx.x >> 6)], tag_value(epoch, v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ void q8_load_query(const float* __restrict__ query_ptr, const float (&by_value)[kDim], float (&q)[kDim]) {
@@ -219,7 +221,7 @@ __device__ __forceinline__ void q8_load_query(const float* __restrict__ query_pt
 template <bool kQueryFromRow, bool kExact>
 __global__ __launch_bounds__(kHalfSeedBlock) void seed_q8_kernel(
     const float* __restrict__ feats, const uint4* __restrict__ q8, int64_t n, int64_t stride_rows, int64_t row_base, QueryArg qarg,
-    const float* __restrict__ query_ptr, int64_t exclude_global, uint32_t* __restrict__ seed_vals) {
+    const float* __restrict__ query_ptr, int64_t exclude_global, unsigned long long* __restrict__ seed_vals, uint32_t epoch) {
     float q[kDim];
     q8_load_query(kQueryFromRow ? query_ptr : nullptr, qarg.q, q);
     const float qn = query_norm(q);
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(kHalfSeedBlock) void seed_q8_kernel(
     Row row;
     row.a = row.b = row.c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if constexpr (kExact) row = load_row(feats, p.row);
-    q8_region_store<kExact>(p, row, q, qn, seed_vals, blockIdx.x);
+    q8_region_store<kExact>(p, row, q, qn, seed_vals, epoch, blockIdx.x);
 }
 
 // The seed riders of a streamed launch (replica.hip.h, seed_rider): four regions per memory round trip.
@@ -240,6 +242,7 @@ __device__ __forceinline__ Q8Query q8_seed_rider(const float* __restrict__ feats
     const float qn = query_norm(q);
     const Q8Query hq = q8_query(q, qn);
     const int64_t n_quads = (n + 3) >> 2;
+    unsigned long long* const out = static_cast<unsigned long long*>(next.out);
     constexpr int kAhead = 4;
     for (int g0 = rider; g0 < next.regions; g0 += kAhead * next.n_wgs) {
         Q8Region s[kAhead];
@@ -258,7 +261,7 @@ __device__ __forceinline__ Q8Query q8_seed_rider(const float* __restrict__ feats
 #pragma unroll
             for (int u = 0; u < kAhead; ++u) {
                 const int g = g0 + u * next.n_wgs;
-                if (g < next.regions) q8_region_store<true>(pick[u], best[u], q, qn, next.out, g);   // uniform
+                if (g < next.regions && g >= next.debug_skip) q8_region_store<true>(pick[u], best[u], q, qn, out, next.epoch, g);   // uniform
             }
         } else {
             Row none;
@@ -266,7 +269,7 @@ __device__ __forceinline__ Q8Query q8_seed_rider(const float* __restrict__ feats
 #pragma unroll
             for (int u = 0; u < kAhead; ++u) {
                 const int g = g0 + u * next.n_wgs;
-                if (g < next.regions) q8_region_store<false>(pick[u], none, q, qn, next.out, g);   // uniform
+                if (g < next.regions && g >= next.debug_skip) q8_region_store<false>(pick[u], none, q, qn, out, next.epoch, g);   // uniform
             }
         }
     }
@@ -278,16 +281,20 @@ __device__ __forceinline__ Q8Query q8_seed_rider(const float* __restrict__ feats
 struct Q8Sample {
     uint32_t v[kHalfSeedPerThread];   // this thread's share of the sample values (0 = empty)
 };
+// Values under another epoch than the reader's count as absent (replica.hip.h, "hand-offs that fail safe").
 template <int kBlock, bool kSameLaunch = false>
-__device__ __forceinline__ Q8Sample q8_load_sample(const uint32_t* seed_vals, int n_seed) {
+__device__ __forceinline__ Q8Sample q8_load_sample(const unsigned long long* seed_vals, int n_seed, uint32_t epoch) {
     Q8Sample s;
+    unsigned long long t[kHalfSeedPerThread];
 #pragma unroll
     for (int r = 0; r < kHalfSeedPerThread; ++r) {
         const int i = static_cast<int>(threadIdx.x) + r * kBlock;
-        s.v[r] = 0u;
+        t[r] = 0ull;
         if (i < n_seed)   // kSameLaunch: written by other workgroups of THIS launch
-            s.v[r] = kSameLaunch ? __hip_atomic_load(&seed_vals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : seed_vals[i];
+            t[r] = kSameLaunch ? __hip_atomic_load(&seed_vals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : seed_vals[i];
     }
+#pragma unroll
+    for (int r = 0; r < kHalfSeedPerThread; ++r) s.v[r] = untag_value(t[r], epoch);
     return s;
 }
 
@@ -358,10 +365,10 @@ template <typename Cfg, bool kQueryFromRow, bool kWithMerge, bool kLoneTail = fa
 __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
     const float* __restrict__ feats, const uint4* __restrict__ q8, int64_t n, int iters, int64_t row_base,
     QueryArg qarg, const float* __restrict__ query_ptr, int64_t exclude_global, int topk, uint64_t* __restrict__ block_lists,
-    const uint32_t* __restrict__ seed_vals, int n_seed /* negative: |n_seed| EXACT sample values */,
+    const unsigned long long* __restrict__ seed_vals /* tagged with `epoch` */, int n_seed /* negative: |n_seed| EXACT sample values */,
     unsigned long long* __restrict__ rescored /* [scanning workgroups] */,
-    PrevMerge prev, NextSeed next, const float* __restrict__ cutoff_ready /* null: select from seed_vals here */,
-    LoneTail lone) {
+    PrevMerge prev, NextSeed next, const unsigned long long* __restrict__ cutoff_ready /* tagged; null: select from seed_vals here */,
+    LoneTail lone, uint32_t epoch /* of this query */) {
     constexpr int kBlock = Cfg::kBlock;
     static_assert(!(kWithMerge && kLoneTail), "a streamed query's merge rides in the next launch");
     __shared__ typename std::conditional<kWithMerge || kLoneTail, HalfScanOrMergeSmem<Cfg>, HalfScanSmemT<Cfg>>::type s_mem;
@@ -383,25 +390,24 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
                 // Last rider out turns the sample into the cutoff.  No device-wide fence: on this part a release /
                 // acquire pair at agent scope writes back and invalidates the whole L2 under the scanners (measured:
                 // the launch took 43 us instead of 28).  Instead the maxima are stored and loaded as device-scope
-                // atomics (write-through stores, L2-bypassing loads); each wave waits for its stores to complete
-                // (workgroup-scope release = s_waitcnt), one thread counts, and the last workgroup's loads are issued
-                // after its counter value came back.
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                // atomics (write-through stores, L2-bypassing loads); each wave waits for ITS stores to complete
+                // (s_waitcnt vmcnt(0): a workgroup-scope fence does not), one thread counts, and the last
+                // workgroup's loads are issued after its counter value came back.  Values and cutoff carry the next
+                // query's epoch and the counter is never reset (replica.hip.h, "hand-offs that fail safe").
+                wait_own_stores();
                 __syncthreads();
                 if (threadIdx.x == 0) {
                     s_mem.scan.seeds = 0;
-                    s_mem.scan.count = next.ctl && __hip_atomic_fetch_add(&next.ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-                                                       static_cast<unsigned>(next.n_wgs) - 1u;
+                    s_mem.scan.count = next.ctl && __hip_atomic_fetch_add(&next.ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u ==
+                                                       next.done_base + static_cast<unsigned>(next.n_wgs);
                 }
                 __syncthreads();
                 if (s_mem.scan.count) {   // uniform
-                    const Q8Sample all = q8_load_sample<kBlock, true>(next.out, next.regions * kHalfSeedWaves);
+                    const Q8Sample all = q8_load_sample<kBlock, true>(static_cast<const unsigned long long*>(next.out),
+                                                                      next.regions * kHalfSeedWaves, next.epoch);
                     const float c = q8_cutoff_from_sample<kBlock>(all, next.regions * kHalfSeedWaves, next.topk, next.exact != 0, nq,
                                                                   &s_mem.scan.seeds, s_mem.scan.sel);
-                    if (threadIdx.x == 0) {
-                        next.ctl->cutoff = c;
-                        next.ctl->done = 0u;
-                    }
+                    if (threadIdx.x == 0) next.ctl->cutoff = tag_value(next.epoch, __float_as_uint(c));
                 }
             }
             __syncthreads();
@@ -450,10 +456,10 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
 #pragma unroll
     for (int r = 0; r < kHalfSeedPerThread; ++r) sample.v[r] = 0u;
     const int n_sample = n_seed < 0 ? -n_seed : n_seed;
-    if (cutoff_ready) {   // uniform: the riders of the launch before this one left it
-        cutoff_left = *cutoff_ready;
+    if (cutoff_ready) {   // uniform: the riders of the launch before this one left it (under this query's epoch, or it does not count)
+        cutoff_left = untag_cutoff(*cutoff_ready, epoch);
     } else {              // ... or this workgroup selects it from the sample values itself: asked for now, used after the query
-        sample = q8_load_sample<kBlock>(seed_vals, n_sample);
+        sample = q8_load_sample<kBlock>(seed_vals, n_sample, epoch);
     }
     float q[kDim];
     q8_load_query(kQueryFromRow ? query_ptr : nullptr, qarg.q, q);

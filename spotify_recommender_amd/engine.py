@@ -221,6 +221,10 @@ class CosineEngine:
         capi.check(self._lib.mi355rec_replica_counters(self._h, ctypes.byref(scans), ctypes.byref(rows)), self._h)
         return {"scans": int(scans.value), "rescored_rows": int(rows.value)}
 
+    def debug_handoff(self, flags: int) -> None:
+        """Test hook (capi.DEBUG_HANDOFF_*): poison / drop the cross-workgroup hand-offs of the streamed scans."""
+        capi.check(self._lib.mi355rec_debug_handoff(self._h, int(flags)), self._h)
+
     def rebuild_replica(self) -> None:
         """After overwriting a borrowed catalogue in place (synchronous)."""
         capi.check(self._lib.mi355rec_rebuild_replica(self._h), self._h)

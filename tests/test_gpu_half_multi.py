@@ -333,3 +333,48 @@ def test_a_stream_of_batches(Engine, torch_cuda):
             want = oracle.scores(small, small[r], threads=0)
             idx, sc = unpack_keys(got[b])
             assert_topn_matches(idx, sc, want, r, 10, ref_idx=oracle.topn_heap(want, r, 10))
+
+
+def test_stream_of_batches_fails_safe_under_stale_hand_offs(Engine, torch_cuda):
+    """The multi-query stream's hand-offs (seed riders -> last rider -> the next launch's cutoffs) under
+    mi355rec_debug_handoff: stale samples of earlier batches (a perfect score under the last epochs), cutoffs of
+    +1.0, dropped stores, launches without a last rider.  Wrong-epoch values count as absent, so every key list must
+    still be the one the plain (not streamed) path returns.  (tests/test_gpu_replica.py has the single-query twin.)"""
+    from spotify_recommender_amd import capi
+    torch = torch_cuda
+    rng = np.random.default_rng(99)
+    n = 1_500_000
+    f = rng.random((n, 12), dtype=np.float32)
+    P, D, L = capi.DEBUG_HANDOFF_POISON, capi.DEBUG_HANDOFF_DROP_STORES, capi.DEBUG_HANDOFF_NO_LAST_RIDER
+    hooks = {2: P, 4: D, 6: L, 8: P | D, 10: P | L, 12: P | D | L, 13: P, 14: P | D | L}
+    topn = 50
+    with Engine(f) as eng:
+        eng.set_batch_path(HALF)
+        batches = [rng.integers(0, n, size=int(b)) for b in rng.choice([2, 12, 12, 32], size=18)]
+        want = []
+        for qrows in batches:       # the reference: each batch alone, not streamed
+            keys = torch.zeros(len(qrows) * topn, dtype=torch.int64, device="cuda")
+            eng.enqueue_batch_keys(f[qrows], qrows.astype(np.int64), topn, keys)
+            want.append(keys)
+        torch.cuda.synchronize()
+        got = []
+        for step, qrows in enumerate(batches):
+            if step in hooks:
+                eng.debug_handoff(hooks[step])
+            keys = torch.zeros(len(qrows) * topn, dtype=torch.int64, device="cuda")
+            eng.enqueue_batch_keys_streamed(f[qrows], qrows.astype(np.int64), topn, keys)
+            got.append(keys)
+            if step == 9:
+                eng.enqueue_flush()
+        eng.debug_handoff(P)
+        eng.enqueue_flush()
+        torch.cuda.synchronize()
+        bad = [i for i in range(len(batches)) if not torch.equal(want[i], got[i])]
+        assert not bad, bad
+        # and against the oracle for one batch that ran right behind a poisoned, last-rider-less launch
+        check = got[13].cpu().numpy().reshape(len(batches[13]), topn)
+        from spotify_recommender_amd.engine import unpack_keys
+        for b, r in enumerate(batches[13][:4]):
+            s = oracle.scores(f, f[r], threads=0)
+            idx, sc = unpack_keys(check[b])
+            assert_topn_matches(idx, sc, s, int(r), topn, ref_idx=oracle.topn_heap(s, int(r), topn))

@@ -1,0 +1,36 @@
+"""What the gfx950 code objects INSIDE the built library say about its kernels (no GPU needed: the AMDGPU
+metadata notes of the artefact that ships are read with llvm-readelf, spotify_recommender_amd/build.py).
+
+VERDICT r3 item 3(b): no kernel may reserve private (scratch) memory.  scan_half_multi_kernel did — a dead
+16 / 24-byte stack slot from a pointer reassembled through a union — and every one of its dispatches set up
+scratch for it."""
+import pytest
+
+from spotify_recommender_amd import build
+
+
+@pytest.fixture(scope="module")
+def kernels(engine_lib):
+    return build.kernel_metadata(build.LIB_ENGINE)
+
+
+def test_no_kernel_reserves_scratch(kernels):
+    assert len(kernels) >= 60
+    bad = [(k["scratch"], k["name"]) for k in kernels if k["scratch"] != 0]
+    assert not bad, bad
+    assert build.check_no_scratch(build.LIB_ENGINE) == len(kernels)
+
+
+def test_hot_kernels_keep_their_occupancy(kernels):
+    """Registers and LDS decide how many workgroups a CU holds; the launch geometry of the host code assumes
+    these (a silent change of either would halve a kernel's resident waves)."""
+    def of(fragment):
+        hits = [k for k in kernels if fragment in k["name"]]
+        assert hits, fragment
+        return hits
+    for k in of("scan_q8_kernel") + of("scan_half_kernel") + of("scan_half_multi_kernel"):
+        assert k["vgpr"] <= 128 and k["lds"] <= 80 * 1024, k          # 512 threads, two workgroups per CU
+    for k in of("11scan_kernelINS_7ScanCfg"):
+        assert k["vgpr"] <= 80, k                                        # three workgroups of 512 per CU
+    for k in of("bq_pass_kernel"):
+        assert k["vgpr"] <= 128 and k["lds"] <= 40 * 1024, k          # four workgroups of 256 per CU

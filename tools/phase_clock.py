@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Where a streamed single-query launch over the 8-bit replica spends its time.  Needs a library built
-with -DMI355REC_PHASE_CLOCK (tools/phase_clock.sh does that, runs this, and rebuilds the product library):
+with -DMI355REC_PHASE_CLOCK, passed with --lib (tools/phase_clock.sh builds it under gpurun_out/, never over the
+product's libmi355rec.so):
 every workgroup stamps a 100 MHz wall clock at entry (0), query ready (1), launch-wide cutoff ready (2),
 tiles done (3), list stored (4); the merger and the seed riders stamp entry (0) and exit (5).
 Printed: per phase, the median and the latest workgroup relative to the first workgroup's entry, for the
@@ -20,12 +21,14 @@ def main():
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--topn", type=int, default=10)
     ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--lib", required=True, help="the instrumented library (tools/phase_clock.sh builds it)")
     args = ap.parse_args()
     import numpy as np
     import torch
     from spotify_recommender_amd import CosineEngine, capi
     from spotify_recommender_amd.synth import synthetic_catalogue
 
+    capi.LIB_PATH = Path(args.lib).resolve()   # before the first capi.lib(): this process only
     lib = capi.lib()
     fn = lib.mi355rec_debug_phase_clock
     fn.restype = ctypes.c_int
