@@ -315,6 +315,8 @@ int mi355rec_enqueue_batch_keys_dev(mi355rec_t* h, const float* queries_dev,
 #define MI355REC_BATCH_Q8 4     /* the same passes with rows from the 8-bit replica (integer matrix core, candidates re-checked
                                    against their fp16 rows): half the bytes, but 3.7 us per query of a pass instead of 0.85 —
                                    AUTO takes it for passes of one or two queries only */
+#define MI355REC_BATCH_MFMA_NOSKIP 5   /* MFMA, but pass 2 looks at every (tile, query block) pair instead of skipping those the
+                                   maxima pass 1 left behind rule out (csrc/batched.hip.h, kTileMax): A/B measurements, tests */
 int mi355rec_set_batch_path(mi355rec_t* h, int path);
 
 /* Diagnostics of the LAST chunk (<= 1024 queries) the batched path served on

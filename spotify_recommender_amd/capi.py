@@ -15,7 +15,7 @@ LIB_PATH = PKG / "libmi355rec.so"
 
 DIM = 12
 MAX_TOPN_FAST = 1024
-BATCH_AUTO, BATCH_MULTI, BATCH_MFMA, BATCH_HALF, BATCH_Q8 = 0, 1, 2, 3, 4
+BATCH_AUTO, BATCH_MULTI, BATCH_MFMA, BATCH_HALF, BATCH_Q8, BATCH_MFMA_NOSKIP = 0, 1, 2, 3, 4, 5
 REPLICA_AUTO, REPLICA_OFF, REPLICA_ON, REPLICA_FP16 = 0, 1, 2, 3
 TRANSPORT_PEER, TRANSPORT_RCCL = 1, 2
 DEBUG_HANDOFF_POISON, DEBUG_HANDOFF_DROP_STORES, DEBUG_HANDOFF_NO_LAST_RIDER = 1, 2, 4

@@ -211,26 +211,59 @@ struct BqPassCfg {
 // packed: `half`, replica.hip.h) instead of the fp32 matrix — half the bytes and none of the
 // per-row norm / scale / convert work; the bound is the same because the replica is built
 // with this kernel's own arithmetic.
-template <int NB, bool kCollect, int kVariant = 0, bool kFromReplica = false>
+// kTileMax (NB >= 16, rows from the replica): PASS 2 SKIPS WHAT PASS 1 HAS ALREADY RULED OUT.  Pass 1 looks at every
+// tile_step-th tile; for those tiles it now also stores, per lane and query block, the maximum approx over the
+// lane's 32 rows of the tile (its two MFMA sub-tiles), rounded UP to fp16: tile_max[visited tile][block pair][lane],
+// 4 KiB per visited 64-row tile at NB = 32.  Once the thresholds are known, a (tile, query block) pair can hold a
+// candidate only if some lane's maximum reaches its query's T' (rounded DOWN to fp16): pass 2 compares the 64 x NB
+// stored maxima of a visited tile with the thresholds (one packed 16-bit subtraction per two blocks) and runs the two
+// MFMAs and their hit test only for the blocks that pass — about one in eight at top-100 (0.13 candidates per pair).
+// Valid because the margin covers ANY summation order of the 16-term sum: a row of the true top-N has approx >= T'
+// + kBqSlack in pass 1's sum as in pass 2's.  Pass 2 deals its tiles so that every wave meets visited and
+// unvisited tiles alike (k-th tile of wave w: k * waves + (w + k) mod waves).
+template <int NB, bool kCollect, int kVariant = 0, bool kFromReplica = false, bool kTileMax = false>
 __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu) void bq_pass_kernel(
     const float* __restrict__ feats, int64_t n, int64_t n_tiles, int tile_step, const uint32_t* __restrict__ bfrag,
     float* __restrict__ gmax /* [NB][8][2 * grid][4] */, int* __restrict__ cand_count,
     uint32_t* __restrict__ cand_rows /* [query][kBqCap] */, int* __restrict__ counters,
-    uint32_t* __restrict__ special_rows, const uint2* __restrict__ half = nullptr) {
+    uint32_t* __restrict__ special_rows, const uint2* __restrict__ half = nullptr,
+    uint4* __restrict__ tile_max = nullptr /* [visited tile][NB / 8][64] */, int max_step = 1 /* pass 2: pass 1's tile_step */,
+    const float* __restrict__ qthr = nullptr, const uint32_t* __restrict__ qflags = nullptr) {
+    static_assert(!kTileMax || (NB >= 16 && kFromReplica && kVariant == 0), "tile maxima: replica rows, 16 or 32 query blocks");
     // n_tiles counts 64-row tiles.  tile_step = 1: every tile.  tile_step > 1 (pass 1 only):
     // every tile_step-th tile — a threshold derived from ANY subset of the rows is a valid
     // lower bound; from a quarter of them it lets about four times as many candidates
     // through and costs a quarter of a pass.
-    __shared__ uint4 s_b[NB][64];   // reused for the group maxima at the end of pass 1
-    __shared__ uint2 s_stage[kCollect ? kBqPassBlock / 64 : 1][kCollect ? kBqStage : 1];   // (query, row) per wave
-    uint2* const stage = s_stage[kCollect ? (threadIdx.x >> 6) : 0];
+    // Pass 2 sits exactly at four workgroups per CU (40 KiB of the CU's 160): with tile maxima the staging buffers are
+    // halved to make room for the thresholds' table and for one DUMMY fragment (block NB: threshold slots -65504,
+    // nothing ever passes) that pads a tile's list of blocks to an even count.
+    constexpr int kStageCap = (kCollect && kTileMax) ? kBqStage / 2 : kBqStage;
+    __shared__ uint4 s_b[NB + ((kCollect && kTileMax) ? 1 : 0)][64];   // reused for the group maxima at the end of pass 1
+    __shared__ uint2 s_stage[kCollect ? kBqPassBlock / 64 : 1][kCollect ? kStageCap : 1];   // (query, row) per wave
+    // (known to the compiler as wave-uniform: the tile index and everything derived from it stay in scalar registers)
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    uint2* const stage = s_stage[kCollect ? wave : 0];
     int staged = 0;   // wave-uniform
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
     const int r = lane & 31;
     const int h = lane >> 5;
 
     for (int i = threadIdx.x; i < NB * 64; i += kBqPassBlock) (&s_b[0][0])[i] = reinterpret_cast<const uint4*>(bfrag)[i];
+    // pass 2 with tile maxima: the thresholds as packed fp16 pairs in the maxima's layout — dword d of query column c
+    // holds T' of query c of blocks 2d and 2d + 1, rounded DOWN; +inf for a query that is not served here (queued /
+    // padding: its threshold slots hold -65504 and nothing ever passes)
+    __shared__ uint32_t s_tq[(kCollect && kTileMax) ? NB / 2 : 1][(kCollect && kTileMax) ? 32 : 1];
+    if constexpr (kCollect && kTileMax) {
+        for (int i = threadIdx.x; i < NB / 2 * 32; i += kBqPassBlock) {
+            const int d = i >> 5, c = i & 31;
+            const int q0 = (2 * d) * 32 + c, q1 = q0 + 32;
+            const float t0 = qflags[q0] == kBqFlagOk ? qthr[q0] : __builtin_inff();
+            const float t1 = qflags[q1] == kBqFlagOk ? qthr[q1] : __builtin_inff();
+            s_tq[d][c] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(t0, t1));   // T' > 0: toward zero = down
+        }
+        if (threadIdx.x < 64)   // the dummy block: no query, -65504 in the threshold slot of every column
+            s_b[NB][threadIdx.x] = make_uint4(0u, 0u, threadIdx.x >= 32 ? bq_pack_h2(-65504.0f, 0.0f) : 0u, 0u);
+    }
     __syncthreads();
 
     int mx[kCollect ? 1 : NB];   // running group maxima (bit patterns of floats >= 0)
@@ -282,7 +315,31 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
         load_row3(first, na, nb, nc);
     }
     int slot = 0;   // wave-uniform: position of `tile` in its group of kPre
-    for (int64_t tile = first; tile < n_tiles; tile += total_waves) {
+    // Which tile comes k rounds after `tile`.  Classic: a fixed stride.  Pass 2 with tile maxima: the wave's position
+    // inside a round moves on by one per round, so that its tiles cycle through the residues mod max_step (with a
+    // fixed stride — a multiple of 4 — a quarter of the waves would own ALL visited tiles and finish early).
+    constexpr bool kRotate = kCollect && kTileMax;
+    int64_t rot_base = 0, rot_pos = first;   // (tile_step == 1 in pass 2)
+    auto next_tile = [&](int64_t t) -> int64_t {
+        if constexpr (kRotate) {
+            const int64_t p = rot_pos + 1 == total_waves ? 0 : rot_pos + 1;
+            return rot_base + total_waves + p;
+        } else {
+            return t + total_waves;
+        }
+    };
+    // (the rotated deal ends with the ROUND: a wave whose tile of the last round lies past the end skips it)
+    for (int64_t tile = first; kRotate ? rot_base < n_tiles : tile < n_tiles; ) {
+        const int64_t after = next_tile(tile);
+        if constexpr (kRotate) {
+            if (tile >= n_tiles) {   // wave-uniform; the prefetched rows (clamped) are simply dropped
+                load_half3(after, pre[0][0], pre[0][1], pre[0][2]);
+                rot_base += total_waves;
+                rot_pos = rot_pos + 1 == total_waves ? 0 : rot_pos + 1;
+                tile = after;
+                continue;
+            }
+        }
         const int64_t row = tile * 64 + lane;
         const bool in_range = row < n;
         uint32_t p0, p1, p2, p3, p4, p5;
@@ -308,7 +365,7 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
                 x = pre[0][0];
                 y = pre[0][1];
                 z = pre[0][2];
-                load_half3(tile + total_waves, pre[0][0], pre[0][1], pre[0][2]);
+                load_half3(after, pre[0][0], pre[0][1], pre[0][2]);
             }
             const bool special = in_range && x.x == kBqNaN2;   // tiny / huge / inf / NaN row: exact chain only
             if constexpr (kCollect) {
@@ -401,6 +458,11 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
             bw[0] = s_b[0][lane];
             if (NB > 1) bw[1] = s_b[1][lane];
             D[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw[0]), zero, 0, 0, 0);
+            // tile maxima: [visited tile][NB / 8][lane] uint4, dword d of a lane = blocks 2d (low half) and 2d + 1
+            // (tile_step is a power of two and divides `tile`)
+            uint4* const tm_out = kTileMax ? tile_max + (tile >> (31 - __builtin_clz(tile_step))) * (NB / 8) * 64 + lane : nullptr;
+            int tu0 = 0, tu1 = 0, t_even = 0;   // first sub-tile's partial maxima; the even block's tile maximum
+            uint32_t tw[4];                     // four finished dwords = eight blocks = one 16-byte store per lane
 #pragma unroll
             for (int m = 0; m < 2 * NB; ++m) {
                 const int blk = m >> 1, sub = m & 1;
@@ -411,7 +473,26 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
                 if (sub == 1 && blk + 2 < NB) bw[blk & 1] = s_b[blk + 2][lane];
                 int u0, u1;
                 tree(D[m & 1], u0, u1);
-                mx[blk] = max3(mx[blk], u0, u1);   // the 8th operation folds the running maximum in
+                if constexpr (!kTileMax) {
+                    mx[blk] = max3(mx[blk], u0, u1);   // the 8th operation folds the running maximum in
+                } else if (sub == 0) {
+                    tu0 = u0;
+                    tu1 = u1;
+                } else {
+                    // this lane's maximum over its 32 rows of the tile for query (blk, r), clamped at 0 (bit patterns
+                    // as signed integers: negative floats are negative)
+                    const int t = max3(max3(tu0, tu1, u0), u1, 0);
+                    mx[blk] = max(mx[blk], t);
+                    if ((blk & 1) == 0) {
+                        t_even = t;
+                    } else {
+                        // two blocks per dword, rounded UP: toward zero (= down, the values are >= 0), then one ulp more
+                        const uint32_t packed = __builtin_bit_cast(
+                            uint32_t, __builtin_amdgcn_cvt_pkrtz(__int_as_float(t_even), __int_as_float(t)));
+                        tw[(blk >> 1) & 3] = packed + 0x00010001u;
+                        if ((blk & 7) == 7) tm_out[(blk >> 3) * 64] = make_uint4(tw[0], tw[1], tw[2], tw[3]);
+                    }
+                }
             }
         } else {
             // pass 2.  Hits go to the wave's LDS staging buffer (ballot + prefix count, no atomics); the
@@ -426,7 +507,7 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
                     const uint64_t who = __ballot(hit);
                     if (who) {   // wave-uniform
                         const int n_hit = __popcll(who);
-                        if (staged + n_hit > kBqStage) {
+                        if (staged + n_hit > kStageCap) {
                             bq_flush_stage(stage, staged, lane, cand_count, cand_rows);
                             staged = 0;
                         }
@@ -467,6 +548,64 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
                 const bq_f16v D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);
                 const bq_f16v D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);
                 check2(D0, D1, 0);
+            } else if constexpr (kTileMax) {
+                // which query blocks of this tile can hold a candidate at all (bit b = block b): every block of a
+                // tile pass 1 did not look at; of a visited tile, the blocks in which some lane's stored maximum
+                // reaches its query's threshold
+                uint32_t need = static_cast<uint32_t>((1ull << NB) - 1ull);
+                if ((tile & (max_step - 1)) == 0) {   // wave-uniform; max_step is a power of two
+                    const uint4* tm = tile_max + (tile >> (31 - __builtin_clz(max_step))) * (NB / 8) * 64 + lane;
+                    // (the thresholds are loop-invariant: without this the compiler keeps all NB / 2 of them in
+                    // registers across the tile loop and the kernel loses a wave per SIMD)
+                    asm volatile("" ::: "memory");
+                    uint4 mv[NB / 8];
+#pragma unroll
+                    for (int j = 0; j < NB / 8; ++j) mv[j] = tm[j * 64];
+                    need = 0u;
+#pragma unroll
+                    for (int d = 0; d < NB / 2; ++d) {
+                        const uint4 four = mv[d >> 2];
+                        const uint32_t mm = (d & 3) == 0 ? four.x : ((d & 3) == 1 ? four.y : ((d & 3) == 2 ? four.z : four.w));
+                        typedef short bq_s2 __attribute__((ext_vector_type(2)));
+                        // fp16 bit patterns of values >= 0 order like integers: maximum - threshold >= 0 per half
+                        const bq_s2 diff = __builtin_bit_cast(bq_s2, mm) - __builtin_bit_cast(bq_s2, s_tq[d][r]);
+                        if (__ballot(diff[0] >= 0)) need |= 1u << (2 * d);
+                        if (__ballot(diff[1] >= 0)) need |= 1u << (2 * d + 1);
+                    }
+                }
+                // The blocks in `need`, in pairs, exactly as the plain loop below runs through ALL blocks: while one
+                // block's two tiles are reduced and tested the next one's MFMAs run and the fragment of the one after
+                // that is on its way from LDS.  An odd count is padded with the dummy block, and the two fragments
+                // fetched past the end are the dummy's as well.
+                auto pop = [&]() -> int {   // wave-uniform: the next block to do
+                    if (!need) return NB;
+                    const int b = __builtin_ctz(need);
+                    need &= need - 1u;
+                    return b;
+                };
+                const int pairs = (__builtin_popcount(need) + 1) >> 1;
+                if (pairs) {   // wave-uniform
+                    int b0 = pop(), b1 = pop();
+                    uint4 bw0 = sb[b0 * 64], bw1 = sb[b1 * 64];
+                    bq_f16v D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);
+                    bq_f16v D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);
+                    bq_f16v D2, D3;
+#pragma unroll 1
+                    for (int i = 0; i < pairs; ++i) {
+                        D2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw1), zero, 0, 0, 0);
+                        D3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], __builtin_bit_cast(bq_h8, bw1), zero, 0, 0, 0);
+                        const int n0 = pop();
+                        bw0 = sb[n0 * 64];
+                        check2(D0, D1, b0);
+                        D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);
+                        D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);
+                        const int n1 = pop();
+                        bw1 = sb[n1 * 64];
+                        check2(D2, D3, b1);
+                        b0 = n0;
+                        b1 = n1;
+                    }
+                }
             } else {
                 static_assert(NB % 2 == 0, "blocks are processed in pairs");
                 uint4 bw0 = sb[0], bw1 = sb[64];
@@ -488,6 +627,11 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
                 }
             }
         }
+        if constexpr (kRotate) {
+            rot_base += total_waves;
+            rot_pos = rot_pos + 1 == total_waves ? 0 : rot_pos + 1;
+        }
+        tile = after;
     }
     if constexpr (kCollect) bq_flush_stage(stage, staged, lane, cand_count, cand_rows);
 

@@ -203,6 +203,11 @@ struct mi355rec {
         int* counters = nullptr;         // [4]
         uint32_t* special_rows = nullptr;
         float* gmax = nullptr;           // [grid][32][64]
+        // pass 1's per-lane maxima of the tiles it looked at, for pass 2 to skip what they rule out (batched.hip.h,
+        // kTileMax): [visited tile][4][64] uint4 = 4 KiB per visited 64-row tile, 16 B per catalogue row at step 4
+        uint4* tile_max = nullptr;
+        int64_t tile_max_tiles = 0;      // visited tiles it has room for
+                                         // (MI355REC_BATCH_MFMA_NOSKIP runs the passes without it: A/B, tests)
         int* queue = nullptr;            // [1024]
         uint64_t* qlists = nullptr;      // [1024][qgrid][kMultiMaxTopK]
         float* d_queries = nullptr;      // device copies of host queries / excludes (one chunk)
@@ -1376,6 +1381,15 @@ void free_bq(mi355rec* h);
 
 int ensure_bq_alloc(mi355rec* h);
 
+// Pass 1 looks at every step-th 64-row tile (a threshold from ANY subset of the rows is valid): 4 once each wave still
+// gets a couple of dozen tiles, less on small shards.  A power of two.
+int bq_step1(const mi355rec* h, int64_t n_tiles) {
+    const auto& b = h->bq;
+    int step1 = n_tiles >= static_cast<int64_t>(b.grid) * (kBqPassBlock / 64) * 16 ? b.step1 : 1;
+    while (step1 > 1 && n_tiles < static_cast<int64_t>(b.grid) * (kBqPassBlock / 64) * 8 * step1) step1 /= 2;
+    return step1;
+}
+
 // First batched call on a handle: allocate the path's scratch (all or nothing).
 int ensure_bq(mi355rec* h) {
     if (h->bq.ready) return MI355REC_OK;
@@ -1417,6 +1431,18 @@ int ensure_bq_alloc(mi355rec* h) {
     HIP_TRY(h, hipMalloc(&b.counters, sizeof(int) * 4));
     HIP_TRY(h, hipMalloc(&b.special_rows, sizeof(uint32_t) * kBqSpecialCap));
     HIP_TRY(h, hipMalloc(&b.gmax, sizeof(float) * static_cast<size_t>(grid) * kBqMaxBlocks * 64));
+    // Room for the tile maxima of pass 1 (rows from the replica only).  Optional: without it pass 2 looks at every
+    // (tile, query block) pair, as before.
+    if (h->d_half) {
+        const int64_t n_tiles = (h->n + 63) / 64;
+        const int64_t visited = (n_tiles + bq_step1(h, n_tiles) - 1) / bq_step1(h, n_tiles);
+        if (hipMalloc(&b.tile_max, sizeof(uint4) * static_cast<size_t>(visited) * (kBqMaxBlocks / 8) * 64) == hipSuccess) {
+            b.tile_max_tiles = visited;
+        } else {
+            (void)hipGetLastError();
+            b.tile_max = nullptr;
+        }
+    }
     HIP_TRY(h, hipMalloc(&b.queue, sizeof(int) * kBqMaxQueries));
     HIP_TRY(h, hipMalloc(&b.qlists, sizeof(uint64_t) * static_cast<size_t>(kBqMaxQueries) * b.qgrid * kMultiMaxTopK));
     HIP_TRY(h, hipMalloc(&b.d_queries, sizeof(float) * kBqMaxQueries * kDim));
@@ -1443,7 +1469,7 @@ int ensure_bq_alloc(mi355rec* h) {
 void free_bq(mi355rec* h) {
     auto& b = h->bq;
     void* dev[] = {b.bfrag, b.qnorm, b.qthr, b.qflags, b.cand_count, b.cand_rows, b.counters, b.special_rows,
-                   b.gmax, b.queue, b.qlists, b.d_queries, b.d_exclude};
+                   b.gmax, b.queue, b.qlists, b.d_queries, b.d_exclude, b.tile_max};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     for (int i = 0; i < mi355rec::Batched::kSlots; ++i) {
@@ -1454,24 +1480,24 @@ void free_bq(mi355rec* h) {
     b = mi355rec::Batched();
 }
 
-template <int NB, bool kFromReplica>
+template <int NB, bool kFromReplica, bool kTileMax>
 void launch_bq_passes(mi355rec* h, int topn, hipStream_t s) {
     auto& b = h->bq;
     const int64_t n_tiles = (h->n + 63) / 64;   // a wave handles 64 rows (two 32-row MFMA tiles) at a time
-    // pass 1 looks at every step1-th tile once each wave still gets a couple of dozen of them
-    int step1 = n_tiles >= static_cast<int64_t>(b.grid) * (kBqPassBlock / 64) * 16 ? b.step1 : 1;
-    while (step1 > 1 && n_tiles < static_cast<int64_t>(b.grid) * (kBqPassBlock / 64) * 8 * step1) step1 /= 2;
+    const int step1 = bq_step1(h, n_tiles);
     const size_t smem = sizeof(float) * b.grid * 2 * 5 + sizeof(int) * (kBqSelectBlock / 64) * 256;
     const uint2* half = reinterpret_cast<const uint2*>(h->d_half);
     int slot = timing_begin(h, h->ev_pass, h->n_pass_pairs, h->pass_launches, s);
-    hipLaunchKernelGGL((bq_pass_kernel<NB, false, 0, kFromReplica>), dim3(b.grid), dim3(kBqPassBlock), 0, s, h->d_feats, h->n,
-                       n_tiles, step1, b.bfrag, b.gmax, b.cand_count, b.cand_rows, b.counters, b.special_rows, half);
+    hipLaunchKernelGGL((bq_pass_kernel<NB, false, 0, kFromReplica, kTileMax>), dim3(b.grid), dim3(kBqPassBlock), 0, s, h->d_feats, h->n,
+                       n_tiles, step1, b.bfrag, b.gmax, b.cand_count, b.cand_rows, b.counters, b.special_rows, half,
+                       b.tile_max, step1, static_cast<const float*>(b.qthr), static_cast<const uint32_t*>(b.qflags));
     timing_end(h, h->ev_pass, h->n_pass_pairs, slot, s);
     hipLaunchKernelGGL(bq_select_kernel, dim3(NB * 8), dim3(kBqSelectBlock), smem, s, b.gmax, b.grid, NB, topn, b.margin, b.bfrag,
                        b.qflags, b.qthr);
     slot = timing_begin(h, h->ev_pass, h->n_pass_pairs, h->pass_launches, s);
-    hipLaunchKernelGGL((bq_pass_kernel<NB, true, 0, kFromReplica>), dim3(b.grid2), dim3(kBqPassBlock), 0, s, h->d_feats, h->n,
-                       n_tiles, 1, b.bfrag, b.gmax, b.cand_count, b.cand_rows, b.counters, b.special_rows, half);
+    hipLaunchKernelGGL((bq_pass_kernel<NB, true, 0, kFromReplica, kTileMax>), dim3(b.grid2), dim3(kBqPassBlock), 0, s, h->d_feats, h->n,
+                       n_tiles, 1, b.bfrag, b.gmax, b.cand_count, b.cand_rows, b.counters, b.special_rows, half,
+                       b.tile_max, step1, static_cast<const float*>(b.qthr), static_cast<const uint32_t*>(b.qflags));
     timing_end(h, h->ev_pass, h->n_pass_pairs, slot, s);
 }
 
@@ -1479,9 +1505,18 @@ template <int NB>
 void launch_bq_passes(mi355rec* h, int topn, hipStream_t s) {
     // the passes read the fp16 replica when the handle has one (it holds their A operand ready-made)
     if (h->d_half && h->replica_mode != MI355REC_REPLICA_OFF) {
-        launch_bq_passes<NB, true>(h, topn, s);
+        // 512 queries and more: pass 1 also leaves the maxima of the tiles it looked at, pass 2 skips what they rule out
+        if constexpr (NB >= 16) {
+            const int64_t n_tiles = (h->n + 63) / 64;
+            const int step1 = bq_step1(h, n_tiles);
+            if (h->batch_path != MI355REC_BATCH_MFMA_NOSKIP && h->bq.tile_max && (n_tiles + step1 - 1) / step1 <= h->bq.tile_max_tiles) {
+                launch_bq_passes<NB, true, true>(h, topn, s);
+                return;
+            }
+        }
+        launch_bq_passes<NB, true, false>(h, topn, s);
     } else {
-        launch_bq_passes<NB, false>(h, topn, s);
+        launch_bq_passes<NB, false, false>(h, topn, s);
     }
 }
 
@@ -1539,7 +1574,7 @@ int stage_queries(mi355rec* h, const float* queries, const int64_t* exclude, int
 bool use_bq(const mi355rec* h, int batch, int topn) {
     if (topn > kMultiMaxTopK || h->n < 1) return false;
     if (h->batch_path == MI355REC_BATCH_MULTI || h->batch_path == MI355REC_BATCH_HALF || h->batch_path == MI355REC_BATCH_Q8) return false;
-    if (h->batch_path == MI355REC_BATCH_MFMA) return true;
+    if (h->batch_path == MI355REC_BATCH_MFMA || h->batch_path == MI355REC_BATCH_MFMA_NOSKIP) return true;
     const bool replica = h->d_half && h->replica_mode != MI355REC_REPLICA_OFF;
     return batch >= (replica ? kBqMinBatchReplica : kBqMinBatch) && h->n >= kBqMinRows;
 }
@@ -1792,7 +1827,7 @@ int mi355rec_enqueue_batch_mixed_keys_streamed(mi355rec_t* h, const float* queri
     if (!h || !out_keys_dev || (!queries && !query_ptrs_dev)) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
     if (batch < 1) return fail(h, MI355REC_ERR_INVALID_ARG, "batch must be positive");
     const bool streamable = h->n >= kBqMinRows && half_multi_ok(h, topn) && h->batch_path != MI355REC_BATCH_MULTI &&
-                            h->batch_path != MI355REC_BATCH_MFMA;
+                            h->batch_path != MI355REC_BATCH_MFMA && h->batch_path != MI355REC_BATCH_MFMA_NOSKIP;
     if (!streamable) {
         // nothing to stream on: the batch is served at once (complete in stream order behind this call)
         if (query_ptrs_dev) return mi355rec_enqueue_batch_mixed_keys(h, queries, query_ptrs_dev, exclude_global, batch, topn, out_keys_dev, stream);
@@ -1975,7 +2010,7 @@ int mi355rec_batched_last_counters(mi355rec_t* h, int32_t* special_rows, int32_t
 int mi355rec_set_batch_path(mi355rec_t* h, int path) {
     if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
     if (path != MI355REC_BATCH_AUTO && path != MI355REC_BATCH_MULTI && path != MI355REC_BATCH_MFMA && path != MI355REC_BATCH_HALF &&
-        path != MI355REC_BATCH_Q8)
+        path != MI355REC_BATCH_Q8 && path != MI355REC_BATCH_MFMA_NOSKIP)
         return fail(h, MI355REC_ERR_INVALID_ARG, "unknown batch path %d", path);
     h->batch_path = path;
     return MI355REC_OK;

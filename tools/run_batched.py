@@ -20,11 +20,15 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--topn", type=int, default=100)
     ap.add_argument("--reps", type=int, default=10)
-    ap.add_argument("--path", type=int, default=0, help="0 auto, 1 multi-query passes, 2 batched MFMA")
+    ap.add_argument("--path", type=int, default=0, help="0 auto, 1 multi-query passes, 2 batched MFMA, 5 batched MFMA without tile skipping")
+    ap.add_argument("--lib", default=None, help="another build of the library (e.g. an MI355REC_EXPERIMENTS one under gpurun_out/)")
     ap.add_argument("--host-queries", action="store_true")
     args = ap.parse_args()
     import numpy as np
     import torch
+    if args.lib:
+        from spotify_recommender_amd import capi
+        capi.LIB_PATH = Path(args.lib).resolve()   # before the first capi.lib(): this process only
     from spotify_recommender_amd import CosineEngine
     from spotify_recommender_amd.synth import synthetic_catalogue
 
