@@ -315,6 +315,11 @@ int mi355rec_enqueue_batch_keys_dev(mi355rec_t* h, const float* queries_dev,
 #define MI355REC_BATCH_Q8 4     /* the same passes with rows from the 8-bit replica (integer matrix core, candidates re-checked
                                    against their fp16 rows): half the bytes, but 3.7 us per query of a pass instead of 0.85 —
                                    AUTO takes it for passes of one or two queries only */
+/* ... and how much of pass 2 the tile maxima of pass 1 saved in that chunk: the (64-row tile, 32-query block) pairs whose
+ * MFMAs pass 2 ran, out of all of them (equal when the chunk ran without tile maxima: fewer than 512 queries, no replica,
+ * MI355REC_BATCH_MFMA_NOSKIP).  Synchronises the device. */
+int mi355rec_batched_pass2_pairs(mi355rec_t* h, int64_t* pairs_done, int64_t* pairs_total);
+
 #define MI355REC_BATCH_MFMA_NOSKIP 5   /* MFMA, but pass 2 looks at every (tile, query block) pair instead of skipping those the
                                    maxima pass 1 left behind rule out (csrc/batched.hip.h, kTileMax): A/B measurements, tests */
 int mi355rec_set_batch_path(mi355rec_t* h, int path);
@@ -397,11 +402,38 @@ typedef struct mi355rec_sharded mi355rec_sharded_t;
 #define MI355REC_TRANSPORT_PEER 1
 #define MI355REC_TRANSPORT_RCCL 2
 
-/* n_devices = 0: every visible device (at most MI355REC_MAX_SHARDS); otherwise
- * devices 0 .. n_devices-1.  `feats_host` is the whole row-major n x 12 matrix;
- * each device receives its own block only. */
+/* n_devices = 0: the library decides (mi355rec_auto_shards: as many devices as keep at least 4 M rows per
+ * shard — a smaller shard is launch-bound and every shard adds to the exchange; 1 device up to 7.9 M rows, 2 at
+ * 10 M, all 8 of a node from 32 M rows on); otherwise devices 0 .. n_devices-1.  `feats_host` is the whole
+ * row-major n x 12 matrix; each device receives its own block only.
+ * (= mi355rec_create_placed(feats, n, dim, NULL, n_devices, MI355REC_PLACEMENT_SHARDED, out).) */
 int mi355rec_create_sharded(const float* feats_host, int64_t n, int dim, int n_devices,
                             mi355rec_sharded_t** out);
+
+/* PLACEMENT of the catalogue on the node's devices (replaces cudaSetDevice(0), Recommender.cu:124).
+ *   MI355REC_PLACEMENT_SHARDED     rows split into contiguous blocks, one per device (north_star; above).  The only
+ *       placement for a catalogue that does not fit one device, and the one that lowers the latency of a query once
+ *       a scan is longer than its launches (100 M rows: 207 us on one device).
+ *   MI355REC_PLACEMENT_REPLICATED  every device holds ALL rows (and both replicas: 84 B per row, 840 MB at 10 M rows)
+ *       and serves whole WINDOWS of the stream by itself, the windows dealt round-robin over the devices: no exchange,
+ *       no merge across devices, tickets and mi355rec_sharded_wait unchanged; synchronous calls go to the replicas in
+ *       turn.  Queries per second scale with the devices for any catalogue that fits one — which a 10 M-row
+ *       catalogue split eight ways does not (1.25 M-row shards are launch-bound at ~12 us per query and every query
+ *       pays the exchange).
+ *   MI355REC_PLACEMENT_AUTO        = SHARDED (over the device count chosen by the size of the catalogue when
+ *       n_devices = 0).
+ * devices: an explicit list of n_devices device ordinals (a device may repeat: virtual shards / replicas, how both
+ * placements are exercised on a one-GPU box), or NULL: devices 0 .. n_devices-1, n_devices = 0 letting the library
+ * choose (SHARDED / AUTO: mi355rec_auto_shards; REPLICATED: every visible device).
+ * For a replicated handle mi355rec_sharded_info reports one "shard" of n rows per replica, and the transport is
+ * meaningless (mi355rec_sharded_set_transport accepts and ignores it). */
+#define MI355REC_PLACEMENT_AUTO 0
+#define MI355REC_PLACEMENT_SHARDED 1
+#define MI355REC_PLACEMENT_REPLICATED 2
+int mi355rec_create_placed(const float* feats_host, int64_t n, int dim, const int* devices, int n_devices,
+                           int placement, mi355rec_sharded_t** out);
+int mi355rec_auto_shards(int64_t n, int visible_devices);       /* the size-aware default; 0 without a device */
+int mi355rec_sharded_placement(const mi355rec_sharded_t* h);    /* MI355REC_PLACEMENT_SHARDED or _REPLICATED */
 
 /* Explicit placement: shard r on device devices[r].  A device may appear more
  * than once (virtual shards: several shards of one GPU; how the orchestration is

@@ -18,6 +18,7 @@ MAX_TOPN_FAST = 1024
 BATCH_AUTO, BATCH_MULTI, BATCH_MFMA, BATCH_HALF, BATCH_Q8, BATCH_MFMA_NOSKIP = 0, 1, 2, 3, 4, 5
 REPLICA_AUTO, REPLICA_OFF, REPLICA_ON, REPLICA_FP16 = 0, 1, 2, 3
 TRANSPORT_PEER, TRANSPORT_RCCL = 1, 2
+PLACEMENT_AUTO, PLACEMENT_SHARDED, PLACEMENT_REPLICATED = 0, 1, 2
 DEBUG_HANDOFF_POISON, DEBUG_HANDOFF_DROP_STORES, DEBUG_HANDOFF_NO_LAST_RIDER = 1, 2, 4
 
 OK = 0
@@ -84,6 +85,7 @@ SIGNATURES = {
     "mi355rec_replica_counters": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64)]),
     "mi355rec_batched_last_counters": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int64),
                                                POINTER(c_int32)]),
+    "mi355rec_batched_pass2_pairs": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64)]),
     "mi355rec_enqueue_merge_keys": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mi355rec_enqueue_merge_keys_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int, c_int,
                                                   c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -93,6 +95,9 @@ SIGNATURES = {
     "mi355rec_fetch_row": (c_int, [c_void_p, c_int64, c_void_p]),
     "mi355rec_create_sharded": (c_int, [c_void_p, c_int64, c_int, c_int, POINTER(c_void_p)]),
     "mi355rec_create_sharded_on": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, POINTER(c_void_p)]),
+    "mi355rec_create_placed": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    "mi355rec_auto_shards": (c_int, [c_int64, c_int]),
+    "mi355rec_sharded_placement": (c_int, [c_void_p]),
     "mi355rec_sharded_destroy": (None, [c_void_p]),
     "mi355rec_sharded_last_error": (c_char_p, [c_void_p]),
     "mi355rec_sharded_set_transport": (c_int, [c_void_p, c_int]),

@@ -134,12 +134,14 @@ __global__ void bq_selfcheck_kernel(float* out) {
 __global__ __launch_bounds__(256) void bq_prepare_kernel(
     const float* __restrict__ queries, int n_queries, int n_blocks, uint32_t* __restrict__ bfrag,
     float* __restrict__ qnorm, uint32_t* __restrict__ qflags, int* __restrict__ cand_count,
-    int* __restrict__ counters /* [0] special rows, [1] queued queries, [2] chunk-wide queue flag */) {
+    int* __restrict__ counters /* [0] special rows, [1] queued queries, [2] chunk-wide queue flag,
+                                  [3] (tile, query block) pairs pass 2 ran its MFMAs for (diagnostics) */) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q == 0) {
         counters[0] = 0;
         counters[1] = 0;
         counters[2] = 0;
+        counters[3] = 0;
     }
     if (q >= n_blocks * 32) return;
     const bool real = q < n_queries;
@@ -213,9 +215,10 @@ struct BqPassCfg {
 // with this kernel's own arithmetic.
 // kTileMax (NB >= 16, rows from the replica): PASS 2 SKIPS WHAT PASS 1 HAS ALREADY RULED OUT.  Pass 1 looks at every
 // tile_step-th tile; for those tiles it now also stores, per lane and query block, the maximum approx over the
-// lane's 32 rows of the tile (its two MFMA sub-tiles), rounded UP to fp16: tile_max[visited tile][block pair][lane],
+// lane's 32 rows of the tile (its two MFMA sub-tiles), as fp16: tile_max[visited tile][block pair][lane],
 // 4 KiB per visited 64-row tile at NB = 32.  Once the thresholds are known, a (tile, query block) pair can hold a
-// candidate only if some lane's maximum reaches its query's T' (rounded DOWN to fp16): pass 2 compares the 64 x NB
+// candidate only if some lane's maximum reaches its query's T' (both rounded toward zero — rounding is monotone, so
+// the comparison of the images never says "below" for a maximum that is not): pass 2 compares the 64 x NB
 // stored maxima of a visited tile with the thresholds (one packed 16-bit subtraction per two blocks) and runs the two
 // MFMAs and their hit test only for the blocks that pass — about one in eight at top-100 (0.13 candidates per pair).
 // Valid because the margin covers ANY summation order of the 16-term sum: a row of the true top-N has approx >= T'
@@ -244,6 +247,7 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     uint2* const stage = s_stage[kCollect ? wave : 0];
     int staged = 0;   // wave-uniform
+    int pairs_done = 0;   // wave-uniform: (tile, query block) pairs this wave ran its MFMAs for (pass 2 with tile maxima)
     const int lane = threadIdx.x & 63;
     const int r = lane & 31;
     const int h = lane >> 5;
@@ -259,7 +263,9 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
             const int q0 = (2 * d) * 32 + c, q1 = q0 + 32;
             const float t0 = qflags[q0] == kBqFlagOk ? qthr[q0] : __builtin_inff();
             const float t1 = qflags[q1] == kBqFlagOk ? qthr[q1] : __builtin_inff();
-            s_tq[d][c] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(t0, t1));   // T' > 0: toward zero = down
+            // Maxima and thresholds are rounded the SAME way (toward zero: one conversion, nothing else, in pass 1's
+            // hot loop); rounding is monotone, so a maximum that reaches T' has an image that reaches the image of T'.
+            s_tq[d][c] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(t0, t1));
         }
         if (threadIdx.x < 64)   // the dummy block: no query, -65504 in the threshold slot of every column
             s_b[NB][threadIdx.x] = make_uint4(0u, 0u, threadIdx.x >= 32 ? bq_pack_h2(-65504.0f, 0.0f) : 0u, 0u);
@@ -315,6 +321,20 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
         load_row3(first, na, nb, nc);
     }
     int slot = 0;   // wave-uniform: position of `tile` in its group of kPre
+    // pass 2 with tile maxima: the stored maxima of the NEXT tile (if pass 1 looked at it) are requested a tile ahead,
+    // like its rows — asked for at the top of the tile itself they cost the wave a memory round trip per visited tile,
+    // most of what skipping its blocks saved (measured: a visited tile took 0.68 of an unvisited one for 0.135 of its MFMAs)
+    uint4 mv[(kCollect && kTileMax) ? NB / 8 : 1];
+    auto load_maxima = [&](int64_t t) {
+        if constexpr (kCollect && kTileMax) {
+            if ((t & (max_step - 1)) == 0 && t < n_tiles) {   // wave-uniform; max_step is a power of two
+                const uint4* tm = tile_max + (t >> (31 - __builtin_clz(max_step))) * (NB / 8) * 64 + lane;
+#pragma unroll
+                for (int j = 0; j < NB / 8; ++j) mv[j] = tm[j * 64];
+            }
+        }
+    };
+    load_maxima(first);
     // Which tile comes k rounds after `tile`.  Classic: a fixed stride.  Pass 2 with tile maxima: the wave's position
     // inside a round moves on by one per round, so that its tiles cycle through the residues mod max_step (with a
     // fixed stride — a multiple of 4 — a quarter of the waves would own ALL visited tiles and finish early).
@@ -486,10 +506,9 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
                     if ((blk & 1) == 0) {
                         t_even = t;
                     } else {
-                        // two blocks per dword, rounded UP: toward zero (= down, the values are >= 0), then one ulp more
-                        const uint32_t packed = __builtin_bit_cast(
+                        // two blocks per dword, rounded toward zero like the thresholds pass 2 compares them with
+                        tw[(blk >> 1) & 3] = __builtin_bit_cast(
                             uint32_t, __builtin_amdgcn_cvt_pkrtz(__int_as_float(t_even), __int_as_float(t)));
-                        tw[(blk >> 1) & 3] = packed + 0x00010001u;
                         if ((blk & 7) == 7) tm_out[(blk >> 3) * 64] = make_uint4(tw[0], tw[1], tw[2], tw[3]);
                     }
                 }
@@ -554,13 +573,9 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
                 // reaches its query's threshold
                 uint32_t need = static_cast<uint32_t>((1ull << NB) - 1ull);
                 if ((tile & (max_step - 1)) == 0) {   // wave-uniform; max_step is a power of two
-                    const uint4* tm = tile_max + (tile >> (31 - __builtin_clz(max_step))) * (NB / 8) * 64 + lane;
                     // (the thresholds are loop-invariant: without this the compiler keeps all NB / 2 of them in
                     // registers across the tile loop and the kernel loses a wave per SIMD)
                     asm volatile("" ::: "memory");
-                    uint4 mv[NB / 8];
-#pragma unroll
-                    for (int j = 0; j < NB / 8; ++j) mv[j] = tm[j * 64];
                     need = 0u;
 #pragma unroll
                     for (int d = 0; d < NB / 2; ++d) {
@@ -573,6 +588,7 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
                         if (__ballot(diff[1] >= 0)) need |= 1u << (2 * d + 1);
                     }
                 }
+                load_maxima(after);   // (this tile's have been consumed)
                 // The blocks in `need`, in pairs, exactly as the plain loop below runs through ALL blocks: while one
                 // block's two tiles are reduced and tested the next one's MFMAs run and the fragment of the one after
                 // that is on its way from LDS.  An odd count is padded with the dummy block, and the two fragments
@@ -584,6 +600,7 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
                     return b;
                 };
                 const int pairs = (__builtin_popcount(need) + 1) >> 1;
+                pairs_done += __builtin_popcount(need);
                 if (pairs) {   // wave-uniform
                     int b0 = pop(), b1 = pop();
                     uint4 bw0 = sb[b0 * 64], bw1 = sb[b1 * 64];
@@ -634,6 +651,9 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
         tile = after;
     }
     if constexpr (kCollect) bq_flush_stage(stage, staged, lane, cand_count, cand_rows);
+    if constexpr (kCollect && kTileMax) {
+        if (lane == 0) atomicAdd(&counters[3], pairs_done);   // diagnostics: one atomic per wave and pass
+    }
 
     if constexpr (!kCollect) {
         // group = (workgroup, lane half): max over the workgroup's 4 waves through LDS

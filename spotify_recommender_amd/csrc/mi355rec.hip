@@ -2007,6 +2007,23 @@ int mi355rec_batched_last_counters(mi355rec_t* h, int32_t* special_rows, int32_t
     return MI355REC_OK;
 }
 
+int mi355rec_batched_pass2_pairs(mi355rec_t* h, int64_t* pairs_done, int64_t* pairs_total) {
+    if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    if (!h->bq.ready) return fail(h, MI355REC_ERR_INVALID_ARG, "no batched call has been made on this handle");
+    DeviceGuard guard(h->device);
+    HIP_TRY(h, hipDeviceSynchronize());
+    int counters[4] = {0, 0, 0, 0};
+    HIP_TRY(h, hipMemcpy(counters, h->bq.counters, sizeof counters, hipMemcpyDeviceToHost));
+    const int blocks = (h->bq.last_count + 31) / 32;
+    int nb = 1;
+    while (nb < blocks) nb *= 2;
+    const int64_t total = ((h->n + 63) / 64) * nb;
+    if (pairs_total) *pairs_total = total;
+    // (0 = the last chunk ran without tile maxima: every pair was looked at)
+    if (pairs_done) *pairs_done = counters[3] > 0 ? counters[3] : total;
+    return MI355REC_OK;
+}
+
 int mi355rec_set_batch_path(mi355rec_t* h, int path) {
     if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
     if (path != MI355REC_BATCH_AUTO && path != MI355REC_BATCH_MULTI && path != MI355REC_BATCH_MFMA && path != MI355REC_BATCH_HALF &&

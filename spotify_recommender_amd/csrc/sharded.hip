@@ -38,6 +38,18 @@
 // A query by ROW never comes back to the host: every shard's kernels read its 48 bytes from
 // the owning shard's memory through the peer mapping (checked once at create time against
 // the by-value path; without all-pairs peer access the row is fetched once per query).
+//
+// PLACEMENT (mi355rec_create_placed).  Row sharding is what north_star specifies and the only way to a lower
+// latency once a scan is longer than its launches; but a shard below ~4 M rows is launch-bound (measured on one
+// MI355X, streamed queries over the 8-bit replica: 12.1 us per query at 1.25 M rows, 15.4 at 3 M, 24.4 at 10 M, 207
+// at 100 M — 11 us of fixed cost + 1.95 us per million rows), and every query of a sharded catalogue pays the
+// exchange on top.  So
+//   SHARDED     rows split over G devices; G given, or (AUTO) as many as keep >= 4 M rows per shard: 1 for the 114 k
+//               catalogue of BASELINE configs[0] and up to 7.9 M rows, 2 at 10 M, all 8 from 32 M rows on;
+//   REPLICATED  every device holds ALL rows (840 MB at 10 M rows with both replicas) and serves whole WINDOWS of the
+//               stream by itself, round-robin: no exchange, no merge across devices, queries/s scale with the
+//               devices for any catalogue that fits one.  Synchronous calls go to the replicas in turn.
+// A "shard" of a replicated handle is a full replica (lo = 0, hi = n).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
@@ -114,6 +126,9 @@ struct Shard {
     // [kStreamDepth][shards][window][topn] receive
     mi355rec_key_t* s_local = nullptr;
     mi355rec_key_t* s_gathered = nullptr;
+    // replicated placement: where the pinned result ring of the stream lives in THIS device's address space
+    int64_t* s_hdidx = nullptr;
+    float* s_hdscore = nullptr;
 };
 
 // ---- one unit of work for a shard's worker (plain data: copied into the worker's ring) --------------------
@@ -144,6 +159,7 @@ struct Task {
     mi355rec_key_t* recv = nullptr;
     size_t stride = 0;
     const mi355rec_key_t* lists = nullptr;   // merge
+    int n_lists = 0;                         // ... of this many lists per query (0: one per shard)
     mi355rec_key_t* out_keys = nullptr;
     int64_t* out_idx = nullptr;
     float* out_score = nullptr;
@@ -177,6 +193,7 @@ struct Window {
     bool handed = false;            // batched windows: the shards have received it (one streamed batch call each)
     bool issued = false;            // its exchange + merge have been enqueued (posted to the first device's worker)
     uint64_t merge_task = 0;        // ... as that worker's task number: `merged` is recorded once it has run
+    int owner = 0;                  // replicated placement: the replica that serves this window (0 otherwise)
 };
 constexpr int kWindowLag = 2;       // a streamed batch is complete, in stream order, behind the second batch call after it
 
@@ -203,6 +220,10 @@ struct mi355rec_sharded {
     float* hd_score = nullptr;
     bool peer_rows = true;              // every shard's device can read every other shard's rows
     bool batched_windows = true;        // mi355rec_sharded_set_window_mode
+    bool replicated = false;            // every "shard" holds all rows (mi355rec_create_placed, MI355REC_PLACEMENT_REPLICATED)
+    int next_replica = 0;               // whose turn the next synchronous call is (replicated)
+    std::vector<hipEvent_t> r_merged;   // replicated: [kStreamDepth][replicas] "this window's results are in host memory",
+                                        // each on its replica's device (an event belongs to a device)
     std::vector<std::unique_ptr<Worker>> workers;   // one per shard when there are several shards, none otherwise
     uint64_t exchange_seq = 0;
     std::string note;                   // why a fast path was switched off at create time (diagnostics)
@@ -390,7 +411,7 @@ int run_task(mi355rec_sharded* h, int r, const Task& t) {
                 }
             }
             // list l of query b starts at b * topn + l * stride
-            S_ENG(h, s, mi355rec_enqueue_merge_keys_batch(s.engine, t.lists, g, t.topn, static_cast<int64_t>(t.stride),
+            S_ENG(h, s, mi355rec_enqueue_merge_keys_batch(s.engine, t.lists, t.n_lists ? t.n_lists : g, t.topn, static_cast<int64_t>(t.stride),
                                                           static_cast<int64_t>(t.topn), t.count, t.topn, t.out_keys, t.out_idx,
                                                           t.out_score, s.stream));
             if (t.copy_back) {
@@ -689,6 +710,18 @@ int locate_row(mi355rec_sharded* h, int64_t global_row, const float** qptr, floa
     return MI355REC_OK;
 }
 
+// Replicated placement, synchronous calls: the replicas take turns; the caller's thread drives the chosen replica's
+// handle itself once that replica's worker is idle (a handle is used by one thread at a time).
+int take_replica(mi355rec_sharded* h, Shard** out) {
+    const int r = h->next_replica;
+    h->next_replica = (r + 1) % static_cast<int>(h->shards.size());
+    const int rc = wait_worker(h, r);
+    if (rc) return rc;
+    S_HIP(h, hipSetDevice(h->shards[r].device));
+    *out = &h->shards[r];
+    return MI355REC_OK;
+}
+
 // ---- the stream of single queries ------------------------------------------------------
 
 void free_stream(mi355rec_sharded* h) {
@@ -716,16 +749,22 @@ int stream_alloc(mi355rec_sharded* h, int topn) {
     const int g = static_cast<int>(h->shards.size());
     const size_t wk = static_cast<size_t>(h->s_window) * topn;   // keys of one shard in one window
     S_HIP(h, hipSetDevice(h->shards[0].device));
-    S_HIP(h, hipMalloc(&h->s_gather0, sizeof(mi355rec_key_t) * kStreamDepth * g * wk));
-    S_HIP(h, hipMalloc(&h->s_keys, sizeof(mi355rec_key_t) * kStreamDepth * wk));
-    S_HIP(h, hipHostMalloc(&h->s_hidx, sizeof(int64_t) * kStreamDepth * wk, hipHostMallocMapped));
-    S_HIP(h, hipHostMalloc(&h->s_hscore, sizeof(float) * kStreamDepth * wk, hipHostMallocMapped));
+    if (!h->replicated) {
+        S_HIP(h, hipMalloc(&h->s_gather0, sizeof(mi355rec_key_t) * kStreamDepth * g * wk));
+        S_HIP(h, hipMalloc(&h->s_keys, sizeof(mi355rec_key_t) * kStreamDepth * wk));
+    }
+    // (portable: in the replicated placement every replica's kernels store their windows' results here)
+    S_HIP(h, hipHostMalloc(&h->s_hidx, sizeof(int64_t) * kStreamDepth * wk, hipHostMallocMapped | hipHostMallocPortable));
+    S_HIP(h, hipHostMalloc(&h->s_hscore, sizeof(float) * kStreamDepth * wk, hipHostMallocMapped | hipHostMallocPortable));
     S_HIP(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->s_hdidx), h->s_hidx, 0));
     S_HIP(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->s_hdscore), h->s_hscore, 0));
     for (Shard& s : h->shards) {
         S_HIP(h, hipSetDevice(s.device));
         S_HIP(h, hipMalloc(&s.s_local, sizeof(mi355rec_key_t) * kStreamDepth * wk));
-        S_HIP(h, hipMalloc(&s.s_gathered, sizeof(mi355rec_key_t) * kStreamDepth * g * wk));
+        // sharded: the all-gather's receive buffer; replicated: the window's unpacked keys
+        S_HIP(h, hipMalloc(&s.s_gathered, sizeof(mi355rec_key_t) * kStreamDepth * (h->replicated ? 1 : g) * wk));
+        S_HIP(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&s.s_hdidx), h->s_hidx, 0));
+        S_HIP(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&s.s_hdscore), h->s_hscore, 0));
     }
     h->s_topn = topn;
     h->s_alloc_window = h->s_window;
@@ -740,6 +779,18 @@ int stream_alloc(mi355rec_sharded* h, int topn) {
 }
 
 int stream_flush(mi355rec_sharded* h);
+
+// Waits until ring entry w's results are in host memory (its merge has been enqueued, then has run).
+int wait_window(mi355rec_sharded* h, int w) {
+    Window& win = h->win[w];
+    const int owner = h->replicated ? win.owner : 0;
+    const int rc = wait_worker(h, owner, win.merge_task);   // `merged` has been recorded ...
+    if (rc) return rc;
+    hipEvent_t ev = h->replicated ? h->r_merged[static_cast<size_t>(w) * h->shards.size() + owner] : win.merged;
+    S_HIP(h, hipSetDevice(h->shards[owner].device));
+    S_HIP(h, hipEventSynchronize(ev));                       // ... and has happened
+    return MI355REC_OK;
+}
 
 // Buffers for (topn, window); a change of geometry closes the stream first.  All or nothing.
 int ensure_stream(mi355rec_sharded* h, int topn) {
@@ -776,6 +827,27 @@ int stream_issue(mi355rec_sharded* h, int w) {
     const int g = static_cast<int>(h->shards.size());
     const int topn = h->s_topn;
     const size_t wk = static_cast<size_t>(h->s_window) * topn;
+    if (h->replicated) {
+        // no exchange: the window's owner unpacks its own key lists (a "merge" of one list per query) straight into
+        // the pinned result ring and records the window's event on its own stream
+        Shard& own = h->shards[win.owner];
+        Task m;
+        m.kind = kTaskMerge;
+        m.seq = 0;
+        m.n_lists = 1;
+        m.lists = own.s_local + static_cast<size_t>(w) * wk;
+        m.stride = wk;
+        m.count = win.count;
+        m.topn = topn;
+        m.out_keys = own.s_gathered + static_cast<size_t>(w) * wk;
+        m.out_idx = own.s_hdidx + static_cast<size_t>(w) * wk;
+        m.out_score = own.s_hdscore + static_cast<size_t>(w) * wk;
+        m.record_after = h->r_merged[static_cast<size_t>(w) * g + win.owner];
+        const int prc = post(h, win.owner, m, &win.merge_task);
+        if (prc) return prc;
+        win.issued = true;
+        return MI355REC_OK;
+    }
     const bool rccl = h->transport == MI355REC_TRANSPORT_RCCL;
     const int rc = exchange_and_merge(
         h, rccl, h->s_gather0 + static_cast<size_t>(w) * g * wk,
@@ -820,6 +892,20 @@ int stream_flush(mi355rec_sharded* h) {
         h->issued_upto = h->next_ticket;
         return MI355REC_OK;
     }
+    if (h->replicated) {   // only the open window is outstanding (a full one was closed by its last query): its owner drains
+        const int W = h->s_window;
+        const int64_t last = (h->next_ticket - 1) / W;
+        const int w = static_cast<int>(last % kStreamDepth);
+        Task t;
+        t.kind = kTaskFlush;
+        int rc = post(h, h->win[w].owner, t);
+        if (rc) return rc;
+        rc = stream_issue(h, w);
+        if (rc) return rc;
+        h->next_ticket = (h->next_ticket + W - 1) / W * W;
+        h->issued_upto = h->next_ticket;
+        return MI355REC_OK;
+    }
     for (int r = 0; r < static_cast<int>(h->shards.size()); ++r) {
         Task t;
         t.kind = kTaskFlush;
@@ -847,6 +933,23 @@ int stream_issue_batched(mi355rec_sharded* h, int w, bool close_all) {
     const size_t at = static_cast<size_t>(w) * W;
     bool any_ptr = false, any_vec = false;
     for (int i = 0; i < win.count; ++i) (h->w_ptr[at + i] ? any_ptr : any_vec) = true;
+    if (h->replicated) {   // the whole window to its owner, drained behind it; nothing to exchange
+        Shard& own = h->shards[win.owner];
+        Task t;
+        t.kind = kTaskBatch;
+        t.queries = any_vec ? &h->w_q[at * MI355REC_DIM] : nullptr;
+        t.qptrs = any_ptr ? &h->w_ptr[at] : nullptr;
+        t.excls = &h->w_excl[at];
+        t.count = win.count;
+        t.topn = topn;
+        t.dst = own.s_local + static_cast<size_t>(w) * wk;
+        t.flush_after = true;
+        const int prc = post(h, win.owner, t);
+        if (prc) return prc;
+        win.handed = true;
+        (void)close_all;
+        return stream_issue(h, w);
+    }
     for (int r = 0; r < g; ++r) {
         Shard& s = h->shards[r];
         Task t;
@@ -880,14 +983,16 @@ int stream_issue_batched(mi355rec_sharded* h, int w, bool close_all) {
     return MI355REC_OK;
 }
 
+// `row` >= 0: the query is that catalogue row and qptr / query12 already locate it for a SHARDED handle; a replicated one
+// reads the row from the replica that serves the window.
 int stream_enqueue(mi355rec_sharded* h, const float* qptr, const float* query12, int64_t exclude_global, int topn,
-                   int64_t* ticket) {
+                   int64_t* ticket, int64_t row = -1) {
     if (topn <= 0 || topn > MI355REC_MAX_TOPN_FAST)
         return sfail(h, MI355REC_ERR_INVALID_ARG, "topn must be in [1, %d] for streamed queries, got %d", MI355REC_MAX_TOPN_FAST, topn);
     const int64_t t0 = now_ns();
     int rc = ensure_stream(h, topn);
     if (rc) return rc;
-    const bool rccl = h->transport == MI355REC_TRANSPORT_RCCL;
+    const bool rccl = !h->replicated && h->transport == MI355REC_TRANSPORT_RCCL;
     if (rccl && (rc = ensure_rccl(h)) != MI355REC_OK) return rc;
     const int g = static_cast<int>(h->shards.size());
     const int W = h->s_window;
@@ -900,16 +1005,21 @@ int stream_enqueue(mi355rec_sharded* h, const float* qptr, const float* query12,
         // The ring entry's previous window (kStreamDepth windows ago) must be done on the device before
         // any shard writes into its buffers again: host back-pressure, normally long satisfied.
         if (win.abs >= 0 && win.issued) {
-            rc = wait_worker(h, 0, win.merge_task);   // its `merged` event has been recorded ...
+            rc = wait_window(h, w);
             if (rc) return rc;
-            S_HIP(h, hipEventSynchronize(win.merged));   // ... and has happened
         }
         win.abs = abs;
         win.count = 0;
         win.handed = false;
         win.issued = false;
+        win.owner = h->replicated ? static_cast<int>(abs % g) : 0;   // whole windows are dealt round-robin
     }
     const size_t wk = static_cast<size_t>(W) * topn;
+    if (h->replicated && row >= 0) {   // every replica holds the row: the window's owner reads its own copy
+        const Shard& own = h->shards[win.owner];
+        const int prc = mi355rec_row_ptr(own.engine, row, &qptr);
+        if (prc != MI355REC_OK) return sfail(h, prc, "replica on device %d: %s", own.device, mi355rec_last_error(own.engine));
+    }
     if (h->s_batched) {
         const size_t at = static_cast<size_t>(w) * W + slot;
         h->w_ptr[at] = qptr;
@@ -919,18 +1029,22 @@ int stream_enqueue(mi355rec_sharded* h, const float* qptr, const float* query12,
         ++h->next_ticket;
         ++h->st_queries;
         if (ticket) *ticket = t;
-        if (slot == W - 1) rc = stream_issue_batched(h, w, false);
+        if (slot == W - 1) {
+            rc = stream_issue_batched(h, w, false);
+            if (h->replicated) h->issued_upto = h->next_ticket;   // (closed and issued at once: nothing lags behind)
+        }
         h->st_host_ns += now_ns() - t0;
         return rc;
     }
     for (int r = 0; r < g; ++r) {
+        if (h->replicated && r != win.owner) continue;   // one replica serves the whole window
         Shard& s = h->shards[r];
         Task t;
         t.kind = kTaskStreamQuery;
         t.topn = topn;
         t.excl = exclude_global;
-        t.dst = rccl ? s.s_local + static_cast<size_t>(w) * wk + static_cast<size_t>(slot) * topn
-                     : h->s_gather0 + (static_cast<size_t>(w) * g + r) * wk + static_cast<size_t>(slot) * topn;
+        t.dst = (rccl || h->replicated) ? s.s_local + static_cast<size_t>(w) * wk + static_cast<size_t>(slot) * topn
+                                        : h->s_gather0 + (static_cast<size_t>(w) * g + r) * wk + static_cast<size_t>(slot) * topn;
         if (qptr) {
             t.qptr = qptr;
         } else {
@@ -944,7 +1058,17 @@ int stream_enqueue(mi355rec_sharded* h, const float* qptr, const float* query12,
     ++h->next_ticket;
     ++h->st_queries;
     if (ticket) *ticket = t;
-    rc = stream_issue_ready(h, false);
+    if (h->replicated) {
+        if (slot == W - 1) {   // the window is full: its owner drains its pipeline and unpacks the results
+            Task f;
+            f.kind = kTaskFlush;
+            rc = post(h, win.owner, f);
+            if (!rc) rc = stream_issue(h, w);
+            h->issued_upto = h->next_ticket;
+        }
+    } else {
+        rc = stream_issue_ready(h, false);
+    }
     h->st_host_ns += now_ns() - t0;
     return rc;
 }
@@ -966,6 +1090,10 @@ void mi355rec_sharded_destroy(mi355rec_sharded_t* h) {
         if (s.stream) (void)hipStreamSynchronize(s.stream);
     }
     free_stream(h);
+    for (size_t i = 0; i < h->r_merged.size(); ++i) {
+        if (!h->r_merged[i]) continue;
+        if (hipSetDevice(h->shards[i % h->shards.size()].device) == hipSuccess) (void)hipEventDestroy(h->r_merged[i]);
+    }
     for (Shard& s : h->shards) {
         if (hipSetDevice(s.device) != hipSuccess) continue;
         if (s.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(s.comm);
@@ -988,8 +1116,13 @@ void mi355rec_sharded_destroy(mi355rec_sharded_t* h) {
     delete h;
 }
 
-int mi355rec_create_sharded_on(const float* feats_host, int64_t n, int dim, const int* devices, int n_shards,
-                               mi355rec_sharded_t** out) {
+}  // extern "C"
+
+namespace {
+
+// Shard r of a SHARDED handle holds its balanced block of rows; of a REPLICATED one, all of them.
+int create_on(const float* feats_host, int64_t n, int dim, const int* devices, int n_shards, bool replicated,
+              mi355rec_sharded_t** out) {
     if (out) *out = nullptr;
     if (!out || !feats_host || !devices) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null argument");
     if (dim != MI355REC_DIM) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "dim must be %d, got %d", MI355REC_DIM, dim);
@@ -1006,6 +1139,7 @@ int mi355rec_create_sharded_on(const float* feats_host, int64_t n, int dim, cons
     DeviceRestore restore;
     mi355rec_sharded* h = new mi355rec_sharded();
     h->n = n;
+    h->replicated = replicated;
     h->shards.resize(n_shards);
     auto bail = [&](int code) {
         const std::string keep = g_sharded_error;
@@ -1017,7 +1151,12 @@ int mi355rec_create_sharded_on(const float* feats_host, int64_t n, int dim, cons
     for (int r = 0; r < n_shards; ++r) {
         Shard& s = h->shards[r];
         s.device = devices[r];
-        bounds(n, n_shards, r, s.lo, s.hi);
+        if (replicated) {
+            s.lo = 0;
+            s.hi = n;
+        } else {
+            bounds(n, n_shards, r, s.lo, s.hi);
+        }
         if (hipSetDevice(s.device) != hipSuccess) return bail(sfail(nullptr, MI355REC_ERR_HIP, "hipSetDevice(%d) failed", s.device));
         const int rc = mi355rec_create(s.hi > s.lo ? feats_host + s.lo * MI355REC_DIM : nullptr, s.hi - s.lo, dim, s.device,
                                        s.lo, &s.engine);
@@ -1028,7 +1167,8 @@ int mi355rec_create_sharded_on(const float* feats_host, int64_t n, int dim, cons
     }
     // Peer mappings.  Stores into the first device's gather buffers need ITS memory mapped on every
     // other device (PEER transport); queries by row need every device's rows mapped on every other.
-    for (int a = 0; a < n_shards; ++a) {
+    // (Replicas never read or write each other's memory.)
+    for (int a = 0; a < n_shards && !replicated; ++a) {
         for (int b = 0; b < n_shards; ++b) {
             const int da = devices[a], db = devices[b];
             if (da == db) continue;
@@ -1050,6 +1190,14 @@ int mi355rec_create_sharded_on(const float* feats_host, int64_t n, int dim, cons
         if (hipEventCreateWithFlags(&w.merged, hipEventDisableTiming) != hipSuccess)
             return bail(sfail(nullptr, MI355REC_ERR_HIP, "event creation on device %d failed", root));
     h->transport = h->peer_ok ? MI355REC_TRANSPORT_PEER : MI355REC_TRANSPORT_RCCL;
+    if (replicated) {   // one "results are in host memory" event per (ring entry, replica), on the replica's device
+        h->r_merged.assign(static_cast<size_t>(kStreamDepth) * n_shards, nullptr);
+        for (int w = 0; w < kStreamDepth; ++w)
+            for (int r = 0; r < n_shards; ++r)
+                if (hipSetDevice(devices[r]) != hipSuccess ||
+                    hipEventCreateWithFlags(&h->r_merged[static_cast<size_t>(w) * n_shards + r], hipEventDisableTiming) != hipSuccess)
+                    return bail(sfail(nullptr, MI355REC_ERR_HIP, "event creation on device %d failed", devices[r]));
+    }
 
     if (n_shards > 1) {   // one worker per shard (none for a single shard: its calls are made by the caller)
         for (int r = 0; r < n_shards; ++r) {
@@ -1064,7 +1212,9 @@ int mi355rec_create_sharded_on(const float* feats_host, int64_t n, int dim, cons
     // error switches the pointer path off for this handle; mi355rec_sharded_info's note says so).
     bool distinct = false;
     for (int r = 1; r < n_shards; ++r) distinct = distinct || devices[r] != devices[0];
-    if (distinct && h->peer_rows && n >= 2) {
+    if (replicated) {
+        // nothing to check: a replica reads its own rows
+    } else if (distinct && h->peer_rows && n >= 2) {
         const int topn = n - 1 < 16 ? static_cast<int>(n - 1) : 16;
         std::vector<int64_t> i_ptr(topn), i_val(topn);
         std::vector<float> s_ptr(topn), s_val(topn);
@@ -1091,24 +1241,71 @@ int mi355rec_create_sharded_on(const float* feats_host, int64_t n, int dim, cons
     return MI355REC_OK;
 }
 
-int mi355rec_create_sharded(const float* feats_host, int64_t n, int dim, int n_devices, mi355rec_sharded_t** out) {
+}  // namespace
+
+extern "C" {
+
+int mi355rec_create_sharded_on(const float* feats_host, int64_t n, int dim, const int* devices, int n_shards,
+                               mi355rec_sharded_t** out) {
+    return create_on(feats_host, n, dim, devices, n_shards, false, out);
+}
+
+// How many devices a row-sharded catalogue of n rows is spread over when the caller does not say (see "PLACEMENT"
+// at the top): as many as keep at least kRowsPerShardAuto rows per shard — a smaller shard is launch-bound, and
+// every further shard adds to the exchange.
+constexpr int64_t kRowsPerShardAuto = 4000000;
+
+int mi355rec_auto_shards(int64_t n, int visible_devices) {
+    if (visible_devices < 1) return 0;
+    int64_t g = n / kRowsPerShardAuto;
+    if (g < 1) g = 1;
+    if (g > visible_devices) g = visible_devices;
+    if (g > MI355REC_MAX_SHARDS) g = MI355REC_MAX_SHARDS;
+    return static_cast<int>(g);
+}
+
+int mi355rec_create_placed(const float* feats_host, int64_t n, int dim, const int* devices, int n_devices, int placement,
+                           mi355rec_sharded_t** out) {
+    if (out) *out = nullptr;
+    if (placement != MI355REC_PLACEMENT_AUTO && placement != MI355REC_PLACEMENT_SHARDED && placement != MI355REC_PLACEMENT_REPLICATED)
+        return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "unknown placement %d", placement);
     const int visible = mi355rec_device_count();
-    if (visible <= 0) {
-        if (out) *out = nullptr;
+    if (visible <= 0)
         return sfail(nullptr, MI355REC_ERR_NO_DEVICE, "no HIP device visible: the MI355X engine has no CPU fallback");
+    std::vector<int> devs;
+    if (devices) {   // an explicit list (a device may repeat: virtual shards / replicas on a one-GPU box)
+        if (n_devices < 1 || n_devices > MI355REC_MAX_SHARDS)
+            return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "n_devices must be in [1, %d] with an explicit list, got %d", MI355REC_MAX_SHARDS, n_devices);
+        devs.assign(devices, devices + n_devices);
+    } else {
+        if (n_devices < 0 || n_devices > visible)
+            return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "n_devices %d but %d device(s) visible", n_devices, visible);
+        int g = n_devices;
+        if (g == 0)   // the library decides: replicas on every device; shards by the size of the catalogue
+            g = placement == MI355REC_PLACEMENT_REPLICATED ? (visible < MI355REC_MAX_SHARDS ? visible : MI355REC_MAX_SHARDS)
+                                                            : mi355rec_auto_shards(n, visible);
+        devs.resize(g);
+        for (int d = 0; d < g; ++d) devs[d] = d;
     }
-    if (n_devices == 0) n_devices = visible < MI355REC_MAX_SHARDS ? visible : MI355REC_MAX_SHARDS;
-    if (n_devices < 0 || n_devices > visible) {
-        if (out) *out = nullptr;
-        return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "n_devices %d but %d device(s) visible", n_devices, visible);
-    }
-    std::vector<int> devs(n_devices);
-    for (int d = 0; d < n_devices; ++d) devs[d] = d;
-    return mi355rec_create_sharded_on(feats_host, n, dim, devs.data(), n_devices, out);
+    return create_on(feats_host, n, dim, devs.data(), static_cast<int>(devs.size()), placement == MI355REC_PLACEMENT_REPLICATED, out);
+}
+
+int mi355rec_create_sharded(const float* feats_host, int64_t n, int dim, int n_devices, mi355rec_sharded_t** out) {
+    return mi355rec_create_placed(feats_host, n, dim, nullptr, n_devices, MI355REC_PLACEMENT_SHARDED, out);
+}
+
+int mi355rec_sharded_placement(const mi355rec_sharded_t* h) {
+    if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    return h->replicated ? MI355REC_PLACEMENT_REPLICATED : MI355REC_PLACEMENT_SHARDED;
 }
 
 int mi355rec_sharded_set_transport(mi355rec_sharded_t* h, int transport) {
     if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    if (h->replicated) {   // nothing is ever exchanged between replicas: either value is accepted and ignored
+        if (transport != MI355REC_TRANSPORT_PEER && transport != MI355REC_TRANSPORT_RCCL)
+            return sfail(h, MI355REC_ERR_INVALID_ARG, "unknown transport %d", transport);
+        return MI355REC_OK;
+    }
     if (transport == MI355REC_TRANSPORT_PEER) {
         if (!h->peer_ok) return sfail(h, MI355REC_ERR_INVALID_ARG, "peer access to device %d is not available from every shard", h->shards[0].device);
     } else if (transport != MI355REC_TRANSPORT_RCCL) {
@@ -1185,6 +1382,14 @@ int mi355rec_sharded_query_batch_topn(mi355rec_sharded_t* h, const float* querie
         const int rc = mi355rec_query_batch_topn(h->shards[0].engine, queries, batch, exclude_global, topn, out_idx, out_score, out_count);
         return rc == MI355REC_OK ? rc : sfail(h, rc, "%s", mi355rec_last_error(h->shards[0].engine));
     }
+    if (h->replicated) {   // any replica is the whole engine
+        DeviceRestore restore;
+        Shard* s = nullptr;
+        int rc = take_replica(h, &s);
+        if (rc) return rc;
+        rc = mi355rec_query_batch_topn(s->engine, queries, batch, exclude_global, topn, out_idx, out_score, out_count);
+        return rc == MI355REC_OK ? rc : sfail(h, rc, "replica on device %d: %s", s->device, mi355rec_last_error(s->engine));
+    }
     // lists are at most n long
     const int eff = static_cast<int64_t>(topn) < h->n ? topn : static_cast<int>(h->n);
     DeviceRestore restore;
@@ -1209,6 +1414,14 @@ int mi355rec_sharded_query_row_topn(mi355rec_sharded_t* h, int64_t global_row, i
     if (h->shards.size() == 1) {   // what Recommender::recommendByIndex costs on a one-GPU box: exactly mi355rec_query_row_topn
         const int rc = mi355rec_query_row_topn(h->shards[0].engine, global_row, topn, out_idx, out_score, out_count);
         return rc == MI355REC_OK ? rc : sfail(h, rc, "%s", mi355rec_last_error(h->shards[0].engine));
+    }
+    if (h->replicated) {
+        DeviceRestore restore;
+        Shard* s = nullptr;
+        int rc = take_replica(h, &s);
+        if (rc) return rc;
+        rc = mi355rec_query_row_topn(s->engine, global_row, topn, out_idx, out_score, out_count);
+        return rc == MI355REC_OK ? rc : sfail(h, rc, "replica on device %d: %s", s->device, mi355rec_last_error(s->engine));
     }
     DeviceRestore restore;
     float q[MI355REC_DIM];
@@ -1235,6 +1448,13 @@ int mi355rec_sharded_scores_row(mi355rec_sharded_t* h, int64_t global_row, float
     if (global_row < 0 || global_row >= h->n)
         return sfail(h, MI355REC_ERR_INVALID_ARG, "Invalid song index: %lld", (long long)global_row);
     DeviceRestore restore;
+    if (h->replicated) {
+        Shard* s = nullptr;
+        int rc = take_replica(h, &s);
+        if (rc) return rc;
+        rc = mi355rec_scores_row(s->engine, global_row, out_host);
+        return rc == MI355REC_OK ? rc : sfail(h, rc, "replica on device %d: %s", s->device, mi355rec_last_error(s->engine));
+    }
     float q[MI355REC_DIM];
     const Shard* own = owner_of(h, global_row);
     int rc = drain_workers(h);   // cold path: the caller's thread drives every shard itself
@@ -1313,11 +1533,13 @@ int mi355rec_sharded_enqueue_row(mi355rec_sharded_t* h, int64_t global_row, int 
     if (global_row < 0 || global_row >= h->n)
         return sfail(h, MI355REC_ERR_INVALID_ARG, "Invalid song index: %lld", (long long)global_row);
     DeviceRestore restore;
-    float q[MI355REC_DIM];
+    float q[MI355REC_DIM] = {0};
     const float* qptr = nullptr;
-    const int rc = locate_row(h, global_row, &qptr, q);
-    if (rc) return rc;
-    return stream_enqueue(h, qptr, q, global_row, topn, ticket);
+    if (!h->replicated) {
+        const int rc = locate_row(h, global_row, &qptr, q);
+        if (rc) return rc;
+    }
+    return stream_enqueue(h, qptr, q, global_row, topn, ticket, global_row);
 }
 
 int mi355rec_sharded_enqueue_flush(mi355rec_sharded_t* h) {
@@ -1347,10 +1569,9 @@ int mi355rec_sharded_wait(mi355rec_sharded_t* h, int64_t ticket, int64_t* out_id
         if (rc) return rc;
     }
     {
-        const int rc = wait_worker(h, 0, win.merge_task);   // the merge has been enqueued and `merged` recorded ...
+        const int rc = wait_window(h, w);   // the merge has been enqueued, `merged` recorded, and the results are in host memory
         if (rc) return rc;
     }
-    S_HIP(h, hipEventSynchronize(win.merged));                // ... and the results are in host memory
     const int topn = h->s_topn;
     const size_t off = (static_cast<size_t>(w) * W + slot) * topn;
     copy_rows(h->s_hidx + off, h->s_hscore + off, 1, topn, topn, out_idx, out_score, out_count);

@@ -211,6 +211,12 @@ class CosineEngine:
         return {"special_rows": sp.value, "queued_queries": qd.value, "candidates_total": tot.value,
                 "candidates_max": mx.value}
 
+    def batched_pass2_pairs(self) -> dict:
+        """(tile, query block) pairs pass 2 of the last batched chunk ran its MFMAs for, out of all (synchronises)."""
+        done, total = ctypes.c_int64(0), ctypes.c_int64(0)
+        capi.check(self._lib.mi355rec_batched_pass2_pairs(self._h, ctypes.byref(done), ctypes.byref(total)), self._h)
+        return {"pairs_done": int(done.value), "pairs_total": int(total.value)}
+
     def set_replica(self, mode: int) -> None:
         """capi.REPLICA_AUTO / REPLICA_OFF (fp32 rows only) / REPLICA_ON: which copy single queries scan."""
         capi.check(self._lib.mi355rec_set_replica(self._h, int(mode)), self._h)
@@ -272,26 +278,29 @@ class CosineEngine:
 
 
 class NodeEngine:
-    """The row-sharded catalogue driven by ONE process (mi355rec_create_sharded):
-    what the C++ Recommender shim uses.  `devices=None` -> every visible GPU;
-    a list may repeat a device (virtual shards on a one-GPU box)."""
+    """The catalogue on the GPUs of one node driven by ONE process (mi355rec_create_placed): what the C++
+    Recommender shim uses.  `placement`: capi.PLACEMENT_SHARDED (rows split over the devices; the default),
+    PLACEMENT_REPLICATED (every device holds all rows and serves whole windows of the stream).
+    `devices=None` -> devices 0 .. n_devices-1, n_devices = 0 letting the library choose; a list may repeat a
+    device (virtual shards / replicas on a one-GPU box)."""
 
-    def __init__(self, feats, devices=None, n_devices: int = 0):
+    def __init__(self, feats, devices=None, n_devices: int = 0, placement: int = capi.PLACEMENT_SHARDED):
         self._lib = capi.lib()
         self._h = ctypes.c_void_p()
         arr = _np_f32(feats)
         if arr.ndim != 2 or arr.shape[1] != capi.DIM:
             raise ValueError("catalogue must be float32 [n, 12]")
-        if devices is None:
-            rc = self._lib.mi355rec_create_sharded(arr.ctypes.data_as(ctypes.c_void_p), arr.shape[0], arr.shape[1],
-                                                   int(n_devices), ctypes.byref(self._h))
-        else:
-            devs = np.ascontiguousarray(np.asarray(devices, dtype=np.int32))
-            rc = self._lib.mi355rec_create_sharded_on(arr.ctypes.data_as(ctypes.c_void_p), arr.shape[0], arr.shape[1],
-                                                      devs.ctypes.data_as(ctypes.c_void_p), len(devs), ctypes.byref(self._h))
+        devs = None if devices is None else np.ascontiguousarray(np.asarray(devices, dtype=np.int32))
+        rc = self._lib.mi355rec_create_placed(
+            arr.ctypes.data_as(ctypes.c_void_p), arr.shape[0], arr.shape[1],
+            devs.ctypes.data_as(ctypes.c_void_p) if devs is not None else None,
+            len(devs) if devs is not None else int(n_devices), int(placement), ctypes.byref(self._h))
         if rc != capi.OK:
             raise capi.Mi355Error(rc, (self._lib.mi355rec_sharded_last_error(None) or b"").decode("utf-8", "replace"))
         self.rows = int(arr.shape[0])
+
+    def placement(self) -> int:
+        return int(self._lib.mi355rec_sharded_placement(self._h))
 
     def _check(self, rc: int) -> None:
         if rc != capi.OK:

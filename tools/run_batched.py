@@ -62,6 +62,7 @@ def main():
                "effective_tflops_24flop_per_pair": round(24.0 * args.rows * args.batch / dt / 1e12, 2)}
         if args.path != 1:
             out.update(eng.batched_last_counters())
+            out.update(eng.batched_pass2_pairs())
         print(json.dumps(out), flush=True)
 
 
