@@ -23,8 +23,10 @@
  * call waits for the earlier one.  For CONCURRENT queries use one handle per
  * stream (handles may share one device matrix through mi355rec_create_device).
  * A stream passed to a call must stay alive until the handle's next call.
- * There is NO CPU fallback: without a gfx950 device every call fails with
- * MI355REC_ERR_NO_DEVICE.
+ * Without a gfx950 device every single-device call (mi355rec_create*) fails with
+ * MI355REC_ERR_NO_DEVICE; the node-level handle (mi355rec_create_sharded / _placed,
+ * what the C++ Recommender sits on) is then served by the product's own CPU backend,
+ * as the reference falls back to its CPU loop — see "NO HIP DEVICE" further down.
  *
  * Numerics: scores are bit-identical to the reference's CPU path
  * (calculateSimilaritiesCPU, Recommender.cu:256-273): strictly sequential
@@ -430,10 +432,22 @@ int mi355rec_create_sharded(const float* feats_host, int64_t n, int dim, int n_d
 #define MI355REC_PLACEMENT_AUTO 0
 #define MI355REC_PLACEMENT_SHARDED 1
 #define MI355REC_PLACEMENT_REPLICATED 2
+#define MI355REC_PLACEMENT_CPU 3   /* reported, never asked for: see "no HIP device" below */
 int mi355rec_create_placed(const float* feats_host, int64_t n, int dim, const int* devices, int n_devices,
                            int placement, mi355rec_sharded_t** out);
 int mi355rec_auto_shards(int64_t n, int visible_devices);       /* the size-aware default; 0 without a device */
-int mi355rec_sharded_placement(const mi355rec_sharded_t* h);    /* MI355REC_PLACEMENT_SHARDED or _REPLICATED */
+int mi355rec_sharded_placement(const mi355rec_sharded_t* h);    /* MI355REC_PLACEMENT_SHARDED, _REPLICATED or _CPU */
+
+/* NO HIP DEVICE.  The reference degrades to its CPU loop when it finds no GPU (Recommender.cu:117-127,176-181:
+ * "No CUDA devices found. Falling back to CPU", then calculateSimilaritiesCPU, :256-273).  So do
+ * mi355rec_create_sharded / mi355rec_create_placed when NO device is visible and the caller left the choice of
+ * devices to the library (devices == NULL, n_devices == 0): the handle is then served by the product's own CPU
+ * backend (csrc/cpu_backend.cpp: the same sequential fp32 chain over the row-major matrix, rows split over OpenMP
+ * threads, a top-N per thread and one merge; canonical order) — every call of this section works, the stream
+ * computes a query when it is enqueued, mi355rec_sharded_info reports 0 shards, mi355rec_sharded_placement
+ * MI355REC_PLACEMENT_CPU and mi355rec_sharded_note says so.  This is BASELINE configs[0] ("CPU cosine path only").
+ * It is never taken on a host with a device, an explicit device list still fails with MI355REC_ERR_NO_DEVICE, and
+ * the single-device calls (mi355rec_create*) have no CPU path at all. */
 
 /* Explicit placement: shard r on device devices[r].  A device may appear more
  * than once (virtual shards: several shards of one GPU; how the orchestration is

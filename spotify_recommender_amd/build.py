@@ -44,7 +44,7 @@ def _run(cmd) -> None:
     proc = subprocess.run([str(c) for c in cmd], capture_output=True, text=True)
     if proc.returncode != 0:
         raise RuntimeError(
-            "build command failed:\n  " + " ".join(str(c) for c in cmd) + "\n" + proc.stdout + proc.stderr
+            "build command failed:\n  " + " ".join(str(c) for c in cmd) + "\n" + (proc.stdout + proc.stderr)[-6000:]
         )
 
 
@@ -97,10 +97,20 @@ def check_no_scratch(lib: Path = LIB_ENGINE) -> int:
     return len(meta)
 
 
+CPU_BACKEND_SRC = CSRC / "cpu_backend.cpp"
+CPU_BACKEND_OBJ = PKG / "cpu_backend.o"
+# The CPU backend (hosts without a HIP device) is plain C++ + OpenMP, compiled by g++ with the reference's own fp
+# behaviour (Makefile:9: -O3, no -march, no -ffast-math; -ffp-contract=off keeps multiply and add apart) and
+# linked into the engine library.
+CPU_BACKEND_FLAGS = ["-std=c++17", "-O3", "-fopenmp", "-ffp-contract=off", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"]
+
+
 def build_engine(force: bool = False) -> Path:
     """Compile the HIP engine for gfx950 (cross-compiles without a GPU)."""
-    if force or _stale(LIB_ENGINE, ENGINE_DEPS):
-        _run([HIPCC, *HIP_FLAGS, "-o", LIB_ENGINE, *ENGINE_SOURCES])
+    if force or _stale(LIB_ENGINE, ENGINE_DEPS + [CPU_BACKEND_SRC, CSRC / "cpu_backend.h"]):
+        _run(["g++", *CPU_BACKEND_FLAGS, "-c", CPU_BACKEND_SRC, "-o", CPU_BACKEND_OBJ])
+        # (the object goes in through the linker: hipcc would take a bare .o behind .hip sources for HIP source)
+        _run([HIPCC, *HIP_FLAGS, "-o", LIB_ENGINE, *ENGINE_SOURCES, f"-Wl,{CPU_BACKEND_OBJ}", "-lgomp"])
         try:
             check_no_scratch(LIB_ENGINE)
         except Exception:

@@ -18,7 +18,7 @@ MAX_TOPN_FAST = 1024
 BATCH_AUTO, BATCH_MULTI, BATCH_MFMA, BATCH_HALF, BATCH_Q8, BATCH_MFMA_NOSKIP = 0, 1, 2, 3, 4, 5
 REPLICA_AUTO, REPLICA_OFF, REPLICA_ON, REPLICA_FP16 = 0, 1, 2, 3
 TRANSPORT_PEER, TRANSPORT_RCCL = 1, 2
-PLACEMENT_AUTO, PLACEMENT_SHARDED, PLACEMENT_REPLICATED = 0, 1, 2
+PLACEMENT_AUTO, PLACEMENT_SHARDED, PLACEMENT_REPLICATED, PLACEMENT_CPU = 0, 1, 2, 3
 DEBUG_HANDOFF_POISON, DEBUG_HANDOFF_DROP_STORES, DEBUG_HANDOFF_NO_LAST_RIDER = 1, 2, 4
 
 OK = 0

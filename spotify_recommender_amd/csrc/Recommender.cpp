@@ -14,7 +14,7 @@ struct Recommender::Impl {
     bool initialized = false;
     bool gpuEnabled = false;
     int numSongs = 0;
-    mi355rec_sharded_t* engine = nullptr;   // the catalogue row-sharded over every visible GPU
+    mi355rec_sharded_t* engine = nullptr;   // the catalogue on the node's GPUs (placement: include/mi355rec.h) — or, without any, on the CPU backend
     int numDevices = 0;
 
     // Only what the lookups need is kept (the reference deep-copies every Song,
@@ -105,20 +105,30 @@ bool startEngine(Recommender::Impl* impl, const float* matrix, size_t n) {
     impl->initialized = false;
     impl->gpuEnabled = false;
     impl->numSongs = static_cast<int>(n);
-    // The reference pins device 0 (Recommender.cu:124); here the rows are sharded over
-    // every visible GPU (one process, one stream per device, xGMI peer stores or one RCCL
-    // all-gather of the per-shard top-N keys: include/mi355rec.h, "row-sharded catalogue").
-    const int rc = mi355rec_create_sharded(matrix, static_cast<int64_t>(n), FEATURE_COUNT, /*n_devices=*/0, &impl->engine);
-    if (rc != MI355REC_OK) {
-        // The reference would say "[GPU Disabled] ... Falling back to CPU" and go
-        // on (:117-181).  There is no CPU path here: fail loudly.
+    // The reference pins device 0 (Recommender.cu:124).  Here the library places the catalogue itself: one device up
+    // to 7.9 M rows, row-sharded over as many as keep 4 M rows per shard beyond that (one process, one stream per
+    // device, xGMI peer stores or one RCCL all-gather of the per-shard top-N keys: include/mi355rec.h, "PLACEMENT").
+    // Without any HIP device the handle is served by the product's own CPU backend, as the reference falls back to
+    // its CPU loop (:117-127,176-181).
+    const int rc = mi355rec_create_placed(matrix, static_cast<int64_t>(n), FEATURE_COUNT, nullptr, /*n_devices=*/0,
+                                          MI355REC_PLACEMENT_AUTO, &impl->engine);
+    if (rc != MI355REC_OK) {   // a device is there but could not be used (or memory ran out): say why and give up
         std::cerr << "[GPU Disabled] " << mi355rec_sharded_last_error(nullptr) << std::endl;
-        std::cerr << "Error: the MI355X recommender needs a HIP device (no CPU fallback)" << std::endl;
+        std::cerr << "Error: the recommender could not be initialized" << std::endl;
         return false;
+    }
+    impl->initialized = true;
+    if (mi355rec_sharded_placement(impl->engine) == MI355REC_PLACEMENT_CPU) {
+        // the reference's own lines for this case (Recommender.cu:120-121,177)
+        std::cerr << "[GPU Disabled] HIP runtime not available: no HIP device visible" << std::endl;
+        std::cerr << "Falling back to CPU similarity computation." << std::endl;
+        std::cout << "Operating in CPU fallback mode (cosine similarity on CPU)." << std::endl;
+        impl->gpuEnabled = false;
+        impl->numDevices = 0;
+        return true;
     }
     mi355rec_sharded_info(impl->engine, &impl->numDevices, nullptr, nullptr, nullptr, nullptr);
     impl->gpuEnabled = true;
-    impl->initialized = true;
     // the reference's stdout line, byte for byte (Recommender.cu:172); the placement note goes to stderr
     std::cout << "Successfully initialized with " << impl->numSongs << " songs on GPU" << std::endl;
     if (impl->numDevices > 1) {

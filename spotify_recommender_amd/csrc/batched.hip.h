@@ -131,6 +131,31 @@ __global__ void bq_selfcheck_kernel(float* out) {
 // B operand of v_mfma_f32_32x32x16_f16: lane l (c = l & 31, h = l >> 5) holds
 // B[k = 8h + j][col c], j = 0..7, i.e. 4 dwords.  bfrag[blk][lane][4].
 // k = 0..11 the normalised query, k = 12, 13 the threshold (select kernel), 14, 15 zero.
+// One query -> its two fragment rows (lo: k 0..7, hi: k 8..11 + zeroed threshold slots), its norm and its flag.
+struct BqPrepared {
+    uint4 lo, hi;
+    float qn;
+    uint32_t flag;
+};
+__device__ __forceinline__ BqPrepared bq_prepare_query(const float* __restrict__ queries, int q, int n_queries) {
+    const bool real = q < n_queries;
+    float v[kDim];
+#pragma unroll
+    for (int j = 0; j < kDim; ++j) v[j] = real ? queries[static_cast<int64_t>(q) * kDim + j] : 0.0f;
+    BqPrepared p;
+    p.qn = query_norm(v);
+    const bool ok = real && p.qn >= kBqMinNorm && p.qn <= kBqMaxNorm;   // false for NaN
+    const float inv = ok ? 1.0f / p.qn : 0.0f;
+    float u[kDim];
+#pragma unroll
+    for (int j = 0; j < kDim; ++j) u[j] = ok ? v[j] * inv : 0.0f;
+    p.lo = make_uint4(bq_pack_h2(u[0], u[1]), bq_pack_h2(u[2], u[3]), bq_pack_h2(u[4], u[5]), bq_pack_h2(u[6], u[7]));
+    p.hi = make_uint4(bq_pack_h2(u[8], u[9]), bq_pack_h2(u[10], u[11]), 0u, 0u);
+    p.flag = ok ? kBqFlagOk : (real ? kBqFlagQueue : kBqFlagPad);
+    return p;
+}
+
+// (A launch of its own only for chunks whose pass 1 does not prepare the queries itself: see bq_pass_kernel.)
 __global__ __launch_bounds__(256) void bq_prepare_kernel(
     const float* __restrict__ queries, int n_queries, int n_blocks, uint32_t* __restrict__ bfrag,
     float* __restrict__ qnorm, uint32_t* __restrict__ qflags, int* __restrict__ cand_count,
@@ -144,23 +169,12 @@ __global__ __launch_bounds__(256) void bq_prepare_kernel(
         counters[3] = 0;
     }
     if (q >= n_blocks * 32) return;
-    const bool real = q < n_queries;
-    float v[kDim];
-#pragma unroll
-    for (int j = 0; j < kDim; ++j) v[j] = real ? queries[static_cast<int64_t>(q) * kDim + j] : 0.0f;
-    const float qn = query_norm(v);
-    const bool ok = real && qn >= kBqMinNorm && qn <= kBqMaxNorm;   // false for NaN
-    const float inv = ok ? 1.0f / qn : 0.0f;
-    float u[kDim];
-#pragma unroll
-    for (int j = 0; j < kDim; ++j) u[j] = ok ? v[j] * inv : 0.0f;
+    const BqPrepared p = bq_prepare_query(queries, q, n_queries);
     const int blk = q >> 5, c = q & 31;
-    uint4* lo = reinterpret_cast<uint4*>(bfrag) + (blk * 64 + c);
-    uint4* hi = reinterpret_cast<uint4*>(bfrag) + (blk * 64 + 32 + c);
-    *lo = make_uint4(bq_pack_h2(u[0], u[1]), bq_pack_h2(u[2], u[3]), bq_pack_h2(u[4], u[5]), bq_pack_h2(u[6], u[7]));
-    *hi = make_uint4(bq_pack_h2(u[8], u[9]), bq_pack_h2(u[10], u[11]), 0u, 0u);
-    qnorm[q] = qn;
-    qflags[q] = ok ? kBqFlagOk : (real ? kBqFlagQueue : kBqFlagPad);
+    reinterpret_cast<uint4*>(bfrag)[blk * 64 + c] = p.lo;
+    reinterpret_cast<uint4*>(bfrag)[blk * 64 + 32 + c] = p.hi;
+    qnorm[q] = p.qn;
+    qflags[q] = p.flag;
     cand_count[q * kBqCountStride] = 0;
 }
 
@@ -231,7 +245,12 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
     uint32_t* __restrict__ cand_rows /* [query][kBqCap] */, int* __restrict__ counters,
     uint32_t* __restrict__ special_rows, const uint2* __restrict__ half = nullptr,
     uint4* __restrict__ tile_max = nullptr /* [visited tile][NB / 8][64] */, int max_step = 1 /* pass 2: pass 1's tile_step */,
-    const float* __restrict__ qthr = nullptr, const uint32_t* __restrict__ qflags = nullptr) {
+    const float* __restrict__ qthr = nullptr, const uint32_t* __restrict__ qflags = nullptr,
+    // pass 1 PREPARES THE QUERIES ITSELF when prep_queries is given (no bq_prepare_kernel launch in front of it): every
+    // workgroup builds the B fragments straight into its LDS from the raw queries, and workgroup 0 also leaves them —
+    // with the norms, the flags and the zeroed counters — in global memory for the kernels behind it
+    const float* __restrict__ prep_queries = nullptr, int prep_count = 0, float* __restrict__ prep_qnorm = nullptr,
+    uint32_t* __restrict__ prep_qflags = nullptr) {
     static_assert(!kTileMax || (NB >= 16 && kFromReplica && kVariant == 0), "tile maxima: replica rows, 16 or 32 query blocks");
     // n_tiles counts 64-row tiles.  tile_step = 1: every tile.  tile_step > 1 (pass 1 only):
     // every tile_step-th tile — a threshold derived from ANY subset of the rows is a valid
@@ -252,7 +271,26 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
     const int r = lane & 31;
     const int h = lane >> 5;
 
-    for (int i = threadIdx.x; i < NB * 64; i += kBqPassBlock) (&s_b[0][0])[i] = reinterpret_cast<const uint4*>(bfrag)[i];
+    if (!kCollect && kFromReplica && prep_queries) {   // uniform (replica-sourced pass 1 only: the fp32-sourced one, which
+                                                        // exists for A/B runs, is short of registers and keeps its prepare launch)
+        uint32_t* const bfrag_out = const_cast<uint32_t*>(bfrag);
+        for (int q = threadIdx.x; q < NB * 32; q += kBqPassBlock) {
+            const BqPrepared p = bq_prepare_query(prep_queries, q, prep_count);
+            const int blk = q >> 5, c = q & 31;
+            s_b[blk][c] = p.lo;
+            s_b[blk][32 + c] = p.hi;
+            if (blockIdx.x == 0) {
+                reinterpret_cast<uint4*>(bfrag_out)[blk * 64 + c] = p.lo;
+                reinterpret_cast<uint4*>(bfrag_out)[blk * 64 + 32 + c] = p.hi;
+                prep_qnorm[q] = p.qn;
+                prep_qflags[q] = p.flag;
+                cand_count[q * kBqCountStride] = 0;
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0;
+    } else {
+        for (int i = threadIdx.x; i < NB * 64; i += kBqPassBlock) (&s_b[0][0])[i] = reinterpret_cast<const uint4*>(bfrag)[i];
+    }
     // pass 2 with tile maxima: the thresholds as packed fp16 pairs in the maxima's layout — dword d of query column c
     // holds T' of query c of blocks 2d and 2d + 1, rounded DOWN; +inf for a query that is not served here (queued /
     // padding: its threshold slots hold -65504 and nothing ever passes)
@@ -518,28 +556,33 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
             // global per-query counters are only touched when the buffer is flushed, 64 entries
             // per round trip.  A returning global atomic per hit kept each wave waiting ~1.5 us
             // about 160 times per pass (measured: 555 vs 485 us).
+            // The rare path, and not a cheap one: measured (tools/bq_exp.sh), the blocks that hold a hit cost three times
+            // what a block without one does — 27 % of a whole pass at 0.13 hits per (tile, block).  So no ballot and
+            // branch per result register: each lane first packs the SIGN bits of its 16 results into a mask (one
+            // v_alignbit each: mask = mask << 1 | sign), and only lanes with a clear bit walk it, one hit per round —
+            // the rounds are wave-uniform and there is usually exactly one.
             auto push_hits = [&](const bq_f16v& d, int blk, int sub) {
                 const uint32_t q = static_cast<uint32_t>(blk * 32 + r);
+                uint32_t signs = 0u;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const bool hit = static_cast<int>(__float_as_uint(d[i])) >= 0;
-                    const uint64_t who = __ballot(hit);
-                    if (who) {   // wave-uniform
-                        const int n_hit = __popcll(who);
-                        if (staged + n_hit > kStageCap) {
-                            bq_flush_stage(stage, staged, lane, cand_count, cand_rows);
-                            staged = 0;
-                        }
-                        if (hit) {
-                            const int slot = staged + lanes_below(who);
-                            // opaque on purpose: otherwise the compiler hoists all row ids of a tile
-                            // out of this rare path into the tile prologue and spills them
-                            uint32_t row_lo = static_cast<uint32_t>(tile * 64) + static_cast<uint32_t>(sub * 32 + 4 * h);
-                            asm volatile("" : "+v"(row_lo));
-                            stage[slot] = make_uint2(q, row_lo + static_cast<uint32_t>((i & 3) + 8 * (i >> 2)));
-                        }
-                        staged += n_hit;
+                for (int i = 15; i >= 0; --i) signs = __builtin_amdgcn_alignbit(signs, __float_as_uint(d[i]), 31);   // bit i = sign of d[i]
+                uint32_t hits = ~signs & 0xffffu;   // D >= +0: approx >= T'
+                // opaque on purpose: otherwise the compiler hoists the row ids out of this rare path into the tile
+                // prologue and spills them
+                uint32_t row_lo = static_cast<uint32_t>(tile * 64) + static_cast<uint32_t>(sub * 32 + 4 * h);
+                asm volatile("" : "+v"(row_lo));
+                for (uint64_t who = __ballot(hits != 0u); who; who = __ballot(hits != 0u)) {   // wave-uniform rounds
+                    const int n_hit = __popcll(who);
+                    if (staged + n_hit > kStageCap) {
+                        bq_flush_stage(stage, staged, lane, cand_count, cand_rows);
+                        staged = 0;
                     }
+                    if (hits) {
+                        const int i = __builtin_ctz(hits);
+                        hits &= hits - 1u;
+                        stage[staged + lanes_below(who)] = make_uint2(q, row_lo + static_cast<uint32_t>((i & 3) + 8 * (i >> 2)));
+                    }
+                    staged += n_hit;
                 }
             };
             // ONE hit test per query block (both 32-row sub-tiles): 16 maxima + 1 compare + 1

@@ -1312,14 +1312,22 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
 // are indices into queries_dev / exclude_dev; they are served in groups of
 // kMultiQueries inside ONE launch (no seed: this is the rare, robust path), lists go
 // to block_lists[position in the queue][workgroup][topk].  Exits at once when the
-// queue is empty.
+// queue is empty — the usual case, in which this launch costs its dispatch and nothing else.
+// The merge of those lists is part of the launch as well (it used to be a second kernel that
+// every batched call paid for): the workgroup that finishes LAST merges every queued query's lists
+// into that query's output row.  Rare path, so the hand-off is the plain one: a device-wide fence
+// before each workgroup counts itself out and one behind the count of the last (`arrive` is zero
+// between launches: the last workgroup resets it, and a launch with an empty queue never touches it).
 template <typename Cfg>
 __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_queued_kernel(
     const float* __restrict__ feats, int64_t n, int iters, int64_t row_base,
     const float* __restrict__ queries_dev, const long long* __restrict__ exclude_dev,
     const int* __restrict__ queue, const int* __restrict__ queue_count, int topk,
-    uint64_t* __restrict__ block_lists) {
+    uint64_t* __restrict__ block_lists, unsigned* __restrict__ arrive,
+    uint64_t* __restrict__ out_keys_base, int64_t* __restrict__ out_idx_base, float* __restrict__ out_score_base,
+    int64_t out_query_stride) {
     const int count = *queue_count;
+    if (count == 0) return;   // uniform over the whole grid
     for (int g0 = 0; g0 < count; g0 += kMultiQueries) {
         const int nq = count - g0 < kMultiQueries ? count - g0 : kMultiQueries;
         auto load_query = [&](int t, float (&qv)[kDim], long long& excl) {
@@ -1330,6 +1338,24 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_queued
         };
         multi_scan_group<Cfg>(feats, n, static_cast<int64_t>(0), static_cast<int64_t>(0), iters, row_base, load_query,
                               nq, g0, topk, block_lists, static_cast<const uint64_t*>(nullptr), 0);
+        __syncthreads();
+    }
+    __shared__ int s_last;
+    __threadfence();   // this workgroup's lists are visible device-wide ...
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const bool last = atomicAdd(arrive, 1u) + 1u == gridDim.x;   // ... before it is counted
+        if (last) *arrive = 0u;
+        s_last = last ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;   // uniform
+    __threadfence();       // ... and the last one sees everybody's
+    __shared__ MergeSmemT<Cfg::kBlock, 1024, kMergeSurvCap> s_merge;   // (one workgroup per CU fits with this: the launch has no more)
+    for (int b = 0; b < count; ++b) {
+        merge_body(s_merge, block_lists, static_cast<int>(gridDim.x), topk, static_cast<int64_t>(topk),
+                   static_cast<int64_t>(gridDim.x) * topk, topk, out_keys_base, out_idx_base, out_score_base, out_query_stride,
+                   static_cast<int64_t>(b), static_cast<int64_t>(queue[b]));
         __syncthreads();
     }
 }
@@ -1453,19 +1479,6 @@ __global__ __launch_bounds__(kMergeBlock) void merge_notify_kernel(
     __threadfence_system();   // every thread: its result stores are ordered before ...
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(done_word, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... the word
-}
-
-// Merge of the lists written by scan_multi_queued_kernel: workgroup b serves the b-th
-// queued query (if there is one) and writes to that query's output row.
-__global__ __launch_bounds__(kMergeBlock) void merge_queued_kernel(
-    const uint64_t* __restrict__ lists_base, int n_lists, int list_len, int64_t list_stride,
-    int64_t lists_query_stride, int topk, const int* __restrict__ queue, const int* __restrict__ queue_count,
-    uint64_t* __restrict__ out_keys_base, int64_t* __restrict__ out_idx_base, float* __restrict__ out_score_base,
-    int64_t out_query_stride) {
-    if (static_cast<int>(blockIdx.x) >= *queue_count) return;
-    __shared__ MergeSmemT<kMergeBlock, kMergeMaxLists, kMergeSurvCap> sm;
-    merge_body(sm, lists_base, n_lists, list_len, list_stride, lists_query_stride, topk, out_keys_base, out_idx_base,
-               out_score_base, out_query_stride, blockIdx.x, queue[blockIdx.x]);
 }
 
 // ---- read-only streaming probe (achievable-HBM ceiling) ---------------------

@@ -1417,7 +1417,7 @@ int ensure_bq_alloc(mi355rec* h) {
         if (v == 1 || v == 2 || v == 4 || v == 8) b.step1 = v;
     }
 #endif
-    b.qgrid = h->cus < kMergeMaxLists ? h->cus : kMergeMaxLists;
+    b.qgrid = h->cus < 1024 ? h->cus : 1024;   // (the queued scan's last workgroup merges up to 1024 lists per query)
     const int64_t tiles = (h->n + MultiConfig::kTileRows - 1) / MultiConfig::kTileRows;
     if (tiles < b.qgrid) b.qgrid = static_cast<int>(tiles);
     b.qiters = static_cast<int>((tiles + b.qgrid - 1) / b.qgrid);
@@ -1428,7 +1428,8 @@ int ensure_bq_alloc(mi355rec* h) {
     HIP_TRY(h, hipMalloc(&b.cand_count, sizeof(int) * kBqMaxQueries * kBqCountStride));
     HIP_TRY(h, hipMemsetAsync(b.cand_count, 0, sizeof(int) * kBqMaxQueries * kBqCountStride, h->stream));
     HIP_TRY(h, hipMalloc(&b.cand_rows, sizeof(uint32_t) * static_cast<size_t>(kBqMaxQueries) * kBqCap));
-    HIP_TRY(h, hipMalloc(&b.counters, sizeof(int) * 4));
+    HIP_TRY(h, hipMalloc(&b.counters, sizeof(int) * 8));   // [0..3]: batched.hip.h; [4]: the queued scan's arrival counter
+    HIP_TRY(h, hipMemsetAsync(b.counters, 0, sizeof(int) * 8, h->stream));
     HIP_TRY(h, hipMalloc(&b.special_rows, sizeof(uint32_t) * kBqSpecialCap));
     HIP_TRY(h, hipMalloc(&b.gmax, sizeof(float) * static_cast<size_t>(grid) * kBqMaxBlocks * 64));
     // Room for the tile maxima of pass 1 (rows from the replica only).  Optional: without it pass 2 looks at every
@@ -1481,28 +1482,46 @@ void free_bq(mi355rec* h) {
 }
 
 template <int NB, bool kFromReplica, bool kTileMax>
-void launch_bq_passes(mi355rec* h, int topn, hipStream_t s) {
+void launch_bq_passes(mi355rec* h, const float* d_queries, int count, int topn, hipStream_t s) {
     auto& b = h->bq;
     const int64_t n_tiles = (h->n + 63) / 64;   // a wave handles 64 rows (two 32-row MFMA tiles) at a time
     const int step1 = bq_step1(h, n_tiles);
     const size_t smem = sizeof(float) * b.grid * 2 * 5 + sizeof(int) * (kBqSelectBlock / 64) * 256;
     const uint2* half = reinterpret_cast<const uint2*>(h->d_half);
+    if constexpr (!kFromReplica) {   // (the replica-sourced pass 1 prepares the queries itself: no launch in front of it)
+        hipLaunchKernelGGL(bq_prepare_kernel, dim3((NB * 32 + 255) / 256), dim3(256), 0, s, d_queries, count, NB, b.bfrag,
+                           b.qnorm, b.qflags, b.cand_count, b.counters);
+        d_queries = nullptr;
+    }
     int slot = timing_begin(h, h->ev_pass, h->n_pass_pairs, h->pass_launches, s);
     hipLaunchKernelGGL((bq_pass_kernel<NB, false, 0, kFromReplica, kTileMax>), dim3(b.grid), dim3(kBqPassBlock), 0, s, h->d_feats, h->n,
                        n_tiles, step1, b.bfrag, b.gmax, b.cand_count, b.cand_rows, b.counters, b.special_rows, half,
-                       b.tile_max, step1, static_cast<const float*>(b.qthr), static_cast<const uint32_t*>(b.qflags));
+                       b.tile_max, step1, static_cast<const float*>(b.qthr), static_cast<const uint32_t*>(b.qflags),
+                       d_queries, count, b.qnorm, b.qflags);
     timing_end(h, h->ev_pass, h->n_pass_pairs, slot, s);
     hipLaunchKernelGGL(bq_select_kernel, dim3(NB * 8), dim3(kBqSelectBlock), smem, s, b.gmax, b.grid, NB, topn, b.margin, b.bfrag,
                        b.qflags, b.qthr);
+    int skip_step = step1;
+#ifdef MI355REC_EXPERIMENTS   // tools builds only: where does pass 2's time go (tools/bq_ab.sh)
+    if (const char* e = std::getenv("MI355REC_BQ_EXP")) {
+        const int v = std::atoi(e);
+        if (v == 1) skip_step = 1 << 30;   // no tile counts as visited: the new loop over ALL blocks of every tile
+        if (v == 2 && kTileMax) {          // every visited tile skips ALL its blocks: what a tile costs without any
+            static std::vector<float> inf(kBqMaxQueries, __builtin_inff());
+            (void)hipMemcpyAsync(b.qthr, inf.data(), sizeof(float) * kBqMaxQueries, hipMemcpyHostToDevice, s);
+        }
+    }
+#endif
     slot = timing_begin(h, h->ev_pass, h->n_pass_pairs, h->pass_launches, s);
     hipLaunchKernelGGL((bq_pass_kernel<NB, true, 0, kFromReplica, kTileMax>), dim3(b.grid2), dim3(kBqPassBlock), 0, s, h->d_feats, h->n,
                        n_tiles, 1, b.bfrag, b.gmax, b.cand_count, b.cand_rows, b.counters, b.special_rows, half,
-                       b.tile_max, step1, static_cast<const float*>(b.qthr), static_cast<const uint32_t*>(b.qflags));
+                       b.tile_max, skip_step, static_cast<const float*>(b.qthr), static_cast<const uint32_t*>(b.qflags),
+                       static_cast<const float*>(nullptr), 0, static_cast<float*>(nullptr), static_cast<uint32_t*>(nullptr));
     timing_end(h, h->ev_pass, h->n_pass_pairs, slot, s);
 }
 
 template <int NB>
-void launch_bq_passes(mi355rec* h, int topn, hipStream_t s) {
+void launch_bq_passes(mi355rec* h, const float* d_queries, int count, int topn, hipStream_t s) {
     // the passes read the fp16 replica when the handle has one (it holds their A operand ready-made)
     if (h->d_half && h->replica_mode != MI355REC_REPLICA_OFF) {
         // 512 queries and more: pass 1 also leaves the maxima of the tiles it looked at, pass 2 skips what they rule out
@@ -1510,13 +1529,13 @@ void launch_bq_passes(mi355rec* h, int topn, hipStream_t s) {
             const int64_t n_tiles = (h->n + 63) / 64;
             const int step1 = bq_step1(h, n_tiles);
             if (h->batch_path != MI355REC_BATCH_MFMA_NOSKIP && h->bq.tile_max && (n_tiles + step1 - 1) / step1 <= h->bq.tile_max_tiles) {
-                launch_bq_passes<NB, true, true>(h, topn, s);
+                launch_bq_passes<NB, true, true>(h, d_queries, count, topn, s);
                 return;
             }
         }
-        launch_bq_passes<NB, true, false>(h, topn, s);
+        launch_bq_passes<NB, true, false>(h, d_queries, count, topn, s);
     } else {
-        launch_bq_passes<NB, false, false>(h, topn, s);
+        launch_bq_passes<NB, false, false>(h, d_queries, count, topn, s);
     }
 }
 
@@ -1527,27 +1546,24 @@ int enqueue_bq_chunk(mi355rec* h, const float* d_queries, const long long* d_exc
     const int blocks = (count + 31) / 32;
     int nb = 1;
     while (nb < blocks) nb *= 2;
-    hipLaunchKernelGGL(bq_prepare_kernel, dim3((nb * 32 + 255) / 256), dim3(256), 0, s, d_queries, count, nb, b.bfrag,
-                       b.qnorm, b.qflags, b.cand_count, b.counters);
+    // (no preparation launch where the rows come from the replica: pass 1 builds the fragments itself, batched.hip.h)
     switch (nb) {
-        case 1: launch_bq_passes<1>(h, topn, s); break;
-        case 2: launch_bq_passes<2>(h, topn, s); break;
-        case 4: launch_bq_passes<4>(h, topn, s); break;
-        case 8: launch_bq_passes<8>(h, topn, s); break;
-        case 16: launch_bq_passes<16>(h, topn, s); break;
-        default: launch_bq_passes<32>(h, topn, s); break;
+        case 1: launch_bq_passes<1>(h, d_queries, count, topn, s); break;
+        case 2: launch_bq_passes<2>(h, d_queries, count, topn, s); break;
+        case 4: launch_bq_passes<4>(h, d_queries, count, topn, s); break;
+        case 8: launch_bq_passes<8>(h, d_queries, count, topn, s); break;
+        case 16: launch_bq_passes<16>(h, d_queries, count, topn, s); break;
+        default: launch_bq_passes<32>(h, d_queries, count, topn, s); break;
     }
     hipLaunchKernelGGL(bq_finalize_kernel, dim3(count), dim3(kBqFinalBlock), 0, s, h->d_feats, h->row_base, d_queries,
                        d_exclude, count, topn, b.qflags, b.cand_count, b.cand_rows, b.counters, b.special_rows, b.queue,
                        out_keys, out_idx, out_score);
-    // The exact multi-query scan for whatever the bound could not be claimed for
-    // (usually nothing: both launches exit at once on an empty queue).
+    // The exact multi-query scan for whatever the bound could not be claimed for, its merge included (usually
+    // nothing: the launch exits at once on an empty queue).
     hipLaunchKernelGGL((scan_multi_queued_kernel<MultiConfig>), dim3(b.qgrid), dim3(MultiConfig::kBlock), 0, s,
                        h->d_feats, h->n, b.qiters, h->row_base, d_queries, d_exclude, b.queue, b.counters + 1, topn,
-                       b.qlists);
-    hipLaunchKernelGGL(merge_queued_kernel, dim3(count), dim3(kMergeBlock), 0, s, b.qlists, b.qgrid, topn,
-                       static_cast<int64_t>(topn), static_cast<int64_t>(b.qgrid) * topn, topn, b.queue, b.counters + 1,
-                       out_keys, out_idx, out_score, static_cast<int64_t>(topn));
+                       b.qlists, reinterpret_cast<unsigned*>(b.counters + 4), out_keys, out_idx, out_score,
+                       static_cast<int64_t>(topn));
     HIP_TRY(h, hipGetLastError());
     ++b.launches;
     b.last_count = count;

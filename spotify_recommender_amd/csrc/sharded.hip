@@ -66,6 +66,7 @@
 #include <string>
 #include <vector>
 
+#include "cpu_backend.h"
 #include "mi355rec.h"
 
 namespace {
@@ -205,6 +206,10 @@ int64_t now_ns() {
 
 struct mi355rec_sharded {
     int64_t n = 0;
+    // A host WITHOUT a HIP device: the product's own CPU backend (csrc/cpu_backend.h; the reference's
+    // "Falling back to CPU", Recommender.cu:117-127,176-181) serves the whole C-ABI of this handle and
+    // everything below stays empty.  Never set when a device is visible.
+    mi355cpu::Node* cpu = nullptr;
     std::vector<Shard> shards;
     int transport = MI355REC_TRANSPORT_PEER;
     bool peer_ok = true;
@@ -280,6 +285,11 @@ int sfail(mi355rec_sharded* h, int code, const char* fmt, ...) {
         if (rc_ != MI355REC_OK)                                                                    \
             return sfail((h), rc_, "shard on device %d: %s", (shard).device, mi355rec_last_error((shard).engine)); \
     } while (0)
+
+// the CPU backend's calls report (code, message) like this
+int cpu_result(mi355rec_sharded* h, int rc, const char* why) {
+    return rc == MI355REC_OK ? rc : sfail(h, rc, "%s", why ? why : "CPU backend: invalid argument");
+}
 
 // balanced contiguous blocks: the first n % g shards hold one row more
 void bounds(int64_t n, int g, int r, int64_t& lo, int64_t& hi) {
@@ -1083,6 +1093,11 @@ const char* mi355rec_sharded_last_error(const mi355rec_sharded_t* h) {
 
 void mi355rec_sharded_destroy(mi355rec_sharded_t* h) {
     if (!h) return;
+    if (h->cpu) {
+        mi355cpu::node_destroy(h->cpu);
+        delete h;
+        return;
+    }
     DeviceRestore restore;
     stop_workers(h);   // they finish what has been posted first
     for (Shard& s : h->shards) {
@@ -1270,8 +1285,27 @@ int mi355rec_create_placed(const float* feats_host, int64_t n, int dim, const in
     if (placement != MI355REC_PLACEMENT_AUTO && placement != MI355REC_PLACEMENT_SHARDED && placement != MI355REC_PLACEMENT_REPLICATED)
         return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "unknown placement %d", placement);
     const int visible = mi355rec_device_count();
-    if (visible <= 0)
-        return sfail(nullptr, MI355REC_ERR_NO_DEVICE, "no HIP device visible: the MI355X engine has no CPU fallback");
+    if (visible <= 0) {
+        // No device at all.  An explicit device list cannot be honoured; otherwise the catalogue is served by the
+        // product's own CPU backend, as the reference falls back to its CPU loop (Recommender.cu:117-127,176-181).
+        if (devices || n_devices > 0)
+            return sfail(nullptr, MI355REC_ERR_NO_DEVICE, "no HIP device visible, and %d device(s) were asked for", n_devices);
+        if (!out || !feats_host) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null argument");
+        if (dim != MI355REC_DIM) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "dim must be %d, got %d", MI355REC_DIM, dim);
+        if (n < 1 || n > 0xfffffffell) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "rows %lld out of range", (long long)n);
+        mi355rec_sharded* h = new mi355rec_sharded();
+        h->n = n;
+        h->peer_rows = false;
+        h->cpu = mi355cpu::node_create(feats_host, n);
+        if (!h->cpu) {
+            delete h;
+            return sfail(nullptr, MI355REC_ERR_OUT_OF_MEMORY, "CPU backend: cannot hold %lld rows", (long long)n);
+        }
+        h->note = "CPU backend: no HIP device visible (" + std::to_string(mi355cpu::threads(mi355cpu::node_catalogue(h->cpu))) +
+                  " OpenMP thread(s))";
+        *out = h;
+        return MI355REC_OK;
+    }
     std::vector<int> devs;
     if (devices) {   // an explicit list (a device may repeat: virtual shards / replicas on a one-GPU box)
         if (n_devices < 1 || n_devices > MI355REC_MAX_SHARDS)
@@ -1296,12 +1330,13 @@ int mi355rec_create_sharded(const float* feats_host, int64_t n, int dim, int n_d
 
 int mi355rec_sharded_placement(const mi355rec_sharded_t* h) {
     if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    if (h->cpu) return MI355REC_PLACEMENT_CPU;
     return h->replicated ? MI355REC_PLACEMENT_REPLICATED : MI355REC_PLACEMENT_SHARDED;
 }
 
 int mi355rec_sharded_set_transport(mi355rec_sharded_t* h, int transport) {
     if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
-    if (h->replicated) {   // nothing is ever exchanged between replicas: either value is accepted and ignored
+    if (h->replicated || h->cpu) {   // nothing is ever exchanged (replicas; the CPU backend): either value is accepted and ignored
         if (transport != MI355REC_TRANSPORT_PEER && transport != MI355REC_TRANSPORT_RCCL)
             return sfail(h, MI355REC_ERR_INVALID_ARG, "unknown transport %d", transport);
         return MI355REC_OK;
@@ -1339,6 +1374,7 @@ const char* mi355rec_sharded_note(const mi355rec_sharded_t* h) { return h ? h->n
 
 int mi355rec_sharded_set_timing(mi355rec_sharded_t* h, int enabled) {
     if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    if (h->cpu) return MI355REC_OK;   // (no kernels to time)
     const int drc = drain_workers(h);
     if (drc) return drc;
     for (Shard& s : h->shards) S_ENG(h, s, mi355rec_set_timing(s.engine, enabled));
@@ -1348,7 +1384,8 @@ int mi355rec_sharded_set_timing(mi355rec_sharded_t* h, int enabled) {
 int mi355rec_sharded_shard_stats(const mi355rec_sharded_t* hc, int shard, mi355rec_stats_t* out) {
     mi355rec_sharded_t* h = const_cast<mi355rec_sharded_t*>(hc);
     if (!h || !out) return sfail(h, MI355REC_ERR_INVALID_ARG, "null argument");
-    if (shard < 0 || shard >= static_cast<int>(h->shards.size())) return sfail(h, MI355REC_ERR_INVALID_ARG, "no shard %d", shard);
+    if (shard < 0 || shard >= static_cast<int>(h->shards.size()))
+        return sfail(h, MI355REC_ERR_INVALID_ARG, h->cpu ? "the CPU backend has no device shard %d" : "no shard %d", shard);
     const int drc = drain_workers(h);
     if (drc) return drc;
     const Shard& s = h->shards[shard];
@@ -1358,6 +1395,7 @@ int mi355rec_sharded_shard_stats(const mi355rec_sharded_t* hc, int shard, mi355r
 
 int mi355rec_sharded_set_replica(mi355rec_sharded_t* h, int mode) {
     if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    if (h->cpu) return MI355REC_OK;   // (the CPU backend scans the fp32 rows, always)
     DeviceRestore restore;
     int rc = stream_flush(h);
     if (rc) return rc;
@@ -1378,6 +1416,16 @@ int mi355rec_sharded_query_batch_topn(mi355rec_sharded_t* h, const float* querie
     if (!h || !queries || !out_idx) return sfail(h, MI355REC_ERR_INVALID_ARG, "null argument");
     if (batch < 1) return sfail(h, MI355REC_ERR_INVALID_ARG, "batch must be positive");
     if (topn <= 0) return sfail(h, MI355REC_ERR_INVALID_ARG, "topn must be positive, got %d", topn);
+    if (h->cpu) {
+        for (int b = 0; b < batch; ++b) {
+            const char* why = nullptr;
+            const int rc = mi355cpu::node_query(h->cpu, queries + static_cast<size_t>(b) * MI355REC_DIM, exclude_global ? exclude_global[b] : -1,
+                                                topn, out_idx + static_cast<size_t>(b) * topn,
+                                                out_score ? out_score + static_cast<size_t>(b) * topn : nullptr, out_count ? out_count + b : nullptr, &why);
+            if (rc) return cpu_result(h, rc, why);
+        }
+        return MI355REC_OK;
+    }
     if (h->shards.size() == 1) {   // one shard: its own handle is the whole engine (row_base 0)
         const int rc = mi355rec_query_batch_topn(h->shards[0].engine, queries, batch, exclude_global, topn, out_idx, out_score, out_count);
         return rc == MI355REC_OK ? rc : sfail(h, rc, "%s", mi355rec_last_error(h->shards[0].engine));
@@ -1411,6 +1459,11 @@ int mi355rec_sharded_query_row_topn(mi355rec_sharded_t* h, int64_t global_row, i
     if (global_row < 0 || global_row >= h->n)
         return sfail(h, MI355REC_ERR_INVALID_ARG, "Invalid song index: %lld", (long long)global_row);
     if (topn <= 0) return sfail(h, MI355REC_ERR_INVALID_ARG, "topn must be positive, got %d", topn);
+    if (h->cpu) {
+        const char* why = nullptr;
+        return cpu_result(h, mi355cpu::node_query(h->cpu, mi355cpu::row(mi355cpu::node_catalogue(h->cpu), global_row), global_row, topn,
+                                                  out_idx, out_score, out_count, &why), why);
+    }
     if (h->shards.size() == 1) {   // what Recommender::recommendByIndex costs on a one-GPU box: exactly mi355rec_query_row_topn
         const int rc = mi355rec_query_row_topn(h->shards[0].engine, global_row, topn, out_idx, out_score, out_count);
         return rc == MI355REC_OK ? rc : sfail(h, rc, "%s", mi355rec_last_error(h->shards[0].engine));
@@ -1447,6 +1500,11 @@ int mi355rec_sharded_scores_row(mi355rec_sharded_t* h, int64_t global_row, float
     if (!h || !out_host) return sfail(h, MI355REC_ERR_INVALID_ARG, "null argument");
     if (global_row < 0 || global_row >= h->n)
         return sfail(h, MI355REC_ERR_INVALID_ARG, "Invalid song index: %lld", (long long)global_row);
+    if (h->cpu) {
+        const mi355cpu::Catalogue* c = mi355cpu::node_catalogue(h->cpu);
+        mi355cpu::scores(c, mi355cpu::row(c, global_row), out_host);
+        return MI355REC_OK;
+    }
     DeviceRestore restore;
     if (h->replicated) {
         Shard* s = nullptr;
@@ -1474,6 +1532,10 @@ int mi355rec_sharded_scores_row(mi355rec_sharded_t* h, int64_t global_row, float
 int mi355rec_sharded_set_window(mi355rec_sharded_t* h, int window) {
     if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
     if (window < 1 || window > kMaxWindow) return sfail(h, MI355REC_ERR_INVALID_ARG, "window must be in [1, %d], got %d", kMaxWindow, window);
+    if (h->cpu) {
+        const char* why = nullptr;
+        return cpu_result(h, mi355cpu::node_set_window(h->cpu, window, &why), why);
+    }
     if (window == h->s_window) return MI355REC_OK;
     DeviceRestore restore;
     int rc = stream_flush(h);   // the open window is closed in the old geometry
@@ -1500,6 +1562,7 @@ int mi355rec_sharded_set_window(mi355rec_sharded_t* h, int window) {
 
 int mi355rec_sharded_set_window_mode(mi355rec_sharded_t* h, int batched) {
     if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    if (h->cpu) return MI355REC_OK;   // (a query is computed when it is enqueued, either way)
     if ((batched != 0) == h->batched_windows) return MI355REC_OK;
     DeviceRestore restore;
     int rc = stream_flush(h);
@@ -1524,6 +1587,10 @@ int mi355rec_sharded_set_window_mode(mi355rec_sharded_t* h, int batched) {
 int mi355rec_sharded_enqueue_query(mi355rec_sharded_t* h, const float* query12, int64_t exclude_global, int topn,
                                    int64_t* ticket) {
     if (!h || !query12) return sfail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (h->cpu) {
+        const char* why = nullptr;
+        return cpu_result(h, mi355cpu::node_enqueue(h->cpu, query12, exclude_global, topn, ticket, &why), why);
+    }
     DeviceRestore restore;
     return stream_enqueue(h, nullptr, query12, exclude_global, topn, ticket);
 }
@@ -1532,6 +1599,11 @@ int mi355rec_sharded_enqueue_row(mi355rec_sharded_t* h, int64_t global_row, int 
     if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
     if (global_row < 0 || global_row >= h->n)
         return sfail(h, MI355REC_ERR_INVALID_ARG, "Invalid song index: %lld", (long long)global_row);
+    if (h->cpu) {
+        const char* why = nullptr;
+        return cpu_result(h, mi355cpu::node_enqueue(h->cpu, mi355cpu::row(mi355cpu::node_catalogue(h->cpu), global_row), global_row, topn,
+                                                    ticket, &why), why);
+    }
     DeviceRestore restore;
     float q[MI355REC_DIM] = {0};
     const float* qptr = nullptr;
@@ -1544,6 +1616,7 @@ int mi355rec_sharded_enqueue_row(mi355rec_sharded_t* h, int64_t global_row, int 
 
 int mi355rec_sharded_enqueue_flush(mi355rec_sharded_t* h) {
     if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    if (h->cpu) return mi355cpu::node_flush(h->cpu);
     DeviceRestore restore;
     const int64_t t0 = now_ns();
     const int rc = stream_flush(h);
@@ -1553,6 +1626,10 @@ int mi355rec_sharded_enqueue_flush(mi355rec_sharded_t* h) {
 
 int mi355rec_sharded_wait(mi355rec_sharded_t* h, int64_t ticket, int64_t* out_idx, float* out_score, int* out_count) {
     if (!h || !out_idx) return sfail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (h->cpu) {
+        const char* why = nullptr;
+        return cpu_result(h, mi355cpu::node_wait(h->cpu, ticket, out_idx, out_score, out_count, &why), why);
+    }
     if (!h->s_topn || ticket < 0 || ticket >= h->next_ticket)
         return sfail(h, MI355REC_ERR_INVALID_ARG, "ticket %lld was never handed out", (long long)ticket);
     DeviceRestore restore;
@@ -1580,6 +1657,10 @@ int mi355rec_sharded_wait(mi355rec_sharded_t* h, int64_t ticket, int64_t* out_id
 
 int mi355rec_sharded_stream_stats(const mi355rec_sharded_t* h, int64_t* queries, int64_t* exchanges, int64_t* host_ns) {
     if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    if (h->cpu) {
+        mi355cpu::node_stream_stats(h->cpu, queries, exchanges, host_ns);   // ("exchanges": windows opened)
+        return MI355REC_OK;
+    }
     if (queries) *queries = h->st_queries;
     if (exchanges) *exchanges = h->st_exchanges;
     if (host_ns) *host_ns = h->st_host_ns;

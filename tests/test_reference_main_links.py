@@ -6,7 +6,7 @@ Recommender.cpp + DataManager.cpp + libmi355rec.so with exactly the command INTE
 Build container only: skipped where /root/reference does not exist (the GPU box).  The reference file is
 copied to a pytest temp directory for the compile (quoted includes look next to the including file first,
 and next to the original lie the reference's own headers); nothing of it is ever stored in the repository.  Without a GPU the binary's query
-modes fail loudly (no CPU fallback), which is what the second half checks."""
+modes are answered by the product's CPU backend (csrc/cpu_backend.cpp), as the reference's are by its CPU loop."""
 import shutil
 import subprocess
 from pathlib import Path
@@ -56,10 +56,12 @@ def test_reference_main_runs_against_the_library(exe, golden_dir, tmp_path):
     p = subprocess.run([exe, "--preprocess", str(golden_dir / "sample_songs.csv")], capture_output=True, text=True, cwd=tmp_path)
     assert p.returncode == 0, p.stdout + p.stderr
     assert (tmp_path / "songs_data.bin").read_bytes() == (golden_dir / "sample_songs_data.bin").read_bytes()
-    # a query: with a GPU it answers; without one it fails loudly (documented deviation: no CPU fallback)
+    # a query: answered on the GPU where there is one, by the product's CPU backend where there is none — as the
+    # reference's own binary answers from its CPU loop without a GPU (Recommender.cu:117-127,176-181)
     p = subprocess.run([exe, "--id", "dupA", "-n", "10"], capture_output=True, text=True, cwd=tmp_path)
+    assert p.returncode == 0 and "Top 3" in p.stdout, p.stdout + p.stderr
     import torch
     if torch.cuda.is_available():
-        assert p.returncode == 0 and "Top 3" in p.stdout, p.stdout + p.stderr
+        assert "songs on GPU" in p.stdout and "CPU fallback" not in p.stdout
     else:
-        assert p.returncode == 1 and "no CPU fallback" in p.stderr, p.stdout + p.stderr
+        assert "Operating in CPU fallback mode (cosine similarity on CPU)." in p.stdout, p.stdout + p.stderr
