@@ -55,6 +55,11 @@ def parse_args():
                          "0 = choose so that at least 16 launches are timed")
     ap.add_argument("--batch", type=int, default=1024, help="queries per call of the batched (configs[4]) leg")
     ap.add_argument("--no-batched", action="store_true")
+    ap.add_argument("--no-c5-shard", action="store_true",
+                    help="skip the second batched leg (a 12.5 M-row shard of BASELINE configs[4], its own catalogue)")
+    ap.add_argument("--placement", choices=["sharded", "replicated"], default="sharded",
+                    help="N > 1, single process: rows split over the devices (north_star), or every device holds all rows "
+                         "and serves whole windows of the stream (include/mi355rec.h, PLACEMENT)")
     ap.add_argument("--window", type=int, default=16,
                     help="N > 1: single queries whose per-rank keys share one all-gather")
     ap.add_argument("--no-streamed", action="store_true",
@@ -105,49 +110,55 @@ def replica_desc(st):
             "scan_kernel", "f32", "fp32 rows (48 B/row")
 
 
-def pmc_traffic(alg: int, want: str):
-    """HBM bytes per scan launch from the committed rocprofv3 PMC passes
-    (profiles/*_pmc_hbm_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs
-    of this same script, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950
-    correction).  PMC counters cannot be read from inside the timed process, so
-    this is only reported when the profiled launch had the same row count."""
-    try:
-        files = sorted((ROOT / "profiles").glob("*_pmc_hbm_traffic.json"))
-        data = json.loads(files[-1].read_text())
-        # several variants of a kernel may have been profiled (plain, streamed, lone): the one launched most often
-        # is the timed stream's
-        hits = [k for name, k in data["kernels"].items() if want in name and k.get("algorithmic_bytes_per_launch") == alg]
-        if hits:
-            k = max(hits, key=lambda e: e.get("FETCH_SIZE_launches", 0))
-            return int(k["hbm_bytes_per_launch"]), f"profiles/{files[-1].name}"
-    except Exception:
-        pass
-    return None, None
+def traffic_fields():
+    """`roofline.traffic` is null in the line: HBM bytes come from PMC counters (separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes over this same command), which the timed process cannot read about itself — earlier rounds copied
+    the figure of a committed profile into the line, which is a citation, not a measurement.  The profiles are the
+    evidence."""
+    files = sorted((ROOT / "profiles").glob("*_pmc_hbm_traffic.json"))
+    return {"traffic": None,
+            "traffic_note": "not measurable from inside the run; per-launch HBM bytes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                            "FETCH doubled per the guide's gfx950 correction) are in profiles/"
+                            + (files[-1].name if files else "*_pmc_hbm_traffic.json")}
 
 
-def host_threads(omp_max: int) -> int:
-    """Threads the CPU baseline may really use: affinity mask, cgroup quota, and
-    the GPU box's per-GPU CPU share (16) bound it, not the socket's core count."""
+def roofline_bound(alg_bytes: int) -> str:
+    """A buffer that a pass can still find in the 256 MiB Infinity Cache when it comes round again is not an HBM
+    stream: its rate is bound by the cache / fabric, and FETCH_SIZE counts cache hits as well (guide, HBM section)."""
+    return "infinity-cache" if alg_bytes <= 128 * 2**20 else "hbm"
+
+
+def host_threads(omp_max: int):
+    """Threads the CPU baseline may really use, and why: the affinity mask, the cgroup quota and BENCH_CPU_THREADS
+    (default 16 = the GPU box's CPU share per GPU) bound it, not the socket's core count."""
+    info = {"nproc": os.cpu_count(), "omp_max_threads": omp_max}
     n = omp_max
     try:
-        n = min(n, len(os.sched_getaffinity(0)))
+        info["affinity"] = len(os.sched_getaffinity(0))
+        n = min(n, info["affinity"])
     except Exception:
-        pass
+        info["affinity"] = None
     try:
         quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        info["cgroup_cpus"] = None if quota == "max" else round(int(quota) / int(period), 2)
         if quota != "max":
             n = min(n, max(1, int(int(quota) / int(period))))
     except Exception:
-        pass
-    return max(1, min(n, int(os.environ.get("BENCH_CPU_THREADS", "16"))))
+        info["cgroup_cpus"] = None
+    info["thread_cap"] = int(os.environ.get("BENCH_CPU_THREADS", "16"))
+    info["thread_cap_source"] = "BENCH_CPU_THREADS" if "BENCH_CPU_THREADS" in os.environ else "default 16: a GPU box's CPU share per GPU"
+    n = max(1, min(n, info["thread_cap"]))
+    return n, info
 
 
 def cpu_baseline(feats_host, topn, query_rows):
-    """The oracle timed on the host cores: B1 (OpenMP, all cores) is the reported
-    value, B0 (the reference's serial loop + heap) rides along.  Bounded sample."""
+    """The oracle timed on the host cores: B1 (OpenMP rows + per-thread top-N) is the reported value — the portable
+    build the checker uses (gcc -O3, no -march: the reference's own flags, Makefile:9) — with the same source built
+    -march=native beside it and B0 (the reference's serial loop + heap over its AoS layout) riding along.  Bounded
+    samples: ~8 + 4 + 6 s."""
     from oracle import oracle
 
-    threads = host_threads(oracle.max_threads())
+    threads, host = host_threads(oracle.max_threads())
     oracle.recommend_omp(feats_host, query_rows[0], topn, threads)  # touch pages / spin up the team
     t0 = time.perf_counter()
     done = 0
@@ -155,6 +166,19 @@ def cpu_baseline(feats_host, topn, query_rows):
         oracle.recommend_omp(feats_host, query_rows[done % len(query_rows)], topn, threads)
         done += 1
     omp_qps = done / (time.perf_counter() - t0)
+    native = None
+    try:
+        run_native, native_flags = oracle.native_recommend_omp()
+        run_native(feats_host, query_rows[0], topn, threads)
+        t0 = time.perf_counter()
+        nd = 0
+        while time.perf_counter() - t0 < 4.0:
+            run_native(feats_host, query_rows[nd % len(query_rows)], topn, threads)
+            nd += 1
+        native = {"value": round(nd / (time.perf_counter() - t0), 3), "unit": "queries/s", "cores": threads,
+                  "flags": native_flags, "sample": f"{nd} queries (4 s)"}
+    except Exception as e:   # no compiler on the box: the portable figure stands alone
+        native = {"unavailable": str(e)[:200]}
     # B0: the reference's serial loop over its AoS layout —
     # features at a 152-byte stride inside vector<Song> (Song.h:21-32)
     import numpy as np
@@ -171,7 +195,10 @@ def cpu_baseline(feats_host, topn, query_rows):
     return {
         "value": round(omp_qps, 3), "unit": "queries/s", "cores": threads, "kind": "port",
         "sample": f"{done} queries ({8.0:.0f} s) x {feats_host.shape[0]} rows top-{topn}, OpenMP rows + per-thread top-N "
-                  f"(oracle/cosine_oracle.c, gcc -O3, no -march)",
+                  f"(oracle/cosine_oracle.c)",
+        "flags": "gcc -std=c11 -O3 -fopenmp -ffp-contract=off, no -march (the reference's own: Makefile:9)",
+        "host": host,
+        "march_native": native,
         "serial_reference_loop_qps": round(serial_qps, 3),
         "serial_sample": f"{serial} queries (6 s), 1 core, 152-byte AoS row stride (Recommender.cu:256-318 restated)",
     }
@@ -207,7 +234,9 @@ def run_node(args, json_fd):
         del full
         torch.cuda.empty_cache()
 
-    node = NodeEngine(feats_host, devices=devices)
+    replicated = args.placement == "replicated"
+    node = NodeEngine(feats_host, devices=devices,
+                      placement=capi.PLACEMENT_REPLICATED if replicated else capi.PLACEMENT_SHARDED)
     info = node.info()
     node.set_window(args.window)
     # `value` is measured with one streamed scan launch per shard per QUERY (each query its own pass over
@@ -275,7 +304,7 @@ def run_node(args, json_fd):
         k_ms = sum(ms32) / len(ms32) if ms32 else 0.0
         fp32_rows = {"ms_per_step": round(dt32 / args.steps * 1e3, 5), "value": round(args.steps / dt32, 2), "unit": "queries/s",
                      "host_enqueue_us_per_query": round(host32, 2),
-                     "roofline": {"bound": "hbm", "algorithmic_bytes_per_launch": rows_local * BYTES_PER_ROW,
+                     "roofline": {"bound": roofline_bound(rows_local * BYTES_PER_ROW), "algorithmic_bytes_per_launch": rows_local * BYTES_PER_ROW,
                                   "avg_kernel_ms": round(k_ms, 5),
                                   "achieved": round(rows_local * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -301,7 +330,7 @@ def run_node(args, json_fd):
 
     # the other transport, same stream (real placements only: RCCL wants one device per shard)
     other = None
-    if not virtual and g > 1:
+    if not virtual and g > 1 and not replicated:
         try:
             node.set_transport(capi.TRANSPORT_RCCL if transport == capi.TRANSPORT_PEER else capi.TRANSPORT_PEER)
             dt2, _, _, host2, ex2 = timed_stream()
@@ -360,7 +389,6 @@ def run_node(args, json_fd):
     row_bytes, alg, kernel_label, kernel_name, dtype_label, replica_label = replica_desc(st_headline)
     kernel_label = kernel_label.format(targs="true, true") + f" ({replica_label})"
     achieved = alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None
-    traffic_bytes, traffic_source = pmc_traffic(alg, kernel_name)
     line = {
         "metric": metric_label(n, topn), "value": round(args.steps / elapsed, 2), "unit": "queries/s",
         "n_gpus": 1 if virtual else g, "steps": args.steps, "warmup": args.warmup,
@@ -369,16 +397,23 @@ def run_node(args, json_fd):
         "dtype": dtype_label,
         "data": "synthetic",
         "config": {
-            "workload": f"{n} synthetic tracks x 12 fp32 features, top-{topn}, row-sharded over "
-                        + (f"{g} VIRTUAL shards of one MI355X (orchestration rehearsal)" if virtual else f"{g} MI355X")
-                        + (" (BASELINE configs[3])" if (n == 10_000_000 and topn == 100) else ""),
-            "engine": "ONE process, the product's C-ABI: mi355rec_create_sharded" + ("_on" if virtual else "") + " (csrc/sharded.hip)",
+            "workload": f"{n} synthetic tracks x 12 fp32 features, top-{topn}, "
+                        + ("REPLICATED on " if replicated else "row-sharded over ")
+                        + (f"{g} VIRTUAL {'replicas' if replicated else 'shards'} of one MI355X (orchestration rehearsal)" if virtual else f"{g} MI355X")
+                        + (" (BASELINE configs[3])" if (n == 10_000_000 and topn == 100 and not replicated) else ""),
+            "engine": "ONE process, the product's C-ABI: mi355rec_create_placed (csrc/sharded.hip)",
+            "placement": args.placement,
+            "placement_note": ("every device holds all rows and serves whole windows of the stream, round-robin: no exchange"
+                               if replicated else
+                               "rows split into contiguous blocks, one per device; one exchange + one merge per window (north_star)"),
             "rows": n, "topn": topn, "shards": g, "virtual_shards": virtual, "devices": devices,
             "rows_per_shard": rows_local, "queries_per_step": 1,
             "transport": "peer" if transport == capi.TRANSPORT_PEER else "rccl",
             "rccl_ranks": g if (transport == capi.TRANSPORT_RCCL or (other is not None and other.get("transport") == "rccl"
                                                                     and "value" in other)) else None,
-            "window": args.window, "window_mode": "streamed: one scan launch per shard per query", "exchanges_in_timed_region": exchanges,
+            "window": args.window,
+            "window_mode": ("streamed: one scan launch per query on the window's replica" if replicated
+                            else "streamed: one scan launch per shard per query"), "exchanges_in_timed_region": exchanges,
             "rows_by_pointer": node.rows_by_pointer(), "note": node.note(),
             "merge": "per shard inside the next query's scan launch (streamed); one exchange + one batched merge per window; "
                      "last window flushed and its result awaited inside the timed region",
@@ -387,17 +422,17 @@ def run_node(args, json_fd):
         "p50_ms": round(lat[len(lat) // 2], 4) if lat else None,
         "p99_ms": round(lat[min(len(lat) - 1, int(len(lat) * 0.99))], 4) if lat else None,
         "roofline": {
-            "bound": "hbm", "per": "shard launch (mean over shards)",
+            "bound": roofline_bound(alg), "per": "shard launch (mean over shards)",
             "kernel": kernel_label,
             "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None,
-            "traffic": traffic_bytes, "traffic_source": traffic_source,
+            **traffic_fields(),
             "algorithmic_bytes_per_launch": alg, "bytes_per_row": row_bytes,
             "survey_bytes_per_row": BYTES_PER_ROW, "avg_kernel_ms": round(k_ms, 5) if k_ms else None,
             "kernel_ms_per_shard": [round(m, 5) for m in shard_ms],
             "infinity_cache_resident": bool(alg <= 128 * 2**20),
         },
-        "host": {"enqueue_us_per_query": round(host_us, 2), "launches_per_query": g,
+        "host": {"enqueue_us_per_query": round(host_us, 2), "launches_per_query": 1 if replicated else g,
                  "note": "wall time of the enqueue/flush calls on the one host thread (all shards), per query"},
         "verified_against_oracle": bool(ok), "verified_queries": checked,
     }
@@ -441,8 +476,8 @@ def main():
     if args.dry_run:
         from spotify_recommender_amd import capi
         capi.lib()   # the product library loads and exports every declared symbol
-        mode = ("node: one process, mi355rec_create_sharded over %d %s" % (
-                    args.virtual_shards if args.virtual_shards > 1 else args.gpus,
+        mode = ("node: one process, mi355rec_create_placed (%s) over %d %s" % (
+                    args.placement, args.virtual_shards if args.virtual_shards > 1 else args.gpus,
                     "virtual shards of device 0" if args.virtual_shards > 1 else "devices")
                 if (world == 1 and (args.gpus > 1 or args.virtual_shards > 1)) else
                 ("rank: one process per GPU over torch.distributed (RCCL), WORLD_SIZE=%d" % world if world > 1 else
@@ -594,16 +629,15 @@ def main():
         lat32.sort()
         eng.set_replica(replica_mode)
         k_ms = float(st32.last_scan_ms)
-        t32, src32 = pmc_traffic(hi - lo, False)
         fp32_rows = {"kernel": "mi355::scan_kernel<ScanCfg<512,1,6,2>, true, false, 0, true>", "steps": args.steps,
                      "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 5), "value": round(1.0 / dt, 2),
                      "unit": "queries/s", "p50_ms": round(lat32[len(lat32) // 2], 4) if lat32 else None,
-                     "roofline": {"bound": "hbm", "algorithmic_bytes_per_launch": (hi - lo) * BYTES_PER_ROW,
+                     "roofline": {"bound": roofline_bound((hi - lo) * BYTES_PER_ROW), "algorithmic_bytes_per_launch": (hi - lo) * BYTES_PER_ROW,
                                   "avg_kernel_ms": round(k_ms, 5),
                                   "achieved": round((hi - lo) * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                   "frac": round((hi - lo) * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if k_ms > 0 else None,
-                                  "traffic": t32, "traffic_source": src32}}
+                                  **traffic_fields()}}
 
     # micro-batched throughput, outside the timed region:
     # 12 queries share one pass over the catalogue, seed/final merge launches shared by 36
@@ -675,7 +709,7 @@ def main():
             eng.set_timing(False)
             k_ms = float(st_m.last_scan_ms)
             alg12 = int(st_m.replica_bytes_per_query)
-            micro["roofline"] = {"bound": "hbm", "kernel": "mi355::scan_half_multi_kernel<true> (up to 32 queries per 24 B/row pass)",
+            micro["roofline"] = {"bound": roofline_bound(alg12), "kernel": "mi355::scan_half_multi_kernel<true> (up to 32 queries per 24 B/row pass)",
                                  "algorithmic_bytes_per_launch": alg12, "avg_kernel_ms": round(k_ms, 5),
                                  "achieved": round(alg12 / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None, "peak": HBM_PEAK_GBPS,
                                  "unit": "GB/s", "frac": round(alg12 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if k_ms > 0 else None}
@@ -723,43 +757,56 @@ def main():
             else:
                 sharded.enqueue_batch(q_host, bq_rows, topn)
 
-        bq_step()
-        fence()
-        eng.set_timing(1)
-        dt = timed(bq_step, 10)
-        pass_ms = float(eng.stats().last_pass_ms)
-        eng.set_timing(False)
-        diag = eng.batched_last_counters()
-        rows_local = hi - lo
-        flops = FLOP_PER_PAIR * float(rows_local) * bq
-        # matrix-core work really issued: v_mfma_f32_32x32x16_f16 = 2*32*32*16 flop; pass 1 visits
-        # every 4th 32-row tile, pass 2 every tile; one MFMA per (tile, block of 32 queries)
-        tiles = (rows_local + 31) // 32
-        blocks = 2
-        while blocks * 32 < min(bq, 1024):
-            blocks *= 2
-        chunks = (bq + 1023) // 1024
-        mfma_flops = 2.0 * 32 * 32 * 16 * tiles * blocks * chunks * (1.0 + 0.25)
-        batched = {
-            "queries_per_call": bq, "value": round(bq / dt, 1),
-            "unit": "queries/s", "ms_per_call": round(dt * 1e3, 4), "rows_per_gpu": rows_local,
-            "roofline": {
-                "bound": "mfma", "kernel": "mi355::bq_pass_kernel (pass 1 + pass 2), v_mfma_f32_32x32x16_f16",
-                "issued_mfma_flops_per_call_per_gpu": mfma_flops,
-                "achieved": round(mfma_flops / dt / 1e12, 1), "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(mfma_flops / dt / 1e12 / FP16_MFMA_PEAK_TFLOPS, 3),
-                "avg_pass_kernel_ms": round(pass_ms, 4),
-                "binding_unit": "VALU issue: 8 v_max3_i32 per MFMA (1024 outputs) + chip power (DESIGN.md §4.6)",
-                "note": "the pre-filter runs on the fp16 matrix cores, so its roofline is the dense fp16 MFMA peak and "
-                        "`achieved` counts the MFMA flops really issued (2*32*32*16 each, pass 1 on every 4th tile)",
-                "survey_priced": {"algorithmic_flops_per_call_per_gpu": flops, "tflops": round(flops / dt / 1e12, 1),
-                                  "fp32_peak": FP32_PEAK_TFLOPS, "ratio": round(flops / dt / 1e12 / FP32_PEAK_TFLOPS, 3),
-                                  "note": "SURVEY.md §8(d)'s 24 flop per (row, query) pair against the fp32 peak: NOT a "
-                                          "roofline fraction (> 1 because the exact fp32 chain only touches the candidates)"},
-            },
-            "candidates_per_query": round(diag["candidates_total"] / max(1, min(bq, 1024) - diag["queued_queries"]), 1),
-            "queued_to_exact_scan": diag["queued_queries"], "special_rows": diag["special_rows"],
-        }
+        def measure_batched(engine, step_fn, rows_local):
+            step_fn()
+            fence()
+            engine.set_timing(1)
+            dt = timed(step_fn, 10)
+            pass_ms = float(engine.stats().last_pass_ms)
+            engine.set_timing(False)
+            diag = engine.batched_last_counters()
+            pairs = engine.batched_pass2_pairs()
+            flops = FLOP_PER_PAIR * float(rows_local) * bq
+            # Matrix-core work really issued: v_mfma_f32_32x32x16_f16 = 2*32*32*16 flop, two of them per (64-row tile,
+            # block of 32 queries) pair.  Pass 1 looks at every 4th tile; pass 2 at the pairs the library counted
+            # (mi355rec_batched_pass2_pairs: all of them without tile skipping, ~78 % with it).
+            tiles64 = (rows_local + 63) // 64
+            blocks = 1
+            while blocks * 32 < min(bq, 1024):
+                blocks *= 2
+            chunks = (bq + 1023) // 1024
+            per_pair = 2 * 2.0 * 32 * 32 * 16
+            pass1_pairs = ((tiles64 + 3) // 4) * blocks
+            issued = per_pair * chunks * (pass1_pairs + pairs["pairs_done"])
+            unskipped = per_pair * chunks * (pass1_pairs + pairs["pairs_total"])
+            return {
+                "queries_per_call": bq, "value": round(bq / dt, 1),
+                "unit": "queries/s", "ms_per_call": round(dt * 1e3, 4), "rows_per_gpu": rows_local,
+                "roofline": {
+                    "bound": "mfma", "kernel": "mi355::bq_pass_kernel (pass 1 + pass 2), v_mfma_f32_32x32x16_f16",
+                    "issued_mfma_flops_per_call_per_gpu": issued,
+                    "achieved": round(issued / dt / 1e12, 1), "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(issued / dt / 1e12 / FP16_MFMA_PEAK_TFLOPS, 3),
+                    "pass2_pairs_done": pairs["pairs_done"], "pass2_pairs_total": pairs["pairs_total"],
+                    "pass2_pairs_skipped_frac": round(1.0 - pairs["pairs_done"] / max(1, pairs["pairs_total"]), 4),
+                    "frac_if_nothing_were_skipped": round(unskipped / dt / 1e12 / FP16_MFMA_PEAK_TFLOPS, 3),
+                    "avg_pass_kernel_ms": round(pass_ms, 4),
+                    "binding_unit": "VALU issue (8 v_max3_i32 per MFMA = 1024 outputs), the hit path (the blocks that hold a "
+                                    "candidate cost 3x a block without one: 27 % of pass 2) and chip power (DESIGN.md §4.6)",
+                    "note": "the pre-filter runs on the fp16 matrix cores, so its roofline is the dense fp16 MFMA peak and `achieved` "
+                            "counts the MFMA flops really issued; pass 2 SKIPS the (tile, block) pairs that the maxima pass 1 left "
+                            "behind rule out, which lowers this fraction while the call gets faster — "
+                            "`frac_if_nothing_were_skipped` prices the same call at the MFMAs a skip-less pass 2 would issue",
+                    "survey_priced": {"algorithmic_flops_per_call_per_gpu": flops, "tflops": round(flops / dt / 1e12, 1),
+                                      "fp32_peak": FP32_PEAK_TFLOPS, "ratio": round(flops / dt / 1e12 / FP32_PEAK_TFLOPS, 3),
+                                      "note": "SURVEY.md §8(d)'s 24 flop per (row, query) pair against the fp32 peak: NOT a "
+                                              "roofline fraction (> 1 because the exact fp32 chain only touches the candidates)"},
+                },
+                "candidates_per_query": round(diag["candidates_total"] / max(1, min(bq, 1024) - diag["queued_queries"]), 1),
+                "queued_to_exact_scan": diag["queued_queries"], "special_rows": diag["special_rows"],
+            }
+
+        batched = measure_batched(eng, bq_step, hi - lo)
         # the first and last query of the batch against the single-query path
         ok = True
         for k in (0, bq - 1):
@@ -775,6 +822,30 @@ def main():
                 b = sharded.batch_keys[k].cpu().numpy()
             ok = ok and bool(np.array_equal(a, b))
         batched["matches_single_query_path"] = ok
+
+        # BASELINE configs[4] as ONE of its eight GPUs sees it: a 12.5 M-row shard of the 100 M catalogue, 1024 queries
+        # per call (the driver-run record carried the 10 M figure only).  Its own catalogue and handle,
+        # built after the headline's legs; skipped for other sizes / ranks.
+        if world == 1 and n == 10_000_000 and topn == 100 and not args.no_c5_shard:
+            c5_rows = 12_500_000
+            c5 = synthetic_catalogue(c5_rows, seed=args.seed + 5, device=dev)
+            with CosineEngine(c5) as eng5:
+                q5_rows = torch.from_numpy(np.array([(k * 104729) % c5_rows for k in range(bq)], dtype=np.int64)).to(dev)
+                q5 = c5[q5_rows].contiguous()
+                k5 = torch.zeros(bq * topn, dtype=torch.int64, device=dev)
+                batched["configs4_shard"] = measure_batched(eng5, lambda: eng5.enqueue_batch_keys_dev(q5, q5_rows, topn, k5), c5_rows)
+                batched["configs4_shard"]["workload"] = ("one 12.5 M-row shard of BASELINE configs[4] (100 M rows over 8 GPUs), 1024 "
+                                                         "device-resident queries per call, top-100")
+                # two of its queries against the single-query path of the same handle
+                ok5 = True
+                one = torch.zeros(topn, dtype=torch.int64, device=dev)
+                for k in (0, bq - 1):
+                    eng5.enqueue_row_keys(int(q5_rows[k].item()), topn, one)
+                    torch.cuda.synchronize()
+                    ok5 = ok5 and bool(torch.equal(one, k5[k * topn:(k + 1) * topn]))
+                batched["configs4_shard"]["matches_single_query_path"] = ok5
+            del c5, q5, k5
+            torch.cuda.empty_cache()
 
     # achievable-HBM ceiling probe on the same buffer (plain read-only stream)
     probe_gbps = None
@@ -800,7 +871,6 @@ def main():
         # a pass only finds its bytes in the 256 MiB Infinity Cache if the whole buffer survives one
         # full pass of itself plus the fp32 fetches: half the cache is the most that can be hoped for
         cache_resident = alg_bytes <= 128 * 2**20
-        traffic_bytes, traffic_source = pmc_traffic(alg_bytes, kernel_pmc)
         if replica:
             targs = "true, true" if streamed else ("true, false" if sharded is None else "false, true")
             kernel_name = (kernel_fmt.format(targs=targs) + " over the "
@@ -831,11 +901,13 @@ def main():
             "p50_ms": round(lat[len(lat) // 2], 4) if lat else None,
             "p99_ms": round(lat[min(len(lat) - 1, int(len(lat) * 0.99))], 4) if lat else None,
             "roofline": {
-                "bound": "hbm",
+                "bound": roofline_bound(alg_bytes),
+                "bound_note": ("the buffer this kernel streams fits the 256 MiB Infinity Cache with room to spare: `achieved` / "
+                               "`frac` are a rate against the HBM peak for comparison, not an HBM figure" if cache_resident else None),
                 "kernel": kernel_name,
                 "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None,
-                "traffic": traffic_bytes, "traffic_source": traffic_source,
+                **traffic_fields(),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_per_row": row_bytes,
                 "survey_bytes_per_row": BYTES_PER_ROW,

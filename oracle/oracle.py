@@ -44,6 +44,38 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+_native = None
+
+
+def native_recommend_omp():
+    """The OpenMP baseline compiled for THIS host (-O3 -march=native, still -ffp-contract=off): bench.py's
+    `cpu_baseline.march_native` variant ("state -march").  Built into a temporary directory at
+    run time — a -march=native object must not travel to another machine — and never used as a checker."""
+    global _native
+    if _native is None:
+        import tempfile
+        d = Path(tempfile.mkdtemp(prefix="oracle_native_"))
+        out = d / "liboracle_native.so"
+        flags = ["-std=c11", "-O3", "-march=native", "-fPIC", "-fopenmp", "-ffp-contract=off"]
+        subprocess.run(["gcc", *flags, "-shared", "-o", str(out), str(HERE / "cosine_oracle.c"), "-lm"], check=True,
+                       capture_output=True)
+        L = ctypes.CDLL(str(out))
+        L.oracle_recommend_omp.argtypes = [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int]
+        L.oracle_recommend_omp.restype = c_int64
+        _native = (L, "gcc " + " ".join(flags))
+    L, flags = _native
+
+    def run(feats, song_index: int, topn: int, threads: int = 0):
+        a = _feats(feats)
+        idx = np.empty(max(topn, 1), dtype=np.int32)
+        sc = np.empty(max(topn, 1), dtype=np.float32)
+        c = L.oracle_recommend_omp(a.ctypes.data, a.strides[0] // 4, a.shape[0], song_index, topn,
+                                   idx.ctypes.data, sc.ctypes.data, threads)
+        return idx[:max(c, 0)].copy(), sc[:max(c, 0)].copy()
+
+    return run, flags
+
+
 def _feats(feats) -> np.ndarray:
     a = np.asarray(feats)
     assert a.dtype == np.float32 and a.ndim == 2 and a.shape[1] >= 12

@@ -1488,11 +1488,13 @@ void launch_bq_passes(mi355rec* h, const float* d_queries, int count, int topn, 
     const int step1 = bq_step1(h, n_tiles);
     const size_t smem = sizeof(float) * b.grid * 2 * 5 + sizeof(int) * (kBqSelectBlock / 64) * 256;
     const uint2* half = reinterpret_cast<const uint2*>(h->d_half);
-    if constexpr (!kFromReplica) {   // (the replica-sourced pass 1 prepares the queries itself: no launch in front of it)
-        hipLaunchKernelGGL(bq_prepare_kernel, dim3((NB * 32 + 255) / 256), dim3(256), 0, s, d_queries, count, NB, b.bfrag,
-                           b.qnorm, b.qflags, b.cand_count, b.counters);
-        d_queries = nullptr;
-    }
+    // The queries are prepared by a launch of their own.  Folding it into pass 1's prologue (every workgroup builds
+    // the fragments from the raw queries itself; bq_pass_kernel still can: prep_queries) was built and measured: the
+    // launch it saves takes 4.4 us, the prologue it adds to each of pass 1's 1024 workgroups made pass 1 13 us slower
+    // (10 M rows x 1024 queries: 102.5 instead of 89.7 us).
+    hipLaunchKernelGGL(bq_prepare_kernel, dim3((NB * 32 + 255) / 256), dim3(256), 0, s, d_queries, count, NB, b.bfrag,
+                       b.qnorm, b.qflags, b.cand_count, b.counters);
+    d_queries = nullptr;
     int slot = timing_begin(h, h->ev_pass, h->n_pass_pairs, h->pass_launches, s);
     hipLaunchKernelGGL((bq_pass_kernel<NB, false, 0, kFromReplica, kTileMax>), dim3(b.grid), dim3(kBqPassBlock), 0, s, h->d_feats, h->n,
                        n_tiles, step1, b.bfrag, b.gmax, b.cand_count, b.cand_rows, b.counters, b.special_rows, half,
@@ -1546,7 +1548,6 @@ int enqueue_bq_chunk(mi355rec* h, const float* d_queries, const long long* d_exc
     const int blocks = (count + 31) / 32;
     int nb = 1;
     while (nb < blocks) nb *= 2;
-    // (no preparation launch where the rows come from the replica: pass 1 builds the fragments itself, batched.hip.h)
     switch (nb) {
         case 1: launch_bq_passes<1>(h, d_queries, count, topn, s); break;
         case 2: launch_bq_passes<2>(h, d_queries, count, topn, s); break;

@@ -25,9 +25,11 @@ def dry(args, env=None):
 def test_plain_multi_gpu_launch_selects_the_product_path():
     for n in (2, 8):
         plan = dry(["--gpus", str(n)])
-        assert plan["mode"].startswith("node: one process, mi355rec_create_sharded") and plan["gpus"] == n
+        assert plan["mode"].startswith("node: one process, mi355rec_create_placed (sharded)") and plan["gpus"] == n
     plan = dry(["--virtual-shards", "8"])
     assert "virtual shards" in plan["mode"]
+    plan = dry(["--gpus", "8", "--placement", "replicated"])
+    assert plan["mode"].startswith("node: one process, mi355rec_create_placed (replicated)")
 
 
 def test_single_and_rank_modes_and_labels():
