@@ -89,6 +89,18 @@ typedef struct {
     int32_t replica_single_row_bytes; /* 12 (8-bit replica), 24 (fp16 replica, MI355REC_REPLICA_FP16) or 0 (no replica)  */
     int32_t lone_fused_queries; /* synchronous single queries served by ONE scan launch that also merged and raised the
                                     completion word (8-bit replica, shards of >= 4 M rows), since create */
+    /* WHICH ROUTE the work took, counted per launch since create (DESIGN.md has the table "AUTO route by rows, batch,
+     * topn"; tests/test_gpu_routes.py asserts the counter that moves for each cell): */
+    int64_t route_fp32;          /* single query: scan over the fp32 rows (48 B/row), plain or streamed             */
+    int64_t route_fp16;          /* single query: scan over the fp16 replica (24 B/row; MI355REC_REPLICA_FP16)      */
+    int64_t route_q8;            /* single query: scan over the 8-bit replica (12 B/row), plain or streamed         */
+    int64_t route_q8_lone;       /* ... of a lone synchronous query that also merged and signalled (one launch)     */
+    int64_t route_multi_fp32;    /* exact multi-query pass over the fp32 rows (<= 12 queries per pass)              */
+    int64_t route_multi_fp16;    /* multi-query pass over the fp16 replica, fp16 matrix-core pre-filter (<= 32)     */
+    int64_t route_multi_q8;      /* multi-query pass over the 8-bit replica, integer matrix-core pre-filter          */
+    int64_t route_mfma_two_pass; /* chunks (<= 1024 queries) of the two-pass batched matrix-core path              */
+    int64_t route_exact_queue;   /* queries that path handed to the exact scan on the device (reading it synchronises) */
+    int32_t device_bytes_per_row; /* what the handle keeps resident per row: 48 (fp32) + 24 (fp16 replica) + 12 (8-bit) */
 } mi355rec_stats_t;
 
 /* Number of visible HIP devices (0 when there is none / no driver). */
@@ -117,6 +129,17 @@ int mi355rec_create(const float* feats_host, int64_t n, int dim, int device,
 int mi355rec_create_device(const float* feats_dev, int64_t n, int dim,
                            int device, int64_t row_base, mi355rec_t** out);
 
+/* The same with FLAGS:
+ *   MI355REC_CREATE_NO_REPLICA   the handle keeps the fp32 rows only: 48 B per row resident instead of 84 (no fp16 and no
+ *                                8-bit copy is built, single queries scan the fp32 rows, batches of 13 and more take the
+ *                                matrix-core path with rows from the fp32 matrix; mi355rec_set_replica(ON) is refused).
+ *                                mi355rec_stats_t::device_bytes_per_row says what a handle holds. */
+#define MI355REC_CREATE_NO_REPLICA 1
+int mi355rec_create_ex(const float* feats_host, int64_t n, int dim, int device, int64_t row_base, int flags,
+                       mi355rec_t** out);
+int mi355rec_create_device_ex(const float* feats_dev, int64_t n, int dim, int device, int64_t row_base, int flags,
+                              mi355rec_t** out);
+
 /* THE fp16 REPLICA.  Next to the fp32 rows every handle keeps a second copy of
  * its shard that is only good enough to rule rows OUT: each row L2-normalised
  * and rounded to fp16, 24 B per row (+50 % device memory, built once inside
@@ -141,8 +164,8 @@ int mi355rec_create_device(const float* feats_dev, int64_t n, int dim,
  * The batched matrix-core path reads its rows from the replica too (they are
  * stored in exactly the form its MFMA operand wants) unless the mode is OFF.
  * The score vector (mi355rec_scores*), rounds of topn > 1024 after the first
- * and the exact multi-query pass always read the fp32 rows.  The environment
- * variable MI355REC_REPLICA=0 creates handles without one.
+ * and the exact multi-query pass always read the fp32 rows.
+ * MI355REC_CREATE_NO_REPLICA (mi355rec_create_ex) creates a handle without either.
  * A replica is a SNAPSHOT: if the caller overwrites a borrowed matrix
  * (mi355rec_create_device) while the handle lives, it must call
  * mi355rec_rebuild_replica before the next query (synchronous). */

@@ -19,6 +19,7 @@ BATCH_AUTO, BATCH_MULTI, BATCH_MFMA, BATCH_HALF, BATCH_Q8, BATCH_MFMA_NOSKIP = 0
 REPLICA_AUTO, REPLICA_OFF, REPLICA_ON, REPLICA_FP16 = 0, 1, 2, 3
 TRANSPORT_PEER, TRANSPORT_RCCL = 1, 2
 PLACEMENT_AUTO, PLACEMENT_SHARDED, PLACEMENT_REPLICATED, PLACEMENT_CPU = 0, 1, 2, 3
+CREATE_NO_REPLICA = 1
 DEBUG_HANDOFF_POISON, DEBUG_HANDOFF_DROP_STORES, DEBUG_HANDOFF_NO_LAST_RIDER = 1, 2, 4
 
 OK = 0
@@ -51,6 +52,16 @@ class Stats(ctypes.Structure):
         ("replica_single_bytes_per_query", c_int64),
         ("replica_single_row_bytes", c_int32),
         ("lone_fused_queries", c_int32),
+        ("route_fp32", c_int64),
+        ("route_fp16", c_int64),
+        ("route_q8", c_int64),
+        ("route_q8_lone", c_int64),
+        ("route_multi_fp32", c_int64),
+        ("route_multi_fp16", c_int64),
+        ("route_multi_q8", c_int64),
+        ("route_mfma_two_pass", c_int64),
+        ("route_exact_queue", c_int64),
+        ("device_bytes_per_row", c_int32),
     ]
 
 
@@ -60,6 +71,8 @@ SIGNATURES = {
     "mi355rec_last_global_error": (c_char_p, []),
     "mi355rec_create": (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, POINTER(c_void_p)]),
     "mi355rec_create_device": (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, POINTER(c_void_p)]),
+    "mi355rec_create_ex": (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, c_int, POINTER(c_void_p)]),
+    "mi355rec_create_device_ex": (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, c_int, POINTER(c_void_p)]),
     "mi355rec_destroy": (None, [c_void_p]),
     "mi355rec_last_error": (c_char_p, [c_void_p]),
     "mi355rec_stats": (c_int, [c_void_p, POINTER(Stats)]),

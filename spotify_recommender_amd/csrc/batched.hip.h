@@ -778,7 +778,10 @@ __global__ __launch_bounds__(kBqSelectBlock) void bq_select_kernel(
             const int need = topk + 1;   // + 1: the query's own row may be among them and is excluded
             float t_prime = 0.0f;
             if (total >= need) {
-                const uint64_t kth = wave_select_threshold<kBqSelectKeys>(mine, need, true, 0, s_hist + wave * 256);
+                // (any T with at least `need` group maxima at or above it is a valid bound: stopping the radix
+                // select a few keys early — up to need / 16 + 1 groups more above T — saves most of its passes and
+                // moves T by a hair)
+                const uint64_t kth = wave_select_threshold<kBqSelectKeys>(mine, need, false, need / 16 + 1, s_hist + wave * 256);
                 const float t = ordered_to_score(static_cast<uint32_t>(kth >> 32));
                 t_prime = t - 2.0f * margin - kBqSlack;
             }
@@ -825,7 +828,10 @@ __global__ __launch_bounds__(kBqFinalBlock) void bq_finalize_kernel(
     const int n_special = counters[0];
     const bool served = qflags[q] == kBqFlagOk && n_cand <= kBqCap && n_special <= kBqSpecialCap;
     if (!served) {   // uniform
-        if (tid == 0) queue[atomicAdd(&counters[1], 1)] = q;
+        if (tid == 0) {
+            queue[atomicAdd(&counters[1], 1)] = q;
+            atomicAdd(&counters[5], 1);   // cumulative since the scratch was allocated (mi355rec_stats_t::route_exact_queue)
+        }
         return;
     }
     float qv[kDim];
@@ -845,14 +851,18 @@ __global__ __launch_bounds__(kBqFinalBlock) void bq_finalize_kernel(
     }
     __syncthreads();
     int c = s_n;
-    if (c > topk && c > kRankDirectMax) {   // uniform: cut to exactly topk in O(c), then rank
+    if (c > topk && c > kRankDirectMax) {   // uniform: cut to a little over topk in O(c), then rank
         uint64_t mine[kBqFinalPerThread];
 #pragma unroll
         for (int u = 0; u < kBqFinalPerThread; ++u) {
             const int i = tid + u * kBqFinalBlock;
             mine[u] = i < c ? s_keys[i] : 0ull;
         }
-        const uint64_t t = block_select_threshold<kBqFinalBlock, kBqFinalPerThread>(mine, topk, true, 0, s_sel);
+        // (not to EXACTLY topk: that takes the radix select through all its byte passes — most of this kernel's time —
+        // where a cut that may leave up to kRankDirectMax - topk keys more stops after two or three; the ranking
+        // below keeps the best topk of whatever is left)
+        const int slack = kRankDirectMax - topk > 0 ? kRankDirectMax - topk : 0;
+        const uint64_t t = block_select_threshold<kBqFinalBlock, kBqFinalPerThread>(mine, topk, slack == 0, slack, s_sel);
         if (tid == 0) s_n = 0;
         __syncthreads();
 #pragma unroll

@@ -114,11 +114,15 @@ struct mi355rec {
     int64_t lone_fused = 0;             // lone queries served by one launch (scan + merge + completion word)
     int64_t half_scans = 0;             // replica scans enqueued since create ...
     int64_t q8_scans = 0;               // ... of which over the 8-bit replica
+    // which route every launch of a query took (mi355rec_stats_t::route_*), since create
+    struct Routes {
+        int64_t fp32 = 0, fp16 = 0, q8 = 0, q8_lone = 0, multi_fp32 = 0, multi_fp16 = 0, multi_q8 = 0, mfma_two_pass = 0;
+    } routes;
     ReplicaGeom hg;                     // geometry of the scan over the fp16 replica ...
     uint4* d_q8 = nullptr;              // 8-bit replica (replica_q8.hip.h): ((n + 3) / 4) quads of rows x 48 B
     ReplicaGeom qg;                     // ... and over the 8-bit one
     int replica_mode = 0;               // MI355REC_REPLICA_AUTO / _OFF / _ON
-    bool replica_allowed = true;        // false: created under MI355REC_REPLICA=0
+    bool replica_allowed = true;        // false: created with MI355REC_CREATE_NO_REPLICA
     float replica_build_ms = 0.f;
     float margin_mix = kBqMarginFlush;   // error bound the single-query replica scan may claim (v_fma_mix_f32) ...
     float margin_mfma = kBqMarginFlush;  // ... and the multi-query pass (matrix core): 1.0e-3 where the device check passes
@@ -449,9 +453,10 @@ int build_replica_inner(mi355rec* h) {
 }
 
 int create_common(const float* feats, bool on_device, int64_t n, int dim, int device,
-                  int64_t row_base, mi355rec_t** out) {
+                  int64_t row_base, int flags, mi355rec_t** out) {
     if (out) *out = nullptr;
     if (!out || (!feats && n != 0)) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (flags & ~MI355REC_CREATE_NO_REPLICA) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "unknown create flags 0x%x", flags);
     if (dim != kDim) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "dim must be %d, got %d", kDim, dim);
     // n == 0 is an EMPTY SHARD (a rank of a row-sharded catalogue with more ranks
     // than rows): every query answers with an all-empty list, merges work as usual.
@@ -545,13 +550,12 @@ int create_common(const float* feats, bool on_device, int64_t n, int dim, int de
         if ((e = hipDeviceSynchronize()) != hipSuccess)
             return cleanup(MI355REC_ERR_HIP, "hipDeviceSynchronize", e);
     }
-    // The fp16 replica (+50 % device memory, one pass over the rows).  MI355REC_REPLICA=0
-    // in the environment keeps a handle fp32-only.
+    // The replicas (fp16 + 8-bit: +75 % device memory, one pass over the rows) unless the caller asked for a handle
+    // without them (MI355REC_CREATE_NO_REPLICA: 48 B per row resident instead of 84).
     // Shards below kReplicaMinRows get none: no AUTO path reads it there (single queries switch over at 1 M
-    // rows, batches at 65536); mi355rec_set_replica(ON) builds it on demand.  If the +50 % cannot be had the
+    // rows, batches at 65536); mi355rec_set_replica(ON) builds it on demand.  If the +75 % cannot be had the
     // handle degrades to fp32-only (same results, 48 B/row) and says so in mi355rec_last_error.
-    const char* renv = std::getenv("MI355REC_REPLICA");
-    h->replica_allowed = !(renv && renv[0] == '0');
+    h->replica_allowed = (flags & MI355REC_CREATE_NO_REPLICA) == 0;
     if (n >= kReplicaMinRows && h->replica_allowed) {
         const int brc = build_replica(h);
         if (brc != MI355REC_OK) {
@@ -719,6 +723,7 @@ int enqueue_scan(mi355rec* h, const float* qptr, const float* query12,
             const int q8_seeds = (q8_exact_sample(h) ? -1 : 1) * h->qg.seed_grid * kHalfSeedWaves;   // (negative: exact values)
             const unsigned long long* const no_cutoff = nullptr;
             if (lone && h->n >= kLoneFusedMinRows) {
+                ++h->routes.q8_lone;
                 // the arrival counters of the launch's tail count up and are never reset: this launch starts from ...
                 LoneTail tail = *lone;
                 const unsigned grid = static_cast<unsigned>(h->qg.grid);
@@ -745,6 +750,7 @@ int enqueue_scan(mi355rec* h, const float* qptr, const float* query12,
                 *fused = true;
                 return MI355REC_OK;
             }
+            ++h->routes.q8;
             if (qptr) {
                 LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, true, false>),
                              dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
@@ -762,6 +768,7 @@ int enqueue_scan(mi355rec* h, const float* qptr, const float* query12,
             return MI355REC_OK;
         }
         *n_lists = h->hg.grid;
+        ++h->routes.fp16;
         uint32_t* const half_seed = reinterpret_cast<uint32_t*>(h->d_half_seed);   // (the fp16 scan's plain sample values)
         enqueue_half_seed(h, false, qptr, qa, exclude_global, h->d_half_seed, 0u, s);
         if (qptr) {
@@ -779,6 +786,7 @@ int enqueue_scan(mi355rec* h, const float* qptr, const float* query12,
         return MI355REC_OK;
     }
     *n_lists = h->grid;
+    ++h->routes.fp32;
     if (qptr) {
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_kernel<ScanConfig, true, false>),
                      dim3(h->grid), dim3(kScanBlock), s,
@@ -851,6 +859,7 @@ int enqueue_multi(mi355rec* h, const float* queries, const int64_t* exclude, int
     }
     for (int g = 0; g < groups; ++g) {
         const int nq = count - g * kMultiQueries < kMultiQueries ? count - g * kMultiQueries : kMultiQueries;
+        ++h->routes.multi_fp32;
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_multi_kernel<MultiConfig>),
                      dim3(h->mgrid), dim3(MultiConfig::kBlock), s,
                      h->d_feats, h->n, static_cast<int64_t>(0), static_cast<int64_t>(0), h->miters, h->row_base,
@@ -916,10 +925,12 @@ int enqueue_half_multi(mi355rec* h, const float* queries, const float* const* qp
         ++h->half_scans;
         if (multi_front_q8(h, nq)) {   // rows from the 8-bit replica through the integer matrix core (replica_multi.hip.h)
             ++h->q8_scans;
+            ++h->routes.multi_q8;
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<false, true>), dim3(h->hg.grid),
                          dim3(kHmBlock), s, h->d_feats, h->d_half, reinterpret_cast<const uint32_t*>(h->d_q8), h->n, h->row_base, arg, nq,
                          g0, topn, h->d_block_lists, h->d_half_mseed, n_seed, h->d_half_rescored, no_ride, arg, no_cuts, epoch);
         } else {
+            ++h->routes.multi_fp16;
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<false, false>), dim3(h->hg.grid),
                          dim3(kHmBlock), s, h->d_feats, h->d_half, static_cast<const uint32_t*>(nullptr), h->n, h->row_base, arg, nq,
                          g0, topn, h->d_block_lists, h->d_half_mseed, n_seed, h->d_half_rescored, no_ride, arg, no_cuts, epoch);
@@ -1013,12 +1024,14 @@ int launch_mstash(mi355rec* h, hipStream_t s, const HalfMultiArg* next, int next
     ++h->half_scans;
     if (multi_front_q8(h, st.nq)) {
         ++h->q8_scans;
+        ++h->routes.multi_q8;
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<true, true>),
                      dim3(scanners + ride.prev_queries + ride.seed_wgs), dim3(kHmBlock), s, h->d_feats, h->d_half,
                      reinterpret_cast<const uint32_t*>(h->d_q8), h->n, h->row_base,
                      st.arg, st.nq, 0, st.topn, h->d_mstream_lists[buf], h->d_mstream_seed[st.seed_buf],
                      h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, ride, next ? *next : st.arg, cuts_ready, st.epoch);
     } else {
+        ++h->routes.multi_fp16;
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<true, false>),
                      dim3(scanners + ride.prev_queries + ride.seed_wgs), dim3(kHmBlock), s, h->d_feats, h->d_half,
                      static_cast<const uint32_t*>(nullptr), h->n, h->row_base,
@@ -1242,6 +1255,7 @@ int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, const float* next
     ++h->half_scans;
     if (st.q8) {
         ++h->q8_scans;
+        ++h->routes.q8;
         const unsigned long long* ready = st.cutoff_ready ? &h->d_stream_ctl[st.seed_buf].cutoff : nullptr;
         const int q8_seeds = q8_exact_sample(h) ? -n_seed : n_seed;   // (negative: exact values)
         if (st.qptr) {
@@ -1259,11 +1273,13 @@ int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, const float* next
                          LoneTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}}, st.epoch);
         }
     } else if (st.qptr) {
+        ++h->routes.fp16;
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, true, true>),
                      dim3(scanners + 1 + next.n_wgs), dim3(HalfConfig::kBlock), s,
                      h->d_feats, h->d_half, h->n, iters, h->row_base, qa, st.qptr, st.exclude, st.topn,
                      h->d_stream_lists[buf], reinterpret_cast<uint32_t*>(h->d_stream_seed[st.seed_buf]), n_seed, h->d_half_rescored, prev, next);
     } else {
+        ++h->routes.fp16;
         std::memcpy(qa.q, st.q, sizeof qa.q);
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, false, true>),
                      dim3(scanners + 1 + next.n_wgs), dim3(HalfConfig::kBlock), s,
@@ -1345,6 +1361,7 @@ int enqueue_streamed(mi355rec* h, const float* qptr, const float* query12, int64
     const int buf = h->pending ? 1 - h->pending_buf : 0;
     PrevMerge prev{nullptr, 0, 0, nullptr};
     if (h->pending) prev = PrevMerge{h->d_stream_lists[h->pending_buf], h->pending_lists, h->pending_topn, h->pending_out};
+    ++h->routes.fp32;
     if (qptr) {
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_kernel<ScanConfig, true, false, 0, true>),
                      dim3(h->sgrid + 1), dim3(kScanBlock), s,
@@ -1567,6 +1584,7 @@ int enqueue_bq_chunk(mi355rec* h, const float* d_queries, const long long* d_exc
                        static_cast<int64_t>(topn));
     HIP_TRY(h, hipGetLastError());
     ++b.launches;
+    ++h->routes.mfma_two_pass;
     b.last_count = count;
     return MI355REC_OK;
 }
@@ -1669,12 +1687,22 @@ const char* mi355rec_last_global_error(void) { return g_last_error.c_str(); }
 
 int mi355rec_create(const float* feats_host, int64_t n, int dim, int device, int64_t row_base,
                     mi355rec_t** out) {
-    return create_common(feats_host, false, n, dim, device, row_base, out);
+    return create_common(feats_host, false, n, dim, device, row_base, 0, out);
 }
 
 int mi355rec_create_device(const float* feats_dev, int64_t n, int dim, int device,
                            int64_t row_base, mi355rec_t** out) {
-    return create_common(feats_dev, true, n, dim, device, row_base, out);
+    return create_common(feats_dev, true, n, dim, device, row_base, 0, out);
+}
+
+int mi355rec_create_ex(const float* feats_host, int64_t n, int dim, int device, int64_t row_base, int flags,
+                       mi355rec_t** out) {
+    return create_common(feats_host, false, n, dim, device, row_base, flags, out);
+}
+
+int mi355rec_create_device_ex(const float* feats_dev, int64_t n, int dim, int device, int64_t row_base, int flags,
+                              mi355rec_t** out) {
+    return create_common(feats_dev, true, n, dim, device, row_base, flags, out);
 }
 
 void mi355rec_destroy(mi355rec_t* h) {
@@ -1771,6 +1799,21 @@ int mi355rec_stats(const mi355rec_t* hc, mi355rec_stats_t* out) {
     out->replica_single_row_bytes = !h->d_half ? 0 : (use_q8(h) ? 12 : 24);
     out->replica_single_bytes_per_query = !h->d_half ? 0 : (use_q8(h) ? ((h->n + 3) / 4) * 48 : ((h->n + 1) / 2) * 48);
     out->lone_fused_queries = static_cast<int32_t>(h->lone_fused & 0x7fffffff);
+    out->route_fp32 = h->routes.fp32;
+    out->route_fp16 = h->routes.fp16;
+    out->route_q8 = h->routes.q8;
+    out->route_q8_lone = h->routes.q8_lone;
+    out->route_multi_fp32 = h->routes.multi_fp32;
+    out->route_multi_fp16 = h->routes.multi_fp16;
+    out->route_multi_q8 = h->routes.multi_q8;
+    out->route_mfma_two_pass = h->routes.mfma_two_pass;
+    out->route_exact_queue = 0;
+    if (h->bq.ready) {   // queries the batched path handed to the exact scan: counted on the device (counters[5], never reset)
+        int queued = 0;
+        (void)hipDeviceSynchronize();
+        if (hipMemcpy(&queued, h->bq.counters + 5, sizeof queued, hipMemcpyDeviceToHost) == hipSuccess) out->route_exact_queue = queued;
+    }
+    out->device_bytes_per_row = 48 + (h->d_half ? 24 : 0) + (h->d_q8 ? 12 : 0);
     return MI355REC_OK;
 }
 
@@ -2056,7 +2099,7 @@ int mi355rec_set_replica(mi355rec_t* h, int mode) {
         return fail(h, MI355REC_ERR_INVALID_ARG, "unknown replica mode %d", mode);
     if ((mode == MI355REC_REPLICA_ON || mode == MI355REC_REPLICA_FP16) && !h->d_half && h->n > 0) {
         if (!h->replica_allowed)
-            return fail(h, MI355REC_ERR_INVALID_ARG, "this handle was created without a replica (MI355REC_REPLICA=0)");
+            return fail(h, MI355REC_ERR_INVALID_ARG, "this handle was created without a replica (MI355REC_CREATE_NO_REPLICA)");
         // a small shard (or one whose replica could not be allocated at create): build it now
         const int rc = mi355rec_rebuild_replica(h);
         if (rc) return rc;
@@ -2132,7 +2175,7 @@ int mi355rec_rebuild_replica(mi355rec_t* h) {
     if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
     if (h->n == 0) return MI355REC_OK;
     if (!h->replica_allowed)
-        return fail(h, MI355REC_ERR_INVALID_ARG, "this handle was created without a replica (MI355REC_REPLICA=0)");
+        return fail(h, MI355REC_ERR_INVALID_ARG, "this handle was created without a replica (MI355REC_CREATE_NO_REPLICA)");
     DeviceGuard guard(h->device);
     int rc = sync_api_begin(h);
     if (rc) return rc;

@@ -28,7 +28,8 @@ class CosineEngine:
     (Recommender.cu:184-254 + :293-315).
     """
 
-    def __init__(self, feats, device: int = 0, row_base: int = 0):
+    def __init__(self, feats, device: int = 0, row_base: int = 0, flags: int = 0):
+        """flags: capi.CREATE_NO_REPLICA = keep the fp32 rows only (48 B per row resident instead of 84)."""
         self._lib = capi.lib()
         self._h = ctypes.c_void_p()
         self._keepalive = None
@@ -47,9 +48,9 @@ class CosineEngine:
                     raise ValueError("catalogue tensor must be contiguous (row-major)")
                 self._keepalive = feats
                 self.device = feats.device.index if feats.device.index is not None else 0
-                rc = self._lib.mi355rec_create_device(
+                rc = self._lib.mi355rec_create_device_ex(
                     ctypes.c_void_p(feats.data_ptr()), feats.shape[0], feats.shape[1],
-                    self.device, int(row_base), ctypes.byref(self._h))
+                    self.device, int(row_base), int(flags), ctypes.byref(self._h))
                 capi.check(rc)
                 self.rows = int(feats.shape[0])
                 self.row_base = int(row_base)
@@ -57,9 +58,9 @@ class CosineEngine:
         arr = _np_f32(feats)
         if arr.ndim != 2 or arr.shape[1] != capi.DIM:
             raise ValueError("catalogue must be float32 [n, 12]")
-        rc = self._lib.mi355rec_create(
+        rc = self._lib.mi355rec_create_ex(
             arr.ctypes.data_as(ctypes.c_void_p), arr.shape[0], arr.shape[1], self.device,
-            int(row_base), ctypes.byref(self._h))
+            int(row_base), int(flags), ctypes.byref(self._h))
         capi.check(rc)
         self.rows = int(arr.shape[0])
         self.row_base = int(row_base)

@@ -280,21 +280,26 @@ def test_rebuild_after_overwriting_a_borrowed_matrix(Engine, torch_cuda):
 
 
 def test_handle_without_a_replica(Engine):
+    """MI355REC_CREATE_NO_REPLICA (a create flag; earlier rounds read an environment variable): 48 B per row resident
+    instead of 84, every query over the fp32 rows."""
+    from spotify_recommender_amd import capi
     rng = np.random.default_rng(14)
-    f = rng.random((50_000, 12), dtype=np.float32)
-    os.environ["MI355REC_REPLICA"] = "0"
-    try:
-        with Engine(f) as eng:
-            st = eng.stats()
-            assert st.replica_bytes_per_query == 0 and st.replica_active == 0
-            with pytest.raises(RuntimeError, match="without a replica"):
-                eng.set_replica(ON)
-            idx, sc = eng.query_row_topn(3, 10)
-            want = oracle.scores(f, f[3], threads=0)
-            assert_topn_matches(idx, sc, want, 3, 10)
-            assert eng.replica_counters() == {"scans": 0, "rescored_rows": 0}
-    finally:
-        del os.environ["MI355REC_REPLICA"]
+    f = rng.random((1_200_000, 12), dtype=np.float32)      # a size at which a default handle WOULD build and scan replicas
+    with Engine(f, flags=capi.CREATE_NO_REPLICA) as eng:
+        st = eng.stats()
+        assert st.replica_bytes_per_query == 0 and st.replica_active == 0 and st.device_bytes_per_row == 48
+        with pytest.raises(RuntimeError, match="without a replica"):
+            eng.set_replica(ON)
+        idx, sc = eng.query_row_topn(3, 10)
+        want = oracle.scores(f, f[3], threads=0)
+        assert_topn_matches(idx, sc, want, 3, 10)
+        assert eng.replica_counters() == {"scans": 0, "rescored_rows": 0}
+        st = eng.stats()
+        assert st.route_fp32 == 1 and st.route_q8 + st.route_q8_lone + st.route_fp16 == 0
+    with Engine(f) as eng:
+        assert eng.stats().device_bytes_per_row == 84
+    with pytest.raises(capi.Mi355Error):
+        Engine(f, flags=64)
 
 
 def test_replica_queries_replay_from_a_hip_graph(Engine, torch_cuda):
