@@ -467,7 +467,8 @@ __device__ __forceinline__ void merge_body(
     MergeSmemT<kThreads, kMaxLists, kSurvCap>& sm, const uint64_t* lists_base, int n_lists, int list_len, int64_t list_stride,
     int64_t lists_query_stride, int topk, uint64_t* __restrict__ out_keys_base,
     int64_t* __restrict__ out_idx_base, float* __restrict__ out_score_base,
-    int64_t out_query_stride, int64_t slot, int64_t out_slot) {
+    int64_t out_query_stride, int64_t slot, int64_t out_slot, int tid_in = -1 /* threadIdx.x, if the caller has a reason to
+    pass it (a caller that merges in a LOOP passes an opaque copy, or what depends on it alone is hoisted out and spilled) */) {
     constexpr int kFirstPer = kMaxLists * kMergeFirst / kThreads;   // first-chunk keys per thread
     constexpr int kSurvPer = kSurvCap / kThreads;
     constexpr int kHeadsPer = kMaxLists / kThreads;
@@ -481,7 +482,7 @@ __device__ __forceinline__ void merge_body(
     int& s_more = sm.more;
     unsigned short* const s_active = sm.active;
 
-    const int tid = threadIdx.x;
+    const int tid = tid_in >= 0 ? tid_in : static_cast<int>(threadIdx.x);
     const uint64_t* lists = lists_base + slot * lists_query_stride;
     uint64_t* out_keys = out_keys_base + out_slot * out_query_stride;
 

@@ -101,6 +101,9 @@ struct mi355rec {
     // that fail safe"); the fp16 single-query scan uses the same buffers as plain uint32_t[]
     unsigned long long* d_half_seed = nullptr;    // kHalfSeedMaxGrid x 8 sample maxima of the query in flight
     unsigned long long* d_half_mseed = nullptr;   // kHmQueries x that: the sample of a multi-query pass over the replica
+    unsigned long long* d_half_mcuts = nullptr;   // [kHmQueries] tagged cutoffs the sample launch of such a pass leaves (its last workgroup) ...
+    SeedCtl* d_half_mctl = nullptr;               // ... and its arrival counter, which counts up from ...
+    unsigned half_mctl_done = 0;                  // ... here (never reset)
     uint32_t epoch_ctr = 0;             // the last epoch handed out (one per query / batch whose sample or cutoff crosses workgroups; never 0)
     unsigned ctl_done[2] = {0u, 0u};    // what d_stream_ctl[i].done holds (the riders' arrival counters are never reset)
     unsigned mctl_done[2] = {0u, 0u};   // ... and d_mstream_ctl[i].done
@@ -298,6 +301,12 @@ int sync_api_begin(mi355rec* h) { return order_stream(h, h->stream); }
 void plan_grid(mi355rec* h, int blocks_per_cu) {
     int64_t max_blocks = static_cast<int64_t>(h->cus) * blocks_per_cu;
     if (max_blocks > kMergeMaxLists) max_blocks = kMergeMaxLists;
+#ifdef MI355REC_EXPERIMENTS   // tools builds only (tools/lat_exp.sh): fewer scanning workgroups = fewer lists for the merge
+    if (const char* e = std::getenv("MI355REC_EXP_FP32_GRID")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v < max_blocks) max_blocks = v;
+    }
+#endif
     const int64_t tiles = (h->n + kScanTileRows - 1) / kScanTileRows;
     h->grid = static_cast<int>(tiles < max_blocks ? tiles : max_blocks);
     h->rows_per_block = 0;
@@ -328,6 +337,12 @@ ReplicaGeom plan_replica(const mi355rec* h, int occ, int tile_rows, int align, d
     if (occ > 3) occ = 3;
     int64_t max_blocks = static_cast<int64_t>(h->cus) * occ;
     if (max_blocks > kRideMaxLists) max_blocks = kRideMaxLists;
+#ifdef MI355REC_EXPERIMENTS
+    if (const char* e = std::getenv("MI355REC_EXP_REPLICA_GRID")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v < max_blocks) max_blocks = v;
+    }
+#endif
     const int64_t tiles = (h->n + tile_rows - 1) / tile_rows;
     g.grid = static_cast<int>(tiles < max_blocks ? tiles : max_blocks);
     g.iters = static_cast<int>((tiles + g.grid - 1) / g.grid);
@@ -377,7 +392,10 @@ void plan_half_grid(mi355rec* h) {
 }
 
 void free_replica(mi355rec* h) {
-    void* bufs[] = {h->d_half, h->d_q8, h->d_stream_ctl, h->d_half_seed, h->d_half_mseed, h->d_half_rescored, h->d_stream_seed[0], h->d_stream_seed[1]};
+    void* bufs[] = {h->d_half, h->d_q8, h->d_stream_ctl, h->d_half_seed, h->d_half_mseed, h->d_half_rescored, h->d_stream_seed[0], h->d_stream_seed[1],
+                    h->d_half_mcuts, h->d_half_mctl};
+    h->d_half_mcuts = nullptr;
+    h->d_half_mctl = nullptr;
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     h->d_half = nullptr;
@@ -395,6 +413,11 @@ int alloc_replica(mi355rec* h, int64_t n_padded) {
     HIP_TRY(h, hipMalloc(&h->d_half_seed, sizeof(unsigned long long) * kHalfSeedMaxGrid * kHalfSeedWaves));
     HIP_TRY(h, hipMalloc(&h->d_half_mseed, sizeof(unsigned long long) * kHmQueries * kHalfSeedMaxGrid * kHalfSeedWaves));
     HIP_TRY(h, hipMalloc(&h->d_half_rescored, sizeof(unsigned long long) * kRideMaxLists));
+    HIP_TRY(h, hipMalloc(&h->d_half_mcuts, sizeof(unsigned long long) * kHmQueries));
+    HIP_TRY(h, hipMemsetAsync(h->d_half_mcuts, 0, sizeof(unsigned long long) * kHmQueries, h->stream));
+    HIP_TRY(h, hipMalloc(&h->d_half_mctl, sizeof(SeedCtl)));
+    HIP_TRY(h, hipMemsetAsync(h->d_half_mctl, 0, sizeof(SeedCtl), h->stream));
+    h->half_mctl_done = 0;
     // the sample buffers of STREAMED queries belong to the replica: whoever has d_half has them
     for (int i = 0; i < 2; ++i)
         HIP_TRY(h, hipMalloc(&h->d_stream_seed[i], sizeof(unsigned long long) * kHalfSeedMaxGrid * kHalfSeedWaves));
@@ -701,6 +724,11 @@ void enqueue_half_seed(mi355rec* h, bool q8, const float* qptr, const QueryArg& 
 // lone != null (a lone query whose caller waits on the host): over the 8-bit replica of a large shard the launch
 // also merges its own lists into lone's buffers (kernels.hip.h, lone_tail) and *fused is set.
 constexpr int64_t kLoneFusedMinRows = 4000000;
+// A LONE synchronous query on a small shard takes the fp32 rows under AUTO: over a replica it is three dependent
+// launches (sample, scan, merge), over the fp32 rows two, and below ~1.5 M rows the sample launch costs more than
+// the bytes it saves (measured from C++, tools/lat_exp.sh, 1 M rows x top-10: p50 27.3 us against 29.7; 3 M rows:
+// 40.6 against 33.5).  Streams are not affected: their sample rides in the previous launch.
+constexpr int64_t kLoneFp32MaxRows = 1500000;
 int enqueue_scan(mi355rec* h, const float* qptr, const float* query12,
                  int64_t exclude_global, int topn, const uint64_t* upper_dev, hipStream_t s, int* n_lists,
                  const LoneTail* lone = nullptr, bool* fused = nullptr) {
@@ -711,7 +739,8 @@ int enqueue_scan(mi355rec* h, const float* qptr, const float* query12,
     const PrevMerge none{nullptr, 0, 0, nullptr};
     const LoneTail no_tail{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}};
     if (fused) *fused = false;
-    if (use_half(h, upper_dev)) {
+    const bool lone_small = lone && h->replica_mode == MI355REC_REPLICA_AUTO && h->n < kLoneFp32MaxRows;
+    if (use_half(h, upper_dev) && !lone_small) {
         NextSeed no_next;
         std::memset(&no_next, 0, sizeof no_next);
         ++h->half_scans;
@@ -909,6 +938,22 @@ void fill_half_multi_arg(HalfMultiArg& arg, float margin, const float* queries, 
     }
 }
 
+// How much of the shard a batch of nq queries samples for its cutoffs (replica_multi.hip.h, hm_sample_regions):
+// regions of 1024 << l rows.  The sample is paid once per batch, the candidates its cutoff lets through once per
+// query: 2.6 % of 10 M rows leave ~5 100 candidates per query, 5 % ~2 700, 10 % ~1 400.  A sample launch of its own
+// is over in a few us whatever it reads; seed riders (`riding`) share the memory system with the pass they ride in,
+// row for row, so a streamed batch samples at most 5 % (measured, tools/hm_riders.sh, 10 M rows x 12 queries: launches
+// of 45.1 / 43.6 / 45.1 us at 2.6 / 5 / 10 %; x 32 queries: 52.3 / 49.7 / 50.2).  Regions must not overlap.
+int hm_sample_log2(const mi355rec* h, int nq, bool riding) {
+    int l = nq >= 12 ? 2 : nq >= 5 ? 1 : 0;
+    if (riding && l > 1) l = 1;
+#ifdef MI355REC_EXPERIMENTS
+    if (const char* e = std::getenv("MI355REC_EXP_SAMPLE_LOG2")) l = std::atoi(e) & 3;
+#endif
+    while (l > 0 && (static_cast<int64_t>(1024) << l) > h->hg.seed_stride) --l;
+    return l;
+}
+
 int enqueue_half_multi(mi355rec* h, const float* queries, const float* const* qptrs, const int64_t* exclude, int count,
                        int topn, uint64_t* out_keys, int64_t* out_idx, float* out_score, hipStream_t s) {
     const int n_seed = h->hg.seed_grid * kHalfSeedWaves;
@@ -919,21 +964,23 @@ int enqueue_half_multi(mi355rec* h, const float* queries, const float* const* qp
         const int nq = count - g0 < kHmQueries ? count - g0 : kHmQueries;
         fill_half_multi_arg(arg, h->margin_mfma, queries, qptrs, exclude, g0, nq);
         const uint32_t epoch = next_epoch(h);
-        const unsigned long long* const no_cuts = nullptr;
+        // the sample launch's last workgroup selects the cutoffs; the pass reads them (stream order)
+        const unsigned long long* const cuts = h->d_half_mcuts;
         hipLaunchKernelGGL(seed_half_multi_kernel, dim3(h->hg.seed_grid), dim3(kHmBlock), 0, s, h->d_half, h->n, h->hg.seed_stride,
-                           arg, nq, h->d_half_mseed, epoch);
+                           arg, nq, h->d_half_mseed, epoch, hm_sample_log2(h, nq, false), h->d_half_mctl, h->half_mctl_done, h->d_half_mcuts, topn);
+        h->half_mctl_done += static_cast<unsigned>(h->hg.seed_grid);
         ++h->half_scans;
         if (multi_front_q8(h, nq)) {   // rows from the 8-bit replica through the integer matrix core (replica_multi.hip.h)
             ++h->q8_scans;
             ++h->routes.multi_q8;
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<false, true>), dim3(h->hg.grid),
                          dim3(kHmBlock), s, h->d_feats, h->d_half, reinterpret_cast<const uint32_t*>(h->d_q8), h->n, h->row_base, arg, nq,
-                         g0, topn, h->d_block_lists, h->d_half_mseed, n_seed, h->d_half_rescored, no_ride, arg, no_cuts, epoch);
+                         g0, topn, h->d_block_lists, h->d_half_mseed, n_seed, h->d_half_rescored, no_ride, arg, cuts, epoch);
         } else {
             ++h->routes.multi_fp16;
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<false, false>), dim3(h->hg.grid),
                          dim3(kHmBlock), s, h->d_feats, h->d_half, static_cast<const uint32_t*>(nullptr), h->n, h->row_base, arg, nq,
-                         g0, topn, h->d_block_lists, h->d_half_mseed, n_seed, h->d_half_rescored, no_ride, arg, no_cuts, epoch);
+                         g0, topn, h->d_block_lists, h->d_half_mseed, n_seed, h->d_half_rescored, no_ride, arg, cuts, epoch);
         }
     }
     HIP_TRY(h, hipGetLastError());
@@ -948,10 +995,14 @@ int enqueue_half_multi(mi355rec* h, const float* queries, const float* const* qp
 
 // ---- a STREAM of batches over the replica (mi355rec_enqueue_batch_keys_streamed) ---------------------
 // The single-query stream's scheme (enqueue_streamed), one level up: the stream runs one call behind —
-// call k + 1 LAUNCHES batch k — and that launch carries, beside its scanners, one merging workgroup per
-// query of batch k - 1 and a few seed riders that take the sample of batch k + 1.  A stream of K batches
+// call k + 1 LAUNCHES batch k — and that launch carries, beside its scanners, a merging workgroup per three
+// queries of batch k - 1 and a few seed riders that take the sample of batch k + 1.  A stream of K batches
 // costs K launches + one sample launch at its head + one merge launch at its tail (the flush).
-constexpr int kHmRiders = 16;   // seed riders of a streamed launch: 16 regions each, one memory round trip per region
+// Workgroups of a streamed launch that do not scan take a scanner's place among the resident ones (measured at 10 M rows:
+// 32 mergers + 64 riders of 512 made a 41 us pass 57 us), so they are as few as can still finish inside the pass:
+constexpr int kHmRiders = 16;       // seed riders per 1024 rows of a sampled region: a rider's wave gets through a 128-row
+                                    // chunk every ~2 us beside a pass (as a scanner's does), 16 (or 32) of them take 33 us
+constexpr int kHmMergesPerWg = 3;   // queries of the previous batch one merging workgroup takes, one after the other (~10 us each)
 
 int ensure_mstream(mi355rec* h) {
     if (h->mstream_ready) return MI355REC_OK;
@@ -997,11 +1048,17 @@ int launch_mstash(mi355rec* h, hipStream_t s, const HalfMultiArg* next, int next
         ride.prev_lists = h->d_mstream_lists[h->mpending.buf];
         ride.prev_out = h->mpending.out;
         ride.prev_queries = h->mpending.nq;
+        ride.merge_wgs = (h->mpending.nq + kHmMergesPerWg - 1) / kHmMergesPerWg;
         ride.prev_n_lists = h->mpending.n_lists;
         ride.prev_topk = h->mpending.topn;
     }
     if (next) {
-        ride.seed_wgs = kHmRiders < h->hg.seed_grid ? kHmRiders : h->hg.seed_grid;
+        ride.sample_log2 = hm_sample_log2(h, next_nq, true);
+        ride.seed_wgs = kHmRiders << ride.sample_log2;
+#ifdef MI355REC_EXPERIMENTS
+        if (const char* e = std::getenv("MI355REC_EXP_RIDERS")) ride.seed_wgs = std::atoi(e) > 0 ? std::atoi(e) : ride.seed_wgs;
+#endif
+        if (ride.seed_wgs > h->hg.seed_grid) ride.seed_wgs = h->hg.seed_grid;
         ride.next_queries = next_nq;
         ride.regions = h->hg.seed_grid;
         ride.stride_rows = h->hg.seed_stride;
@@ -1019,21 +1076,21 @@ int launch_mstash(mi355rec* h, hipStream_t s, const HalfMultiArg* next, int next
     }
     const unsigned long long* cuts_ready = st.cuts_ready ? h->d_mstream_cuts + st.seed_buf * kHmQueries : nullptr;
     // the launch stays within one resident wave of workgroups: the riders and mergers take scanner slots
-    int scanners = h->hg.grid - ride.prev_queries - ride.seed_wgs;
+    int scanners = h->hg.grid - ride.merge_wgs - ride.seed_wgs;
     if (scanners < 1) scanners = 1;
     ++h->half_scans;
     if (multi_front_q8(h, st.nq)) {
         ++h->q8_scans;
         ++h->routes.multi_q8;
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<true, true>),
-                     dim3(scanners + ride.prev_queries + ride.seed_wgs), dim3(kHmBlock), s, h->d_feats, h->d_half,
+                     dim3(scanners + ride.merge_wgs + ride.seed_wgs), dim3(kHmBlock), s, h->d_feats, h->d_half,
                      reinterpret_cast<const uint32_t*>(h->d_q8), h->n, h->row_base,
                      st.arg, st.nq, 0, st.topn, h->d_mstream_lists[buf], h->d_mstream_seed[st.seed_buf],
                      h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, ride, next ? *next : st.arg, cuts_ready, st.epoch);
     } else {
         ++h->routes.multi_fp16;
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<true, false>),
-                     dim3(scanners + ride.prev_queries + ride.seed_wgs), dim3(kHmBlock), s, h->d_feats, h->d_half,
+                     dim3(scanners + ride.merge_wgs + ride.seed_wgs), dim3(kHmBlock), s, h->d_feats, h->d_half,
                      static_cast<const uint32_t*>(nullptr), h->n, h->row_base,
                      st.arg, st.nq, 0, st.topn, h->d_mstream_lists[buf], h->d_mstream_seed[st.seed_buf],
                      h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, ride, next ? *next : st.arg, cuts_ready, st.epoch);
@@ -1083,8 +1140,11 @@ int enqueue_mstream(mi355rec* h, const float* queries, const float* const* qptrs
         cuts_ready = h->hg.seed_grid > 0;   // (launch_mstash gave the launch seed riders)
     } else {   // the head of a stream: a sample launch of its own
         hipLaunchKernelGGL(seed_half_multi_kernel, dim3(h->hg.seed_grid), dim3(kHmBlock), 0, s, h->d_half, h->n, h->hg.seed_stride,
-                           arg, nq, h->d_mstream_seed[seed_buf], epoch);
+                           arg, nq, h->d_mstream_seed[seed_buf], epoch, hm_sample_log2(h, nq, false), h->d_mstream_ctl + seed_buf,
+                           h->mctl_done[seed_buf], h->d_mstream_cuts + seed_buf * kHmQueries, topn);
         HIP_TRY(h, hipGetLastError());
+        h->mctl_done[seed_buf] += static_cast<unsigned>(h->hg.seed_grid);
+        cuts_ready = h->hg.seed_grid > 0;
     }
     auto& st = h->mstash;
     st.has = true;

@@ -58,6 +58,9 @@ constexpr int kHmWaves = kHmBlock / 64;
 #endif
 constexpr int kHmChunks = MI355_HM_CHUNKS;         // 128-row chunks (one pair load per lane) a wave handles per step
 constexpr int kHmStepRows = 128 * kHmChunks;
+#ifndef MI355_HM_EXP
+#define MI355_HM_EXP 0   // tools/hm_exp.sh builds the timing experiments 1 ... 3 under gpurun_out/ (never the product library)
+#endif
 constexpr int kHmStage = 128;                      // staged (query, row) candidates per wave
 constexpr int kHmPrivate = 4;                      // keys per (wave, query) kept in the wave's own list before the shared one is touched
 constexpr int kHmKeyCap = 192;                     // kept keys per query and workgroup
@@ -167,17 +170,25 @@ __device__ __forceinline__ int hm_tile_max(const bq_f16v& d) {   // max over the
 }
 
 // ---- the sample: [query][region * 8 + wave] ordered-u32 approx maxima -----------------------------
-// The sample of replica.hip.h — 1024 rows of up to 256 evenly spaced regions, one maximum per 128-row wave
-// tile — for every query of a batch at once, on the matrix core: one wave = one 128-row chunk = four MFMAs
-// against the batch's B fragment with ZERO threshold slots (D = approx), a max over the 64 results a lane
-// holds for its query column, the two half-waves combined.  Masked rows (special, past the end) contribute an
-// approx of exactly 0 and the query's own row is not masked at all, so only POSITIVE maxima are published
-// (0 = nothing usable) and the cutoff is taken from the (topk + 1)-th largest: topk + 1 tiles with a
-// positive maximum >= v hold topk + 1 distinct genuine rows with approx >= v, at least topk of them not the
-// excluded one.  Workgroup `first`, `first + every`, ... of the regions; called by all 512 threads.
+// The sample of replica.hip.h — up to 256 evenly spaced regions, one maximum per wave tile — for every query of a
+// batch at once, on the matrix core: a wave takes 128-row chunks = four MFMAs each against the batch's B fragment
+// with ZERO threshold slots (D = approx), a max over the 64 results a lane holds for its query column, the two
+// half-waves combined.  Masked rows (special, past the end) contribute an approx of exactly 0 and the query's own
+// row is not masked at all, so only POSITIVE maxima are published (0 = nothing usable) and the cutoff is taken from
+// the (topk + 1)-th largest: topk + 1 tiles with a positive maximum >= v hold topk + 1 distinct genuine rows with
+// approx >= v, at least topk of them not the excluded one.
+// HOW MUCH is sampled depends on the batch: a region is 1024 << log2_mult rows (wave w: chunks w, 8 + w, ... of it,
+// ONE maximum over them, so the sample stays 2048 values per query whatever its size).  The rows a cutoff lets through
+// to the exact chain are about topk / (sampled fraction) plus the margin band — ~5 100 per query from the 2.6 % of
+// 10 M rows that 1024-row regions are, ~1 400 from 10 % — and they are paid per QUERY while the sample is paid once per
+// BATCH; the host picks log2_mult from the batch size (hm_sample_log2).  Regions are >= 1024 << log2_mult rows apart
+// (host), so no row is sampled twice.
+// Workgroup `first`, `first + every`, ... of the regions; called by all 512 threads.  kDepth chunks are in flight per wave.
+template <int kDepth>
 __device__ __forceinline__ void hm_sample_regions(const uint4* __restrict__ half, int64_t n, int64_t stride_rows, int regions,
                                                   int first, int every, const uint4* bfrag, int n_queries,
-                                                  unsigned long long* __restrict__ seed_vals, uint32_t epoch, int debug_skip = 0) {
+                                                  unsigned long long* __restrict__ seed_vals, uint32_t epoch, int log2_mult,
+                                                  int debug_skip = 0) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t n_pairs = (n + 1) >> 1;
@@ -185,49 +196,52 @@ __device__ __forceinline__ void hm_sample_regions(const uint4* __restrict__ half
     const bq_h8 B = __builtin_bit_cast(bq_h8, bfrag[lane]);
     const bq_f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     const int64_t per_query = static_cast<int64_t>(regions) * kHalfSeedWaves;
-    auto load = [&](HalfTile& t, int g) {
-        int64_t pair = ((static_cast<int64_t>(g) * stride_rows) >> 1) + wave * 64 + lane;
+    const int mult = 1 << log2_mult;
+    const int mine = first < regions ? (regions - first + every - 1) / every : 0;
+    const int total = mine << log2_mult;   // this wave's chunks: item i = chunk (i & (mult - 1)) of its region i >> log2_mult
+    auto region_of = [&](int i) { return first + (i >> log2_mult) * every; };
+    auto chunk_of = [&](int i) { return (i & (mult - 1)) * kHalfSeedWaves + wave; };
+    auto load = [&](HalfTile& t, int i) {
+        int64_t pair = ((static_cast<int64_t>(region_of(i)) * stride_rows) >> 1) + chunk_of(i) * 64 + lane;
         pair = pair < n_pairs ? pair : n_pairs - 1;
         const uint4* p = half + pair * 3;
         t.t0 = p[0];
         t.t1 = p[1];
         t.t2 = p[2];
     };
-    HalfTile t;
-    if (first < regions) load(t, first);
-    for (int g = first; g < regions; g += every) {
-        const HalfTile cur = t;
-        if (g + every < regions) load(t, g + every);   // the next region's rows are on their way while this one is reduced
-        const uint32_t chunk_row = static_cast<uint32_t>(((static_cast<int64_t>(g) * stride_rows) & ~1ll) + wave * 128);
-        int m = static_cast<int>(0x80000000u);
+    HalfTile t[kDepth];
 #pragma unroll
-        for (int S = 0; S < 2; ++S) {
-            const HmTiles a = hm_make_tiles(cur, S, chunk_row, n32);
-            const bq_f16v D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.a0, B, zero, 0, 0, 0);
-            const bq_f16v D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.a1, B, zero, 0, 0, 0);
-            m = max(m, max(hm_tile_max(D0), hm_tile_max(D1)));
+    for (int k = 0; k < kDepth; ++k)
+        if (k < total) load(t[k], k);
+    int m = static_cast<int>(0x80000000u);
+    for (int i0 = 0; i0 < total; i0 += kDepth) {
+#pragma unroll
+        for (int k = 0; k < kDepth; ++k) {
+            const int i = i0 + k;
+            if (i >= total) break;   // uniform
+            const HalfTile cur = t[k];
+            if (i + kDepth < total) load(t[k], i + kDepth);   // later chunks are on their way while this one is reduced
+            const int g = region_of(i);
+            const uint32_t chunk_row = static_cast<uint32_t>(((static_cast<int64_t>(g) * stride_rows) & ~1ll) + chunk_of(i) * 128);
+#pragma unroll
+            for (int S = 0; S < 2; ++S) {
+                const HmTiles a = hm_make_tiles(cur, S, chunk_row, n32);
+                const bq_f16v D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.a0, B, zero, 0, 0, 0);
+                const bq_f16v D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.a1, B, zero, 0, 0, 0);
+                m = max(m, max(hm_tile_max(D0), hm_tile_max(D1)));
+            }
+            if ((i & (mult - 1)) != mult - 1) continue;   // uniform: more chunks of this region to come
+            m = max(m, __shfl_xor(m, 32));   // lanes c and 32 + c hold the two row halves of query c
+            // a positive float's bits are a positive int; its ordered image sets the top bit
+            const uint32_t v = m > 0 ? (static_cast<uint32_t>(m) | 0x80000000u) : 0u;
+            // written THROUGH to device scope, under the batch's epoch: the last seed rider of the same launch may read it
+            // (hoisted cutoffs; replica.hip.h, "hand-offs that fail safe")
+            if (lane < n_queries && g >= debug_skip)
+                __hip_atomic_store(&seed_vals[lane * per_query + static_cast<int64_t>(g) * kHalfSeedWaves + wave], tag_value(epoch, v),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            m = static_cast<int>(0x80000000u);
         }
-        m = max(m, __shfl_xor(m, 32));   // lanes c and 32 + c hold the two row halves of query c
-        // a positive float's bits are a positive int; its ordered image sets the top bit
-        const uint32_t v = m > 0 ? (static_cast<uint32_t>(m) | 0x80000000u) : 0u;
-        // written THROUGH to device scope, under the batch's epoch: the last seed rider of the same launch may read it
-        // (hoisted cutoffs; replica.hip.h, "hand-offs that fail safe")
-        if (lane < n_queries && g >= debug_skip)
-            __hip_atomic_store(&seed_vals[lane * per_query + static_cast<int64_t>(g) * kHalfSeedWaves + wave], tag_value(epoch, v),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-}
-
-__global__ __launch_bounds__(kHmBlock) void seed_half_multi_kernel(
-    const uint4* __restrict__ half, int64_t n, int64_t stride_rows, HalfMultiArg arg, int n_queries,
-    unsigned long long* __restrict__ seed_vals /* [query][gridDim.x * kHalfSeedWaves], tagged with `epoch` */, uint32_t epoch) {
-    __shared__ uint4 s_b[64];
-    if (threadIdx.x < kHmQueries) {
-        float q[kDim], qn;
-        hm_build_fragment(arg, n_queries, threadIdx.x, 0u, s_b, q, qn);
-    }
-    __syncthreads();
-    hm_sample_regions(half, n, stride_rows, gridDim.x, blockIdx.x, gridDim.x, s_b, n_queries, seed_vals, epoch);
 }
 
 // ---- shared memory of one scanning workgroup ---------------------------------------------------------
@@ -496,13 +510,67 @@ __device__ __forceinline__ void hm_exact_step(HalfMultiSmem& sm, const float* __
     }
 }
 
+// The end of a sampling workgroup (a sample launch's, or a seed rider's): it arrives, and the LAST ones to arrive select
+// the batch's cutoffs from the sample and leave them, tagged, in `cuts` — eight queries (one per wave) per workgroup, so
+// a batch of 32 is shared by the last four.  They do not wait for each other: a sample that still misses the values of
+// the few workgroups behind it (their slots carry another epoch and count as empty) gives a LOWER (topk + 1)-th largest
+// maximum, i.e. a looser cutoff that is just as valid.  The hand-off is replica.hip.h's ("hand-offs that fail safe"):
+// write-through sample stores, vmcnt(0), a monotonic arrival counter whose base the host tracks, epoch-tagged values; a
+// cutoff nobody wrote reads as "every row is a candidate" in the pass.  Called by all 512 threads; `s_round` is theirs.
+__device__ __forceinline__ void hm_arrive_and_select(SeedCtl* ctl, unsigned done_base, unsigned total, int n_queries,
+                                                     const uint32_t* ok /* shared: the bound can be claimed for query q */,
+                                                     const unsigned long long* seed_vals, int n_seed, int topk, float margin,
+                                                     uint32_t epoch, unsigned long long* cuts, unsigned* s_round) {
+    wait_own_stores();   // this wave's write-through sample stores have completed
+    __syncthreads();
+    if (threadIdx.x == 0)   // arrival a (0-based) takes round total - 1 - a: the last to arrive round 0, the one before it round 1, ...
+        *s_round = done_base + total - 1u - __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned rounds = static_cast<unsigned>((n_queries + kHmWaves - 1) / kHmWaves);
+    const int lane = threadIdx.x & 63;
+    for (unsigned r = *s_round; r < rounds; r += total) {   // uniform; (fewer workgroups than rounds: the last ones take several)
+        const int qi = static_cast<int>(r) * kHmWaves + static_cast<int>(threadIdx.x >> 6);
+        if (qi >= n_queries) continue;   // wave-uniform
+        // (a query the bound cannot be claimed for keeps "every row is a candidate")
+        const float cut = ok[qi] ? hm_seed_cutoff<true>(seed_vals + static_cast<int64_t>(qi) * n_seed, n_seed, topk + 1, margin, epoch)
+                                 : -__builtin_inff();
+        if (lane == 0) cuts[qi] = tag_value(epoch, __float_as_uint(cut));
+    }
+}
+
+// The sample launch of a call on its own (and of the head of a stream).  Its last workgroups also select the cutoffs
+// (hm_arrive_and_select) — the pass behind it then reads 32 words where each of its 512 workgroups would otherwise
+// select from 16 KB of sample values per query (measured at 10 M rows: the pass of 12 queries 49.8 -> 42.4 us, of 32
+// queries 62.6 -> 45.8 us).
+__global__ __launch_bounds__(kHmBlock) void seed_half_multi_kernel(
+    const uint4* __restrict__ half, int64_t n, int64_t stride_rows, HalfMultiArg arg, int n_queries,
+    unsigned long long* __restrict__ seed_vals /* [query][gridDim.x * kHalfSeedWaves], tagged with `epoch` */, uint32_t epoch,
+    int log2_mult /* rows per region = 1024 << log2_mult */, SeedCtl* __restrict__ ctl /* arrival counter (null: no cutoffs) */,
+    unsigned done_base, unsigned long long* __restrict__ cuts /* [n_queries] tagged cutoffs */, int topk) {
+    __shared__ uint4 s_b[64];
+    __shared__ uint32_t s_ok[kHmQueries];
+    __shared__ unsigned s_round;
+    if (threadIdx.x < kHmQueries) {
+        float q[kDim], qn;
+        s_ok[threadIdx.x] = hm_build_fragment(arg, n_queries, threadIdx.x, 0u, s_b, q, qn) ? 1u : 0u;
+    }
+    __syncthreads();
+    hm_sample_regions<4>(half, n, stride_rows, gridDim.x, blockIdx.x, gridDim.x, s_b, n_queries, seed_vals, epoch, log2_mult);
+    if (ctl)   // uniform
+        hm_arrive_and_select(ctl, done_base, gridDim.x, n_queries, s_ok, seed_vals, static_cast<int>(gridDim.x) * kHalfSeedWaves, topk,
+                             arg.margin, epoch, cuts, &s_round);
+}
+
 // What else a launch of a STREAM of batches carries beside the scanners (mi355rec_enqueue_batch_keys_streamed):
 // one merging workgroup per query of the PREVIOUS batch (merge_body over that batch's per-workgroup lists, as
 // scan_half_kernel's riding merger) and a few "seed riders" that take the sample of the NEXT batch.
 struct HmRide {
     const uint64_t* prev_lists;   // [prev_queries][prev_n_lists][prev_topk]
     uint64_t* prev_out;           // [prev_queries][prev_topk]
-    int prev_queries;             // merging workgroups in this launch (0 = none)
+    int prev_queries;             // queries of the previous batch to merge in this launch (0 = none) ...
+    int merge_wgs;                // ... by this many merging workgroups: query q by workgroup q % merge_wgs (~10 us per
+                                  // query at 10 M rows, so three or four fit beside a pass; every workgroup that does not
+                                  // scan takes a scanner's place among the resident ones)
     int prev_n_lists;
     int prev_topk;
     int seed_wgs;                 // seed riders in this launch (0 = none)
@@ -516,6 +584,7 @@ struct HmRide {
     SeedCtl* next_ctl;            // null: the next launch selects its cutoffs itself
     unsigned long long* next_cuts;   // [kHmQueries]: tag_value(next_epoch, bits of the cutoff)
     int next_topk;
+    int sample_log2;              // rows per sampled region of the next batch = 1024 << this (hm_sample_regions)
     uint32_t next_epoch;          // of the next batch: the tag of its sample values and of its cutoffs
     uint32_t done_base;           // next_ctl->done before this launch's riders arrive (counted up, never reset)
     int debug_skip;               // test hook (0 in the product): the riders do NOT store regions below this one
@@ -549,14 +618,19 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
     unsigned nblocks = gridDim.x;   // scanning workgroups
     HalfMultiSmem* smp;
     if constexpr (kRide) {
-        nblocks = gridDim.x - static_cast<unsigned>(ride.prev_queries) - static_cast<unsigned>(ride.seed_wgs);
+        nblocks = gridDim.x - static_cast<unsigned>(ride.merge_wgs) - static_cast<unsigned>(ride.seed_wgs);
         if (bid >= nblocks) {
             const int extra = static_cast<int>(bid - nblocks);
-            if (extra < ride.prev_queries) {   // the merger of one query of the previous batch
-                merge_body(s_mem.merge, ride.prev_lists, ride.prev_n_lists, ride.prev_topk, static_cast<int64_t>(ride.prev_topk),
-                           static_cast<int64_t>(ride.prev_n_lists) * ride.prev_topk, ride.prev_topk, ride.prev_out,
-                           static_cast<int64_t*>(nullptr), static_cast<float*>(nullptr), static_cast<int64_t>(ride.prev_topk),
-                           static_cast<int64_t>(extra), static_cast<int64_t>(extra));
+            if (extra < ride.merge_wgs) {   // a merger: queries extra, extra + merge_wgs, ... of the previous batch, one after the other
+                for (int pq = extra; pq < ride.prev_queries; pq += ride.merge_wgs) {
+                    if (pq != extra) __syncthreads();   // the merge before is done with the shared memory
+                    int t = tid;
+                    asm volatile("" : "+v"(t));   // (see merge_body)
+                    merge_body(s_mem.merge, ride.prev_lists, ride.prev_n_lists, ride.prev_topk, static_cast<int64_t>(ride.prev_topk),
+                               static_cast<int64_t>(ride.prev_n_lists) * ride.prev_topk, ride.prev_topk, ride.prev_out,
+                               static_cast<int64_t*>(nullptr), static_cast<float*>(nullptr), static_cast<int64_t>(ride.prev_topk),
+                               static_cast<int64_t>(pq), static_cast<int64_t>(pq), t);
+                }
             } else {                           // a seed rider: its share of the next batch's sample
                 uint4* const fb = s_mem.scan.bfrag;
                 if (tid < kHmQueries) {
@@ -564,26 +638,12 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
                     s_mem.scan.ok[tid] = hm_build_fragment(next, ride.next_queries, tid, 0u, fb, q, qn) ? 1u : 0u;
                 }
                 __syncthreads();
-                hm_sample_regions(half, n, ride.stride_rows, ride.regions, extra - ride.prev_queries, ride.seed_wgs, fb,
-                                  ride.next_queries, ride.next_seed_vals, ride.next_epoch, ride.debug_skip);
-                if (ride.next_ctl) {   // uniform: last rider out selects the next batch's cutoffs
-                    wait_own_stores();   // this wave's write-through sample stores have completed
-                    __syncthreads();
-                    if (tid == 0)
-                        s_mem.scan.rescored = __hip_atomic_fetch_add(&ride.next_ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u ==
-                                              ride.done_base + static_cast<unsigned>(ride.seed_wgs);
-                    __syncthreads();
-                    if (s_mem.scan.rescored) {   // uniform
-                        const int n_next = ride.regions * kHalfSeedWaves;
-                        for (int qi = wave; qi < ride.next_queries; qi += kHmWaves) {
-                            // (a query the bound cannot be claimed for keeps "every row is a candidate")
-                            const float cut = s_mem.scan.ok[qi] ? hm_seed_cutoff<true>(ride.next_seed_vals + static_cast<int64_t>(qi) * n_next,
-                                                                                      n_next, ride.next_topk + 1, next.margin, ride.next_epoch)
-                                                                : -__builtin_inff();
-                            if (lane == 0) ride.next_cuts[qi] = tag_value(ride.next_epoch, __float_as_uint(cut));
-                        }
-                    }
-                }
+                hm_sample_regions<4>(half, n, ride.stride_rows, ride.regions, extra - ride.merge_wgs, ride.seed_wgs, fb,
+                                     ride.next_queries, ride.next_seed_vals, ride.next_epoch, ride.sample_log2, ride.debug_skip);
+                if (ride.next_ctl)   // uniform: the last riders out select the next batch's cutoffs
+                    hm_arrive_and_select(ride.next_ctl, ride.done_base, static_cast<unsigned>(ride.seed_wgs), ride.next_queries,
+                                         s_mem.scan.ok, ride.next_seed_vals, ride.regions * kHalfSeedWaves, ride.next_topk, next.margin,
+                                         ride.next_epoch, ride.next_cuts, reinterpret_cast<unsigned*>(&s_mem.scan.rescored));
             }
             return;
         }
@@ -687,33 +747,34 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
     // D layout: lane holds column c = lane & 31 (the query) and, in register i, the row that lane
     // (i & 3) + 8 (i >> 2) + 4 (lane >> 5) of the tile's 32 lanes loaded.  `first_row` = row of the tile's
     // lane 0, rows of consecutive lanes are 2 apart (a lane holds a pair).
+    // Each lane packs the SIGN bits of its 16 results into a mask (one v_alignbit per register: mask = mask << 1 | sign)
+    // and the lanes with a clear bit walk it, one hit per wave-uniform round — instead of a ballot and a branch per
+    // result register, which at 32 queries per pass ran for nearly every MFMA (batched.hip.h's push_hits, measured
+    // there: the blocks that hold a hit cost three times the others).
     auto push_hits = [&](const bq_f16v& d, uint32_t first_row, int lane0, uint64_t special) {
-        auto bits = [&](int i) { return static_cast<int>(__float_as_uint(d[i])); };
+        uint32_t signs = 0u;
 #pragma unroll
-        for (int g4 = 0; g4 < 16; g4 += 4) {
-            // four registers at a time first: a tile that holds a hit usually holds one
-            if (!__ballot(max(max(bits(g4), bits(g4 + 1)), max(bits(g4 + 2), bits(g4 + 3))) >= 0)) continue;   // wave-uniform
-#pragma unroll
-            for (int i = g4; i < g4 + 4; ++i) {
-                if (__ballot(bits(i) >= 0)) {   // wave-uniform, rare
-                    // opaque on purpose: otherwise the compiler hoists the row ids of all 16 registers out of
-                    // this rare path into the tile prologue and spills them
-                    uint32_t lr = 4u * static_cast<uint32_t>(hh);
-                    asm volatile("" : "+v"(lr));
-                    lr += static_cast<uint32_t>((i & 3) + 8 * (i >> 2));   // the lane of the tile that loaded the row
-                    const uint32_t row = first_row + 2u * lr;
-                    // out-of-range rows and special rows were zeroed in A (D = -T'): never through this path
-                    const bool hit = bits(i) >= 0 && row < n32 && !((special >> (lane0 + lr)) & 1ull);
-                    const uint64_t who = __ballot(hit);
-                    if (who) {
-                        const int n_hit = __popcll(who);
-                        if (staged + n_hit > kHmStage) {
-                            overflow = true;   // the whole step is redone through the exact chain (hm_exact_step)
-                        } else {
-                            if (hit) stage[staged + lanes_below(who)] = make_uint2(static_cast<uint32_t>(lane & 31), row);
-                            staged += n_hit;
-                        }
-                    }
+        for (int i = 15; i >= 0; --i) signs = __builtin_amdgcn_alignbit(signs, __float_as_uint(d[i]), 31);   // bit i = sign of d[i]
+        uint32_t hits = ~signs & 0xffffu;   // D >= +0: approx >= T'
+        // opaque on purpose: otherwise the compiler hoists the row ids of all 16 registers out of this rare path
+        // into the tile prologue and spills them
+        uint32_t lr0 = 4u * static_cast<uint32_t>(hh);
+        asm volatile("" : "+v"(lr0));
+        for (uint64_t any = __ballot(hits != 0u); any; any = __ballot(hits != 0u)) {   // wave-uniform rounds
+            const int i = hits ? __builtin_ctz(hits) : 0;
+            const uint32_t lr = lr0 + static_cast<uint32_t>((i & 3) + 8 * (i >> 2));   // the lane of the tile that loaded the row
+            const uint32_t row = first_row + 2u * lr;
+            // out-of-range rows and special rows were zeroed in A (D = -T'): never through this path
+            const bool hit = hits != 0u && row < n32 && !((special >> (lane0 + lr)) & 1ull);
+            hits &= hits - 1u;
+            const uint64_t who = __ballot(hit);
+            if (who) {
+                const int n_hit = __popcll(who);
+                if (staged + n_hit > kHmStage) {
+                    overflow = true;   // the whole step is redone through the exact chain (hm_exact_step)
+                } else {
+                    if (hit) stage[staged + lanes_below(who)] = make_uint2(static_cast<uint32_t>(lane & 31), row);
+                    staged += n_hit;
                 }
             }
         }
@@ -724,7 +785,15 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
         // the fragment is re-read every step (its cutoffs tighten); the barrier keeps the compiler from hoisting it
         asm volatile("" ::: "memory");
         if constexpr (!kQ8) {
+#if MI355_HM_EXP == 4   // EXPERIMENT (wrong results): only query 0's column of the B operand is live, the others hold zeros
+            uint4 bw = sm.bfrag[lane];
+            if ((lane & 31) >= 1) {
+                bw.x = bw.y = 0u;
+                if (lane < 32) bw.z = bw.w = 0u;
+            }
+#else
             const uint4 bw = sm.bfrag[lane];
+#endif
             const bq_h8 B = __builtin_bit_cast(bq_h8, bw);
     #pragma unroll
             for (int u = 0; u < kHmChunks; ++u) {
@@ -748,10 +817,14 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
                     const bq_f16v D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.a0, B, zero, 0, 0, 0);
                     const bq_f16v D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.a1, B, zero, 0, 0, 0);
                     const int ma = hm_tile_max(D0), mb = hm_tile_max(D1);
+#if MI355_HM_EXP == 1   // EXPERIMENT (wrong results): hits are seen but not extracted
+                    if (__ballot(max(ma, mb) >= 0) == 0x12345ull) staged = 1;
+#else
                     if (__builtin_expect(__ballot(max(ma, mb) >= 0) != 0ull, 0)) {   // some D >= +0: approx >= T'
                         if (__ballot(ma >= 0)) push_hits(D0, chunk_row + S, 0, a.special);
                         if (__ballot(mb >= 0)) push_hits(D1, chunk_row + 64u + S, 32, a.special);
                     }
+#endif
                 }
                 load_chunk(T[u], step + total_waves, u);   // this chunk's registers are free again: the next step's rows
             }
@@ -840,11 +913,18 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
             }
         }
     }
+#if MI355_HM_EXP == 2   // EXPERIMENT (wrong results): the candidates are extracted but never scored
+    if (staged > 100000) n_rescored = 1;
+#else
     n_rescored += hm_resolve_stage(sm, staged, feats, row_base, topk, kQ8 ? reinterpret_cast<const uint32_t*>(half) : nullptr);
+#endif
     if (lane == 0) atomicAdd(&sm.rescored, n_rescored);
     __syncthreads();
     if (tid == 0) rescored[bid] += static_cast<unsigned long long>(sm.rescored);   // launches of a handle are stream-ordered
 
+#if MI355_HM_EXP == 3   // EXPERIMENT (wrong results): no lists are written
+    if (n_rescored >= 0) return;
+#endif
     // ---- every query's best topk of this workgroup, sorted, one wave per query
     static_assert(kHmWaves * kHmPrivate <= 64, "one lane per private key in the final gather");
     for (int qi = wave; qi < n_queries; qi += kHmWaves) {

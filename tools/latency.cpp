@@ -7,7 +7,8 @@
 //   g++ -O2 -std=c++17 -Iinclude tools/latency.cpp spotify_recommender_amd/csrc/Recommender.cpp \
 //       spotify_recommender_amd/csrc/DataManager.cpp -Lspotify_recommender_amd -lmi355rec \
 //       -Wl,-rpath,'$ORIGIN/../spotify_recommender_amd' -o tools/latency
-//   tools/latency [rows=10000000] [topn=100] [queries=2000] [virtual_shards=0]
+//   tools/latency [rows=10000000] [topn=100] [queries=2000] [virtual_shards=0] [replica_mode=-1]
+//   (replica_mode >= 0: mi355rec_set_replica on the single-device handle before (a) is measured — 1 = the fp32 rows)
 #include <algorithm>
 #include <chrono>
 #include <cstdarg>
@@ -63,6 +64,7 @@ int main(int argc, char** argv) {
     const int topn = argc > 2 ? atoi(argv[2]) : 100;
     const int queries = argc > 3 ? atoi(argv[3]) : 2000;
     const int vshards = argc > 4 ? atoi(argv[4]) : 0;
+    const int replica_mode = argc > 5 ? atoi(argv[5]) : -1;
     std::vector<float> feats(static_cast<size_t>(n) * 12);
     std::mt19937 gen(12345);
     std::uniform_real_distribution<float> dist(0.0f, 1.0f);
@@ -81,6 +83,11 @@ int main(int argc, char** argv) {
             std::fprintf(stderr, "create failed: %s\n", mi355rec_last_global_error());
             return 1;
         }
+        if (replica_mode >= 0 && mi355rec_set_replica(h, replica_mode) != MI355REC_OK) {
+            std::fprintf(stderr, "set_replica failed: %s\n", mi355rec_last_error(h));
+            return 1;
+        }
+        add("\"replica_mode\": %d, ", replica_mode);
         const Pct p = measure(queries, n, [&](int64_t row) {
             if (mi355rec_query_row_topn(h, row, topn, idx.data(), score.data(), &count) == MI355REC_OK) return true;
             std::fprintf(stderr, "query failed: %s\n", mi355rec_last_error(h));

@@ -22,7 +22,13 @@ def main():
     ap.add_argument("--calls", type=int, default=40)
     ap.add_argument("--only-stream", type=int, default=0, help="only a stream of batches of this many queries (profiling)")
     ap.add_argument("--fp16", action="store_true", help="rows from the fp16 replica (24 B/row: the default from three queries per pass up) instead of the 8-bit one")
+    ap.add_argument("--lib", default=None, help="another build of the library (e.g. an MI355REC_EXPERIMENTS one under gpurun_out/)")
+    ap.add_argument("--sizes", default="1,2,4,8,12,16,24,32", help="batch sizes of the single calls ('' = none)")
+    ap.add_argument("--streams", default="2,12,32", help="batch sizes of the streams ('' = none)")
     args = ap.parse_args()
+    if args.lib:
+        from spotify_recommender_amd import capi as _capi
+        _capi.LIB_PATH = Path(args.lib).resolve()   # before the first capi.lib(): this process only
     import numpy as np
     import torch
     from spotify_recommender_amd import CosineEngine, capi
@@ -38,7 +44,7 @@ def main():
         out["margin_single"], out["margin_multi"] = round(float(st0.replica_margin_single), 6), round(float(st0.replica_margin_multi), 6)
         eng.set_batch_path(capi.BATCH_HALF if args.fp16 else capi.BATCH_Q8)
         out["front_end"] = "fp16 replica, 24 B/row" if args.fp16 else "8-bit replica, 12 B/row, fp16 re-check of the candidates"
-        sizes = (1, 2, 4, 8, 12, 16, 24, 32) if not args.only_stream else ()
+        sizes = tuple(int(x) for x in args.sizes.split(",") if x) if not args.only_stream else ()
         for nb in sizes:
             keys = torch.zeros(nb * topn, dtype=torch.int64, device="cuda")
             ex = np.array(rows[:nb], dtype=np.int64)
@@ -57,7 +63,7 @@ def main():
             out["single_calls"].append({"queries": nb, "us_per_call": round(dt * 1e6, 1), "queries_per_s": round(nb / dt),
                                         "pass_kernel_us": round(st.last_scan_ms * 1e3, 1), "merge_kernel_us": round(st.last_merge_ms * 1e3, 1),
                                         "rows_to_exact_chain_per_query": round((a["rescored_rows"] - b["rescored_rows"]) / args.calls / nb)})
-        for nb in ((2, 12, 32) if not args.only_stream else (args.only_stream,)):
+        for nb in (tuple(int(x) for x in args.streams.split(",") if x) if not args.only_stream else (args.only_stream,)):
             ring = [torch.zeros(nb * topn, dtype=torch.int64, device="cuda") for _ in range(4)]
             ex = np.array(rows[:nb], dtype=np.int64)
             for k in range(6):
