@@ -34,7 +34,7 @@ with open(f"profiles/{tag}_kernel_stats.csv", "w", newline="") as f:
 shutil.copy(bench_json, f"profiles/{tag}_bench_n1.json")
 out = {
     "command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 40 --warmup 5 "
-               "--no-cpu-baseline --latency-queries 5   (one counter per pass, kernel-trace in its own run)",
+               "--no-cpu-baseline --no-c5-shard --latency-queries 5   (one counter per pass, kernel-trace in its own run)",
     "unit_note": "rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB. On gfx950 FETCH_SIZE counts 64 B per 128 B request "
                  "of a wide coalesced read, so read bytes = 2 * FETCH_SIZE * 1024 (MI355X_MICROARCH.md, HBM section); "
                  "the stream probe (a pure coalesced read of the same bytes) calibrates that factor; WRITE_SIZE is exact.",
@@ -70,11 +70,14 @@ for k, d in out["kernels"].items():
         alg = (rows + 1) // 2 * 48
         d["note"] = "scan over the fp16 replica: 24 B per row + the fp32 rows it cannot rule out (a few thousand per query)"
     elif "bq_pass_kernel" in k:
-        # bq_pass_kernel<NB, kCollect, kVariant, kFromReplica>: pass 2 (kCollect) reads every row once, pass 1
-        # every 4th 64-row tile; 24 B per row from the fp16 replica, 48 B from the fp32 matrix
+        # bq_pass_kernel<NB, kCollect, kVariant, kFromReplica, kTileMax>: pass 2 (kCollect) reads every row once, pass 1
+        # every 4th 64-row tile; 24 B per row from the fp16 replica, 48 B from the fp32 matrix.  With kTileMax pass 1 also
+        # leaves 128 B per query block and visited tile (its per-lane maxima, fp16) and pass 2 reads them back
         args = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
         per_row = 24 if len(args) > 3 and args[3] == "true" else 48
         alg = rows * per_row if args[1] == "true" else rows * per_row // 4
+        if len(args) > 4 and args[4] == "true":
+            alg += (rows // 64 // 4) * int(args[0]) * 128
         d["note"] = "batched path: rows are read once per pass whatever the number of queries (<= 1024 per pass)"
     if alg is not None:
         d["algorithmic_bytes_per_launch"] = alg
