@@ -274,10 +274,11 @@ int mi355rec_enqueue_ptr_keys_streamed(mi355rec_t* h, const float* query12_dev, 
                                        int topn, mi355rec_key_t* out_keys_dev, void* stream);
 
 /* `batch` queries (batch x 12 floats, host; exclude_global may be NULL).
- * On a shard with a replica (>= 65536 rows, topn <= 128) 2 ... 16 queries go in
+ * On a shard with a replica (>= 65536 rows, topn <= 128) 2 ... 32 queries go in
  * ONE multi-query pass over the fp16 replica (csrc/replica_multi.hip.h: fp16
  * matrix-core pre-filter for up to 32 queries per 24 B/row pass, candidates
- * resolved by the exact chain in the same launch), 17 and more take the two-pass
+ * resolved by the exact chain in the same launch; 2 queries: over the 8-bit
+ * replica), 33 and more take the two-pass
  * batched matrix-core path (mi355rec_set_batch_path forces either); without a
  * replica up to 12 queries — or any batch on a shard below 65536 rows — go in
  * exact multi-query passes over the fp32 rows (12 queries per pass; topn > 128
@@ -564,10 +565,11 @@ int mi355rec_sharded_stream_stats(const mi355rec_sharded_t* h, int64_t* queries,
  *   POISON          now (synchronises the device): every sample buffer and every left-behind cutoff of the handle is
  *                   overwritten with the most hostile values an EARLIER query could have left (a perfect score, a
  *                   cutoff of +1.0) under the epochs of the last queries;
- *   DROP_STORES     the seed riders of the next streamed launch do not store the first half of their regions (the
- *                   last rider then reads whatever was there before);
- *   NO_LAST_RIDER   the next streamed launch is told a wrong arrival count, so none of its riders selects a cutoff
- *                   (the following launch then finds whatever cutoff was there before).
+ *   DROP_STORES     the next sampling launch (the seed riders of a streamed launch, or the sample launch of a batch on
+ *                   its own / at the head of a stream) does not store the first half of its regions (whoever selects
+ *                   the cutoffs then reads whatever was there before);
+ *   NO_LAST_RIDER   the next sampling launch is told a wrong arrival count, so none of its workgroups selects a cutoff
+ *                   (the pass behind it then finds whatever cutoff was there before).
  * Never needed in production; tests/test_gpu_replica.py and tests/test_gpu_half_multi.py use it. */
 #define MI355REC_DEBUG_HANDOFF_POISON 1
 #define MI355REC_DEBUG_HANDOFF_DROP_STORES 2

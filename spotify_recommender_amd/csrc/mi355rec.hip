@@ -967,8 +967,11 @@ int enqueue_half_multi(mi355rec* h, const float* queries, const float* const* qp
         // the sample launch's last workgroup selects the cutoffs; the pass reads them (stream order)
         const unsigned long long* const cuts = h->d_half_mcuts;
         hipLaunchKernelGGL(seed_half_multi_kernel, dim3(h->hg.seed_grid), dim3(kHmBlock), 0, s, h->d_half, h->n, h->hg.seed_stride,
-                           arg, nq, h->d_half_mseed, epoch, hm_sample_log2(h, nq, false), h->d_half_mctl, h->half_mctl_done, h->d_half_mcuts, topn);
+                           arg, nq, h->d_half_mseed, epoch, hm_sample_log2(h, nq, false), h->d_half_mctl,
+                           h->half_mctl_done + (h->dbg_no_last ? 0x40000000u : 0u), h->d_half_mcuts, topn, h->dbg_skip_regions);
         h->half_mctl_done += static_cast<unsigned>(h->hg.seed_grid);
+        h->dbg_no_last = false;   // (test hooks of mi355rec_debug_handoff: they apply to ONE sampling launch)
+        h->dbg_skip_regions = 0;
         ++h->half_scans;
         if (multi_front_q8(h, nq)) {   // rows from the 8-bit replica through the integer matrix core (replica_multi.hip.h)
             ++h->q8_scans;
@@ -1141,9 +1144,12 @@ int enqueue_mstream(mi355rec* h, const float* queries, const float* const* qptrs
     } else {   // the head of a stream: a sample launch of its own
         hipLaunchKernelGGL(seed_half_multi_kernel, dim3(h->hg.seed_grid), dim3(kHmBlock), 0, s, h->d_half, h->n, h->hg.seed_stride,
                            arg, nq, h->d_mstream_seed[seed_buf], epoch, hm_sample_log2(h, nq, false), h->d_mstream_ctl + seed_buf,
-                           h->mctl_done[seed_buf], h->d_mstream_cuts + seed_buf * kHmQueries, topn);
+                           h->mctl_done[seed_buf] + (h->dbg_no_last ? 0x40000000u : 0u), h->d_mstream_cuts + seed_buf * kHmQueries, topn,
+                           h->dbg_skip_regions);
         HIP_TRY(h, hipGetLastError());
         h->mctl_done[seed_buf] += static_cast<unsigned>(h->hg.seed_grid);
+        h->dbg_no_last = false;
+        h->dbg_skip_regions = 0;
         cuts_ready = h->hg.seed_grid > 0;
     }
     auto& st = h->mstash;
@@ -1449,8 +1455,9 @@ int enqueue_streamed(mi355rec* h, const float* qptr, const float* query12, int64
 
 constexpr int64_t kBqMinRows = 65536;   // below this the launch count, not the arithmetic, decides
 constexpr int kBqMinBatch = 13;          // without a replica: up to 12 queries are ONE exact multi-query pass (141 us at 10 M rows)
-constexpr int kHmAutoMax = 16;           // up to here a batch goes in ONE multi-query pass over the replica (measured at 10 M
-                                         // rows x top-100: 71 / 82 / 88 us per call for 2 / 12 / 16 queries, the matrix-core path 88)
+constexpr int kHmAutoMax = 32;           // up to here a batch goes in ONE multi-query pass over the replica (measured at 10 M
+                                         // rows x top-100, round 4: 70 / 76 / 78 / 81 us per call for 2 / 12 / 16 / 32 queries, the
+                                         // matrix-core path 88-93 for any chunk of <= 32)
 constexpr int kBqMinBatchReplica = 3;    // with one, the passes cost ~92 us for any chunk of <= 32 queries (two single
                                          // replica scans cost 88): measured at 10 M rows, tools/run_batched.py
 
@@ -2198,10 +2205,11 @@ int mi355rec_debug_handoff(mi355rec_t* h, int flags) {
             ctl[0].cutoff = ctl[1].cutoff = stale_cut;   // (the arrival counters stay what they are)
             HIP_TRY(h, hipMemcpy(h->d_stream_ctl, ctl, sizeof ctl, hipMemcpyHostToDevice));
         }
-        if (h->d_mstream_cuts) {
-            std::vector<unsigned long long> cuts(2 * kHmQueries, stale_cut);
+        std::vector<unsigned long long> cuts(2 * kHmQueries, stale_cut);
+        if (h->d_mstream_cuts)
             HIP_TRY(h, hipMemcpy(h->d_mstream_cuts, cuts.data(), sizeof(unsigned long long) * cuts.size(), hipMemcpyHostToDevice));
-        }
+        if (h->d_half_mcuts)
+            HIP_TRY(h, hipMemcpy(h->d_half_mcuts, cuts.data(), sizeof(unsigned long long) * kHmQueries, hipMemcpyHostToDevice));
     }
     if (flags & MI355REC_DEBUG_HANDOFF_DROP_STORES) h->dbg_skip_regions = kHalfSeedMaxGrid / 2;
     if (flags & MI355REC_DEBUG_HANDOFF_NO_LAST_RIDER) h->dbg_no_last = true;

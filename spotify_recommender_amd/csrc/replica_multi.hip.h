@@ -546,7 +546,8 @@ __global__ __launch_bounds__(kHmBlock) void seed_half_multi_kernel(
     const uint4* __restrict__ half, int64_t n, int64_t stride_rows, HalfMultiArg arg, int n_queries,
     unsigned long long* __restrict__ seed_vals /* [query][gridDim.x * kHalfSeedWaves], tagged with `epoch` */, uint32_t epoch,
     int log2_mult /* rows per region = 1024 << log2_mult */, SeedCtl* __restrict__ ctl /* arrival counter (null: no cutoffs) */,
-    unsigned done_base, unsigned long long* __restrict__ cuts /* [n_queries] tagged cutoffs */, int topk) {
+    unsigned done_base, unsigned long long* __restrict__ cuts /* [n_queries] tagged cutoffs */, int topk,
+    int debug_skip /* test hook (mi355rec_debug_handoff): the regions below this are sampled but not stored */) {
     __shared__ uint4 s_b[64];
     __shared__ uint32_t s_ok[kHmQueries];
     __shared__ unsigned s_round;
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(kHmBlock) void seed_half_multi_kernel(
         s_ok[threadIdx.x] = hm_build_fragment(arg, n_queries, threadIdx.x, 0u, s_b, q, qn) ? 1u : 0u;
     }
     __syncthreads();
-    hm_sample_regions<4>(half, n, stride_rows, gridDim.x, blockIdx.x, gridDim.x, s_b, n_queries, seed_vals, epoch, log2_mult);
+    hm_sample_regions<4>(half, n, stride_rows, gridDim.x, blockIdx.x, gridDim.x, s_b, n_queries, seed_vals, epoch, log2_mult, debug_skip);
     if (ctl)   // uniform
         hm_arrive_and_select(ctl, done_base, gridDim.x, n_queries, s_ok, seed_vals, static_cast<int>(gridDim.x) * kHalfSeedWaves, topk,
                              arg.margin, epoch, cuts, &s_round);

@@ -3,7 +3,7 @@
 candidates, or 24 B/row through the fp16 matrix core — candidates resolved in the same launch; every key
 is still the exact fp32 chain on the fp32 row.
 Through the C-ABI (mi355rec_query_batch_topn / _enqueue_batch_keys with MI355REC_BATCH_HALF forced, and
-under AUTO where up to 16 queries on a shard with a replica take this path), against the oracle:
+under AUTO where up to 32 queries on a shard with a replica take this path), against the oracle:
 scores bit-exact, ids tie-aware, keys identical to the single-query path.
 
 The hostile cases are the replica scan's own (tests/test_gpu_replica.py): value ranges of the error
@@ -113,20 +113,20 @@ def test_batches_match_the_oracle_and_the_single_query_path(Engine, torch_cuda, 
         assert 1 <= per_pass < 0.05 * n * 32, per_pass
 
 
-def test_up_to_16_queries_take_this_path_under_auto(Engine):
+def test_up_to_32_queries_take_this_path_under_auto(Engine):
     rng = np.random.default_rng(5)
     n = 400_000
     f = rng.random((n, 12), dtype=np.float32)
     rows = rng.integers(0, n, size=32)
     with Engine(f) as eng:
-        for batch in (2, 12, 16):
+        for batch in (2, 12, 16, 32):
             before = eng.replica_counters()["scans"]
             check_batch(eng, f, f[rows[:batch]], rows[:batch].astype(np.int64), 100, "auto", path=AUTO)
             assert eng.replica_counters()["scans"] == before + 1      # ONE pass over the replica
-        # 17 and more queries: the two-pass matrix-core path (no replica SCAN is counted)
+        # 33 and more queries: the two-pass matrix-core path (no replica SCAN is counted)
         before = eng.replica_counters()["scans"]
-        rows13 = rng.integers(0, n, size=17)
-        check_batch(eng, f, f[rows13], rows13.astype(np.int64), 100, "auto 17", path=AUTO)
+        rows13 = rng.integers(0, n, size=33)
+        check_batch(eng, f, f[rows13], rows13.astype(np.int64), 100, "auto 33", path=AUTO)
         assert eng.replica_counters()["scans"] == before
         assert eng.batched_last_counters()["queued_queries"] == 0
 
@@ -371,6 +371,13 @@ def test_stream_of_batches_fails_safe_under_stale_hand_offs(Engine, torch_cuda):
         torch.cuda.synchronize()
         bad = [i for i in range(len(batches)) if not torch.equal(want[i], got[i])]
         assert not bad, bad
+        # a batch on its own hands its cutoffs from the sample launch's last workgroups to the pass: the same hooks
+        for step, hook in enumerate((P, D, L, P | D | L, P | L)):
+            eng.debug_handoff(hook)
+            keys = torch.zeros(len(batches[step]) * topn, dtype=torch.int64, device="cuda")
+            eng.enqueue_batch_keys(f[batches[step]], batches[step].astype(np.int64), topn, keys)
+            torch.cuda.synchronize()
+            assert torch.equal(want[step], keys), (step, hook)
         # and against the oracle for one batch that ran right behind a poisoned, last-rider-less launch
         check = got[13].cpu().numpy().reshape(len(batches[13]), topn)
         from spotify_recommender_amd.engine import unpack_keys

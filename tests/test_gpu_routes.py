@@ -49,12 +49,14 @@ CELLS = [
     # batches on a shard WITHOUT a replica (< 65536 rows): exact 12-query passes, whatever the count
     (30_000, "batch", 2, 10, {"route_multi_fp32": 1}),
     (30_000, "batch", 40, 10, {"route_multi_fp32": 4}),
-    # batches with a replica: 2 queries -> one pass through the 8-bit front end; 3 ... 16 -> one pass over the fp16
-    # replica; 17 and more -> the two-pass matrix-core path (chunks of 1024)
+    # batches with a replica: 2 queries -> one pass through the 8-bit front end; 3 ... 32 -> one pass over the fp16
+    # replica; 33 and more -> the two-pass matrix-core path (chunks of 1024)
     (300_000, "batch", 2, 100, {"route_multi_q8": 1}),
     (300_000, "batch", 3, 100, {"route_multi_fp16": 1}),
     (300_000, "batch", 16, 100, {"route_multi_fp16": 1}),
-    (300_000, "batch", 17, 100, {"route_mfma_two_pass": 1}),
+    (300_000, "batch", 17, 100, {"route_multi_fp16": 1}),
+    (300_000, "batch", 32, 100, {"route_multi_fp16": 1}),
+    (300_000, "batch", 33, 100, {"route_mfma_two_pass": 1}),
     (1_500_000, "batch", 1200, 50, {"route_mfma_two_pass": 2}),
     (300_000, "dev", 64, 100, {"route_mfma_two_pass": 1}),
     # topn above 128: no multi-query pass holds that many keys per query -> one scan per query
