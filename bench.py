@@ -237,6 +237,8 @@ def run_node(args, json_fd):
     replicated = args.placement == "replicated"
     node = NodeEngine(feats_host, devices=devices,
                       placement=capi.PLACEMENT_REPLICATED if replicated else capi.PLACEMENT_SHARDED)
+    if node.placement() == capi.PLACEMENT_CPU:   # (cannot happen with an explicit device list; never measure the CPU backend)
+        raise RuntimeError("the node handle is served by the CPU backend: no HIP device is visible to libmi355rec.so")
     info = node.info()
     node.set_window(args.window)
     # `value` is measured with one streamed scan launch per shard per QUERY (each query its own pass over

@@ -24,3 +24,15 @@ def engine_lib():
     if not capi.LIB_PATH.exists():
         build.build_engine()
     return capi.lib()
+
+
+@pytest.fixture(autouse=True)
+def _gpu_tests_run_on_the_gpu(request):
+    """A test marked `gpu` must exercise the HIP path: the library has to see a device, so that the node-level entry
+    points cannot hand such a test the CPU backend of device-less hosts (csrc/cpu_backend.cpp) without anyone noticing."""
+    if request.node.get_closest_marker("gpu") is not None:
+        import torch
+        assert torch.cuda.is_available(), "a test marked gpu is running without a GPU"
+        from spotify_recommender_amd import capi
+        assert capi.lib().mi355rec_device_count() > 0, "libmi355rec.so sees no HIP device on a GPU box"
+    yield
