@@ -83,6 +83,49 @@ def kernel_metadata(lib: Path = LIB_ENGINE) -> list:
     return out
 
 
+def handoff_sites(lib: Path = LIB_ENGINE) -> list:
+    """Disassembles the gfx950 code objects inside a built library and returns, for every "barrier, then one thread
+    counts the workgroup in" site (an s_barrier followed within a few instructions by a RETURNING global_atomic_add:
+    the arrival of a cross-workgroup hand-off), whether an `s_waitcnt vmcnt(0)` stands before that
+    barrier: [(kernel, has_vmcnt0)].  A workgroup-scope fence does not wait for a wave's global stores on gfx950
+    (ADVICE r3): without the wait the count can reach memory before the write-through stores it announces."""
+    import re
+    import tempfile
+
+    sites = []
+    with tempfile.TemporaryDirectory() as tmp:
+        fat = Path(tmp) / "fat.bin"
+        _run([LLVM_BIN / "llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", lib, Path(tmp) / "copy.so"])
+        blob = fat.read_bytes()
+        starts = [m.start() for m in re.finditer(re.escape(BUNDLE_MAGIC), blob)]
+        for i, a in enumerate(starts):
+            b = starts[i + 1] if i + 1 < len(starts) else len(blob)
+            part, co = Path(tmp) / f"bundle{i}.bin", Path(tmp) / f"dev{i}.co"
+            part.write_bytes(blob[a:b])
+            _run([LLVM_BIN / "clang-offload-bundler", "--unbundle", "--type=o", f"--input={part}",
+                  f"--targets=hipv4-amdgcn-amd-amdhsa--{OFFLOAD_ARCH}", f"--output={co}"])
+            text = subprocess.run([str(LLVM_BIN / "llvm-objdump"), "-d", "--no-show-raw-insn", str(co)],
+                                  capture_output=True, text=True, check=True).stdout
+            kernel, window = None, []
+            for line in text.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+                if m:
+                    kernel, window = m.group(1), []
+                    continue
+                ins = line.strip()
+                if not ins or kernel is None:
+                    continue
+                window.append(ins)
+                del window[:-80]
+                if ins.startswith("global_atomic_add") and " sc0" in ins:   # a returning add: somebody wants to know its place
+                    near = window[-64:-1]
+                    if any(x.startswith("s_barrier") for x in near):
+                        before = window[:-1]
+                        last_bar = max(j for j, x in enumerate(before) if x.startswith("s_barrier"))
+                        sites.append((kernel, any("vmcnt(0)" in x for x in before[max(0, last_bar - 40):last_bar])))
+    return sites
+
+
 def check_no_scratch(lib: Path = LIB_ENGINE) -> int:
     """No kernel of the engine may reserve private (scratch) memory: a dispatch of such a kernel sets up
     scratch even when no instruction touches it (scan_half_multi_kernel did, for a dead 16-byte stack slot:

@@ -34,3 +34,15 @@ def test_hot_kernels_keep_their_occupancy(kernels):
         assert k["vgpr"] <= 80, k                                        # three workgroups of 512 per CU
     for k in of("bq_pass_kernel"):
         assert k["vgpr"] <= 128 and k["lds"] <= 40 * 1024, k          # four workgroups of 256 per CU
+
+
+def test_hand_offs_wait_for_their_stores(engine_lib):
+    """at every "barrier, then one thread counts the workgroup in" site the waves must have waited for
+    their own global stores (s_waitcnt vmcnt(0)) before the barrier — a workgroup-scope release does not on gfx950.
+    Read from the disassembly of the library that ships."""
+    sites = build.handoff_sites(build.LIB_ENGINE)
+    kernels = {k for k, _ in sites}
+    for fragment in ("scan_q8_kernel", "scan_half_multi_kernel", "seed_half_multi_kernel", "scan_multi_queued_kernel"):
+        assert any(fragment in k for k in kernels), (fragment, sorted(kernels))
+    bad = sorted({k for k, ok in sites if not ok})
+    assert not bad, bad
