@@ -107,6 +107,25 @@ class CosineEngine:
             score.ctypes.data_as(ctypes.c_void_p), ctypes.byref(count)), self._h)
         return idx[:count.value].copy(), score[:count.value].copy()
 
+    def bound_query_row_topn(self, topn: int):
+        """`mi355rec_query_row_topn` with CALLER-OWNED result buffers bound once, as a C or C++ host would call it: returns
+        call(row) -> (idx, score, count), the same two arrays every time (valid until the next call).  What a latency
+        loop should use: query_row_topn() allocates and converts per call (~3 us of Python around a 46 us query)."""
+        topn = int(topn)
+        n_out = max(topn, 1)
+        idx = np.empty(n_out, dtype=np.int64)
+        score = np.empty(n_out, dtype=np.float32)
+        count = ctypes.c_int(0)
+        p_idx, p_score, p_count = idx.ctypes.data_as(ctypes.c_void_p), score.ctypes.data_as(ctypes.c_void_p), ctypes.byref(count)
+        fn, h = self._lib.mi355rec_query_row_topn, self._h
+
+        def call(local_row: int):
+            rc = fn(h, local_row, topn, p_idx, p_score, p_count)
+            if rc:
+                capi.check(rc, h)
+            return idx, score, count.value
+        return call
+
     def query_topn(self, query, exclude_global: int, topn: int) -> Tuple[np.ndarray, np.ndarray]:
         q = _np_f32(query).reshape(capi.DIM)
         n_out = max(int(topn), 1)
