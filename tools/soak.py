@@ -68,6 +68,34 @@ def main():
                 torch.cuda.synchronize()
                 bad_b += not torch.equal(single, outs[c][b * 100:(b + 1) * 100])
         out["batch_stream_mismatches"] = int(bad_b)
+        # batches on their OWN (the sample launch's last workgroups hand the cutoffs to the pass, round 4) and streams of
+        # 2- and 32-query batches, sizes mixed; every batch checked against single queries over the fp32 rows
+        eng.set_replica(capi.REPLICA_ON)
+        sizes = rng.choice([2, 5, 12, 20, 32], size=120)
+        lone_outs, stream_outs, offs = [], [], []
+        off = 0
+        for nbq in sizes:
+            sl = slice(off, off + int(nbq))
+            offs.append(sl)
+            qv = t[torch.tensor(rows[sl], device="cuda")].cpu().numpy()
+            k1 = torch.zeros(int(nbq) * 100, dtype=torch.int64, device="cuda")
+            eng.enqueue_batch_keys(qv, rows[sl].astype(np.int64), 100, k1)
+            lone_outs.append(k1)
+            k2 = torch.zeros(int(nbq) * 100, dtype=torch.int64, device="cuda")
+            eng.enqueue_batch_keys_streamed(qv, rows[sl].astype(np.int64), 100, k2)
+            stream_outs.append(k2)
+            off += int(nbq)
+        eng.enqueue_flush()
+        torch.cuda.synchronize()
+        eng.set_replica(capi.REPLICA_OFF)
+        bad_m = 0
+        for c in range(0, len(sizes), 3):
+            for b, r in enumerate(rows[offs[c]]):
+                eng.enqueue_row_keys(int(r), 100, single)
+                torch.cuda.synchronize()
+                bad_m += not torch.equal(single, lone_outs[c][b * 100:(b + 1) * 100])
+                bad_m += not torch.equal(single, stream_outs[c][b * 100:(b + 1) * 100])
+        out["mixed_batch_mismatches"] = int(bad_m)
         # lone synchronous queries (scan + merge + completion word in one launch at this size)
         eng.set_replica(capi.REPLICA_ON)
         bad_l = 0
@@ -78,7 +106,7 @@ def main():
         out["lone_mismatches"] = int(bad_l)
         out["lone_fused_queries"] = int(eng.stats().lone_fused_queries)
     print(json.dumps(out), flush=True)
-    return 1 if (out["streamed_mismatches"] or out["batch_stream_mismatches"] or out["lone_mismatches"]) else 0
+    return 1 if (out["streamed_mismatches"] or out["batch_stream_mismatches"] or out["mixed_batch_mismatches"] or out["lone_mismatches"]) else 0
 
 
 if __name__ == "__main__":
