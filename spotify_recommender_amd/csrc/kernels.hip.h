@@ -820,6 +820,38 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
     SelectSmem& s_sel = *s_sel_p;
     int& s_count = *s_count_p;
 
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    // rows_per_block > 0: workgroup b owns the contiguous rows [b*rpb, (b+1)*rpb).
+    // rows_per_block == 0: tiles are dealt round-robin (tile t -> workgroup t % grid),
+    // so at any moment the whole chip reads one moving ~20 MB window of the matrix.
+    const bool interleaved = rows_per_block == 0;
+    const int64_t blk_begin = static_cast<int64_t>(bid) * (interleaved ? kTileRows : rows_per_block);
+    const int64_t tile_stride = interleaved ? static_cast<int64_t>(nblocks) * kTileRows : kTileRows;
+    int64_t blk_end = interleaved ? n : blk_begin + rows_per_block;
+    if (blk_end > n) blk_end = n;
+    // rows past the block's end re-read its last row (one cached line) so the
+    // prefetch can be unconditional: a conditional load would make the compiler
+    // wait vmcnt(0) at the join and serialise the pipeline
+    const int64_t last_row = blk_end - 1;  // the host launches only non-empty blocks
+
+    auto load_tile = [&](Row (&dst)[kRowsPerThread], int it) {
+        const int64_t tile_begin = blk_begin + static_cast<int64_t>(it) * tile_stride;
+#pragma unroll
+        for (int u = 0; u < kRowsPerThread; ++u) {
+            const int64_t r = tile_begin + u * kBlock + tid;
+            dst[u] = load_row(feats, r < blk_end ? r : last_row);
+        }
+    };
+
+    // The first tile(s) are requested BEFORE the query is: the query's 12 floats sit behind two dependent scalar loads
+    // (the pointer, then the row) and a norm, the tile behind one vector load, and neither needs the other — issued in
+    // source order the tile waited ~1.5-2 us for the query on every launch (a sixth of a 1 M-row scan).
+    constexpr int kDepth = Cfg::kDepth;
+    Row ring[kDepth][kRowsPerThread];
+#pragma unroll
+    for (int d = 0; d < kDepth - 1; ++d) load_tile(ring[d], d);
+
     float q[kDim];
     if constexpr (kQueryFromRow) {
         // 12 floats anywhere this device can read: a resident row of this shard, a row of
@@ -836,21 +868,6 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
     // below the last key of round r-1 (0 there = catalogue exhausted).
     // (streamed queries are single-round: no bound, and two VGPRs the riding variant needs)
     const uint64_t upper = kWithMerge ? ~0ull : (upper_ptr ? *upper_ptr : ~0ull);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    // rows_per_block > 0: workgroup b owns the contiguous rows [b*rpb, (b+1)*rpb).
-    // rows_per_block == 0: tiles are dealt round-robin (tile t -> workgroup t % grid),
-    // so at any moment the whole chip reads one moving ~20 MB window of the matrix.
-    const bool interleaved = rows_per_block == 0;
-    const int64_t blk_begin = static_cast<int64_t>(bid) * (interleaved ? kTileRows : rows_per_block);
-    const int64_t tile_stride = interleaved ? static_cast<int64_t>(nblocks) * kTileRows : kTileRows;
-    int64_t blk_end = interleaved ? n : blk_begin + rows_per_block;
-    if (blk_end > n) blk_end = n;
-    // rows past the block's end re-read its last row (one cached line) so the
-    // prefetch can be unconditional: a conditional load would make the compiler
-    // wait vmcnt(0) at the join and serialise the pipeline
-    const int64_t last_row = blk_end - 1;  // the host launches only non-empty blocks
 
     if constexpr (!kScoresOnly) {
         if (tid == 0) s_count = 0;
@@ -869,15 +886,6 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
     // costs an LDS atomic round trip in the streaming loop).
     int compact_at = 2 * topk > 256 ? 2 * topk : 256;
     if (compact_at > kCandLimit) compact_at = kCandLimit;
-
-    auto load_tile = [&](Row (&dst)[kRowsPerThread], int it) {
-        const int64_t tile_begin = blk_begin + static_cast<int64_t>(it) * tile_stride;
-#pragma unroll
-        for (int u = 0; u < kRowsPerThread; ++u) {
-            const int64_t r = tile_begin + u * kBlock + tid;
-            dst[u] = load_row(feats, r < blk_end ? r : last_row);
-        }
-    };
 
     auto process_tile = [&](const Row (&rows)[kRowsPerThread], int it) {
         const int64_t tile_begin = blk_begin + static_cast<int64_t>(it) * tile_stride;
@@ -928,10 +936,6 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
 
     // kDepth tiles in flight per lane: the loads of tile it + kDepth - 1 are issued
     // before tile it is scored (register ring, statically indexed).
-    constexpr int kDepth = Cfg::kDepth;
-    Row ring[kDepth][kRowsPerThread];
-#pragma unroll
-    for (int d = 0; d < kDepth - 1; ++d) load_tile(ring[d], d);
     for (int it = 0; it < iters; it += kDepth) {
 #pragma unroll
         for (int sidx = 0; sidx < kDepth; ++sidx) {
