@@ -184,16 +184,17 @@ __device__ __forceinline__ int hm_tile_max(const bq_f16v& d) {   // max over the
 // BATCH; the host picks log2_mult from the batch size (hm_sample_log2).  Regions are >= 1024 << log2_mult rows apart
 // (host), so no row is sampled twice.
 // Workgroup `first`, `first + every`, ... of the regions; called by all 512 threads.  kDepth chunks are in flight per wave.
-template <int kDepth>
+// `make_fragment` builds the batch's B fragment at `bfrag` (and ends with a barrier); it is called AFTER the first chunks
+// have been requested — they need nothing of the queries, which sit behind dependent loads and a normalisation.
+template <int kDepth, typename MakeFragment>
 __device__ __forceinline__ void hm_sample_regions(const uint4* __restrict__ half, int64_t n, int64_t stride_rows, int regions,
                                                   int first, int every, const uint4* bfrag, int n_queries,
                                                   unsigned long long* __restrict__ seed_vals, uint32_t epoch, int log2_mult,
-                                                  int debug_skip = 0) {
+                                                  int debug_skip, MakeFragment&& make_fragment) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t n_pairs = (n + 1) >> 1;
     const uint32_t n32 = static_cast<uint32_t>(n);
-    const bq_h8 B = __builtin_bit_cast(bq_h8, bfrag[lane]);
     const bq_f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     const int64_t per_query = static_cast<int64_t>(regions) * kHalfSeedWaves;
     const int mult = 1 << log2_mult;
@@ -213,6 +214,8 @@ __device__ __forceinline__ void hm_sample_regions(const uint4* __restrict__ half
 #pragma unroll
     for (int k = 0; k < kDepth; ++k)
         if (k < total) load(t[k], k);
+    make_fragment();
+    const bq_h8 B = __builtin_bit_cast(bq_h8, bfrag[lane]);
     int m = static_cast<int>(0x80000000u);
     for (int i0 = 0; i0 < total; i0 += kDepth) {
 #pragma unroll
@@ -551,12 +554,14 @@ __global__ __launch_bounds__(kHmBlock) void seed_half_multi_kernel(
     __shared__ uint4 s_b[64];
     __shared__ uint32_t s_ok[kHmQueries];
     __shared__ unsigned s_round;
-    if (threadIdx.x < kHmQueries) {
-        float q[kDim], qn;
-        s_ok[threadIdx.x] = hm_build_fragment(arg, n_queries, threadIdx.x, 0u, s_b, q, qn) ? 1u : 0u;
-    }
-    __syncthreads();
-    hm_sample_regions<4>(half, n, stride_rows, gridDim.x, blockIdx.x, gridDim.x, s_b, n_queries, seed_vals, epoch, log2_mult, debug_skip);
+    hm_sample_regions<4>(half, n, stride_rows, gridDim.x, blockIdx.x, gridDim.x, s_b, n_queries, seed_vals, epoch, log2_mult, debug_skip,
+                         [&]() {
+                             if (threadIdx.x < kHmQueries) {
+                                 float q[kDim], qn;
+                                 s_ok[threadIdx.x] = hm_build_fragment(arg, n_queries, threadIdx.x, 0u, s_b, q, qn) ? 1u : 0u;
+                             }
+                             __syncthreads();
+                         });
     if (ctl)   // uniform
         hm_arrive_and_select(ctl, done_base, gridDim.x, n_queries, s_ok, seed_vals, static_cast<int>(gridDim.x) * kHalfSeedWaves, topk,
                              arg.margin, epoch, cuts, &s_round);
@@ -634,13 +639,15 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
                 }
             } else {                           // a seed rider: its share of the next batch's sample
                 uint4* const fb = s_mem.scan.bfrag;
-                if (tid < kHmQueries) {
-                    float q[kDim], qn;
-                    s_mem.scan.ok[tid] = hm_build_fragment(next, ride.next_queries, tid, 0u, fb, q, qn) ? 1u : 0u;
-                }
-                __syncthreads();
                 hm_sample_regions<4>(half, n, ride.stride_rows, ride.regions, extra - ride.merge_wgs, ride.seed_wgs, fb,
-                                     ride.next_queries, ride.next_seed_vals, ride.next_epoch, ride.sample_log2, ride.debug_skip);
+                                     ride.next_queries, ride.next_seed_vals, ride.next_epoch, ride.sample_log2, ride.debug_skip,
+                                     [&]() {
+                                         if (tid < kHmQueries) {
+                                             float q[kDim], qn;
+                                             s_mem.scan.ok[tid] = hm_build_fragment(next, ride.next_queries, tid, 0u, fb, q, qn) ? 1u : 0u;
+                                         }
+                                         __syncthreads();
+                                     });
                 if (ride.next_ctl)   // uniform: the last riders out select the next batch's cutoffs
                     hm_arrive_and_select(ride.next_ctl, ride.done_base, static_cast<unsigned>(ride.seed_wgs), ride.next_queries,
                                          s_mem.scan.ok, ride.next_seed_vals, ride.regions * kHalfSeedWaves, ride.next_topk, next.margin,

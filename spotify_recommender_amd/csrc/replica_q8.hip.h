@@ -222,11 +222,13 @@ template <bool kQueryFromRow, bool kExact>
 __global__ __launch_bounds__(kHalfSeedBlock) void seed_q8_kernel(
     const float* __restrict__ feats, const uint4* __restrict__ q8, int64_t n, int64_t stride_rows, int64_t row_base, QueryArg qarg,
     const float* __restrict__ query_ptr, int64_t exclude_global, unsigned long long* __restrict__ seed_vals, uint32_t epoch) {
+    // the region's rows are requested FIRST: they need nothing of the query, whose 12 floats sit behind two dependent
+    // scalar loads and a norm (this launch is on the critical path of a query alone)
+    const Q8Region s = q8_region_load(q8, (n + 3) >> 2, stride_rows, blockIdx.x);
     float q[kDim];
     q8_load_query(kQueryFromRow ? query_ptr : nullptr, qarg.q, q);
     const float qn = query_norm(q);
     const Q8Query hq = q8_query(q, qn);
-    const Q8Region s = q8_region_load(q8, (n + 3) >> 2, stride_rows, blockIdx.x);
     const Q8Pick p = q8_region_pick(s, hq, n, row_base, exclude_global);
     Row row;
     row.a = row.b = row.c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -237,23 +239,30 @@ __global__ __launch_bounds__(kHalfSeedBlock) void seed_q8_kernel(
 // The seed riders of a streamed launch (replica.hip.h, seed_rider): four regions per memory round trip.
 __device__ __forceinline__ Q8Query q8_seed_rider(const float* __restrict__ feats, const uint4* __restrict__ q8, int64_t n,
                                                  int64_t row_base, const NextSeed& next, int rider) {
-    float q[kDim];
-    q8_load_query(next.query_ptr, next.q, q);
-    const float qn = query_norm(q);
-    const Q8Query hq = q8_query(q, qn);
     const int64_t n_quads = (n + 3) >> 2;
     unsigned long long* const out = static_cast<unsigned long long*>(next.out);
     constexpr int kAhead = 4;
-    for (int g0 = rider; g0 < next.regions; g0 += kAhead * next.n_wgs) {
-        Q8Region s[kAhead];
+    // A round's regions are requested before anything that does not need them: the first round before the QUERY is
+    // (two dependent scalar loads and a norm: on a 1 M-row shard the riders' chain is the longest thing in the launch),
+    // every later one right after the round before has been reduced, under its winners' fetches and stores.
+    Q8Region s[kAhead];
+    auto load_round = [&](int g0) {
 #pragma unroll
         for (int u = 0; u < kAhead; ++u) {
             const int g = g0 + u * next.n_wgs;
             s[u] = q8_region_load(q8, n_quads, next.stride_rows, g < next.regions ? g : rider);
         }
+    };
+    if (rider < next.regions) load_round(rider);
+    float q[kDim];
+    q8_load_query(next.query_ptr, next.q, q);
+    const float qn = query_norm(q);
+    const Q8Query hq = q8_query(q, qn);
+    for (int g0 = rider; g0 < next.regions; g0 += kAhead * next.n_wgs) {
         Q8Pick pick[kAhead];
 #pragma unroll
         for (int u = 0; u < kAhead; ++u) pick[u] = q8_region_pick(s[u], hq, n, row_base, next.exclude_global);
+        if (g0 + kAhead * next.n_wgs < next.regions) load_round(g0 + kAhead * next.n_wgs);   // uniform
         if (next.exact) {   // uniform: the four winners' rows, one more round trip with four fetches in flight
             Row best[kAhead];
 #pragma unroll
