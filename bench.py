@@ -495,6 +495,9 @@ def main():
         return run_node(args, json_fd)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1 and args.placement != "sharded":
+        raise SystemExit("--placement replicated is a mode of the single-process node handle (launch bench.py plainly); "
+                         "one process per GPU under torch.distributed is north_star's row sharding + one all-gather")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     force_sharded = os.environ.get("BENCH_FORCE_SHARDED") == "1"  # exercise the RCCL path on one GPU
