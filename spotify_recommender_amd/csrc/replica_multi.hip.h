@@ -270,6 +270,7 @@ struct alignas(16) HalfMultiSmem {
     uint4 bfrag8[kHmQueries];
     float m8[kHmQueries];
     int q8;
+    uint32_t select_here;                       // bit q: nobody left a cutoff for query q under this batch's epoch — this workgroup selects it
 };
 
 // -T' as the fp16 pair (hi, lo) of the B fragment's threshold slots.  T' = -inf ("every row is a
@@ -721,18 +722,32 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
         sm.rescored = 0;
         sm.margin = arg.margin;
         sm.q8 = kQ8 ? 1 : 0;
+        sm.select_here = 0u;
     }
     __syncthreads();
-    if (cuts_ready) {   // uniform: the last seed rider of the launch before this one selected them
-        if (tid < n_queries && sm.ok[tid]) {
-            const float cut = untag_cutoff(cuts_ready[tid], epoch);   // another epoch: no launch-wide cutoff for this query
-            sm.cut[tid] = cut;
-            reinterpret_cast<uint32_t*>(&sm.bfrag[32 + tid])[2] = hm_threshold_slots(cut);
-            if constexpr (kQ8) reinterpret_cast<uint32_t*>(&sm.bfrag8[tid])[3] = hm_q8_slots(cut + arg.margin + kBqSlack - sm.m8[tid]);
+    // The cutoffs: normally left, tagged with this batch's epoch, by the last sampling workgroups (the sample launch's,
+    // or the seed riders of the launch before).  A cutoff that is NOT there under this epoch (a hand-off that went
+    // wrong: replica.hip.h, "hand-offs that fail safe") is selected here from whatever sample values carry the epoch —
+    // what every workgroup did for every query before round 4 — so a broken hand-off costs microseconds, not a scan
+    // without a cutoff.
+    if (tid < n_queries && sm.ok[tid]) {
+        bool have = false;
+        if (cuts_ready) {   // uniform
+            const unsigned long long w = cuts_ready[tid];
+            have = static_cast<uint32_t>(w >> 32) == epoch;
+            if (have) {
+                const float cut = __uint_as_float(static_cast<uint32_t>(w));
+                sm.cut[tid] = cut;
+                reinterpret_cast<uint32_t*>(&sm.bfrag[32 + tid])[2] = hm_threshold_slots(cut);
+                if constexpr (kQ8) reinterpret_cast<uint32_t*>(&sm.bfrag8[tid])[3] = hm_q8_slots(cut + arg.margin + kBqSlack - sm.m8[tid]);
+            }
         }
-    } else if (n_seed > 0) {
+        if (!have && n_seed > 0) atomicOr(&sm.select_here, 1u << tid);
+    }
+    __syncthreads();
+    if (const uint32_t todo = sm.select_here) {   // uniform, rare
         for (int qi = wave; qi < n_queries; qi += kHmWaves) {
-            if (sm.ok[qi]) {   // uniform
+            if ((todo >> qi) & 1u) {   // wave-uniform
                 // the (topk + 1)-th largest: the query's own row may be among the sampled ones (hm_sample_regions)
                 const float cut = hm_seed_cutoff(seed_vals + static_cast<int64_t>(qi) * n_seed, n_seed, topk + 1, arg.margin, epoch);
                 if (lane == 0) {
@@ -742,8 +757,8 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
                 }
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
 
     int staged = 0;       // wave-uniform
     int n_rescored = 0;   // wave-uniform (diagnostics)
