@@ -22,7 +22,11 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--check", type=int, default=64, help="queries compared between the two paths")
     ap.add_argument("--only", type=int, default=-1, help="time only this mode (1 fp32 rows, 2 8-bit replica, 3 fp16 replica)")
+    ap.add_argument("--lib", default=None, help="another build of the library (e.g. an MI355REC_EXPERIMENTS one under gpurun_out/)")
     args = ap.parse_args()
+    if args.lib:
+        from spotify_recommender_amd import capi as _capi
+        _capi.LIB_PATH = Path(args.lib).resolve()   # before the first capi.lib(): this process only
     import numpy as np
     import torch
     from spotify_recommender_amd import CosineEngine, capi
