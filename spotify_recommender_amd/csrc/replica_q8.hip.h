@@ -291,44 +291,124 @@ struct Q8Sample {
     uint32_t v[kHalfSeedPerThread];   // this thread's share of the sample values (0 = empty)
 };
 // Values under another epoch than the reader's count as absent (replica.hip.h, "hand-offs that fail safe").
-template <int kBlock, bool kSameLaunch = false>
-__device__ __forceinline__ Q8Sample q8_load_sample(const unsigned long long* seed_vals, int n_seed, uint32_t epoch) {
-    Q8Sample s;
+// (request and use are two calls: the scan asks for its sample FIRST — before its first tile: loads complete in order,
+// and behind the tile the sample of a 1 M-row shard was not usable before the tile was, 3 us later — and looks at it
+// after the query)
+struct Q8SampleRaw {
     unsigned long long t[kHalfSeedPerThread];
+};
+template <int kBlock, bool kSameLaunch = false>
+__device__ __forceinline__ Q8SampleRaw q8_request_sample(const unsigned long long* seed_vals, int n_seed) {
+    Q8SampleRaw raw;
 #pragma unroll
     for (int r = 0; r < kHalfSeedPerThread; ++r) {
         const int i = static_cast<int>(threadIdx.x) + r * kBlock;
-        t[r] = 0ull;
+        raw.t[r] = 0ull;
         if (i < n_seed)   // kSameLaunch: written by other workgroups of THIS launch
-            t[r] = kSameLaunch ? __hip_atomic_load(&seed_vals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : seed_vals[i];
+            raw.t[r] = kSameLaunch ? __hip_atomic_load(&seed_vals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : seed_vals[i];
     }
+    return raw;
+}
+__device__ __forceinline__ Q8Sample q8_finish_sample(const Q8SampleRaw& raw, uint32_t epoch) {
+    Q8Sample s;
 #pragma unroll
-    for (int r = 0; r < kHalfSeedPerThread; ++r) s.v[r] = untag_value(t[r], epoch);
+    for (int r = 0; r < kHalfSeedPerThread; ++r) s.v[r] = untag_value(raw.t[r], epoch);
     return s;
 }
+template <int kBlock, bool kSameLaunch = false>
+__device__ __forceinline__ Q8Sample q8_load_sample(const unsigned long long* seed_vals, int n_seed, uint32_t epoch) {
+    return q8_finish_sample(q8_request_sample<kBlock, kSameLaunch>(seed_vals, n_seed), epoch);
+}
+
+// The cutoff is "any T with at least topk sample values >= T", as high as is cheap to find — not a k-th order
+// statistic to the last bit.  So ONE histogram pass instead of a radix select: the values are binned linearly over
+// [max - kQ8SelSpan, max] (1024 bins of 2.4e-4: a fiftieth of the smallest margin the cutoff then subtracts), the bins
+// are summed from the top, and T is the lower edge of the bin in which the count reaches topk.  Four barriers in all
+// against two per byte pass of the radix select over the 64-bit (value, index) keys (measured: 3.4 us of every
+// workgroup's prologue wherever the cutoff is not handed over by the launch before — shards below ~4 M rows and
+// every query alone).  A sample whose topk-th value lies more than kQ8SelSpan below its maximum lands in the last bin
+// and takes the radix select as before.
+constexpr int kQ8SelBins = 1024;
+constexpr float kQ8SelSpan = 0.25f;
+constexpr int kQ8SelScratch = kQ8SelBins + 16;   // ints of LDS scratch the selection needs (bins, block max, wave totals, result)
 
 template <int kBlock>
 __device__ __forceinline__ float q8_cutoff_from_sample(const Q8Sample& sample, int n_seed, int topk, bool exact_values,
-                                                       const Q8Query& hq, int* s_seeds /* zeroed */, SelectSmem& s_sel) {
+                                                       const Q8Query& hq, int* s_seeds /* zeroed */, SelectSmem& s_sel,
+                                                       int* s_bins /* kQ8SelScratch ints nobody else is using */) {
+    static_assert(kQ8SelBins % kBlock == 0, "whole bins per thread");
+    constexpr int kPer = kQ8SelBins / kBlock;
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
     float cutoff = -__builtin_inff();
     if (hq.ok && n_seed > 0) {   // uniform
-        uint64_t mine[kHalfSeedPerThread];
+        uint32_t vmax = 0u;
         int have = 0;
 #pragma unroll
         for (int r = 0; r < kHalfSeedPerThread; ++r) {
-            const int i = tid + r * kBlock;
-            const uint32_t v = sample.v[r];
-            mine[r] = v ? (static_cast<uint64_t>(v) << 32) | static_cast<uint32_t>(i + 1) : 0ull;
-            have += v != 0u;
+            vmax = sample.v[r] > vmax ? sample.v[r] : vmax;
+            have += sample.v[r] != 0u;
         }
+        for (int i = tid; i < kQ8SelScratch; i += kBlock) s_bins[i] = 0;
+        vmax = wave_max_u32(vmax);
+        __syncthreads();   // the scratch is zero
+        if (lane == 0 && vmax) atomicMax(reinterpret_cast<unsigned int*>(&s_bins[kQ8SelBins]), vmax);
         if (have) atomicAdd(s_seeds, have);
         __syncthreads();
         if (*s_seeds >= topk) {   // uniform
-            // any T with at least topk maxima >= T will do: stopping a few keys early (<= topk/8 + 2 extra) saves
-            // most of the radix passes and moves the cutoff by a hair
-            const uint64_t t = block_select_threshold<kBlock, kHalfSeedPerThread>(mine, topk, false, topk / 8 + 2, s_sel);
-            const float v = ordered_to_score(static_cast<uint32_t>(t >> 32));
+            const float smax = ordered_to_score(static_cast<uint32_t>(s_bins[kQ8SelBins]));
+#pragma unroll
+            for (int r = 0; r < kHalfSeedPerThread; ++r) {
+                if (sample.v[r]) {
+                    const float d = (smax - ordered_to_score(sample.v[r])) * (static_cast<float>(kQ8SelBins) / kQ8SelSpan);
+                    int bin = static_cast<int>(d);
+                    bin = (d >= 0.0f && bin < kQ8SelBins - 1) ? bin : (d >= 0.0f ? kQ8SelBins - 1 : 0);   // (NaN: the last bin)
+                    if (!(d == d)) bin = kQ8SelBins - 1;
+                    atomicAdd(&s_bins[bin], 1);
+                }
+            }
+            __syncthreads();
+            // thread t owns bins [t * kPer, (t + 1) * kPer): bin 0 holds the largest values
+            int mine_bins[kPer];
+            int c = 0;
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                mine_bins[u] = s_bins[tid * kPer + u];
+                c += mine_bins[u];
+            }
+            int incl = wave_inclusive_scan(c);
+            if (lane == 63) s_bins[kQ8SelBins + 1 + wave] = incl;
+            __syncthreads();
+            int before = 0;
+            for (int w = 0; w < wave; ++w) before += s_bins[kQ8SelBins + 1 + w];   // (<= 7 reads, wave-uniform)
+            incl += before;
+            int run = incl - c;
+            if (run < topk && incl >= topk) {   // exactly one thread: the count reaches topk inside its bins
+                int bin = tid * kPer;
+#pragma unroll
+                for (int u = 0; u < kPer; ++u) {
+                    if (run < topk) bin = tid * kPer + u;
+                    run += mine_bins[u];
+                }
+                s_bins[kQ8SelBins + 12] = bin + 1;
+            }
+            __syncthreads();
+            const int found = s_bins[kQ8SelBins + 12] - 1;
+            float v;
+            if (found >= 0 && found < kQ8SelBins - 1) {   // uniform
+                // every value of bins 0 .. found is >= this edge (2e-6: the rounding of the bin arithmetic)
+                v = smax - static_cast<float>(found + 1) * (kQ8SelSpan / static_cast<float>(kQ8SelBins)) - 2.0e-6f;
+            } else {   // the topk-th value lies far below the maximum (or the values are not what they should be): exact
+                uint64_t keys[kHalfSeedPerThread];
+#pragma unroll
+                for (int r = 0; r < kHalfSeedPerThread; ++r) {
+                    const int i = tid + r * kBlock;
+                    keys[r] = sample.v[r] ? (static_cast<uint64_t>(sample.v[r]) << 32) | static_cast<uint32_t>(i + 1) : 0ull;
+                }
+                const uint64_t t = block_select_threshold<kBlock, kHalfSeedPerThread>(keys, topk, false, topk / 8 + 2, s_sel);
+                v = ordered_to_score(static_cast<uint32_t>(t >> 32));
+            }
             // one margin below an EXACT score of a real row, two below an approximate one (the margin carries its own slack)
             cutoff = exact_values ? v - hq.margin : v - 2.0f * hq.margin;
         }
@@ -403,20 +483,22 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
                 // (s_waitcnt vmcnt(0): a workgroup-scope fence does not), one thread counts, and the last
                 // workgroup's loads are issued after its counter value came back.  Values and cutoff carry the next
                 // query's epoch and the counter is never reset (replica.hip.h, "hand-offs that fail safe").
+                if (next.ctl) {   // uniform; null: nobody reads the sample inside this launch (small shards: the next launch selects)
                 wait_own_stores();
                 __syncthreads();
                 if (threadIdx.x == 0) {
                     s_mem.scan.seeds = 0;
-                    s_mem.scan.count = next.ctl && __hip_atomic_fetch_add(&next.ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u ==
-                                                       next.done_base + static_cast<unsigned>(next.n_wgs);
+                    s_mem.scan.count = __hip_atomic_fetch_add(&next.ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u ==
+                                       next.done_base + static_cast<unsigned>(next.n_wgs);
                 }
                 __syncthreads();
                 if (s_mem.scan.count) {   // uniform
                     const Q8Sample all = q8_load_sample<kBlock, true>(static_cast<const unsigned long long*>(next.out),
                                                                       next.regions * kHalfSeedWaves, next.epoch);
                     const float c = q8_cutoff_from_sample<kBlock>(all, next.regions * kHalfSeedWaves, next.topk, next.exact != 0, nq,
-                                                                  &s_mem.scan.seeds, s_mem.scan.sel);
+                                                                  &s_mem.scan.seeds, s_mem.scan.sel, reinterpret_cast<int*>(s_mem.scan.cand));
                     if (threadIdx.x == 0) next.ctl->cutoff = tag_value(next.epoch, __float_as_uint(c));
+                }
                 }
             }
             __syncthreads();
@@ -455,25 +537,28 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
         dst.t2 = p[2];
     };
 
-    // everything the first tile needs is asked for at once: its 48 B per lane, the finished cutoff, the query
+    // everything the first tile needs is asked for at once: the finished cutoff — or, where this workgroup selects it
+    // itself, the sample values, FIRST: they come back before the tile does and the selection runs under its latency —
+    // the tile's 48 B per lane, the query
     constexpr int kDepth = Cfg::kDepth;
-    HalfTile ring[kDepth];
-#pragma unroll
-    for (int d = 0; d < kDepth - 1; ++d) load_tile(ring[d], d);
     float cutoff_left = 0.0f;
-    Q8Sample sample;
+    Q8SampleRaw sample_raw;
 #pragma unroll
-    for (int r = 0; r < kHalfSeedPerThread; ++r) sample.v[r] = 0u;
+    for (int r = 0; r < kHalfSeedPerThread; ++r) sample_raw.t[r] = 0ull;
     const int n_sample = n_seed < 0 ? -n_seed : n_seed;
     if (cutoff_ready) {   // uniform: the riders of the launch before this one left it (under this query's epoch, or it does not count)
         cutoff_left = untag_cutoff(*cutoff_ready, epoch);
-    } else {              // ... or this workgroup selects it from the sample values itself: asked for now, used after the query
-        sample = q8_load_sample<kBlock>(seed_vals, n_sample, epoch);
+    } else {              // ... or this workgroup selects it from the sample values itself
+        sample_raw = q8_request_sample<kBlock>(seed_vals, n_sample);
     }
+    HalfTile ring[kDepth];
+#pragma unroll
+    for (int d = 0; d < kDepth - 1; ++d) load_tile(ring[d], d);
     float q[kDim];
     q8_load_query(kQueryFromRow ? query_ptr : nullptr, qarg.q, q);
     const float qn = query_norm(q);
     const Q8Query hq = q8_query(q, qn);
+    const Q8Sample sample = q8_finish_sample(sample_raw, epoch);
     if (hq.c != 0.0f || n >= 0) MI355REC_PHASE(1);   // (depends on the query: not hoisted above its load)
 
     // ---- launch-wide cutoff (while the first tiles are in flight)
@@ -488,7 +573,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
     if (cutoff_ready) {   // uniform
         cutoff = cutoff_left;
     } else {
-        cutoff = q8_cutoff_from_sample<kBlock>(sample, n_sample, topk, n_seed < 0, hq, &sm->seeds, s_sel);
+        cutoff = q8_cutoff_from_sample<kBlock>(sample, n_sample, topk, n_seed < 0, hq, &sm->seeds, s_sel, reinterpret_cast<int*>(s_cand));
     }
     MI355REC_PHASE(2);
     uint64_t thr = 0;
