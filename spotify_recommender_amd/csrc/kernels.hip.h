@@ -646,7 +646,10 @@ __device__ __forceinline__ void merge_body(
             const int i = tid + r * kThreads;
             mine[r] = i < c ? s_surv[i] : 0ull;
         }
-        const uint64_t t = block_select_threshold<kThreads, kSurvPer>(mine, topk, true, 0, s_sel);
+        // (not to EXACTLY topk: that takes the radix select through all its byte passes; a cut that may leave up to
+        // kRankCountMax - topk keys more stops after one or two, and the ranking below keeps the best topk of what is left)
+        const int cut_slack = kRankCountMax > topk ? kRankCountMax - topk : 0;
+        const uint64_t t = block_select_threshold<kThreads, kSurvPer>(mine, topk, cut_slack == 0, cut_slack, s_sel);
         if (tid == 0) s_count = 0;
         __syncthreads();
 #pragma unroll
