@@ -328,13 +328,15 @@ __device__ __forceinline__ void hm_build_fragment8(HalfMultiSmem& sm, int c, boo
 
 // The launch-wide cutoff of one query from its sample maxima, by one wave (see the header).
 // Values under another epoch than the reader's count as absent (replica.hip.h, "hand-offs that fail safe").
-template <bool kSameLaunch = false>   // the values were written by other workgroups of THIS launch: read past the L2
+template <bool kSameLaunch = false /* the values were written by other workgroups of THIS launch: read past the L2 */,
+          int kBurstMax = 16 /* requests in flight per lane: 32 = all of them, one round trip (a sample launch has the
+                                registers for it; the scanning kernel does not) */>
 __device__ __forceinline__ float hm_seed_cutoff(const unsigned long long* vals, int n_seed, int topk, float margin, uint32_t epoch) {
     const int lane = threadIdx.x & 63;
     // the lane's (up to 32) sample maxima, sixteen requests in flight at a time; each goes straight into the lane's
     // four largest (an insertion network per value)
     constexpr int kPer = kHalfSeedMaxGrid * kHalfSeedWaves / 64;
-    constexpr int kBurst = kPer < 16 ? kPer : 16;
+    constexpr int kBurst = kPer < kBurstMax ? kPer : kBurstMax;
     static_assert(kPer % kBurst == 0, "whole bursts");
     uint32_t m1 = 0u, m2 = 0u, m3 = 0u, m4 = 0u;
 #pragma unroll
@@ -521,6 +523,7 @@ __device__ __forceinline__ void hm_exact_step(HalfMultiSmem& sm, const float* __
 // maximum, i.e. a looser cutoff that is just as valid.  The hand-off is replica.hip.h's ("hand-offs that fail safe"):
 // write-through sample stores, vmcnt(0), a monotonic arrival counter whose base the host tracks, epoch-tagged values; a
 // cutoff nobody wrote reads as "every row is a candidate" in the pass.  Called by all 512 threads; `s_round` is theirs.
+template <int kBurstMax = 16>
 __device__ __forceinline__ void hm_arrive_and_select(SeedCtl* ctl, unsigned done_base, unsigned total, int n_queries,
                                                      const uint32_t* ok /* shared: the bound can be claimed for query q */,
                                                      const unsigned long long* seed_vals, int n_seed, int topk, float margin,
@@ -536,7 +539,7 @@ __device__ __forceinline__ void hm_arrive_and_select(SeedCtl* ctl, unsigned done
         const int qi = static_cast<int>(r) * kHmWaves + static_cast<int>(threadIdx.x >> 6);
         if (qi >= n_queries) continue;   // wave-uniform
         // (a query the bound cannot be claimed for keeps "every row is a candidate")
-        const float cut = ok[qi] ? hm_seed_cutoff<true>(seed_vals + static_cast<int64_t>(qi) * n_seed, n_seed, topk + 1, margin, epoch)
+        const float cut = ok[qi] ? hm_seed_cutoff<true, kBurstMax>(seed_vals + static_cast<int64_t>(qi) * n_seed, n_seed, topk + 1, margin, epoch)
                                  : -__builtin_inff();
         if (lane == 0) cuts[qi] = tag_value(epoch, __float_as_uint(cut));
     }
@@ -564,8 +567,8 @@ __global__ __launch_bounds__(kHmBlock) void seed_half_multi_kernel(
                              __syncthreads();
                          });
     if (ctl)   // uniform
-        hm_arrive_and_select(ctl, done_base, gridDim.x, n_queries, s_ok, seed_vals, static_cast<int>(gridDim.x) * kHalfSeedWaves, topk,
-                             arg.margin, epoch, cuts, &s_round);
+        hm_arrive_and_select<32>(ctl, done_base, gridDim.x, n_queries, s_ok, seed_vals, static_cast<int>(gridDim.x) * kHalfSeedWaves, topk,
+                                 arg.margin, epoch, cuts, &s_round);
 }
 
 // What else a launch of a STREAM of batches carries beside the scanners (mi355rec_enqueue_batch_keys_streamed):
