@@ -538,15 +538,24 @@ __device__ __forceinline__ void merge_body(
             local_nonzero += hk[u] != 0ull;
         }
         for (int l = tid; l < n_lists; l += kThreads) s_active[l] = 0xffff;
-        if (local_nonzero) atomicAdd(&s_pair[0], local_nonzero);
+        {   // one LDS atomic per wave (hundreds of threads adding to the one word serialise: measured 2 us in the 8-bit
+            // scan's sample selection, the same pattern)
+            const int wave_nonzero = __builtin_amdgcn_readlane(wave_inclusive_scan(local_nonzero), 63);
+            if ((tid & 63) == 0 && wave_nonzero) atomicAdd(&s_pair[0], wave_nonzero);
+        }
         __syncthreads();
         if (s_pair[0] >= need_lists)  // uniform
             thr = block_select_threshold<kThreads, kFirstPer>(hk, need_lists, false, slack, s_sel);
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < kFirstPer; ++u) {
-            if (k[u] >= thr) {
-                const int slot = atomicAdd(&s_count, 1);
+            const bool pass = k[u] >= thr;
+            const uint64_t who = __ballot(pass);   // (uniform loop: every lane takes part)
+            int base = 0;
+            if ((tid & 63) == 0 && who) base = atomicAdd(&s_count, __popcll(who));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (pass) {
+                const int slot = base + lanes_below(who);
                 if (slot < kSurvCap) s_surv[slot] = k[u];
                 else s_overflow = 1;
                 if (j == first - 1) {  // the whole first chunk passed: look deeper

@@ -372,6 +372,15 @@ ReplicaGeom plan_replica(const mi355rec* h, int occ, int tile_rows, int align, d
             g.riders = riders;
             g.r_scan = g.grid - 1 - riders;
             g.r_iters = static_cast<int>((tiles + g.r_scan - 1) / g.r_scan);
+            // Whole rounds only: where the cap above binds (a 1 M-row shard: 61 riders for 256 regions) the last dozen
+            // regions would cost every rider's launch one more round trip for a twentieth of the sample — on a shard
+            // that small the riders are the last workgroups out (phase clock: 9.5 us of a 9.5 us launch).
+            const int64_t whole = static_cast<int64_t>(riders) * 4 * rounds;
+            if (whole < sg && whole >= sg - sg / 8) {
+                sg = whole;
+                g.seed_grid = static_cast<int>(sg);
+                g.seed_stride = (h->n / sg) / align * align;
+            }
         }
     }
     return g;

@@ -426,7 +426,10 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_half_kernel(
             mine[r] = v ? (static_cast<uint64_t>(v) << 32) | static_cast<uint32_t>(i + 1) : 0ull;
             have += v != 0u;
         }
-        if (have) atomicAdd(&sm->seeds, have);
+        {   // one LDS atomic per wave, not per thread (replica_q8.hip.h: 2 us of serialised atomics otherwise)
+            const int wave_have = __builtin_amdgcn_readlane(wave_inclusive_scan(have), 63);
+            if ((tid & 63) == 0 && wave_have) atomicAdd(&sm->seeds, wave_have);
+        }
         __syncthreads();
         if (sm->seeds >= topk) {   // uniform
             const uint64_t t = block_select_threshold<kBlock, kHalfSeedPerThread>(mine, topk, true, 0, s_sel);

@@ -354,7 +354,11 @@ __device__ __forceinline__ float q8_cutoff_from_sample(const Q8Sample& sample, i
         vmax = wave_max_u32(vmax);
         __syncthreads();   // the scratch is zero
         if (lane == 0 && vmax) atomicMax(reinterpret_cast<unsigned int*>(&s_bins[kQ8SelBins]), vmax);
-        if (have) atomicAdd(s_seeds, have);
+        // ONE count per wave: 512 threads adding to the one LDS word were 2 us of serialised atomics — most of what this
+        // selection cost (the phase clock had the sample values back 1.4 us after the workgroup's entry and the cutoff
+        // only at 5.0 us)
+        const int wave_have = __builtin_amdgcn_readlane(wave_inclusive_scan(have), 63);
+        if (lane == 0 && wave_have) atomicAdd(s_seeds, wave_have);
         __syncthreads();
         if (*s_seeds >= topk) {   // uniform
             const float smax = ordered_to_score(static_cast<uint32_t>(s_bins[kQ8SelBins]));
@@ -549,7 +553,11 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
     if (cutoff_ready) {   // uniform: the riders of the launch before this one left it (under this query's epoch, or it does not count)
         cutoff_left = untag_cutoff(*cutoff_ready, epoch);
     } else {              // ... or this workgroup selects it from the sample values itself
+#ifdef MI355_Q8_SAMPLE_SC1   // experiment: coherent loads
+        sample_raw = q8_request_sample<kBlock, true>(seed_vals, n_sample);
+#else
         sample_raw = q8_request_sample<kBlock>(seed_vals, n_sample);
+#endif
     }
     HalfTile ring[kDepth];
 #pragma unroll
@@ -560,6 +568,9 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
     const Q8Query hq = q8_query(q, qn);
     const Q8Sample sample = q8_finish_sample(sample_raw, epoch);
     if (hq.c != 0.0f || n >= 0) MI355REC_PHASE(1);   // (depends on the query: not hoisted above its load)
+#ifdef MI355REC_PHASE_CLOCK
+    if (sample.v[0] != 0x12345u || n >= 0) MI355REC_PHASE(6);   // (depends on this thread's sample values: they have arrived)
+#endif
 
     // ---- launch-wide cutoff (while the first tiles are in flight)
     if (tid == 0) {

@@ -60,6 +60,9 @@ def main():
     for i, nm in enumerate(names):
         v = scan[:, i] - t0
         out[nm] = {"first": us(v.min()), "median": us(np.median(v)), "last": us(v.max())}
+    if (scan[:, 6] > 0).any():   # (builds that stamp it: the workgroup's sample values have arrived)
+        v = scan[scan[:, 6] > 0][:, 6] - t0
+        out["sample_arrived"] = {"first": us(v.min()), "median": us(np.median(v)), "last": us(v.max())}
     d = scan[:, 1:5] - scan[:, 0:4]
     out["per_workgroup_phase_us_median"] = {f"{names[i]}->{names[i + 1]}": us(np.median(d[:, i])) for i in range(4)}
     # does a workgroup's speed depend on where it runs?  (blockIdx % 8 = XCD under the round-robin dispatch)
