@@ -372,11 +372,11 @@ ReplicaGeom plan_replica(const mi355rec* h, int occ, int tile_rows, int align, d
             g.riders = riders;
             g.r_scan = g.grid - 1 - riders;
             g.r_iters = static_cast<int>((tiles + g.r_scan - 1) / g.r_scan);
-            // Whole rounds only: where the cap above binds (a 1 M-row shard: 61 riders for 256 regions) the last dozen
-            // regions would cost every rider's launch one more round trip for a twentieth of the sample — on a shard
-            // that small the riders are the last workgroups out (phase clock: 9.5 us of a 9.5 us launch).
+            // Whole rounds only: where the cap above binds (a 1 M-row shard: 61 riders for 256 regions) the last few
+            // regions would cost every rider's launch one more round trip — on a shard that small the riders are the
+            // last workgroups out (phase clock: 9.5 us of a 9.5 us launch) and its sample is half its rows anyway.
             const int64_t whole = static_cast<int64_t>(riders) * 4 * rounds;
-            if (whole < sg && whole >= sg - sg / 8) {
+            if (whole < sg && whole >= 64) {
                 sg = whole;
                 g.seed_grid = static_cast<int>(sg);
                 g.seed_stride = (h->n / sg) / align * align;
@@ -733,11 +733,11 @@ void enqueue_half_seed(mi355rec* h, bool q8, const float* qptr, const QueryArg& 
 // lone != null (a lone query whose caller waits on the host): over the 8-bit replica of a large shard the launch
 // also merges its own lists into lone's buffers (kernels.hip.h, lone_tail) and *fused is set.
 constexpr int64_t kLoneFusedMinRows = 4000000;
-// A LONE synchronous query on a small shard takes the fp32 rows under AUTO: over a replica it is three dependent
-// launches (sample, scan, merge), over the fp32 rows two, and below ~1.5 M rows the sample launch costs more than
-// the bytes it saves (measured from C++, tools/lat_exp.sh, 1 M rows x top-10: p50 27.3 us against 29.7; 3 M rows:
-// 40.6 against 33.5).  Streams are not affected: their sample rides in the previous launch.
-constexpr int64_t kLoneFp32MaxRows = 1500000;
+// (Round 4 had a LONE synchronous query below 1.5 M rows read the fp32 rows — two launches against the replica's three
+// were worth more than the bytes: 27.3 against 29.7 us at 1 M rows.  Once the 8-bit scan's prologue had been fixed —
+// sample requested before the first tile, one LDS atomic per wave in its selection — the replica won from 1 M rows up
+// again (tools/route_thresholds.sh: 25.7 against 27.4 us at 1 M, 27.1 against 30.4 at 1.4 M, 28.3 against 39.9 at 3 M;
+// 28.0 against 24.3 at 0.7 M), which is where single queries take it anyway: the rule is gone.)
 int enqueue_scan(mi355rec* h, const float* qptr, const float* query12,
                  int64_t exclude_global, int topn, const uint64_t* upper_dev, hipStream_t s, int* n_lists,
                  const LoneTail* lone = nullptr, bool* fused = nullptr) {
@@ -748,8 +748,7 @@ int enqueue_scan(mi355rec* h, const float* qptr, const float* query12,
     const PrevMerge none{nullptr, 0, 0, nullptr};
     const LoneTail no_tail{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}};
     if (fused) *fused = false;
-    const bool lone_small = lone && h->replica_mode == MI355REC_REPLICA_AUTO && h->n < kLoneFp32MaxRows;
-    if (use_half(h, upper_dev) && !lone_small) {
+    if (use_half(h, upper_dev)) {
         NextSeed no_next;
         std::memset(&no_next, 0, sizeof no_next);
         ++h->half_scans;

@@ -30,14 +30,12 @@ def catalogues():
 # (rows, how, batch, topn) -> {route: launches}.  `how`: sync = mi355rec_query_row_topn, keys = _enqueue_row_keys,
 # stream = one streamed query + flush, batch = mi355rec_query_batch_topn, dev = _enqueue_batch_keys_dev
 CELLS = [
-    # single queries: the fp32 rows below 1 M rows; the 8-bit replica from there on — except a LONE synchronous query
-    # below 1.5 M rows, which has nobody to hide its sample launch behind and reads the fp32 rows in one launch instead
-    # (csrc/mi355rec.hip kLoneFp32MaxRows); a lone synchronous query on a shard of >= 4 M rows in ONE launch that also
-    # merges and signals
+    # single queries: the fp32 rows below 1 M rows; the 8-bit replica from there on; a lone synchronous query on a
+    # shard of >= 4 M rows in ONE launch that also merges and signals
     (30_000, "sync", 1, 10, {"route_fp32": 1}),
     (300_000, "sync", 1, 100, {"route_fp32": 1}),
     (300_000, "stream", 1, 100, {"route_fp32": 1}),
-    (1_100_000, "sync", 1, 10, {"route_fp32": 1}),
+    (1_100_000, "sync", 1, 10, {"route_q8": 1}),
     (1_100_000, "keys", 1, 10, {"route_q8": 1}),
     (1_100_000, "stream", 1, 10, {"route_q8": 1}),
     (1_500_000, "sync", 1, 100, {"route_q8": 1}),
