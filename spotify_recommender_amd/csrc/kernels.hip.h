@@ -375,8 +375,13 @@ __device__ inline uint64_t compact_candidates(uint64_t* s_cand, int* s_count, in
     if (threadIdx.x == 0) *s_count = 0;
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < kCandPerThread; ++r) {
-        if (mine[r] >= t) s_cand[atomicAdd(s_count, 1)] = mine[r];
+    for (int r = 0; r < kCandPerThread; ++r) {   // (uniform loop) one LDS atomic per wave: per-thread adds to the one word serialise
+        const bool keep = mine[r] >= t;
+        const uint64_t who = __ballot(keep);
+        int base = 0;
+        if ((threadIdx.x & 63) == 0 && who) base = atomicAdd(s_count, __popcll(who));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (keep) s_cand[base + lanes_below(who)] = mine[r];
     }
     __syncthreads();
     return t - 1ull;
@@ -662,11 +667,13 @@ __device__ __forceinline__ void merge_body(
         if (tid == 0) s_count = 0;
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < kSurvPer; ++r) {
-            if (mine[r] >= t) {
-                const int pos = atomicAdd(&s_count, 1);
-                if (pos < kSurvCap) s_surv[pos] = mine[r];
-            }
+        for (int r = 0; r < kSurvPer; ++r) {   // (uniform loop) one LDS atomic per wave
+            const bool keep = mine[r] >= t;
+            const uint64_t who = __ballot(keep);
+            int base = 0;
+            if ((tid & 63) == 0 && who) base = atomicAdd(&s_count, __popcll(who));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (keep && base + lanes_below(who) < kSurvCap) s_surv[base + lanes_below(who)] = mine[r];
         }
         __syncthreads();
         c = s_count < kSurvCap ? s_count : kSurvCap;
