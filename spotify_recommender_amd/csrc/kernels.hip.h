@@ -21,6 +21,19 @@
 
 namespace mi355 {
 
+#ifdef MI355REC_PHASE_CLOCK   // tools/ builds only (tools/phase_clock.sh): 100 MHz wall-clock stamps, [workgroup][phase]
+__device__ unsigned long long g_phase_clock[1024 * 8];
+// the phases of ONE merge (merge_body in the workgroup with blockIdx.x == 0: merge_notify_kernel), kept in row 1023
+#define MI355REC_MPHASE(i)                                                                       \
+    do {                                                                                         \
+        if (threadIdx.x == 0 && blockIdx.x == 0) g_phase_clock[1023 * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define MI355REC_MPHASE(i) \
+    do {                   \
+    } while (0)
+#endif
+
 constexpr int kDim = 12;              // Song.h:12
 constexpr int kMaxTopK = 1024;        // MI355REC_MAX_TOPN_FAST
 constexpr int kCandLimit = 2 * kMaxTopK;  // a tile is never entered with more candidates
@@ -491,6 +504,7 @@ __device__ __forceinline__ void merge_body(
     const uint64_t* lists = lists_base + slot * lists_query_stride;
     uint64_t* out_keys = out_keys_base + out_slot * out_query_stride;
 
+    MI355REC_MPHASE(0);
     if (tid == 0) {
         s_count = 0;
         s_overflow = 0;
@@ -588,6 +602,7 @@ __device__ __forceinline__ void merge_body(
             thr = block_select_threshold<kThreads, kHeadsPer>(heads, need_lists, false, slack, s_sel);
     }
     __syncthreads();
+    MI355REC_MPHASE(1);   // first chunk loaded, threshold selected, survivors appended
 
     // Deeper rounds: round d looks at keys [first + d*C, first + (d+1)*C) of every
     // list that is still active (its previous chunk passed entirely); the loads
@@ -651,6 +666,7 @@ __device__ __forceinline__ void merge_body(
         __syncthreads();
     }
 
+    MI355REC_MPHASE(2);   // deeper rounds done
     int c = s_count < kSurvCap ? s_count : kSurvCap;
     __syncthreads();
     if (c > topk && c > kRankDirectMax) {  // uniform: too many to rank, cut to exactly topk in O(c)
@@ -678,8 +694,10 @@ __device__ __forceinline__ void merge_body(
         __syncthreads();
         c = s_count < kSurvCap ? s_count : kSurvCap;
     }
+    MI355REC_MPHASE(3);   // final cut done
     block_rank_and_store<kThreads>(s_surv, c, s_top, topk);
     __syncthreads();
+    MI355REC_MPHASE(4);   // ranked
     for (int i = tid; i < topk; i += kThreads) {
         const uint64_t k = s_top[i];
         out_keys[i] = k;

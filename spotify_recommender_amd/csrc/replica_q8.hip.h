@@ -421,7 +421,6 @@ __device__ __forceinline__ float q8_cutoff_from_sample(const Q8Sample& sample, i
 }
 
 #ifdef MI355REC_PHASE_CLOCK   // tools/ builds only: where a launch spends its time (100 MHz wall clock, per workgroup)
-__device__ unsigned long long g_phase_clock[1024 * 8];
 #define MI355REC_PHASE(i)                                                                   \
     do {                                                                                    \
         if (threadIdx.x == 0 && blockIdx.x < 1024) g_phase_clock[blockIdx.x * 8 + (i)] = wall_clock64(); \
