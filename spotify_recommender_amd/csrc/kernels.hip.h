@@ -764,7 +764,9 @@ __device__ __forceinline__ void lone_tail(MergeSmem& msm, int* s_flag, const uin
                      lt.out_keys, lt.out_idx, lt.out_score, static_cast<int64_t>(0), static_cast<int64_t>(0),
                      static_cast<int64_t>(0));
     if (lt.done_word) {   // uniform
-        __threadfence_system();   // every thread: its result stores are ordered before ...
+        // the waves that stored results order their stores before ... (the others have nothing to release: a system-scope
+        // fence is an L2 write-back per wave, and sixteen of them queue up)
+        if (static_cast<int>(threadIdx.x) < ((topk + 63) & ~63)) __threadfence_system();
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(lt.done_word, lt.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... the word
     }
@@ -1525,7 +1527,9 @@ __global__ __launch_bounds__(kMergeBlock) void merge_notify_kernel(
     __shared__ MergeSmemT<kMergeBlock, kMergeMaxLists, kMergeSurvCap> sm;
     merge_body(sm, lists_base, n_lists, list_len, list_stride, static_cast<int64_t>(0), topk, out_keys_base, out_idx_base,
                out_score_base, static_cast<int64_t>(0), static_cast<int64_t>(0), static_cast<int64_t>(0));
-    __threadfence_system();   // every thread: its result stores are ordered before ...
+    // the waves that stored results order their stores before ... (the others have nothing to release: a system-scope
+    // fence is an L2 write-back per wave, and sixteen of them queue up)
+    if (static_cast<int>(threadIdx.x) < ((topk + 63) & ~63)) __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(done_word, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... the word
 }
