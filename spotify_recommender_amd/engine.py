@@ -542,56 +542,95 @@ class ShardedEngine:
                                       self.out_idx[:k], self.out_score[:k])
 
     # -- windowed single queries: one all-gather per `window` queries ---------------
-    def enqueue_query_windowed(self, query, exclude_global: int, topn: int, window: int = 16) -> None:
+    def enqueue_query_windowed(self, query, exclude_global: int, topn: int, window: int = 16) -> int:
         """A stream of single queries on a sharded catalogue: every query is still one
         full pass over every shard, but the exchange is amortised — the local merge of
         query k rides in the scan launch of query k + 1 (streamed C-ABI calls) and the
         per-rank key lists of `window` queries cross xGMI in ONE all-gather followed by ONE
-        batched merge launch.  Results appear in `self.window_keys / window_idx /
-        window_score` ([window, topn]) when a window closes (`flush_window`)."""
+        batched merge launch.
+
+        The local stream is NOT drained when a window fills: a streamed query's keys are complete, in stream
+        order, behind the second streamed call after it (the stream runs one call behind and its merge rides in
+        the launch after that; csrc/sharded.hip keeps the same lag, kWindowLag), so a full window's all-gather
+        is enqueued two queries into the NEXT window.  Returns the number of queries whose results became
+        available during this call (0 or `window`): they are in `self.window_keys / window_idx / window_score`
+        ([count, topn]; also appended to `self.merged_windows`, which every call resets).  `flush_window`
+        closes what is left."""
         torch = self._torch
         k, w = int(topn), int(window)
         if k > self.max_topn:
             raise ValueError(f"topn {topn} > max_topn {self.max_topn}")
+        self.merged_windows = []
         if getattr(self, "_w_shape", None) != (w, k):
-            if getattr(self, "_w_count", 0):
+            if getattr(self, "_w_count", 0) or getattr(self, "_w_pending", None) is not None:
                 self.flush_window()
+                self.merged_windows = []
             dev = self.device
-            self._w_local = torch.zeros(w * k, dtype=torch.int64, device=dev)
-            self._w_gather = torch.zeros(self.world * w * k, dtype=torch.int64, device=dev)
-            self._w_keys = torch.zeros(w * k, dtype=torch.int64, device=dev)
-            self._w_idx = torch.full((w * k,), -1, dtype=torch.int64, device=dev)
-            self._w_score = torch.zeros(w * k, dtype=torch.float32, device=dev)
+            self._w_local = [torch.zeros(w * k, dtype=torch.int64, device=dev) for _ in range(2)]
+            self._w_gather = [torch.zeros(self.world * w * k, dtype=torch.int64, device=dev) for _ in range(2)]
+            self._w_keys = [torch.zeros(w * k, dtype=torch.int64, device=dev) for _ in range(2)]
+            self._w_idx = [torch.full((w * k,), -1, dtype=torch.int64, device=dev) for _ in range(2)]
+            self._w_score = [torch.zeros(w * k, dtype=torch.float32, device=dev) for _ in range(2)]
             self._w_shape = (w, k)
             self._w_count = 0
-        slot = self._w_count
-        self.local.enqueue_query_keys_streamed(query, exclude_global, k, self._w_local[slot * k:(slot + 1) * k])
+            self._w_cur = 0
+            self._w_pending = None
+        slot, buf = self._w_count, self._w_cur
+        self.local.enqueue_query_keys_streamed(query, exclude_global, k, self._w_local[buf][slot * k:(slot + 1) * k])
         self._w_count += 1
+        done = 0
+        if self._w_pending is not None and self._w_count >= 2:   # the window before is complete behind this call
+            done = self._merge_window(*self._w_pending)
+            self._w_pending = None
         if self._w_count == w:
-            self.flush_window()
+            if w >= 3:   # (a smaller window would fill again before its predecessor is two calls old)
+                self._w_pending = (buf, w)
+                self._w_cur = 1 - buf
+                self._w_count = 0
+            else:
+                done = self.flush_window()
+        return done
 
-    def flush_window(self) -> int:
-        """Closes the current window (possibly partial): flush the last local merge, ONE
-        all-gather, ONE batched merge.  Returns the number of queries in the window."""
-        cnt = getattr(self, "_w_count", 0)
-        if cnt == 0:
-            return 0
+    def _merge_window(self, buf: int, cnt: int) -> int:
+        """ONE all-gather + ONE batched merge for the `cnt` queries of window buffer `buf` (its local key lists are
+        complete in stream order)."""
         w, k = self._w_shape
         need = cnt * k
-        self.local.enqueue_flush()
-        local = self._w_local[:need]
+        local = self._w_local[buf][:need]
         if self.world == 1 and not self.always_gather:
             gathered = local
         else:
-            gathered = self._w_gather[: self.world * need]
+            gathered = self._w_gather[buf][: self.world * need]
             self._all_gather(gathered, local)
-        self.local.enqueue_merge_keys_batch(gathered, self.world, k, need, k, cnt, k, self._w_keys[:need],
-                                            self._w_idx[:need], self._w_score[:need])
-        self.window_keys = self._w_keys[:need].view(cnt, k)
-        self.window_idx = self._w_idx[:need].view(cnt, k)
-        self.window_score = self._w_score[:need].view(cnt, k)
-        self._w_count = 0
+        self.local.enqueue_merge_keys_batch(gathered, self.world, k, need, k, cnt, k, self._w_keys[buf][:need],
+                                            self._w_idx[buf][:need], self._w_score[buf][:need])
+        self.window_keys = self._w_keys[buf][:need].view(cnt, k)
+        self.window_idx = self._w_idx[buf][:need].view(cnt, k)
+        self.window_score = self._w_score[buf][:need].view(cnt, k)
+        if not hasattr(self, "merged_windows"):
+            self.merged_windows = []
+        self.merged_windows.append((self.window_keys, self.window_idx, self.window_score))
         return cnt
+
+    def flush_window(self) -> int:
+        """Closes the stream of windows: drains the local pipeline, then merges the window that was still waiting
+        for its lag (if any) and the open, possibly partial one — each ONE all-gather + ONE batched merge.  Returns
+        the number of queries of the LAST window merged (0: nothing was outstanding); `self.merged_windows` lists
+        the results of every window this call merged, oldest first."""
+        self.merged_windows = []
+        cnt = getattr(self, "_w_count", 0)
+        pending = getattr(self, "_w_pending", None)
+        if cnt == 0 and pending is None:
+            return 0
+        self.local.enqueue_flush()
+        done = 0
+        if pending is not None:
+            done = self._merge_window(*pending)
+            self._w_pending = None
+        if cnt:
+            done = self._merge_window(self._w_cur, cnt)
+            self._w_count = 0
+        return done
 
     def enqueue_batch(self, queries, exclude_global, topn: int):
         """`batch` queries: local multi-query passes, ONE all-gather of batch*topn

@@ -114,13 +114,23 @@ def _worker(rank, world, port, n_rows, result_dir):
         # windowed single queries: one all-gather per window of 4, a partial last window
         qrows = [3, n_rows // 2, n_rows - 1, 17, 4242, 99]
         got = []
+        # (a full window is merged two queries into the next one: the local stream is not drained in between)
+        done = []
         for q in qrows:
-            eng.enqueue_query_windowed(f[q], q, 10, window=4)
-            if eng._w_count == 0:
+            n_done = eng.enqueue_query_windowed(f[q], q, 10, window=4)
+            done.append(n_done)
+            if n_done:
                 got.extend(eng.window_idx.numpy().copy())
+        assert done == [0, 0, 0, 0, 0, 4], done
         assert eng.flush_window() == 2
         got.extend(eng.window_idx.numpy().copy())
         assert eng.flush_window() == 0
+        # a flush with a full window still waiting for its lag merges both, oldest first
+        for q in qrows[:5]:
+            assert eng.enqueue_query_windowed(f[q], q, 10, window=4) == 0
+        assert eng.flush_window() == 1 and [int(x[1].shape[0]) for x in eng.merged_windows] == [4, 1]
+        both = np.concatenate([x[1].numpy() for x in eng.merged_windows])
+        assert np.array_equal(both, np.array(got[:5]))
         for q, idx in zip(qrows, got):
             ci, _ = oracle.topn_canonical(oracle.scores(f, f[q]), q, 10)
             assert idx.tolist() == ci.tolist(), (rank, q)
