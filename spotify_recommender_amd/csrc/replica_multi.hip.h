@@ -533,6 +533,7 @@ __device__ __forceinline__ void hm_arrive_and_select(SeedCtl* ctl, unsigned done
     if (threadIdx.x == 0)   // arrival a (0-based) takes round total - 1 - a: the last to arrive round 0, the one before it round 1, ...
         *s_round = done_base + total - 1u - __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    MI355REC_PHASE(3);   // arrived
     const unsigned rounds = static_cast<unsigned>((n_queries + kHmWaves - 1) / kHmWaves);
     const int lane = threadIdx.x & 63;
     for (unsigned r = *s_round; r < rounds; r += total) {   // uniform; (fewer workgroups than rounds: the last ones take several)
@@ -543,6 +544,7 @@ __device__ __forceinline__ void hm_arrive_and_select(SeedCtl* ctl, unsigned done
                                  : -__builtin_inff();
         if (lane == 0) cuts[qi] = tag_value(epoch, __float_as_uint(cut));
     }
+    if (*s_round < rounds) MI355REC_PHASE(4);   // (a selecting workgroup) selected
 }
 
 // The sample launch of a call on its own (and of the head of a stream).  Its last workgroups also select the cutoffs
@@ -558,6 +560,7 @@ __global__ __launch_bounds__(kHmBlock) void seed_half_multi_kernel(
     __shared__ uint4 s_b[64];
     __shared__ uint32_t s_ok[kHmQueries];
     __shared__ unsigned s_round;
+    MI355REC_PHASE(0);
     hm_sample_regions<4>(half, n, stride_rows, gridDim.x, blockIdx.x, gridDim.x, s_b, n_queries, seed_vals, epoch, log2_mult, debug_skip,
                          [&]() {
                              if (threadIdx.x < kHmQueries) {
@@ -565,7 +568,9 @@ __global__ __launch_bounds__(kHmBlock) void seed_half_multi_kernel(
                                  s_ok[threadIdx.x] = hm_build_fragment(arg, n_queries, threadIdx.x, 0u, s_b, q, qn) ? 1u : 0u;
                              }
                              __syncthreads();
+                             MI355REC_PHASE(1);   // fragment built
                          });
+    MI355REC_PHASE(2);   // sampled, values stored
     if (ctl)   // uniform
         hm_arrive_and_select<32>(ctl, done_base, gridDim.x, n_queries, s_ok, seed_vals, static_cast<int>(gridDim.x) * kHalfSeedWaves, topk,
                                  arg.margin, epoch, cuts, &s_round);
