@@ -107,14 +107,16 @@ __device__ __forceinline__ void hm_load_query(const HalfMultiArg& arg, int i, fl
 // threshold slots, 0.  `slots`: what real queries start with in k = 12, 13 (0 for the sample: D = approx; +inf
 // for the scan: every row is a candidate until a cutoff is known); a padding column can never hit (-65504).
 // Called by threads 0..31; returns the query (for the caller's own bookkeeping).
-__device__ __forceinline__ bool hm_build_fragment(const HalfMultiArg& arg, int n_queries, int c, uint32_t slots, uint4* bfrag,
-                                                  float (&q)[kDim], float& qn) {
+// (two steps, so that a caller can REQUEST the query before other loads and look at it after them: loads complete in order)
+__device__ __forceinline__ void hm_request_query(const HalfMultiArg& arg, int n_queries, int c, float (&q)[kDim]) {
     if (c < n_queries) {
         hm_load_query(arg, c, q);
     } else {
 #pragma unroll
         for (int j = 0; j < kDim; ++j) q[j] = 0.0f;
     }
+}
+__device__ __forceinline__ bool hm_finish_fragment(const float (&q)[kDim], int n_queries, int c, uint32_t slots, uint4* bfrag, float& qn) {
     qn = query_norm(q);
     const bool ok = c < n_queries && qn >= kBqMinNorm && qn <= kBqMaxNorm;   // false for NaN
     const float inv = ok ? 1.0f / qn : 0.0f;
@@ -124,6 +126,11 @@ __device__ __forceinline__ bool hm_build_fragment(const HalfMultiArg& arg, int n
     bfrag[c] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
     bfrag[32 + c] = make_uint4(hp[4], hp[5], c < n_queries ? slots : 0x0000fbffu, 0u);
     return ok;
+}
+__device__ __forceinline__ bool hm_build_fragment(const HalfMultiArg& arg, int n_queries, int c, uint32_t slots, uint4* bfrag,
+                                                  float (&q)[kDim], float& qn) {
+    hm_request_query(arg, n_queries, c, q);
+    return hm_finish_fragment(q, n_queries, c, slots, bfrag, qn);
 }
 
 // The two 32-row A operands of one row set of a chunk (a lane's even rows, S = 0, or its odd rows, S = 1);
@@ -185,7 +192,8 @@ __device__ __forceinline__ int hm_tile_max(const bq_f16v& d) {   // max over the
 // (host), so no row is sampled twice.
 // Workgroup `first`, `first + every`, ... of the regions; called by all 512 threads.  kDepth chunks are in flight per wave.
 // `make_fragment` builds the batch's B fragment at `bfrag` (and ends with a barrier); it is called AFTER the first chunks
-// have been requested — they need nothing of the queries, which sit behind dependent loads and a normalisation.
+// have been requested — the caller has requested the queries before calling this, so that the fragment's inputs come
+// back ahead of the cold rows (loads complete in order).
 template <int kDepth, typename MakeFragment>
 __device__ __forceinline__ void hm_sample_regions(const uint4* __restrict__ half, int64_t n, int64_t stride_rows, int regions,
                                                   int first, int every, const uint4* bfrag, int n_queries,
@@ -561,11 +569,13 @@ __global__ __launch_bounds__(kHmBlock) void seed_half_multi_kernel(
     __shared__ uint32_t s_ok[kHmQueries];
     __shared__ unsigned s_round;
     MI355REC_PHASE(0);
+    float q_pre[kDim];   // the queries are requested BEFORE the rows (and looked at behind them: loads complete in order)
+    if (threadIdx.x < kHmQueries) hm_request_query(arg, n_queries, threadIdx.x, q_pre);
     hm_sample_regions<4>(half, n, stride_rows, gridDim.x, blockIdx.x, gridDim.x, s_b, n_queries, seed_vals, epoch, log2_mult, debug_skip,
                          [&]() {
                              if (threadIdx.x < kHmQueries) {
-                                 float q[kDim], qn;
-                                 s_ok[threadIdx.x] = hm_build_fragment(arg, n_queries, threadIdx.x, 0u, s_b, q, qn) ? 1u : 0u;
+                                 float qn;
+                                 s_ok[threadIdx.x] = hm_finish_fragment(q_pre, n_queries, threadIdx.x, 0u, s_b, qn) ? 1u : 0u;
                              }
                              __syncthreads();
                              MI355REC_PHASE(1);   // fragment built
@@ -648,12 +658,14 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
                 }
             } else {                           // a seed rider: its share of the next batch's sample
                 uint4* const fb = s_mem.scan.bfrag;
+                float q_pre[kDim];   // (requested before the rows: see seed_half_multi_kernel)
+                if (tid < kHmQueries) hm_request_query(next, ride.next_queries, tid, q_pre);
                 hm_sample_regions<4>(half, n, ride.stride_rows, ride.regions, extra - ride.merge_wgs, ride.seed_wgs, fb,
                                      ride.next_queries, ride.next_seed_vals, ride.next_epoch, ride.sample_log2, ride.debug_skip,
                                      [&]() {
                                          if (tid < kHmQueries) {
-                                             float q[kDim], qn;
-                                             s_mem.scan.ok[tid] = hm_build_fragment(next, ride.next_queries, tid, 0u, fb, q, qn) ? 1u : 0u;
+                                             float qn;
+                                             s_mem.scan.ok[tid] = hm_finish_fragment(q_pre, ride.next_queries, tid, 0u, fb, qn) ? 1u : 0u;
                                          }
                                          __syncthreads();
                                      });
@@ -698,6 +710,15 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
         dst.d1 = p[1];
         dst.d2 = p[2];
     };
+    // The queries and the cutoffs left for them are REQUESTED before the first rows: loads complete in order, and behind
+    // twelve cold 16-byte loads per lane the B fragment was not ready before 3.5 us into the launch (tools/seed_clock.py
+    // on the sample launch, which had the same order) — with the cutoffs' load another round trip behind a barrier.
+    float q_pre[kDim];
+    unsigned long long cut_pre = 0ull;
+    if (tid < kHmQueries) {
+        hm_request_query(arg, n_queries, tid, q_pre);
+        if (cuts_ready && tid < n_queries) cut_pre = cuts_ready[tid];
+    }
     HalfTile T[kQ8 ? 1 : kHmChunks];
     Row8 G[kQ8 ? kHmGroups : 1];
     if constexpr (kQ8) {
@@ -708,14 +729,20 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
         for (int u = 0; u < kHmChunks; ++u) load_chunk(T[u], step, u);
     }
 
-    // ---- per-query state and the B fragment; the cutoffs from the sample while the first loads are in flight
+    // ---- per-query state, the B fragment and the cutoffs, while the first rows are in flight
+    if (tid == 0) {   // (the same wave as the block below: its LDS operations are performed in order)
+        sm.rescored = 0;
+        sm.margin = arg.margin;
+        sm.q8 = kQ8 ? 1 : 0;
+        sm.select_here = 0u;
+    }
     if (tid < kHmQueries) {
-        float q[kDim], qn;
+        float qn;
         // a real query starts with "every row is a candidate" (+inf in the threshold slots)
-        const bool ok = hm_build_fragment(arg, n_queries, tid, 0x00007c00u, sm.bfrag, q, qn);
-        if constexpr (kQ8) hm_build_fragment8(sm, tid, tid < n_queries, ok, q, qn);
+        const bool ok = hm_finish_fragment(q_pre, n_queries, tid, 0x00007c00u, sm.bfrag, qn);
+        if constexpr (kQ8) hm_build_fragment8(sm, tid, tid < n_queries, ok, q_pre, qn);
 #pragma unroll
-        for (int j = 0; j < kDim; ++j) sm.qf[tid][j] = q[j];
+        for (int j = 0; j < kDim; ++j) sm.qf[tid][j] = q_pre[j];
         sm.qn[tid] = qn;
         sm.cut[tid] = -__builtin_inff();
         sm.thr[tid] = 0ull;
@@ -725,32 +752,22 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
 #pragma unroll
         for (int w = 0; w < kHmWaves; ++w) sm.pcount[w][tid] = 0;
         sm.ok[tid] = ok ? 1u : 0u;
-    }
-    if (tid == 0) {
-        sm.rescored = 0;
-        sm.margin = arg.margin;
-        sm.q8 = kQ8 ? 1 : 0;
-        sm.select_here = 0u;
-    }
-    __syncthreads();
-    // The cutoffs: normally left, tagged with this batch's epoch, by the last sampling workgroups (the sample launch's,
-    // or the seed riders of the launch before).  A cutoff that is NOT there under this epoch (a hand-off that went
-    // wrong: replica.hip.h, "hand-offs that fail safe") is selected here from whatever sample values carry the epoch —
-    // what every workgroup did for every query before round 4 — so a broken hand-off costs microseconds, not a scan
-    // without a cutoff.
-    if (tid < n_queries && sm.ok[tid]) {
-        bool have = false;
-        if (cuts_ready) {   // uniform
-            const unsigned long long w = cuts_ready[tid];
-            have = static_cast<uint32_t>(w >> 32) == epoch;
+        // The cutoffs: normally left, tagged with this batch's epoch, by the last sampling workgroups (the sample
+        // launch's, or the seed riders of the launch before).  A cutoff that is NOT there under this epoch (a hand-off
+        // that went wrong: replica.hip.h, "hand-offs that fail safe") is selected below from whatever sample values
+        // carry the epoch — what every workgroup did for every query before round 4 — so a broken hand-off costs
+        // microseconds, not a scan without a cutoff.
+        if (tid < n_queries && ok) {
+            const bool have = cuts_ready && static_cast<uint32_t>(cut_pre >> 32) == epoch;
             if (have) {
-                const float cut = __uint_as_float(static_cast<uint32_t>(w));
+                const float cut = __uint_as_float(static_cast<uint32_t>(cut_pre));
                 sm.cut[tid] = cut;
                 reinterpret_cast<uint32_t*>(&sm.bfrag[32 + tid])[2] = hm_threshold_slots(cut);
                 if constexpr (kQ8) reinterpret_cast<uint32_t*>(&sm.bfrag8[tid])[3] = hm_q8_slots(cut + arg.margin + kBqSlack - sm.m8[tid]);
+            } else if (n_seed > 0) {
+                atomicOr(&sm.select_here, 1u << tid);
             }
         }
-        if (!have && n_seed > 0) atomicOr(&sm.select_here, 1u << tid);
     }
     __syncthreads();
     if (const uint32_t todo = sm.select_here) {   // uniform, rare
