@@ -642,6 +642,7 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
     const unsigned bid = blockIdx.x;
     unsigned nblocks = gridDim.x;   // scanning workgroups
     HalfMultiSmem* smp;
+    MI355REC_PHASE(0);
     if constexpr (kRide) {
         nblocks = gridDim.x - static_cast<unsigned>(ride.merge_wgs) - static_cast<unsigned>(ride.seed_wgs);
         if (bid >= nblocks) {
@@ -674,6 +675,7 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
                                          s_mem.scan.ok, ride.next_seed_vals, ride.regions * kHalfSeedWaves, ride.next_topk, next.margin,
                                          ride.next_epoch, ride.next_cuts, reinterpret_cast<unsigned*>(&s_mem.scan.rescored));
             }
+            MI355REC_PHASE(5);   // a merger or a rider is done
             return;
         }
         smp = &s_mem.scan;
@@ -785,6 +787,7 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
         __syncthreads();
     }
 
+    MI355REC_PHASE(1);    // fragment and cutoffs in place
     int staged = 0;       // wave-uniform
     int n_rescored = 0;   // wave-uniform (diagnostics)
     uint2* const stage = sm.stage[wave];
@@ -961,11 +964,13 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
             }
         }
     }
+    MI355REC_PHASE(2);    // (wave 0 of the workgroup) its steps are done
 #if MI355_HM_EXP == 2   // EXPERIMENT (wrong results): the candidates are extracted but never scored
     if (staged > 100000) n_rescored = 1;
 #else
     n_rescored += hm_resolve_stage(sm, staged, feats, row_base, topk, kQ8 ? reinterpret_cast<const uint32_t*>(half) : nullptr);
 #endif
+    MI355REC_PHASE(3);    // ... and its last candidates resolved
     if (lane == 0) atomicAdd(&sm.rescored, n_rescored);
     __syncthreads();
     if (tid == 0) rescored[bid] += static_cast<unsigned long long>(sm.rescored);   // launches of a handle are stream-ordered
@@ -991,6 +996,7 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
         uint64_t* dst = block_lists + (static_cast<int64_t>(slot0 + qi) * nblocks + bid) * topk;
         wave_rank_and_store(sm.keys[qi], c, dst, topk);
     }
+    MI355REC_PHASE(4);    // (wave 0) its share of the lists stored
 }
 
 }  // namespace mi355
