@@ -28,8 +28,16 @@ __device__ unsigned long long g_phase_clock[1024 * 8];
     do {                                                                                         \
         if (threadIdx.x == 0 && blockIdx.x == 0) g_phase_clock[1023 * 8 + (i)] = wall_clock64(); \
     } while (0)
+// the phases of every workgroup of the fp32 scan (row = blockIdx.x, as the 8-bit scan's MI355REC_PHASE)
+#define MI355REC_KPHASE(i)                                                                  \
+    do {                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < 1023) g_phase_clock[blockIdx.x * 8 + (i)] = wall_clock64(); \
+    } while (0)
 #else
 #define MI355REC_MPHASE(i) \
+    do {                   \
+    } while (0)
+#define MI355REC_KPHASE(i) \
     do {                   \
     } while (0)
 #endif
@@ -824,6 +832,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
     constexpr int kRowsPerThread = Cfg::kRowsPerThread;
     constexpr int kTileRows = Cfg::kTileRows;
     static_assert(!(kWithMerge && kScoresOnly), "the riding merger belongs to top-N scans");
+    MI355REC_KPHASE(0);
     // Plain statics for the ordinary scan (exactly the round-1 layout: the kernel sits at
     // 79 of its 80 VGPRs and one more costs a spill); the union only in the riding variant.
     __shared__ uint64_t s_cand_plain[(kScoresOnly || kWithMerge) ? 1 : Cfg::kCandCap];
@@ -902,6 +911,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
         for (int j = 0; j < kDim; ++j) q[j] = qarg.q[j];
     }
     const float qn = query_norm(q);
+    if (qn >= 0.0f || n >= 0) MI355REC_KPHASE(1);   // (depends on the query)
     // Only keys strictly below *upper_ptr take part (nullptr: no bound).  This is
     // how topn > kMaxTopK is served: round r asks for the best kMaxTopK keys
     // below the last key of round r-1 (0 there = catalogue exhausted).
@@ -983,12 +993,17 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
         }
     }
 
+    MI355REC_KPHASE(3);   // tiles done
     if constexpr (!kScoresOnly) {
         __syncthreads();
-        if (s_count > kRankDirectMax && s_count > topk)  // uniform
-            compact_candidates<kBlock, Cfg::kCandPerThread>(s_cand, &s_count, topk, true, s_sel);
+        // (from kRankCountMax keys up the ranking is a bitonic sort of the next power of two — 45 barrier stages, ~2.7 us
+        // for the ~250 keys a scan without a launch-wide cutoff ends with; an INEXACT cut to topk + topk / 4 first costs a
+        // radix pass or two and leaves a set the counting rank handles)
+        if (s_count > kRankCountMax && s_count > topk)  // uniform
+            compact_candidates<kBlock, Cfg::kCandPerThread>(s_cand, &s_count, topk, false, s_sel);
         __syncthreads();
         block_rank_and_store<kBlock>(s_cand, s_count, block_lists + static_cast<int64_t>(bid) * topk, topk);
+        MI355REC_KPHASE(4);   // list stored
     }
 }
 

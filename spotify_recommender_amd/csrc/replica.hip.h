@@ -521,8 +521,11 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_half_kernel(
     if (lane == 0 && n_rescored) atomicAdd(&sm->rescored, n_rescored);
     __syncthreads();
     if (tid == 0) rescored[bid] += static_cast<unsigned long long>(sm->rescored);   // launches of a handle are stream-ordered
-    if (s_count > kRankDirectMax && s_count > topk)  // uniform
-        compact_candidates<kBlock, Cfg::kCandPerThread>(s_cand, &s_count, topk, true, s_sel);
+    // (from kRankCountMax keys up the ranking is a bitonic sort of the next power of two — 45 barrier stages, ~2.7 us
+    // for the ~250 keys a scan without a launch-wide cutoff ends with; an INEXACT cut to topk + topk / 4 first costs a
+    // radix pass or two and leaves a set the counting rank handles)
+    if (s_count > kRankCountMax && s_count > topk)  // uniform
+        compact_candidates<kBlock, Cfg::kCandPerThread>(s_cand, &s_count, topk, false, s_sel);
     __syncthreads();
     block_rank_and_store<kBlock>(s_cand, s_count, block_lists + static_cast<int64_t>(bid) * topk, topk);
 }
