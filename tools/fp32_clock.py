@@ -30,8 +30,10 @@ with CosineEngine(t) as eng:
     assert fn(buf.ctypes.data, buf.size) == 0
     eng.enqueue_flush()
     torch.cuda.synchronize()
-c = buf.reshape(1024, 8).astype(np.int64)[:1023]
-c = c[(c[:, 0] > 0) & (c[:, 4] > 0)]
+c_all = buf.reshape(1024, 8).astype(np.int64)[:1023]
+ok = (c_all[:, 0] > 0) & (c_all[:, 4] > 0)
+bids = np.nonzero(ok)[0]
+c = c_all[ok]
 t0 = c[:, 0].min()
 us = lambda x: round(float(x) / 100.0, 2)
 out = {"rows": a.rows, "topn": a.topn, "scanners": int(len(c))}
@@ -39,4 +41,12 @@ for i, nm in ((0, "entry"), (1, "query_ready"), (3, "tiles_done"), (4, "list_sto
     v = c[:, i] - t0
     out[nm] = {"first": us(v.min()), "median": us(np.median(v)), "p95": us(np.percentile(v, 95)), "last": us(v.max())}
 out["launch_span_us"] = us(c[:, 4].max() - t0)
+# who finishes when: deciles of tiles_done, its median by dispatch order (thirds of blockIdx: with three workgroups per CU
+# the dispatcher fills every CU once before it comes round again) and by XCD (blockIdx % 8)
+td = c[:, 3] - t0
+out["tiles_done_deciles"] = [us(np.percentile(td, p)) for p in range(0, 101, 10)]
+third = (len(bids) + 2) // 3
+out["tiles_done_median_by_third_of_blockIdx"] = [us(np.median(td[(bids >= k * third) & (bids < (k + 1) * third)])) for k in range(3)]
+out["tiles_done_median_by_xcd"] = [us(np.median(td[bids % 8 == x])) for x in range(8)]
+out["tiles_done_last_by_xcd"] = [us(td[bids % 8 == x].max()) for x in range(8)]
 print(json.dumps(out))
