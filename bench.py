@@ -270,7 +270,7 @@ def run_node(args, json_fd):
     def timed_stream():
         stream(0, args.warmup)
         sync_all()
-        stride = args.event_stride if args.event_stride > 0 else max(1, args.steps // (16 if args.steps >= 64 else 3))
+        stride = args.event_stride if args.event_stride > 0 else max(1, -(-args.steps // (16 if args.steps >= 64 else 3)))
         if not args.no_kernel_events:
             node.set_timing(stride)
         st0 = node.stream_stats()
@@ -569,8 +569,8 @@ def main():
     fence()
     rc_before = eng.replica_counters() if replica else None
     # a timed launch costs ~6 us of stream time (start / stop signals around the dispatch): 16 timed launches
-    # in a long run (every 18th of the default 300), 3 in a short one (the driver's 20-step run: every 6th)
-    stride = args.event_stride if args.event_stride > 0 else max(1, args.steps // (16 if args.steps >= 64 else 3))
+    # in a long run (every 19th of the default 300), 3 in a short one (the driver's 20-step run: every 7th)
+    stride = args.event_stride if args.event_stride > 0 else max(1, -(-args.steps // (16 if args.steps >= 64 else 3)))
     if not args.no_kernel_events:
         eng.set_timing(stride)  # HIP events around every k-th scan / merge launch
     t0 = time.perf_counter()
