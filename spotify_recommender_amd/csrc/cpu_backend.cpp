@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <vector>
 
 namespace mi355cpu {
@@ -104,9 +105,15 @@ struct Catalogue {
 
 Catalogue* create(const float* feats_rowmajor, int64_t n, int threads) {
     if (n < 0 || (n > 0 && !feats_rowmajor)) return nullptr;
-    Catalogue* c = new Catalogue();
-    c->n = n;
-    c->feats.assign(feats_rowmajor, feats_rowmajor + static_cast<size_t>(n) * kDim);
+    Catalogue* c = nullptr;
+    try {   // (called from behind a C-ABI: no exception may leave)
+        c = new Catalogue();
+        c->n = n;
+        c->feats.assign(feats_rowmajor, feats_rowmajor + static_cast<size_t>(n) * kDim);
+    } catch (const std::bad_alloc&) {
+        delete c;
+        return nullptr;
+    }
     int t = threads > 0 ? threads : omp_get_max_threads();
     if (threads <= 0) {   // no more threads than the process may really run (a cgroup quota throttles the rest)
         const int quota = cpu_quota();
@@ -209,7 +216,11 @@ struct Node {
 Node* node_create(const float* feats_rowmajor, int64_t n) {
     Catalogue* c = create(feats_rowmajor, n, 0);
     if (!c) return nullptr;
-    Node* h = new Node();
+    Node* h = new (std::nothrow) Node();
+    if (!h) {
+        destroy(c);
+        return nullptr;
+    }
     h->cat = c;
     return h;
 }
@@ -228,7 +239,13 @@ int node_query(Node* h, const float* q12, int64_t exclude, int topn_asked, int64
         *why = "topn must be positive";
         return MI355REC_ERR_INVALID_ARG;
     }
-    const int c = topn(h->cat, q12, exclude, topn_asked, out_idx, out_score);
+    int c = 0;
+    try {
+        c = topn(h->cat, q12, exclude, topn_asked, out_idx, out_score);
+    } catch (const std::bad_alloc&) {
+        *why = "out of host memory";
+        return MI355REC_ERR_OUT_OF_MEMORY;
+    }
     for (int i = c; i < topn_asked; ++i) {   // the C-ABI pads with -1 / 0
         out_idx[i] = -1;
         if (out_score) out_score[i] = 0.0f;
@@ -260,10 +277,16 @@ int node_enqueue(Node* h, const float* q12, int64_t exclude, int topn_asked, int
     const int W = h->window;
     if (h->s_topn != topn_asked) {   // a change of geometry closes the stream; tickets keep growing, window-aligned
         node_flush(h);
+        h->s_topn = 0;
+        try {
+            h->idx.assign(static_cast<size_t>(kDepth) * W * topn_asked, -1);
+            h->score.assign(static_cast<size_t>(kDepth) * W * topn_asked, 0.0f);
+            h->counts.assign(static_cast<size_t>(kDepth) * W, 0);
+        } catch (const std::bad_alloc&) {
+            *why = "out of host memory";
+            return MI355REC_ERR_OUT_OF_MEMORY;
+        }
         h->s_topn = topn_asked;
-        h->idx.assign(static_cast<size_t>(kDepth) * W * topn_asked, -1);
-        h->score.assign(static_cast<size_t>(kDepth) * W * topn_asked, 0.0f);
-        h->counts.assign(static_cast<size_t>(kDepth) * W, 0);
         for (auto& w : h->win) w = Node::Win();
     }
     const int64_t t = h->next_ticket;
@@ -276,7 +299,13 @@ int node_enqueue(Node* h, const float* q12, int64_t exclude, int topn_asked, int
         ++h->st_windows;
     }
     const size_t at = (static_cast<size_t>(w) * W + slot) * topn_asked;
-    const int c = topn(h->cat, q12, exclude, topn_asked, &h->idx[at], &h->score[at]);
+    int c = 0;
+    try {
+        c = topn(h->cat, q12, exclude, topn_asked, &h->idx[at], &h->score[at]);
+    } catch (const std::bad_alloc&) {
+        *why = "out of host memory";
+        return MI355REC_ERR_OUT_OF_MEMORY;
+    }
     for (int i = c; i < topn_asked; ++i) {
         h->idx[at + i] = -1;
         h->score[at + i] = 0.0f;
