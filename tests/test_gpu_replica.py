@@ -242,6 +242,46 @@ def test_duplicates_and_mass_ties_at_the_nth_score(Engine):
         check_queries(eng, f, None, np.array([qrow]), (1, 100, 300), "duplicates of the query", rows=np.array([qrow]))
 
 
+@pytest.mark.parametrize("clusters", [3, 40])
+def test_clustered_catalogue_where_a_replica_rules_little_out(Engine, torch_cuda, clusters):
+    """Rows shaped like min-max normalised audio features in a few tight clusters (discrete key / mode / genre columns,
+    spread 0.01, 2 % exact duplicates): every row of the query's cluster lies within the pre-filters' margins of the
+    cutoff, so a third (3 clusters) or a fortieth of the catalogue goes to the exact chain — candidate buffers fill,
+    compactions run under pressure, a tile holds many candidates instead of one.  Same keys as the oracle, lone and
+    streamed; and the diagnostics show the pressure was there."""
+    torch = torch_cuda
+    rng = np.random.default_rng(100 + clusters)
+    n = 1_300_003
+    centres = rng.random((clusters, 12), dtype=np.float32)
+    centres[:, 2] = rng.integers(0, 12, clusters).astype(np.float32) / np.float32(11)
+    centres[:, 4] = rng.integers(0, 2, clusters).astype(np.float32)
+    centres[:, 11] = rng.integers(0, 114, clusters).astype(np.float32) / np.float32(113)
+    which = rng.integers(0, clusters, n)
+    noise = (rng.standard_normal((n, 12)) * 0.01).astype(np.float32)
+    noise[:, [2, 4, 11]] = 0
+    f = np.clip(centres[which] + noise, 0, 1).astype(np.float32)
+    dup = rng.integers(0, n, n // 50)
+    f[dup] = f[rng.integers(0, n, n // 50)]
+    rows = rng.integers(0, n, size=5)
+    with Engine(f) as eng:
+        eng.set_replica(ON)
+        before = eng.replica_counters()
+        check_queries(eng, f, None, rows, (10, 100, 1000), f"{clusters} clusters", rows=rows)
+        after = eng.replica_counters()
+        per_scan = (after["rescored_rows"] - before["rescored_rows"]) / (after["scans"] - before["scans"])
+        assert per_scan > 0.5 * n / clusters, per_scan     # the whole cluster, or most of it, went to the exact chain
+        ring = torch.zeros((len(rows), 100), dtype=torch.int64, device="cuda")
+        for i, r in enumerate(rows):
+            eng.enqueue_row_keys_streamed(int(r), 100, ring[i])
+        eng.enqueue_flush()
+        torch.cuda.synchronize()
+        from spotify_recommender_amd.engine import unpack_keys
+        for i, r in enumerate(rows):
+            want = oracle.scores(f, f[int(r)], threads=0)
+            idx, sc = unpack_keys(ring[i].cpu().numpy())
+            assert_topn_matches(idx, sc, want, int(r), 100, ref_idx=oracle.topn_heap(want, int(r), 100))
+
+
 def test_small_and_ragged_shards(Engine):
     """Fewer rows than one sampled region, fewer than topn, one row, row_base shards."""
     rng = np.random.default_rng(12)

@@ -15,6 +15,31 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 
 
+def clustered_catalogue(n, spread, seed=777, clusters=3000):
+    """Rows shaped like the reference's min-max normalised features (Song.h:18-19: danceability, energy, key, loudness,
+    mode, speechiness, acousticness, instrumentalness, liveness, valence, tempo, genre_id — DataManager.cpp:286-299):
+    cluster centres in [0,1]^12 with key in {0..11}/11, mode in {0,1}, genre in {0..113}/113, Gaussian spread around the
+    continuous columns, and 2 % exact duplicates (the same track on several albums)."""
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    centres = torch.rand((clusters, 12), device="cuda", generator=g)
+    centres[:, 2] = torch.randint(0, 12, (clusters,), device="cuda", generator=g).float() / 11.0
+    centres[:, 4] = torch.randint(0, 2, (clusters,), device="cuda", generator=g).float()
+    centres[:, 7] = centres[:, 7] ** 4          # instrumentalness: mostly near 0
+    centres[:, 5] = centres[:, 5] ** 3 * 0.5    # speechiness: small
+    centres[:, 11] = torch.randint(0, 114, (clusters,), device="cuda", generator=g).float() / 113.0
+    which = torch.randint(0, clusters, (n,), device="cuda", generator=g)
+    t = centres[which]
+    noise = torch.randn((n, 12), device="cuda", generator=g) * spread
+    noise[:, [2, 4, 11]] = 0.0                  # discrete columns stay on their grid
+    t = (t + noise).clamp_(0.0, 1.0)
+    dup = torch.randint(0, n, (n // 50,), device="cuda", generator=g)
+    src = torch.randint(0, n, (n // 50,), device="cuda", generator=g)
+    t[dup] = t[src]
+    return t.contiguous()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=10_000_000)
@@ -23,6 +48,11 @@ def main():
     ap.add_argument("--check", type=int, default=64, help="queries compared between the two paths")
     ap.add_argument("--only", type=int, default=-1, help="time only this mode (1 fp32 rows, 2 8-bit replica, 3 fp16 replica)")
     ap.add_argument("--lib", default=None, help="another build of the library (e.g. an MI355REC_EXPERIMENTS one under gpurun_out/)")
+    ap.add_argument("--catalogue", default="uniform", choices=["uniform", "clustered"],
+                    help="clustered: min-max normalised audio-feature look-alike (discrete key / mode / genre columns, a few thousand "
+                         "tight clusters, exact duplicates) instead of uniform noise: what the replicas cannot rule out grows")
+    ap.add_argument("--spread", type=float, default=0.03, help="clustered: standard deviation of a cluster")
+    ap.add_argument("--clusters", type=int, default=3000, help="clustered: number of clusters")
     args = ap.parse_args()
     if args.lib:
         from spotify_recommender_amd import capi as _capi
@@ -32,7 +62,10 @@ def main():
     from spotify_recommender_amd import CosineEngine, capi
     from spotify_recommender_amd.synth import synthetic_catalogue
 
-    t = synthetic_catalogue(args.rows, seed=12345)
+    if args.catalogue == "clustered":
+        t = clustered_catalogue(args.rows, args.spread, clusters=args.clusters)
+    else:
+        t = synthetic_catalogue(args.rows, seed=12345)
     rows = [(k * 7919 + 13) % args.rows for k in range(max(args.check, args.steps + 20, 200))]   # 200: the latency loop below
     out = {"rows": args.rows, "topn": args.topn}
     with CosineEngine(t) as eng:
