@@ -330,10 +330,12 @@ int mi355rec_enqueue_batch_keys_dev(mi355rec_t* h, const float* queries_dev,
  * csrc/batched.hip.h) selects a few hundred candidate rows per query that are
  * then scored with the exact fp32 chain — results stay bit-identical to the
  * single-query path.  Queries the bound cannot be claimed for (tiny / huge /
- * non-finite norms, fewer than topn+1 clearly positive groups, more than 2048
- * candidates) are served by the exact multi-query scan inside the same call.
+ * non-finite norms, fewer than topn+1 clearly positive groups, more candidates
+ * than a query's list holds: about rows / 64, at most 65536) are served by the
+ * exact multi-query scan inside the same call.
  * MULTI / MFMA force one path (tests, A/B measurements).  The first batched
- * call allocates the path's scratch (~0.3 GB); later calls allocate nothing. */
+ * call allocates the path's scratch (~0.3 GB + the candidate lists, 8 ... 256
+ * MB); later calls allocate nothing. */
 #define MI355REC_BATCH_AUTO 0
 #define MI355REC_BATCH_MULTI 1
 #define MI355REC_BATCH_MFMA 2

@@ -35,7 +35,7 @@
 // Queries (or whole chunks) the bound cannot be claimed for are QUEUED on the
 // device and served by the exact multi-query scan (scan_multi_queued_kernel):
 // tiny / huge / non-finite query norms, T' <= 0 (fewer than topN+1 groups with a
-// clearly positive maximum), more candidates than kBqCap (mass ties at the
+// clearly positive maximum), more candidates than the per-query list holds (mass ties at the
 // threshold), more special rows than kBqSpecialCap.
 //
 // Rows: "valid" = |row|^2 in [kBqMinNorm2, kBqMaxNorm2] (then, with a valid
@@ -72,10 +72,16 @@ typedef float bq_f16v __attribute__((ext_vector_type(16)));
 
 constexpr int kBqMaxBlocks = 32;             // 32 queries per block -> 1024 queries per chunk
 constexpr int kBqMaxQueries = kBqMaxBlocks * 32;
-constexpr int kBqCap = 2048;                 // candidate rows kept per query
+// Candidate rows kept per query: a power of two near rows / 64 between these two (the host's choice, mi355rec.hip;
+// 8 MiB ... 256 MiB of row ids per 1024-query chunk).  The passes read it from counters[6] where they flush their
+// staging buffers — not a kernel argument: the pass kernel's register allocation is what it is.
+constexpr int kBqCapMin = 2048;
+constexpr int kBqCapMax = 65536;
 constexpr int kBqSpecialCap = 1024;          // special rows kept per chunk
 constexpr int kBqFinalBlock = 256;           // threads of the finalize workgroup
-constexpr int kBqFinalPerThread = (kBqCap + kBqSpecialCap) / kBqFinalBlock;
+constexpr int kBqFinalChunk = 2048;          // candidates scored between two cuts of the finalize workgroup's key buffer
+constexpr int kBqFinalKeys = kBqFinalChunk + 1024;   // keys that buffer holds: a chunk + what a cut may leave (<= 1024)
+constexpr int kBqFinalPerThread = kBqFinalKeys / kBqFinalBlock;
 constexpr int kBqPassBlock = 256;            // 4 waves, one per SIMD; 4-5 workgroups per CU
 constexpr float kBqMargin = 1.0e-3f;         // fp16 subnormals kept (verified per device by bq_selfcheck_kernel)
 constexpr float kBqMarginFlush = 1.5e-3f;    // bound if they were flushed
@@ -208,11 +214,11 @@ __global__ __launch_bounds__(256) void bq_prepare_kernel(
 constexpr int kBqStage = 256;   // entries per wave (2 KiB); a block adds at most 64 per register
 
 __device__ __forceinline__ void bq_flush_stage(const uint2* stage, int staged, int lane, int* __restrict__ cand_count,
-                                               uint32_t* __restrict__ cand_rows) {
+                                               uint32_t* __restrict__ cand_rows, int cand_cap) {
     for (int e = lane; e < staged; e += 64) {
         const uint2 qr = stage[e];
         const int pos = atomicAdd(&cand_count[qr.x * kBqCountStride], 1);
-        if (pos < kBqCap) cand_rows[static_cast<int64_t>(qr.x) * kBqCap + pos] = qr.y;
+        if (pos < cand_cap) cand_rows[static_cast<int64_t>(qr.x) * cand_cap + pos] = qr.y;
     }
 }
 
@@ -242,7 +248,7 @@ template <int NB, bool kCollect, int kVariant = 0, bool kFromReplica = false, bo
 __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu) void bq_pass_kernel(
     const float* __restrict__ feats, int64_t n, int64_t n_tiles, int tile_step, const uint32_t* __restrict__ bfrag,
     float* __restrict__ gmax /* [NB][8][2 * grid][4] */, int* __restrict__ cand_count,
-    uint32_t* __restrict__ cand_rows /* [query][kBqCap] */, int* __restrict__ counters,
+    uint32_t* __restrict__ cand_rows /* [query][counters[6]] */, int* __restrict__ counters,
     uint32_t* __restrict__ special_rows, const uint2* __restrict__ half = nullptr,
     uint4* __restrict__ tile_max = nullptr /* [visited tile][NB / 8][64] */, int max_step = 1 /* pass 2: pass 1's tile_step */,
     const float* __restrict__ qthr = nullptr, const uint32_t* __restrict__ qflags = nullptr,
@@ -575,7 +581,7 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
                 for (uint64_t who = __ballot(hits != 0u); who; who = __ballot(hits != 0u)) {   // wave-uniform rounds
                     const int n_hit = __popcll(who);
                     if (staged + n_hit > kStageCap) {
-                        bq_flush_stage(stage, staged, lane, cand_count, cand_rows);
+                        bq_flush_stage(stage, staged, lane, cand_count, cand_rows, counters[6]);
                         staged = 0;
                     }
                     if (hits) {
@@ -694,7 +700,7 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
         }
         tile = after;
     }
-    if constexpr (kCollect) bq_flush_stage(stage, staged, lane, cand_count, cand_rows);
+    if constexpr (kCollect) bq_flush_stage(stage, staged, lane, cand_count, cand_rows, counters[6]);
     if constexpr (kCollect && kTileMax) {
         if (lane == 0) atomicAdd(&counters[3], pairs_done);   // diagnostics: one atomic per wave and pass
     }
@@ -815,10 +821,15 @@ __global__ __launch_bounds__(kBqFinalBlock) void bq_finalize_kernel(
     const float* __restrict__ feats, int64_t row_base, const float* __restrict__ queries,
     const long long* __restrict__ exclude /* may be null */, int n_queries, int topk,
     const uint32_t* __restrict__ qflags, const int* __restrict__ cand_count,
-    const uint32_t* __restrict__ cand_rows, int* __restrict__ counters,
+    const uint32_t* __restrict__ cand_rows, int cand_cap, int* __restrict__ counters,
     const uint32_t* __restrict__ special_rows, int* __restrict__ queue /* [n_queries] */,
     uint64_t* __restrict__ out_keys, int64_t* __restrict__ out_idx, float* __restrict__ out_score) {
-    __shared__ uint64_t s_keys[kBqCap + kBqSpecialCap];
+    // Until round 4's end a query kept at most 2048 candidates, all of them in this buffer at once — and a catalogue
+    // whose rows CLUSTER (3000 clusters of 3300 rows, spread 0.03: profiles/r04_clustered.jsonl) sent 986 of 1024
+    // queries to the exact queue, 43 ms per batch instead of 0.55.  Now the global list holds up to 65536 rows per query and the
+    // buffer is worked in chunks: score 2048 candidates, cut to a little over topk, go on — with the cut's threshold
+    // as a floor for what is appended later.
+    __shared__ uint64_t s_keys[kBqFinalKeys];
     __shared__ uint64_t s_top[kMultiMaxTopK];
     __shared__ SelectSmem s_sel;
     __shared__ int s_n;
@@ -826,7 +837,7 @@ __global__ __launch_bounds__(kBqFinalBlock) void bq_finalize_kernel(
     const int tid = threadIdx.x;
     const int n_cand = cand_count[q * kBqCountStride];
     const int n_special = counters[0];
-    const bool served = qflags[q] == kBqFlagOk && n_cand <= kBqCap && n_special <= kBqSpecialCap;
+    const bool served = qflags[q] == kBqFlagOk && n_cand <= cand_cap && n_special <= kBqSpecialCap;
     if (!served) {   // uniform
         if (tid == 0) {
             queue[atomicAdd(&counters[1], 1)] = q;
@@ -842,25 +853,18 @@ __global__ __launch_bounds__(kBqFinalBlock) void bq_finalize_kernel(
     if (tid == 0) s_n = 0;
     __syncthreads();
     const int total = n_cand + n_special;
-    for (int i = tid; i < total; i += kBqFinalBlock) {
-        const uint32_t row = i < n_cand ? cand_rows[static_cast<int64_t>(q) * kBqCap + i] : special_rows[i - n_cand];
-        const Row rr = load_row(feats, static_cast<int64_t>(row));
-        const float s = cosine_score(qv, qn, rr);
-        const int64_t g = row_base + row;
-        if (g != excl) s_keys[atomicAdd(&s_n, 1)] = pack_key(s, static_cast<uint32_t>(g));
-    }
-    __syncthreads();
-    int c = s_n;
-    if (c > topk && c > kRankDirectMax) {   // uniform: cut to a little over topk in O(c), then rank
+    uint64_t floor_key = 0;   // uniform: keys at or below it cannot be among the best topk any more
+    int c = 0;
+    // cut the buffer to a little over topk in O(c) (not to EXACTLY topk: that takes the radix select through all its
+    // byte passes — most of this kernel's time — where a cut that may leave up to kRankDirectMax - topk keys more
+    // stops after two or three; the ranking below keeps the best topk of whatever is left)
+    auto cut = [&]() {
         uint64_t mine[kBqFinalPerThread];
 #pragma unroll
         for (int u = 0; u < kBqFinalPerThread; ++u) {
             const int i = tid + u * kBqFinalBlock;
             mine[u] = i < c ? s_keys[i] : 0ull;
         }
-        // (not to EXACTLY topk: that takes the radix select through all its byte passes — most of this kernel's time —
-        // where a cut that may leave up to kRankDirectMax - topk keys more stops after two or three; the ranking
-        // below keeps the best topk of whatever is left)
         const int slack = kRankDirectMax - topk > 0 ? kRankDirectMax - topk : 0;
         const uint64_t t = block_select_threshold<kBqFinalBlock, kBqFinalPerThread>(mine, topk, slack == 0, slack, s_sel);
         if (tid == 0) s_n = 0;
@@ -870,6 +874,24 @@ __global__ __launch_bounds__(kBqFinalBlock) void bq_finalize_kernel(
             if (mine[u] >= t) s_keys[atomicAdd(&s_n, 1)] = mine[u];
         __syncthreads();
         c = s_n;
+        if (t > floor_key + 1) floor_key = t - 1;   // (at least topk keys >= t are kept)
+    };
+    for (int base = 0; base < total; base += kBqFinalChunk) {   // uniform
+        const int end = base + kBqFinalChunk < total ? base + kBqFinalChunk : total;
+        for (int i = base + tid; i < end; i += kBqFinalBlock) {
+            const uint32_t row = i < n_cand ? cand_rows[static_cast<int64_t>(q) * cand_cap + i] : special_rows[i - n_cand];
+            const Row rr = load_row(feats, static_cast<int64_t>(row));
+            const float s = cosine_score(qv, qn, rr);
+            const int64_t g = row_base + row;
+            const uint64_t key = pack_key(s, static_cast<uint32_t>(g));
+            if (g != excl && key > floor_key) s_keys[atomicAdd(&s_n, 1)] = key;
+        }
+        __syncthreads();
+        c = s_n;
+        __syncthreads();   // (everybody has read the count before a cut resets it)
+        // a cut leaves at most max(topk, kRankDirectMax) keys (ties cannot inflate it: keys are unique), so the next chunk
+        // always fits; what the last one leaves is what the ranking below can take
+        if (c > topk && c > kRankDirectMax) cut();
     }
     block_rank_and_store<kBqFinalBlock>(s_keys, c, s_top, topk);
     __syncthreads();

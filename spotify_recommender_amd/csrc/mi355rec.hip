@@ -206,7 +206,8 @@ struct mi355rec {
         float* qthr = nullptr;
         uint32_t* qflags = nullptr;
         int* cand_count = nullptr;
-        uint32_t* cand_rows = nullptr;   // [1024][kBqCap]
+        uint32_t* cand_rows = nullptr;   // [1024][cand_cap]
+        int cand_cap = 0;                // candidate rows kept per query, also in counters[6] for the passes
         int* counters = nullptr;         // [4]
         uint32_t* special_rows = nullptr;
         float* gmax = nullptr;           // [grid][32][64]
@@ -1519,9 +1520,14 @@ int ensure_bq_alloc(mi355rec* h) {
     HIP_TRY(h, hipMalloc(&b.qflags, sizeof(uint32_t) * kBqMaxQueries));
     HIP_TRY(h, hipMalloc(&b.cand_count, sizeof(int) * kBqMaxQueries * kBqCountStride));
     HIP_TRY(h, hipMemsetAsync(b.cand_count, 0, sizeof(int) * kBqMaxQueries * kBqCountStride, h->stream));
-    HIP_TRY(h, hipMalloc(&b.cand_rows, sizeof(uint32_t) * static_cast<size_t>(kBqMaxQueries) * kBqCap));
-    HIP_TRY(h, hipMalloc(&b.counters, sizeof(int) * 8));   // [0..3]: batched.hip.h; [4]: the queued scan's arrival counter
+    // A query keeps about rows / 64 candidates at most (a power of two in [2048, 65536]): uniform rows need ~650 at 10 M,
+    // rows that cluster a whole cluster's worth (profiles/r04_clustered.jsonl); past it the query goes to the exact queue.
+    b.cand_cap = kBqCapMin;
+    while (b.cand_cap < kBqCapMax && static_cast<int64_t>(b.cand_cap) * 64 < h->n) b.cand_cap *= 2;
+    HIP_TRY(h, hipMalloc(&b.cand_rows, sizeof(uint32_t) * static_cast<size_t>(kBqMaxQueries) * b.cand_cap));
+    HIP_TRY(h, hipMalloc(&b.counters, sizeof(int) * 8));   // [0..3]: batched.hip.h; [4]: the queued scan's arrival counter; [6]: cand_cap
     HIP_TRY(h, hipMemsetAsync(b.counters, 0, sizeof(int) * 8, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(b.counters + 6, &b.cand_cap, sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMalloc(&b.special_rows, sizeof(uint32_t) * kBqSpecialCap));
     HIP_TRY(h, hipMalloc(&b.gmax, sizeof(float) * static_cast<size_t>(grid) * kBqMaxBlocks * 64));
     // Room for the tile maxima of pass 1 (rows from the replica only).  Optional: without it pass 2 looks at every
@@ -1649,7 +1655,7 @@ int enqueue_bq_chunk(mi355rec* h, const float* d_queries, const long long* d_exc
         default: launch_bq_passes<32>(h, d_queries, count, topn, s); break;
     }
     hipLaunchKernelGGL(bq_finalize_kernel, dim3(count), dim3(kBqFinalBlock), 0, s, h->d_feats, h->row_base, d_queries,
-                       d_exclude, count, topn, b.qflags, b.cand_count, b.cand_rows, b.counters, b.special_rows, b.queue,
+                       d_exclude, count, topn, b.qflags, b.cand_count, b.cand_rows, b.cand_cap, b.counters, b.special_rows, b.queue,
                        out_keys, out_idx, out_score);
     // The exact multi-query scan for whatever the bound could not be claimed for, its merge included (usually
     // nothing: the launch exits at once on an empty queue).

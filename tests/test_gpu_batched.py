@@ -119,6 +119,39 @@ def test_queries_the_bound_cannot_be_claimed_for(Engine):
             assert d["queued_queries"] == queued, (topn, d)
 
 
+@pytest.mark.parametrize("clusters,served", [(100, True), (3, False)])
+def test_clustered_catalogue_many_candidates_per_query(Engine, clusters, served):
+    """Rows in tight clusters (spread 0.01; what min-max normalised audio features look like far more than uniform noise
+    does): every row of a query's cluster passes the fp16 pre-filter.  100 clusters of ~13 000 rows: the per-query lists
+    (32 768 rows at this size) hold them and the finalize workgroup works through them in chunks — several cuts, the
+    floor of one cut filtering the next chunk; until the end of round 4 the cap was 2048 and all of these queries went
+    to the exact queue (43 ms per 1024 queries at 10 M rows instead of 0.8).  3 clusters: past any list, the exact queue."""
+    rng = np.random.default_rng(500 + clusters)
+    n = 1_300_003
+    centres = rng.random((clusters, 12), dtype=np.float32)
+    centres[:, 2] = rng.integers(0, 12, clusters).astype(np.float32) / np.float32(11)
+    centres[:, 4] = rng.integers(0, 2, clusters).astype(np.float32)
+    which = rng.integers(0, clusters, n)
+    noise = (rng.standard_normal((n, 12)) * 0.01).astype(np.float32)
+    noise[:, [2, 4]] = 0
+    f = np.clip(centres[which] + noise, 0, 1).astype(np.float32)
+    dup = rng.integers(0, n, n // 50)
+    f[dup] = f[rng.integers(0, n, n // 50)]            # exact duplicates: ties inside the lists
+    batch = 96
+    qrows = rng.integers(0, n, size=batch)
+    queries = f[qrows].copy()
+    excl = qrows.astype(np.int64)
+    with Engine(f) as eng:
+        mfma(eng)
+        for topn in (100, 10):
+            check_batch(eng, f, queries, excl, topn, f"{clusters} clusters", sample=range(0, batch, 7))
+            d = eng.batched_last_counters()
+            if served:
+                assert d["queued_queries"] == 0 and 2048 < d["candidates_max"] <= 32768, d
+            else:
+                assert d["queued_queries"] == batch, d
+
+
 def test_candidate_overflow_and_special_rows(Engine):
     """(a) every row identical: each query has 90 000 candidates at its threshold ->
     all queries overflow into the exact scan; (b) more special rows (tiny norms,

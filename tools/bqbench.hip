@@ -46,8 +46,8 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&feats, n * 12 * sizeof(float)));
     CK(hipMalloc(&queries, 1024 * 12 * sizeof(float)));
     CK(hipMalloc(&qnorm, 1024 * 4)); CK(hipMalloc(&qflags, 1024 * 4)); CK(hipMalloc(&cand_count, 1024 * 4 * kBqCountStride));
-    CK(hipMalloc(&bfrag, NB * 64 * 16)); CK(hipMalloc(&counters, 16)); CK(hipMalloc(&special, kBqSpecialCap * 4));
-    CK(hipMalloc(&cand_rows, (size_t)1024 * kBqCap * 4));
+    CK(hipMalloc(&bfrag, NB * 64 * 16)); CK(hipMalloc(&counters, 32)); { int cap = kBqCapMin; CK(hipMemset(counters, 0, 32)); CK(hipMemcpy(counters + 6, &cap, 4, hipMemcpyHostToDevice)); } CK(hipMalloc(&special, kBqSpecialCap * 4));
+    CK(hipMalloc(&cand_rows, (size_t)1024 * kBqCapMin * 4));
     const int grid = 256 * per_cu;
     CK(hipMalloc(&gmax, (size_t)grid * NB * 64 * 4));
     fill_kernel<<<4096, 256>>>(feats, n * 12, 1u);

@@ -23,6 +23,10 @@ def main():
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 multi-query passes, 2 batched MFMA, 5 batched MFMA without tile skipping")
     ap.add_argument("--lib", default=None, help="another build of the library (e.g. an MI355REC_EXPERIMENTS one under gpurun_out/)")
     ap.add_argument("--host-queries", action="store_true")
+    ap.add_argument("--catalogue", default="uniform", choices=["uniform", "clustered"])
+    ap.add_argument("--spread", type=float, default=0.03)
+    ap.add_argument("--clusters", type=int, default=3000)
+    ap.add_argument("--check", type=int, default=0, help="compare this many of the batch's queries with the single-query fp32 scan, key for key")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -32,7 +36,12 @@ def main():
     from spotify_recommender_amd import CosineEngine
     from spotify_recommender_amd.synth import synthetic_catalogue
 
-    t = synthetic_catalogue(args.rows, seed=12345)
+    if args.catalogue == "clustered":
+        sys.path.insert(0, str(Path(__file__).resolve().parent))
+        from catalogues import clustered_catalogue
+        t = clustered_catalogue(args.rows, args.spread, clusters=args.clusters)
+    else:
+        t = synthetic_catalogue(args.rows, seed=12345)
     rows = np.array([(k * 7919) % args.rows for k in range(args.batch)], dtype=np.int64)
     qd = t[torch.from_numpy(rows).cuda()].contiguous()
     ed = torch.from_numpy(rows).cuda()
@@ -63,6 +72,14 @@ def main():
         if args.path != 1:
             out.update(eng.batched_last_counters())
             out.update(eng.batched_pass2_pairs())
+        if args.check:
+            from spotify_recommender_amd import capi
+            eng.set_replica(capi.REPLICA_OFF)
+            ref = torch.zeros((args.check, args.topn), dtype=torch.int64, device="cuda")
+            for i in range(args.check):
+                eng.enqueue_row_keys(int(rows[i]), args.topn, ref[i])
+            torch.cuda.synchronize()
+            out["matches_single_query_fp32_scan"] = bool(torch.equal(ref, keys.view(args.batch, args.topn)[:args.check]))
         print(json.dumps(out), flush=True)
 
 

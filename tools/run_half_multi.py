@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--lib", default=None, help="another build of the library (e.g. an MI355REC_EXPERIMENTS one under gpurun_out/)")
     ap.add_argument("--sizes", default="1,2,4,8,12,16,24,32", help="batch sizes of the single calls ('' = none)")
     ap.add_argument("--streams", default="2,12,32", help="batch sizes of the streams ('' = none)")
+    ap.add_argument("--catalogue", default="uniform", choices=["uniform", "clustered"])
+    ap.add_argument("--spread", type=float, default=0.03)
+    ap.add_argument("--clusters", type=int, default=3000)
     args = ap.parse_args()
     if args.lib:
         from spotify_recommender_amd import capi as _capi
@@ -35,7 +38,12 @@ def main():
     from spotify_recommender_amd.synth import synthetic_catalogue
 
     n, topn = args.rows, args.topn
-    t = synthetic_catalogue(n, seed=12345)
+    if args.catalogue == "clustered":
+        sys.path.insert(0, str(Path(__file__).resolve().parent))
+        from catalogues import clustered_catalogue
+        t = clustered_catalogue(n, args.spread, clusters=args.clusters)
+    else:
+        t = synthetic_catalogue(n, seed=12345)
     rows = [(k * 7919) % n for k in range(64)]
     q = t[torch.tensor(rows, device="cuda")].cpu().numpy()
     out = {"rows": n, "topn": topn, "single_calls": [], "streams": []}
@@ -63,6 +71,17 @@ def main():
             out["single_calls"].append({"queries": nb, "us_per_call": round(dt * 1e6, 1), "queries_per_s": round(nb / dt),
                                         "pass_kernel_us": round(st.last_scan_ms * 1e3, 1), "merge_kernel_us": round(st.last_merge_ms * 1e3, 1),
                                         "rows_to_exact_chain_per_query": round((a["rescored_rows"] - b["rescored_rows"]) / args.calls / nb)})
+        if sizes:   # the largest single call once more, against the single-query scan over the fp32 rows
+            nb = max(sizes)
+            keys = torch.zeros(nb * topn, dtype=torch.int64, device="cuda")
+            eng.enqueue_batch_keys(q[:nb], np.array(rows[:nb], dtype=np.int64), topn, keys)
+            eng.set_replica(capi.REPLICA_OFF)
+            ref = torch.zeros((nb, topn), dtype=torch.int64, device="cuda")
+            for i in range(nb):
+                eng.enqueue_row_keys(rows[i], topn, ref[i])
+            torch.cuda.synchronize()
+            out["matches_single_query_fp32_scan"] = bool(torch.equal(ref, keys.view(nb, topn)))
+            eng.set_replica(capi.REPLICA_AUTO)
         for nb in (tuple(int(x) for x in args.streams.split(",") if x) if not args.only_stream else (args.only_stream,)):
             ring = [torch.zeros(nb * topn, dtype=torch.int64, device="cuda") for _ in range(4)]
             ex = np.array(rows[:nb], dtype=np.int64)
