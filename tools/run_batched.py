@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--host-queries", action="store_true")
     ap.add_argument("--catalogue", default="uniform", choices=["uniform", "clustered"])
     ap.add_argument("--spread", type=float, default=0.03)
+    ap.add_argument("--contiguous", action="store_true", help="clustered: a cluster's rows lie next to each other")
     ap.add_argument("--clusters", type=int, default=3000)
     ap.add_argument("--check", type=int, default=0, help="compare this many of the batch's queries with the single-query fp32 scan, key for key")
     args = ap.parse_args()
@@ -39,7 +40,7 @@ def main():
     if args.catalogue == "clustered":
         sys.path.insert(0, str(Path(__file__).resolve().parent))
         from catalogues import clustered_catalogue
-        t = clustered_catalogue(args.rows, args.spread, clusters=args.clusters)
+        t = clustered_catalogue(args.rows, args.spread, clusters=args.clusters, contiguous=args.contiguous)
     else:
         t = synthetic_catalogue(args.rows, seed=12345)
     rows = np.array([(k * 7919) % args.rows for k in range(args.batch)], dtype=np.int64)

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--streams", default="2,12,32", help="batch sizes of the streams ('' = none)")
     ap.add_argument("--catalogue", default="uniform", choices=["uniform", "clustered"])
     ap.add_argument("--spread", type=float, default=0.03)
+    ap.add_argument("--contiguous", action="store_true", help="clustered: a cluster's rows lie next to each other")
     ap.add_argument("--clusters", type=int, default=3000)
     args = ap.parse_args()
     if args.lib:
@@ -41,7 +42,7 @@ def main():
     if args.catalogue == "clustered":
         sys.path.insert(0, str(Path(__file__).resolve().parent))
         from catalogues import clustered_catalogue
-        t = clustered_catalogue(n, args.spread, clusters=args.clusters)
+        t = clustered_catalogue(n, args.spread, clusters=args.clusters, contiguous=args.contiguous)
     else:
         t = synthetic_catalogue(n, seed=12345)
     rows = [(k * 7919) % n for k in range(64)]

@@ -29,6 +29,7 @@ def main():
                     help="clustered: min-max normalised audio-feature look-alike (discrete key / mode / genre columns, a few thousand "
                          "tight clusters, exact duplicates) instead of uniform noise: what the replicas cannot rule out grows")
     ap.add_argument("--spread", type=float, default=0.03, help="clustered: standard deviation of a cluster")
+    ap.add_argument("--contiguous", action="store_true", help="clustered: a cluster's rows lie next to each other")
     ap.add_argument("--clusters", type=int, default=3000, help="clustered: number of clusters")
     args = ap.parse_args()
     if args.lib:
@@ -40,7 +41,7 @@ def main():
     from spotify_recommender_amd.synth import synthetic_catalogue
 
     if args.catalogue == "clustered":
-        t = clustered_catalogue(args.rows, args.spread, clusters=args.clusters)
+        t = clustered_catalogue(args.rows, args.spread, clusters=args.clusters, contiguous=args.contiguous)
     else:
         t = synthetic_catalogue(args.rows, seed=12345)
     rows = [(k * 7919 + 13) % args.rows for k in range(max(args.check, args.steps + 20, 200))]   # 200: the latency loop below
