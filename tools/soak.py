@@ -18,6 +18,10 @@ def main():
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--queries", type=int, default=6000)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--catalogue", default="uniform", choices=["uniform", "clustered"], help="clustered: tools/catalogues.py")
+    ap.add_argument("--spread", type=float, default=0.03)
+    ap.add_argument("--clusters", type=int, default=3000)
+    ap.add_argument("--contiguous", action="store_true")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -26,10 +30,17 @@ def main():
 
     n = args.rows
     rng = np.random.default_rng(args.seed)
-    t = synthetic_catalogue(n, seed=12345)
+    if args.catalogue == "clustered":
+        sys.path.insert(0, str(Path(__file__).resolve().parent))
+        from catalogues import clustered_catalogue
+        t = clustered_catalogue(n, args.spread, clusters=args.clusters, contiguous=args.contiguous)
+    else:
+        t = synthetic_catalogue(n, seed=12345)
     rows = rng.integers(0, n, size=args.queries)
     topns = rng.choice([1, 10, 100, 100, 100, 500, 1000], size=args.queries)
     out = {"rows": n, "queries": args.queries}
+    if args.catalogue == "clustered":
+        out.update({"catalogue": "clustered", "clusters": args.clusters, "spread": args.spread, "contiguous": args.contiguous})
     with CosineEngine(t) as eng:
         ref = []
         got = []
