@@ -103,6 +103,15 @@ typedef struct {
     int32_t device_bytes_per_row; /* what the handle keeps resident per row: 48 (fp32) + 24 (fp16 replica) + 12 (8-bit) */
 } mi355rec_stats_t;
 
+/* What this build of the library was compiled with.  The product build returns 0.  The tools/ scripts build
+ * instrumented copies under gpurun_out/ (never the product library): MI355REC_BUILD_EXPERIMENTS = environment knobs for
+ * A/B runs and the routes that only exist for A/B (single queries over the fp16 replica: MI355REC_REPLICA_FP16; the
+ * 8-bit front end of the multi-query pass: MI355REC_BATCH_Q8); MI355REC_BUILD_PHASE_CLOCK = per-workgroup phase stamps
+ * (csrc/experiments.hip.h). */
+#define MI355REC_BUILD_EXPERIMENTS 1
+#define MI355REC_BUILD_PHASE_CLOCK 2
+int mi355rec_build_flags(void);
+
 /* Number of visible HIP devices (0 when there is none / no driver). */
 int mi355rec_device_count(void);
 

@@ -21,6 +21,7 @@ TRANSPORT_PEER, TRANSPORT_RCCL = 1, 2
 PLACEMENT_AUTO, PLACEMENT_SHARDED, PLACEMENT_REPLICATED, PLACEMENT_CPU = 0, 1, 2, 3
 CREATE_NO_REPLICA = 1
 DEBUG_HANDOFF_POISON, DEBUG_HANDOFF_DROP_STORES, DEBUG_HANDOFF_NO_LAST_RIDER = 1, 2, 4
+BUILD_EXPERIMENTS, BUILD_PHASE_CLOCK = 1, 2
 
 OK = 0
 ERR_INVALID_ARG = -1
@@ -67,6 +68,7 @@ class Stats(ctypes.Structure):
 
 # name -> (restype, argtypes); mirrors include/mi355rec.h one to one
 SIGNATURES = {
+    "mi355rec_build_flags": (c_int, []),
     "mi355rec_device_count": (c_int, []),
     "mi355rec_last_global_error": (c_char_p, []),
     "mi355rec_create": (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, POINTER(c_void_p)]),
@@ -168,6 +170,11 @@ def lib() -> ctypes.CDLL:
             fn.argtypes = argtypes
         _lib = handle
     return _lib
+
+
+def has_experiments() -> bool:
+    """True when the loaded library is an MI355REC_EXPERIMENTS build (tools/: A/B routes and environment knobs)."""
+    return bool(lib().mi355rec_build_flags() & BUILD_EXPERIMENTS)
 
 
 class Mi355Error(RuntimeError):

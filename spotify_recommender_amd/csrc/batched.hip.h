@@ -162,11 +162,30 @@ __device__ __forceinline__ BqPrepared bq_prepare_query(const float* __restrict__
 }
 
 // (A launch of its own only for chunks whose pass 1 does not prepare the queries itself: see bq_pass_kernel.)
+// The first prep_blocks workgroups prepare the queries.  The launch may carry n_queries more: workgroup prep_blocks + q
+// then takes query q's NEIGHBOURHOOD bound (handoff.hip.h: the exact topk-th best score among the 2048 rows around the
+// row the query excludes — its own, for recommendByIndex, Recommender.cu:275-318) into nb_vals[q] (ordered-u32 image,
+// 0 = none).  bq_select_kernel takes it as one more lower bound on the query's threshold: pass 1's group maxima come
+// from every 4th tile dealt round-robin over the waves, and on a catalogue sorted by genre only a handful of its 2048
+// groups ever see the query's own cluster.
 __global__ __launch_bounds__(256) void bq_prepare_kernel(
     const float* __restrict__ queries, int n_queries, int n_blocks, uint32_t* __restrict__ bfrag,
     float* __restrict__ qnorm, uint32_t* __restrict__ qflags, int* __restrict__ cand_count,
     int* __restrict__ counters /* [0] special rows, [1] queued queries, [2] chunk-wide queue flag,
-                                  [3] (tile, query block) pairs pass 2 ran its MFMAs for (diagnostics) */) {
+                                  [3] (tile, query block) pairs pass 2 ran its MFMAs for (diagnostics) */,
+    int prep_blocks, const float* __restrict__ feats, int64_t n, int64_t row_base, const long long* __restrict__ exclude /* may be null */,
+    int topk, uint32_t* __restrict__ nb_vals /* [n_queries] */) {
+    if (static_cast<int>(blockIdx.x) >= prep_blocks) {   // uniform: a neighbourhood workgroup
+        __shared__ SelectSmem s_sel;
+        __shared__ int s_count;
+        const int nq = static_cast<int>(blockIdx.x) - prep_blocks;
+        float qv[kDim];
+#pragma unroll
+        for (int j = 0; j < kDim; ++j) qv[j] = queries[static_cast<int64_t>(nq) * kDim + j];
+        const uint32_t v = nbhd_bound<256>(feats, n, row_base, exclude ? exclude[nq] : -1ll, qv, query_norm(qv), topk, s_sel, &s_count);
+        if (threadIdx.x == 0) nb_vals[nq] = v;
+        return;
+    }
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q == 0) {
         counters[0] = 0;
@@ -741,7 +760,9 @@ constexpr int kBqSelectKeys = kBqMaxPassGrid * kBqGroupsPerBlock / 64;   // grou
 
 __global__ __launch_bounds__(kBqSelectBlock) void bq_select_kernel(
     const float* __restrict__ gmax, int grid_pass1, int n_blocks, int topk, float margin,
-    uint32_t* __restrict__ bfrag, uint32_t* __restrict__ qflags, float* __restrict__ qthr) {
+    uint32_t* __restrict__ bfrag, uint32_t* __restrict__ qflags, float* __restrict__ qthr,
+    const uint32_t* __restrict__ nb_vals /* per query: the neighbourhood's exact bound (bq_prepare_kernel), 0 = none; null: not taken */,
+    int n_queries) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bq_smem[];
     float* s_vals = reinterpret_cast<float*>(bq_smem);                        // [2 * grid][5]
     int* s_hist = reinterpret_cast<int*>(s_vals + static_cast<size_t>(grid_pass1) * 2 * 5);  // [4][256]
@@ -791,6 +812,11 @@ __global__ __launch_bounds__(kBqSelectBlock) void bq_select_kernel(
                 const float t = ordered_to_score(static_cast<uint32_t>(kth >> 32));
                 t_prime = t - 2.0f * margin - kBqSlack;
             }
+            if (nb_vals && q < n_queries) {   // wave-uniform: topk rows score at least this EXACTLY — one margin
+                const uint32_t nbv = nb_vals[q];
+                const float nb_t = nbv ? ordered_to_score(nbv) - margin - kBqSlack : 0.0f;
+                t_prime = nb_t > t_prime ? nb_t : t_prime;
+            }
             if (t_prime > 0.0f) {
                 thr_out = t_prime;
             } else {
@@ -823,7 +849,8 @@ __global__ __launch_bounds__(kBqFinalBlock) void bq_finalize_kernel(
     const uint32_t* __restrict__ qflags, const int* __restrict__ cand_count,
     const uint32_t* __restrict__ cand_rows, int cand_cap, int* __restrict__ counters,
     const uint32_t* __restrict__ special_rows, int* __restrict__ queue /* [n_queries] */,
-    uint64_t* __restrict__ out_keys, int64_t* __restrict__ out_idx, float* __restrict__ out_score) {
+    uint64_t* __restrict__ out_keys, int64_t* __restrict__ out_idx, float* __restrict__ out_score,
+    const uint32_t* __restrict__ nb_vals /* the neighbourhood bounds (bq_prepare_kernel), or null */) {
     // Until round 4's end a query kept at most 2048 candidates, all of them in this buffer at once — and a catalogue
     // whose rows CLUSTER (3000 clusters of 3300 rows, spread 0.03: profiles/r04_clustered.jsonl) sent 986 of 1024
     // queries to the exact queue, 43 ms per batch instead of 0.55.  Now the global list holds up to 65536 rows per query and the
@@ -854,6 +881,10 @@ __global__ __launch_bounds__(kBqFinalBlock) void bq_finalize_kernel(
     __syncthreads();
     const int total = n_cand + n_special;
     uint64_t floor_key = 0;   // uniform: keys at or below it cannot be among the best topk any more
+    if (nb_vals) {            // (at least topk rows score >= the neighbourhood's exact bound: a key AT it stays)
+        const uint32_t nbv = nb_vals[q];
+        if (nbv) floor_key = (static_cast<uint64_t>(nbv) << 32) - 1ull;
+    }
     int c = 0;
     // cut the buffer to a little over topk in O(c) (not to EXACTLY topk: that takes the radix select through all its
     // byte passes — most of this kernel's time — where a cut that may leave up to kRankDirectMax - topk keys more

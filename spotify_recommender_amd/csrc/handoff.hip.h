@@ -1,0 +1,361 @@
+// handoff.hip.h — the LAUNCH-WIDE BOUND of a query and how it travels between workgroups and launches.
+//
+// The reference scores every row for every query (Recommender.cu:184-254) and keeps the best topN on the host
+// (:293-315).  A row can be among them only if its score reaches the topN-th best score of the shard; every scan of
+// this engine therefore starts from a LOWER BOUND of that score, found before the scan by looking at a few rows:
+//
+//   * a spread SAMPLE: up to 256 evenly spaced regions, one value per 64-lane wave tile of each (the tile's best row),
+//     v = the topN-th largest of those <= 2048 values: topN distinct rows score >= v.  Taken over the rows the scan
+//     itself streams (fp32 rows: f32_sample_regions below; 8-bit replica: replica_q8.hip.h; fp16 replica, many queries
+//     at once on the matrix core: replica_multi.hip.h);
+//   * the query row's NEIGHBOURHOOD (nbhd_bound): the topN-th best EXACT score among the 2048 rows around the row the
+//     query excludes — for recommendByIndex (Recommender.cu:275-318) that is the query's own row.  A catalogue that
+//     is sorted by genre, artist or album keeps similar rows next to each other (DataManager.cpp:244-250,299: genre
+//     ids are handed out in order of first appearance and end up in features[11]); there an evenly spaced sample sees
+//     eight rows of the query's cluster, never a hundred, and its bound comes from OTHER clusters.  The neighbourhood
+//     is disjoint from nothing and needs to be: it is simply a SECOND lower bound, and the scan takes the larger.
+//
+// Both are bounds on EXACT scores of real rows, so a scan over the fp32 rows uses them as they are and a scan over a
+// replica subtracts its error bound once.  They only ever rule rows OUT; whatever a broken or missing bound lets
+// through is scored by the exact chain as always.
+//
+// HAND-OFFS THAT FAIL SAFE.  Values cross workgroups outside the stream order of launches in two places: the sample
+// values the "seed riders" of a launch leave for the rider that finishes last (same launch), and the bound that rider
+// leaves for the scanners of the next launch.  Both decide which rows a scan may skip, so a reader that picked up a
+// value of an EARLIER query (the buffers alternate) could place the bound above the true N-th score: a silently wrong
+// top-N.  Every such value therefore carries the EPOCH of the query it belongs to in its upper word, written with the
+// value by one 64-bit store; a reader that finds another epoch treats the value as absent — fewer sample values, or
+// no launch-wide bound at all, both of which only LOWER the bound (slower, never wrong).  Arrival counters count up
+// across launches and are never reset: the host tells each launch the count it starts from, so a missed or repeated
+// reset cannot make a rider believe it is the last one.  (tests/test_gpu_replica.py poisons the buffers and drops
+// stores through mi355rec_debug_handoff to check this.)
+#pragma once
+
+#include "core.hip.h"
+
+#pragma clang fp contract(off)
+
+namespace mi355 {
+
+constexpr int kHalfSeedBlock = 512;            // threads of a sampling workgroup
+constexpr int kHalfSeedWaves = kHalfSeedBlock / 64;
+constexpr int kHalfSeedMaxGrid = 256;          // sampled regions: <= 2048 sample values per query
+constexpr int kHalfSeedPerThread = 4;          // x 512 threads of a workgroup that selects from them
+constexpr int kNbhdRows = 2048;                // rows around the excluded row that give the neighbourhood's bound
+constexpr int kNbhdSlot = kHalfSeedMaxGrid * kHalfSeedWaves;   // where a single query's sample buffer keeps that bound ...
+constexpr int kSampleSlots = kNbhdSlot + 8;                    // ... so such a buffer holds this many tagged values
+
+__device__ __forceinline__ unsigned long long tag_value(uint32_t epoch, uint32_t v) {
+    return (static_cast<unsigned long long>(epoch) << 32) | v;
+}
+__device__ __forceinline__ uint32_t untag_value(unsigned long long t, uint32_t epoch) {   // 0 = absent
+    return static_cast<uint32_t>(t >> 32) == epoch ? static_cast<uint32_t>(t) : 0u;
+}
+// A float left under an epoch (a cutoff, a bound): -inf (nothing is ruled out) when the epoch is not the reader's.
+__device__ __forceinline__ float untag_cutoff(unsigned long long t, uint32_t epoch) {
+    return static_cast<uint32_t>(t >> 32) == epoch ? __uint_as_float(static_cast<uint32_t>(t)) : -__builtin_inff();
+}
+// Every wave's write-through stores have reached device scope before the workgroup counts itself out.  (A
+// workgroup-scope release fence does NOT wait for global stores on this target: the ISA showed
+// `s_waitcnt lgkmcnt(0); s_barrier` between the sc1 stores and the counter atomic.)
+__device__ __forceinline__ void wait_own_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+struct SeedCtl {
+    unsigned done;               // riders that have stored their sample, counted up across launches, never reset
+    unsigned pad;
+    unsigned long long cutoff;   // tag_value(epoch, bits of a float): what the last rider made of the sample for the next launch
+};
+
+// What a streamed launch carries for the NEXT query: after the scanners and the merger come next.n_wgs "seed riders"
+// that take its sample and, with next.nbhd, one more workgroup (the LAST of the grid) for its neighbourhood.  They are
+// resident from the start like everybody else — the host launches that many scanners fewer.
+struct NextSeed {
+    float q[kDim];             // the next query (used when query_ptr is null)
+    const float* query_ptr;    // ... or where its 12 floats live (a resident row, possibly of another shard)
+    long long exclude_global;
+    void* out;                 // its sample buffer: kSampleSlots epoch-tagged unsigned long long (fp16 single-query scan of
+                               // experiment builds: plain uint32_t[], read by the NEXT launch only)
+    int n_wgs;                 // seed riders in this launch (0 = none)
+    int regions;
+    long long stride_rows;
+    // the rider that finishes LAST turns the sample into the next launch's bound, so that launch starts scanning at
+    // once instead of selecting in every workgroup
+    SeedCtl* ctl;
+    int topk;                  // of the next query
+    int exact;                 // 8-bit replica: sample values are exact scores of the waves' best rows (one margin) or approximate ones (two)
+    uint32_t epoch;            // of the next query: the tag of its sample values and of its bound
+    uint32_t done_base;        // ctl->done before this launch's riders arrive
+    int debug_skip;            // test hook (0 in the product): the riders do NOT store regions below this one
+    int nbhd;                  // 1: the grid's last workgroup computes the next query's neighbourhood bound into out[kNbhdSlot]
+};
+
+// ---- the neighbourhood of the excluded row ------------------------------------------------------------------
+// Called by ALL kThreads threads of a workgroup (barriers inside).  Scores the kNbhdRows rows around local row
+// (exclude_global - row_base) with the exact chain and returns the ordered-u32 image of a score v such that at least
+// `topk` of them — the excluded row left out — score >= v; 0 when the excluded row is not a row of this shard or the
+// neighbourhood holds fewer than topk rows.
+template <int kThreads>
+__device__ inline uint32_t nbhd_bound(const float* __restrict__ feats, int64_t n, int64_t row_base, int64_t exclude_global,
+                                      const float (&q)[kDim], float qn, int topk, SelectSmem& sel, int* s_count) {
+    static_assert(kNbhdRows % kThreads == 0, "whole rows per thread");
+    constexpr int kPer = kNbhdRows / kThreads;
+    const int tid = threadIdx.x;
+    const int64_t center = exclude_global - row_base;
+    if (center < 0 || center >= n || topk < 1) return 0u;   // uniform
+    int64_t lo = center - kNbhdRows / 2;
+    if (lo > n - kNbhdRows) lo = n - kNbhdRows;
+    if (lo < 0) lo = 0;
+    Row rows[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int64_t r = lo + u * kThreads + tid;
+        rows[u] = load_row(feats, r < n ? r : n - 1);
+    }
+    uint64_t keys[kPer];
+    int have = 0;
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int64_t r = lo + u * kThreads + tid;
+        const float s = cosine_score(q, qn, rows[u]);
+        const bool use = r < n && r != center;
+        // unique keys: the score's image in the high word, the position in the low word
+        keys[u] = use ? (static_cast<uint64_t>(score_to_ordered(s)) << 32) | static_cast<uint32_t>(u * kThreads + tid + 1) : 0ull;
+        have += use ? 1 : 0;
+    }
+    if (tid == 0) *s_count = 0;
+    __syncthreads();
+    {   // one LDS atomic per wave
+        const int wave_have = __builtin_amdgcn_readlane(wave_inclusive_scan(have), 63);
+        if ((tid & 63) == 0 && wave_have) atomicAdd(s_count, wave_have);
+    }
+    __syncthreads();
+    if (*s_count < topk) return 0u;   // uniform
+    // any T with at least topk keys at or above it is a valid bound: stop the radix select a few keys early
+    const uint64_t t = block_select_threshold<kThreads, kPer>(keys, topk, false, topk / 8 + 2, sel);
+    return static_cast<uint32_t>(t >> 32);
+}
+
+// The neighbourhood workgroup of a sample launch or of a streamed launch's riders: the bound goes, under the query's
+// epoch, to slot kNbhdSlot of the query's sample buffer — read by the NEXT launch on the stream (plain store: a
+// kernel boundary lies between).  Always stores, so that a slot never keeps an older query's value under a live epoch.
+template <int kThreads>
+__device__ inline void nbhd_to_slot(const float* __restrict__ feats, int64_t n, int64_t row_base, const float* query_ptr,
+                                    const float (&by_value)[kDim], int64_t exclude_global, int topk, uint32_t epoch,
+                                    unsigned long long* __restrict__ sample_buf, SelectSmem& sel, int* s_count) {
+    float q[kDim];
+    if (query_ptr) {
+#pragma unroll
+        for (int j = 0; j < kDim; ++j) q[j] = query_ptr[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < kDim; ++j) q[j] = by_value[j];
+    }
+    const uint32_t v = nbhd_bound<kThreads>(feats, n, row_base, exclude_global, q, query_norm(q), topk, sel, s_count);
+    if (threadIdx.x == 0) sample_buf[kNbhdSlot] = tag_value(epoch, v);
+}
+
+// ---- selecting from <= 2048 sample values ----------------------------------------------------------------------
+struct Sample {
+    uint32_t v[kHalfSeedPerThread];   // this thread's share of the sample values (ordered-u32 images; 0 = empty)
+};
+// (request and use are two calls: a scan asks for its sample FIRST — before its first tile: loads complete in order,
+// and behind the tile the sample of a 1 M-row shard was not usable before the tile was, 3 us later — and looks at it
+// after the query)
+struct SampleRaw {
+    unsigned long long t[kHalfSeedPerThread];
+};
+template <int kBlock, bool kSameLaunch = false>
+__device__ __forceinline__ SampleRaw sample_request(const unsigned long long* seed_vals, int n_seed) {
+    SampleRaw raw;
+#pragma unroll
+    for (int r = 0; r < kHalfSeedPerThread; ++r) {
+        const int i = static_cast<int>(threadIdx.x) + r * kBlock;
+        raw.t[r] = 0ull;
+        if (i < n_seed)   // kSameLaunch: written by other workgroups of THIS launch
+            raw.t[r] = kSameLaunch ? __hip_atomic_load(&seed_vals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : seed_vals[i];
+    }
+    return raw;
+}
+// Values under another epoch than the reader's count as absent.
+__device__ __forceinline__ Sample sample_finish(const SampleRaw& raw, uint32_t epoch) {
+    Sample s;
+#pragma unroll
+    for (int r = 0; r < kHalfSeedPerThread; ++r) s.v[r] = untag_value(raw.t[r], epoch);
+    return s;
+}
+template <int kBlock, bool kSameLaunch = false>
+__device__ __forceinline__ Sample sample_load(const unsigned long long* seed_vals, int n_seed, uint32_t epoch) {
+    return sample_finish(sample_request<kBlock, kSameLaunch>(seed_vals, n_seed), epoch);
+}
+
+// "Any v with at least topk sample values >= v", as high as is cheap to find — not a k-th order statistic to the last
+// bit.  So ONE histogram pass instead of a radix select: the values are binned linearly over [max - kSelSpan, max]
+// (1024 bins of 2.4e-4: a fiftieth of the smallest margin a replica scan then subtracts), the bins are summed from the
+// top, and v is the lower edge of the bin in which the count reaches topk.  Four barriers in all against two per byte
+// pass of the radix select over the 64-bit (value, index) keys (measured: 3.4 us of every workgroup's prologue
+// wherever the bound is not handed over by the launch before — shards below ~4 M rows and every query alone).  A
+// sample whose topk-th value lies more than kSelSpan below its maximum lands in the last bin and takes the radix
+// select as before.  Returns -inf when the sample holds fewer than topk values.  Called by all kBlock threads.
+constexpr int kSelBins = 1024;
+constexpr float kSelSpan = 0.25f;
+constexpr int kSelScratch = kSelBins + 16;   // ints of LDS scratch the selection needs (bins, block max, wave totals, result)
+
+template <int kBlock>
+__device__ __forceinline__ float sample_kth_value(const Sample& sample, int n_seed, int topk, int* s_seeds /* zeroed */,
+                                                  SelectSmem& s_sel, int* s_bins /* kSelScratch ints nobody else is using */) {
+    static_assert(kSelBins % kBlock == 0, "whole bins per thread");
+    constexpr int kPer = kSelBins / kBlock;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    float v = -__builtin_inff();
+    if (n_seed <= 0) return v;   // uniform
+    uint32_t vmax = 0u;
+    int have = 0;
+#pragma unroll
+    for (int r = 0; r < kHalfSeedPerThread; ++r) {
+        vmax = sample.v[r] > vmax ? sample.v[r] : vmax;
+        have += sample.v[r] != 0u;
+    }
+    for (int i = tid; i < kSelScratch; i += kBlock) s_bins[i] = 0;
+    vmax = wave_max_u32(vmax);
+    __syncthreads();   // the scratch is zero
+    if (lane == 0 && vmax) atomicMax(reinterpret_cast<unsigned int*>(&s_bins[kSelBins]), vmax);
+    // ONE count per wave: 512 threads adding to the one LDS word were 2 us of serialised atomics — most of what this
+    // selection cost (the phase clock had the sample values back 1.4 us after the workgroup's entry and the cutoff
+    // only at 5.0 us)
+    const int wave_have = __builtin_amdgcn_readlane(wave_inclusive_scan(have), 63);
+    if (lane == 0 && wave_have) atomicAdd(s_seeds, wave_have);
+    __syncthreads();
+    if (*s_seeds < topk) return v;   // uniform
+    const float smax = ordered_to_score(static_cast<uint32_t>(s_bins[kSelBins]));
+#pragma unroll
+    for (int r = 0; r < kHalfSeedPerThread; ++r) {
+        if (sample.v[r]) {
+            const float d = (smax - ordered_to_score(sample.v[r])) * (static_cast<float>(kSelBins) / kSelSpan);
+            int bin = static_cast<int>(d);
+            bin = (d >= 0.0f && bin < kSelBins - 1) ? bin : (d >= 0.0f ? kSelBins - 1 : 0);   // (NaN: the last bin)
+            if (!(d == d)) bin = kSelBins - 1;
+            atomicAdd(&s_bins[bin], 1);
+        }
+    }
+    __syncthreads();
+    // thread t owns bins [t * kPer, (t + 1) * kPer): bin 0 holds the largest values
+    int mine_bins[kPer];
+    int c = 0;
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        mine_bins[u] = s_bins[tid * kPer + u];
+        c += mine_bins[u];
+    }
+    int incl = wave_inclusive_scan(c);
+    if (lane == 63) s_bins[kSelBins + 1 + wave] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += s_bins[kSelBins + 1 + w];   // (<= 7 reads, wave-uniform)
+    incl += before;
+    int run = incl - c;
+    if (run < topk && incl >= topk) {   // exactly one thread: the count reaches topk inside its bins
+        int bin = tid * kPer;
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            if (run < topk) bin = tid * kPer + u;
+            run += mine_bins[u];
+        }
+        s_bins[kSelBins + 12] = bin + 1;
+    }
+    __syncthreads();
+    const int found = s_bins[kSelBins + 12] - 1;
+    if (found >= 0 && found < kSelBins - 1) {   // uniform
+        // every value of bins 0 .. found is >= this edge (2e-6: the rounding of the bin arithmetic)
+        v = smax - static_cast<float>(found + 1) * (kSelSpan / static_cast<float>(kSelBins)) - 2.0e-6f;
+    } else {   // the topk-th value lies far below the maximum (or the values are not what they should be): exact
+        uint64_t keys[kHalfSeedPerThread];
+#pragma unroll
+        for (int r = 0; r < kHalfSeedPerThread; ++r) {
+            const int i = tid + r * kBlock;
+            keys[r] = sample.v[r] ? (static_cast<uint64_t>(sample.v[r]) << 32) | static_cast<uint32_t>(i + 1) : 0ull;
+        }
+        const uint64_t t = block_select_threshold<kBlock, kHalfSeedPerThread>(keys, topk, false, topk / 8 + 2, s_sel);
+        v = ordered_to_score(static_cast<uint32_t>(t >> 32));
+    }
+    return v;
+}
+
+// The end of a seed rider (or of a workgroup of a sample launch) whose launch also SELECTS: it arrives, and the one
+// that finds itself last loads the whole sample past its L2 and selects.  No device-wide fence: on this part a release
+// / acquire pair at agent scope writes back and invalidates the whole L2 under the scanners (measured: the launch took
+// 43 us instead of 28).  Instead the values are stored and loaded as device-scope atomics (write-through stores,
+// L2-bypassing loads); each wave waits for ITS stores to complete (s_waitcnt vmcnt(0): a workgroup-scope fence does
+// not), one thread counts, and the last workgroup's loads are issued after its counter value came back.
+// Returns true in the last workgroup, with `v` = the sample's topk-th value (-inf: the sample cannot say).
+// Called by all kBlock threads; s_flag / s_seeds are LDS ints, s_bins kSelScratch ints of LDS scratch.
+template <int kBlock>
+__device__ __forceinline__ bool sample_arrive_and_select(SeedCtl* ctl, unsigned done_base, unsigned n_arrivals,
+                                                         const unsigned long long* seed_vals, int n_seed, int topk, uint32_t epoch,
+                                                         int* s_flag, int* s_seeds, SelectSmem& s_sel, int* s_bins, float& v) {
+    wait_own_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *s_seeds = 0;
+        *s_flag = __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == done_base + n_arrivals;
+    }
+    __syncthreads();
+    if (!*s_flag) return false;   // uniform
+    const Sample all = sample_load<kBlock, true>(seed_vals, n_seed, epoch);
+    v = sample_kth_value<kBlock>(all, n_seed, topk, s_seeds, s_sel, s_bins);
+    return true;
+}
+
+// ---- the sample over the fp32 rows ---------------------------------------------------------------------------------
+// A REGION is kHalfSeedBlock rows from row g * stride_rows on (stride_rows >= kHalfSeedBlock: no row is in two regions),
+// one row per lane: every wave leaves the best EXACT score of its 64 rows (the excluded row left out) at
+// out[g * 8 + wave], under the query's epoch, written through to device scope (the last rider of the same launch
+// reads it).  Rider `rider` of `next.n_wgs` takes regions rider, rider + n_wgs, ...; four regions per memory round
+// trip.  Called by all kHalfSeedBlock threads.
+__device__ __forceinline__ void f32_sample_regions(const float* __restrict__ feats, int64_t n, int64_t row_base, const NextSeed& next,
+                                                   int rider) {
+    constexpr int kAhead = 4;
+    const int tid = threadIdx.x;
+    unsigned long long* const out = static_cast<unsigned long long*>(next.out);
+    Row rows[kAhead];
+    auto load_round = [&](int g0) {
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const int g = g0 + u * next.n_wgs;
+            const int64_t r = static_cast<int64_t>(g < next.regions ? g : rider) * next.stride_rows + tid;
+            rows[u] = load_row(feats, r < n ? r : n - 1);
+        }
+    };
+    if (rider < next.regions) load_round(rider);   // (before the query: its 12 floats sit behind two dependent scalar loads)
+    float q[kDim];
+    if (next.query_ptr) {
+#pragma unroll
+        for (int j = 0; j < kDim; ++j) q[j] = next.query_ptr[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < kDim; ++j) q[j] = next.q[j];
+    }
+    const float qn = query_norm(q);
+    for (int g0 = rider; g0 < next.regions; g0 += kAhead * next.n_wgs) {
+        uint32_t v[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const int g = g0 + u * next.n_wgs;
+            const int64_t r = static_cast<int64_t>(g < next.regions ? g : rider) * next.stride_rows + tid;
+            const float s = cosine_score(q, qn, rows[u]);
+            const bool use = r < n && row_base + r != next.exclude_global;
+            v[u] = wave_max_u32(use ? score_to_ordered(s) : 0u);
+        }
+        if (g0 + kAhead * next.n_wgs < next.regions) load_round(g0 + kAhead * next.n_wgs);   // uniform
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const int g = g0 + u * next.n_wgs;
+            if (g < next.regions && g >= next.debug_skip && (tid & 63) == 0)
+                __hip_atomic_store(&out[g * kHalfSeedWaves + (tid >> 6)], tag_value(next.epoch, v[u]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+}  // namespace mi355

@@ -1,4 +1,4 @@
-// kernels.hip.h — device code of the MI355X cosine top-N engine (gfx950 only).
+// kernels.hip.h — the streaming scans over the fp32 rows (gfx950 only).
 //
 // One streaming pass over the row-major N x 12 fp32 catalogue replaces the
 // reference's three device passes + host heap:
@@ -6,779 +6,16 @@
 //   computeNormsKernel     Recommender.cu:48-59     (row norms, 2nd matrix read)
 //   normalizeSimilarities  Recommender.cu:62-77     (divide / threshold / clamp)
 //   host heap top-N        Recommender.cu:293-315
-// Arithmetic follows the reference's CPU path bit for bit
-// (calculateSimilaritiesCPU, Recommender.cu:256-273): sequential j = 0..11,
-// multiply and add rounded separately (contraction is OFF for this file),
-// correctly rounded sqrtf and '/', threshold 1e-8f, std::min/std::max clamp.
+// Arithmetic: core.hip.h (the reference's CPU path, Recommender.cu:256-273, bit for bit).
 #pragma once
 
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-#include <type_traits>
+#include "core.hip.h"
+#include "merge.hip.h"
+#include "handoff.hip.h"
 
 #pragma clang fp contract(off)
 
 namespace mi355 {
-
-#ifdef MI355REC_PHASE_CLOCK   // tools/ builds only (tools/phase_clock.sh): 100 MHz wall-clock stamps, [workgroup][phase]
-__device__ unsigned long long g_phase_clock[1024 * 8];
-// the phases of ONE merge (merge_body in the workgroup with blockIdx.x == 0: merge_notify_kernel), kept in row 1023
-#define MI355REC_MPHASE(i)                                                                       \
-    do {                                                                                         \
-        if (threadIdx.x == 0 && blockIdx.x == 0) g_phase_clock[1023 * 8 + (i)] = wall_clock64(); \
-    } while (0)
-// the phases of every workgroup of the fp32 scan (row = blockIdx.x, as the 8-bit scan's MI355REC_PHASE)
-#define MI355REC_KPHASE(i)                                                                  \
-    do {                                                                                    \
-        if (threadIdx.x == 0 && blockIdx.x < 1023) g_phase_clock[blockIdx.x * 8 + (i)] = wall_clock64(); \
-    } while (0)
-#else
-#define MI355REC_MPHASE(i) \
-    do {                   \
-    } while (0)
-#define MI355REC_KPHASE(i) \
-    do {                   \
-    } while (0)
-#endif
-
-constexpr int kDim = 12;              // Song.h:12
-constexpr int kMaxTopK = 1024;        // MI355REC_MAX_TOPN_FAST
-constexpr int kCandLimit = 2 * kMaxTopK;  // a tile is never entered with more candidates
-
-// Geometry of the streaming scan: threads per workgroup, rows in flight per lane
-// per tile, and the minimum waves per SIMD the register allocator must leave
-// room for (__launch_bounds__'s second argument).
-template <int kBlockT, int kRowsT, int kMinWavesT, int kDepthT = 2>
-struct ScanCfg {
-    static constexpr int kBlock = kBlockT;
-    static constexpr int kRowsPerThread = kRowsT;
-    static constexpr int kMinWaves = kMinWavesT;
-    static constexpr int kDepth = kDepthT;   // tiles in flight per lane (register ring)
-    static constexpr int kTileRows = kBlockT * kRowsT;
-    static constexpr int kCandCap = kCandLimit + kTileRows;  // LDS candidate slots
-    static constexpr int kCandPerThread = (kCandCap + kBlockT - 1) / kBlockT;
-};
-using DefaultScanCfg = ScanCfg<512, 1, 6>;
-constexpr int kProbeBlock = 512;      // stream_probe_kernel
-constexpr int kMergeBlock = 1024;
-constexpr int kMergeMaxLists = 2048;
-constexpr int kMergeSurvCap = 4096;
-constexpr int kMergeChunk = 16;       // keys probed per list per deeper merge round
-constexpr int kMergeFirst = 4;        // keys of every list loaded up front (many-lists case)
-constexpr int kMergeFirstPerThread = 8;  // covers kMergeMaxLists * kMergeFirst keys
-constexpr int kMergeSurvPerThread = kMergeSurvCap / kMergeBlock;
-constexpr int kMergeHeadsPerThread = kMergeMaxLists / kMergeBlock;
-
-
-struct QueryArg {
-    float q[kDim];
-    float margin;   // error bound of the fp16 pre-filter the launch may claim (replica scans only; set by the host)
-};
-
-// ---- packed keys -----------------------------------------------------------
-
-__host__ __device__ inline uint32_t score_to_ordered(float s) {
-    s = s + 0.0f;  // -0.0f -> +0.0f: float-equal scores get equal images
-    union { float f; uint32_t u; } c;
-    c.f = s;
-    return (c.u & 0x80000000u) ? ~c.u : (c.u | 0x80000000u);
-}
-
-__host__ __device__ inline float ordered_to_score(uint32_t o) {
-    union { float f; uint32_t u; } c;
-    c.u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
-    return c.f;
-}
-
-__host__ __device__ inline uint64_t pack_key(float s, uint32_t global_row) {
-    return (static_cast<uint64_t>(score_to_ordered(s)) << 32) |
-           static_cast<uint64_t>(~global_row);
-}
-
-// ---- the score of one row ----------------------------------------------------
-
-struct Row {
-    float4 a, b, c;
-};
-
-__device__ __forceinline__ float query_norm(const float (&q)[kDim]) {
-    float qn = 0.0f;  // Recommender.cu:259-261
-#pragma unroll
-    for (int j = 0; j < kDim; ++j) qn = qn + q[j] * q[j];
-    return sqrtf(qn);
-}
-
-__device__ __forceinline__ float cosine_score(const float (&q)[kDim], float qn,
-                                              const Row& r) {
-    const float f[kDim] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y,
-                           r.b.z, r.b.w, r.c.x, r.c.y, r.c.z, r.c.w};
-    float dot = 0.0f;  // Recommender.cu:264-269
-    float nrm = 0.0f;
-#pragma unroll
-    for (int j = 0; j < kDim; ++j) {
-        dot = dot + q[j] * f[j];
-        nrm = nrm + f[j] * f[j];
-    }
-    const float den = sqrtf(nrm) * qn;  // :270
-    float s = 0.0f;
-    if (den > 1e-8f) {                  // :271
-        const float t = dot / den;
-        const float m = (t < 1.0f) ? t : 1.0f;   // std::min(1.0f, t)
-        s = (-1.0f < m) ? m : -1.0f;             // std::max(-1.0f, m)
-    }
-    return s;
-}
-
-// Cheap UPPER-BOUND test used only to skip rows that cannot beat the running
-// threshold: the cosine evaluated with packed FMAs (even/odd partial sums) and
-// v_rsq_f32.  Against the exactly rounded reference chain its error is
-// <= ~2e-6 (12-term fp32 accumulation in a different order + 1-ulp rsq + two
-// multiplies), so a row is skipped only when approx < threshold_score -
-// kApproxMargin; everything else (NaN included) is re-scored with
-// cosine_score().  Only used while the threshold score is > 0, where the
-// reference's "den <= 1e-8 -> 0" rows can never qualify.
-// The bound only holds while no fp32 sum overflows: in a different summation
-// order an overflow can appear in one chain and not in the other (e.g. q =
-// (1e19,1e19,1e19,0..), f = (3e19,3e19,-3e19,0..): the reference's sequential
-// chain gives inf/inf = NaN -> clamped to 1.0, the paired chain a finite 0).
-// So the pre-filter is trusted only for |row|^2 < kApproxMaxNorm2 (checked per
-// row: anything else is re-scored exactly) and |q| < kApproxMaxQueryNorm
-// (checked once per query: otherwise the pre-filter stays off); then
-// |partial sums| <= |row||q| < 1e37 in every order.
-constexpr float kApproxMargin = 8e-6f;
-constexpr float kApproxMaxNorm2 = 1e37f;
-constexpr float kApproxMaxQueryNorm = 3e18f;
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float approx_cosine(const float (&q)[kDim], float inv_qn, const Row& r) {
-    const float f[kDim] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y,
-                           r.b.z, r.b.w, r.c.x, r.c.y, r.c.z, r.c.w};
-    v2f d = {0.0f, 0.0f};
-    v2f m = {0.0f, 0.0f};
-#pragma unroll
-    for (int p = 0; p < kDim / 2; ++p) {
-        const v2f ff = {f[2 * p], f[2 * p + 1]};
-        const v2f qq = {q[2 * p], q[2 * p + 1]};
-        d = __builtin_elementwise_fma(ff, qq, d);
-        m = __builtin_elementwise_fma(ff, ff, m);
-    }
-    const float nrm2 = m.x + m.y;
-    const float a = (d.x + d.y) * __builtin_amdgcn_rsqf(nrm2) * inv_qn;
-    return nrm2 < kApproxMaxNorm2 ? a : __builtin_nanf("");  // NaN = "cannot tell": the caller re-scores exactly
-}
-
-__device__ __forceinline__ Row load_row(const float* __restrict__ feats, int64_t row) {
-    const float4* p = reinterpret_cast<const float4*>(feats + row * kDim);
-    Row r;
-    r.a = p[0];
-    r.b = p[1];
-    r.c = p[2];
-    return r;
-}
-
-// Number of set bits of `mask` below this lane: v_mbcnt_lo + v_mbcnt_hi, no 64-bit
-// (1 << lane) - 1 mask to keep in two VGPRs across the streaming loop.
-__device__ __forceinline__ int lanes_below(uint64_t mask) {
-    return static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
-                                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u)));
-}
-
-// ---- workgroup-level selection ------------------------------------------------
-// Ranking c candidates by counting costs ~c*c/32 LDS cycles (85 us at c = 2560),
-// so thresholds come from an O(c) MSB-first radix select on LDS histograms and
-// only the final <= topk survivors are ever ranked.
-
-struct SelectSmem {
-    int hist[256];
-    unsigned int hi_max;
-    unsigned int hi_min;
-    int digit;
-    int above;
-    int in_bin;
-    int pad;
-};
-
-// Inclusive prefix sum across the 64 lanes of a wave in DPP (no LDS traffic):
-// four row_shr steps scan each row of 16 lanes, row_bcast:15 / row_bcast:31
-// carry the row totals forward.
-__device__ __forceinline__ int wave_inclusive_scan(int x) {
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);  // row_shr:1
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);  // row_shr:2
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);  // row_shr:4
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);  // row_shr:8
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1,3
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2,3
-    return x;
-}
-
-// Wave-wide max / min of a 32-bit value in DPP; the result is returned in every lane.
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
-    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
-    x = mx(x, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x111, 0xf, 0xf, true)));
-    x = mx(x, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x112, 0xf, 0xf, true)));
-    x = mx(x, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x114, 0xf, 0xf, true)));
-    x = mx(x, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x118, 0xf, 0xf, true)));
-    x = mx(x, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x142, 0xa, 0xf, false)));
-    x = mx(x, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x143, 0xc, 0xf, false)));
-    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(x), 63));
-}
-
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) { return ~wave_max_u32(~x); }
-
-// Every thread of the workgroup calls this with its share of the keys in
-// registers (0 = empty slot; keys are unique).  Precondition: at least `need`
-// non-empty keys in total, need >= 1.  Returns T with |{key >= T}| >= need;
-// with `exact` the count is exactly `need`, otherwise up to `slack` extra keys
-// may remain (fewer passes).  Digits are taken relative to the smallest key so
-// the first pass already separates the candidates.  Two barriers per pass:
-// wave 0 scans the 256 bins (lane l owns bins 255-4l .. 252-4l, so a prefix
-// scan over lanes is a suffix scan over bins) and clears them for the next pass.
-template <int kThreads, int kPerThread>
-__device__ inline uint64_t block_select_threshold(const uint64_t (&mine)[kPerThread], int need,
-                                                  bool exact, int slack, SelectSmem& sm) {
-    static_assert(kThreads >= 256, "histogram is cleared by the first 256 threads");
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-
-    // range of the score halves (32-bit, one LDS atomic per wave); the digits
-    // below are relative to base = smallest score << 32
-    uint32_t mx = 0, mn = ~0u;
-#pragma unroll
-    for (int r = 0; r < kPerThread; ++r) {
-        if (mine[r]) {
-            const uint32_t hi = static_cast<uint32_t>(mine[r] >> 32);
-            mx = hi > mx ? hi : mx;
-            mn = hi < mn ? hi : mn;
-        }
-    }
-    mx = wave_max_u32(mx);
-    mn = wave_min_u32(mn);
-    if (tid < 256) sm.hist[tid] = 0;
-    if (tid == 0) {
-        sm.hi_max = 0u;
-        sm.hi_min = ~0u;
-    }
-    __syncthreads();
-    if (lane == 0) {
-        atomicMax(&sm.hi_max, mx);
-        atomicMin(&sm.hi_min, mn);
-    }
-    __syncthreads();
-    const uint64_t base = static_cast<uint64_t>(sm.hi_min) << 32;
-    const uint64_t span = (static_cast<uint64_t>(sm.hi_max - sm.hi_min) << 32) | 0xffffffffull;
-    int shift = span ? (64 - __clzll(static_cast<long long>(span))) - 8 : 0;
-    if (shift < 0) shift = 0;
-    uint64_t prefix = 0, mask = 0;
-
-    for (;;) {
-#pragma unroll
-        for (int r = 0; r < kPerThread; ++r) {
-            const uint64_t k = mine[r];
-            if (k) {
-                const uint64_t v = k - base;
-                if ((v & mask) == prefix) atomicAdd(&sm.hist[static_cast<int>((v >> shift) & 255u)], 1);
-            }
-        }
-        __syncthreads();
-        if (tid < 64) {
-            const int top = 255 - 4 * lane;  // this lane's highest bin
-            const int h0 = sm.hist[top], h1 = sm.hist[top - 1], h2 = sm.hist[top - 2], h3 = sm.hist[top - 3];
-            sm.hist[top] = 0; sm.hist[top - 1] = 0; sm.hist[top - 2] = 0; sm.hist[top - 3] = 0;
-            const int lane_sum = h0 + h1 + h2 + h3;
-            int cum = wave_inclusive_scan(lane_sum) - lane_sum;  // keys in bins above this lane's
-            const int hs[4] = {h0, h1, h2, h3};
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                if (cum < need && cum + hs[b] >= need) {
-                    sm.digit = top - b;
-                    sm.above = cum;
-                    sm.in_bin = hs[b];
-                }
-                cum += hs[b];
-            }
-        }
-        __syncthreads();
-        const int digit = sm.digit, above = sm.above, in_bin = sm.in_bin;
-        prefix |= static_cast<uint64_t>(digit) << shift;
-        mask |= 255ull << shift;
-        need -= above;
-        if (shift == 0 || in_bin == need || (!exact && in_bin - need <= slack)) break;
-        shift = shift > 8 ? shift - 8 : 0;
-    }
-    return base + prefix;
-}
-
-// Writes the best min(c, topk) of the `c` unique keys in s_keys to dst in descending
-// order, zero-filling up to dst[topk).  Small sets are ranked by counting (~c*c/32 LDS
-// cycles); from kRankCountMax keys up the keys are sorted IN PLACE by a bitonic
-// network in LDS (log2(P)*(log2(P)+1)/2 stages of one compare-exchange per thread
-// pair: 55 stages for 1024 keys, ~1 us, where counting cost 12 us per workgroup at
-// topN = 1000).  Needs room for the next power of two >= c in s_keys; every thread of
-// the workgroup must call it (barriers inside).
-constexpr int kRankDirectMax = 384;   // callers cut larger survivor sets to exactly topk first (O(c) select)
-constexpr int kRankCountMax = 160;
-// kCoherent: the list is stored THROUGH to device scope (another workgroup of the same launch will read it:
-// lone_tail).
-template <bool kCoherent>
-__device__ __forceinline__ void st_key(uint64_t* p, uint64_t v) {
-    if constexpr (kCoherent) {
-        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        *p = v;
-    }
-}
-
-template <int kThreads, bool kCoherent = false>
-__device__ inline void block_rank_and_store(uint64_t* s_keys, int c, uint64_t* dst, int topk) {
-    for (int i = threadIdx.x; i < topk; i += kThreads) {
-        if (i >= c) st_key<kCoherent>(&dst[i], 0ull);
-    }
-    if (c > kRankCountMax) {   // uniform
-        int p2 = 256;
-        while (p2 < c) p2 <<= 1;
-        for (int i = c + threadIdx.x; i < p2; i += kThreads) s_keys[i] = 0ull;   // empty keys sort last
-        __syncthreads();
-        for (int k = 2; k <= p2; k <<= 1) {
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int t = threadIdx.x; t < (p2 >> 1); t += kThreads) {
-                    // pair (lo, lo + j) with bit j clear in lo; descending overall
-                    const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                    const int hi = lo | j;
-                    const uint64_t a = s_keys[lo], b = s_keys[hi];
-                    const bool down = (lo & k) == 0;   // this run sorts descending
-                    if ((a < b) == down) {
-                        s_keys[lo] = b;
-                        s_keys[hi] = a;
-                    }
-                }
-                __syncthreads();
-            }
-        }
-        const int n_out = c < topk ? c : topk;
-        for (int i = threadIdx.x; i < n_out; i += kThreads) st_key<kCoherent>(&dst[i], s_keys[i]);
-        return;
-    }
-    for (int i = threadIdx.x; i < c; i += kThreads) {
-        const uint64_t mine = s_keys[i];
-        int rank = 0;
-        int j = 0;
-        for (; j + 8 <= c; j += 8) {
-            const uint64_t k0 = s_keys[j], k1 = s_keys[j + 1], k2 = s_keys[j + 2], k3 = s_keys[j + 3];
-            const uint64_t k4 = s_keys[j + 4], k5 = s_keys[j + 5], k6 = s_keys[j + 6], k7 = s_keys[j + 7];
-            rank += (k0 > mine) + (k1 > mine) + (k2 > mine) + (k3 > mine) +
-                    (k4 > mine) + (k5 > mine) + (k6 > mine) + (k7 > mine);
-        }
-        for (; j < c; ++j) rank += (s_keys[j] > mine);
-        if (rank < topk) st_key<kCoherent>(&dst[rank], mine);
-    }
-}
-
-// Shrinks s_cand[0..*s_count) to the keys >= T where T bounds the topk-th best
-// (exactly topk keys remain with `exact`), and returns the filter threshold for
-// the streaming loop: later keys pass iff key > return value.
-template <int kThreads, int kCandPerThread>
-__device__ inline uint64_t compact_candidates(uint64_t* s_cand, int* s_count, int topk,
-                                              bool exact, SelectSmem& sm) {
-    __syncthreads();
-    const int c = *s_count;
-    if (c <= topk) return 0ull;  // uniform: nothing to drop yet
-    uint64_t mine[kCandPerThread];
-#pragma unroll
-    for (int r = 0; r < kCandPerThread; ++r) {
-        const int i = threadIdx.x + r * kThreads;
-        mine[r] = i < c ? s_cand[i] : 0ull;
-    }
-    int slack = topk / 4;
-    if (slack < 16) slack = 16;
-    const uint64_t t = block_select_threshold<kThreads, kCandPerThread>(mine, topk, exact, slack, sm);
-    if (threadIdx.x == 0) *s_count = 0;
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < kCandPerThread; ++r) {   // (uniform loop) one LDS atomic per wave: per-thread adds to the one word serialise
-        const bool keep = mine[r] >= t;
-        const uint64_t who = __ballot(keep);
-        int base = 0;
-        if ((threadIdx.x & 63) == 0 && who) base = atomicAdd(s_count, __popcll(who));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (keep) s_cand[base + lanes_below(who)] = mine[r];
-    }
-    __syncthreads();
-    return t - 1ull;
-}
-
-// ---- merge of sorted candidate lists -----------------------------------------
-// n_lists lists of list_len keys (each sorted descending, 0-padded) -> the best
-// topk keys, sorted descending, 0-padded; optional unpack to (row, score).
-// One workgroup per query (blockIdx.x = query in a batch): list l of query b starts
-// at lists_base + b*lists_query_stride + l*list_stride, so both layouts work:
-// [query][list][key] (per-workgroup lists of a scan) and [list][query][key]
-// (per-rank results of a batch after the all-gather).
-//
-// A key can only be in the global top-k if it is >= T whenever m lists each
-// hold >= j keys that are >= T with m*j >= topk.  With plenty of lists j = 1:
-// T = the topk-th largest list HEAD; with few (8 per-rank lists) deeper probes.
-// Lists are sorted, so each list's survivors are a prefix; for statistically
-// similar shards ~1.2*topk keys survive in total.  They are cut to exactly
-// topk by the radix select and ranked.  If more than kMergeSurvCap survive
-// (adversarial input), an exact radix select over all keys in global memory
-// finds the topk-th key instead.
-
-// Lists written by OTHER workgroups of the SAME launch (lone_tail below) are read past this XCD's L2, with
-// device-scope atomic loads; lists of an earlier launch with plain loads.
-template <bool kCoherent>
-__device__ __forceinline__ uint64_t ld_key(const uint64_t* p) {
-    if constexpr (kCoherent) {
-        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        return *p;
-    }
-}
-
-template <int kThreads, bool kCoherent = false>
-__device__ inline uint64_t merge_global_radix_select(const uint64_t* lists,
-                                                     int64_t total, int list_len, int64_t list_stride,
-                                                     int topk, int* s_hist, int* s_pair) {
-    // returns the topk-th largest key (0 if fewer than topk non-zero keys)
-    uint64_t prefix = 0, mask = 0;
-    int remaining = topk;
-    for (int pass = 7; pass >= 0; --pass) {
-        for (int i = threadIdx.x; i < 256; i += kThreads) s_hist[i] = 0;
-        __syncthreads();
-        const int shift = pass * 8;
-        for (int64_t i = threadIdx.x; i < total; i += kThreads) {
-            const uint64_t k = ld_key<kCoherent>(&lists[(i / list_len) * list_stride + (i % list_len)]);
-            if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255], 1);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int acc = 0, d = 255;
-            for (; d > 0; --d) {
-                if (acc + s_hist[d] >= remaining) break;
-                acc += s_hist[d];
-            }
-            s_pair[0] = d;
-            s_pair[1] = remaining - acc;
-        }
-        __syncthreads();
-        prefix |= static_cast<uint64_t>(s_pair[0]) << shift;
-        mask |= 255ull << shift;
-        remaining = s_pair[1];
-        __syncthreads();
-    }
-    return prefix;
-}
-
-// `slot` = which list set (lists_base + slot * lists_query_stride), `out_slot` = which
-// output row (out_*_base + out_slot * out_query_stride).
-// Shared memory of one merge: the product's merge kernels use <1024 threads, 2048 lists,
-// 4096 survivors>; the merger that rides along in a scan launch (scan_kernel<.., kWithMerge>)
-// uses the scan's block size and smaller bounds so that it fits the scan's register and LDS
-// budget (an overflowing survivor set falls back to the exact radix select either way).
-template <int kThreads, int kMaxLists, int kSurvCap>
-struct MergeSmemT {
-    uint64_t surv[kSurvCap];
-    uint64_t top[kMaxTopK];
-    SelectSmem sel;
-    int pair[2];
-    int count;
-    int overflow;
-    int more;
-    unsigned short active[kMaxLists];
-};
-
-template <bool kCoherent = false, int kThreads, int kMaxLists, int kSurvCap>
-__device__ __forceinline__ void merge_body(
-    MergeSmemT<kThreads, kMaxLists, kSurvCap>& sm, const uint64_t* lists_base, int n_lists, int list_len, int64_t list_stride,
-    int64_t lists_query_stride, int topk, uint64_t* __restrict__ out_keys_base,
-    int64_t* __restrict__ out_idx_base, float* __restrict__ out_score_base,
-    int64_t out_query_stride, int64_t slot, int64_t out_slot, int tid_in = -1 /* threadIdx.x, if the caller has a reason to
-    pass it (a caller that merges in a LOOP passes an opaque copy, or what depends on it alone is hoisted out and spilled) */) {
-    constexpr int kFirstPer = kMaxLists * kMergeFirst / kThreads;   // first-chunk keys per thread
-    constexpr int kSurvPer = kSurvCap / kThreads;
-    constexpr int kHeadsPer = kMaxLists / kThreads;
-    static_assert(kThreads % kMergeFirst == 0 && kSurvCap % kThreads == 0 && kMaxLists % kThreads == 0, "even shares");
-    uint64_t* const s_surv = sm.surv;
-    uint64_t* const s_top = sm.top;
-    SelectSmem& s_sel = sm.sel;
-    int* const s_pair = sm.pair;
-    int& s_count = sm.count;
-    int& s_overflow = sm.overflow;
-    int& s_more = sm.more;
-    unsigned short* const s_active = sm.active;
-
-    const int tid = tid_in >= 0 ? tid_in : static_cast<int>(threadIdx.x);
-    const uint64_t* lists = lists_base + slot * lists_query_stride;
-    uint64_t* out_keys = out_keys_base + out_slot * out_query_stride;
-
-    MI355REC_MPHASE(0);
-    if (tid == 0) {
-        s_count = 0;
-        s_overflow = 0;
-        s_pair[0] = 0;
-        s_more = 0;
-    }
-    __syncthreads();
-    int probe = 1;
-    if (n_lists < 2 * topk) probe = (2 * topk + n_lists - 1) / n_lists;
-    if (probe > list_len) probe = list_len;
-    const int need_lists = (topk + probe - 1) / probe;
-    int slack = need_lists / 8;
-    uint64_t thr = 1;  // accept every non-empty key
-    int first = 0;     // keys [0, first) of every list are already dealt with
-
-    const int64_t total_keys = static_cast<int64_t>(n_lists) * list_len;
-    if (total_keys <= kSurvCap) {
-        // Small input (e.g. one list of topn keys per rank after the all-gather):
-        // take every key in one load phase; the select / rank below does the rest.
-        // (one LDS atomic per wave instead of one per key; measured on the 326 top-10 lists of a 1 M-row scan: no
-        // difference, 9.1 vs 9.3 us for the whole merge_notify_kernel — the merge is latency, not atomics)
-        first = list_len;
-        for (int64_t i0 = 0; i0 < total_keys; i0 += kThreads) {   // uniform trip count: every lane takes part in the ballot
-            const int64_t i = i0 + tid;
-            const uint64_t k = i < total_keys ? ld_key<kCoherent>(&lists[(i / list_len) * list_stride + (i % list_len)]) : 0ull;
-            const uint64_t have = __ballot(k != 0ull);
-            int base = 0;
-            if ((tid & 63) == 0 && have) base = atomicAdd(&s_count, __popcll(have));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (k) s_surv[base + lanes_below(have)] = k;
-        }
-    } else if (probe == 1 && n_lists * kMergeFirst <= kThreads * kFirstPer) {
-        // Many lists (the per-workgroup lists of one scan).  ONE load phase brings
-        // in the first kMergeFirst keys of every list; the heads among them give
-        // the threshold and the rest is filtered from registers, so the usual
-        // case costs a single global-memory round trip.
-        first = kMergeFirst < list_len ? kMergeFirst : list_len;
-        uint64_t k[kFirstPer];
-        uint64_t hk[kFirstPer];
-        const int j = tid % kMergeFirst;  // kThreads % kMergeFirst == 0
-        int local_nonzero = 0;
-#pragma unroll
-        for (int u = 0; u < kFirstPer; ++u) {
-            const int l = (u * kThreads + tid) / kMergeFirst;
-            k[u] = (l < n_lists && j < list_len) ? ld_key<kCoherent>(&lists[static_cast<int64_t>(l) * list_stride + j]) : 0ull;
-        }
-#pragma unroll
-        for (int u = 0; u < kFirstPer; ++u) {
-            hk[u] = j == 0 ? k[u] : 0ull;
-            local_nonzero += hk[u] != 0ull;
-        }
-        for (int l = tid; l < n_lists; l += kThreads) s_active[l] = 0xffff;
-        {   // one LDS atomic per wave (hundreds of threads adding to the one word serialise: measured 2 us in the 8-bit
-            // scan's sample selection, the same pattern)
-            const int wave_nonzero = __builtin_amdgcn_readlane(wave_inclusive_scan(local_nonzero), 63);
-            if ((tid & 63) == 0 && wave_nonzero) atomicAdd(&s_pair[0], wave_nonzero);
-        }
-        __syncthreads();
-        if (s_pair[0] >= need_lists)  // uniform
-            thr = block_select_threshold<kThreads, kFirstPer>(hk, need_lists, false, slack, s_sel);
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < kFirstPer; ++u) {
-            const bool pass = k[u] >= thr;
-            const uint64_t who = __ballot(pass);   // (uniform loop: every lane takes part)
-            int base = 0;
-            if ((tid & 63) == 0 && who) base = atomicAdd(&s_count, __popcll(who));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (pass) {
-                const int slot = base + lanes_below(who);
-                if (slot < kSurvCap) s_surv[slot] = k[u];
-                else s_overflow = 1;
-                if (j == first - 1) {  // the whole first chunk passed: look deeper
-                    s_active[(u * kThreads + tid) / kMergeFirst] = 0;
-                    s_more = 1;
-                }
-            }
-        }
-    } else {
-        // Few lists (e.g. one per rank) or very many: probe each list at depth
-        // `probe` and start the rounds from the top of every list.
-        uint64_t heads[kHeadsPer];
-        int local_nonzero = 0;
-#pragma unroll
-        for (int r = 0; r < kHeadsPer; ++r) {
-            const int l = tid + r * kThreads;
-            heads[r] = l < n_lists ? ld_key<kCoherent>(&lists[static_cast<int64_t>(l) * list_stride + (probe - 1)]) : 0ull;
-            local_nonzero += heads[r] != 0ull;
-            if (l < n_lists) s_active[l] = 0;
-        }
-        if (tid == 0) s_more = 1;  // every list starts active
-        if (local_nonzero) atomicAdd(&s_pair[0], local_nonzero);
-        __syncthreads();
-        if (s_pair[0] >= need_lists)  // uniform; the select needs >= need_lists non-empty probes
-            thr = block_select_threshold<kThreads, kHeadsPer>(heads, need_lists, false, slack, s_sel);
-    }
-    __syncthreads();
-    MI355REC_MPHASE(1);   // first chunk loaded, threshold selected, survivors appended
-
-    // Deeper rounds: round d looks at keys [first + d*C, first + (d+1)*C) of every
-    // list that is still active (its previous chunk passed entirely); the loads
-    // of a round are independent and issued before any of them is consumed.
-    // With the first-chunk phase above this loop usually does not run at all.
-    for (int round = 0; first + round * kMergeChunk < list_len && !s_overflow; ++round) {
-        // s_more was raised by whoever marked a list active for this round
-        if (!s_more) break;  // uniform: read after a barrier, rewritten only after the next one
-        __syncthreads();
-        if (tid == 0) s_more = 0;
-        __syncthreads();
-        const int total = n_lists * kMergeChunk;
-        for (int t0 = 0; t0 < total; t0 += kThreads * 8) {
-            uint64_t k[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int t = t0 + u * kThreads + tid;
-                const int l = t / kMergeChunk;
-                const int pos = first + round * kMergeChunk + (t % kMergeChunk);
-                const bool live = t < total && pos < list_len && s_active[l] == round;
-                k[u] = live ? ld_key<kCoherent>(&lists[static_cast<int64_t>(l) * list_stride + pos]) : 0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (k[u] >= thr) {
-                    const int slot = atomicAdd(&s_count, 1);
-                    if (slot < kSurvCap) s_surv[slot] = k[u];
-                    else s_overflow = 1;
-                }
-            }
-        }
-        __syncthreads();
-        // a list stays active iff the LAST key of this chunk passed
-        for (int l = tid; l < n_lists; l += kThreads) {
-            if (s_active[l] == round) {
-                const int last = first + (round + 1) * kMergeChunk - 1;
-                if (last < list_len && ld_key<kCoherent>(&lists[static_cast<int64_t>(l) * list_stride + last]) >= thr) {
-                    s_active[l] = static_cast<unsigned short>(round + 1);
-                    s_more = 1;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    __syncthreads();
-    if (s_overflow) {
-        // exact fallback: radix-select the topk-th key over everything
-        const int64_t total = static_cast<int64_t>(n_lists) * list_len;
-        uint64_t kth = merge_global_radix_select<kThreads, kCoherent>(lists, total, list_len, list_stride, topk, s_sel.hist, s_pair);
-        if (kth == 0) kth = 1;
-        if (tid == 0) s_count = 0;
-        __syncthreads();
-        for (int64_t i0 = 0; i0 < total; i0 += kThreads) {
-            const int64_t i = i0 + tid;
-            const uint64_t k = (i < total) ? ld_key<kCoherent>(&lists[(i / list_len) * list_stride + (i % list_len)]) : 0ull;
-            if (k >= kth) {
-                const int pos = atomicAdd(&s_count, 1);  // exactly topk keys when unique
-                if (pos < kSurvCap) s_surv[pos] = k;
-            }
-        }
-        __syncthreads();
-    }
-
-    MI355REC_MPHASE(2);   // deeper rounds done
-    int c = s_count < kSurvCap ? s_count : kSurvCap;
-    __syncthreads();
-    if (c > topk && c > kRankDirectMax) {  // uniform: too many to rank, cut to exactly topk in O(c)
-        uint64_t mine[kSurvPer];
-#pragma unroll
-        for (int r = 0; r < kSurvPer; ++r) {
-            const int i = tid + r * kThreads;
-            mine[r] = i < c ? s_surv[i] : 0ull;
-        }
-        // (not to EXACTLY topk: that takes the radix select through all its byte passes; a cut that may leave up to
-        // kRankCountMax - topk keys more stops after one or two, and the ranking below keeps the best topk of what is left)
-        const int cut_slack = kRankCountMax > topk ? kRankCountMax - topk : 0;
-        const uint64_t t = block_select_threshold<kThreads, kSurvPer>(mine, topk, cut_slack == 0, cut_slack, s_sel);
-        if (tid == 0) s_count = 0;
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < kSurvPer; ++r) {   // (uniform loop) one LDS atomic per wave
-            const bool keep = mine[r] >= t;
-            const uint64_t who = __ballot(keep);
-            int base = 0;
-            if ((tid & 63) == 0 && who) base = atomicAdd(&s_count, __popcll(who));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (keep && base + lanes_below(who) < kSurvCap) s_surv[base + lanes_below(who)] = mine[r];
-        }
-        __syncthreads();
-        c = s_count < kSurvCap ? s_count : kSurvCap;
-    }
-    MI355REC_MPHASE(3);   // final cut done
-    block_rank_and_store<kThreads>(s_surv, c, s_top, topk);
-    __syncthreads();
-    MI355REC_MPHASE(4);   // ranked
-    for (int i = tid; i < topk; i += kThreads) {
-        const uint64_t k = s_top[i];
-        out_keys[i] = k;
-        if (out_idx_base) {
-            out_idx_base[out_slot * out_query_stride + i] =
-                k ? static_cast<int64_t>(static_cast<uint32_t>(~static_cast<uint32_t>(k))) : -1;
-        }
-        if (out_score_base) {
-            out_score_base[out_slot * out_query_stride + i] =
-                k ? ordered_to_score(static_cast<uint32_t>(k >> 32)) : 0.0f;
-        }
-    }
-}
-
-// ---- one launch per lone query --------------------------------------------------
-// A caller that waits for ONE query on the host (mi355rec_query_row_topn, what Recommender::recommend sits on)
-// pays three launches: sample, scan, merge.  With a LoneTail (the scan over the 8-bit replica on shards of
-// >= 4 M rows; measured from C++: 46 us instead of 49 at 10 M rows, but 31 instead of 28 at 1 M, where the
-// separate 1024-thread merge kernel beats the last workgroup of the scan) the scan is the last one: every workgroup
-// stores its list through to device scope and counts itself out (two levels: eight group counters, then one, so
-// that no counter sees more than ~100 arrivals); the workgroup that finds itself last merges all lists — read
-// past its L2 — into the caller's buffers and, like merge_notify_kernel, raises the completion word the host
-// polls.  No fences under the scanners (see scan_q8_kernel's seed riders for what those cost) and no spinning:
-// every workgroup leaves after one atomic or two.
-struct LoneTail {
-    unsigned* counters;       // [9]: groups 0..7 (blockIdx % 8), then the count of finished groups; counted up across launches, never reset
-    uint64_t* out_keys;
-    int64_t* out_idx;         // may be device-visible pinned host memory
-    float* out_score;
-    uint32_t* done_word;      // null: no completion word
-    uint32_t done_value;
-    unsigned base[9];         // what each counter holds before this launch's arrivals (the host keeps the books: lone_tail_bases)
-};
-
-// The arrivals a launch of `grid` workgroups adds to counter g (g < 8), resp. to counter 8 (host and device agree on this).
-__host__ __device__ inline unsigned lone_tail_groups(unsigned grid) { return grid < 8u ? grid : 8u; }
-__host__ __device__ inline unsigned lone_tail_members(unsigned grid, unsigned g) {
-    const unsigned groups = lone_tail_groups(grid);
-    return g < groups ? (grid - g + groups - 1u) / groups : 0u;
-}
-
-// Every thread of every workgroup calls this after block_rank_and_store<.., true>; `s_flag` is any LDS word the
-// caller can spare.  n_lists = gridDim.x lists of topk keys at `lists`.
-// A workgroup is "last" only when the counter reaches exactly base + members: the counters are never reset, so no
-// missed or repeated reset can make two workgroups (or none of this launch's own) believe they are the last one;
-// a counter that does not add up leaves the completion word unwritten and the host call fails loudly (wait_done).
-template <typename MergeSmem>
-__device__ __forceinline__ void lone_tail(MergeSmem& msm, int* s_flag, const uint64_t* lists, int topk, const LoneTail& lt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through list stores have completed (a workgroup-scope fence does not wait for them)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned groups = lone_tail_groups(gridDim.x);
-        const unsigned g = blockIdx.x % groups;
-        const unsigned members = lone_tail_members(gridDim.x, g);
-        int last = 0;
-        if (__hip_atomic_fetch_add(&lt.counters[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == lt.base[g] + members)
-            last = __hip_atomic_fetch_add(&lt.counters[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == lt.base[8] + groups;
-        *s_flag = last;
-    }
-    __syncthreads();
-    if (!*s_flag) return;   // uniform
-    __syncthreads();          // (the flag may live in the union the merge is about to use)
-    merge_body<true>(msm, lists, static_cast<int>(gridDim.x), topk, static_cast<int64_t>(topk), static_cast<int64_t>(0), topk,
-                     lt.out_keys, lt.out_idx, lt.out_score, static_cast<int64_t>(0), static_cast<int64_t>(0),
-                     static_cast<int64_t>(0));
-    if (lt.done_word) {   // uniform
-        // the waves that stored results order their stores before ... (the others have nothing to release: a system-scope
-        // fence is an L2 write-back per wave, and sixteen of them queue up)
-        if (static_cast<int>(threadIdx.x) < ((topk + 63) & ~63)) __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(lt.done_word, lt.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... the word
-    }
-}
 
 // ---- streaming scan ----------------------------------------------------------
 // Tiles of kTileRows rows are dealt round-robin over the workgroups (or, with
@@ -801,6 +38,16 @@ __device__ __forceinline__ void lone_tail(MergeSmem& msm, int* s_flag, const uin
 // kernel and its boundary disappear from the critical path of a stream of single queries.
 // The host launches one scan workgroup fewer than are resident (767 + the merger on a
 // 256-CU part), so nothing waits for a slot.
+// LAUNCH-WIDE BOUND (handoff.hip.h).  Workgroup-local thresholds alone let every workgroup find its own way up: on a
+// catalogue whose similar rows lie next to each other (sorted by genre) a workgroup meets a better cluster a few times
+// per launch and each time a whole tile passes its stale threshold into LDS appends and a radix compaction (measured
+// at 10 M rows, 300 contiguous clusters: 204 us per query instead of 81).  So the scan starts from the largest of two
+// exact lower bounds of the shard's topk-th score, when the host has them: `bound_ctl` (what the last seed rider of
+// the launch before, or the sample launch, made of a spread sample of the fp32 rows) and slot kNbhdSlot of
+// `sample_buf` (the neighbourhood of the excluded row), both tagged with this query's `epoch`.  Exact scores of real
+// rows: the key threshold starts AT the bound, no margin.  In a streamed launch (kWithMerge) the workgroups behind
+// the merger are the seed riders of the NEXT query (`next`: f32_sample_regions, then the last one selects) and, last
+// of the grid, its neighbourhood.
 struct PrevMerge {
     const uint64_t* lists;   // [n_lists][topk] of the previous query, nullptr = nothing pending
     int n_lists;
@@ -815,6 +62,7 @@ struct ScanSmemT {
     uint64_t cand[Cfg::kCandCap];
     SelectSmem sel;
     int count;
+    int seeds;   // (seed riders: the count of present sample values)
 };
 template <typename Cfg, bool kWithMerge>
 union ScanOrMergeSmem {
@@ -827,8 +75,12 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
     const float* __restrict__ feats, int64_t n, int64_t rows_per_block, int iters,
     int64_t row_base, QueryArg qarg, const float* __restrict__ query_ptr, int64_t exclude_global,
     int topk, uint64_t* __restrict__ block_lists, float* __restrict__ scores_out,
-    const uint64_t* __restrict__ upper_ptr, PrevMerge prev) {
+    const uint64_t* __restrict__ upper_ptr, PrevMerge prev,
+    const unsigned long long* __restrict__ bound_ctl /* tagged float: >= topk rows score at least this (null: none) */,
+    const unsigned long long* __restrict__ sample_buf /* its slot kNbhdSlot: the neighbourhood's bound (null: none) */,
+    uint32_t epoch /* of this query */, NextSeed next) {
     constexpr int kBlock = Cfg::kBlock;
+    static_assert(!kWithMerge || kBlock == kHalfSeedBlock, "the seed riders are sampling workgroups");
     constexpr int kRowsPerThread = Cfg::kRowsPerThread;
     constexpr int kTileRows = Cfg::kTileRows;
     static_assert(!(kWithMerge && kScoresOnly), "the riding merger belongs to top-N scans");
@@ -839,19 +91,38 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
     __shared__ SelectSmem s_sel_plain;
     __shared__ int s_count_plain;
     __shared__ typename std::conditional<kWithMerge, ScanOrMergeSmem<Cfg, true>, int>::type s_ride;
+    // scanning workgroups [0, nblocks), then the merger, then the seed riders, then (next.nbhd) the neighbourhood
+    const unsigned nblocks = kWithMerge ? gridDim.x - 1u - static_cast<unsigned>(next.n_wgs) - static_cast<unsigned>(next.nbhd) : gridDim.x;
     if constexpr (kWithMerge) {
-        if (blockIdx.x == gridDim.x - 1) {      // the merger (the LAST workgroup: the scanners keep blockIdx = tile slot)
-            if (prev.lists)
-                merge_body(s_ride.merge, prev.lists, prev.n_lists, prev.topk, static_cast<int64_t>(prev.topk),
-                           static_cast<int64_t>(0), prev.topk, prev.out_keys, static_cast<int64_t*>(nullptr),
-                           static_cast<float*>(nullptr), static_cast<int64_t>(0), static_cast<int64_t>(0),
-                           static_cast<int64_t>(0));
+        if (blockIdx.x >= nblocks) {
+            if (blockIdx.x == nblocks) {      // the merger (behind the scanners: they keep blockIdx = tile slot)
+                if (prev.lists)
+                    merge_body(s_ride.merge, prev.lists, prev.n_lists, prev.topk, static_cast<int64_t>(prev.topk),
+                               static_cast<int64_t>(0), prev.topk, prev.out_keys, static_cast<int64_t*>(nullptr),
+                               static_cast<float*>(nullptr), static_cast<int64_t>(0), static_cast<int64_t>(0),
+                               static_cast<int64_t>(0));
+            } else if (next.nbhd && blockIdx.x == gridDim.x - 1u) {   // the next query's neighbourhood
+                nbhd_to_slot<kBlock>(feats, n, row_base, next.query_ptr, next.q, next.exclude_global, next.topk, next.epoch,
+                                     static_cast<unsigned long long*>(next.out), s_ride.scan.sel, &s_ride.scan.count);
+            } else {                              // a seed rider: its share of the next query's sample
+                f32_sample_regions(feats, n, row_base, next, static_cast<int>(blockIdx.x - nblocks - 1u));
+                if (next.ctl) {   // uniform: the last rider out turns the sample into the next launch's bound
+                    float v;
+                    if (sample_arrive_and_select<kBlock>(next.ctl, next.done_base, static_cast<unsigned>(next.n_wgs),
+                                                         static_cast<const unsigned long long*>(next.out), next.regions * kHalfSeedWaves,
+                                                         next.topk, next.epoch, &s_ride.scan.count, &s_ride.scan.seeds, s_ride.scan.sel,
+                                                         reinterpret_cast<int*>(s_ride.scan.cand), v)) {
+                        if (threadIdx.x == 0) next.ctl->cutoff = tag_value(next.epoch, __float_as_uint(v));
+                    }
+                }
+            }
             return;
         }
+    } else {
+        (void)next;
     }
-    // this workgroup's index among the scanning workgroups, and their number
+    // this workgroup's index among the scanning workgroups
     const unsigned bid = blockIdx.x;
-    const unsigned nblocks = kWithMerge ? gridDim.x - 1u : gridDim.x;
     uint64_t* s_cand;
     SelectSmem* s_sel_p;
     int* s_count_p;
@@ -910,6 +181,9 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
 #pragma unroll
         for (int j = 0; j < kDim; ++j) q[j] = qarg.q[j];
     }
+    // (wave-uniform: scalar loads, requested with the query)
+    const unsigned long long bound_raw = bound_ctl ? *bound_ctl : 0ull;
+    const unsigned long long nbhd_raw = sample_buf ? sample_buf[kNbhdSlot] : 0ull;
     const float qn = query_norm(q);
     if (qn >= 0.0f || n >= 0) MI355REC_KPHASE(1);   // (depends on the query)
     // Only keys strictly below *upper_ptr take part (nullptr: no bound).  This is
@@ -929,6 +203,20 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
     if constexpr ((kDebug & 4) != 0) {
         thr = pack_key(0.985f, 0u);
         cutoff = 0.985f - kApproxMargin;
+    }
+    if constexpr (!kScoresOnly) {
+        // the launch-wide bound: the larger of the sample's and the neighbourhood's (0 / -inf: absent, or another query's)
+        uint32_t vb = untag_value(nbhd_raw, epoch);
+        const float sample_v = untag_cutoff(bound_raw, epoch);
+        if (sample_v > -3.0e38f) {
+            const uint32_t o = score_to_ordered(sample_v);
+            vb = o > vb ? o : vb;
+        }
+        if (vb) {   // at least topk rows score >= the bound: keys below it are dropped (a key AT it passes: key > thr)
+            thr = (static_cast<uint64_t>(vb) << 32) - 1ull;
+            const float vs = ordered_to_score(vb);
+            if (prefilter_ok && vs > 0.0f) cutoff = vs - kApproxMargin;
+        }
     }
     // Re-tighten the threshold once ~topk NEW candidates have piled up (the
     // select is O(c), but every candidate that slips past a stale threshold
@@ -1004,6 +292,31 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
         __syncthreads();
         block_rank_and_store<kBlock>(s_cand, s_count, block_lists + static_cast<int64_t>(bid) * topk, topk);
         MI355REC_KPHASE(4);   // list stored
+    }
+}
+
+// ---- the sample launch of a query ALONE over the fp32 rows -----------------------------------------------------
+// A streamed query's sample rides in the launch before it (scan_kernel<.., kWithMerge>); a query on its own gets this
+// launch first where the shard is large enough for ~5 us to be worth a launch-wide bound: workgroup g < next.regions
+// takes region g (next.n_wgs == next.regions), the last to arrive selects the bound into next.ctl->cutoff, and
+// (next.nbhd) one more workgroup takes the neighbourhood of the excluded row into next.out[kNbhdSlot].
+__global__ __launch_bounds__(kHalfSeedBlock) void seed_f32_kernel(const float* __restrict__ feats, int64_t n, int64_t row_base, NextSeed next) {
+    __shared__ SelectSmem s_sel;
+    __shared__ int s_flag, s_seeds;
+    __shared__ int s_bins[kSelScratch];
+    if (static_cast<int>(blockIdx.x) >= next.regions) {   // uniform: the neighbourhood workgroup
+        nbhd_to_slot<kHalfSeedBlock>(feats, n, row_base, next.query_ptr, next.q, next.exclude_global, next.topk, next.epoch,
+                                     static_cast<unsigned long long*>(next.out), s_sel, &s_flag);
+        return;
+    }
+    f32_sample_regions(feats, n, row_base, next, static_cast<int>(blockIdx.x));
+    if (next.ctl) {   // uniform
+        float v;
+        if (sample_arrive_and_select<kHalfSeedBlock>(next.ctl, next.done_base, static_cast<unsigned>(next.n_wgs),
+                                                     static_cast<const unsigned long long*>(next.out), next.regions * kHalfSeedWaves, next.topk,
+                                                     next.epoch, &s_flag, &s_seeds, s_sel, s_bins, v)) {
+            if (threadIdx.x == 0) next.ctl->cutoff = tag_value(next.epoch, __float_as_uint(v));
+        }
     }
 }
 
@@ -1517,36 +830,6 @@ __global__ __launch_bounds__(kMergeBlock) void seed_select_kernel(
     }
     // scan_multi_kernel reads slot [query][topk - 1] as "the sample's topk-th key"
     if (tid == 0) seed_keys[static_cast<int64_t>(blockIdx.x) * topk + (topk - 1)] = t;
-}
-
-// ---- merge kernels (the merge body itself is defined above the streaming scan) ------
-
-__global__ __launch_bounds__(kMergeBlock) void merge_kernel(
-    const uint64_t* __restrict__ lists_base, int n_lists, int list_len, int64_t list_stride,
-    int64_t lists_query_stride, int topk, uint64_t* __restrict__ out_keys_base,
-    int64_t* __restrict__ out_idx_base, float* __restrict__ out_score_base,
-    int64_t out_query_stride) {
-    __shared__ MergeSmemT<kMergeBlock, kMergeMaxLists, kMergeSurvCap> sm;
-    merge_body(sm, lists_base, n_lists, list_len, list_stride, lists_query_stride, topk, out_keys_base, out_idx_base,
-               out_score_base, out_query_stride, blockIdx.x, blockIdx.x);
-}
-
-// The same merge for a caller that WAITS ON THE HOST (mi355rec_query_row_topn): out_idx / out_score are
-// device-visible addresses of pinned host memory, and after them the workgroup stores `done_value` to
-// *done_word (pinned host memory as well), so the host can poll one word instead of going through
-// hipStreamSynchronize's completion path (~3 us of a 60 us query).
-__global__ __launch_bounds__(kMergeBlock) void merge_notify_kernel(
-    const uint64_t* __restrict__ lists_base, int n_lists, int list_len, int64_t list_stride, int topk,
-    uint64_t* __restrict__ out_keys_base, int64_t* __restrict__ out_idx_base, float* __restrict__ out_score_base,
-    uint32_t* done_word, uint32_t done_value) {
-    __shared__ MergeSmemT<kMergeBlock, kMergeMaxLists, kMergeSurvCap> sm;
-    merge_body(sm, lists_base, n_lists, list_len, list_stride, static_cast<int64_t>(0), topk, out_keys_base, out_idx_base,
-               out_score_base, static_cast<int64_t>(0), static_cast<int64_t>(0), static_cast<int64_t>(0));
-    // the waves that stored results order their stores before ... (the others have nothing to release: a system-scope
-    // fence is an L2 write-back per wave, and sixteen of them queue up)
-    if (static_cast<int>(threadIdx.x) < ((topk + 63) & ~63)) __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(done_word, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... the word
 }
 
 // ---- read-only streaming probe (achievable-HBM ceiling) ---------------------

@@ -55,10 +55,22 @@ constexpr int64_t kHalfAutoMinRows = 1000000;   // below this a query is launch-
                                                 // 13.5 us per streamed query at 1 M rows, equal at 300 k)
 constexpr int kScanBlock = ScanConfig::kBlock;
 constexpr int kScanTileRows = ScanConfig::kTileRows;
+constexpr int64_t kF32SampleMinRows = 2000000;  // below this a fp32 scan is a dozen microseconds: no sample (the neighbourhood still rides)
+constexpr int kFp32 = 0, kFp16 = 1, kQ8 = 2;    // which rows a single-query scan streams (mi355rec::Stashed::kind)
 const float* const kNoQueryPtr = nullptr;   // kernel argument of the variants that take the query by value
 
 // Launch geometry of a single-query scan over a replica of the catalogue (fp16: replica.hip.h,
 // 8-bit: replica_q8.hip.h).
+// The sample of the fp32 rows (handoff.hip.h, f32_sample_regions) that gives the fp32 scan its launch-wide bound, and
+// the geometry of a streamed fp32 launch that carries the NEXT query's seed riders and neighbourhood workgroup.
+struct F32Geom {
+    int seed_grid = 0;                  // sampled regions of kHalfSeedBlock rows (0: the shard is too small to be worth a sample) ...
+    int64_t seed_stride = 0;            // ... and the rows between their starts
+    int riders = 0;                     // seed riders of a streamed launch (0: none)
+    int nbhd = 0;                       // 1: a streamed launch also carries the next query's neighbourhood workgroup
+    int r_scan = 0, r_iters = 0;        // its scanners and their tiles
+};
+
 struct ReplicaGeom {
     int grid = 0, iters = 0;            // plain launch
     int sgrid = 0, siters = 0;          // streamed launch without seed riders (one more workgroup is the merger)
@@ -91,6 +103,7 @@ struct mi355rec {
     // the scan launch of query k + 1; two more list buffers alternate
     uint64_t* d_stream_lists[2] = {nullptr, nullptr};
     int sgrid = 0, siters = 0;          // scanning workgroups of a streamed launch (one slot is the merger's)
+    F32Geom fg;                         // the fp32 scan's sample and riders
     bool streamed_ready = false;        // both list buffers exist
     bool pending = false;               // a streamed query's lists wait for their merge
     int pending_buf = 0, pending_topn = 0;
@@ -99,7 +112,10 @@ struct mi355rec {
     uint4* d_half = nullptr;            // ((n + 1) / 2) pairs of rows x 48 B
     // sample maxima: 8 bytes per entry — epoch-tagged values (8-bit scan, multi-query pass: replica.hip.h, "hand-offs
     // that fail safe"); the fp16 single-query scan uses the same buffers as plain uint32_t[]
-    unsigned long long* d_half_seed = nullptr;    // kHalfSeedMaxGrid x 8 sample maxima of the query in flight
+    unsigned long long* d_half_seed = nullptr;    // kSampleSlots tagged values: the sample of the query in flight + its neighbourhood's bound
+                                                  // (every handle has it and d_stream_seed / d_stream_ctl: the fp32 scan takes a bound too)
+    SeedCtl* d_lone_ctl = nullptr;                // arrival counter and bound of the fp32 sample launch of a query alone ...
+    unsigned lone_ctl_done = 0;                   // ... which counts up from here (never reset)
     unsigned long long* d_half_mseed = nullptr;   // kHmQueries x that: the sample of a multi-query pass over the replica
     unsigned long long* d_half_mcuts = nullptr;   // [kHmQueries] tagged cutoffs the sample launch of such a pass leaves (its last workgroup) ...
     SeedCtl* d_half_mctl = nullptr;               // ... and its arrival counter, which counts up from ...
@@ -113,7 +129,8 @@ struct mi355rec {
     int dbg_skip_regions = 0;
     bool dbg_no_last = false;
     unsigned long long* d_half_rescored = nullptr;   // [kRideMaxLists] rows sent to the exact chain, per workgroup slot
-    unsigned* d_lone_ctr = nullptr;     // [9] arrival counters of a lone query's launch (kernels.hip.h, LoneTail); zero between launches
+    unsigned* d_lone_ctr = nullptr;     // [9] arrival counters of a lone query's launch (merge.hip.h, LoneTail): they count up across
+                                        // launches and are never reset; lone_base is what they hold
     int64_t lone_fused = 0;             // lone queries served by one launch (scan + merge + completion word)
     int64_t half_scans = 0;             // replica scans enqueued since create ...
     int64_t q8_scans = 0;               // ... of which over the 8-bit replica
@@ -142,8 +159,8 @@ struct mi355rec {
         uint64_t* out = nullptr;
         int seed_buf = 0;               // which of d_stream_seed holds ITS sample maxima
         uint32_t epoch = 0;             // the tag of its sample values and of its cutoff
-        bool q8 = false;                // that sample was taken over the 8-bit replica, so its scan runs there
-        bool cutoff_ready = false;      // ... by riders, whose last one left the launch-wide cutoff in d_stream_ctl
+        int kind = 0;                   // which rows its scan streams — and its sample was taken over: kFp32, kFp16 (experiment builds), kQ8
+        bool cutoff_ready = false;      // ... by riders, whose last one left the launch-wide cutoff / bound in d_stream_ctl
     } stashed;
     unsigned long long* d_stream_seed[2] = {nullptr, nullptr};
     SeedCtl* d_stream_ctl = nullptr;    // [2]: rider count and finished cutoff beside each of d_stream_seed (8-bit replica)
@@ -210,6 +227,7 @@ struct mi355rec {
         int cand_cap = 0;                // candidate rows kept per query, also in counters[6] for the passes
         int* counters = nullptr;         // [4]
         uint32_t* special_rows = nullptr;
+        uint32_t* nb_vals = nullptr;     // [1024] the queries' neighbourhood bounds (bq_prepare_kernel), ordered-u32, 0 = none
         float* gmax = nullptr;           // [grid][32][64]
         // pass 1's per-lane maxima of the tiles it looked at, for pass 2 to skip what they rule out (batched.hip.h,
         // kTileMax): [visited tile][4][64] uint4 = 4 KiB per visited 64-row tile, 16 B per catalogue row at step 4
@@ -302,16 +320,45 @@ int sync_api_begin(mi355rec* h) { return order_stream(h, h->stream); }
 void plan_grid(mi355rec* h, int blocks_per_cu) {
     int64_t max_blocks = static_cast<int64_t>(h->cus) * blocks_per_cu;
     if (max_blocks > kMergeMaxLists) max_blocks = kMergeMaxLists;
-#ifdef MI355REC_EXPERIMENTS   // tools builds only (tools/lat_exp.sh): fewer scanning workgroups = fewer lists for the merge
-    if (const char* e = std::getenv("MI355REC_EXP_FP32_GRID")) {
-        const int v = std::atoi(e);
-        if (v >= 1 && v < max_blocks) max_blocks = v;
-    }
-#endif
+    MI355REC_EXP_INT(max_blocks, "MI355REC_EXP_FP32_GRID", 1, max_blocks - 1);   // (tools/lat_exp.sh: fewer lists for the merge)
     const int64_t tiles = (h->n + kScanTileRows - 1) / kScanTileRows;
     h->grid = static_cast<int>(tiles < max_blocks ? tiles : max_blocks);
     h->rows_per_block = 0;
     h->iters = static_cast<int>((tiles + h->grid - 1) / h->grid);
+    // a streamed launch: one workgroup is the merger of the query before ...
+    int g = h->grid > 1 ? h->grid - 1 : 1;
+    if (g > kRideMaxLists - 1) g = kRideMaxLists - 1;
+    MI355REC_EXP_INT(g, "MI355REC_EXP_SGRID", 1, g - 1);
+    if (tiles < g) g = static_cast<int>(tiles);
+    h->sgrid = g;
+    h->siters = static_cast<int>((tiles + g - 1) / g);
+    // ... and, where the launch can spare them, a few are the NEXT query's seed riders and its neighbourhood workgroup
+    // (handoff.hip.h): a rider takes four regions per memory round trip (~2.5 us) and should be done well before the
+    // scanners (~3 us per tile each) are.
+    F32Geom& f = h->fg;
+    f = F32Geom();
+    f.r_scan = h->sgrid;
+    f.r_iters = h->siters;
+    int64_t sg = h->n / kHalfSeedBlock;
+    if (sg > kHalfSeedMaxGrid) sg = kHalfSeedMaxGrid;
+    if (h->n >= kF32SampleMinRows && sg >= 64) {
+        f.seed_grid = static_cast<int>(sg);
+        f.seed_stride = h->n / sg;
+    }
+    if (h->grid >= 16 && h->grid == max_blocks && h->n >= kNbhdRows) {
+        f.nbhd = 1;
+        if (f.seed_grid > 0) {
+            int rounds = static_cast<int>(h->siters * 3.0 / 12.0);
+            if (rounds < 1) rounds = 1;
+            int riders = (f.seed_grid + 4 * rounds - 1) / (4 * rounds);
+            if (riders > h->grid / 16) riders = h->grid / 16;
+            MI355REC_EXP_INT(riders, "MI355REC_EXP_F32_RIDERS", 0, h->grid / 4);
+            f.riders = riders;
+        }
+        f.r_scan = h->grid - 1 - f.riders - f.nbhd;
+        if (f.r_scan > kRideMaxLists - 1) f.r_scan = kRideMaxLists - 1;
+        f.r_iters = static_cast<int>((tiles + f.r_scan - 1) / f.r_scan);
+    }
 }
 
 // Multi-query pass: same round-robin tile mapping for the full pass; the seed
@@ -338,12 +385,7 @@ ReplicaGeom plan_replica(const mi355rec* h, int occ, int tile_rows, int align, d
     if (occ > 3) occ = 3;
     int64_t max_blocks = static_cast<int64_t>(h->cus) * occ;
     if (max_blocks > kRideMaxLists) max_blocks = kRideMaxLists;
-#ifdef MI355REC_EXPERIMENTS
-    if (const char* e = std::getenv("MI355REC_EXP_REPLICA_GRID")) {
-        const int v = std::atoi(e);
-        if (v >= 1 && v < max_blocks) max_blocks = v;
-    }
-#endif
+    MI355REC_EXP_INT(max_blocks, "MI355REC_EXP_REPLICA_GRID", 1, max_blocks - 1);
     const int64_t tiles = (h->n + tile_rows - 1) / tile_rows;
     g.grid = static_cast<int>(tiles < max_blocks ? tiles : max_blocks);
     g.iters = static_cast<int>((tiles + g.grid - 1) / g.grid);
@@ -363,15 +405,10 @@ ReplicaGeom plan_replica(const mi355rec* h, int occ, int tile_rows, int align, d
         if (rounds < 1) rounds = 1;
         int riders = static_cast<int>((sg + 4 * rounds - 1) / (4 * rounds));
         if (riders > g.grid / 8) riders = g.grid / 8;
-#ifdef MI355REC_EXPERIMENTS   // A/B builds of tools/ only: the product reads no tuning knob from the environment
-        if (const char* e = std::getenv("MI355REC_EXP_RIDERS")) {
-            const int v = std::atoi(e);
-            if (v >= 0 && v <= g.grid / 2) riders = v;
-        }
-#endif
+        MI355REC_EXP_INT(riders, "MI355REC_EXP_RIDERS", 0, g.grid / 2);
         if (riders > 0) {
             g.riders = riders;
-            g.r_scan = g.grid - 1 - riders;
+            g.r_scan = g.grid - 2 - riders;   // (the merger, and the next query's neighbourhood workgroup)
             g.r_iters = static_cast<int>((tiles + g.r_scan - 1) / g.r_scan);
             // Whole rounds only: where the cap above binds (a 1 M-row shard: 61 riders for 256 regions) the last few
             // regions would cost every rider's launch one more round trip — on a shard that small the riders are the
@@ -389,52 +426,37 @@ ReplicaGeom plan_replica(const mi355rec* h, int occ, int tile_rows, int align, d
 
 void plan_half_grid(mi355rec* h) {
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_half_kernel<HalfConfig, true, false>, HalfConfig::kBlock, 0) != hipSuccess) occ = 1;
-#ifdef MI355REC_EXPERIMENTS
-    if (const char* e = std::getenv("MI355REC_EXP_HOCC")) {
-        const int v = std::atoi(e);
-        if (v >= 1 && v <= 4) occ = v;
-    }
-#endif
+    // the fp16 replica: the multi-query pass's workgroups and sampled regions (experiment builds: also the single-query scan's)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_half_multi_kernel<false, false>, kHmBlock, 0) != hipSuccess) occ = 1;
+    MI355REC_EXP_INT(occ, "MI355REC_EXP_HOCC", 1, 4);
     h->hg = plan_replica(h, occ, HalfConfig::kTileRows, 2, 2.1);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_q8_kernel<Q8Config, true, false>, Q8Config::kBlock, 0) != hipSuccess) occ = 1;
     h->qg = plan_replica(h, occ, Q8Config::kTileRows, 4, 2.1);
 }
 
 void free_replica(mi355rec* h) {
-    void* bufs[] = {h->d_half, h->d_q8, h->d_stream_ctl, h->d_half_seed, h->d_half_mseed, h->d_half_rescored, h->d_stream_seed[0], h->d_stream_seed[1],
-                    h->d_half_mcuts, h->d_half_mctl};
+    void* bufs[] = {h->d_half, h->d_q8, h->d_half_mseed, h->d_half_rescored, h->d_half_mcuts, h->d_half_mctl};
     h->d_half_mcuts = nullptr;
     h->d_half_mctl = nullptr;
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     h->d_half = nullptr;
     h->d_q8 = nullptr;
-    h->d_stream_ctl = nullptr;
-    h->d_half_seed = nullptr;
     h->d_half_mseed = nullptr;
     h->d_half_rescored = nullptr;
-    h->d_stream_seed[0] = h->d_stream_seed[1] = nullptr;
 }
 
 int alloc_replica(mi355rec* h, int64_t n_padded) {
     HIP_TRY(h, hipMalloc(&h->d_half, static_cast<size_t>(n_padded) * 24));
     HIP_TRY(h, hipMalloc(&h->d_q8, static_cast<size_t>((h->n + 3) / 4) * 48));
-    HIP_TRY(h, hipMalloc(&h->d_half_seed, sizeof(unsigned long long) * kHalfSeedMaxGrid * kHalfSeedWaves));
-    HIP_TRY(h, hipMalloc(&h->d_half_mseed, sizeof(unsigned long long) * kHmQueries * kHalfSeedMaxGrid * kHalfSeedWaves));
+    HIP_TRY(h, hipMalloc(&h->d_half_mseed, sizeof(unsigned long long) * kHmSampleSlots));
     HIP_TRY(h, hipMalloc(&h->d_half_rescored, sizeof(unsigned long long) * kRideMaxLists));
     HIP_TRY(h, hipMalloc(&h->d_half_mcuts, sizeof(unsigned long long) * kHmQueries));
     HIP_TRY(h, hipMemsetAsync(h->d_half_mcuts, 0, sizeof(unsigned long long) * kHmQueries, h->stream));
     HIP_TRY(h, hipMalloc(&h->d_half_mctl, sizeof(SeedCtl)));
     HIP_TRY(h, hipMemsetAsync(h->d_half_mctl, 0, sizeof(SeedCtl), h->stream));
     h->half_mctl_done = 0;
-    // the sample buffers of STREAMED queries belong to the replica: whoever has d_half has them
-    for (int i = 0; i < 2; ++i)
-        HIP_TRY(h, hipMalloc(&h->d_stream_seed[i], sizeof(unsigned long long) * kHalfSeedMaxGrid * kHalfSeedWaves));
     HIP_TRY(h, hipMemsetAsync(h->d_half_rescored, 0, sizeof(unsigned long long) * kRideMaxLists, h->stream));
-    HIP_TRY(h, hipMalloc(&h->d_stream_ctl, sizeof(SeedCtl) * 2));
-    HIP_TRY(h, hipMemsetAsync(h->d_stream_ctl, 0, sizeof(SeedCtl) * 2, h->stream));
-    h->ctl_done[0] = h->ctl_done[1] = 0u;
     return MI355REC_OK;
 }
 
@@ -568,6 +590,17 @@ int create_common(const float* feats, bool on_device, int64_t n, int dim, int de
         return cleanup(MI355REC_ERR_OUT_OF_MEMORY, "hipMalloc(block lists)", e);
     if ((e = hipMalloc(&h->d_lone_ctr, sizeof(unsigned) * 16)) != hipSuccess || (e = hipMemset(h->d_lone_ctr, 0, sizeof(unsigned) * 16)) != hipSuccess)
         return cleanup(MI355REC_ERR_OUT_OF_MEMORY, "hipMalloc(lone counters)", e);
+    // the sample / bound buffers of single queries (handoff.hip.h): every scan takes a launch-wide bound, over whichever rows
+    {
+        unsigned long long** seeds[] = {&h->d_half_seed, &h->d_stream_seed[0], &h->d_stream_seed[1]};
+        for (unsigned long long** b : seeds)
+            if ((e = hipMalloc(b, sizeof(unsigned long long) * kSampleSlots)) != hipSuccess ||
+                (e = hipMemset(*b, 0, sizeof(unsigned long long) * kSampleSlots)) != hipSuccess)
+                return cleanup(MI355REC_ERR_OUT_OF_MEMORY, "hipMalloc(sample values)", e);
+        if ((e = hipMalloc(&h->d_stream_ctl, sizeof(SeedCtl) * 2)) != hipSuccess || (e = hipMemset(h->d_stream_ctl, 0, sizeof(SeedCtl) * 2)) != hipSuccess ||
+            (e = hipMalloc(&h->d_lone_ctl, sizeof(SeedCtl))) != hipSuccess || (e = hipMemset(h->d_lone_ctl, 0, sizeof(SeedCtl))) != hipSuccess)
+            return cleanup(MI355REC_ERR_OUT_OF_MEMORY, "hipMalloc(sample control)", e);
+    }
     if ((e = hipMalloc(&h->d_seed_vals, sizeof(uint32_t) * kMultiChain * static_cast<size_t>(h->mgrid) * kSeedWaves)) != hipSuccess)
         return cleanup(MI355REC_ERR_OUT_OF_MEMORY, "hipMalloc(seed values)", e);
     if ((e = hipMalloc(&h->d_seed_keys, sizeof(uint64_t) * kMultiChain * kMultiMaxTopK)) != hipSuccess)
@@ -687,8 +720,15 @@ bool use_half(const mi355rec* h, const uint64_t* upper_dev) {
     return h->replica_mode == MI355REC_REPLICA_ON || h->replica_mode == MI355REC_REPLICA_FP16 || h->n >= kHalfAutoMinRows;
 }
 
-// Single queries prefer the 8-bit replica (half the bytes per row); MI355REC_REPLICA_FP16 keeps them on the fp16 one.
+// Single queries stream the 8-bit replica (half the fp16 one's bytes per row); experiment builds can keep them on the
+// fp16 one (MI355REC_REPLICA_FP16: A/B).
 bool use_q8(const mi355rec* h) { return h->d_q8 && h->replica_mode != MI355REC_REPLICA_FP16; }
+
+// Which rows the next single query on this handle streams.
+int single_kind(const mi355rec* h, const uint64_t* upper_dev) {
+    if (!use_half(h, upper_dev)) return kFp32;
+    return use_q8(h) ? kQ8 : kFp16;
+}
 
 // Streamed launches over the 8-bit replica: the last seed rider out turns the sample into the next launch's
 // cutoff (saves a ~4 us select in every workgroup of that launch).  The riders then take sample + select
@@ -698,27 +738,30 @@ bool q8_hoists(const mi355rec* h) { return h->qg.riders > 0 && h->qg.r_iters >= 
 // where the extra fetch per sampled wave is not on the launch's critical path.
 bool q8_exact_sample(const mi355rec* h) { return h->qg.iters >= 3; }
 
-// The sample that seeds the launch-wide cutoff of the next scan over the replica.
-// (8-bit replica: the values are tagged with `epoch`, which the scan that reads them is given as well)
-void enqueue_half_seed(mi355rec* h, bool q8, const float* qptr, const QueryArg& qa, int64_t exclude_global, unsigned long long* seed_buf,
-                       uint32_t epoch, hipStream_t s) {
-    uint32_t* const seed_out = reinterpret_cast<uint32_t*>(seed_buf);   // the fp16 scan's plain values
-    if (q8) {
-        if (h->qg.seed_grid <= 0) return;
-#define SEED_Q8(FROM_ROW, EXACT, QP)                                                                                       \
-    hipLaunchKernelGGL((seed_q8_kernel<FROM_ROW, EXACT>), dim3(h->qg.seed_grid), dim3(kHalfSeedBlock), 0, s, h->d_feats, h->d_q8, \
-                       h->n, h->qg.seed_stride, h->row_base, qa, QP, exclude_global, seed_buf, epoch)
-        if (q8_exact_sample(h)) {
-            if (qptr) SEED_Q8(true, true, qptr);
-            else SEED_Q8(false, true, kNoQueryPtr);
-        } else {
-            if (qptr) SEED_Q8(true, false, qptr);
-            else SEED_Q8(false, false, kNoQueryPtr);
-        }
+// Is the row a query excludes a row of THIS shard?  Then its neighbourhood gives the scan a bound (handoff.hip.h).
+bool nbhd_applies(const mi355rec* h, int64_t exclude_global) {
+    return exclude_global >= h->row_base && exclude_global < h->row_base + h->n && h->n >= kNbhdRows;
+}
+
+// The sample launch of a query ALONE over a replica (the first query of a stream as well): the sampled regions and,
+// when the excluded row is a row of this shard, one more workgroup for its neighbourhood.  The values are tagged with
+// `epoch`, which the scan that reads them is given as well.
+void enqueue_half_seed(mi355rec* h, int kind, const float* qptr, const QueryArg& qa, int64_t exclude_global, int topn,
+                       unsigned long long* seed_buf, uint32_t epoch, hipStream_t s) {
+    if (kind == kQ8) {
+        const int extra = nbhd_applies(h, exclude_global) ? 1 : 0;
+        if (h->qg.seed_grid + extra <= 0) return;
+#define SEED_Q8(EXACT)                                                                                                     \
+    hipLaunchKernelGGL((seed_q8_kernel<EXACT>), dim3(h->qg.seed_grid + extra), dim3(kHalfSeedBlock), 0, s, h->d_feats, h->d_q8, \
+                       h->n, h->qg.seed_stride, h->row_base, qa, qptr, exclude_global, seed_buf, epoch, h->qg.seed_grid, topn)
+        if (q8_exact_sample(h)) SEED_Q8(true);
+        else SEED_Q8(false);
 #undef SEED_Q8
         return;
     }
+#ifdef MI355REC_EXPERIMENTS
     if (h->hg.seed_grid <= 0) return;
+    uint32_t* const seed_out = reinterpret_cast<uint32_t*>(seed_buf);   // the fp16 scan's plain values
     if (qptr) {
         hipLaunchKernelGGL((seed_half_kernel<true>), dim3(h->hg.seed_grid), dim3(kHalfSeedBlock), 0, s, h->d_feats, h->d_half,
                            h->n, h->hg.seed_stride, h->row_base, qa, qptr, exclude_global, seed_out);
@@ -726,14 +769,48 @@ void enqueue_half_seed(mi355rec* h, bool q8, const float* qptr, const QueryArg& 
         hipLaunchKernelGGL((seed_half_kernel<false>), dim3(h->hg.seed_grid), dim3(kHalfSeedBlock), 0, s, h->d_feats, h->d_half,
                            h->n, h->hg.seed_stride, h->row_base, qa, kNoQueryPtr, exclude_global, seed_out);
     }
+#endif
+}
+
+// The same for a query alone over the fp32 rows (kernels.hip.h, seed_f32_kernel): the regions' last workgroup leaves the
+// bound in `ctl`, the neighbourhood workgroup its own in seed_buf[kNbhdSlot].  `*ctl_done` is what ctl->done holds (the
+// counter is never reset).  Returns whether a sample (hence a bound in `ctl`) was enqueued.
+bool enqueue_f32_seed(mi355rec* h, const float* qptr, const float* query12, int64_t exclude_global, int topn,
+                      unsigned long long* seed_buf, SeedCtl* ctl, unsigned* ctl_done, uint32_t epoch, hipStream_t s) {
+    NextSeed sd;
+    std::memset(&sd, 0, sizeof sd);
+    sd.query_ptr = qptr;
+    if (!qptr) std::memcpy(sd.q, query12, sizeof sd.q);
+    sd.exclude_global = exclude_global;
+    sd.out = seed_buf;
+    sd.regions = h->fg.seed_grid;
+    sd.n_wgs = h->fg.seed_grid;
+    sd.stride_rows = h->fg.seed_stride;
+    sd.ctl = sd.regions > 0 ? ctl : nullptr;
+    sd.topk = topn;
+    sd.epoch = epoch;
+    sd.done_base = *ctl_done + (h->dbg_no_last ? 0x40000000u : 0u);
+    sd.debug_skip = h->dbg_skip_regions;
+    sd.nbhd = nbhd_applies(h, exclude_global) ? 1 : 0;
+    if (sd.regions + sd.nbhd <= 0) return false;
+    hipLaunchKernelGGL(seed_f32_kernel, dim3(sd.regions + sd.nbhd), dim3(kHalfSeedBlock), 0, s, h->d_feats, h->n, h->row_base, sd);
+    if (sd.regions > 0) {
+        *ctl_done += static_cast<unsigned>(sd.regions);
+        h->dbg_no_last = false;   // (test hooks of mi355rec_debug_handoff: they apply to ONE sampling launch)
+        h->dbg_skip_regions = 0;
+    }
+    return sd.regions > 0;
 }
 
 // Enqueue the scan for one query.  qptr != null: the kernel reads the query's 12 floats from there
 // (a resident row, or any other device-readable address).
 // *n_lists = per-workgroup lists it leaves in d_block_lists.
 // lone != null (a lone query whose caller waits on the host): over the 8-bit replica of a large shard the launch
-// also merges its own lists into lone's buffers (kernels.hip.h, lone_tail) and *fused is set.
+// also merges its own lists into lone's buffers (merge.hip.h, lone_tail) and *fused is set.
 constexpr int64_t kLoneFusedMinRows = 4000000;
+// A query alone over the fp32 rows gets a sample launch of its own (~5 us) from here up: below, the scan is a dozen
+// microseconds and launch-bound.
+constexpr int64_t kF32LoneSeedMinRows = 4000000;
 // (Round 4 had a LONE synchronous query below 1.5 M rows read the fp32 rows — two launches against the replica's three
 // were worth more than the bytes: 27.3 against 29.7 us at 1 M rows.  Once the 8-bit scan's prologue had been fixed —
 // sample requested before the first tile, one LDS atomic per wave in its selection — the replica won from 1 M rows up
@@ -748,67 +825,70 @@ int enqueue_scan(mi355rec* h, const float* qptr, const float* query12,
     if (!qptr) std::memcpy(qa.q, query12, sizeof qa.q);
     const PrevMerge none{nullptr, 0, 0, nullptr};
     const LoneTail no_tail{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}};
+    NextSeed no_next;
+    std::memset(&no_next, 0, sizeof no_next);
     if (fused) *fused = false;
-    if (use_half(h, upper_dev)) {
-        NextSeed no_next;
-        std::memset(&no_next, 0, sizeof no_next);
+    const int kind = single_kind(h, upper_dev);
+    if (kind == kQ8) {
         ++h->half_scans;
-        if (use_q8(h)) {
-            *n_lists = h->qg.grid;
-            ++h->q8_scans;
-            const uint32_t epoch = next_epoch(h);
-            enqueue_half_seed(h, true, qptr, qa, exclude_global, h->d_half_seed, epoch, s);
-            const int q8_seeds = (q8_exact_sample(h) ? -1 : 1) * h->qg.seed_grid * kHalfSeedWaves;   // (negative: exact values)
-            const unsigned long long* const no_cutoff = nullptr;
-            if (lone && h->n >= kLoneFusedMinRows) {
-                ++h->routes.q8_lone;
-                // the arrival counters of the launch's tail count up and are never reset: this launch starts from ...
-                LoneTail tail = *lone;
-                const unsigned grid = static_cast<unsigned>(h->qg.grid);
-                for (unsigned g = 0; g < 8u; ++g) {
-                    tail.base[g] = h->lone_base[g];
-                    h->lone_base[g] += lone_tail_members(grid, g);
-                }
-                tail.base[8] = h->lone_base[8];
-                h->lone_base[8] += lone_tail_groups(grid);
-                if (qptr) {
-                    LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, true, false, true>),
-                                 dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
-                                 h->d_feats, h->d_q8, h->n, h->qg.iters, h->row_base, qa, qptr, exclude_global, topn,
-                                 h->d_block_lists, h->d_half_seed, q8_seeds, h->d_half_rescored, none, no_next,
-                                 no_cutoff, tail, epoch);
-                } else {
-                    LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, false, false, true>),
-                                 dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
-                                 h->d_feats, h->d_q8, h->n, h->qg.iters, h->row_base, qa, kNoQueryPtr, exclude_global, topn,
-                                 h->d_block_lists, h->d_half_seed, q8_seeds, h->d_half_rescored, none, no_next,
-                                 no_cutoff, tail, epoch);
-                }
-                HIP_TRY(h, hipGetLastError());
-                *fused = true;
-                return MI355REC_OK;
-            }
-            ++h->routes.q8;
+        *n_lists = h->qg.grid;
+        ++h->q8_scans;
+        const uint32_t epoch = next_epoch(h);
+        enqueue_half_seed(h, kQ8, qptr, qa, exclude_global, topn, h->d_half_seed, epoch, s);
+        const int q8_seeds = (q8_exact_sample(h) ? -1 : 1) * h->qg.seed_grid * kHalfSeedWaves;   // (negative: exact values)
+        const unsigned long long* const no_cutoff = nullptr;
+        if (lone && h->n >= kLoneFusedMinRows) {
+            ++h->routes.q8_lone;
+            // the arrival counters of the launch's tail count up and are never reset: this launch starts from ...
+            LoneTail tail = *lone;
+            const unsigned grid = static_cast<unsigned>(h->qg.grid);
+            for (unsigned g = 0; g < 8u; ++g) tail.base[g] = h->lone_base[g];
+            tail.base[8] = h->lone_base[8];
             if (qptr) {
-                LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, true, false>),
+                LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, true, false, true>),
                              dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
                              h->d_feats, h->d_q8, h->n, h->qg.iters, h->row_base, qa, qptr, exclude_global, topn,
                              h->d_block_lists, h->d_half_seed, q8_seeds, h->d_half_rescored, none, no_next,
-                             no_cutoff, no_tail, epoch);
+                             no_cutoff, tail, epoch);
             } else {
-                LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, false, false>),
+                LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, false, false, true>),
                              dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
                              h->d_feats, h->d_q8, h->n, h->qg.iters, h->row_base, qa, kNoQueryPtr, exclude_global, topn,
                              h->d_block_lists, h->d_half_seed, q8_seeds, h->d_half_rescored, none, no_next,
-                             no_cutoff, no_tail, epoch);
+                             no_cutoff, tail, epoch);
             }
             HIP_TRY(h, hipGetLastError());
+            // (the books move only once the launch is known to have been accepted: a refused launch leaves host and
+            // device counters in step)
+            for (unsigned g = 0; g < 8u; ++g) h->lone_base[g] += lone_tail_members(grid, g);
+            h->lone_base[8] += lone_tail_groups(grid);
+            *fused = true;
             return MI355REC_OK;
         }
+        ++h->routes.q8;
+        if (qptr) {
+            LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, true, false>),
+                         dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
+                         h->d_feats, h->d_q8, h->n, h->qg.iters, h->row_base, qa, qptr, exclude_global, topn,
+                         h->d_block_lists, h->d_half_seed, q8_seeds, h->d_half_rescored, none, no_next,
+                         no_cutoff, no_tail, epoch);
+        } else {
+            LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, false, false>),
+                         dim3(h->qg.grid), dim3(Q8Config::kBlock), s,
+                         h->d_feats, h->d_q8, h->n, h->qg.iters, h->row_base, qa, kNoQueryPtr, exclude_global, topn,
+                         h->d_block_lists, h->d_half_seed, q8_seeds, h->d_half_rescored, none, no_next,
+                         no_cutoff, no_tail, epoch);
+        }
+        HIP_TRY(h, hipGetLastError());
+        return MI355REC_OK;
+    }
+#ifdef MI355REC_EXPERIMENTS
+    if (kind == kFp16) {
+        ++h->half_scans;
         *n_lists = h->hg.grid;
         ++h->routes.fp16;
         uint32_t* const half_seed = reinterpret_cast<uint32_t*>(h->d_half_seed);   // (the fp16 scan's plain sample values)
-        enqueue_half_seed(h, false, qptr, qa, exclude_global, h->d_half_seed, 0u, s);
+        enqueue_half_seed(h, kFp16, qptr, qa, exclude_global, topn, h->d_half_seed, 0u, s);
         if (qptr) {
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, true, false>),
                          dim3(h->hg.grid), dim3(HalfConfig::kBlock), s,
@@ -823,20 +903,32 @@ int enqueue_scan(mi355rec* h, const float* qptr, const float* query12,
         HIP_TRY(h, hipGetLastError());
         return MI355REC_OK;
     }
+#endif
     *n_lists = h->grid;
     ++h->routes.fp32;
+    // The launch-wide bound (kernels.hip.h): on shards where ~5 us are worth it, and never for the later rounds of
+    // topn > 1024 (they look for keys BELOW the round before: a lower bound on the best keys says nothing there).
+    const unsigned long long* bound = nullptr;
+    const unsigned long long* sample = nullptr;
+    uint32_t epoch = 0u;
+    if (!upper_dev && h->n >= kF32LoneSeedMinRows) {
+        epoch = next_epoch(h);
+        if (enqueue_f32_seed(h, qptr, query12, exclude_global, topn, h->d_half_seed, h->d_lone_ctl, &h->lone_ctl_done, epoch, s))
+            bound = &h->d_lone_ctl->cutoff;
+        sample = h->d_half_seed;
+    }
     if (qptr) {
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_kernel<ScanConfig, true, false>),
                      dim3(h->grid), dim3(kScanBlock), s,
                      h->d_feats, h->n, h->rows_per_block, h->iters, h->row_base, qa,
                      qptr, exclude_global, topn, h->d_block_lists,
-                     static_cast<float*>(nullptr), upper_dev, none);
+                     static_cast<float*>(nullptr), upper_dev, none, bound, sample, epoch, no_next);
     } else {
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_kernel<ScanConfig, false, false>),
                      dim3(h->grid), dim3(kScanBlock), s,
                      h->d_feats, h->n, h->rows_per_block, h->iters, h->row_base, qa,
                      kNoQueryPtr, exclude_global, topn, h->d_block_lists,
-                     static_cast<float*>(nullptr), upper_dev, none);
+                     static_cast<float*>(nullptr), upper_dev, none, bound, sample, epoch, no_next);
     }
     HIP_TRY(h, hipGetLastError());
     return MI355REC_OK;
@@ -921,9 +1013,17 @@ int enqueue_multi(mi355rec* h, const float* queries, const int64_t* exclude, int
 // its candidates) moves half the bytes but its bound is 25x the fp16 one: ~1 % of the (row, query) pairs come
 // back as candidates, 3.7 us per query of a pass against 0.85 us (measured, 10 M rows: 1 query 36.9 vs 44.1 us,
 // 2: 41.9 vs 44.7, 12: 82 vs 53, 32: 152 vs 71).  So: passes of one or two queries, or when forced.
+// Round 5: the front end is an A/B route of experiment builds (its one AUTO cell, passes of two queries, was worth
+// 2.6 us per call and a second instantiation of the pass kernel to keep bit-identical).
 bool multi_front_q8(const mi355rec* h, int nq) {
+#ifdef MI355REC_EXPERIMENTS
     if (!use_q8(h) || h->batch_path == MI355REC_BATCH_HALF) return false;
     return h->batch_path == MI355REC_BATCH_Q8 || nq <= 2;
+#else
+    (void)h;
+    (void)nq;
+    return false;
+#endif
 }
 
 bool half_multi_ok(const mi355rec* h, int topn) {
@@ -956,9 +1056,7 @@ void fill_half_multi_arg(HalfMultiArg& arg, float margin, const float* queries, 
 int hm_sample_log2(const mi355rec* h, int nq, bool riding) {
     int l = nq >= 12 ? 2 : nq >= 5 ? 1 : 0;
     if (riding && l > 1) l = 1;
-#ifdef MI355REC_EXPERIMENTS
-    if (const char* e = std::getenv("MI355REC_EXP_SAMPLE_LOG2")) l = std::atoi(e) & 3;
-#endif
+    MI355REC_EXP_INT(l, "MI355REC_EXP_SAMPLE_LOG2", 0, 3);
     while (l > 0 && (static_cast<int64_t>(1024) << l) > h->hg.seed_stride) --l;
     return l;
 }
@@ -975,20 +1073,25 @@ int enqueue_half_multi(mi355rec* h, const float* queries, const float* const* qp
         const uint32_t epoch = next_epoch(h);
         // the sample launch's last workgroup selects the cutoffs; the pass reads them (stream order)
         const unsigned long long* const cuts = h->d_half_mcuts;
-        hipLaunchKernelGGL(seed_half_multi_kernel, dim3(h->hg.seed_grid), dim3(kHmBlock), 0, s, h->d_half, h->n, h->hg.seed_stride,
-                           arg, nq, h->d_half_mseed, epoch, hm_sample_log2(h, nq, false), h->d_half_mctl,
+        // (+ one workgroup per query for its neighbourhood's bound: handoff.hip.h)
+        hipLaunchKernelGGL(seed_half_multi_kernel, dim3(h->hg.seed_grid + nq), dim3(kHmBlock), 0, s, h->d_feats, h->d_half, h->n, h->row_base,
+                           h->hg.seed_stride, arg, nq, h->hg.seed_grid, h->d_half_mseed, epoch, hm_sample_log2(h, nq, false), h->d_half_mctl,
                            h->half_mctl_done + (h->dbg_no_last ? 0x40000000u : 0u), h->d_half_mcuts, topn, h->dbg_skip_regions);
+        HIP_TRY(h, hipGetLastError());
         h->half_mctl_done += static_cast<unsigned>(h->hg.seed_grid);
         h->dbg_no_last = false;   // (test hooks of mi355rec_debug_handoff: they apply to ONE sampling launch)
         h->dbg_skip_regions = 0;
         ++h->half_scans;
+#ifdef MI355REC_EXPERIMENTS
         if (multi_front_q8(h, nq)) {   // rows from the 8-bit replica through the integer matrix core (replica_multi.hip.h)
             ++h->q8_scans;
             ++h->routes.multi_q8;
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<false, true>), dim3(h->hg.grid),
                          dim3(kHmBlock), s, h->d_feats, h->d_half, reinterpret_cast<const uint32_t*>(h->d_q8), h->n, h->row_base, arg, nq,
                          g0, topn, h->d_block_lists, h->d_half_mseed, n_seed, h->d_half_rescored, no_ride, arg, cuts, epoch);
-        } else {
+        } else
+#endif
+        {
             ++h->routes.multi_fp16;
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<false, false>), dim3(h->hg.grid),
                          dim3(kHmBlock), s, h->d_feats, h->d_half, static_cast<const uint32_t*>(nullptr), h->n, h->row_base, arg, nq,
@@ -1015,11 +1118,12 @@ int enqueue_half_multi(mi355rec* h, const float* queries, const float* const* qp
 constexpr int kHmRiders = 16;       // seed riders per 1024 rows of a sampled region: a rider's wave gets through a 128-row
                                     // chunk every ~2 us beside a pass (as a scanner's does), 16 (or 32) of them take 33 us
 constexpr int kHmMergesPerWg = 3;   // queries of the previous batch one merging workgroup takes, one after the other (~10 us each)
+constexpr int kHmNbhdPerWg = 4;     // queries of the next batch one neighbourhood workgroup takes, one after the other (~4 us each)
 
 int ensure_mstream(mi355rec* h) {
     if (h->mstream_ready) return MI355REC_OK;
     const size_t list_bytes = sizeof(uint64_t) * static_cast<size_t>(kHmQueries) * h->hg.grid * kMultiMaxTopK;
-    const size_t seed_bytes = sizeof(unsigned long long) * static_cast<size_t>(kHmQueries) * kHalfSeedMaxGrid * kHalfSeedWaves;
+    const size_t seed_bytes = sizeof(unsigned long long) * static_cast<size_t>(kHmSampleSlots);
     hipError_t e = hipSuccess;
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
         e = hipMalloc(&h->d_mstream_lists[i], list_bytes);
@@ -1067,10 +1171,9 @@ int launch_mstash(mi355rec* h, hipStream_t s, const HalfMultiArg* next, int next
     if (next) {
         ride.sample_log2 = hm_sample_log2(h, next_nq, true);
         ride.seed_wgs = kHmRiders << ride.sample_log2;
-#ifdef MI355REC_EXPERIMENTS
-        if (const char* e = std::getenv("MI355REC_EXP_RIDERS")) ride.seed_wgs = std::atoi(e) > 0 ? std::atoi(e) : ride.seed_wgs;
-#endif
+        MI355REC_EXP_INT(ride.seed_wgs, "MI355REC_EXP_RIDERS", 1, 512);
         if (ride.seed_wgs > h->hg.seed_grid) ride.seed_wgs = h->hg.seed_grid;
+        ride.nb_wgs = (next_nq + kHmNbhdPerWg - 1) / kHmNbhdPerWg;
         ride.next_queries = next_nq;
         ride.regions = h->hg.seed_grid;
         ride.stride_rows = h->hg.seed_stride;
@@ -1081,33 +1184,37 @@ int launch_mstash(mi355rec* h, hipStream_t s, const HalfMultiArg* next, int next
         ride.next_epoch = next_epoch_tag;
         // the riders' arrival counter counts up and is never reset: this launch's riders start from ...
         ride.done_base = h->mctl_done[next_buf] + (h->dbg_no_last ? 0x40000000u : 0u);
-        h->mctl_done[next_buf] += static_cast<unsigned>(ride.seed_wgs);
         ride.debug_skip = h->dbg_skip_regions;
         h->dbg_no_last = false;
         h->dbg_skip_regions = 0;
     }
     const unsigned long long* cuts_ready = st.cuts_ready ? h->d_mstream_cuts + st.seed_buf * kHmQueries : nullptr;
     // the launch stays within one resident wave of workgroups: the riders and mergers take scanner slots
-    int scanners = h->hg.grid - ride.merge_wgs - ride.seed_wgs;
+    const int others = ride.merge_wgs + ride.seed_wgs + ride.nb_wgs;
+    int scanners = h->hg.grid - others;
     if (scanners < 1) scanners = 1;
     ++h->half_scans;
+#ifdef MI355REC_EXPERIMENTS
     if (multi_front_q8(h, st.nq)) {
         ++h->q8_scans;
         ++h->routes.multi_q8;
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<true, true>),
-                     dim3(scanners + ride.merge_wgs + ride.seed_wgs), dim3(kHmBlock), s, h->d_feats, h->d_half,
+                     dim3(scanners + others), dim3(kHmBlock), s, h->d_feats, h->d_half,
                      reinterpret_cast<const uint32_t*>(h->d_q8), h->n, h->row_base,
                      st.arg, st.nq, 0, st.topn, h->d_mstream_lists[buf], h->d_mstream_seed[st.seed_buf],
                      h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, ride, next ? *next : st.arg, cuts_ready, st.epoch);
-    } else {
+    } else
+#endif
+    {
         ++h->routes.multi_fp16;
         LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_multi_kernel<true, false>),
-                     dim3(scanners + ride.merge_wgs + ride.seed_wgs), dim3(kHmBlock), s, h->d_feats, h->d_half,
+                     dim3(scanners + others), dim3(kHmBlock), s, h->d_feats, h->d_half,
                      static_cast<const uint32_t*>(nullptr), h->n, h->row_base,
                      st.arg, st.nq, 0, st.topn, h->d_mstream_lists[buf], h->d_mstream_seed[st.seed_buf],
                      h->hg.seed_grid * kHalfSeedWaves, h->d_half_rescored, ride, next ? *next : st.arg, cuts_ready, st.epoch);
     }
     HIP_TRY(h, hipGetLastError());
+    if (next) h->mctl_done[next_buf] += static_cast<unsigned>(ride.seed_wgs);   // (the books move once the launch has been accepted)
     h->mpending.has = true;
     h->mpending.buf = buf;
     h->mpending.nq = st.nq;
@@ -1151,10 +1258,10 @@ int enqueue_mstream(mi355rec* h, const float* queries, const float* const* qptrs
         if (rc) return rc;
         cuts_ready = h->hg.seed_grid > 0;   // (launch_mstash gave the launch seed riders)
     } else {   // the head of a stream: a sample launch of its own
-        hipLaunchKernelGGL(seed_half_multi_kernel, dim3(h->hg.seed_grid), dim3(kHmBlock), 0, s, h->d_half, h->n, h->hg.seed_stride,
-                           arg, nq, h->d_mstream_seed[seed_buf], epoch, hm_sample_log2(h, nq, false), h->d_mstream_ctl + seed_buf,
-                           h->mctl_done[seed_buf] + (h->dbg_no_last ? 0x40000000u : 0u), h->d_mstream_cuts + seed_buf * kHmQueries, topn,
-                           h->dbg_skip_regions);
+        hipLaunchKernelGGL(seed_half_multi_kernel, dim3(h->hg.seed_grid + nq), dim3(kHmBlock), 0, s, h->d_feats, h->d_half, h->n, h->row_base,
+                           h->hg.seed_stride, arg, nq, h->hg.seed_grid, h->d_mstream_seed[seed_buf], epoch, hm_sample_log2(h, nq, false),
+                           h->d_mstream_ctl + seed_buf, h->mctl_done[seed_buf] + (h->dbg_no_last ? 0x40000000u : 0u),
+                           h->d_mstream_cuts + seed_buf * kHmQueries, topn, h->dbg_skip_regions);
         HIP_TRY(h, hipGetLastError());
         h->mctl_done[seed_buf] += static_cast<unsigned>(h->hg.seed_grid);
         h->dbg_no_last = false;
@@ -1235,9 +1342,12 @@ int wait_done(mi355rec* h, uint32_t want) {
 }
 
 // ---- streamed single queries -------------------------------------------------------
-// scan(k+1) and merge(k) share one launch: workgroup 0 merges the previous query's lists,
-// the others scan.  One scanning workgroup fewer than the plain scan uses, so the launch
-// still fits the chip in one wave of workgroups.
+// A stream of single queries runs ONE CALL BEHIND: query k is launched by call k + 1 (or by the flush), and its launch
+// carries, beside the scanners, the merger of query k - 1's lists (one workgroup) and — where the launch can spare
+// them — the seed riders and the neighbourhood workgroup of query k + 1 (handoff.hip.h), so that every launch starts
+// from a launch-wide bound without a sample launch of its own.  That holds for all three kinds of rows a scan can
+// stream (fp32, 8-bit replica; fp16 replica in experiment builds).  One scanning workgroup fewer than the plain scan
+// uses per non-scanning one, so the launch still fits the chip in one wave of workgroups.
 int ensure_streamed_alloc(mi355rec* h);
 int ensure_streamed(mi355rec* h) {
     if (h->streamed_ready) return MI355REC_OK;
@@ -1254,19 +1364,7 @@ int ensure_streamed(mi355rec* h) {
 }
 
 int ensure_streamed_alloc(mi355rec* h) {
-    const int64_t tiles = (h->n + kScanTileRows - 1) / kScanTileRows;
-    int g = h->grid > 1 ? h->grid - 1 : 1;
-    if (g > kRideMaxLists - 1) g = kRideMaxLists - 1;
-#ifdef MI355REC_EXPERIMENTS
-    if (const char* e = std::getenv("MI355REC_EXP_SGRID")) {
-        const int v = std::atoi(e);
-        if (v >= 1 && v < g) g = v;
-    }
-#endif
-    if (tiles < g) g = static_cast<int>(tiles);
-    h->sgrid = g;
-    h->siters = static_cast<int>((tiles + g - 1) / g);
-    int most = g > h->hg.sgrid ? g : h->hg.sgrid;
+    int most = h->sgrid > h->hg.sgrid ? h->sgrid : h->hg.sgrid;
     if (h->qg.sgrid > most) most = h->qg.sgrid;
     for (int i = 0; i < 2; ++i)
         HIP_TRY(h, hipMalloc(&h->d_stream_lists[i], sizeof(uint64_t) * static_cast<size_t>(most) * kMaxTopK));
@@ -1287,11 +1385,29 @@ int flush_streamed(mi355rec* h, hipStream_t s) {
                          h->pending_out, nullptr, nullptr, s);
 }
 
-// Launches the stashed streamed query over the replica: scanners + the riding merger of the query
-// before it + (with_next) the seed riders of the query after it.
+// How many seed riders a streamed launch over `kind` rows carries for the NEXT query, and whether their last one
+// leaves that query's bound (cutoff) in d_stream_ctl.
+int stream_riders(const mi355rec* h, int kind) { return kind == kFp32 ? h->fg.riders : (kind == kQ8 ? h->qg.riders : h->hg.riders); }
+bool stream_hoists(const mi355rec* h, int kind) {
+    return kind == kFp32 ? h->fg.riders > 0 : (kind == kQ8 ? q8_hoists(h) : false);
+}
+// ... and whether the launch has a workgroup for the next query's neighbourhood at all.
+bool stream_nbhd(const mi355rec* h, int kind) { return kind == kFp32 ? h->fg.nbhd != 0 : (kind == kQ8 ? h->qg.riders > 0 : false); }
+
+// Launches the stashed streamed query: scanners + the riding merger of the query before it + (with_next) the seed
+// riders and the neighbourhood workgroup of the query after it.
 int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, const float* next_ptr, const float* next_q,
                    int64_t next_exclude, int next_topn, int next_buf, uint32_t next_epoch_tag) {
     auto& st = h->stashed;
+    // The fp32 scan's riding merger keeps 2048 survivors; with ~770 lists and topN near 1000 about
+    // 2.2 topN keys survive its first cut, and an overflow drops into the exact radix select over all
+    // keys in global memory (correct, ~1 ms).  Such a query's merge gets its own launch instead.
+    if (st.kind == kFp32 && h->pending && h->pending_topn > kRideTopnMax) {
+        h->pending = false;
+        const int rc = enqueue_merge(h, h->d_stream_lists[h->pending_buf], h->pending_lists, h->pending_topn, h->pending_topn,
+                                     h->pending_out, nullptr, nullptr, s);
+        if (rc) return rc;
+    }
     const int buf = h->pending ? 1 - h->pending_buf : 0;
     PrevMerge prev{nullptr, 0, 0, nullptr};
     if (h->pending) prev = PrevMerge{h->d_stream_lists[h->pending_buf], h->pending_lists, h->pending_topn, h->pending_out};
@@ -1299,69 +1415,108 @@ int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, const float* next
     std::memset(&next, 0, sizeof next);
     next.query_ptr = nullptr;
     next.exclude_global = -1;
-    const ReplicaGeom& g = st.q8 ? h->qg : h->hg;
-    int scanners = g.sgrid, iters = g.siters;
-    if (with_next && g.riders > 0) {
+    int scanners, iters;
+    if (st.kind == kFp32) {
+        scanners = h->sgrid;
+        iters = h->siters;
+    } else {
+        const ReplicaGeom& g = st.kind == kQ8 ? h->qg : h->hg;
+        scanners = g.sgrid;
+        iters = g.siters;
+    }
+    unsigned riders_arriving = 0u;
+    if (with_next && (stream_riders(h, st.kind) > 0 || stream_nbhd(h, st.kind))) {
         next.query_ptr = next_ptr;
         if (!next_ptr) std::memcpy(next.q, next_q, sizeof next.q);
         next.exclude_global = next_exclude;
         next.out = h->d_stream_seed[next_buf];
-        next.n_wgs = g.riders;
-        next.regions = g.seed_grid;
-        next.stride_rows = g.seed_stride;
-        next.ctl = (st.q8 && q8_hoists(h)) ? h->d_stream_ctl + next_buf : nullptr;
+        next.n_wgs = stream_riders(h, st.kind);
+        next.nbhd = stream_nbhd(h, st.kind) ? 1 : 0;   // (it stores its slot even when the excluded row is not of this shard)
+        if (st.kind == kFp32) {
+            next.regions = h->fg.seed_grid;
+            next.stride_rows = h->fg.seed_stride;
+            scanners = h->fg.r_scan;
+            iters = h->fg.r_iters;
+        } else {
+            const ReplicaGeom& g = st.kind == kQ8 ? h->qg : h->hg;
+            next.regions = g.seed_grid;
+            next.stride_rows = g.seed_stride;
+            scanners = g.r_scan;
+            iters = g.r_iters;
+        }
+        next.ctl = (next.n_wgs > 0 && stream_hoists(h, st.kind)) ? h->d_stream_ctl + next_buf : nullptr;
         next.topk = next_topn;
-        next.exact = st.q8 && q8_exact_sample(h);
+        next.exact = st.kind == kQ8 && q8_exact_sample(h);
         next.epoch = next_epoch_tag;
         if (next.ctl) {   // the riders' arrival counter counts up and is never reset: this launch's riders start from ...
             next.done_base = h->ctl_done[next_buf] + (h->dbg_no_last ? 0x40000000u : 0u);
-            h->ctl_done[next_buf] += static_cast<unsigned>(g.riders);
+            riders_arriving = static_cast<unsigned>(next.n_wgs);
         }
         next.debug_skip = h->dbg_skip_regions;
         h->dbg_no_last = false;
         h->dbg_skip_regions = 0;
-        scanners = g.r_scan;
-        iters = g.r_iters;
     }
     QueryArg qa;
     std::memset(&qa, 0, sizeof qa);
     qa.margin = h->margin_mix;
-    const int n_seed = g.seed_grid * kHalfSeedWaves;
-    ++h->half_scans;
-    if (st.q8) {
+    if (!st.qptr) std::memcpy(qa.q, st.q, sizeof qa.q);
+    const dim3 grid(static_cast<unsigned>(scanners + 1 + next.n_wgs + next.nbhd));
+    unsigned long long* const my_seed = h->d_stream_seed[st.seed_buf];
+    const unsigned long long* ready = st.cutoff_ready ? &h->d_stream_ctl[st.seed_buf].cutoff : nullptr;
+    if (st.kind == kQ8) {
+        ++h->half_scans;
         ++h->q8_scans;
         ++h->routes.q8;
-        const unsigned long long* ready = st.cutoff_ready ? &h->d_stream_ctl[st.seed_buf].cutoff : nullptr;
+        const int n_seed = h->qg.seed_grid * kHalfSeedWaves;
         const int q8_seeds = q8_exact_sample(h) ? -n_seed : n_seed;   // (negative: exact values)
+        const LoneTail no_tail{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}};
         if (st.qptr) {
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, true, true>),
-                         dim3(scanners + 1 + next.n_wgs), dim3(Q8Config::kBlock), s,
+                         grid, dim3(Q8Config::kBlock), s,
                          h->d_feats, h->d_q8, h->n, iters, h->row_base, qa, st.qptr, st.exclude, st.topn,
-                         h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], q8_seeds, h->d_half_rescored, prev, next, ready,
-                         LoneTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}}, st.epoch);
+                         h->d_stream_lists[buf], my_seed, q8_seeds, h->d_half_rescored, prev, next, ready, no_tail, st.epoch);
         } else {
-            std::memcpy(qa.q, st.q, sizeof qa.q);
             LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_q8_kernel<Q8Config, false, true>),
-                         dim3(scanners + 1 + next.n_wgs), dim3(Q8Config::kBlock), s,
+                         grid, dim3(Q8Config::kBlock), s,
                          h->d_feats, h->d_q8, h->n, iters, h->row_base, qa, kNoQueryPtr, st.exclude, st.topn,
-                         h->d_stream_lists[buf], h->d_stream_seed[st.seed_buf], q8_seeds, h->d_half_rescored, prev, next, ready,
-                         LoneTail{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}}, st.epoch);
+                         h->d_stream_lists[buf], my_seed, q8_seeds, h->d_half_rescored, prev, next, ready, no_tail, st.epoch);
         }
-    } else if (st.qptr) {
+#ifdef MI355REC_EXPERIMENTS
+    } else if (st.kind == kFp16) {
+        ++h->half_scans;
         ++h->routes.fp16;
-        LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, true, true>),
-                     dim3(scanners + 1 + next.n_wgs), dim3(HalfConfig::kBlock), s,
-                     h->d_feats, h->d_half, h->n, iters, h->row_base, qa, st.qptr, st.exclude, st.topn,
-                     h->d_stream_lists[buf], reinterpret_cast<uint32_t*>(h->d_stream_seed[st.seed_buf]), n_seed, h->d_half_rescored, prev, next);
+        const int n_seed = h->hg.seed_grid * kHalfSeedWaves;
+        if (st.qptr) {
+            LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, true, true>),
+                         grid, dim3(HalfConfig::kBlock), s,
+                         h->d_feats, h->d_half, h->n, iters, h->row_base, qa, st.qptr, st.exclude, st.topn,
+                         h->d_stream_lists[buf], reinterpret_cast<uint32_t*>(my_seed), n_seed, h->d_half_rescored, prev, next);
+        } else {
+            LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, false, true>),
+                         grid, dim3(HalfConfig::kBlock), s,
+                         h->d_feats, h->d_half, h->n, iters, h->row_base, qa, kNoQueryPtr, st.exclude, st.topn,
+                         h->d_stream_lists[buf], reinterpret_cast<uint32_t*>(my_seed), n_seed, h->d_half_rescored, prev, next);
+        }
+#endif
     } else {
-        ++h->routes.fp16;
-        std::memcpy(qa.q, st.q, sizeof qa.q);
-        LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_half_kernel<HalfConfig, false, true>),
-                     dim3(scanners + 1 + next.n_wgs), dim3(HalfConfig::kBlock), s,
-                     h->d_feats, h->d_half, h->n, iters, h->row_base, qa, kNoQueryPtr, st.exclude, st.topn,
-                     h->d_stream_lists[buf], reinterpret_cast<uint32_t*>(h->d_stream_seed[st.seed_buf]), n_seed, h->d_half_rescored, prev, next);
+        ++h->routes.fp32;
+        if (st.qptr) {
+            LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_kernel<ScanConfig, true, false, 0, true>),
+                         grid, dim3(kScanBlock), s,
+                         h->d_feats, h->n, static_cast<int64_t>(0), iters, h->row_base, qa, st.qptr,
+                         st.exclude, st.topn, h->d_stream_lists[buf], static_cast<float*>(nullptr),
+                         static_cast<const uint64_t*>(nullptr), prev, ready, my_seed, st.epoch, next);
+        } else {
+            LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_kernel<ScanConfig, false, false, 0, true>),
+                         grid, dim3(kScanBlock), s,
+                         h->d_feats, h->n, static_cast<int64_t>(0), iters, h->row_base, qa, kNoQueryPtr,
+                         st.exclude, st.topn, h->d_stream_lists[buf], static_cast<float*>(nullptr),
+                         static_cast<const uint64_t*>(nullptr), prev, ready, my_seed, st.epoch, next);
+        }
     }
     HIP_TRY(h, hipGetLastError());
+    // (the books move only once the launch is known to have been accepted)
+    if (riders_arriving) h->ctl_done[next_buf] += riders_arriving;
     h->pending = true;
     h->pending_buf = buf;
     h->pending_topn = st.topn;
@@ -1379,84 +1534,52 @@ int enqueue_streamed(mi355rec* h, const float* qptr, const float* query12, int64
     if (rc) return rc;
     rc = flush_mstream(h, s);   // a stream of BATCHES on this handle is closed first
     if (rc) return rc;
-#ifdef MI355REC_EXPERIMENTS
-    static const bool exp_nomerge = std::getenv("MI355REC_EXP_RIDE_NOMERGE") != nullptr;
-    if (h->pending && exp_nomerge) {
+    if (MI355REC_EXP_FLAG("MI355REC_EXP_RIDE_NOMERGE") && h->pending) {
         rc = flush_streamed(h, s);
         if (rc) return rc;
     }
-#endif
-    QueryArg qa;
-    std::memset(&qa, 0, sizeof qa);
-    qa.margin = h->margin_mix;
-    if (use_half(h, nullptr)) {
-        // One call behind: the query of the PREVIOUS call is launched now, and its launch takes the
-        // sample of this one (seed riders).  The first query of a stream needs a seed launch of its own.
-        int seed_buf = 0;
-        bool sampled = false;
-        const bool q8 = use_q8(h);
-        const uint32_t epoch = next_epoch(h);   // the tag of this query's sample values and cutoff
-        if (h->stashed.has) {
-            seed_buf = 1 - h->stashed.seed_buf;
-            // the riders of a launch sample the replica that launch scans: a change of replica
-            // (mi355rec_set_replica) between two calls costs the next query a seed launch of its own
-            sampled = h->stashed.q8 == q8 && (q8 ? h->qg.riders : h->hg.riders) > 0;
-            rc = launch_stashed(h, s, sampled, qptr, query12, exclude_global, topn, seed_buf, epoch);
-            if (rc) return rc;
-        }
-        if (!sampled && (q8 ? h->qg.seed_grid : h->hg.seed_grid) > 0) {   // first query of a stream, or a shard too small to spare riders
+    // One call behind: the query of the PREVIOUS call is launched now, and its launch takes the sample and the
+    // neighbourhood of this one.  The first query of a stream needs a sample launch of its own.
+    const int kind = single_kind(h, nullptr);
+    int seed_buf = 0;
+    bool sampled = false, nbhd_taken = false;
+    const uint32_t epoch = next_epoch(h);   // the tag of this query's sample values and bound
+    if (h->stashed.has) {
+        seed_buf = 1 - h->stashed.seed_buf;
+        // the riders of a launch sample the rows that launch scans: a change of rows (mi355rec_set_replica) between two
+        // calls costs the next query a sample launch of its own
+        const bool same = h->stashed.kind == kind;
+        sampled = same && stream_riders(h, kind) > 0;
+        nbhd_taken = same && stream_nbhd(h, kind);
+        rc = launch_stashed(h, s, same, qptr, query12, exclude_global, topn, seed_buf, epoch);
+        if (rc) return rc;
+    }
+    bool bound_ready = sampled && stream_hoists(h, kind);
+    if (!sampled) {   // first query of a stream, or a shard too small to spare riders
+        if (kind == kFp32) {
+            if (h->n >= kF32LoneSeedMinRows)
+                bound_ready = enqueue_f32_seed(h, qptr, query12, exclude_global, topn, h->d_stream_seed[seed_buf], h->d_stream_ctl + seed_buf,
+                                               &h->ctl_done[seed_buf], epoch, s);
+        } else if (!nbhd_taken) {
+            QueryArg qa;
+            std::memset(&qa, 0, sizeof qa);
+            qa.margin = h->margin_mix;
             if (!qptr) std::memcpy(qa.q, query12, sizeof qa.q);
-            enqueue_half_seed(h, q8, qptr, qa, exclude_global, h->d_stream_seed[seed_buf], epoch, s);
-            HIP_TRY(h, hipGetLastError());
+            enqueue_half_seed(h, kind, qptr, qa, exclude_global, topn, h->d_stream_seed[seed_buf], epoch, s);
         }
-        auto& st = h->stashed;
-        st.has = true;
-        st.qptr = qptr;
-        if (!qptr) std::memcpy(st.q, query12, sizeof st.q);
-        st.exclude = exclude_global;
-        st.topn = topn;
-        st.out = out_keys;
-        st.seed_buf = seed_buf;
-        st.epoch = epoch;
-        st.q8 = q8;
-        st.cutoff_ready = q8 && sampled && q8_hoists(h);
-        return MI355REC_OK;
+        HIP_TRY(h, hipGetLastError());
     }
-    if (h->stashed.has) {   // the path changed under a stream (mi355rec_set_replica): the stashed query goes first
-        rc = launch_stashed(h, s, false, nullptr, nullptr, -1, 0, 0, 0u);
-        if (rc) return rc;
-    }
-    // The fp32 scan's riding merger keeps 2048 survivors; with ~770 lists and topN near 1000 about
-    // 2.2 topN keys survive its first cut, and an overflow drops into the exact radix select over all
-    // keys in global memory (correct, ~1 ms).  Such a query's merge gets its own launch instead.
-    if (h->pending && h->pending_topn > kRideTopnMax) {
-        rc = flush_streamed(h, s);
-        if (rc) return rc;
-    }
-    const int buf = h->pending ? 1 - h->pending_buf : 0;
-    PrevMerge prev{nullptr, 0, 0, nullptr};
-    if (h->pending) prev = PrevMerge{h->d_stream_lists[h->pending_buf], h->pending_lists, h->pending_topn, h->pending_out};
-    ++h->routes.fp32;
-    if (qptr) {
-        LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_kernel<ScanConfig, true, false, 0, true>),
-                     dim3(h->sgrid + 1), dim3(kScanBlock), s,
-                     h->d_feats, h->n, static_cast<int64_t>(0), h->siters, h->row_base, qa, qptr,
-                     exclude_global, topn, h->d_stream_lists[buf], static_cast<float*>(nullptr),
-                     static_cast<const uint64_t*>(nullptr), prev);
-    } else {
-        std::memcpy(qa.q, query12, sizeof qa.q);
-        LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, (scan_kernel<ScanConfig, false, false, 0, true>),
-                     dim3(h->sgrid + 1), dim3(kScanBlock), s,
-                     h->d_feats, h->n, static_cast<int64_t>(0), h->siters, h->row_base, qa, kNoQueryPtr,
-                     exclude_global, topn, h->d_stream_lists[buf], static_cast<float*>(nullptr),
-                     static_cast<const uint64_t*>(nullptr), prev);
-    }
-    HIP_TRY(h, hipGetLastError());
-    h->pending = true;
-    h->pending_buf = buf;
-    h->pending_topn = topn;
-    h->pending_out = out_keys;
-    h->pending_lists = h->sgrid;
+    auto& st = h->stashed;
+    st.has = true;
+    st.qptr = qptr;
+    if (!qptr) std::memcpy(st.q, query12, sizeof st.q);
+    st.exclude = exclude_global;
+    st.topn = topn;
+    st.out = out_keys;
+    st.seed_buf = seed_buf;
+    st.epoch = epoch;
+    st.kind = kind;
+    st.cutoff_ready = bound_ready;
     return MI355REC_OK;
 }
 
@@ -1504,12 +1627,11 @@ int ensure_bq_alloc(mi355rec* h) {
     if (grid > kBqMaxPassGrid) grid = kBqMaxPassGrid;
     b.grid = grid;
     b.grid2 = h->cus * b.occ2;
-#ifdef MI355REC_EXPERIMENTS
-    if (const char* e = std::getenv("MI355REC_BQ_STEP1")) {
-        const int v = std::atoi(e);
+    {
+        int v = b.step1;
+        MI355REC_EXP_INT(v, "MI355REC_BQ_STEP1", 1, 8);
         if (v == 1 || v == 2 || v == 4 || v == 8) b.step1 = v;
     }
-#endif
     b.qgrid = h->cus < 1024 ? h->cus : 1024;   // (the queued scan's last workgroup merges up to 1024 lists per query)
     const int64_t tiles = (h->n + MultiConfig::kTileRows - 1) / MultiConfig::kTileRows;
     if (tiles < b.qgrid) b.qgrid = static_cast<int>(tiles);
@@ -1529,6 +1651,7 @@ int ensure_bq_alloc(mi355rec* h) {
     HIP_TRY(h, hipMemsetAsync(b.counters, 0, sizeof(int) * 8, h->stream));
     HIP_TRY(h, hipMemcpyAsync(b.counters + 6, &b.cand_cap, sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMalloc(&b.special_rows, sizeof(uint32_t) * kBqSpecialCap));
+    HIP_TRY(h, hipMalloc(&b.nb_vals, sizeof(uint32_t) * kBqMaxQueries));
     HIP_TRY(h, hipMalloc(&b.gmax, sizeof(float) * static_cast<size_t>(grid) * kBqMaxBlocks * 64));
     // Room for the tile maxima of pass 1 (rows from the replica only).  Optional: without it pass 2 looks at every
     // (tile, query block) pair, as before.
@@ -1567,7 +1690,7 @@ int ensure_bq_alloc(mi355rec* h) {
 
 void free_bq(mi355rec* h) {
     auto& b = h->bq;
-    void* dev[] = {b.bfrag, b.qnorm, b.qthr, b.qflags, b.cand_count, b.cand_rows, b.counters, b.special_rows,
+    void* dev[] = {b.bfrag, b.qnorm, b.qthr, b.qflags, b.cand_count, b.cand_rows, b.counters, b.special_rows, b.nb_vals,
                    b.gmax, b.queue, b.qlists, b.d_queries, b.d_exclude, b.tile_max};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -1580,7 +1703,7 @@ void free_bq(mi355rec* h) {
 }
 
 template <int NB, bool kFromReplica, bool kTileMax>
-void launch_bq_passes(mi355rec* h, const float* d_queries, int count, int topn, hipStream_t s) {
+void launch_bq_passes(mi355rec* h, const float* d_queries, const long long* d_exclude, int count, int topn, hipStream_t s) {
     auto& b = h->bq;
     const int64_t n_tiles = (h->n + 63) / 64;   // a wave handles 64 rows (two 32-row MFMA tiles) at a time
     const int step1 = bq_step1(h, n_tiles);
@@ -1590,8 +1713,12 @@ void launch_bq_passes(mi355rec* h, const float* d_queries, int count, int topn, 
     // the fragments from the raw queries itself; bq_pass_kernel still can: prep_queries) was built and measured: the
     // launch it saves takes 4.4 us, the prologue it adds to each of pass 1's 1024 workgroups made pass 1 13 us slower
     // (10 M rows x 1024 queries: 102.5 instead of 89.7 us).
-    hipLaunchKernelGGL(bq_prepare_kernel, dim3((NB * 32 + 255) / 256), dim3(256), 0, s, d_queries, count, NB, b.bfrag,
-                       b.qnorm, b.qflags, b.cand_count, b.counters);
+    // The same launch takes every query's NEIGHBOURHOOD bound (one workgroup each: batched.hip.h) when the queries exclude
+    // rows — their own, for recommendByIndex — so that bq_select has it beside pass 1's group maxima.
+    const int prep_blocks = (NB * 32 + 255) / 256;
+    const bool nbhd = d_exclude != nullptr && h->n >= kNbhdRows;
+    hipLaunchKernelGGL(bq_prepare_kernel, dim3(prep_blocks + (nbhd ? count : 0)), dim3(256), 0, s, d_queries, count, NB, b.bfrag,
+                       b.qnorm, b.qflags, b.cand_count, b.counters, prep_blocks, h->d_feats, h->n, h->row_base, d_exclude, topn, b.nb_vals);
     d_queries = nullptr;
     int slot = timing_begin(h, h->ev_pass, h->n_pass_pairs, h->pass_launches, s);
     hipLaunchKernelGGL((bq_pass_kernel<NB, false, 0, kFromReplica, kTileMax>), dim3(b.grid), dim3(kBqPassBlock), 0, s, h->d_feats, h->n,
@@ -1600,18 +1727,17 @@ void launch_bq_passes(mi355rec* h, const float* d_queries, int count, int topn, 
                        d_queries, count, b.qnorm, b.qflags);
     timing_end(h, h->ev_pass, h->n_pass_pairs, slot, s);
     hipLaunchKernelGGL(bq_select_kernel, dim3(NB * 8), dim3(kBqSelectBlock), smem, s, b.gmax, b.grid, NB, topn, b.margin, b.bfrag,
-                       b.qflags, b.qthr);
+                       b.qflags, b.qthr, nbhd ? static_cast<const uint32_t*>(b.nb_vals) : static_cast<const uint32_t*>(nullptr), count);
     int skip_step = step1;
-#ifdef MI355REC_EXPERIMENTS   // tools builds only: where does pass 2's time go (tools/bq_ab.sh)
-    if (const char* e = std::getenv("MI355REC_BQ_EXP")) {
-        const int v = std::atoi(e);
+    {   // experiment builds only: where does pass 2's time go (tools/bq_ab.sh)
+        int v = 0;
+        MI355REC_EXP_INT(v, "MI355REC_BQ_EXP", 1, 2);
         if (v == 1) skip_step = 1 << 30;   // no tile counts as visited: the new loop over ALL blocks of every tile
         if (v == 2 && kTileMax) {          // every visited tile skips ALL its blocks: what a tile costs without any
             static std::vector<float> inf(kBqMaxQueries, __builtin_inff());
             (void)hipMemcpyAsync(b.qthr, inf.data(), sizeof(float) * kBqMaxQueries, hipMemcpyHostToDevice, s);
         }
     }
-#endif
     slot = timing_begin(h, h->ev_pass, h->n_pass_pairs, h->pass_launches, s);
     hipLaunchKernelGGL((bq_pass_kernel<NB, true, 0, kFromReplica, kTileMax>), dim3(b.grid2), dim3(kBqPassBlock), 0, s, h->d_feats, h->n,
                        n_tiles, 1, b.bfrag, b.gmax, b.cand_count, b.cand_rows, b.counters, b.special_rows, half,
@@ -1621,7 +1747,7 @@ void launch_bq_passes(mi355rec* h, const float* d_queries, int count, int topn, 
 }
 
 template <int NB>
-void launch_bq_passes(mi355rec* h, const float* d_queries, int count, int topn, hipStream_t s) {
+void launch_bq_passes(mi355rec* h, const float* d_queries, const long long* d_exclude, int count, int topn, hipStream_t s) {
     // the passes read the fp16 replica when the handle has one (it holds their A operand ready-made)
     if (h->d_half && h->replica_mode != MI355REC_REPLICA_OFF) {
         // 512 queries and more: pass 1 also leaves the maxima of the tiles it looked at, pass 2 skips what they rule out
@@ -1629,13 +1755,13 @@ void launch_bq_passes(mi355rec* h, const float* d_queries, int count, int topn, 
             const int64_t n_tiles = (h->n + 63) / 64;
             const int step1 = bq_step1(h, n_tiles);
             if (h->batch_path != MI355REC_BATCH_MFMA_NOSKIP && h->bq.tile_max && (n_tiles + step1 - 1) / step1 <= h->bq.tile_max_tiles) {
-                launch_bq_passes<NB, true, true>(h, d_queries, count, topn, s);
+                launch_bq_passes<NB, true, true>(h, d_queries, d_exclude, count, topn, s);
                 return;
             }
         }
-        launch_bq_passes<NB, true, false>(h, d_queries, count, topn, s);
+        launch_bq_passes<NB, true, false>(h, d_queries, d_exclude, count, topn, s);
     } else {
-        launch_bq_passes<NB, false, false>(h, d_queries, count, topn, s);
+        launch_bq_passes<NB, false, false>(h, d_queries, d_exclude, count, topn, s);
     }
 }
 
@@ -1647,16 +1773,17 @@ int enqueue_bq_chunk(mi355rec* h, const float* d_queries, const long long* d_exc
     int nb = 1;
     while (nb < blocks) nb *= 2;
     switch (nb) {
-        case 1: launch_bq_passes<1>(h, d_queries, count, topn, s); break;
-        case 2: launch_bq_passes<2>(h, d_queries, count, topn, s); break;
-        case 4: launch_bq_passes<4>(h, d_queries, count, topn, s); break;
-        case 8: launch_bq_passes<8>(h, d_queries, count, topn, s); break;
-        case 16: launch_bq_passes<16>(h, d_queries, count, topn, s); break;
-        default: launch_bq_passes<32>(h, d_queries, count, topn, s); break;
+        case 1: launch_bq_passes<1>(h, d_queries, d_exclude, count, topn, s); break;
+        case 2: launch_bq_passes<2>(h, d_queries, d_exclude, count, topn, s); break;
+        case 4: launch_bq_passes<4>(h, d_queries, d_exclude, count, topn, s); break;
+        case 8: launch_bq_passes<8>(h, d_queries, d_exclude, count, topn, s); break;
+        case 16: launch_bq_passes<16>(h, d_queries, d_exclude, count, topn, s); break;
+        default: launch_bq_passes<32>(h, d_queries, d_exclude, count, topn, s); break;
     }
     hipLaunchKernelGGL(bq_finalize_kernel, dim3(count), dim3(kBqFinalBlock), 0, s, h->d_feats, h->row_base, d_queries,
                        d_exclude, count, topn, b.qflags, b.cand_count, b.cand_rows, b.cand_cap, b.counters, b.special_rows, b.queue,
-                       out_keys, out_idx, out_score);
+                       out_keys, out_idx, out_score,
+                       (d_exclude != nullptr && h->n >= kNbhdRows) ? static_cast<const uint32_t*>(b.nb_vals) : static_cast<const uint32_t*>(nullptr));
     // The exact multi-query scan for whatever the bound could not be claimed for, its merge included (usually
     // nothing: the launch exits at once on an empty queue).
     hipLaunchKernelGGL((scan_multi_queued_kernel<MultiConfig>), dim3(b.qgrid), dim3(MultiConfig::kBlock), 0, s,
@@ -1758,6 +1885,17 @@ int enqueue_batch(mi355rec* h, const float* queries, const int64_t* exclude_glob
 
 extern "C" {
 
+int mi355rec_build_flags(void) {
+    int flags = 0;
+#ifdef MI355REC_EXPERIMENTS
+    flags |= MI355REC_BUILD_EXPERIMENTS;
+#endif
+#ifdef MI355REC_PHASE_CLOCK
+    flags |= MI355REC_BUILD_PHASE_CLOCK;
+#endif
+    return flags;
+}
+
 int mi355rec_device_count(void) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess) return 0;
@@ -1803,6 +1941,11 @@ void mi355rec_destroy(mi355rec_t* h) {
     if (h->owned_feats) (void)hipFree(h->owned_feats);
     if (h->d_block_lists) (void)hipFree(h->d_block_lists);
     if (h->d_lone_ctr) (void)hipFree(h->d_lone_ctr);
+    {
+        void* bufs[] = {h->d_half_seed, h->d_stream_seed[0], h->d_stream_seed[1], h->d_stream_ctl, h->d_lone_ctl};
+        for (void* b : bufs)
+            if (b) (void)hipFree(b);
+    }
     if (h->d_stream_lists[0]) (void)hipFree(h->d_stream_lists[0]);
     if (h->d_stream_lists[1]) (void)hipFree(h->d_stream_lists[1]);
     if (h->d_seed_keys) (void)hipFree(h->d_seed_keys);
@@ -1889,10 +2032,15 @@ int mi355rec_stats(const mi355rec_t* hc, mi355rec_stats_t* out) {
     out->route_multi_q8 = h->routes.multi_q8;
     out->route_mfma_two_pass = h->routes.mfma_two_pass;
     out->route_exact_queue = 0;
-    if (h->bq.ready) {   // queries the batched path handed to the exact scan: counted on the device (counters[5], never reset)
+    if (h->bq.ready) {
+        // queries the batched path handed to the exact scan: counted on the device (counters[5], never reset).  Read on the
+        // handle's own stream (behind what the synchronous API enqueued there) — not a device-wide synchronisation: a
+        // serving loop that polls the statistics does not stall the other streams.  Work still in flight on a caller's
+        // stream is not in the figure yet.
         int queued = 0;
-        (void)hipDeviceSynchronize();
-        if (hipMemcpy(&queued, h->bq.counters + 5, sizeof queued, hipMemcpyDeviceToHost) == hipSuccess) out->route_exact_queue = queued;
+        if (hipMemcpyAsync(&queued, h->bq.counters + 5, sizeof queued, hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
+            hipStreamSynchronize(h->stream) == hipSuccess)
+            out->route_exact_queue = queued;
     }
     out->device_bytes_per_row = 48 + (h->d_half ? 24 : 0) + (h->d_q8 ? 12 : 0);
     return MI355REC_OK;
@@ -2170,6 +2318,10 @@ int mi355rec_set_batch_path(mi355rec_t* h, int path) {
     if (path != MI355REC_BATCH_AUTO && path != MI355REC_BATCH_MULTI && path != MI355REC_BATCH_MFMA && path != MI355REC_BATCH_HALF &&
         path != MI355REC_BATCH_Q8 && path != MI355REC_BATCH_MFMA_NOSKIP)
         return fail(h, MI355REC_ERR_INVALID_ARG, "unknown batch path %d", path);
+#ifndef MI355REC_EXPERIMENTS
+    if (path == MI355REC_BATCH_Q8)
+        return fail(h, MI355REC_ERR_INVALID_ARG, "MI355REC_BATCH_Q8 (the 8-bit front end of the multi-query pass) exists in MI355REC_EXPERIMENTS builds only");
+#endif
     h->batch_path = path;
     return MI355REC_OK;
 }
@@ -2178,6 +2330,10 @@ int mi355rec_set_replica(mi355rec_t* h, int mode) {
     if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
     if (mode != MI355REC_REPLICA_AUTO && mode != MI355REC_REPLICA_OFF && mode != MI355REC_REPLICA_ON && mode != MI355REC_REPLICA_FP16)
         return fail(h, MI355REC_ERR_INVALID_ARG, "unknown replica mode %d", mode);
+#ifndef MI355REC_EXPERIMENTS
+    if (mode == MI355REC_REPLICA_FP16)
+        return fail(h, MI355REC_ERR_INVALID_ARG, "MI355REC_REPLICA_FP16 (single queries over the fp16 replica) exists in MI355REC_EXPERIMENTS builds only");
+#endif
     if ((mode == MI355REC_REPLICA_ON || mode == MI355REC_REPLICA_FP16) && !h->d_half && h->n > 0) {
         if (!h->replica_allowed)
             return fail(h, MI355REC_ERR_INVALID_ARG, "this handle was created without a replica (MI355REC_CREATE_NO_REPLICA)");
@@ -2198,8 +2354,8 @@ int mi355rec_debug_handoff(mi355rec_t* h, int flags) {
         // what a reader would find if the stores it depends on had not landed: the values of EARLIER queries (the
         // buffers alternate), here the most hostile ones — a perfect score under each of the last three epochs
         const uint32_t one = score_to_ordered(1.0f);
-        const size_t per = static_cast<size_t>(kHalfSeedMaxGrid) * kHalfSeedWaves;
-        std::vector<unsigned long long> vals(per * kHmQueries);
+        const size_t per = static_cast<size_t>(kSampleSlots);   // (the neighbourhood's slot included)
+        std::vector<unsigned long long> vals(static_cast<size_t>(kHmSampleSlots));
         for (size_t i = 0; i < vals.size(); ++i)
             vals[i] = (static_cast<unsigned long long>(h->epoch_ctr - 1u - static_cast<uint32_t>(i % 3)) << 32) | one;
         unsigned long long* single[] = {h->d_half_seed, h->d_stream_seed[0], h->d_stream_seed[1]};
@@ -2218,6 +2374,12 @@ int mi355rec_debug_handoff(mi355rec_t* h, int flags) {
             HIP_TRY(h, hipMemcpy(ctl, h->d_stream_ctl, sizeof ctl, hipMemcpyDeviceToHost));
             ctl[0].cutoff = ctl[1].cutoff = stale_cut;   // (the arrival counters stay what they are)
             HIP_TRY(h, hipMemcpy(h->d_stream_ctl, ctl, sizeof ctl, hipMemcpyHostToDevice));
+        }
+        if (h->d_lone_ctl) {
+            SeedCtl ctl;
+            HIP_TRY(h, hipMemcpy(&ctl, h->d_lone_ctl, sizeof ctl, hipMemcpyDeviceToHost));
+            ctl.cutoff = stale_cut;
+            HIP_TRY(h, hipMemcpy(h->d_lone_ctl, &ctl, sizeof ctl, hipMemcpyHostToDevice));
         }
         std::vector<unsigned long long> cuts(2 * kHmQueries, stale_cut);
         if (h->d_mstream_cuts)
@@ -2320,17 +2482,21 @@ int mi355rec_enqueue_scores(mi355rec_t* h, int64_t local_row, const float* query
     QueryArg qa;
     std::memset(&qa, 0, sizeof qa);
     qa.margin = h->margin_mix;
+    NextSeed no_next;
+    std::memset(&no_next, 0, sizeof no_next);
     if (local_row >= 0) {
         hipLaunchKernelGGL((scan_kernel<ScanConfig, true, true>), dim3(h->grid), dim3(kScanBlock), 0, s, h->d_feats,
                            h->n, h->rows_per_block, h->iters, h->row_base, qa, h->d_feats + local_row * kDim,
                            static_cast<int64_t>(-1), 1, static_cast<uint64_t*>(nullptr), out_scores_dev,
-                           static_cast<const uint64_t*>(nullptr), PrevMerge{nullptr, 0, 0, nullptr});
+                           static_cast<const uint64_t*>(nullptr), PrevMerge{nullptr, 0, 0, nullptr},
+                           static_cast<const unsigned long long*>(nullptr), static_cast<const unsigned long long*>(nullptr), 0u, no_next);
     } else {
         std::memcpy(qa.q, query12, sizeof qa.q);
         hipLaunchKernelGGL((scan_kernel<ScanConfig, false, true>), dim3(h->grid), dim3(kScanBlock), 0, s, h->d_feats,
                            h->n, h->rows_per_block, h->iters, h->row_base, qa, kNoQueryPtr,
                            static_cast<int64_t>(-1), 1, static_cast<uint64_t*>(nullptr), out_scores_dev,
-                           static_cast<const uint64_t*>(nullptr), PrevMerge{nullptr, 0, 0, nullptr});
+                           static_cast<const uint64_t*>(nullptr), PrevMerge{nullptr, 0, 0, nullptr},
+                           static_cast<const unsigned long long*>(nullptr), static_cast<const unsigned long long*>(nullptr), 0u, no_next);
     }
     HIP_TRY(h, hipGetLastError());
     return MI355REC_OK;

@@ -43,10 +43,7 @@ namespace mi355 {
 
 constexpr float kHalfMargin = kBqMarginFlush;   // what a launch claims unless the device check below allows the tighter bound
 constexpr uint32_t kHalfNaN2 = kBqNaN2;        // two fp16 quiet NaNs: "always score this row exactly"
-constexpr int kHalfSeedBlock = 512;
-constexpr int kHalfSeedWaves = kHalfSeedBlock / 64;
-constexpr int kHalfSeedMaxGrid = 256;          // <= 2048 sample maxima
-constexpr int kHalfSeedPerThread = 4;          // x 512 threads of a scanning workgroup
+// (the sampling geometry — kHalfSeedBlock, kHalfSeedWaves, kHalfSeedMaxGrid — and the hand-off types live in handoff.hip.h)
 
 // ---- building the replica ---------------------------------------------------------
 // One thread per row; rows [n, n_padded) (n_padded even) are padding and hold NaN.
@@ -150,6 +147,9 @@ __global__ void half_selfcheck_kernel(float* out) {
     }
 }
 
+#ifdef MI355REC_EXPERIMENTS   // the single-query scan over THIS replica is an A/B route of tools builds (single queries stream
+                              // the 8-bit replica, replica_q8.hip.h); the product keeps the replica as the operand store of the
+                              // matrix-core passes (batched.hip.h, replica_multi.hip.h)
 // ---- the sample that seeds the launch-wide cutoff -------------------------------------
 // A REGION is 1024 rows from row g * stride_rows on (stride_rows even and >= 1024, so no row is in
 // two regions): one ordered-u32 approx maximum per 128-row wave tile (0 = nothing usable) goes to
@@ -212,60 +212,8 @@ __global__ __launch_bounds__(kHalfSeedBlock) void seed_half_kernel(
 
 // In a STREAM of queries the sample of query k + 1 is taken by a few workgroups of query k's scan
 // launch instead of a launch of its own (scan_half_kernel<.., kWithMerge>: after the scanners and the
-// merger come next.n_wgs "seed riders").  They are resident from the start like everybody else — the
-// host launches that many scanners fewer — and each walks its share of the regions, four loads in
+// merger come next.n_wgs "seed riders", handoff.hip.h).  Each walks its share of the regions, four loads in
 // flight at a time.
-// HAND-OFFS THAT FAIL SAFE.  Two kinds of values cross workgroups outside the stream order of launches: the sample
-// values the seed riders of a launch leave for the rider that finishes last (same launch), and the cutoff that rider
-// leaves for the scanners of the next launch.  Both decide which rows a scan may skip, so a reader that picked up a
-// value of an EARLIER query (the buffers alternate) could place the cutoff above the true N-th score: a silently
-// wrong top-N.  Every such value therefore carries the EPOCH of the query it belongs to in its upper word, written
-// with the value by one 64-bit store; a reader that finds another epoch treats the value as absent — fewer sample
-// values, or no launch-wide cutoff at all, both of which only LOWER the cutoff (slower, never wrong).  The riders'
-// arrival counter counts up across launches and is never reset: the host tells each launch the count it starts
-// from, so a missed or repeated reset cannot make a rider believe it is the last one.
-// (tests/test_gpu_replica.py poisons the buffers and drops stores through mi355rec_debug_handoff to check this.)
-__device__ __forceinline__ unsigned long long tag_value(uint32_t epoch, uint32_t v) {
-    return (static_cast<unsigned long long>(epoch) << 32) | v;
-}
-__device__ __forceinline__ uint32_t untag_value(unsigned long long t, uint32_t epoch) {   // 0 = absent
-    return static_cast<uint32_t>(t >> 32) == epoch ? static_cast<uint32_t>(t) : 0u;
-}
-// A cutoff left by the riders of the launch before: the float's bits under its epoch; -inf (no launch-wide cutoff:
-// the workgroup-local thresholds take over) when the epoch is not the reader's.
-__device__ __forceinline__ float untag_cutoff(unsigned long long t, uint32_t epoch) {
-    return static_cast<uint32_t>(t >> 32) == epoch ? __uint_as_float(static_cast<uint32_t>(t)) : -__builtin_inff();
-}
-// Every wave's write-through stores have reached device scope before the workgroup counts itself out.  (A
-// workgroup-scope release fence does NOT wait for global stores on this target: the ISA showed
-// `s_waitcnt lgkmcnt(0); s_barrier` between the sc1 stores and the counter atomic.)
-__device__ __forceinline__ void wait_own_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-struct SeedCtl {
-    unsigned done;               // riders that have stored their sample, counted up across launches, never reset
-    unsigned pad;
-    unsigned long long cutoff;   // tag_value(epoch, bits of the next launch's launch-wide cutoff)
-};
-
-struct NextSeed {
-    float q[kDim];             // the next query (used when query_ptr is null)
-    const float* query_ptr;    // ... or where its 12 floats live (a resident row, possibly of another shard)
-    long long exclude_global;
-    void* out;                 // its sample maxima: uint32_t[] (fp16 replica: read by the NEXT launch only) or
-                               // epoch-tagged unsigned long long[] (8-bit replica: read by the last rider of this launch)
-    int n_wgs;                 // seed riders in this launch (0 = none)
-    int regions;
-    long long stride_rows;
-    // 8-bit replica only (replica_q8.hip.h): the rider that finishes LAST turns the sample into the next launch's
-    // cutoff, so that launch starts scanning at once instead of selecting in every workgroup
-    SeedCtl* ctl;
-    int topk;                  // of the next query
-    int exact;                 // sample values are exact scores of the waves' best rows (one margin) or their approximate ones (two)
-    uint32_t epoch;            // of the next query: the tag of its sample values and of its cutoff
-    uint32_t done_base;        // ctl->done before this launch's riders arrive
-    int debug_skip;            // test hook (0 in the product): the riders do NOT store regions below this one
-};
-
 __device__ __forceinline__ void seed_rider(const float* __restrict__ feats, const uint4* __restrict__ half, int64_t n,
                                            int64_t row_base, const NextSeed& next, int rider) {
     float q[kDim];
@@ -294,6 +242,8 @@ __device__ __forceinline__ void seed_rider(const float* __restrict__ feats, cons
         }
     }
 }
+
+#endif   // MI355REC_EXPERIMENTS
 
 // ---- the scan --------------------------------------------------------------------------
 // One lane = one PAIR of rows = 48 B of replica (3 x dwordx4, the fp32 scan's own load
@@ -336,6 +286,7 @@ struct HalfTile {
     uint4 t0, t1, t2;
 };
 
+#ifdef MI355REC_EXPERIMENTS
 // kWithMerge (streamed queries): workgroups [0, S) scan, workgroup S merges the PREVIOUS streamed
 // query (as scan_kernel's riding merger), workgroups (S, gridDim) are seed riders for the NEXT one;
 // S = gridDim.x - 1 - next.n_wgs.
@@ -529,5 +480,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_half_kernel(
     __syncthreads();
     block_rank_and_store<kBlock>(s_cand, s_count, block_lists + static_cast<int64_t>(bid) * topk, topk);
 }
+
+#endif   // MI355REC_EXPERIMENTS
 
 }  // namespace mi355

@@ -66,6 +66,10 @@ constexpr int kHmPrivate = 4;                      // keys per (wave, query) kep
 constexpr int kHmKeyCap = 192;                     // kept keys per query and workgroup
 constexpr int kHmKeysPerLane = kHmKeyCap / 64;
 static_assert(kMultiMaxTopK + 64 <= kHmKeyCap, "a wave-level append of 64 keys always fits after an exact compaction");
+// A batch's sample buffer: [query][<= 2048 tagged sample maxima], then one tagged NEIGHBOURHOOD bound per query
+// (handoff.hip.h: the exact topk-th best score among the rows around the query's excluded row; 0 = none).
+constexpr int kHmNbhdBase = kHmQueries * kHalfSeedMaxGrid * kHalfSeedWaves;
+constexpr int kHmSampleSlots = kHmNbhdBase + kHmQueries;
 
 struct HalfMultiArg {
     float q[kHmQueries][kDim];            // query i by value — or, when bit i of ptr_mask is set, q[i][0..1] hold a POINTER to
@@ -252,6 +256,21 @@ __device__ __forceinline__ void hm_sample_regions(const uint4* __restrict__ half
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             m = static_cast<int>(0x80000000u);
         }
+    }
+}
+
+// The neighbourhood bounds of a batch (handoff.hip.h): queries first, first + every, ... of the batch by this
+// workgroup, one after the other, each to its slot behind the sample values under the batch's epoch.  Read by the NEXT
+// launch on the stream (the pass), so plain stores do.  Called by all kHmBlock threads.
+__device__ __forceinline__ void hm_nbhd_queries(const float* __restrict__ feats, int64_t n, int64_t row_base, const HalfMultiArg& arg,
+                                                int n_queries, int first, int every, int topk, uint32_t epoch,
+                                                unsigned long long* __restrict__ seed_vals, SelectSmem& sel, int* s_count) {
+    for (int j = first; j < n_queries; j += every) {   // uniform
+        if (j != first) __syncthreads();   // the select before is done with the shared memory
+        float q[kDim];
+        hm_load_query(arg, j, q);
+        const uint32_t v = nbhd_bound<kHmBlock>(feats, n, row_base, arg.exclude[j], q, query_norm(q), topk, sel, s_count);
+        if (threadIdx.x == 0) seed_vals[kHmNbhdBase + j] = tag_value(epoch, v);
     }
 }
 
@@ -500,16 +519,19 @@ __device__ __forceinline__ int hm_resolve_stage(HalfMultiSmem& sm, int staged, c
     return n_exact;
 }
 
-// A step whose candidates did not fit the staging buffer (hostile data: no usable cutoff, special rows
-// everywhere): every (row, query) pair of the step through the exact chain, no pre-filter.
+// A step whose candidates did not fit the staging buffer (no usable cutoff, special rows everywhere — or simply a
+// step that lies INSIDE a query's cluster on a catalogue sorted by genre: 256 candidates for that one query): the
+// step's rows through the exact chain, no pre-filter, for the queries in `cols` — the columns that noted a candidate in
+// this step (every column when a special row was met).  A column that noted none has none: its rows were all ruled out.
 __device__ __forceinline__ void hm_exact_step(HalfMultiSmem& sm, const float* __restrict__ feats, int64_t n, int64_t row_base,
-                                              int64_t first_row, int n_queries, int topk) {
+                                              int64_t first_row, uint32_t cols, int topk) {
     const int lane = threadIdx.x & 63;
     for (int u = 0; u < kHmStepRows / 64; ++u) {
         const int64_t row = first_row + u * 64 + lane;
         const bool have = row < n;
         const Row r = load_row(feats, have ? row : static_cast<int64_t>(0));
-        for (int q0 = 0; q0 < n_queries; ++q0) {
+        for (uint32_t rest = cols; rest; rest &= rest - 1u) {   // wave-uniform
+            const int q0 = __builtin_ctz(rest);
             float qv[kDim];
 #pragma unroll
             for (int j = 0; j < kDim; ++j) qv[j] = sm.qf[q0][j];
@@ -560,8 +582,9 @@ __device__ __forceinline__ void hm_arrive_and_select(SeedCtl* ctl, unsigned done
 // select from 16 KB of sample values per query (measured at 10 M rows: the pass of 12 queries 49.8 -> 42.4 us, of 32
 // queries 62.6 -> 45.8 us).
 __global__ __launch_bounds__(kHmBlock) void seed_half_multi_kernel(
-    const uint4* __restrict__ half, int64_t n, int64_t stride_rows, HalfMultiArg arg, int n_queries,
-    unsigned long long* __restrict__ seed_vals /* [query][gridDim.x * kHalfSeedWaves], tagged with `epoch` */, uint32_t epoch,
+    const float* __restrict__ feats, const uint4* __restrict__ half, int64_t n, int64_t row_base, int64_t stride_rows, HalfMultiArg arg,
+    int n_queries, int regions /* the first `regions` workgroups sample; the rest take the queries' neighbourhoods */,
+    unsigned long long* __restrict__ seed_vals /* [query][regions * kHalfSeedWaves] + the neighbourhood slots, tagged with `epoch` */, uint32_t epoch,
     int log2_mult /* rows per region = 1024 << log2_mult */, SeedCtl* __restrict__ ctl /* arrival counter (null: no cutoffs) */,
     unsigned done_base, unsigned long long* __restrict__ cuts /* [n_queries] tagged cutoffs */, int topk,
     int debug_skip /* test hook (mi355rec_debug_handoff): the regions below this are sampled but not stored */) {
@@ -569,9 +592,15 @@ __global__ __launch_bounds__(kHmBlock) void seed_half_multi_kernel(
     __shared__ uint32_t s_ok[kHmQueries];
     __shared__ unsigned s_round;
     MI355REC_PHASE(0);
+    if (static_cast<int>(blockIdx.x) >= regions) {   // uniform: a neighbourhood workgroup (they do not arrive: the PASS reads their slots)
+        __shared__ SelectSmem s_sel;
+        hm_nbhd_queries(feats, n, row_base, arg, n_queries, static_cast<int>(blockIdx.x) - regions, static_cast<int>(gridDim.x) - regions, topk,
+                        epoch, seed_vals, s_sel, reinterpret_cast<int*>(&s_round));
+        return;
+    }
     float q_pre[kDim];   // the queries are requested BEFORE the rows (and looked at behind them: loads complete in order)
     if (threadIdx.x < kHmQueries) hm_request_query(arg, n_queries, threadIdx.x, q_pre);
-    hm_sample_regions<4>(half, n, stride_rows, gridDim.x, blockIdx.x, gridDim.x, s_b, n_queries, seed_vals, epoch, log2_mult, debug_skip,
+    hm_sample_regions<4>(half, n, stride_rows, regions, blockIdx.x, regions, s_b, n_queries, seed_vals, epoch, log2_mult, debug_skip,
                          [&]() {
                              if (threadIdx.x < kHmQueries) {
                                  float qn;
@@ -582,7 +611,7 @@ __global__ __launch_bounds__(kHmBlock) void seed_half_multi_kernel(
                          });
     MI355REC_PHASE(2);   // sampled, values stored
     if (ctl)   // uniform
-        hm_arrive_and_select<32>(ctl, done_base, gridDim.x, n_queries, s_ok, seed_vals, static_cast<int>(gridDim.x) * kHalfSeedWaves, topk,
+        hm_arrive_and_select<32>(ctl, done_base, static_cast<unsigned>(regions), n_queries, s_ok, seed_vals, regions * kHalfSeedWaves, topk,
                                  arg.margin, epoch, cuts, &s_round);
 }
 
@@ -599,6 +628,8 @@ struct HmRide {
     int prev_n_lists;
     int prev_topk;
     int seed_wgs;                 // seed riders in this launch (0 = none)
+    int nb_wgs;                   // ... and, behind them, workgroups that take the next batch's neighbourhood bounds (query j by
+                                  // workgroup j % nb_wgs; ~4 us per query)
     int next_queries;
     int regions;
     long long stride_rows;
@@ -622,7 +653,10 @@ union HmSmemU {
 };
 
 // block_lists[(slot0 + query) * S + workgroup][topk], each list sorted descending, 0-padded; S = the scanning
-// workgroups = gridDim.x - ride.prev_queries - ride.seed_wgs.
+// workgroups = gridDim.x - ride.merge_wgs - ride.seed_wgs - ride.nb_wgs.
+// seed_vals (when given) also holds the batch's neighbourhood bounds behind the sample values (kHmNbhdBase): EXACT
+// scores v with at least topk rows at or above them, so a query starts with thr AT v and a cutoff of at least
+// v - margin whatever the sample said.
 // kQ8: the rows are streamed from the 8-bit replica `q8` (12 B per row) through the integer matrix core and a
 // candidate is re-checked against its fp16 row before the exact chain (see "the 8-bit front end" above); the
 // sample of the NEXT batch is still taken over the fp16 replica.
@@ -644,10 +678,14 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
     HalfMultiSmem* smp;
     MI355REC_PHASE(0);
     if constexpr (kRide) {
-        nblocks = gridDim.x - static_cast<unsigned>(ride.merge_wgs) - static_cast<unsigned>(ride.seed_wgs);
+        nblocks = gridDim.x - static_cast<unsigned>(ride.merge_wgs) - static_cast<unsigned>(ride.seed_wgs) - static_cast<unsigned>(ride.nb_wgs);
         if (bid >= nblocks) {
             const int extra = static_cast<int>(bid - nblocks);
-            if (extra < ride.merge_wgs) {   // a merger: queries extra, extra + merge_wgs, ... of the previous batch, one after the other
+            if (extra >= ride.merge_wgs + ride.seed_wgs) {   // the next batch's neighbourhood bounds (read by the next launch)
+                hm_nbhd_queries(feats, n, row_base, next, ride.next_queries, extra - ride.merge_wgs - ride.seed_wgs, ride.nb_wgs,
+                                ride.next_topk, ride.next_epoch, ride.next_seed_vals, *reinterpret_cast<SelectSmem*>(&s_mem.scan.hist[0][0]),
+                                &s_mem.scan.rescored);
+            } else if (extra < ride.merge_wgs) {   // a merger: queries extra, extra + merge_wgs, ... of the previous batch, one after the other
                 for (int pq = extra; pq < ride.prev_queries; pq += ride.merge_wgs) {
                     if (pq != extra) __syncthreads();   // the merge before is done with the shared memory
                     int t = tid;
@@ -716,10 +754,11 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
     // twelve cold 16-byte loads per lane the B fragment was not ready before 3.5 us into the launch (tools/seed_clock.py
     // on the sample launch, which had the same order) — with the cutoffs' load another round trip behind a barrier.
     float q_pre[kDim];
-    unsigned long long cut_pre = 0ull;
+    unsigned long long cut_pre = 0ull, nb_pre = 0ull;
     if (tid < kHmQueries) {
         hm_request_query(arg, n_queries, tid, q_pre);
         if (cuts_ready && tid < n_queries) cut_pre = cuts_ready[tid];
+        if (seed_vals && tid < n_queries) nb_pre = seed_vals[kHmNbhdBase + tid];
     }
     HalfTile T[kQ8 ? 1 : kHmChunks];
     Row8 G[kQ8 ? kHmGroups : 1];
@@ -770,13 +809,24 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
                 atomicOr(&sm.select_here, 1u << tid);
             }
         }
+        // the neighbourhood's bound (valid whatever the pre-filter may claim): at least topk rows score >= it
+        if (const uint32_t nbv = tid < n_queries ? untag_value(nb_pre, epoch) : 0u) {
+            sm.thr[tid] = (static_cast<unsigned long long>(nbv) << 32) - 1ull;   // (a key AT the bound passes: key > thr)
+            const float nb_cut = ordered_to_score(nbv) - arg.margin - kBqSlack;
+            if (ok && nb_cut > sm.cut[tid]) {
+                sm.cut[tid] = nb_cut;
+                reinterpret_cast<uint32_t*>(&sm.bfrag[32 + tid])[2] = hm_threshold_slots(nb_cut);
+                if constexpr (kQ8) reinterpret_cast<uint32_t*>(&sm.bfrag8[tid])[3] = hm_q8_slots(nb_cut + arg.margin + kBqSlack - sm.m8[tid]);
+            }
+        }
     }
     __syncthreads();
     if (const uint32_t todo = sm.select_here) {   // uniform, rare
         for (int qi = wave; qi < n_queries; qi += kHmWaves) {
             if ((todo >> qi) & 1u) {   // wave-uniform
                 // the (topk + 1)-th largest: the query's own row may be among the sampled ones (hm_sample_regions)
-                const float cut = hm_seed_cutoff(seed_vals + static_cast<int64_t>(qi) * n_seed, n_seed, topk + 1, arg.margin, epoch);
+                float cut = hm_seed_cutoff(seed_vals + static_cast<int64_t>(qi) * n_seed, n_seed, topk + 1, arg.margin, epoch);
+                cut = cut > sm.cut[qi] ? cut : sm.cut[qi];   // (the neighbourhood's may be there already)
                 if (lane == 0) {
                     sm.cut[qi] = cut;
                     reinterpret_cast<uint32_t*>(&sm.bfrag[32 + qi])[2] = hm_threshold_slots(cut);
@@ -794,7 +844,8 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
 
     const bq_f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     const uint32_t n32 = static_cast<uint32_t>(n);   // n <= 2^32 - 2 (mi355rec_create)
-    bool overflow = false;   // wave-uniform: this step's candidates did not fit the staging buffer
+    bool overflow = false;   // wave-uniform: this step's candidates did not fit the staging buffer ...
+    uint32_t step_cols = 0u; // ... and which query columns have noted a candidate in this step so far (bit c = query c)
     // D layout: lane holds column c = lane & 31 (the query) and, in register i, the row that lane
     // (i & 3) + 8 (i >> 2) + 4 (lane >> 5) of the tile's 32 lanes loaded.  `first_row` = row of the tile's
     // lane 0, rows of consecutive lanes are 2 apart (a lane holds a pair).
@@ -812,6 +863,7 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
         uint32_t lr0 = 4u * static_cast<uint32_t>(hh);
         asm volatile("" : "+v"(lr0));
         for (uint64_t any = __ballot(hits != 0u); any; any = __ballot(hits != 0u)) {   // wave-uniform rounds
+            step_cols |= static_cast<uint32_t>(any) | static_cast<uint32_t>(any >> 32);   // lanes c and 32 + c hold query column c
             const int i = hits ? __builtin_ctz(hits) : 0;
             const uint32_t lr = lr0 + static_cast<uint32_t>((i & 3) + 8 * (i >> 2));   // the lane of the tile that loaded the row
             const uint32_t row = first_row + 2u * lr;
@@ -833,6 +885,7 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
 
     for (; step < n_steps; step += total_waves) {
         const int staged_before = staged;
+        step_cols = 0u;
         // the fragment is re-read every step (its cutoffs tighten); the barrier keeps the compiler from hoisting it
         asm volatile("" ::: "memory");
         if constexpr (!kQ8) {
@@ -853,6 +906,7 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
                 for (int S = 0; S < 2; ++S) {   // the lanes' even rows, then their odd rows
                     const HmTiles a = hm_make_tiles(T[u], S, chunk_row, n32);
                     if (a.special) {   // uniform, rare: one candidate per (special row, query)
+                        step_cols = 0xffffffffu;
                         uint64_t sp = a.special;
                         while (sp) {
                             const int src = __ffsll(static_cast<long long>(sp)) - 1;
@@ -898,6 +952,7 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
                                   keep ? static_cast<int>(G[g].d2 ^ 0x80808080u) : 0, static_cast<int>(kHmQ8RowConst)};
                 const uint64_t special = __ballot(is_special);
                 if (special) {   // uniform, rare: one candidate per (special row, query), straight to the exact chain
+                    step_cols = 0xffffffffu;
                     uint64_t sp = special;
                     while (sp) {
                         const int src = __ffsll(static_cast<long long>(sp)) - 1;
@@ -933,6 +988,7 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
                                     const uint32_t row = first_row + lr;
                                     const bool hit = d[i] >= 0 && row < n32 && !((special >> (lane0 + lr)) & 1ull);
                                     const uint64_t who = __ballot(hit);
+                                    step_cols |= static_cast<uint32_t>(who) | static_cast<uint32_t>(who >> 32);
                                     if (who) {
                                         const int n_hit = __popcll(who);
                                         if (staged + n_hit > kHmStage) {
@@ -958,8 +1014,9 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
             n_rescored += hm_resolve_stage(sm, staged, feats, row_base, topk, kQ8 ? reinterpret_cast<const uint32_t*>(half) : nullptr);
             staged = 0;
             if (overflow) {
-                hm_exact_step(sm, feats, n, row_base, step * kHmStepRows, n_queries, topk);
-                n_rescored += kHmStepRows * n_queries;
+                const uint32_t cols = step_cols & (n_queries >= 32 ? 0xffffffffu : (1u << n_queries) - 1u);
+                hm_exact_step(sm, feats, n, row_base, step * kHmStepRows, cols, topk);
+                n_rescored += kHmStepRows * __builtin_popcount(cols);
                 overflow = false;
             }
         }

@@ -217,16 +217,24 @@ __device__ __forceinline__ void q8_load_query(const float* __restrict__ query_pt
     }
 }
 
-// One workgroup per region (single queries; the first query of a stream).
-template <bool kQueryFromRow, bool kExact>
+// One workgroup per region (single queries; the first query of a stream) and, when the grid has one more workgroup
+// than regions, the neighbourhood of the excluded row (handoff.hip.h) by that last one.
+template <bool kExact>
 __global__ __launch_bounds__(kHalfSeedBlock) void seed_q8_kernel(
     const float* __restrict__ feats, const uint4* __restrict__ q8, int64_t n, int64_t stride_rows, int64_t row_base, QueryArg qarg,
-    const float* __restrict__ query_ptr, int64_t exclude_global, unsigned long long* __restrict__ seed_vals, uint32_t epoch) {
+    const float* __restrict__ query_ptr /* null: the query is qarg.q */, int64_t exclude_global,
+    unsigned long long* __restrict__ seed_vals, uint32_t epoch, int regions, int topk) {
+    if (static_cast<int>(blockIdx.x) >= regions) {   // uniform
+        __shared__ SelectSmem s_sel;
+        __shared__ int s_count;
+        nbhd_to_slot<kHalfSeedBlock>(feats, n, row_base, query_ptr, qarg.q, exclude_global, topk, epoch, seed_vals, s_sel, &s_count);
+        return;
+    }
     // the region's rows are requested FIRST: they need nothing of the query, whose 12 floats sit behind two dependent
     // scalar loads and a norm (this launch is on the critical path of a query alone)
     const Q8Region s = q8_region_load(q8, (n + 3) >> 2, stride_rows, blockIdx.x);
     float q[kDim];
-    q8_load_query(kQueryFromRow ? query_ptr : nullptr, qarg.q, q);
+    q8_load_query(query_ptr, qarg.q, q);
     const float qn = query_norm(q);
     const Q8Query hq = q8_query(q, qn);
     const Q8Pick p = q8_region_pick(s, hq, n, row_base, exclude_global);
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(kHalfSeedBlock) void seed_q8_kernel(
     q8_region_store<kExact>(p, row, q, qn, seed_vals, epoch, blockIdx.x);
 }
 
-// The seed riders of a streamed launch (replica.hip.h, seed_rider): four regions per memory round trip.
+// The seed riders of a streamed launch (handoff.hip.h, NextSeed): four regions per memory round trip.
 __device__ __forceinline__ Q8Query q8_seed_rider(const float* __restrict__ feats, const uint4* __restrict__ q8, int64_t n,
                                                  int64_t row_base, const NextSeed& next, int rider) {
     const int64_t n_quads = (n + 3) >> 2;
@@ -285,151 +293,18 @@ __device__ __forceinline__ Q8Query q8_seed_rider(const float* __restrict__ feats
     return hq;
 }
 
-// The launch-wide cutoff from n_seed sample maxima (approximate scores, ordered; 0 = empty): a row whose
-// approximate score is below it cannot be among the best topk.  -inf when the sample cannot say.
-struct Q8Sample {
-    uint32_t v[kHalfSeedPerThread];   // this thread's share of the sample values (0 = empty)
-};
-// Values under another epoch than the reader's count as absent (replica.hip.h, "hand-offs that fail safe").
-// (request and use are two calls: the scan asks for its sample FIRST — before its first tile: loads complete in order,
-// and behind the tile the sample of a 1 M-row shard was not usable before the tile was, 3 us later — and looks at it
-// after the query)
-struct Q8SampleRaw {
-    unsigned long long t[kHalfSeedPerThread];
-};
-template <int kBlock, bool kSameLaunch = false>
-__device__ __forceinline__ Q8SampleRaw q8_request_sample(const unsigned long long* seed_vals, int n_seed) {
-    Q8SampleRaw raw;
-#pragma unroll
-    for (int r = 0; r < kHalfSeedPerThread; ++r) {
-        const int i = static_cast<int>(threadIdx.x) + r * kBlock;
-        raw.t[r] = 0ull;
-        if (i < n_seed)   // kSameLaunch: written by other workgroups of THIS launch
-            raw.t[r] = kSameLaunch ? __hip_atomic_load(&seed_vals[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : seed_vals[i];
-    }
-    return raw;
-}
-__device__ __forceinline__ Q8Sample q8_finish_sample(const Q8SampleRaw& raw, uint32_t epoch) {
-    Q8Sample s;
-#pragma unroll
-    for (int r = 0; r < kHalfSeedPerThread; ++r) s.v[r] = untag_value(raw.t[r], epoch);
-    return s;
-}
-template <int kBlock, bool kSameLaunch = false>
-__device__ __forceinline__ Q8Sample q8_load_sample(const unsigned long long* seed_vals, int n_seed, uint32_t epoch) {
-    return q8_finish_sample(q8_request_sample<kBlock, kSameLaunch>(seed_vals, n_seed), epoch);
-}
-
-// The cutoff is "any T with at least topk sample values >= T", as high as is cheap to find — not a k-th order
-// statistic to the last bit.  So ONE histogram pass instead of a radix select: the values are binned linearly over
-// [max - kQ8SelSpan, max] (1024 bins of 2.4e-4: a fiftieth of the smallest margin the cutoff then subtracts), the bins
-// are summed from the top, and T is the lower edge of the bin in which the count reaches topk.  Four barriers in all
-// against two per byte pass of the radix select over the 64-bit (value, index) keys (measured: 3.4 us of every
-// workgroup's prologue wherever the cutoff is not handed over by the launch before — shards below ~4 M rows and
-// every query alone).  A sample whose topk-th value lies more than kQ8SelSpan below its maximum lands in the last bin
-// and takes the radix select as before.
-constexpr int kQ8SelBins = 1024;
-constexpr float kQ8SelSpan = 0.25f;
-constexpr int kQ8SelScratch = kQ8SelBins + 16;   // ints of LDS scratch the selection needs (bins, block max, wave totals, result)
-
+// The launch-wide cutoff from n_seed sample values (handoff.hip.h: sample_kth_value): a row whose approximate score
+// is below it cannot be among the best topk.  -inf when the sample cannot say, or the bound cannot be claimed for
+// the query.  One margin below an EXACT score of a real row, two below an approximate one (the margin carries its
+// own slack).
 template <int kBlock>
-__device__ __forceinline__ float q8_cutoff_from_sample(const Q8Sample& sample, int n_seed, int topk, bool exact_values,
+__device__ __forceinline__ float q8_cutoff_from_sample(const Sample& sample, int n_seed, int topk, bool exact_values,
                                                        const Q8Query& hq, int* s_seeds /* zeroed */, SelectSmem& s_sel,
-                                                       int* s_bins /* kQ8SelScratch ints nobody else is using */) {
-    static_assert(kQ8SelBins % kBlock == 0, "whole bins per thread");
-    constexpr int kPer = kQ8SelBins / kBlock;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    float cutoff = -__builtin_inff();
-    if (hq.ok && n_seed > 0) {   // uniform
-        uint32_t vmax = 0u;
-        int have = 0;
-#pragma unroll
-        for (int r = 0; r < kHalfSeedPerThread; ++r) {
-            vmax = sample.v[r] > vmax ? sample.v[r] : vmax;
-            have += sample.v[r] != 0u;
-        }
-        for (int i = tid; i < kQ8SelScratch; i += kBlock) s_bins[i] = 0;
-        vmax = wave_max_u32(vmax);
-        __syncthreads();   // the scratch is zero
-        if (lane == 0 && vmax) atomicMax(reinterpret_cast<unsigned int*>(&s_bins[kQ8SelBins]), vmax);
-        // ONE count per wave: 512 threads adding to the one LDS word were 2 us of serialised atomics — most of what this
-        // selection cost (the phase clock had the sample values back 1.4 us after the workgroup's entry and the cutoff
-        // only at 5.0 us)
-        const int wave_have = __builtin_amdgcn_readlane(wave_inclusive_scan(have), 63);
-        if (lane == 0 && wave_have) atomicAdd(s_seeds, wave_have);
-        __syncthreads();
-        if (*s_seeds >= topk) {   // uniform
-            const float smax = ordered_to_score(static_cast<uint32_t>(s_bins[kQ8SelBins]));
-#pragma unroll
-            for (int r = 0; r < kHalfSeedPerThread; ++r) {
-                if (sample.v[r]) {
-                    const float d = (smax - ordered_to_score(sample.v[r])) * (static_cast<float>(kQ8SelBins) / kQ8SelSpan);
-                    int bin = static_cast<int>(d);
-                    bin = (d >= 0.0f && bin < kQ8SelBins - 1) ? bin : (d >= 0.0f ? kQ8SelBins - 1 : 0);   // (NaN: the last bin)
-                    if (!(d == d)) bin = kQ8SelBins - 1;
-                    atomicAdd(&s_bins[bin], 1);
-                }
-            }
-            __syncthreads();
-            // thread t owns bins [t * kPer, (t + 1) * kPer): bin 0 holds the largest values
-            int mine_bins[kPer];
-            int c = 0;
-#pragma unroll
-            for (int u = 0; u < kPer; ++u) {
-                mine_bins[u] = s_bins[tid * kPer + u];
-                c += mine_bins[u];
-            }
-            int incl = wave_inclusive_scan(c);
-            if (lane == 63) s_bins[kQ8SelBins + 1 + wave] = incl;
-            __syncthreads();
-            int before = 0;
-            for (int w = 0; w < wave; ++w) before += s_bins[kQ8SelBins + 1 + w];   // (<= 7 reads, wave-uniform)
-            incl += before;
-            int run = incl - c;
-            if (run < topk && incl >= topk) {   // exactly one thread: the count reaches topk inside its bins
-                int bin = tid * kPer;
-#pragma unroll
-                for (int u = 0; u < kPer; ++u) {
-                    if (run < topk) bin = tid * kPer + u;
-                    run += mine_bins[u];
-                }
-                s_bins[kQ8SelBins + 12] = bin + 1;
-            }
-            __syncthreads();
-            const int found = s_bins[kQ8SelBins + 12] - 1;
-            float v;
-            if (found >= 0 && found < kQ8SelBins - 1) {   // uniform
-                // every value of bins 0 .. found is >= this edge (2e-6: the rounding of the bin arithmetic)
-                v = smax - static_cast<float>(found + 1) * (kQ8SelSpan / static_cast<float>(kQ8SelBins)) - 2.0e-6f;
-            } else {   // the topk-th value lies far below the maximum (or the values are not what they should be): exact
-                uint64_t keys[kHalfSeedPerThread];
-#pragma unroll
-                for (int r = 0; r < kHalfSeedPerThread; ++r) {
-                    const int i = tid + r * kBlock;
-                    keys[r] = sample.v[r] ? (static_cast<uint64_t>(sample.v[r]) << 32) | static_cast<uint32_t>(i + 1) : 0ull;
-                }
-                const uint64_t t = block_select_threshold<kBlock, kHalfSeedPerThread>(keys, topk, false, topk / 8 + 2, s_sel);
-                v = ordered_to_score(static_cast<uint32_t>(t >> 32));
-            }
-            // one margin below an EXACT score of a real row, two below an approximate one (the margin carries its own slack)
-            cutoff = exact_values ? v - hq.margin : v - 2.0f * hq.margin;
-        }
-    }
-    return cutoff;
+                                                       int* s_bins /* kSelScratch ints nobody else is using */) {
+    if (!hq.ok) return -__builtin_inff();   // uniform
+    const float v = sample_kth_value<kBlock>(sample, n_seed, topk, s_seeds, s_sel, s_bins);
+    return exact_values ? v - hq.margin : v - 2.0f * hq.margin;   // (-inf stays -inf)
 }
-
-#ifdef MI355REC_PHASE_CLOCK   // tools/ builds only: where a launch spends its time (100 MHz wall clock, per workgroup)
-#define MI355REC_PHASE(i)                                                                   \
-    do {                                                                                    \
-        if (threadIdx.x == 0 && blockIdx.x < 1024) g_phase_clock[blockIdx.x * 8 + (i)] = wall_clock64(); \
-    } while (0)
-#else
-#define MI355REC_PHASE(i) \
-    do {                  \
-    } while (0)
-#endif
 
 // ---- the scan ----------------------------------------------------------------------------------------------
 template <int kBlockT, int kMinWavesT, int kDepthT>
@@ -443,8 +318,12 @@ struct Q8Cfg {
 };
 using DefaultQ8Cfg = Q8Cfg<512, 4, 2>;
 
-// kWithMerge (streamed queries): workgroups [0, S) scan, workgroup S merges the PREVIOUS streamed query,
-// workgroups (S, gridDim) are seed riders for the NEXT one; S = gridDim.x - 1 - next.n_wgs (scan_half_kernel).
+// kWithMerge (streamed queries): workgroups [0, S) scan, workgroup S merges the PREVIOUS streamed query, the next
+// next.n_wgs workgroups are seed riders for the NEXT one and (next.nbhd) the last of the grid takes that query's
+// neighbourhood (handoff.hip.h); S = gridDim.x - 1 - next.n_wgs - next.nbhd.
+// Slot kNbhdSlot of `seed_vals` holds, under this query's epoch, the neighbourhood's EXACT bound v (0: none): keys below
+// it are dropped at once and v - margin is one more lower bound on the cutoff — what keeps a catalogue sorted by genre
+// (the query's cluster in ONE sampled region at most) from scanning with another cluster's cutoff.
 //
 // Tiles are dealt round-robin.  Handing them out dynamically (ticket counters, the merger and the riders joining
 // once their job was done) was built and measured: every workgroup then finished within 2 us of the others
@@ -469,7 +348,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
     unsigned nblocks = gridDim.x;   // scanning workgroups
     MI355REC_PHASE(0);
     if constexpr (kWithMerge) {
-        nblocks = gridDim.x - 1u - static_cast<unsigned>(next.n_wgs);
+        nblocks = gridDim.x - 1u - static_cast<unsigned>(next.n_wgs) - static_cast<unsigned>(next.nbhd);
         if (blockIdx.x >= nblocks) {
             if (blockIdx.x == nblocks) {
                 if (prev.lists)
@@ -477,31 +356,23 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
                                static_cast<int64_t>(0), prev.topk, prev.out_keys, static_cast<int64_t*>(nullptr),
                                static_cast<float*>(nullptr), static_cast<int64_t>(0), static_cast<int64_t>(0),
                                static_cast<int64_t>(0));
+            } else if (next.nbhd && blockIdx.x == gridDim.x - 1u) {   // the next query's neighbourhood: read by the NEXT launch
+                nbhd_to_slot<kBlock>(feats, n, row_base, next.query_ptr, next.q, next.exclude_global, next.topk, next.epoch,
+                                     static_cast<unsigned long long*>(next.out), s_mem.scan.sel, &s_mem.scan.count);
             } else {
                 const Q8Query nq = q8_seed_rider(feats, q8, n, row_base, next, static_cast<int>(blockIdx.x - nblocks - 1u));
-                // Last rider out turns the sample into the cutoff.  No device-wide fence: on this part a release /
-                // acquire pair at agent scope writes back and invalidates the whole L2 under the scanners (measured:
-                // the launch took 43 us instead of 28).  Instead the maxima are stored and loaded as device-scope
-                // atomics (write-through stores, L2-bypassing loads); each wave waits for ITS stores to complete
-                // (s_waitcnt vmcnt(0): a workgroup-scope fence does not), one thread counts, and the last
-                // workgroup's loads are issued after its counter value came back.  Values and cutoff carry the next
-                // query's epoch and the counter is never reset (replica.hip.h, "hand-offs that fail safe").
+                // Last rider out turns the sample into the cutoff (handoff.hip.h, sample_arrive_and_select: no device-wide
+                // fence under the scanners).  Values and cutoff carry the next query's epoch and the counter is never reset.
                 if (next.ctl) {   // uniform; null: nobody reads the sample inside this launch (small shards: the next launch selects)
-                wait_own_stores();
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    s_mem.scan.seeds = 0;
-                    s_mem.scan.count = __hip_atomic_fetch_add(&next.ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u ==
-                                       next.done_base + static_cast<unsigned>(next.n_wgs);
-                }
-                __syncthreads();
-                if (s_mem.scan.count) {   // uniform
-                    const Q8Sample all = q8_load_sample<kBlock, true>(static_cast<const unsigned long long*>(next.out),
-                                                                      next.regions * kHalfSeedWaves, next.epoch);
-                    const float c = q8_cutoff_from_sample<kBlock>(all, next.regions * kHalfSeedWaves, next.topk, next.exact != 0, nq,
-                                                                  &s_mem.scan.seeds, s_mem.scan.sel, reinterpret_cast<int*>(s_mem.scan.cand));
-                    if (threadIdx.x == 0) next.ctl->cutoff = tag_value(next.epoch, __float_as_uint(c));
-                }
+                    float v;
+                    if (sample_arrive_and_select<kBlock>(next.ctl, next.done_base, static_cast<unsigned>(next.n_wgs),
+                                                         static_cast<const unsigned long long*>(next.out), next.regions * kHalfSeedWaves,
+                                                         next.topk, next.epoch, &s_mem.scan.count, &s_mem.scan.seeds, s_mem.scan.sel,
+                                                         reinterpret_cast<int*>(s_mem.scan.cand), v)) {
+                        // one margin below an EXACT score of a real row, two below an approximate one
+                        const float c = !nq.ok ? -__builtin_inff() : (next.exact != 0 ? v - nq.margin : v - 2.0f * nq.margin);
+                        if (threadIdx.x == 0) next.ctl->cutoff = tag_value(next.epoch, __float_as_uint(c));
+                    }
                 }
             }
             __syncthreads();
@@ -545,18 +416,15 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
     // the tile's 48 B per lane, the query
     constexpr int kDepth = Cfg::kDepth;
     float cutoff_left = 0.0f;
-    Q8SampleRaw sample_raw;
+    const unsigned long long nbhd_raw = seed_vals[kNbhdSlot];   // (wave-uniform: a scalar load)
+    SampleRaw sample_raw;
 #pragma unroll
     for (int r = 0; r < kHalfSeedPerThread; ++r) sample_raw.t[r] = 0ull;
     const int n_sample = n_seed < 0 ? -n_seed : n_seed;
     if (cutoff_ready) {   // uniform: the riders of the launch before this one left it (under this query's epoch, or it does not count)
         cutoff_left = untag_cutoff(*cutoff_ready, epoch);
     } else {              // ... or this workgroup selects it from the sample values itself
-#ifdef MI355_Q8_SAMPLE_SC1   // experiment: coherent loads
-        sample_raw = q8_request_sample<kBlock, true>(seed_vals, n_sample);
-#else
-        sample_raw = q8_request_sample<kBlock>(seed_vals, n_sample);
-#endif
+        sample_raw = sample_request<kBlock>(seed_vals, n_sample);
     }
     HalfTile ring[kDepth];
 #pragma unroll
@@ -565,11 +433,9 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
     q8_load_query(kQueryFromRow ? query_ptr : nullptr, qarg.q, q);
     const float qn = query_norm(q);
     const Q8Query hq = q8_query(q, qn);
-    const Q8Sample sample = q8_finish_sample(sample_raw, epoch);
+    const Sample sample = sample_finish(sample_raw, epoch);
     if (hq.c != 0.0f || n >= 0) MI355REC_PHASE(1);   // (depends on the query: not hoisted above its load)
-#ifdef MI355REC_PHASE_CLOCK
     if (sample.v[0] != 0x12345u || n >= 0) MI355REC_PHASE(6);   // (depends on this thread's sample values: they have arrived)
-#endif
 
     // ---- launch-wide cutoff (while the first tiles are in flight)
     if (tid == 0) {
@@ -585,8 +451,15 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
     } else {
         cutoff = q8_cutoff_from_sample<kBlock>(sample, n_sample, topk, n_seed < 0, hq, &sm->seeds, s_sel, reinterpret_cast<int*>(s_cand));
     }
-    MI355REC_PHASE(2);
     uint64_t thr = 0;
+    if (const uint32_t nbv = untag_value(nbhd_raw, epoch)) {   // uniform: at least topk rows score >= this EXACT bound
+        thr = (static_cast<uint64_t>(nbv) << 32) - 1ull;   // (a key AT the bound passes: key > thr)
+        if (hq.ok) {
+            const float nb_cut = ordered_to_score(nbv) - hq.margin;
+            cutoff = nb_cut > cutoff ? nb_cut : cutoff;
+        }
+    }
+    MI355REC_PHASE(2);
     int compact_at = 2 * topk > 256 ? 2 * topk : 256;
     if (compact_at > kCandLimit) compact_at = kCandLimit;
 

@@ -1,0 +1,191 @@
+"""Catalogues whose similar rows lie NEXT TO EACH OTHER — what the reference's own input looks like once a CSV is grouped
+by genre, artist or album: genre ids are handed out in order of first appearance (DataManager.cpp:244-250) and end up,
+divided by G - 1, in features[11] (:299), a ramp along the row index — against the ORACLE on every route (VERDICT r4
+item 1).
+
+On such a catalogue an evenly spaced sample sees a handful of rows of the query's own cluster, so a launch-wide bound
+taken from it comes from OTHER clusters; round 4 measured the fp32 scan at 2.5x and the multi-query pass at 5-11x their
+uniform-row times there (keys right everywhere).  Round 5 gives every route a second lower bound, the NEIGHBOURHOOD of the
+row the query excludes (csrc/handoff.hip.h), and the fp32 scan a launch-wide bound at all.  These tests check what must
+not change — ids, order and score BITS are the oracle's (Recommender.cu:256-318) — and, through the diagnostics, that the
+neighbourhood really bounds what goes to the exact chain (a build that lost it would still pass the parity half).
+
+Sizes: 4.2 M rows (every single-query route at its production geometry: the fused lone launch from 4 M rows, the fp32
+scan's seed riders from 2 M, its sample launch from 4 M), clusters of ~3 300 and ~33 000 rows (3000 and 300 clusters at
+BASELINE's 10 M rows), with and without the genre ramp.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.parity import assert_topn_matches
+
+pytestmark = pytest.mark.gpu
+
+N = 4_200_000
+TOPN = 100
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.fixture(scope="module", params=[(1272, False), (1272, True), (127, False), (127, True)],
+                ids=["3300-row clusters", "3300-row clusters + genre ramp", "33000-row clusters", "33000-row clusters + genre ramp"])
+def catalogue(request, torch_cuda):
+    from spotify_recommender_amd.synth import clustered_catalogue
+    clusters, ramp = request.param
+    spread = 0.03 if clusters > 1000 else 0.01   # (the two shapes profiles/r04_clustered.jsonl was measured on)
+    t = clustered_catalogue(N, spread, seed=4242 + clusters, clusters=clusters, contiguous=True, ramp=ramp)
+    f = t.cpu().numpy()
+    assert f.dtype == np.float32 and f.shape == (N, 12)
+    if ramp:
+        assert np.all(np.diff(f[::1000, 11]) >= 0), "the genre column must ramp with the row index"
+    return {"dev": t, "host": f, "clusters": clusters, "rows_per_cluster": N // clusters, "ramp": ramp}
+
+
+@pytest.fixture(scope="module")
+def engine(catalogue):
+    from spotify_recommender_amd.engine import CosineEngine
+    with CosineEngine(catalogue["dev"]) as eng:
+        yield eng
+
+
+def query_rows(count, seed):
+    """Catalogue rows as queries (recommendByIndex): spread over the shard, first and last rows included."""
+    rng = np.random.default_rng(seed)
+    rows = rng.integers(0, N, size=count)
+    rows[0], rows[1] = 0, N - 1
+    return rows.astype(np.int64)
+
+
+def check(f, row, idx, sc, label, topn=TOPN):
+    want = oracle.scores(f, f[row], threads=0)
+    try:
+        assert_topn_matches(idx, sc, want, int(row), topn, ref_idx=oracle.topn_heap(want, int(row), topn))
+    except AssertionError as e:
+        raise AssertionError(f"{label}: query row {row}: {e}") from e
+
+
+def test_single_query_routes_lone_and_streamed(catalogue, engine, torch_cuda):
+    """The fp32 scan and the 8-bit stream, each as a query alone (synchronous call) and as a stream, against the oracle;
+    the 8-bit scan must not send more than a few clusters' worth of rows to the exact chain."""
+    torch = torch_cuda
+    from spotify_recommender_amd import capi
+    from spotify_recommender_amd.engine import unpack_keys
+    f, eng = catalogue["host"], engine
+    rows = query_rows(10, 11)
+    for mode, name in ((capi.REPLICA_OFF, "fp32 rows"), (capi.REPLICA_AUTO, "8-bit replica")):
+        eng.set_replica(mode)
+        r0 = {k: getattr(eng.stats(), k) for k in ("route_fp32", "route_q8", "route_q8_lone")}
+        for r in rows[:4]:
+            idx, sc = eng.query_row_topn(int(r), TOPN)
+            check(f, r, idx, sc, f"{name}, alone")
+        keys = torch.zeros((len(rows), TOPN), dtype=torch.int64, device="cuda")
+        c0 = eng.replica_counters()
+        for i, r in enumerate(rows):
+            eng.enqueue_row_keys_streamed(int(r), TOPN, keys[i])
+        eng.enqueue_flush()
+        torch.cuda.synchronize()
+        c1 = eng.replica_counters()
+        for i, r in enumerate(rows):
+            idx, sc = unpack_keys(keys[i].cpu().numpy())
+            check(f, r, idx, sc, f"{name}, streamed")
+        r1 = {k: getattr(eng.stats(), k) for k in r0}
+        if mode == capi.REPLICA_OFF:
+            assert r1["route_fp32"] - r0["route_fp32"] == 4 + len(rows) and r1["route_q8"] == r0["route_q8"]
+        else:
+            assert r1["route_q8_lone"] - r0["route_q8_lone"] == 4 and r1["route_q8"] - r0["route_q8"] == len(rows)
+            per_query = (c1["rescored_rows"] - c0["rescored_rows"]) / len(rows)
+            # what the 8-bit replica cannot tell from the query's own cluster (its bound is ~0.012) and nothing like the
+            # 1.2-1.4 % of the shard round 4's cutoff let through
+            assert per_query < 4 * catalogue["rows_per_cluster"] + 4000, per_query
+    eng.set_replica(capi.REPLICA_AUTO)
+
+
+def test_queries_by_value_and_excluded_rows_that_are_not_the_query(catalogue, engine):
+    """The neighbourhood is taken around the row a query EXCLUDES.  A vector that is not that row (a new track, a row of
+    another cluster, a perturbed row) gets a bound that is merely valid — the result is the oracle's all the same."""
+    from spotify_recommender_amd import capi
+    f, eng = catalogue["host"], engine
+    rng = np.random.default_rng(5)
+    rows = query_rows(6, 23)
+    cases = [(f[rows[0]].copy(), int(rows[3])),                                  # a row of ONE cluster, excluding a row of another
+             ((f[rows[1]] + rng.normal(0, 0.02, 12)).astype(np.float32), int(rows[1])),   # near its excluded row, not equal to it
+             (rng.random(12, dtype=np.float32), -1),                             # a new track: nothing excluded
+             (rng.random(12, dtype=np.float32), int(rows[2])),
+             (np.zeros(12, np.float32), int(rows[4])),                           # zero query: every score is 0 (Recommender.cu:271)
+             (-f[rows[5]], int(rows[5]))]                                        # the opposite of a row: every cosine negative
+    for mode in (capi.REPLICA_OFF, capi.REPLICA_AUTO):
+        eng.set_replica(mode)
+        for q, ex in cases:
+            want = oracle.scores(f, np.ascontiguousarray(q), threads=0)
+            for topn in (10, TOPN):
+                idx, sc = eng.query_topn(q, ex, topn)
+                assert_topn_matches(idx, sc, want, ex, topn, ref_idx=oracle.topn_heap(want, ex, topn))
+    eng.set_replica(capi.REPLICA_AUTO)
+
+
+@pytest.mark.parametrize("batch", [12, 32])
+def test_multi_query_pass_alone_and_streamed(catalogue, engine, torch_cuda, batch):
+    """One pass over the fp16 replica for 12 / 32 queries (csrc/replica_multi.hip.h): a call on its own and a stream of
+    such calls, every list against the oracle; the rows sent to the exact chain stay near the clusters' own size."""
+    torch = torch_cuda
+    from spotify_recommender_amd import capi
+    from spotify_recommender_amd.engine import unpack_keys
+    f, eng = catalogue["host"], engine
+    eng.set_batch_path(capi.BATCH_AUTO)
+    rows = query_rows(3 * batch, 100 + batch)
+    r0 = eng.stats().route_multi_fp16
+    c0 = eng.replica_counters()
+    idx, sc, counts = eng.query_batch_topn(f[rows[:batch]], rows[:batch], TOPN)
+    c1 = eng.replica_counters()
+    for b in range(batch):
+        check(f, rows[b], idx[b][:counts[b]], sc[b][:counts[b]], f"{batch}-query call")
+    assert eng.stats().route_multi_fp16 - r0 == 1
+    per_query = (c1["rescored_rows"] - c0["rescored_rows"]) / batch
+    assert per_query < 3 * catalogue["rows_per_cluster"] + 3000, per_query
+    outs = [torch.zeros(batch * TOPN, dtype=torch.int64, device="cuda") for _ in range(3)]
+    for k in range(3):
+        sel = rows[k * batch:(k + 1) * batch]
+        eng.enqueue_batch_keys_streamed(f[sel], sel, TOPN, outs[k])
+    eng.enqueue_flush()
+    torch.cuda.synchronize()
+    for k in range(3):
+        got = outs[k].view(batch, TOPN).cpu().numpy()
+        for b in range(0, batch, 3):   # (every third list of a streamed batch: the oracle is the slow half of this test)
+            i2, s2 = unpack_keys(got[b])
+            check(f, rows[k * batch + b], i2, s2, f"stream of {batch}-query batches, batch {k}")
+
+
+def test_a_batch_of_1024_queries(catalogue, engine, torch_cuda):
+    """The two-pass matrix-core path (csrc/batched.hip.h) at its full chunk: 1024 catalogue rows as queries, 96 of the lists
+    against the oracle, all of them against each other's obvious invariants, nothing handed to the exact queue."""
+    torch = torch_cuda
+    from spotify_recommender_amd import capi
+    from spotify_recommender_amd.engine import unpack_keys
+    f, eng = catalogue["host"], engine
+    eng.set_batch_path(capi.BATCH_AUTO)
+    rows = query_rows(1024, 7)
+    qd = catalogue["dev"][torch.from_numpy(rows).cuda()].contiguous()
+    ex = torch.from_numpy(rows).cuda()
+    keys = torch.zeros(1024 * TOPN, dtype=torch.int64, device="cuda")
+    r0 = eng.stats().route_mfma_two_pass
+    eng.enqueue_batch_keys_dev(qd, ex, TOPN, keys)
+    torch.cuda.synchronize()
+    assert eng.stats().route_mfma_two_pass - r0 == 1
+    d = eng.batched_last_counters()
+    assert d["queued_queries"] == 0, d
+    # the candidates of a query: its own cluster and what the fp16 bound cannot tell from it — not several clusters' worth
+    assert d["candidates_max"] < 3 * catalogue["rows_per_cluster"] + 3000, d
+    got = keys.view(1024, TOPN).cpu().numpy()
+    assert (got != 0).all(), "every query of a 4.2 M-row shard has 100 results"
+    for b in list(range(64)) + list(range(64, 1024, 30)):
+        idx, sc = unpack_keys(got[b])
+        check(f, rows[b], idx, sc, "1024-query batch")
+    for b in range(1024):
+        idx, _ = unpack_keys(got[b])
+        assert rows[b] not in idx, b

@@ -47,9 +47,9 @@ CELLS = [
     # batches on a shard WITHOUT a replica (< 65536 rows): exact 12-query passes, whatever the count
     (30_000, "batch", 2, 10, {"route_multi_fp32": 1}),
     (30_000, "batch", 40, 10, {"route_multi_fp32": 4}),
-    # batches with a replica: 2 queries -> one pass through the 8-bit front end; 3 ... 32 -> one pass over the fp16
-    # replica; 33 and more -> the two-pass matrix-core path (chunks of 1024)
-    (300_000, "batch", 2, 100, {"route_multi_q8": 1}),
+    # batches with a replica: 2 ... 32 queries -> one pass over the fp16 replica; 33 and more -> the two-pass matrix-core
+    # path (chunks of 1024)
+    (300_000, "batch", 2, 100, {"route_multi_fp16": 1}),
     (300_000, "batch", 3, 100, {"route_multi_fp16": 1}),
     (300_000, "batch", 16, 100, {"route_multi_fp16": 1}),
     (300_000, "batch", 17, 100, {"route_multi_fp16": 1}),
@@ -110,20 +110,31 @@ def test_forced_routes_and_the_exact_queue(catalogues):
     rng = np.random.default_rng(5)
     with CosineEngine(f) as eng:
         r0 = routes(eng)
-        eng.set_replica(capi.REPLICA_FP16)
-        eng.query_row_topn(7, 10)
+        exp = capi.has_experiments()   # the A/B routes of MI355REC_EXPERIMENTS builds: refused by the product library
+        if exp:
+            eng.set_replica(capi.REPLICA_FP16)
+            eng.query_row_topn(7, 10)
+        else:
+            with pytest.raises(capi.Mi355Error):
+                eng.set_replica(capi.REPLICA_FP16)
+            with pytest.raises(capi.Mi355Error):
+                eng.set_batch_path(capi.BATCH_Q8)
         eng.set_replica(capi.REPLICA_OFF)
         eng.query_row_topn(7, 10)
         eng.set_replica(capi.REPLICA_AUTO)
-        eng.set_batch_path(capi.BATCH_Q8)
-        eng.query_batch_topn(f[[1, 2, 3, 4, 5]], np.array([1, 2, 3, 4, 5]), 10)
+        if exp:
+            eng.set_batch_path(capi.BATCH_Q8)
+            eng.query_batch_topn(f[[1, 2, 3, 4, 5]], np.array([1, 2, 3, 4, 5]), 10)
         eng.set_batch_path(capi.BATCH_MULTI)
         eng.query_batch_topn(f[[1, 2, 3]], np.array([1, 2, 3]), 10)
         eng.set_batch_path(capi.BATCH_MFMA_NOSKIP)
         eng.query_batch_topn(f[[1, 2, 3]], np.array([1, 2, 3]), 10)
         r1 = routes(eng)
         moved = {r: r1[r] - r0[r] for r in ROUTES if r1[r] != r0[r]}
-        assert moved == {"route_fp16": 1, "route_fp32": 1, "route_multi_q8": 1, "route_multi_fp32": 1, "route_mfma_two_pass": 1}, moved
+        want = {"route_fp32": 1, "route_multi_fp32": 1, "route_mfma_two_pass": 1}
+        if exp:
+            want.update({"route_fp16": 1, "route_multi_q8": 1})
+        assert moved == want, moved
         # a zero query and a huge one cannot claim the pre-filter's bound: the matrix-core path queues them
         eng.set_batch_path(capi.BATCH_MFMA)
         q = f[rng.integers(0, len(f), size=40)].copy()

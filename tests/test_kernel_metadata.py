@@ -15,7 +15,7 @@ def kernels(engine_lib):
 
 
 def test_no_kernel_reserves_scratch(kernels):
-    assert len(kernels) >= 60
+    assert 40 <= len(kernels) <= 60, len(kernels)   # (at most sixty kernels to keep bit-identical)
     bad = [(k["scratch"], k["name"]) for k in kernels if k["scratch"] != 0]
     assert not bad, bad
     assert build.check_no_scratch(build.LIB_ENGINE) == len(kernels)
@@ -28,7 +28,7 @@ def test_hot_kernels_keep_their_occupancy(kernels):
         hits = [k for k in kernels if fragment in k["name"]]
         assert hits, fragment
         return hits
-    for k in of("scan_q8_kernel") + of("scan_half_kernel") + of("scan_half_multi_kernel"):
+    for k in of("scan_q8_kernel") + of("scan_half_multi_kernel"):
         assert k["vgpr"] <= 128 and k["lds"] <= 80 * 1024, k          # 512 threads, two workgroups per CU
     for k in of("11scan_kernelINS_7ScanCfg"):
         assert k["vgpr"] <= 80, k                                        # three workgroups of 512 per CU
@@ -42,7 +42,8 @@ def test_hand_offs_wait_for_their_stores(engine_lib):
     Read from the disassembly of the library that ships."""
     sites = build.handoff_sites(build.LIB_ENGINE)
     kernels = {k for k, _ in sites}
-    for fragment in ("scan_q8_kernel", "scan_half_multi_kernel", "seed_half_multi_kernel", "scan_multi_queued_kernel"):
+    for fragment in ("scan_q8_kernel", "scan_half_multi_kernel", "seed_half_multi_kernel", "scan_multi_queued_kernel",
+                     "11scan_kernelINS_7ScanCfg", "seed_f32_kernel"):
         assert any(fragment in k for k in kernels), (fragment, sorted(kernels))
     bad = sorted({k for k, ok in sites if not ok})
     assert not bad, bad

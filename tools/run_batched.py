@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--catalogue", default="uniform", choices=["uniform", "clustered"])
     ap.add_argument("--spread", type=float, default=0.03)
     ap.add_argument("--contiguous", action="store_true", help="clustered: a cluster's rows lie next to each other")
+    ap.add_argument("--ramp", action="store_true", help="clustered + contiguous: features[11] = cluster / (clusters - 1), the genre ramp of a CSV grouped by genre (DataManager.cpp:244-250,299)")
     ap.add_argument("--clusters", type=int, default=3000)
     ap.add_argument("--check", type=int, default=0, help="compare this many of the batch's queries with the single-query fp32 scan, key for key")
     args = ap.parse_args()
@@ -40,7 +41,7 @@ def main():
     if args.catalogue == "clustered":
         sys.path.insert(0, str(Path(__file__).resolve().parent))
         from catalogues import clustered_catalogue
-        t = clustered_catalogue(args.rows, args.spread, clusters=args.clusters, contiguous=args.contiguous)
+        t = clustered_catalogue(args.rows, args.spread, clusters=args.clusters, contiguous=args.contiguous, ramp=args.ramp)
     else:
         t = synthetic_catalogue(args.rows, seed=12345)
     rows = np.array([(k * 7919) % args.rows for k in range(args.batch)], dtype=np.int64)

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--catalogue", default="uniform", choices=["uniform", "clustered"])
     ap.add_argument("--spread", type=float, default=0.03)
     ap.add_argument("--contiguous", action="store_true", help="clustered: a cluster's rows lie next to each other")
+    ap.add_argument("--ramp", action="store_true", help="clustered + contiguous: features[11] = cluster / (clusters - 1), the genre ramp of a CSV grouped by genre (DataManager.cpp:244-250,299)")
     ap.add_argument("--clusters", type=int, default=3000)
     args = ap.parse_args()
     if args.lib:
@@ -42,7 +43,7 @@ def main():
     if args.catalogue == "clustered":
         sys.path.insert(0, str(Path(__file__).resolve().parent))
         from catalogues import clustered_catalogue
-        t = clustered_catalogue(n, args.spread, clusters=args.clusters, contiguous=args.contiguous)
+        t = clustered_catalogue(n, args.spread, clusters=args.clusters, contiguous=args.contiguous, ramp=args.ramp)
     else:
         t = synthetic_catalogue(n, seed=12345)
     rows = [(k * 7919) % n for k in range(64)]
@@ -51,8 +52,10 @@ def main():
     with CosineEngine(t) as eng:
         st0 = eng.stats()
         out["margin_single"], out["margin_multi"] = round(float(st0.replica_margin_single), 6), round(float(st0.replica_margin_multi), 6)
-        eng.set_batch_path(capi.BATCH_HALF if args.fp16 else capi.BATCH_Q8)
-        out["front_end"] = "fp16 replica, 24 B/row" if args.fp16 else "8-bit replica, 12 B/row, fp16 re-check of the candidates"
+        # (the 8-bit front end is an A/B route of MI355REC_EXPERIMENTS builds since round 5: --lib such a build to time it)
+        front_q8 = not args.fp16 and capi.has_experiments()
+        eng.set_batch_path(capi.BATCH_Q8 if front_q8 else capi.BATCH_HALF)
+        out["front_end"] = "8-bit replica, 12 B/row, fp16 re-check of the candidates" if front_q8 else "fp16 replica, 24 B/row"
         sizes = tuple(int(x) for x in args.sizes.split(",") if x) if not args.only_stream else ()
         for nb in sizes:
             keys = torch.zeros(nb * topn, dtype=torch.int64, device="cuda")

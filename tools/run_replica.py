@@ -30,6 +30,7 @@ def main():
                          "tight clusters, exact duplicates) instead of uniform noise: what the replicas cannot rule out grows")
     ap.add_argument("--spread", type=float, default=0.03, help="clustered: standard deviation of a cluster")
     ap.add_argument("--contiguous", action="store_true", help="clustered: a cluster's rows lie next to each other")
+    ap.add_argument("--ramp", action="store_true", help="clustered + contiguous: features[11] = cluster / (clusters - 1), the genre ramp of a CSV grouped by genre (DataManager.cpp:244-250,299)")
     ap.add_argument("--clusters", type=int, default=3000, help="clustered: number of clusters")
     args = ap.parse_args()
     if args.lib:
@@ -41,7 +42,7 @@ def main():
     from spotify_recommender_amd.synth import synthetic_catalogue
 
     if args.catalogue == "clustered":
-        t = clustered_catalogue(args.rows, args.spread, clusters=args.clusters, contiguous=args.contiguous)
+        t = clustered_catalogue(args.rows, args.spread, clusters=args.clusters, contiguous=args.contiguous, ramp=args.ramp)
     else:
         t = synthetic_catalogue(args.rows, seed=12345)
     rows = [(k * 7919 + 13) % args.rows for k in range(max(args.check, args.steps + 20, 200))]   # 200: the latency loop below
@@ -51,13 +52,15 @@ def main():
         out["replica_build_ms"] = round(float(st.replica_build_ms), 3)
         out["replica_grid_blocks"] = int(st.replica_grid_blocks)
         keys = {m: torch.zeros((args.check, args.topn), dtype=torch.int64, device="cuda") for m in (1, 2, 3)}
+        # (single queries over the fp16 replica: an A/B route of MI355REC_EXPERIMENTS builds since round 5 — use --lib)
+        fp16 = capi.has_experiments()
         if args.only < 0:
-            for mode in (capi.REPLICA_OFF, capi.REPLICA_ON, capi.REPLICA_FP16):
+            for mode in (capi.REPLICA_OFF, capi.REPLICA_ON) + ((capi.REPLICA_FP16,) if fp16 else ()):
                 eng.set_replica(mode)
                 for i in range(args.check):
                     eng.enqueue_row_keys(rows[i], args.topn, keys[mode][i])
                 torch.cuda.synchronize()
-            for mode, name in ((2, "q8"), (3, "fp16")):
+            for mode, name in ((2, "q8"),) + (((3, "fp16"),) if fp16 else ()):
                 same = bool(torch.equal(keys[1], keys[mode]))
                 out[f"keys_identical_{name}"] = same
                 if not same:
@@ -73,7 +76,7 @@ def main():
                 out[f"streamed_identical_{name}"] = bool(torch.equal(sk, keys[1]))
         ring = torch.zeros((64, args.topn), dtype=torch.int64, device="cuda")
         for mode, name in ((capi.REPLICA_OFF, "fp32_rows"), (capi.REPLICA_FP16, "replica_fp16"), (capi.REPLICA_ON, "replica_q8")):
-            if args.only >= 0 and args.only != mode:
+            if (args.only >= 0 and args.only != mode) or (mode == capi.REPLICA_FP16 and not fp16):
                 continue
             eng.set_replica(mode)
             for i in range(20):

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--spread", type=float, default=0.03)
     ap.add_argument("--clusters", type=int, default=3000)
     ap.add_argument("--contiguous", action="store_true")
+    ap.add_argument("--ramp", action="store_true", help="clustered + contiguous: features[11] = cluster / (clusters - 1), the genre ramp of a CSV grouped by genre (DataManager.cpp:244-250,299)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -33,7 +34,7 @@ def main():
     if args.catalogue == "clustered":
         sys.path.insert(0, str(Path(__file__).resolve().parent))
         from catalogues import clustered_catalogue
-        t = clustered_catalogue(n, args.spread, clusters=args.clusters, contiguous=args.contiguous)
+        t = clustered_catalogue(n, args.spread, clusters=args.clusters, contiguous=args.contiguous, ramp=args.ramp)
     else:
         t = synthetic_catalogue(n, seed=12345)
     rows = rng.integers(0, n, size=args.queries)
