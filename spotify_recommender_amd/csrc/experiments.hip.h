@@ -22,6 +22,20 @@ __device__ unsigned long long g_phase_clock[1024 * 8];   // [workgroup][phase]
     do {                                                                                                  \
         if (threadIdx.x == 0 && blockIdx.x < 1023) g_phase_clock[blockIdx.x * 8 + (i)] = wall_clock64();  \
     } while (0)
+// a duration (or a count) accumulated into a slot by the calling thread: MI355REC_PHASE_T0(t) ... MI355REC_PHASE_ADD(i, t)
+#define MI355REC_PHASE_ZERO(i)                                                            \
+    do {                                                                                  \
+        if (threadIdx.x == 0 && blockIdx.x < 1023) g_phase_clock[blockIdx.x * 8 + (i)] = 0; \
+    } while (0)
+#define MI355REC_PHASE_T0(t) const unsigned long long t = wall_clock64()
+#define MI355REC_PHASE_ADD(i, t)                                                                            \
+    do {                                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < 1023) g_phase_clock[blockIdx.x * 8 + (i)] += wall_clock64() - (t); \
+    } while (0)
+#define MI355REC_PHASE_COUNT(i)                                                            \
+    do {                                                                                   \
+        if (threadIdx.x == 0 && blockIdx.x < 1023) g_phase_clock[blockIdx.x * 8 + (i)] += 1; \
+    } while (0)
 // phases of ONE merge (merge_body in the workgroup with blockIdx.x == 0: merge_notify_kernel), kept in row 1023
 #define MI355REC_MPHASE(i)                                                                       \
     do {                                                                                         \
@@ -30,6 +44,18 @@ __device__ unsigned long long g_phase_clock[1024 * 8];   // [workgroup][phase]
 #else
 #define MI355REC_PHASE(i) \
     do {                  \
+    } while (0)
+#define MI355REC_PHASE_ZERO(i) \
+    do {                       \
+    } while (0)
+#define MI355REC_PHASE_T0(t) \
+    do {                     \
+    } while (0)
+#define MI355REC_PHASE_ADD(i, t) \
+    do {                         \
+    } while (0)
+#define MI355REC_PHASE_COUNT(i) \
+    do {                        \
     } while (0)
 #define MI355REC_MPHASE(i) \
     do {                   \

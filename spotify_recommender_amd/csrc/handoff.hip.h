@@ -48,12 +48,13 @@ constexpr int kSampleSlots = kNbhdSlot + 8;                    // ... so such a 
 __device__ __forceinline__ unsigned long long tag_value(uint32_t epoch, uint32_t v) {
     return (static_cast<unsigned long long>(epoch) << 32) | v;
 }
+// (Epoch 0 is never handed out: a reader that has none — a launch without a bound — and a zeroed buffer both read as absent.)
 __device__ __forceinline__ uint32_t untag_value(unsigned long long t, uint32_t epoch) {   // 0 = absent
-    return static_cast<uint32_t>(t >> 32) == epoch ? static_cast<uint32_t>(t) : 0u;
+    return (epoch != 0u && static_cast<uint32_t>(t >> 32) == epoch) ? static_cast<uint32_t>(t) : 0u;
 }
 // A float left under an epoch (a cutoff, a bound): -inf (nothing is ruled out) when the epoch is not the reader's.
 __device__ __forceinline__ float untag_cutoff(unsigned long long t, uint32_t epoch) {
-    return static_cast<uint32_t>(t >> 32) == epoch ? __uint_as_float(static_cast<uint32_t>(t)) : -__builtin_inff();
+    return (epoch != 0u && static_cast<uint32_t>(t >> 32) == epoch) ? __uint_as_float(static_cast<uint32_t>(t)) : -__builtin_inff();
 }
 // Every wave's write-through stores have reached device scope before the workgroup counts itself out.  (A
 // workgroup-scope release fence does NOT wait for global stores on this target: the ISA showed

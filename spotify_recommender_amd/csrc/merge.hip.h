@@ -172,9 +172,40 @@ __device__ __forceinline__ void merge_body(
             if ((tid & 63) == 0 && wave_nonzero) atomicAdd(&s_pair[0], wave_nonzero);
         }
         __syncthreads();
-        if (s_pair[0] >= need_lists)  // uniform
+        const int nonempty = s_pair[0];
+        // FEW NON-EMPTY LISTS.  With a launch-wide bound most workgroups of a scan keep nothing, and on a catalogue whose
+        // similar rows lie next to each other the whole top-k sits in the lists of the two or twenty workgroups that met
+        // the query's cluster: fewer heads than the threshold select needs, thr stays 1, and those lists were then walked
+        // 16 keys per dependent round trip (a query alone at 10 M rows, 3000 contiguous clusters: 67 us against 47 on
+        // uniform rows, all of it here).  Instead: ONE load phase over all keys of the non-empty lists, when they fit.
+        const bool sparse = nonempty < need_lists && static_cast<int64_t>(nonempty) * list_len <= kSurvCap;   // uniform
+        if (nonempty >= need_lists)  // uniform
             thr = block_select_threshold<kThreads, kFirstPer>(hk, need_lists, false, slack, s_sel);
+        if (tid == 0) s_pair[1] = 0;
         __syncthreads();
+        if (sparse) {   // uniform
+#pragma unroll
+            for (int u = 0; u < kFirstPer; ++u)
+                if (hk[u]) s_active[atomicAdd(&s_pair[1], 1)] = static_cast<unsigned short>((u * kThreads + tid) / kMergeFirst);
+            __syncthreads();
+            first = list_len;   // every key is taken here: no deeper rounds (s_more stays 0)
+            const int total = s_pair[1] * list_len;   // <= kSurvCap
+            // all loads are requested before the first is looked at: ONE memory round trip, not one per kThreads keys
+            uint64_t kk[kSurvPer];
+#pragma unroll
+            for (int r = 0; r < kSurvPer; ++r) {
+                const int i = r * kThreads + tid;
+                kk[r] = i < total ? ld_key<kCoherent>(&lists[static_cast<int64_t>(s_active[i / list_len]) * list_stride + (i % list_len)]) : 0ull;
+            }
+#pragma unroll
+            for (int r = 0; r < kSurvPer; ++r) {   // (uniform loop: every lane takes part in the ballot)
+                const uint64_t have = __ballot(kk[r] != 0ull);
+                int base = 0;
+                if ((tid & 63) == 0 && have) base = atomicAdd(&s_count, __popcll(have));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (kk[r]) s_surv[base + lanes_below(have)] = kk[r];
+            }
+        } else {
 #pragma unroll
         for (int u = 0; u < kFirstPer; ++u) {
             const bool pass = k[u] >= thr;
@@ -191,6 +222,7 @@ __device__ __forceinline__ void merge_body(
                     s_more = 1;
                 }
             }
+        }
         }
     } else {
         // Few lists (e.g. one per rank) or very many: probe each list at depth

@@ -526,23 +526,28 @@ __device__ __forceinline__ int hm_resolve_stage(HalfMultiSmem& sm, int staged, c
 __device__ __forceinline__ void hm_exact_step(HalfMultiSmem& sm, const float* __restrict__ feats, int64_t n, int64_t row_base,
                                               int64_t first_row, uint32_t cols, int topk) {
     const int lane = threadIdx.x & 63;
-    for (int u = 0; u < kHmStepRows / 64; ++u) {
+    constexpr int kGroups = kHmStepRows / 64;
+    // the next 64 rows are requested before these are scored (all of the step's rows at once spilled)
+    Row cur = load_row(feats, first_row + lane < n ? first_row + lane : static_cast<int64_t>(0));
+#pragma unroll 1
+    for (int u = 0; u < kGroups; ++u) {
         const int64_t row = first_row + u * 64 + lane;
-        const bool have = row < n;
-        const Row r = load_row(feats, have ? row : static_cast<int64_t>(0));
+        const int64_t ahead = row + 64;
+        const Row nxt = load_row(feats, (u + 1 < kGroups && ahead < n) ? ahead : static_cast<int64_t>(0));
         for (uint32_t rest = cols; rest; rest &= rest - 1u) {   // wave-uniform
             const int q0 = __builtin_ctz(rest);
             float qv[kDim];
 #pragma unroll
             for (int j = 0; j < kDim; ++j) qv[j] = sm.qf[q0][j];
-            const float s = cosine_score(qv, sm.qn[q0], r);
+            const float s = cosine_score(qv, sm.qn[q0], cur);
             const int64_t g = row_base + row;
             uint64_t key = pack_key(s, static_cast<uint32_t>(g));
             if (g == sm.excl[q0]) key = 0;
             const uint64_t seen = __hip_atomic_load(&sm.thr[q0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const bool pass = have && key > seen;
+            const bool pass = row < n && key > seen;
             if (__ballot(pass)) hm_append_locked(sm, q0, pass, key, topk);
         }
+        cur = nxt;
     }
 }
 
@@ -677,6 +682,8 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
     unsigned nblocks = gridDim.x;   // scanning workgroups
     HalfMultiSmem* smp;
     MI355REC_PHASE(0);
+    MI355REC_PHASE_ZERO(6);
+    MI355REC_PHASE_ZERO(7);
     if constexpr (kRide) {
         nblocks = gridDim.x - static_cast<unsigned>(ride.merge_wgs) - static_cast<unsigned>(ride.seed_wgs) - static_cast<unsigned>(ride.nb_wgs);
         if (bid >= nblocks) {
@@ -728,7 +735,12 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
     const int64_t last_pair = n_pairs - 1;
     const int64_t n_steps = (n_pairs + 64 * kHmChunks - 1) / (64 * kHmChunks);
     const int64_t total_waves = static_cast<int64_t>(nblocks) * kHmWaves;
-    int64_t step = static_cast<int64_t>(bid) * kHmWaves + wave;   // consecutive steps to consecutive waves: one moving window
+    // Consecutive steps go to consecutive WORKGROUPS (wave w of workgroup b: steps w * nblocks + b, + total_waves, ...): the
+    // chip still reads one moving window of total_waves steps, but a run of steps that lies inside a query's cluster (a
+    // catalogue sorted by genre: thirteen steps of 256 rows for a 3300-row cluster, every row a candidate) is spread over
+    // as many workgroups, one wave each, instead of queueing on ONE workgroup's per-query lock (measured at 10 M rows, 3000
+    // contiguous clusters, 12 queries: 82 us per pass with consecutive steps on consecutive waves).
+    int64_t step = static_cast<int64_t>(wave) * nblocks + bid;
     auto load_chunk = [&](HalfTile& dst, int64_t st, int u) {
         int64_t pair = (st * kHmChunks + u) * 64 + lane;
         pair = pair < n_pairs ? pair : last_pair;   // unconditional prefetch (see scan_kernel)
@@ -862,8 +874,19 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
         // into the tile prologue and spills them
         uint32_t lr0 = 4u * static_cast<uint32_t>(hh);
         asm volatile("" : "+v"(lr0));
+        {
+            const uint64_t any0 = __ballot(hits != 0u);
+            step_cols |= static_cast<uint32_t>(any0) | static_cast<uint32_t>(any0 >> 32);   // lanes c and 32 + c hold query column c
+        }
+        // A column whose sixteen results in a lane ALL hit: the tile lies inside that query's cluster (a catalogue sorted by
+        // genre) — or there is no cutoff at all.  Either way the step will not fit the staging buffer: it goes through the
+        // exact chain for the columns that hit (hm_exact_step), and noting its hits one wave-uniform round at a time
+        // first (128 rounds for a step of 256 rows: measured ~10 us, as much as the exact step itself) would be wasted.
+        if (overflow || __ballot(hits == 0xffffu)) {   // uniform
+            overflow = true;
+            return;
+        }
         for (uint64_t any = __ballot(hits != 0u); any; any = __ballot(hits != 0u)) {   // wave-uniform rounds
-            step_cols |= static_cast<uint32_t>(any) | static_cast<uint32_t>(any >> 32);   // lanes c and 32 + c hold query column c
             const int i = hits ? __builtin_ctz(hits) : 0;
             const uint32_t lr = lr0 + static_cast<uint32_t>((i & 3) + 8 * (i >> 2));   // the lane of the tile that loaded the row
             const uint32_t row = first_row + 2u * lr;
@@ -1010,6 +1033,8 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
         // The buffer is drained when it is half full, so that only a step with more than 64 candidates of
         // its own can overflow it; such a step forgets what it noted and goes through the exact chain whole.
         if (__builtin_expect(overflow || staged >= kHmStage / 2, 0)) {   // uniform, rare
+            MI355REC_PHASE_T0(t_drain);
+            if (overflow) MI355REC_PHASE_COUNT(7);
             if (overflow) staged = staged_before;
             n_rescored += hm_resolve_stage(sm, staged, feats, row_base, topk, kQ8 ? reinterpret_cast<const uint32_t*>(half) : nullptr);
             staged = 0;
@@ -1019,6 +1044,7 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
                 n_rescored += kHmStepRows * __builtin_popcount(cols);
                 overflow = false;
             }
+            MI355REC_PHASE_ADD(6, t_drain);   // (wave 0) time in drains and exact steps, [7] = exact steps
         }
     }
     MI355REC_PHASE(2);    // (wave 0 of the workgroup) its steps are done

@@ -42,8 +42,8 @@ def catalogue(request, torch_cuda):
     t = clustered_catalogue(N, spread, seed=4242 + clusters, clusters=clusters, contiguous=True, ramp=ramp)
     f = t.cpu().numpy()
     assert f.dtype == np.float32 and f.shape == (N, 12)
-    if ramp:
-        assert np.all(np.diff(f[::1000, 11]) >= 0), "the genre column must ramp with the row index"
+    if ramp:   # (2 % of the rows are copies of random other rows: the ramp holds for the rest)
+        assert np.mean(np.diff(f[::1000, 11]) >= 0) > 0.9 and f[:1000, 11].mean() < 0.05 and f[-1000:, 11].mean() > 0.95
     return {"dev": t, "host": f, "clusters": clusters, "rows_per_cluster": N // clusters, "ramp": ramp}
 
 

@@ -53,8 +53,10 @@ def test_randomised_parity():
                               p=[.03, .03, .05, .05, .05, .05, .1, .1, .1, .14, .15, .1, .05]))
         f = make_catalogue(rng, rows)
         with CosineEngine(f) as eng:
-            # single queries over the 8-bit replica / the fp16 one (forced on: AUTO starts at 1 M rows) / AUTO
-            eng.set_replica((2, 3, 0)[case % 3])
+            # single queries over the 8-bit replica (forced on: AUTO starts at 1 M rows) / the fp32 rows / AUTO — and, in
+            # MI355REC_EXPERIMENTS builds, the fp16 replica in place of the fp32 rows
+            from spotify_recommender_amd import capi
+            eng.set_replica((2, 3 if capi.has_experiments() else 1, 0)[case % 3])
             for _ in range(3):
                 topn = int(rng.choice([1, 2, 10, 100, 128, 129, 1000, 1024, 1025, 2500]))
                 q = int(rng.integers(0, rows))
@@ -139,7 +141,9 @@ def test_randomised_multi_query_and_sharded_streams():
         topn = int(rng.choice([1, 5, 50, 100, 128]))
         # ---- one handle: forced multi-query passes, then a stream of batches
         with CosineEngine(f) as eng:
-            eng.set_batch_path(3 + case % 2)   # the multi-query pass forced, rows from the fp16 / the 8-bit replica
+            from spotify_recommender_amd import capi
+            # the multi-query pass forced: rows from the fp16 replica (experiment builds: every other case from the 8-bit one)
+            eng.set_batch_path(3 + (case % 2 if capi.has_experiments() else 0))
             batch = int(rng.integers(2, 45))
             qrows = rng.integers(0, rows, size=batch)
             queries = f[qrows].copy()
