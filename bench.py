@@ -65,10 +65,22 @@ def parse_args():
     ap.add_argument("--no-streamed", action="store_true",
                     help="merge every query in its own launch instead of inside the next query's scan launch")
     ap.add_argument("--replica-fp16", action="store_true",
-                    help="A/B: single queries scan the 24 B/row fp16 replica instead of the 12 B/row 8-bit one")
+                    help="A/B (an MI355REC_EXPERIMENTS build of the library only): single queries scan the 24 B/row fp16 "
+                         "replica instead of the 12 B/row 8-bit one")
     ap.add_argument("--no-replica", action="store_true",
                     help="scan the fp32 rows (48 B/row, the reference's own traffic) instead of a replica")
     ap.add_argument("--latency-queries", type=int, default=1000)
+    ap.add_argument("--catalogue", choices=["uniform", "clustered-contiguous"], default="uniform",
+                    help="clustered-contiguous: the `clustered` object (every route over a catalogue sorted by genre, "
+                         "spotify_recommender_amd/synth.py) covers 3000 and 300 contiguous clusters with and without the genre "
+                         "ramp instead of the one shape the default run carries")
+    ap.add_argument("--no-clustered", action="store_true", help="skip the `clustered` object")
+    ap.add_argument("--no-config0", action="store_true",
+                    help="skip the `config0` object (BASELINE configs[0]: a 114 000-track CSV -> songs_data.bin -> top-10 on the GPU "
+                         "path and on the product's CPU backend)")
+    ap.add_argument("--preflight", action="store_true",
+                    help="--gpus N, single process: print the peer-access matrix, the placement AUTO would choose and the device "
+                         "memory per shard, run ONE query per transport against the oracle, and exit before any timing")
     ap.add_argument("--virtual-shards", type=int, default=0,
                     help="drive the product's single-process row-sharded engine (mi355rec_create_sharded_on) with this "
                          "many shards of ONE GPU: the multi-GPU orchestration rehearsed on a one-GPU box")
@@ -151,6 +163,276 @@ def host_threads(omp_max: int):
     return n, info
 
 
+def probe_gbps_of(eng, torch, which, n_bytes, dev):
+    """The plain read-only stream over one buffer of the handle (csrc/kernels.hip.h, stream_probe_kernel), 20 timed
+    launches behind 3 untimed ones: GB/s, or None when the handle has no such buffer."""
+    from spotify_recommender_amd import capi
+    sink = torch.zeros(4096, dtype=torch.int32, device=dev)
+    try:
+        for _ in range(3):
+            eng.enqueue_stream_probe(sink, which=which)
+    except capi.Mi355Error:
+        return None
+    torch.cuda.synchronize()
+    eng.set_timing(True)
+    for _ in range(20):
+        eng.enqueue_stream_probe(sink, which=which)
+    torch.cuda.synchronize()
+    ms = float(eng.stats().last_scan_ms)
+    eng.set_timing(False)
+    return n_bytes / (ms * 1e-3) / 1e9 if ms > 0 else None
+
+
+def stream_leg(eng, torch, rows, topn, steps, warmup):
+    """A stream of single queries (merge riding in the next launch, flush inside the timed region): us per step, the scan
+    kernel's mean time from the library's HIP events, rows sent to the exact chain per query, the last result."""
+    ring = [torch.zeros(topn, dtype=torch.int64, device="cuda") for _ in range(4)]
+    for k in range(warmup):
+        eng.enqueue_row_keys_streamed(int(rows[k % len(rows)]), topn, ring[k % 4])
+    eng.enqueue_flush()
+    torch.cuda.synchronize()
+    c0 = eng.replica_counters()
+    eng.set_timing(max(1, steps // 16))
+    t0 = time.perf_counter()
+    for k in range(steps):
+        eng.enqueue_row_keys_streamed(int(rows[(warmup + k) % len(rows)]), topn, ring[k % 4])
+    eng.enqueue_flush()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    k_ms = float(eng.stats().last_scan_ms)
+    eng.set_timing(False)
+    c1 = eng.replica_counters()
+    return {"us_per_step": round(dt * 1e6, 2), "queries_per_s": round(1.0 / dt, 1), "scan_kernel_us": round(k_ms * 1e3, 2),
+            "rows_to_exact_chain_per_query": round((c1["rescored_rows"] - c0["rescored_rows"]) / steps, 1)}, \
+        (int(rows[(warmup + steps - 1) % len(rows)]), ring[(steps - 1) % 4].clone())
+
+
+def clustered_object(args, torch, np, dev, shapes):
+    """Every route over catalogues whose similar rows lie NEXT TO EACH OTHER (a CSV grouped by genre: DataManager.cpp:244-250,299)
+    — where an evenly spaced sample misses the query's own cluster and the launch-wide bound has to come from the excluded
+    row's neighbourhood (csrc/handoff.hip.h).  Same sizes as the headline (rows x top-N), its own catalogue and handle per
+    shape; a few results of each are checked against the oracle."""
+    from oracle import oracle
+    from spotify_recommender_amd import CosineEngine, capi
+    from spotify_recommender_amd.engine import unpack_keys
+    from spotify_recommender_amd.synth import clustered_catalogue
+    n, topn = args.rows, args.topn
+    out = {"rows": n, "topn": topn, "generator": "spotify_recommender_amd.synth.clustered_catalogue(contiguous=True), seed 777",
+           "queries": "catalogue rows (k * 104729) mod N: spread over the whole shard", "shapes": []}
+    q_rows = [(k * 104729) % n for k in range(2048)]
+    for clusters, spread, ramp in shapes:
+        t = clustered_catalogue(n, spread, clusters=clusters, contiguous=True, ramp=ramp, device=dev)
+        shape = {"clusters": clusters, "rows_per_cluster": n // clusters, "spread": spread, "genre_ramp": ramp}
+        checks = []
+        with CosineEngine(t) as eng:
+            eng.set_replica(capi.REPLICA_OFF)
+            shape["fp32_rows_stream"], last = stream_leg(eng, torch, q_rows, topn, 100, 10)
+            checks.append(last)
+            eng.set_replica(capi.REPLICA_AUTO)
+            shape["replica_q8_stream"], last = stream_leg(eng, torch, q_rows, topn, 200, 20)
+            checks.append(last)
+            lat = []
+            for k in range(100):
+                t1 = time.perf_counter()
+                res = eng.query_row_topn(q_rows[300 + k], topn)
+                lat.append((time.perf_counter() - t1) * 1e6)
+            lat.sort()
+            shape["one_query_alone_p50_us"] = round(lat[len(lat) // 2], 1)
+            checks.append((q_rows[399], res))
+            if topn <= 128:
+                for nb in (12, 32):
+                    sel = np.array(q_rows[400:400 + nb], dtype=np.int64)
+                    qv = t[torch.from_numpy(sel).to(dev)].cpu().numpy()
+                    rings = [torch.zeros(nb * topn, dtype=torch.int64, device=dev) for _ in range(4)]
+                    for k in range(4):
+                        eng.enqueue_batch_keys_streamed(qv, sel, topn, rings[k % 4])
+                    eng.enqueue_flush()
+                    torch.cuda.synchronize()
+                    eng.set_timing(1)
+                    t1 = time.perf_counter()
+                    for k in range(20):
+                        eng.enqueue_batch_keys_streamed(qv, sel, topn, rings[k % 4])
+                    eng.enqueue_flush()
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t1) / 20
+                    k_ms = float(eng.stats().last_scan_ms)
+                    eng.set_timing(False)
+                    shape[f"pass_of_{nb}_streamed"] = {"us_per_call": round(dt * 1e6, 1), "queries_per_s": round(nb / dt, 1),
+                                                       "launch_kernel_us": round(k_ms * 1e3, 1)}
+                    checks.append((int(sel[nb - 1]), rings[3][(nb - 1) * topn:nb * topn].clone()))
+                bq = min(args.batch, 1024)
+                bsel = torch.from_numpy(np.array(q_rows[500:500 + bq], dtype=np.int64)).to(dev)
+                qd = t[bsel].contiguous()
+                keys = torch.zeros(bq * topn, dtype=torch.int64, device=dev)
+                eng.enqueue_batch_keys_dev(qd, bsel, topn, keys)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    eng.enqueue_batch_keys_dev(qd, bsel, topn, keys)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / 5
+                d = eng.batched_last_counters()
+                shape[f"batch_of_{bq}"] = {"ms_per_call": round(dt * 1e3, 4), "queries_per_s": round(bq / dt, 1),
+                                           "candidates_per_query": round(d["candidates_total"] / max(1, bq - d["queued_queries"]), 1),
+                                           "candidates_max": d["candidates_max"], "queued_to_exact_scan": d["queued_queries"]}
+                checks.append((q_rows[500 + bq // 2], keys[(bq // 2) * topn:(bq // 2 + 1) * topn].clone()))
+        host = t.cpu().numpy()
+        ok = True
+        for row, got in checks:
+            if isinstance(got, tuple):
+                idx, sc = got
+            else:
+                idx, sc = unpack_keys(got.cpu().numpy())
+            want = oracle.scores(host, host[row], threads=0)
+            ci, cs = oracle.topn_canonical(want, row, topn)
+            ok = ok and np.asarray(idx).tolist() == ci.tolist() and bool(np.array_equal(np.asarray(sc), cs + np.float32(0)))
+        shape["verified_against_oracle"] = bool(ok)
+        shape["verified_queries"] = len(checks)
+        out["shapes"].append(shape)
+        del t, host
+        torch.cuda.empty_cache()
+    return out
+
+
+def config0_object(torch, np):
+    """BASELINE configs[0]: a 114 000-track Spotify-shaped CSV (114 genres x 1000 tracks, grouped by genre like the Kaggle
+    file) -> DataManager preprocessing -> songs_data.bin -> top-10, on the GPU path (a query alone and a stream) and — in a
+    FRESH CHILD PROCESS started with the devices hidden, never a re-exec of this one — on the product's own CPU backend
+    (csrc/cpu_backend.cpp), with the oracle's OpenMP port on the same features beside them and the load + initialize times
+    of SURVEY.md §8(f) rank 3."""
+    import ctypes
+    import subprocess
+    import tempfile
+    from oracle import oracle
+    from spotify_recommender_amd import CosineEngine, build, capi
+    build.build_shim()
+    L = ctypes.CDLL(str(build.LIB_SHIM))
+    L.shim_preprocess.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    L.shim_fast_load.argtypes = [ctypes.c_char_p]
+    L.shim_fast_load.restype = ctypes.c_void_p
+    L.shim_fast_initialize.argtypes = [ctypes.c_void_p]
+    L.shim_fast_free.argtypes = [ctypes.c_void_p]
+    L.shim_load.argtypes = [ctypes.c_char_p]
+    L.shim_load.restype = ctypes.c_void_p
+    L.shim_free.argtypes = [ctypes.c_void_p]
+    L.shim_song_features.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    n, topn = 114_000, 10
+    out = {"workload": "BASELINE configs[0]: 114 000-track CSV (114 genres x 1000, grouped by genre), 12 features, top-10",
+           "rows": n, "topn": topn}
+    with tempfile.TemporaryDirectory() as tmp:
+        tmp = Path(tmp)
+        rng = np.random.default_rng(114)
+        cols = ("track_id,track_name,artists,danceability,energy,key,loudness,mode,speechiness,"
+                "acousticness,instrumentalness,liveness,valence,tempo,track_genre")
+        lines = [cols]
+        for g in range(114):
+            block = rng.random((1000, 9))
+            for i in range(1000):
+                r = block[i]
+                k = g * 1000 + i
+                lines.append(f"t{k:06d},Track {k},Artist {k % 5000},{r[0]:.4f},{r[1]:.4f},{int(r[2] * 12)},"
+                             f"{-60 * r[3]:.3f},{int(r[4] * 2)},{r[5]:.4f},{r[6]:.5f},{r[7] ** 6:.6f},"
+                             f"{r[8]:.4f},{(r[0] + r[1]) / 2:.4f},{60 + 140 * r[2]:.3f},genre{g:03d}")
+        csv = tmp / "dataset.csv"
+        csv.write_text("\n".join(lines) + "\n")
+        binf = tmp / "songs_data.bin"
+        t0 = time.perf_counter()
+        assert L.shim_preprocess(str(csv).encode(), str(binf).encode()) == 1
+        out["preprocess_csv_s"] = round(time.perf_counter() - t0, 3)
+        out["songs_data_bin_bytes"] = binf.stat().st_size
+        t0 = time.perf_counter()
+        fast = L.shim_fast_load(str(binf).encode())
+        assert fast and L.shim_fast_initialize(fast) == 1
+        out["load_and_initialize_s"] = {"loadCatalogue + initialize(matrix)": round(time.perf_counter() - t0, 4)}
+        L.shim_fast_free(fast)
+        t0 = time.perf_counter()
+        slow = L.shim_load(str(binf).encode())
+        L.shim_initialize.argtypes = [ctypes.c_void_p]
+        assert slow and L.shim_initialize(slow) == 1
+        out["load_and_initialize_s"]["loadData + initialize(vector<Song>) (the reference's path)"] = round(time.perf_counter() - t0, 4)
+        feats = np.zeros((n, 12), np.float32)
+        gid = ctypes.c_int(0)
+        for i in range(n):
+            L.shim_song_features(slow, i, feats[i].ctypes.data, ctypes.byref(gid))
+        L.shim_free(slow)
+        np.save(tmp / "feats.npy", feats)
+        q_rows = [(k * 7919) % n for k in range(1200)]
+        # (i) the GPU path
+        with CosineEngine(feats) as eng:
+            st = eng.stats()
+            for k in range(50):
+                eng.query_row_topn(q_rows[k], topn)
+            lat = []
+            for k in range(500):
+                t1 = time.perf_counter()
+                res = eng.query_row_topn(q_rows[50 + k], topn)
+                lat.append((time.perf_counter() - t1) * 1e6)
+            lat.sort()
+            leg, last = stream_leg(eng, torch, q_rows, topn, 1000, 100)
+            out["gpu"] = {"route": "fp32 rows (48 B/row; shards below 1 M rows are launch-bound either way)" if not st.replica_active else "replica",
+                          "one_query_alone_p50_us": round(lat[len(lat) // 2], 1), "one_query_alone_p99_us": round(lat[int(len(lat) * 0.99)], 1),
+                          "streamed_queries_per_s": leg["queries_per_s"], "streamed_us_per_query": leg["us_per_step"],
+                          "scan_kernel_us": leg["scan_kernel_us"]}
+            want = oracle.scores(feats, feats[q_rows[549]], threads=0)
+            ci, cs = oracle.topn_canonical(want, q_rows[549], topn)
+            out["gpu"]["verified_against_oracle"] = bool(res[0].tolist() == ci.tolist() and np.array_equal(res[1], cs + np.float32(0)))
+        # (ii) the product's CPU backend, in a child that never sees a device
+        child = ("import sys, time, json, numpy as np\n"
+                 f"sys.path.insert(0, {str(ROOT)!r})\n"
+                 "from spotify_recommender_amd import capi\n"
+                 "from spotify_recommender_amd.engine import NodeEngine\n"
+                 f"f = np.load({str(tmp / 'feats.npy')!r})\n"
+                 "assert capi.lib().mi355rec_device_count() == 0, 'the child must not see a device'\n"
+                 "node = NodeEngine(f, n_devices=0, placement=capi.PLACEMENT_AUTO)\n"
+                 "assert node.placement() == capi.PLACEMENT_CPU\n"
+                 f"rows = [(k * 7919) % {n} for k in range(4000)]\n"
+                 f"for k in range(20): node.query_row_topn(rows[k], {topn})\n"
+                 "lat = []\n"
+                 "t0 = time.perf_counter(); done = 0\n"
+                 "while time.perf_counter() - t0 < 4.0:\n"
+                 "    t1 = time.perf_counter()\n"
+                 f"    r = node.query_row_topn(rows[20 + done % 3000], {topn})\n"
+                 "    lat.append(time.perf_counter() - t1); done += 1\n"
+                 "dt = time.perf_counter() - t0\n"
+                 "lat.sort()\n"
+                 f"last = node.query_row_topn(rows[7], {topn})\n"
+                 "print(json.dumps({'queries_per_s': round(done / dt, 1), 'p50_us': round(lat[len(lat) // 2] * 1e6, 1), 'queries': done,\n"
+                 "                  'note': node.note(), 'idx': last[0].tolist(), 'score_bits': np.asarray(last[1]).view(np.uint32).tolist()}))\n")
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        p = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, env=env, timeout=180)
+        if p.returncode == 0:
+            r = json.loads(p.stdout.strip().splitlines()[-1])
+            want = oracle.scores(feats, feats[q_rows[7]], threads=0)
+            ci, cs = oracle.topn_canonical(want, q_rows[7], topn)
+            import re
+            m = re.search(r"\((\d+) ", r["note"])
+            threads = int(m.group(1)) if m else None
+            out["cpu_backend"] = {"queries_per_s": r["queries_per_s"], "one_query_p50_us": r["p50_us"], "sample": f"{r['queries']} queries (4 s)",
+                                  "threads": threads, "note": r["note"], "process": "fresh child, HIP_VISIBLE_DEVICES='' before any GPU call",
+                                  "verified_against_oracle": bool(r["idx"] == ci.tolist() and
+                                                                  r["score_bits"] == (cs + np.float32(0)).view(np.uint32).tolist())}
+        else:
+            out["cpu_backend"] = {"unavailable": (p.stderr or p.stdout)[-400:]}
+        # (iii) the oracle's OpenMP port on the same features (the checker, timed as in cpu_baseline)
+        threads, host = host_threads(oracle.max_threads())
+        oracle.recommend_omp(feats, q_rows[0], topn, threads)
+        t0 = time.perf_counter()
+        done = 0
+        while time.perf_counter() - t0 < 3.0:
+            oracle.recommend_omp(feats, q_rows[done % 1000], topn, threads)
+            done += 1
+        out["oracle_port"] = {"queries_per_s": round(done / (time.perf_counter() - t0), 1), "threads": threads, "sample": f"{done} queries (3 s)",
+                              "kind": "port (oracle/cosine_oracle.c, OpenMP rows + per-thread top-N)"}
+        oracle.recommend_by_index(feats, q_rows[0], topn)
+        t0 = time.perf_counter()
+        done = 0
+        while time.perf_counter() - t0 < 2.0:
+            oracle.recommend_by_index(feats, q_rows[done % 1000], topn)
+            done += 1
+        out["oracle_port"]["serial_reference_loop_qps"] = round(done / (time.perf_counter() - t0), 1)
+    return out
+
+
 def cpu_baseline(feats_host, topn, query_rows):
     """The oracle timed on the host cores: B1 (OpenMP rows + per-thread top-N) is the reported value — the portable
     build the checker uses (gcc -O3, no -march: the reference's own flags, Makefile:9) — with the same source built
@@ -204,6 +486,71 @@ def cpu_baseline(feats_host, topn, query_rows):
     }
 
 
+def preflight(args, json_fd, torch, np, capi, NodeEngine, feats_host, devices, virtual):
+    """`--gpus N --preflight`: what a first contact with N real GPUs should say BEFORE anything is timed — which device can
+    map which (the PEER transport stores keys through those mappings and reads query rows through them), the placement and
+    shard count AUTO would choose for this catalogue, the device memory a shard needs against what each device has free —
+    and ONE query per transport and placement through the product's node handle against the oracle, so that a
+    misconfigured node fails here with a sentence, not in the timed stream with a hang."""
+    from oracle import oracle
+    n, topn = args.rows, args.topn
+    g = len(devices)
+    real = sorted(set(devices))
+    report = {"preflight": True, "gpus": g, "virtual": bool(virtual), "rows": n, "topn": topn, "devices_visible": torch.cuda.device_count()}
+    peer = {}
+    for a in real:
+        peer[str(a)] = {str(b): (bool(torch.cuda.can_device_access_peer(a, b)) if a != b else True) for b in real}
+    report["peer_access"] = peer
+    report["all_pairs_peer"] = all(all(v.values()) for v in peer.values())
+    auto = int(capi.lib().mi355rec_auto_shards(n, torch.cuda.device_count()))
+    report["auto_placement"] = {"shards": auto, "rule": "SHARDED over clamp(rows // 4 M, 1, visible devices) devices (include/mi355rec.h, PLACEMENT)",
+                                "rows_per_shard": -(-n // max(1, auto))}
+    rows_per = -(-n // g)
+    report["memory"] = {"bytes_per_row_resident": 84, "note": "48 B fp32 row + 24 B fp16 replica + 12 B 8-bit replica",
+                        "sharded_bytes_per_device": rows_per * 84, "replicated_bytes_per_device": n * 84,
+                        "free_bytes": {str(d): int(torch.cuda.mem_get_info(d)[0]) for d in real}}
+    row = (7 * 7919) % n
+    want = oracle.scores(feats_host, feats_host[row], threads=0)
+    ci, cs = oracle.topn_canonical(want, row, topn)
+    checks = []
+    ok_all = True
+    plan = [(capi.PLACEMENT_SHARDED, capi.TRANSPORT_PEER, "sharded / peer stores"),
+            (capi.PLACEMENT_SHARDED, capi.TRANSPORT_RCCL, "sharded / one ncclAllGather per rank"),
+            (capi.PLACEMENT_REPLICATED, None, "replicated (no exchange)")]
+    for placement, transport, label in plan:
+        entry = {"what": label}
+        try:
+            if transport == capi.TRANSPORT_RCCL and virtual:
+                raise RuntimeError("RCCL wants one device per rank: not with virtual shards of one GPU")
+            node = NodeEngine(feats_host, devices=devices, placement=placement)
+            try:
+                if transport is not None:
+                    node.set_transport(transport)
+                idx, sc = node.query_row_topn(row, topn)             # the synchronous call
+                t = node.enqueue_row(row, topn)                      # ... and the ticketed stream
+                node.enqueue_flush()
+                idx2, sc2 = node.wait(t, topn)
+                good = (idx.tolist() == ci.tolist() and bool(np.array_equal(sc, cs + np.float32(0))) and
+                        idx2.tolist() == ci.tolist() and bool(np.array_equal(sc2, cs + np.float32(0))))
+                entry.update({"matches_oracle": bool(good), "rows_by_pointer": node.rows_by_pointer(), "note": node.note(),
+                              "shard_rows": node.info()["shard_rows"]})
+                ok_all = ok_all and good
+            finally:
+                node.close()
+        except Exception as e:
+            entry["failed"] = str(e)[:300]
+            if not (transport == capi.TRANSPORT_RCCL and virtual):
+                ok_all = False
+        checks.append(entry)
+    report["one_query_per_transport"] = checks
+    report["ok"] = bool(ok_all)
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(report) + "\n").encode())
+    if not ok_all:
+        raise SystemExit("preflight FAILED: " + "; ".join(f"{c['what']}: {c.get('failed', 'result differs from the oracle')}"
+                                                          for c in checks if c.get("failed") or c.get("matches_oracle") is False))
+
+
 def run_node(args, json_fd):
     """`--gpus N` launched plainly (or `--virtual-shards G`): ONE process drives every shard through the
     product's row-sharded C-ABI handle (mi355rec_create_sharded / _on, csrc/sharded.hip) — the engine the
@@ -234,6 +581,8 @@ def run_node(args, json_fd):
         del full
         torch.cuda.empty_cache()
 
+    if args.preflight:
+        return preflight(args, json_fd, torch, np, capi, NodeEngine, feats_host, devices, virtual)
     replicated = args.placement == "replicated"
     node = NodeEngine(feats_host, devices=devices,
                       placement=capi.PLACEMENT_REPLICATED if replicated else capi.PLACEMENT_SHARDED)
@@ -524,6 +873,9 @@ def main():
 
     eng = CosineEngine(shard, row_base=lo)
     from spotify_recommender_amd import capi
+    if args.replica_fp16 and not capi.has_experiments():
+        raise SystemExit("--replica-fp16 needs an MI355REC_EXPERIMENTS build of libmi355rec.so (single queries over the fp16 replica "
+                         "are an A/B route since round 5)")
     replica_mode = capi.REPLICA_FP16 if args.replica_fp16 else capi.REPLICA_AUTO
     if args.no_replica:
         eng.set_replica(capi.REPLICA_OFF)
@@ -856,21 +1208,17 @@ def main():
             del c5, q5, k5
             torch.cuda.empty_cache()
 
-    # achievable-HBM ceiling probe on the same buffer (plain read-only stream)
-    probe_gbps = None
+    # The read ceiling of EVERY buffer a timed kernel streams, taken over that very buffer in the state the timed stream
+    # leaves it in (a plain read-only kernel, csrc/kernels.hip.h stream_probe_kernel): the 480 MB fp32 matrix comes from
+    # HBM, the 120 MB 8-bit replica sits in the 256 MiB Infinity Cache between two passes — a kernel's rate is only ever
+    # held against the probe of ITS buffer.
+    probe_gbps = probe_q8 = probe_fp16 = None
     if not args.no_kernel_events:
-        sink = torch.zeros(4096, dtype=torch.int32, device=dev)
-        for _ in range(3):
-            eng.enqueue_stream_probe(sink)
-        torch.cuda.synchronize()
-        eng.set_timing(True)
-        for _ in range(20):
-            eng.enqueue_stream_probe(sink)
-        torch.cuda.synchronize()
-        probe_ms = eng.stats().last_scan_ms
-        eng.set_timing(False)
-        if probe_ms > 0:
-            probe_gbps = (hi - lo) * BYTES_PER_ROW / (probe_ms * 1e-3) / 1e9
+        rows_l = hi - lo
+        probe_gbps = probe_gbps_of(eng, torch, capi.PROBE_FP32_ROWS, rows_l * BYTES_PER_ROW, dev)
+        if replica:
+            probe_q8 = probe_gbps_of(eng, torch, capi.PROBE_Q8_REPLICA, (rows_l + 3) // 4 * 48, dev)
+            probe_fp16 = probe_gbps_of(eng, torch, capi.PROBE_FP16_REPLICA, (rows_l + 1) // 2 * 48, dev)
 
     if rank == 0:
         qps = args.steps / elapsed
@@ -880,6 +1228,13 @@ def main():
         # a pass only finds its bytes in the 256 MiB Infinity Cache if the whole buffer survives one
         # full pass of itself plus the fp32 fetches: half the cache is the most that can be hoped for
         cache_resident = alg_bytes <= 128 * 2**20
+        own_probe = {12: probe_q8, 24: probe_fp16}.get(row_bytes, probe_gbps)   # the plain read of the buffer THIS kernel streams
+        if cache_resident and own_probe:
+            # a cache-resident buffer has no spec-sheet ceiling: the measured plain read of the same buffer is the ceiling
+            peak, peak_source = own_probe, ("measured: plain read-only stream over the same buffer, resident in the Infinity Cache as "
+                                            "the timed stream leaves it (stream_probe_kernel, 20 launches)")
+        else:
+            peak, peak_source = HBM_PEAK_GBPS, "MI355X_MICROARCH.md: HBM3E spec peak"
         if replica:
             targs = "true, true" if streamed else ("true, false" if sharded is None else "false, true")
             kernel_name = (kernel_fmt.format(targs=targs) + " over the "
@@ -911,19 +1266,24 @@ def main():
             "p99_ms": round(lat[min(len(lat) - 1, int(len(lat) * 0.99))], 4) if lat else None,
             "roofline": {
                 "bound": roofline_bound(alg_bytes),
-                "bound_note": ("the buffer this kernel streams fits the 256 MiB Infinity Cache with room to spare: `achieved` / "
-                               "`frac` are a rate against the HBM peak for comparison, not an HBM figure" if cache_resident else None),
+                "bound_note": ("the buffer this kernel streams fits the 256 MiB Infinity Cache with room to spare: `peak` is the "
+                               "measured plain read of that same buffer, not the HBM spec peak; the HBM-bound figure of SURVEY.md "
+                               "§8(d) is `survey_frac` (the fp32 scan, 480 MB per query)" if cache_resident else None),
                 "kernel": kernel_name,
-                "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None,
+                "achieved": round(achieved, 1) if achieved else None, "peak": round(peak, 1), "unit": "GB/s",
+                "frac": round(achieved / peak, 4) if achieved else None,
+                "peak_source": peak_source,
                 **traffic_fields(),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_per_row": row_bytes,
                 "survey_bytes_per_row": BYTES_PER_ROW,
                 "avg_kernel_ms": round(scan_ms, 5) if scan_ms else None,
                 "merge_kernel_ms": round(float(st.last_merge_ms), 5),
-                "stream_probe_gbps": round(probe_gbps, 1) if probe_gbps else None,
-                "frac_of_stream_probe": round(achieved / probe_gbps, 4) if (achieved and probe_gbps) else None,
+                # plain reads of each buffer, GB/s (a kernel is only ever compared with the probe of ITS buffer)
+                "stream_probes_gbps": {"fp32_rows": round(probe_gbps, 1) if probe_gbps else None,
+                                       "q8_replica": round(probe_q8, 1) if probe_q8 else None,
+                                       "fp16_replica": round(probe_fp16, 1) if probe_fp16 else None},
+                "frac_of_own_buffer_probe": round(achieved / own_probe, 4) if (achieved and own_probe) else None,
                 "infinity_cache_resident": bool(cache_resident),
             },
         }
@@ -938,21 +1298,41 @@ def main():
             if scan_ms > 0:
                 # the same launch priced at the survey's 48 B/row: exceeds the HBM peak BECAUSE those bytes are not moved
                 eq = (hi - lo) * BYTES_PER_ROW / (scan_ms * 1e-3) / 1e9
-                line["roofline"]["at_survey_bytes_per_row"] = {"achieved": round(eq, 1), "frac": round(eq / HBM_PEAK_GBPS, 4),
-                                                               "note": f"{(hi - lo) * BYTES_PER_ROW / 1e6:.0f} MB-equivalent per query; the kernel moves {row_bytes / BYTES_PER_ROW:.2f}x of that"}
+                line["roofline"]["at_survey_bytes_per_row"] = {"equivalent_gbps": round(eq, 1),
+                                                               "note": f"{(hi - lo) * BYTES_PER_ROW / 1e6:.0f} MB-equivalent per query; the kernel moves {row_bytes / BYTES_PER_ROW:.2f}x "
+                                                                       "of that, so this is a throughput figure, not a fraction of any memory's peak"}
         if fp32_rows is not None:
             line["fp32_rows"] = fp32_rows
             # SURVEY.md §8(d) prices a query at 48 B/row: that is the fp32 scan's roofline, measured in this run
             line["roofline"]["survey_frac"] = fp32_rows["roofline"]["frac"]
             line["roofline"]["survey_achieved"] = fp32_rows["roofline"]["achieved"]
             line["roofline"]["survey_kernel"] = "mi355::scan_kernel over the fp32 rows (48 B/row): the `fp32_rows` object"
+            if probe_gbps and fp32_rows["roofline"]["achieved"]:
+                fp32_rows["roofline"]["stream_probe_gbps"] = round(probe_gbps, 1)
+                fp32_rows["roofline"]["frac_of_stream_probe"] = round(fp32_rows["roofline"]["achieved"] / probe_gbps, 4)
         elif not replica:
             line["roofline"]["survey_frac"] = line["roofline"]["frac"]
             line["roofline"]["survey_achieved"] = line["roofline"]["achieved"]
         if micro is not None:
+            if micro.get("roofline") and probe_fp16 and micro["roofline"].get("achieved"):
+                mr = micro["roofline"]
+                mr["stream_probe_gbps"] = round(probe_fp16, 1)
+                mr["frac_of_own_buffer_probe"] = round(mr["achieved"] / probe_fp16, 4)
+                mr["peak_note"] = ("`frac` is against the HBM spec peak: the 240 MB fp16 replica does not survive a pass in the 256 MiB "
+                                   "Infinity Cache; `frac_of_own_buffer_probe` is against the plain read of that same buffer")
             line["microbatch"] = micro
         if batched is not None:
             line["batched"] = batched
+        if world == 1 and not args.no_clustered and (hi - lo) >= 4_000_000:
+            shapes = ([(3000, 0.03, False), (3000, 0.03, True), (300, 0.01, False), (300, 0.01, True)]
+                      if args.catalogue == "clustered-contiguous" else [(3000, 0.03, True)])
+            shapes = [(max(2, c * n // 10_000_000), sp, r) for c, sp, r in shapes]   # (clusters of ~3300 / ~33000 rows whatever --rows is)
+            line["clustered"] = clustered_object(args, torch, np, dev, shapes)
+        if world == 1 and not args.no_config0:
+            try:
+                line["config0"] = config0_object(torch, np)
+            except Exception as e:   # (a box without g++ for the shim, ...): the headline stands without it
+                line["config0"] = {"unavailable": repr(e)[:300]}
         if feats_host is not None:
             line["cpu_baseline"] = cpu_baseline(feats_host, topn, q_rows[:64])
             # several queries of the run, checked against the oracle (checker only)

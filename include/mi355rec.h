@@ -402,6 +402,15 @@ int mi355rec_enqueue_scores(mi355rec_t* h, int64_t local_row,
  * ceiling probe of SURVEY.md §8(d)); writes one checksum word per workgroup
  * to sink_dev (>= compute_units uint32). */
 int mi355rec_enqueue_stream_probe(mi355rec_t* h, uint32_t* sink_dev, void* stream);
+/* The same plain read over ANOTHER buffer of the handle, so that a kernel's rate can be held against the read ceiling of
+ * the buffer it actually streams, in the memory that buffer actually lives in (a 120 MB 8-bit replica sits in the 256 MiB
+ * Infinity Cache; the 480 MB fp32 matrix does not): MI355REC_PROBE_FP32_ROWS (what mi355rec_enqueue_stream_probe
+ * reads), _FP16_REPLICA (24 B/row: the multi-query and batched passes), _Q8_REPLICA (12 B/row: single queries).
+ * MI355REC_ERR_INVALID_ARG when the handle has no such buffer. */
+#define MI355REC_PROBE_FP32_ROWS 0
+#define MI355REC_PROBE_FP16_REPLICA 1
+#define MI355REC_PROBE_Q8_REPLICA 2
+int mi355rec_enqueue_stream_probe_of(mi355rec_t* h, int which, uint32_t* sink_dev, void* stream);
 
 /* Brackets the following scan / merge launches with HIP events on their stream
  * so that mi355rec_stats reports last_scan_ms / last_merge_ms (averages over

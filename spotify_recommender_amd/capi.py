@@ -22,6 +22,7 @@ PLACEMENT_AUTO, PLACEMENT_SHARDED, PLACEMENT_REPLICATED, PLACEMENT_CPU = 0, 1, 2
 CREATE_NO_REPLICA = 1
 DEBUG_HANDOFF_POISON, DEBUG_HANDOFF_DROP_STORES, DEBUG_HANDOFF_NO_LAST_RIDER = 1, 2, 4
 BUILD_EXPERIMENTS, BUILD_PHASE_CLOCK = 1, 2
+PROBE_FP32_ROWS, PROBE_FP16_REPLICA, PROBE_Q8_REPLICA = 0, 1, 2
 
 OK = 0
 ERR_INVALID_ARG = -1
@@ -106,6 +107,7 @@ SIGNATURES = {
                                                   c_void_p, c_void_p, c_void_p, c_void_p]),
     "mi355rec_enqueue_scores": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "mi355rec_enqueue_stream_probe": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "mi355rec_enqueue_stream_probe_of": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "mi355rec_set_timing": (c_int, [c_void_p, c_int]),
     "mi355rec_fetch_row": (c_int, [c_void_p, c_int64, c_void_p]),
     "mi355rec_create_sharded": (c_int, [c_void_p, c_int64, c_int, c_int, POINTER(c_void_p)]),

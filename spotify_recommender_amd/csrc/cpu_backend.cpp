@@ -76,21 +76,22 @@ inline float score(const float* q, float qn, const float* f) {   // Recommender.
     return 0.0f;
 }
 
-// Keeps the best `cap` keys it has been shown: a buffer of up to 2 * cap keys, cut back by selection when full.
+// Keeps the best `cap` keys it has been shown in a caller-owned buffer of 2 * cap keys, cut back by selection when
+// full.  It never allocates: it is used inside an OpenMP region, which no exception may leave.
 struct Best {
-    std::vector<uint64_t> keys;
-    size_t cap;
+    uint64_t* keys = nullptr;
+    size_t size = 0;
+    size_t cap = 0;
     uint64_t floor = 0;   // a key must beat this to be worth keeping (rises at every cut)
-    explicit Best(size_t cap_) : cap(cap_) { keys.reserve(2 * cap_ + 1); }
     inline void offer(uint64_t k) {
         if (k <= floor) return;
-        keys.push_back(k);
-        if (keys.size() >= 2 * cap) cut();
+        keys[size++] = k;
+        if (size >= 2 * cap) cut();
     }
     void cut() {
-        if (keys.size() <= cap) return;
-        std::nth_element(keys.begin(), keys.begin() + (cap - 1), keys.end(), std::greater<uint64_t>());
-        keys.resize(cap);
+        if (size <= cap) return;
+        std::nth_element(keys, keys + (cap - 1), keys + size, std::greater<uint64_t>());
+        size = cap;
         floor = keys[cap - 1] - 1;   // keys are unique (they carry the row): the cap-th best stays, nothing below it can matter
     }
 };
@@ -133,11 +134,14 @@ int64_t rows(const Catalogue* c) { return c->n; }
 int threads(const Catalogue* c) { return c->threads; }
 const float* row(const Catalogue* c, int64_t r) { return c->feats.data() + static_cast<size_t>(r) * kDim; }
 
+// The team of a call is exactly the threads that have rows to score (c->threads: bounded by the cgroup quota and by one
+// thread per ~64 k rows).  Without the clause every call forks the process's whole default team; the threads without
+// work then spin at the join barrier — in a CPU-quota container they burn the quota the workers need.
 void scores(const Catalogue* c, const float* q12, float* out_n) {
     const float qn = query_norm(q12);
     const float* f = c->feats.data();
     const int64_t n = c->n;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(c->threads)
     for (int64_t i = 0; i < n; ++i) out_n[i] = score(q12, qn, f + i * kDim);
 }
 
@@ -147,35 +151,46 @@ int topn(const Catalogue* c, const float* q12, int64_t exclude, int topn, int64_
     const float* f = c->feats.data();
     const int64_t n = c->n;
     const size_t cap = static_cast<size_t>(static_cast<int64_t>(topn) < n ? topn : n);
-    // The rows go to `parts` of the team's threads in contiguous blocks; the team itself is the process's default one
-    // (other OpenMP users of the process — numpy, torch — keep theirs, and libgomp does not rebuild its pool per call).
+    // The rows go to `parts` threads in contiguous blocks.  Everything the region needs is allocated HERE, before it (a
+    // std::bad_alloc from these lines reaches the caller's try / catch; one thrown inside the region would be
+    // std::terminate behind the C-ABI): one flat pool, 2 * cap keys per part, and the parts' bookkeeping.
     const int parts = c->threads;
-    std::vector<Best> per_thread(static_cast<size_t>(parts), Best(cap));
-#pragma omp parallel
+    std::vector<uint64_t> pool(static_cast<size_t>(parts) * 2 * cap);
+    std::vector<Best> per_part(static_cast<size_t>(parts));
+    for (int p = 0; p < parts; ++p) {
+        per_part[static_cast<size_t>(p)].keys = pool.data() + static_cast<size_t>(p) * 2 * cap;
+        per_part[static_cast<size_t>(p)].cap = cap;
+    }
+#pragma omp parallel num_threads(parts)
     {
-        const int team = omp_get_num_threads();
+        const int team = omp_get_num_threads();   // (may be smaller than asked for: nested regions, OMP_THREAD_LIMIT)
         const int use = parts < team ? parts : team;
         const int t = omp_get_thread_num();
         if (t < use) {
             // (fewer threads than parts: the last thread takes the remaining parts as well)
             const int p0 = t, p1 = (t == use - 1) ? parts : t + 1;
             for (int p = p0; p < p1; ++p) {
-                Best& mine = per_thread[static_cast<size_t>(p)];
+                Best& mine = per_part[static_cast<size_t>(p)];
                 const int64_t lo = n * p / parts, hi = n * (p + 1) / parts;
                 for (int64_t i = lo; i < hi; ++i) {
                     if (i == exclude) continue;   // by index, not by score (Recommender.cu:296)
                     mine.offer(pack(score(q12, qn, f + i * kDim), static_cast<uint32_t>(i)));
                 }
+                mine.cut();   // at most cap keys per part from here on
             }
         }
     }
-    std::vector<uint64_t> all;
-    for (Best& b : per_thread) all.insert(all.end(), b.keys.begin(), b.keys.end());
-    const size_t count = all.size() < cap ? all.size() : cap;
-    std::partial_sort(all.begin(), all.begin() + count, all.end(), std::greater<uint64_t>());
+    // the parts' survivors, compacted to the front of the pool (part p's keys start at or behind where they go) and cut
+    size_t total = 0;
+    for (const Best& b : per_part) {
+        std::memmove(pool.data() + total, b.keys, b.size * sizeof(uint64_t));
+        total += b.size;
+    }
+    const size_t count = total < cap ? total : cap;
+    std::partial_sort(pool.begin(), pool.begin() + count, pool.begin() + total, std::greater<uint64_t>());
     for (size_t i = 0; i < count; ++i) {
-        out_idx[i] = static_cast<int64_t>(static_cast<uint32_t>(~static_cast<uint32_t>(all[i])));
-        if (out_score) out_score[i] = unordered(static_cast<uint32_t>(all[i] >> 32));
+        out_idx[i] = static_cast<int64_t>(static_cast<uint32_t>(~static_cast<uint32_t>(pool[i])));
+        if (out_score) out_score[i] = unordered(static_cast<uint32_t>(pool[i] >> 32));
     }
     return static_cast<int>(count);
 }

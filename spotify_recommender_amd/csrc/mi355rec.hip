@@ -2503,13 +2503,30 @@ int mi355rec_enqueue_scores(mi355rec_t* h, int64_t local_row, const float* query
 }
 
 int mi355rec_enqueue_stream_probe(mi355rec_t* h, uint32_t* sink_dev, void* stream) {
+    return mi355rec_enqueue_stream_probe_of(h, MI355REC_PROBE_FP32_ROWS, sink_dev, stream);
+}
+
+int mi355rec_enqueue_stream_probe_of(mi355rec_t* h, int which, uint32_t* sink_dev, void* stream) {
     if (!h || !sink_dev) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
     if (h->n == 0) return MI355REC_OK;
+    const float4* buf = nullptr;
+    int64_t n_vec = 0;   // 16-byte vectors
+    if (which == MI355REC_PROBE_FP32_ROWS) {
+        buf = reinterpret_cast<const float4*>(h->d_feats);
+        n_vec = h->n * 3;
+    } else if (which == MI355REC_PROBE_FP16_REPLICA && h->d_half) {
+        buf = reinterpret_cast<const float4*>(h->d_half);
+        n_vec = ((h->n + 1) / 2) * 3;
+    } else if (which == MI355REC_PROBE_Q8_REPLICA && h->d_q8) {
+        buf = reinterpret_cast<const float4*>(h->d_q8);
+        n_vec = ((h->n + 3) / 4) * 3;
+    } else {
+        return fail(h, MI355REC_ERR_INVALID_ARG, "no such buffer to probe (%d)", which);
+    }
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     LAUNCH_TIMED(h, h->ev_scan, h->n_scan_pairs, h->scan_launches, stream_probe_kernel,
-                 dim3(h->cus), dim3(kProbeBlock), s,
-                 reinterpret_cast<const float4*>(h->d_feats), h->n * 3, sink_dev);
+                 dim3(h->cus), dim3(kProbeBlock), s, buf, n_vec, sink_dev);
     HIP_TRY(h, hipGetLastError());
     return MI355REC_OK;
 }

@@ -1293,16 +1293,24 @@ int mi355rec_create_placed(const float* feats_host, int64_t n, int dim, const in
         if (!out || !feats_host) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null argument");
         if (dim != MI355REC_DIM) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "dim must be %d, got %d", MI355REC_DIM, dim);
         if (n < 1 || n > 0xfffffffell) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "rows %lld out of range", (long long)n);
-        mi355rec_sharded* h = new mi355rec_sharded();
-        h->n = n;
-        h->peer_rows = false;
-        h->cpu = mi355cpu::node_create(feats_host, n);
-        if (!h->cpu) {
+        mi355rec_sharded* h = nullptr;
+        try {   // (nothing may leave a C entry point as an exception: the handle and its note allocate)
+            h = new mi355rec_sharded();
+            h->n = n;
+            h->peer_rows = false;
+            h->cpu = mi355cpu::node_create(feats_host, n);
+            if (!h->cpu) {
+                delete h;
+                return sfail(nullptr, MI355REC_ERR_OUT_OF_MEMORY, "CPU backend: cannot hold %lld rows", (long long)n);
+            }
+            h->note = "CPU backend: no HIP device visible (" + std::to_string(mi355cpu::threads(mi355cpu::node_catalogue(h->cpu))) +
+                      " OpenMP thread(s))";
+        } catch (const std::bad_alloc&) {
+            if (h && h->cpu) mi355cpu::node_destroy(h->cpu);
+            if (h) h->cpu = nullptr;
             delete h;
-            return sfail(nullptr, MI355REC_ERR_OUT_OF_MEMORY, "CPU backend: cannot hold %lld rows", (long long)n);
+            return sfail(nullptr, MI355REC_ERR_OUT_OF_MEMORY, "out of host memory for the CPU backend's handle");
         }
-        h->note = "CPU backend: no HIP device visible (" + std::to_string(mi355cpu::threads(mi355cpu::node_catalogue(h->cpu))) +
-                  " OpenMP thread(s))";
         *out = h;
         return MI355REC_OK;
     }

@@ -283,9 +283,10 @@ class CosineEngine:
             self._h, int(local_row), q.ctypes.data_as(ctypes.c_void_p) if q is not None else None,
             ctypes.c_void_p(out_scores.data_ptr()), self._stream_ptr(stream)), self._h)
 
-    def enqueue_stream_probe(self, sink, stream=None) -> None:
-        capi.check(self._lib.mi355rec_enqueue_stream_probe(
-            self._h, ctypes.c_void_p(sink.data_ptr()), self._stream_ptr(stream)), self._h)
+    def enqueue_stream_probe(self, sink, stream=None, which: int = capi.PROBE_FP32_ROWS) -> None:
+        """The plain read-only stream over one of the handle's buffers (fp32 rows, fp16 replica, 8-bit replica)."""
+        capi.check(self._lib.mi355rec_enqueue_stream_probe_of(
+            self._h, int(which), ctypes.c_void_p(sink.data_ptr()), self._stream_ptr(stream)), self._h)
 
     def set_timing(self, enabled) -> None:
         """0/False off, 1/True every launch, k > 1 every k-th launch."""

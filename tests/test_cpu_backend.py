@@ -229,3 +229,67 @@ def test_config1_114k_csv_on_the_cpu_backend(shim, tmp_path, capfd):
         assert "Operating in CPU fallback mode" in p.stdout and "Top 10" in p.stdout
         runs.append([l for l in p.stdout.splitlines() if "Track " in l])
     assert runs[0] == runs[1] and len(runs[0]) >= 11      # the query's block + ten recommendations
+
+
+def test_out_of_memory_inside_a_query_is_an_error_code_not_a_terminate(tmp_path):
+    """ADVICE r4 / VERDICT r4 item 4: everything a query allocates is allocated BEFORE its OpenMP region (an exception that
+    leaves such a region is std::terminate behind the C-ABI).  A child process creates the CPU-backed node handle on 114 000
+    rows, then lowers its address-space limit to what it already uses and asks for as many results as there are rows
+    (a few MB of keys per thread): the call must come back with MI355REC_ERR_OUT_OF_MEMORY, the process must live, and
+    with the limit lifted the same handle must answer again."""
+    child = r'''
+import resource, sys
+import numpy as np
+sys.path.insert(0, %r)
+from spotify_recommender_amd import capi
+from spotify_recommender_amd.engine import NodeEngine
+rng = np.random.default_rng(3)
+f = rng.random((114_000, 12), dtype=np.float32)
+node = NodeEngine(f, n_devices=0, placement=capi.PLACEMENT_AUTO)
+assert node.placement() == capi.PLACEMENT_CPU
+idx, sc = node.query_row_topn(5, 10)
+assert len(idx) == 10
+out_idx = np.empty(114_000, np.int64); out_sc = np.empty(114_000, np.float32)   # the caller's buffers exist before the squeeze
+import ctypes
+vm = int([l for l in open("/proc/self/status") if l.startswith("VmSize")][0].split()[1]) * 1024
+soft, hard = resource.getrlimit(resource.RLIMIT_AS)
+resource.setrlimit(resource.RLIMIT_AS, (vm + (1 << 20), hard))
+cnt = ctypes.c_int(0)
+rc = node._lib.mi355rec_sharded_query_row_topn(node._h, 5, 114_000, ctypes.c_void_p(out_idx.ctypes.data), ctypes.c_void_p(out_sc.ctypes.data), ctypes.byref(cnt))
+resource.setrlimit(resource.RLIMIT_AS, (soft, hard))
+assert rc == capi.ERR_OUT_OF_MEMORY, rc
+rc = node._lib.mi355rec_sharded_query_row_topn(node._h, 5, 114_000, ctypes.c_void_p(out_idx.ctypes.data), ctypes.c_void_p(out_sc.ctypes.data), ctypes.byref(cnt))
+assert rc == capi.OK and cnt.value == 113_999, (rc, cnt.value)
+assert out_idx[:10].tolist() == idx.tolist()
+print("SURVIVED")
+''' % str(ROOT)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    p = subprocess.run([os.sys.executable, "-c", child], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0 and "SURVIVED" in p.stdout, (p.returncode, p.stdout[-400:], p.stderr[-800:])
+
+
+def test_a_query_forks_no_more_threads_than_have_rows():
+    """ADVICE r4 (medium): the team of a call is the threads that have work (num_threads(parts)), not the process's whole
+    default team — the rest would spin at the join barrier and, under a cgroup CPU quota, burn what the workers need.
+    Counted from outside: the threads of a child process after its first queries on 114 000 rows (two parts)."""
+    child = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+os.environ["OMP_NUM_THREADS"] = "8"
+from spotify_recommender_amd import capi
+from spotify_recommender_amd.engine import NodeEngine
+f = np.random.default_rng(1).random((114_000, 12), dtype=np.float32)
+node = NodeEngine(f, n_devices=0, placement=capi.PLACEMENT_AUTO)
+before = len(os.listdir("/proc/self/task"))
+for r in range(20):
+    node.query_row_topn(r, 10)
+after = len(os.listdir("/proc/self/task"))
+print("THREADS", before, after, node.note())
+''' % str(ROOT)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", OMP_NUM_THREADS="8")
+    p = subprocess.run([os.sys.executable, "-c", child], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-800:]
+    before, after = [int(x) for x in p.stdout.split("THREADS")[1].split()[:2]]
+    # 114 000 rows = at most two parts: the queries may add ONE worker thread to the caller's, not seven
+    assert after - before <= 1, p.stdout

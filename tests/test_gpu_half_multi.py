@@ -29,15 +29,15 @@ def torch_cuda():
     return torch
 
 
-@pytest.fixture(params=["q8", "fp16"])
+from tests.conftest import experiment_build
+
+
+@pytest.fixture(params=["q8", "fp16"] if experiment_build() else ["fp16"])
 def Engine(torch_cuda, request):
     """Every test runs once per front end of the multi-query pass: rows streamed from the fp16 replica
     (MI355REC_BATCH_HALF: the product's) or from the 8-bit replica through the integer matrix core
     (MI355REC_BATCH_Q8: an A/B route of MI355REC_EXPERIMENTS builds since round 5 — skipped on the product library)."""
-    from spotify_recommender_amd import capi
     from spotify_recommender_amd.engine import CosineEngine
-    if request.param == "q8" and not capi.has_experiments():
-        pytest.skip("the 8-bit front end of the multi-query pass exists in MI355REC_EXPERIMENTS builds only")
 
     class FrontEnd(CosineEngine):
         """HALF forced by a test means "the multi-query pass whatever the count": with this fixture's front end."""

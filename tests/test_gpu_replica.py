@@ -25,13 +25,16 @@ pytestmark = pytest.mark.gpu
 ON, OFF = 2, 1     # ON is rebound per test by replica_kind: 2 = ON (8-bit replica), 3 = FP16
 
 
-@pytest.fixture(autouse=True, params=[2, 3], ids=["q8", "fp16"])
+from tests.conftest import experiment_build
+
+# (single queries over the fp16 replica are an A/B route of MI355REC_EXPERIMENTS builds since round 5: the product library
+# runs every test over the 8-bit replica only)
+KINDS = [2, 3] if experiment_build() else [2]
+
+
+@pytest.fixture(autouse=True, params=KINDS, ids=["q8", "fp16"][:len(KINDS)])
 def replica_kind(request):
     global ON
-    if request.param == 3:
-        from spotify_recommender_amd import capi
-        if not capi.has_experiments():
-            pytest.skip("single queries over the fp16 replica are an A/B route of MI355REC_EXPERIMENTS builds (round 5)")
     ON = request.param
     yield request.param
     ON = 2
