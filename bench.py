@@ -88,7 +88,7 @@ def parse_args():
                     help="no GPU work: resolve the launch mode, load the C-ABI library, print the plan as one JSON line")
     ap.add_argument("--transport", choices=["auto", "peer", "rccl"], default="auto",
                     help="N > 1, single process: how the per-shard key lists meet (default: peer stores where every "
-                         "device can map the first one's memory, else one grouped ncclAllGather)")
+                         "device can map the first one's memory, else one ncclAllGather per rank)")
     return ap.parse_args()
 
 
@@ -556,7 +556,7 @@ def run_node(args, json_fd):
     product's row-sharded C-ABI handle (mi355rec_create_sharded / _on, csrc/sharded.hip) — the engine the
     C++ Recommender uses in place of the reference's cudaSetDevice(0) (Recommender.cu:124).  A step is one
     query = one streamed scan launch on EVERY shard; the per-shard key lists of `--window` queries share one
-    exchange (peer stores or one grouped ncclAllGather) and one batched merge whose results land in host
+    exchange (peer stores or one ncclAllGather per rank) and one batched merge whose results land in host
     memory.  The flush of the last window and the wait for the last result are inside the timed region."""
     import numpy as np
     import torch

@@ -7,10 +7,12 @@
 // lives behind the C-ABI in include/mi355rec.h.
 //
 // Behavioural contract:
-//  - initialize(): false for an empty song list (Recommender.cu:103-106).
-//    DEVIATION: the reference degrades to a CPU loop when the GPU is missing
-//    (Recommender.cu:117-181) and still returns true; this engine has no CPU
-//    path, so without a gfx950 device it prints the reason and returns false.
+//  - initialize(): false for an empty song list (Recommender.cu:103-106).  On a
+//    host WITHOUT a HIP device it does what the reference does (Recommender.cu:
+//    117-127,176-181): prints the reference's fallback lines, serves the
+//    catalogue from the product's own CPU backend (csrc/cpu_backend.cpp, behind
+//    mi355rec_create_placed) and returns true with isGPUEnabled() == false.  On a
+//    host WITH a device nothing ever falls back: a failed HIP call is an error.
 //  - recommendByIndex(): ids of the topN most cosine-similar songs, best
 //    first, the query excluded by index; min(topN, N-1) results; {} plus the
 //    reference's stderr text for an uninitialised object or a bad index.

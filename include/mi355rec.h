@@ -435,8 +435,9 @@ int mi355rec_fetch_row(mi355rec_t* h, int64_t local_row, float* out12_host);
  *       into the first device's gather buffer through a peer mapping (xGMI
  *       point-to-point) and an event per shard orders the final merge behind
  *       them — no collective, no copy launch.  Default when peer access exists.
- *   MI355REC_TRANSPORT_RCCL  one grouped ncclAllGather per call (ncclCommInitAll,
- *       ncclGroupStart/End); librccl is opened on first use of this transport.
+ *   MI355REC_TRANSPORT_RCCL  one ncclAllGather per rank per exchange, issued by that rank's worker
+ *       thread on its own stream (communicators from ncclCommInitAll; one thread per communicator,
+ *       so no ncclGroupStart/End); librccl is opened on first use of this transport.
  * The mi355rec_sharded_query_* calls are synchronous (results in host memory on
  * return); the STREAM calls further down only enqueue.  One host thread at a time
  * per handle.  topn > 1024 is served exactly but slowly (per-shard rounds, the G
@@ -539,7 +540,7 @@ int mi355rec_sharded_scores_row(mi355rec_sharded_t* h, int64_t global_row, float
  * merge of query k rides in the scan launch of query k + 1) — and returns a TICKET.
  * The per-shard key lists of `window` consecutive queries cross xGMI in ONE exchange
  * (peer stores straight into the first device's gather buffer + one event per shard,
- * or one grouped ncclAllGather) followed by ONE batched merge launch on the first
+ * or one ncclAllGather per rank) followed by ONE batched merge launch on the first
  * device, whose results (global row ids + scores) the merge kernel stores straight
  * into pinned host memory.  No call but mi355rec_sharded_wait synchronises, nothing
  * is allocated after the first call with a given (topn, window).

@@ -121,9 +121,11 @@ Catalogue* create(const float* feats_rowmajor, int64_t n, int threads) {
         if (quota > 0 && t > quota) t = quota;
     }
     if (t < 1) t = 1;
-    // a thread per ~64 k rows at most (~0.7 ms of rows): below that the fork costs more than the rows
-    // (114 k rows on an 8-vCPU VM: 0.5-0.9 ms per query on 2 threads, 1.1-1.3 ms on one)
-    const int64_t useful = n / 65536 + 1;
+    // a thread per ~8 k rows at most (~0.1 ms of rows: below that the fork costs more than the rows).  Measured on an
+    // 8-vCPU host at 114 000 rows x top-10, the team being exactly the threads with rows (num_threads below): 1 040
+    // queries/s on 2 threads, 2 970 on 4, 4 340 on 8.  (Round 4 allowed a thread per 64 k rows: with the process's whole
+    // default team forked per call the idle threads' spinning made more threads look worse than they are.)
+    const int64_t useful = n / 8192 + 1;
     if (t > useful) t = static_cast<int>(useful);
     c->threads = t;
     return c;

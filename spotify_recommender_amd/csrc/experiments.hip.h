@@ -28,13 +28,19 @@ __device__ unsigned long long g_phase_clock[1024 * 8];   // [workgroup][phase]
         if (threadIdx.x == 0 && blockIdx.x < 1023) g_phase_clock[blockIdx.x * 8 + (i)] = 0; \
     } while (0)
 #define MI355REC_PHASE_T0(t) const unsigned long long t = wall_clock64()
-#define MI355REC_PHASE_ADD(i, t)                                                                            \
-    do {                                                                                                    \
-        if (threadIdx.x == 0 && blockIdx.x < 1023) g_phase_clock[blockIdx.x * 8 + (i)] += wall_clock64() - (t); \
+// by lane 0 of EVERY wave of the workgroup: the workgroup's slot takes the LARGEST duration any of its waves has
+// accumulated (the wave passes its own running total), resp. the sum of the waves' counts, resp. the latest stamp
+#define MI355REC_PHASE_WAVE_MAX(i, total)                                                                    \
+    do {                                                                                                     \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 1023) atomicMax(&g_phase_clock[blockIdx.x * 8 + (i)], (total)); \
     } while (0)
-#define MI355REC_PHASE_COUNT(i)                                                            \
-    do {                                                                                   \
-        if (threadIdx.x == 0 && blockIdx.x < 1023) g_phase_clock[blockIdx.x * 8 + (i)] += 1; \
+#define MI355REC_PHASE_WAVE_COUNT(i)                                                                    \
+    do {                                                                                                \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 1023) atomicAdd(&g_phase_clock[blockIdx.x * 8 + (i)], 1ull); \
+    } while (0)
+#define MI355REC_PHASE_WAVE_LAST(i)                                                                              \
+    do {                                                                                                         \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 1023) atomicMax(&g_phase_clock[blockIdx.x * 8 + (i)], wall_clock64()); \
     } while (0)
 // phases of ONE merge (merge_body in the workgroup with blockIdx.x == 0: merge_notify_kernel), kept in row 1023
 #define MI355REC_MPHASE(i)                                                                       \
@@ -51,11 +57,14 @@ __device__ unsigned long long g_phase_clock[1024 * 8];   // [workgroup][phase]
 #define MI355REC_PHASE_T0(t) \
     do {                     \
     } while (0)
-#define MI355REC_PHASE_ADD(i, t) \
-    do {                         \
+#define MI355REC_PHASE_WAVE_MAX(i, total) \
+    do {                                  \
     } while (0)
-#define MI355REC_PHASE_COUNT(i) \
-    do {                        \
+#define MI355REC_PHASE_WAVE_COUNT(i) \
+    do {                             \
+    } while (0)
+#define MI355REC_PHASE_WAVE_LAST(i) \
+    do {                            \
     } while (0)
 #define MI355REC_MPHASE(i) \
     do {                   \

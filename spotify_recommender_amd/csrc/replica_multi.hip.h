@@ -62,6 +62,7 @@ constexpr int kHmStepRows = 128 * kHmChunks;
 #define MI355_HM_EXP 0   // tools/hm_exp.sh builds the timing experiments 1 ... 3 under gpurun_out/ (never the product library)
 #endif
 constexpr int kHmStage = 128;                      // staged (query, row) candidates per wave
+constexpr int kHmDenseHits = 12;                   // more hits than this in ONE MFMA: the step takes the exact chain whole
 constexpr int kHmPrivate = 4;                      // keys per (wave, query) kept in the wave's own list before the shared one is touched
 constexpr int kHmKeyCap = 192;                     // kept keys per query and workgroup
 constexpr int kHmKeysPerLane = kHmKeyCap / 64;
@@ -527,27 +528,33 @@ __device__ __forceinline__ void hm_exact_step(HalfMultiSmem& sm, const float* __
                                               int64_t first_row, uint32_t cols, int topk) {
     const int lane = threadIdx.x & 63;
     constexpr int kGroups = kHmStepRows / 64;
-    // the next 64 rows are requested before these are scored (all of the step's rows at once spilled)
-    Row cur = load_row(feats, first_row + lane < n ? first_row + lane : static_cast<int64_t>(0));
-#pragma unroll 1
+    // ALL of the step's rows are requested before the first is scored: one memory round trip under a saturated memory
+    // system (~2-3 us), not kGroups of them.  (The caller drops the replica rows it has in flight for its next step and
+    // requests them again afterwards: their registers are what makes room for these.)
+    Row r[kGroups];
+#pragma unroll
     for (int u = 0; u < kGroups; ++u) {
         const int64_t row = first_row + u * 64 + lane;
-        const int64_t ahead = row + 64;
-        const Row nxt = load_row(feats, (u + 1 < kGroups && ahead < n) ? ahead : static_cast<int64_t>(0));
-        for (uint32_t rest = cols; rest; rest &= rest - 1u) {   // wave-uniform
-            const int q0 = __builtin_ctz(rest);
-            float qv[kDim];
+        r[u] = load_row(feats, row < n ? row : static_cast<int64_t>(0));
+    }
+    for (uint32_t rest = cols; rest; rest &= rest - 1u) {   // wave-uniform
+        const int q0 = __builtin_ctz(rest);
+        float qv[kDim];   // (wave-uniform: kept in scalar registers — the vector ones hold the rows)
 #pragma unroll
-            for (int j = 0; j < kDim; ++j) qv[j] = sm.qf[q0][j];
-            const float s = cosine_score(qv, sm.qn[q0], cur);
+        for (int j = 0; j < kDim; ++j) qv[j] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sm.qf[q0][j])));
+        const float qn = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sm.qn[q0])));
+        const long long excl = sm.excl[q0];
+#pragma unroll
+        for (int u = 0; u < kGroups; ++u) {
+            const int64_t row = first_row + u * 64 + lane;
+            const float s = cosine_score(qv, qn, r[u]);
             const int64_t g = row_base + row;
             uint64_t key = pack_key(s, static_cast<uint32_t>(g));
-            if (g == sm.excl[q0]) key = 0;
+            if (g == excl) key = 0;
             const uint64_t seen = __hip_atomic_load(&sm.thr[q0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const bool pass = row < n && key > seen;
             if (__ballot(pass)) hm_append_locked(sm, q0, pass, key, topk);
         }
-        cur = nxt;
     }
 }
 
@@ -682,6 +689,8 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
     unsigned nblocks = gridDim.x;   // scanning workgroups
     HalfMultiSmem* smp;
     MI355REC_PHASE(0);
+    MI355REC_PHASE_ZERO(2);
+    MI355REC_PHASE_ZERO(3);
     MI355REC_PHASE_ZERO(6);
     MI355REC_PHASE_ZERO(7);
     if constexpr (kRide) {
@@ -856,6 +865,9 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
 
     const bq_f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     const uint32_t n32 = static_cast<uint32_t>(n);   // n <= 2^32 - 2 (mi355rec_create)
+#ifdef MI355REC_PHASE_CLOCK
+    unsigned long long drain_total = 0ull, hot_total = 0ull;
+#endif
     bool overflow = false;   // wave-uniform: this step's candidates did not fit the staging buffer ...
     uint32_t step_cols = 0u; // ... and which query columns have noted a candidate in this step so far (bit c = query c)
     // D layout: lane holds column c = lane & 31 (the query) and, in register i, the row that lane
@@ -878,13 +890,18 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
             const uint64_t any0 = __ballot(hits != 0u);
             step_cols |= static_cast<uint32_t>(any0) | static_cast<uint32_t>(any0 >> 32);   // lanes c and 32 + c hold query column c
         }
-        // A column whose sixteen results in a lane ALL hit: the tile lies inside that query's cluster (a catalogue sorted by
-        // genre) — or there is no cutoff at all.  Either way the step will not fit the staging buffer: it goes through the
-        // exact chain for the columns that hit (hm_exact_step), and noting its hits one wave-uniform round at a time
-        // first (128 rounds for a step of 256 rows: measured ~10 us, as much as the exact step itself) would be wasted.
-        if (overflow || __ballot(hits == 0xffffu)) {   // uniform
-            overflow = true;
-            return;
+        // MORE THAN A DOZEN HITS IN ONE MFMA (32 rows x 32 queries; a seeded pass over spread rows sees 0.03 per query): the
+        // tile lies inside a query's cluster (a catalogue sorted by genre) — or there is no cutoff at all.  Either way the
+        // step will not fit the staging buffer: it goes through the exact chain for the columns that hit (hm_exact_step),
+        // and noting its hits first, one wave-uniform round each — two lanes busy per round when ONE column is dense —
+        // would be wasted (measured with stamps: 12-14 us of a hot step's 20, the exact step itself 5).
+        if (overflow) return;   // uniform: already decided for this step
+        {
+            const int n_hits = __builtin_amdgcn_readlane(wave_inclusive_scan(__builtin_popcount(hits)), 63);
+            if (n_hits > kHmDenseHits) {   // uniform
+                overflow = true;
+                return;
+            }
         }
         for (uint64_t any = __ballot(hits != 0u); any; any = __ballot(hits != 0u)) {   // wave-uniform rounds
             const int i = hits ? __builtin_ctz(hits) : 0;
@@ -909,6 +926,7 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
     for (; step < n_steps; step += total_waves) {
         const int staged_before = staged;
         step_cols = 0u;
+        MI355REC_PHASE_T0(t_step);
         // the fragment is re-read every step (its cutoffs tighten); the barrier keeps the compiler from hoisting it
         asm volatile("" ::: "memory");
         if constexpr (!kQ8) {
@@ -1034,7 +1052,13 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
         // its own can overflow it; such a step forgets what it noted and goes through the exact chain whole.
         if (__builtin_expect(overflow || staged >= kHmStage / 2, 0)) {   // uniform, rare
             MI355REC_PHASE_T0(t_drain);
-            if (overflow) MI355REC_PHASE_COUNT(7);
+            if (overflow) MI355REC_PHASE_WAVE_COUNT(7);
+#ifdef MI355REC_PHASE_CLOCK   // [3] = the most any wave of the workgroup spent in the matrix-core / hit-noting part of steps that overflowed
+            if (overflow) {
+                hot_total += t_drain - t_step;
+                MI355REC_PHASE_WAVE_MAX(3, hot_total);
+            }
+#endif
             if (overflow) staged = staged_before;
             n_rescored += hm_resolve_stage(sm, staged, feats, row_base, topk, kQ8 ? reinterpret_cast<const uint32_t*>(half) : nullptr);
             staged = 0;
@@ -1043,17 +1067,30 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
                 hm_exact_step(sm, feats, n, row_base, step * kHmStepRows, cols, topk);
                 n_rescored += kHmStepRows * __builtin_popcount(cols);
                 overflow = false;
+                // (the next step's replica rows again: see hm_exact_step)
+                if constexpr (kQ8) {
+#pragma unroll
+                    for (int g = 0; g < kHmGroups; ++g) load_group(G[g], step + total_waves, g);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < kHmChunks; ++u) load_chunk(T[u], step + total_waves, u);
+                }
             }
-            MI355REC_PHASE_ADD(6, t_drain);   // (wave 0) time in drains and exact steps, [7] = exact steps
+#ifdef MI355REC_PHASE_CLOCK   // [6] = the most any wave of the workgroup spent in drains and exact steps, [7] = the workgroup's exact steps
+            drain_total += wall_clock64() - t_drain;
+            MI355REC_PHASE_WAVE_MAX(6, drain_total);
+#endif
         }
     }
-    MI355REC_PHASE(2);    // (wave 0 of the workgroup) its steps are done
+    MI355REC_PHASE_WAVE_LAST(2);    // the last wave of the workgroup has done its steps
 #if MI355_HM_EXP == 2   // EXPERIMENT (wrong results): the candidates are extracted but never scored
     if (staged > 100000) n_rescored = 1;
 #else
     n_rescored += hm_resolve_stage(sm, staged, feats, row_base, topk, kQ8 ? reinterpret_cast<const uint32_t*>(half) : nullptr);
 #endif
+#ifndef MI355REC_PHASE_CLOCK
     MI355REC_PHASE(3);    // ... and its last candidates resolved
+#endif
     if (lane == 0) atomicAdd(&sm.rescored, n_rescored);
     __syncthreads();
     if (tid == 0) rescored[bid] += static_cast<unsigned long long>(sm.rescored);   // launches of a handle are stream-ordered

@@ -271,7 +271,8 @@ print("SURVIVED")
 def test_a_query_forks_no_more_threads_than_have_rows():
     """the team of a call is the threads that have work (num_threads(parts)), not the process's whole
     default team — the rest would spin at the join barrier and, under a cgroup CPU quota, burn what the workers need.
-    Counted from outside: the threads of a child process after its first queries on 114 000 rows (two parts)."""
+    Counted from outside: the threads of a child process after its first queries on 10 000 rows (two parts: a thread per
+    8192 rows) with OMP_NUM_THREADS = 8."""
     child = r'''
 import os, sys
 import numpy as np
@@ -279,7 +280,7 @@ sys.path.insert(0, %r)
 os.environ["OMP_NUM_THREADS"] = "8"
 from spotify_recommender_amd import capi
 from spotify_recommender_amd.engine import NodeEngine
-f = np.random.default_rng(1).random((114_000, 12), dtype=np.float32)
+f = np.random.default_rng(1).random((10_000, 12), dtype=np.float32)
 node = NodeEngine(f, n_devices=0, placement=capi.PLACEMENT_AUTO)
 before = len(os.listdir("/proc/self/task"))
 for r in range(20):
@@ -291,5 +292,5 @@ print("THREADS", before, after, node.note())
     p = subprocess.run([os.sys.executable, "-c", child], capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode == 0, p.stderr[-800:]
     before, after = [int(x) for x in p.stdout.split("THREADS")[1].split()[:2]]
-    # 114 000 rows = at most two parts: the queries may add ONE worker thread to the caller's, not seven
+    # 10 000 rows = two parts: the queries may add ONE worker thread to the caller's, not seven
     assert after - before <= 1, p.stdout
