@@ -232,6 +232,33 @@ __global__ __launch_bounds__(256) void bq_prepare_kernel(
 // order, no barrier involved.
 constexpr int kBqStage = 256;   // entries per wave (2 KiB); a block adds at most 64 per register
 
+// Scheduling experiments of pass 2's inner loop (tools/bq_sched.sh builds them under gpurun_out/):
+// MI355_BQ_SCHED & 1: raise the wave's priority while it issues its two MFMAs; & 2: ask the scheduler to interleave the
+// MFMAs of a block with the reduction of the block before (one MFMA, eight VALU, one MFMA, the rest).
+#ifndef MI355_BQ_SCHED
+#define MI355_BQ_SCHED 0
+#endif
+#if MI355_BQ_SCHED & 1
+#define MI355_BQ_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define MI355_BQ_PRIO(p) \
+    do {                 \
+    } while (0)
+#endif
+#if MI355_BQ_SCHED & 2
+#define MI355_BQ_INTERLEAVE()                                  \
+    do {                                                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     \
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     \
+        __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);     \
+    } while (0)
+#else
+#define MI355_BQ_INTERLEAVE() \
+    do {                      \
+    } while (0)
+#endif
+
 __device__ __forceinline__ void bq_flush_stage(const uint2* stage, int staged, int lane, int* __restrict__ cand_count,
                                                uint32_t* __restrict__ cand_rows, int cand_cap) {
     for (int e = lane; e < staged; e += 64) {
@@ -678,16 +705,22 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
                     bq_f16v D2, D3;
 #pragma unroll 1
                     for (int i = 0; i < pairs; ++i) {
+                        MI355_BQ_PRIO(2);
                         D2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw1), zero, 0, 0, 0);
                         D3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], __builtin_bit_cast(bq_h8, bw1), zero, 0, 0, 0);
+                        MI355_BQ_PRIO(0);
                         const int n0 = pop();
                         bw0 = sb[n0 * 64];
                         check2(D0, D1, b0);
+                        MI355_BQ_INTERLEAVE();
+                        MI355_BQ_PRIO(2);
                         D0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);
                         D1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], __builtin_bit_cast(bq_h8, bw0), zero, 0, 0, 0);
+                        MI355_BQ_PRIO(0);
                         const int n1 = pop();
                         bw1 = sb[n1 * 64];
                         check2(D2, D3, b1);
+                        MI355_BQ_INTERLEAVE();
                         b0 = n0;
                         b1 = n1;
                     }

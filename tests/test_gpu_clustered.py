@@ -189,3 +189,38 @@ def test_a_batch_of_1024_queries(catalogue, engine, torch_cuda):
     for b in range(1024):
         idx, _ = unpack_keys(got[b])
         assert rows[b] not in idx, b
+
+
+def test_rounds_of_topn_above_1024(catalogue, engine):
+    """topn > 1024 is served in rounds of 1024; round r looks for keys BELOW the last key of round r - 1, so a lower bound on
+    the BEST keys (sample or neighbourhood) must not be applied to it.  2500 results from inside a cluster and from its edge."""
+    from spotify_recommender_amd import capi
+    f, eng = catalogue["host"], engine
+    rows = query_rows(3, 77)
+    for mode in (capi.REPLICA_OFF, capi.REPLICA_AUTO):
+        eng.set_replica(mode)
+        for r in rows[:2]:
+            idx, sc = eng.query_row_topn(int(r), 2500)
+            check(f, r, idx, sc, f"topn 2500, mode {mode}", topn=2500)
+    eng.set_replica(capi.REPLICA_AUTO)
+
+
+def test_row_sharded_node_over_contiguous_clusters(catalogue, torch_cuda):
+    """The same catalogue split into four VIRTUAL shards of one GPU (csrc/sharded.hip): a query's excluded row belongs to ONE
+    shard — only that shard has a neighbourhood for it, the others see an excluded row outside their range — and the merged
+    result must not depend on the split.  Synchronous calls and the ticketed stream, both window modes."""
+    from spotify_recommender_amd.engine import NodeEngine
+    f = catalogue["host"]
+    rows = query_rows(20, 5)
+    rows[2], rows[3] = N // 4 - 1, N // 4          # the last row of shard 0, the first of shard 1
+    with NodeEngine(f, devices=[0, 0, 0, 0]) as node:
+        for r in rows[:5]:
+            idx, sc = node.query_row_topn(int(r), TOPN)
+            check(f, r, idx, sc, "node, synchronous")
+        for batched in (False, True):
+            node.set_window_mode(batched)
+            tickets = [node.enqueue_row(int(r), TOPN) for r in rows]
+            node.enqueue_flush()
+            for r, t in list(zip(rows, tickets))[-8:]:
+                idx, sc = node.wait(t, TOPN)
+                check(f, r, idx, sc, f"node, stream (batched windows: {batched})")

@@ -569,24 +569,32 @@ def test_two_thousand_streamed_queries_key_for_key(Engine, torch_cuda):
 
 
 def test_hand_offs_fail_safe_under_stale_values(Engine, torch_cuda):
-    """VERDICT r3 item 3(a) / ADVICE r3 (high).  Inside a streamed launch over the 8-bit replica the seed riders hand
-    their sample to the rider that finishes last, and that one hands the next launch its cutoff — outside the stream
-    order.  mi355rec_debug_handoff makes a reader find what it would find if those stores had NOT landed: the most
-    hostile values an earlier query could have left (a perfect score, a cutoff of +1.0 that rules out every row) under
-    the last queries' epochs, sample stores that never happen, a launch in which no rider is the last.  A value under
-    the wrong epoch must count as absent (the cutoff only gets LOWER): every key list must still equal the fp32
-    scan's, and the rows sent to the exact chain must go UP — proof that the stale values were met and refused."""
+    """VERDICT r3 item 3(a) / ADVICE r3 (high).  Inside a streamed launch the seed riders hand their sample to the rider
+    that finishes last, and that one hands the next launch its cutoff (8-bit replica) or its bound (fp32 rows, round 5) —
+    outside the stream order; the sample launch of a query alone over the fp32 rows ends the same way.
+    mi355rec_debug_handoff makes a reader find what it would find if those stores had NOT landed: the most hostile values
+    an earlier query could have left (a perfect score, a cutoff of +1.0 that rules out every row) under the last queries'
+    epochs — the neighbourhood's slot included — sample stores that never happen, a launch in which no rider is the last.
+    A value under the wrong epoch must count as absent (the bound only gets LOWER): every key list must still equal the
+    ORACLE's, over both kinds of rows, and over the replica the rows sent to the exact chain must go UP — proof that the
+    stale values were met and refused."""
     if ON == 3:
         pytest.skip("the fp16 single-query scan hands its sample from launch to launch in stream order only")
     from spotify_recommender_amd import capi
+    from spotify_recommender_amd.engine import unpack_keys
     torch = torch_cuda
     rng = np.random.default_rng(4242)
     n = 4_000_000
     f = torch.rand((n, 12), generator=torch.Generator(device="cuda").manual_seed(9), device="cuda", dtype=torch.float32)
+    host = f.cpu().numpy()
     rows = rng.integers(0, n, size=72)
     topns = rng.choice([10, 100, 100, 300], size=72)
     P, D, L = capi.DEBUG_HANDOFF_POISON, capi.DEBUG_HANDOFF_DROP_STORES, capi.DEBUG_HANDOFF_NO_LAST_RIDER
     hooks = {7: P, 13: D, 19: L, 25: P | D, 31: P | L, 37: D | L, 43: P | D | L, 44: P, 45: P | D | L, 60: P | D | L}
+    want = []
+    for i in range(len(rows)):
+        ci, _ = oracle.topn_canonical(oracle.scores(host, host[rows[i]], threads=0), int(rows[i]), int(topns[i]))
+        want.append(ci.tolist())
 
     def stream(eng, with_hooks):
         outs = []
@@ -602,29 +610,26 @@ def test_hand_offs_fail_safe_under_stale_values(Engine, torch_cuda):
             eng.debug_handoff(P)       # ... and with the last query still stashed
         eng.enqueue_flush()
         torch.cuda.synchronize()
-        return outs
+        return [unpack_keys(k.cpu().numpy())[0].tolist() for k in outs]
 
     with Engine(f) as eng:
-        eng.set_replica(OFF)
-        want = stream(eng, False)
-        eng.set_replica(ON)
-        c0 = eng.replica_counters()["rescored_rows"]
-        clean = stream(eng, False)
-        c1 = eng.replica_counters()["rescored_rows"]
-        hostile = stream(eng, True)
-        c2 = eng.replica_counters()["rescored_rows"]
-        assert all(torch.equal(a, b) for a, b in zip(want, clean))
-        bad = [i for i in range(len(rows)) if not torch.equal(want[i], hostile[i])]
-        assert not bad, (len(bad), bad[:8])
-        # refused values cost candidates: far more rows took the exact chain than in the clean stream
-        assert c2 - c1 > 3 * (c1 - c0), (c1 - c0, c2 - c1)
-        # lone queries (their launch's last workgroup merges: arrival counters that are never reset) after all that
-        for r, topn in ((int(rows[0]), 100), (int(rows[1]), 10), (int(rows[2]), 1000)):
-            idx, sc = eng.query_row_topn(r, topn)
-            ref = torch.zeros(topn, dtype=torch.int64, device="cuda")
-            eng.set_replica(OFF)
-            eng.enqueue_row_keys(r, topn, ref)
-            torch.cuda.synchronize()
-            eng.set_replica(ON)
-            got = (~ref.cpu().numpy().view(np.uint64) & np.uint64(0xffffffff)).astype(np.int64)
-            assert idx.tolist() == got.tolist()
+        for mode in (OFF, ON):
+            eng.set_replica(mode)
+            c0 = eng.replica_counters()["rescored_rows"]
+            clean = stream(eng, False)
+            c1 = eng.replica_counters()["rescored_rows"]
+            hostile = stream(eng, True)
+            c2 = eng.replica_counters()["rescored_rows"]
+            bad = [i for i in range(len(rows)) if clean[i] != want[i]]
+            assert not bad, (mode, "clean", len(bad), bad[:8])
+            bad = [i for i in range(len(rows)) if hostile[i] != want[i]]
+            assert not bad, (mode, "hostile", len(bad), bad[:8])
+            if mode == ON:   # refused values cost candidates: far more rows took the exact chain than in the clean stream
+                assert c2 - c1 > 3 * (c1 - c0), (c1 - c0, c2 - c1)
+            # queries alone (the sample launch's last workgroup selects; over the replica the scan's last workgroup merges:
+            # arrival counters that are never reset) after all that, and right behind a poisoning
+            for r, topn in ((int(rows[0]), 100), (int(rows[1]), 10), (int(rows[2]), 1000)):
+                eng.debug_handoff(P | L if topn == 10 else P)
+                idx, sc = eng.query_row_topn(r, topn)
+                ci, _ = oracle.topn_canonical(oracle.scores(host, host[r], threads=0), r, topn)
+                assert idx.tolist() == ci.tolist(), (mode, r, topn)
