@@ -697,8 +697,11 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
 // into that query's output row.  Rare path, so the hand-off is the plain one: a device-wide fence
 // before each workgroup counts itself out and one behind the count of the last (`arrive` is zero
 // between launches: the last workgroup resets it, and a launch with an empty queue never touches it).
+// (Launch bounds it can meet: one workgroup per CU is all the launch ever has — its grid is the CU count and the merge's
+// shared memory, 120 KB, allows no second one — so two waves per SIMD, not the pass kernel's four: the compiler used to
+// warn "desired occupancy was 4, final occupancy is 2".)
 template <typename Cfg>
-__global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_queued_kernel(
+__global__ __launch_bounds__(Cfg::kBlock, 2) void scan_multi_queued_kernel(
     const float* __restrict__ feats, int64_t n, int iters, int64_t row_base,
     const float* __restrict__ queries_dev, const long long* __restrict__ exclude_dev,
     const int* __restrict__ queue, const int* __restrict__ queue_count, int topk,
