@@ -78,6 +78,7 @@ constexpr int kBqMaxQueries = kBqMaxBlocks * 32;
 constexpr int kBqCapMin = 2048;
 constexpr int kBqCapMax = 65536;
 constexpr int kBqSpecialCap = 1024;          // special rows kept per chunk
+constexpr int kBqNbhdRows = 1024;            // rows around a query's excluded row that give its neighbourhood bound (handoff.hip.h)
 constexpr int kBqFinalBlock = 256;           // threads of the finalize workgroup
 constexpr int kBqFinalChunk = 2048;          // candidates scored between two cuts of the finalize workgroup's key buffer
 constexpr int kBqFinalKeys = kBqFinalChunk + 1024;   // keys that buffer holds: a chunk + what a cut may leave (<= 1024)
@@ -177,12 +178,14 @@ __global__ __launch_bounds__(256) void bq_prepare_kernel(
     int topk, uint32_t* __restrict__ nb_vals /* [n_queries] */) {
     if (static_cast<int>(blockIdx.x) >= prep_blocks) {   // uniform: a neighbourhood workgroup
         __shared__ SelectSmem s_sel;
-        __shared__ int s_count;
+        __shared__ int s_bins[kSelScratch];
         const int nq = static_cast<int>(blockIdx.x) - prep_blocks;
+        // (1024 rows here, not the single queries' 2048: a thousand of these workgroups ride in every chunk's first launch)
+        const Nbhd<256, kBqNbhdRows> nb = nbhd_request<256, kBqNbhdRows>(feats, n, row_base, exclude ? exclude[nq] : -1ll);
         float qv[kDim];
 #pragma unroll
         for (int j = 0; j < kDim; ++j) qv[j] = queries[static_cast<int64_t>(nq) * kDim + j];
-        const uint32_t v = nbhd_bound<256>(feats, n, row_base, exclude ? exclude[nq] : -1ll, qv, query_norm(qv), topk, s_sel, &s_count);
+        const uint32_t v = nbhd_finish<256, kBqNbhdRows>(nb, n, qv, query_norm(qv), topk, s_sel, s_bins);
         if (threadIdx.x == 0) nb_vals[nq] = v;
         return;
     }

@@ -90,71 +90,6 @@ struct NextSeed {
     int nbhd;                  // 1: the grid's last workgroup computes the next query's neighbourhood bound into out[kNbhdSlot]
 };
 
-// ---- the neighbourhood of the excluded row ------------------------------------------------------------------
-// Called by ALL kThreads threads of a workgroup (barriers inside).  Scores the kNbhdRows rows around local row
-// (exclude_global - row_base) with the exact chain and returns the ordered-u32 image of a score v such that at least
-// `topk` of them — the excluded row left out — score >= v; 0 when the excluded row is not a row of this shard or the
-// neighbourhood holds fewer than topk rows.
-template <int kThreads>
-__device__ inline uint32_t nbhd_bound(const float* __restrict__ feats, int64_t n, int64_t row_base, int64_t exclude_global,
-                                      const float (&q)[kDim], float qn, int topk, SelectSmem& sel, int* s_count) {
-    static_assert(kNbhdRows % kThreads == 0, "whole rows per thread");
-    constexpr int kPer = kNbhdRows / kThreads;
-    const int tid = threadIdx.x;
-    const int64_t center = exclude_global - row_base;
-    if (center < 0 || center >= n || topk < 1) return 0u;   // uniform
-    int64_t lo = center - kNbhdRows / 2;
-    if (lo > n - kNbhdRows) lo = n - kNbhdRows;
-    if (lo < 0) lo = 0;
-    Row rows[kPer];
-#pragma unroll
-    for (int u = 0; u < kPer; ++u) {
-        const int64_t r = lo + u * kThreads + tid;
-        rows[u] = load_row(feats, r < n ? r : n - 1);
-    }
-    uint64_t keys[kPer];
-    int have = 0;
-#pragma unroll
-    for (int u = 0; u < kPer; ++u) {
-        const int64_t r = lo + u * kThreads + tid;
-        const float s = cosine_score(q, qn, rows[u]);
-        const bool use = r < n && r != center;
-        // unique keys: the score's image in the high word, the position in the low word
-        keys[u] = use ? (static_cast<uint64_t>(score_to_ordered(s)) << 32) | static_cast<uint32_t>(u * kThreads + tid + 1) : 0ull;
-        have += use ? 1 : 0;
-    }
-    if (tid == 0) *s_count = 0;
-    __syncthreads();
-    {   // one LDS atomic per wave
-        const int wave_have = __builtin_amdgcn_readlane(wave_inclusive_scan(have), 63);
-        if ((tid & 63) == 0 && wave_have) atomicAdd(s_count, wave_have);
-    }
-    __syncthreads();
-    if (*s_count < topk) return 0u;   // uniform
-    // any T with at least topk keys at or above it is a valid bound: stop the radix select a few keys early
-    const uint64_t t = block_select_threshold<kThreads, kPer>(keys, topk, false, topk / 8 + 2, sel);
-    return static_cast<uint32_t>(t >> 32);
-}
-
-// The neighbourhood workgroup of a sample launch or of a streamed launch's riders: the bound goes, under the query's
-// epoch, to slot kNbhdSlot of the query's sample buffer — read by the NEXT launch on the stream (plain store: a
-// kernel boundary lies between).  Always stores, so that a slot never keeps an older query's value under a live epoch.
-template <int kThreads>
-__device__ inline void nbhd_to_slot(const float* __restrict__ feats, int64_t n, int64_t row_base, const float* query_ptr,
-                                    const float (&by_value)[kDim], int64_t exclude_global, int topk, uint32_t epoch,
-                                    unsigned long long* __restrict__ sample_buf, SelectSmem& sel, int* s_count) {
-    float q[kDim];
-    if (query_ptr) {
-#pragma unroll
-        for (int j = 0; j < kDim; ++j) q[j] = query_ptr[j];
-    } else {
-#pragma unroll
-        for (int j = 0; j < kDim; ++j) q[j] = by_value[j];
-    }
-    const uint32_t v = nbhd_bound<kThreads>(feats, n, row_base, exclude_global, q, query_norm(q), topk, sel, s_count);
-    if (threadIdx.x == 0) sample_buf[kNbhdSlot] = tag_value(epoch, v);
-}
-
 // ---- selecting from <= 2048 sample values ----------------------------------------------------------------------
 struct Sample {
     uint32_t v[kHalfSeedPerThread];   // this thread's share of the sample values (ordered-u32 images; 0 = empty)
@@ -201,9 +136,9 @@ constexpr int kSelBins = 1024;
 constexpr float kSelSpan = 0.25f;
 constexpr int kSelScratch = kSelBins + 16;   // ints of LDS scratch the selection needs (bins, block max, wave totals, result)
 
-template <int kBlock>
-__device__ __forceinline__ float sample_kth_value(const Sample& sample, int n_seed, int topk, int* s_seeds /* zeroed */,
-                                                  SelectSmem& s_sel, int* s_bins /* kSelScratch ints nobody else is using */) {
+template <int kBlock, int kVals>
+__device__ __forceinline__ float kth_of_values(const uint32_t (&vals)[kVals], int n_seed, int topk, int* s_seeds /* zeroed */,
+                                               SelectSmem& s_sel, int* s_bins /* kSelScratch ints nobody else is using */) {
     static_assert(kSelBins % kBlock == 0, "whole bins per thread");
     constexpr int kPer = kSelBins / kBlock;
     const int tid = threadIdx.x;
@@ -214,9 +149,9 @@ __device__ __forceinline__ float sample_kth_value(const Sample& sample, int n_se
     uint32_t vmax = 0u;
     int have = 0;
 #pragma unroll
-    for (int r = 0; r < kHalfSeedPerThread; ++r) {
-        vmax = sample.v[r] > vmax ? sample.v[r] : vmax;
-        have += sample.v[r] != 0u;
+    for (int r = 0; r < kVals; ++r) {
+        vmax = vals[r] > vmax ? vals[r] : vmax;
+        have += vals[r] != 0u;
     }
     for (int i = tid; i < kSelScratch; i += kBlock) s_bins[i] = 0;
     vmax = wave_max_u32(vmax);
@@ -231,9 +166,9 @@ __device__ __forceinline__ float sample_kth_value(const Sample& sample, int n_se
     if (*s_seeds < topk) return v;   // uniform
     const float smax = ordered_to_score(static_cast<uint32_t>(s_bins[kSelBins]));
 #pragma unroll
-    for (int r = 0; r < kHalfSeedPerThread; ++r) {
-        if (sample.v[r]) {
-            const float d = (smax - ordered_to_score(sample.v[r])) * (static_cast<float>(kSelBins) / kSelSpan);
+    for (int r = 0; r < kVals; ++r) {
+        if (vals[r]) {
+            const float d = (smax - ordered_to_score(vals[r])) * (static_cast<float>(kSelBins) / kSelSpan);
             int bin = static_cast<int>(d);
             bin = (d >= 0.0f && bin < kSelBins - 1) ? bin : (d >= 0.0f ? kSelBins - 1 : 0);   // (NaN: the last bin)
             if (!(d == d)) bin = kSelBins - 1;
@@ -271,16 +206,105 @@ __device__ __forceinline__ float sample_kth_value(const Sample& sample, int n_se
         // every value of bins 0 .. found is >= this edge (2e-6: the rounding of the bin arithmetic)
         v = smax - static_cast<float>(found + 1) * (kSelSpan / static_cast<float>(kSelBins)) - 2.0e-6f;
     } else {   // the topk-th value lies far below the maximum (or the values are not what they should be): exact
-        uint64_t keys[kHalfSeedPerThread];
+        uint64_t keys[kVals];
 #pragma unroll
-        for (int r = 0; r < kHalfSeedPerThread; ++r) {
+        for (int r = 0; r < kVals; ++r) {
             const int i = tid + r * kBlock;
-            keys[r] = sample.v[r] ? (static_cast<uint64_t>(sample.v[r]) << 32) | static_cast<uint32_t>(i + 1) : 0ull;
+            keys[r] = vals[r] ? (static_cast<uint64_t>(vals[r]) << 32) | static_cast<uint32_t>(i + 1) : 0ull;
         }
-        const uint64_t t = block_select_threshold<kBlock, kHalfSeedPerThread>(keys, topk, false, topk / 8 + 2, s_sel);
+        const uint64_t t = block_select_threshold<kBlock, kVals>(keys, topk, false, topk / 8 + 2, s_sel);
         v = ordered_to_score(static_cast<uint32_t>(t >> 32));
     }
     return v;
+}
+
+template <int kBlock>
+__device__ __forceinline__ float sample_kth_value(const Sample& sample, int n_seed, int topk, int* s_seeds /* zeroed */,
+                                                  SelectSmem& s_sel, int* s_bins /* kSelScratch ints nobody else is using */) {
+    return kth_of_values<kBlock, kHalfSeedPerThread>(sample.v, n_seed, topk, s_seeds, s_sel, s_bins);
+}
+
+// ---- the neighbourhood of the excluded row ------------------------------------------------------------------
+// Called by ALL kThreads threads of a workgroup (barriers inside).  Scores the kRows rows around local row
+// (exclude_global - row_base) with the exact chain and returns the ordered-u32 image of a score v such that at least
+// `topk` of them — the excluded row left out — score >= v; 0 when the excluded row is not a row of this shard or the
+// neighbourhood holds fewer than topk rows.  Two halves, so that a caller can REQUEST the rows before it loads its
+// query (which sits behind two dependent scalar loads and a norm: this work is on the critical path of a query alone).
+template <int kThreads, int kRows = kNbhdRows>
+struct Nbhd {
+    static_assert(kRows % kThreads == 0, "whole rows per thread");
+    static constexpr int kPer = kRows / kThreads;
+    Row rows[kPer];
+    int64_t lo, center;
+    bool have;   // uniform
+};
+
+template <int kThreads, int kRows = kNbhdRows>
+__device__ __forceinline__ Nbhd<kThreads, kRows> nbhd_request(const float* __restrict__ feats, int64_t n, int64_t row_base,
+                                                              int64_t exclude_global) {
+    Nbhd<kThreads, kRows> nb;
+    nb.center = exclude_global - row_base;
+    nb.have = nb.center >= 0 && nb.center < n;
+    int64_t lo = nb.center - kRows / 2;
+    if (lo > n - kRows) lo = n - kRows;
+    if (lo < 0) lo = 0;
+    nb.lo = lo;
+    if (nb.have) {   // uniform
+#pragma unroll
+        for (int u = 0; u < nb.kPer; ++u) {
+            const int64_t r = lo + u * kThreads + static_cast<int>(threadIdx.x);
+            nb.rows[u] = load_row(feats, r < n ? r : n - 1);
+        }
+    }
+    return nb;
+}
+
+// `s_bins`: kSelScratch ints of LDS nobody else is using (the selection's histogram; its spare word counts the rows).
+template <int kThreads, int kRows = kNbhdRows>
+__device__ inline uint32_t nbhd_finish(const Nbhd<kThreads, kRows>& nb, int64_t n, const float (&q)[kDim], float qn, int topk,
+                                       SelectSmem& sel, int* s_bins) {
+    constexpr int kPer = Nbhd<kThreads, kRows>::kPer;
+    const int tid = threadIdx.x;
+    if (!nb.have || topk < 1) return 0u;   // uniform
+    uint32_t vals[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int64_t r = nb.lo + u * kThreads + tid;
+        const float s = cosine_score(q, qn, nb.rows[u]);
+        vals[u] = (r < n && r != nb.center) ? score_to_ordered(s) : 0u;   // (an exact score's image is never 0)
+    }
+    // "any v with at least topk of the scores at or above it" by ONE linear histogram pass (kth_of_values: five barriers
+    // where the radix select over 64-bit keys took eight or more — this workgroup is the last one out of the sample launch
+    // of a query alone); -inf: fewer than topk rows
+    const float v = kth_of_values<kThreads, kPer>(vals, kRows, topk, &s_bins[kSelBins + 13], sel, s_bins);
+    return v > -3.0e38f ? score_to_ordered(v) : 0u;
+}
+
+template <int kThreads, int kRows = kNbhdRows>
+__device__ inline uint32_t nbhd_bound(const float* __restrict__ feats, int64_t n, int64_t row_base, int64_t exclude_global,
+                                      const float (&q)[kDim], float qn, int topk, SelectSmem& sel, int* s_bins) {
+    const Nbhd<kThreads, kRows> nb = nbhd_request<kThreads, kRows>(feats, n, row_base, exclude_global);
+    return nbhd_finish<kThreads, kRows>(nb, n, q, qn, topk, sel, s_bins);
+}
+
+// The neighbourhood workgroup of a sample launch or of a streamed launch's riders: the bound goes, under the query's
+// epoch, to slot kNbhdSlot of the query's sample buffer — read by the NEXT launch on the stream (plain store: a
+// kernel boundary lies between).  Always stores, so that a slot never keeps an older query's value under a live epoch.
+template <int kThreads>
+__device__ inline void nbhd_to_slot(const float* __restrict__ feats, int64_t n, int64_t row_base, const float* query_ptr,
+                                    const float (&by_value)[kDim], int64_t exclude_global, int topk, uint32_t epoch,
+                                    unsigned long long* __restrict__ sample_buf, SelectSmem& sel, int* s_bins) {
+    const Nbhd<kThreads> nb = nbhd_request<kThreads>(feats, n, row_base, exclude_global);   // the rows first ...
+    float q[kDim];                                                                            // ... then the query
+    if (query_ptr) {
+#pragma unroll
+        for (int j = 0; j < kDim; ++j) q[j] = query_ptr[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < kDim; ++j) q[j] = by_value[j];
+    }
+    const uint32_t v = nbhd_finish<kThreads>(nb, n, q, query_norm(q), topk, sel, s_bins);
+    if (threadIdx.x == 0) sample_buf[kNbhdSlot] = tag_value(epoch, v);
 }
 
 // The end of a seed rider (or of a workgroup of a sample launch) whose launch also SELECTS: it arrives, and the one

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
                                static_cast<int64_t>(0));
             } else if (next.nbhd && blockIdx.x == gridDim.x - 1u) {   // the next query's neighbourhood
                 nbhd_to_slot<kBlock>(feats, n, row_base, next.query_ptr, next.q, next.exclude_global, next.topk, next.epoch,
-                                     static_cast<unsigned long long*>(next.out), s_ride.scan.sel, &s_ride.scan.count);
+                                     static_cast<unsigned long long*>(next.out), s_ride.scan.sel, reinterpret_cast<int*>(s_ride.scan.cand));
             } else {                              // a seed rider: its share of the next query's sample
                 f32_sample_regions(feats, n, row_base, next, static_cast<int>(blockIdx.x - nblocks - 1u));
                 if (next.ctl) {   // uniform: the last rider out turns the sample into the next launch's bound
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kHalfSeedBlock) void seed_f32_kernel(const float* _
     __shared__ int s_bins[kSelScratch];
     if (static_cast<int>(blockIdx.x) >= next.regions) {   // uniform: the neighbourhood workgroup
         nbhd_to_slot<kHalfSeedBlock>(feats, n, row_base, next.query_ptr, next.q, next.exclude_global, next.topk, next.epoch,
-                                     static_cast<unsigned long long*>(next.out), s_sel, &s_flag);
+                                     static_cast<unsigned long long*>(next.out), s_sel, s_bins);
         return;
     }
     f32_sample_regions(feats, n, row_base, next, static_cast<int>(blockIdx.x));
