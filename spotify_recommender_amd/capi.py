@@ -166,8 +166,15 @@ def lib() -> ctypes.CDLL:
         except Exception:  # pragma: no cover
             pass
         handle = ctypes.CDLL(str(LIB_PATH))
+        import os
+        lenient = os.environ.get("MI355REC_CAPI_LENIENT") == "1"   # tools only: A/B against a library of an EARLIER round (--lib)
         for name, (restype, argtypes) in SIGNATURES.items():
-            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            try:
+                fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            except AttributeError:
+                if lenient:
+                    continue
+                raise
             fn.restype = restype
             fn.argtypes = argtypes
         _lib = handle
@@ -176,7 +183,10 @@ def lib() -> ctypes.CDLL:
 
 def has_experiments() -> bool:
     """True when the loaded library is an MI355REC_EXPERIMENTS build (tools/: A/B routes and environment knobs)."""
-    return bool(lib().mi355rec_build_flags() & BUILD_EXPERIMENTS)
+    L = lib()
+    if not hasattr(L, "mi355rec_build_flags"):   # (a library of an earlier round, loaded leniently by a tool)
+        return False
+    return bool(L.mi355rec_build_flags() & BUILD_EXPERIMENTS)
 
 
 class Mi355Error(RuntimeError):

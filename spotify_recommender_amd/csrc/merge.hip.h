@@ -118,6 +118,7 @@ __device__ __forceinline__ void merge_body(
         s_count = 0;
         s_overflow = 0;
         s_pair[0] = 0;
+        s_pair[1] = 0;
         s_more = 0;
     }
     __syncthreads();
@@ -160,27 +161,35 @@ __device__ __forceinline__ void merge_body(
             const int l = (u * kThreads + tid) / kMergeFirst;
             k[u] = (l < n_lists && j < list_len) ? ld_key<kCoherent>(&lists[static_cast<int64_t>(l) * list_stride + j]) : 0ull;
         }
+        int local_full = 0;   // lists whose whole first chunk is there: with thr = 1 they are the ones deeper rounds would walk
 #pragma unroll
         for (int u = 0; u < kFirstPer; ++u) {
             hk[u] = j == 0 ? k[u] : 0ull;
             local_nonzero += hk[u] != 0ull;
+            local_full += (j == first - 1 && k[u] != 0ull) ? 1 : 0;
         }
         for (int l = tid; l < n_lists; l += kThreads) s_active[l] = 0xffff;
         {   // one LDS atomic per wave (hundreds of threads adding to the one word serialise: measured 2 us in the 8-bit
             // scan's sample selection, the same pattern)
             const int wave_nonzero = __builtin_amdgcn_readlane(wave_inclusive_scan(local_nonzero), 63);
             if ((tid & 63) == 0 && wave_nonzero) atomicAdd(&s_pair[0], wave_nonzero);
+            const int wave_full = __builtin_amdgcn_readlane(wave_inclusive_scan(local_full), 63);
+            if ((tid & 63) == 0 && wave_full) atomicAdd(&s_pair[1], wave_full);
         }
         __syncthreads();
         const int nonempty = s_pair[0];
+        const int full_chunks = s_pair[1];
         // FEW NON-EMPTY LISTS.  With a launch-wide bound most workgroups of a scan keep nothing, and on a catalogue whose
         // similar rows lie next to each other the whole top-k sits in the lists of the two or twenty workgroups that met
         // the query's cluster: fewer heads than the threshold select needs, thr stays 1, and those lists were then walked
         // 16 keys per dependent round trip (a query alone at 10 M rows, 3000 contiguous clusters: 67 us against 47 on
         // uniform rows, all of it here).  Instead: ONE load phase over all keys of the non-empty lists, when they fit.
-        const bool sparse = nonempty < need_lists && static_cast<int64_t>(nonempty) * list_len <= kSurvCap;   // uniform
+        // (only where some list WOULD be walked: many lists of two or three keys each — a uniform catalogue under a good bound
+        // — are done after the first phase as they are, and a second load phase would only add a round trip)
+        const bool sparse = nonempty < need_lists && full_chunks > 0 && static_cast<int64_t>(nonempty) * list_len <= kSurvCap;   // uniform
         if (nonempty >= need_lists)  // uniform
             thr = block_select_threshold<kThreads, kFirstPer>(hk, need_lists, false, slack, s_sel);
+        __syncthreads();   // (everybody has read the two counts)
         if (tid == 0) s_pair[1] = 0;
         __syncthreads();
         if (sparse) {   // uniform

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--topn", type=int, default=100)
     ap.add_argument("--calls", type=int, default=40)
+    ap.add_argument("--no-exclude", action="store_true", help="the queries exclude no row (no neighbourhood bound is taken: handoff.hip.h)")
     ap.add_argument("--only-stream", type=int, default=0, help="only a stream of batches of this many queries (profiling)")
     ap.add_argument("--fp16", action="store_true", help="rows from the fp16 replica (24 B/row: the default from three queries per pass up) instead of the 8-bit one")
     ap.add_argument("--lib", default=None, help="another build of the library (e.g. an MI355REC_EXPERIMENTS one under gpurun_out/)")
@@ -59,7 +60,7 @@ def main():
         sizes = tuple(int(x) for x in args.sizes.split(",") if x) if not args.only_stream else ()
         for nb in sizes:
             keys = torch.zeros(nb * topn, dtype=torch.int64, device="cuda")
-            ex = np.array(rows[:nb], dtype=np.int64)
+            ex = np.full(nb, -1, dtype=np.int64) if args.no_exclude else np.array(rows[:nb], dtype=np.int64)
             eng.enqueue_batch_keys(q[:nb], ex, topn, keys)
             torch.cuda.synchronize()
             b = eng.replica_counters()
@@ -88,7 +89,7 @@ def main():
             eng.set_replica(capi.REPLICA_AUTO)
         for nb in (tuple(int(x) for x in args.streams.split(",") if x) if not args.only_stream else (args.only_stream,)):
             ring = [torch.zeros(nb * topn, dtype=torch.int64, device="cuda") for _ in range(4)]
-            ex = np.array(rows[:nb], dtype=np.int64)
+            ex = np.full(nb, -1, dtype=np.int64) if args.no_exclude else np.array(rows[:nb], dtype=np.int64)
             for k in range(6):
                 eng.enqueue_batch_keys_streamed(q[:nb], ex, topn, ring[k % 4])
             eng.enqueue_flush()
