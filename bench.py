@@ -1153,7 +1153,7 @@ def main():
                     "frac_if_nothing_were_skipped": round(unskipped / dt / 1e12 / FP16_MFMA_PEAK_TFLOPS, 3),
                     "avg_pass_kernel_ms": round(pass_ms, 4),
                     "binding_unit": "VALU issue (8 v_max3_i32 per MFMA = 1024 outputs), the hit path (the blocks that hold a "
-                                    "candidate cost ~3x a block without one) and chip power; 62 of the 81 cycles a SIMD spends per MFMA are vector issue (profiles/r04_pmc_batched_pass.json, DESIGN.md §4.6)",
+                                    "candidate cost ~3x a block without one) and chip power; 62 of the 81 cycles a SIMD spends per MFMA are vector issue (profiles/r05_pmc_batched_pass.json, DESIGN.md §5.5)",
                     "note": "the pre-filter runs on the fp16 matrix cores, so its roofline is the dense fp16 MFMA peak and `achieved` "
                             "counts the MFMA flops really issued; pass 2 SKIPS the (tile, block) pairs that the maxima pass 1 left "
                             "behind rule out, which lowers this fraction while the call gets faster — "

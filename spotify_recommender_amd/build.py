@@ -86,7 +86,7 @@ def kernel_metadata(lib: Path = LIB_ENGINE) -> list:
 def handoff_sites(lib: Path = LIB_ENGINE) -> list:
     """Disassembles the gfx950 code objects inside a built library and returns, for every "barrier, then one thread
     counts the workgroup in" site (an s_barrier followed within a few instructions by a RETURNING global_atomic_add:
-    the arrival of a cross-workgroup hand-off, DESIGN.md §4.11), whether an `s_waitcnt vmcnt(0)` stands before that
+    the arrival of a cross-workgroup hand-off, DESIGN.md §4), whether an `s_waitcnt vmcnt(0)` stands before that
     barrier: [(kernel, has_vmcnt0)].  A workgroup-scope fence does not wait for a wave's global stores on gfx950
     (ADVICE r3): without the wait the count can reach memory before the write-through stores it announces."""
     import re

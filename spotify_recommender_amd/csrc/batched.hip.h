@@ -177,15 +177,14 @@ __global__ __launch_bounds__(256) void bq_prepare_kernel(
     int prep_blocks, const float* __restrict__ feats, int64_t n, int64_t row_base, const long long* __restrict__ exclude /* may be null */,
     int topk, uint32_t* __restrict__ nb_vals /* [n_queries] */) {
     if (static_cast<int>(blockIdx.x) >= prep_blocks) {   // uniform: a neighbourhood workgroup
-        __shared__ SelectSmem s_sel;
-        __shared__ int s_bins[kSelScratch];
+        __shared__ int s_scratch[Nbhd<256, kBqNbhdRows>::kScratch];
         const int nq = static_cast<int>(blockIdx.x) - prep_blocks;
         // (1024 rows here, not the single queries' 2048: a thousand of these workgroups ride in every chunk's first launch)
-        const Nbhd<256, kBqNbhdRows> nb = nbhd_request<256, kBqNbhdRows>(feats, n, row_base, exclude ? exclude[nq] : -1ll);
+        const Nbhd<256, kBqNbhdRows> nb = nbhd_request<256, kBqNbhdRows>(feats, n, row_base, exclude ? exclude[nq] : -1ll, topk);
         float qv[kDim];
 #pragma unroll
         for (int j = 0; j < kDim; ++j) qv[j] = queries[static_cast<int64_t>(nq) * kDim + j];
-        const uint32_t v = nbhd_finish<256, kBqNbhdRows>(nb, n, qv, query_norm(qv), topk, s_sel, s_bins);
+        const uint32_t v = nbhd_finish<256, kBqNbhdRows>(nb, qv, query_norm(qv), topk, s_scratch);
         if (threadIdx.x == 0) nb_vals[nq] = v;
         return;
     }

@@ -383,4 +383,148 @@ __device__ inline uint64_t compact_candidates(uint64_t* s_cand, int* s_count, in
     return t - 1ull;
 }
 
+// ---- wave-level selection (no workgroup barrier: LDS operations of one wave execute in order) ---------------------------
+// Wave-level twin of block_select_threshold: the calling wave holds `c` unique
+// keys in registers (0 = empty), `hist` is 256 ints of LDS private to the wave.
+// No barriers: LDS operations of one wave execute in order.
+template <int kKeys>
+__device__ inline uint64_t wave_select_threshold(const uint64_t (&mine)[kKeys], int need, bool exact,
+                                                 int slack, int* hist) {
+    const int lane = threadIdx.x & 63;
+    uint32_t mx = 0, mn = ~0u;
+#pragma unroll
+    for (int r = 0; r < kKeys; ++r) {
+        if (mine[r]) {
+            const uint32_t hi = static_cast<uint32_t>(mine[r] >> 32);
+            mx = hi > mx ? hi : mx;
+            mn = hi < mn ? hi : mn;
+        }
+    }
+    mx = wave_max_u32(mx);
+    mn = wave_min_u32(mn);
+    const uint64_t base = static_cast<uint64_t>(mn) << 32;
+    const uint64_t span = (static_cast<uint64_t>(mx - mn) << 32) | 0xffffffffull;
+    int shift = (64 - __clzll(static_cast<long long>(span))) - 8;
+    if (shift < 0) shift = 0;
+    uint64_t prefix = 0, mask = 0;
+    const int top = 255 - 4 * lane;
+    hist[top] = 0; hist[top - 1] = 0; hist[top - 2] = 0; hist[top - 3] = 0;
+    for (;;) {
+#pragma unroll
+        for (int r = 0; r < kKeys; ++r) {
+            const uint64_t k = mine[r];
+            if (k) {
+                const uint64_t v = k - base;
+                if ((v & mask) == prefix) atomicAdd(&hist[static_cast<int>((v >> shift) & 255u)], 1);
+            }
+        }
+        const int h0 = hist[top], h1 = hist[top - 1], h2 = hist[top - 2], h3 = hist[top - 3];
+        hist[top] = 0; hist[top - 1] = 0; hist[top - 2] = 0; hist[top - 3] = 0;
+        const int lane_sum = h0 + h1 + h2 + h3;
+        int cum = wave_inclusive_scan(lane_sum) - lane_sum;
+        const int hs[4] = {h0, h1, h2, h3};
+        int digit = 0, above = 0, in_bin = 0;
+        bool found = false;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (cum < need && cum + hs[b] >= need) {
+                found = true;
+                digit = top - b;
+                above = cum;
+                in_bin = hs[b];
+            }
+            cum += hs[b];
+        }
+        const uint64_t who = __ballot(found);
+        const int src = __ffsll(static_cast<long long>(who)) - 1;  // exactly one lane when the precondition holds
+        digit = __builtin_amdgcn_readlane(digit, src);
+        above = __builtin_amdgcn_readlane(above, src);
+        in_bin = __builtin_amdgcn_readlane(in_bin, src);
+        prefix |= static_cast<uint64_t>(digit) << shift;
+        mask |= 255ull << shift;
+        need -= above;
+        if (shift == 0 || in_bin == need || (!exact && in_bin - need <= slack)) break;
+        shift = shift > 8 ? shift - 8 : 0;
+    }
+    return base + prefix;
+}
+
+// Wave-level compaction of one query's candidate buffer: keep the keys >= T where
+// T bounds the topk-th best.  Returns the new filter threshold (key > thr passes).
+template <int kKeys>
+__device__ inline uint64_t wave_compact(uint64_t* cand, int* count, int topk, bool exact, int* hist) {
+    const int lane = threadIdx.x & 63;
+    const int c = *count;
+    if (c <= topk) return 0ull;
+    uint64_t mine[kKeys];
+#pragma unroll
+    for (int r = 0; r < kKeys; ++r) {
+        const int i = lane + r * 64;
+        mine[r] = i < c ? cand[i] : 0ull;
+    }
+    int slack = topk / 4;
+    if (slack < 16) slack = 16;
+    const uint64_t t = wave_select_threshold<kKeys>(mine, topk, exact, slack, hist);
+    int base = 0;
+#pragma unroll
+    for (int r = 0; r < kKeys; ++r) {
+        const bool keep = mine[r] >= t;  // t >= 1, so empty slots drop out
+        const uint64_t b = __ballot(keep);
+        if (keep) cand[base + lanes_below(b)] = mine[r];
+        base += __popcll(b);
+    }
+    if (lane == 0) *count = base;
+    return t - 1ull;
+}
+
+// The same with the count kept in a (wave-uniform) REGISTER.  A count that lane 0 stores to LDS and
+// the other lanes load back right away is a data race as far as the compiler is concerned (each lane
+// is a thread: it may keep using the value it loaded before) — callers that compact between two
+// workgroup barriers can use wave_compact; a wave that compacts in the middle of its own work must
+// carry the count itself.
+template <int kKeys>
+__device__ inline uint64_t wave_compact_reg(uint64_t* cand, int& c, int topk, bool exact, int* hist) {
+    const int lane = threadIdx.x & 63;
+    if (c <= topk) return 0ull;   // uniform
+    uint64_t mine[kKeys];
+#pragma unroll
+    for (int r = 0; r < kKeys; ++r) {
+        const int i = lane + r * 64;
+        mine[r] = i < c ? cand[i] : 0ull;
+    }
+    int slack = topk / 4;
+    if (slack < 16) slack = 16;
+    const uint64_t t = wave_select_threshold<kKeys>(mine, topk, exact, slack, hist);
+    int base = 0;
+#pragma unroll
+    for (int r = 0; r < kKeys; ++r) {
+        const bool keep = mine[r] >= t;  // t >= 1, so empty slots drop out
+        const uint64_t b = __ballot(keep);
+        if (keep) cand[base + lanes_below(b)] = mine[r];
+        base += __popcll(b);
+    }
+    c = base;
+    return t - 1ull;
+}
+
+// Wave-level ranking of c <= kRankDirectMax unique keys into dst (descending, best topk).
+__device__ inline void wave_rank_and_store(const uint64_t* keys, int c, uint64_t* dst, int topk) {
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < topk; i += 64)
+        if (i >= c) dst[i] = 0ull;
+    for (int i = lane; i < c; i += 64) {
+        const uint64_t mine = keys[i];
+        int rank = 0;
+        int j = 0;
+        for (; j + 8 <= c; j += 8) {
+            const uint64_t k0 = keys[j], k1 = keys[j + 1], k2 = keys[j + 2], k3 = keys[j + 3];
+            const uint64_t k4 = keys[j + 4], k5 = keys[j + 5], k6 = keys[j + 6], k7 = keys[j + 7];
+            rank += (k0 > mine) + (k1 > mine) + (k2 > mine) + (k3 > mine) +
+                    (k4 > mine) + (k5 > mine) + (k6 > mine) + (k7 > mine);
+        }
+        for (; j < c; ++j) rank += (keys[j] > mine);
+        if (rank < topk) dst[rank] = mine;
+    }
+}
+
 }  // namespace mi355

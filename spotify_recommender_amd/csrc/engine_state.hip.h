@@ -334,8 +334,9 @@ void plan_grid(mi355rec* h, int blocks_per_cu) {
     h->sgrid = g;
     h->siters = static_cast<int>((tiles + g - 1) / g);
     // ... and, where the launch can spare them, a few are the NEXT query's seed riders and its neighbourhood workgroup
-    // (handoff.hip.h): a rider takes four regions per memory round trip (~2.5 us) and should be done well before the
-    // scanners (~3 us per tile each) are.
+    // (handoff.hip.h): a rider takes two regions per memory round trip (~2.5 us) and should be done well before the
+    // scanners (~3 us per tile each) are; sized as if it took four, which still leaves it under half of the launch
+    // (10 M rows: 11 riders x 12 round trips = 30 of 80 us).
     F32Geom& f = h->fg;
     f = F32Geom();
     f.r_scan = h->sgrid;

@@ -225,77 +225,141 @@ __device__ __forceinline__ float sample_kth_value(const Sample& sample, int n_se
 }
 
 // ---- the neighbourhood of the excluded row ------------------------------------------------------------------
-// Called by ALL kThreads threads of a workgroup (barriers inside).  Scores the kRows rows around local row
+// Called by ALL kThreads threads of a workgroup (one barrier pair inside).  Scores up to kRows rows around local row
 // (exclude_global - row_base) with the exact chain and returns the ordered-u32 image of a score v such that at least
-// `topk` of them — the excluded row left out — score >= v; 0 when the excluded row is not a row of this shard or the
-// neighbourhood holds fewer than topk rows.  Two halves, so that a caller can REQUEST the rows before it loads its
-// query (which sits behind two dependent scalar loads and a norm: this work is on the critical path of a query alone).
+// `topk` of them — the excluded row left out — score >= v; 0 when the excluded row is not a row of this shard (or the shard
+// is smaller than a neighbourhood).  Two halves, so that a caller can REQUEST the rows before it loads its query (which
+// sits behind two dependent scalar loads and a norm: this work is on the critical path of a query alone).
+// How many rows: 16 x topk, in whole rounds of kThreads, at most kRows — 512 rows at top-10, all 2048 from top-100 up (the
+// bound wants the topk-th best of a few times topk rows of the query's cluster, not of every row a workgroup can hold:
+// at 1 M rows x top-10 the neighbourhood workgroup is the last one out of the sample launch of a query alone).
+// Selection without workgroup barriers: every WAVE takes the ceil(topk / waves)-th largest of ITS rows (the wave-level
+// radix select, digits relative to the wave's own range: in a tight cluster all scores lie within 1e-4 of each other and
+// a fixed-width histogram cannot tell them apart — tried, and the fp32 scan's bound fell below the whole cluster), and
+// v = the smallest of those: each wave holds that many rows at or above its value, so their union holds topk at or above v.
 template <int kThreads, int kRows = kNbhdRows>
 struct Nbhd {
     static_assert(kRows % kThreads == 0, "whole rows per thread");
     static constexpr int kPer = kRows / kThreads;
+    static constexpr int kWaves = kThreads / 64;
+    static constexpr int kScratch = kWaves * 256 + 4;   // ints of LDS scratch nbhd_finish needs
     Row rows[kPer];
     int64_t lo, center;
+    int per;     // uniform: rows per thread in use
     bool have;   // uniform
 };
 
 template <int kThreads, int kRows = kNbhdRows>
 __device__ __forceinline__ Nbhd<kThreads, kRows> nbhd_request(const float* __restrict__ feats, int64_t n, int64_t row_base,
-                                                              int64_t exclude_global) {
+                                                              int64_t exclude_global, int topk) {
     Nbhd<kThreads, kRows> nb;
     nb.center = exclude_global - row_base;
-    nb.have = nb.center >= 0 && nb.center < n;
-    int64_t lo = nb.center - kRows / 2;
-    if (lo > n - kRows) lo = n - kRows;
+    int per = (16 * topk + kThreads - 1) / kThreads;
+    per = per < 1 ? 1 : (per > nb.kPer ? nb.kPer : per);
+    nb.per = per;
+    const int64_t rows = static_cast<int64_t>(per) * kThreads;
+    nb.have = nb.center >= 0 && nb.center < n && n >= rows && topk >= 1;
+    int64_t lo = nb.center - rows / 2;
+    if (lo > n - rows) lo = n - rows;
     if (lo < 0) lo = 0;
     nb.lo = lo;
     if (nb.have) {   // uniform
 #pragma unroll
         for (int u = 0; u < nb.kPer; ++u) {
-            const int64_t r = lo + u * kThreads + static_cast<int>(threadIdx.x);
-            nb.rows[u] = load_row(feats, r < n ? r : n - 1);
+            if (u < per)   // uniform
+                nb.rows[u] = load_row(feats, lo + u * kThreads + static_cast<int>(threadIdx.x));
         }
     }
     return nb;
 }
 
-// `s_bins`: kSelScratch ints of LDS nobody else is using (the selection's histogram; its spare word counts the rows).
+// The selection: `keys` = this thread's rows (0 = none), rows_per_wave = how many rows a wave holds among them.
+// `s_scratch`: Nbhd::kScratch ints of LDS nobody else is using.
+template <int kThreads, int kKeys>
+__device__ inline uint32_t nbhd_select(const uint64_t (&keys)[kKeys], int rows_per_wave, int topk, int* s_scratch) {
+    constexpr int kWaves = kThreads / 64;
+    const int tid = threadIdx.x;
+    unsigned* const s_min = reinterpret_cast<unsigned*>(&s_scratch[kWaves * 256]);
+    if (tid == 0) *s_min = ~0u;
+    __syncthreads();
+    // a wave holds rows_per_wave rows, one of which may be the excluded one
+    int need = (topk + kWaves - 1) / kWaves;
+    if (need > rows_per_wave - 1) need = rows_per_wave - 1;   // (then fewer than topk rows stand behind the bound: checked below)
+    const uint64_t t = wave_select_threshold<kKeys>(keys, need, false, need / 8 + 1, s_scratch + (tid >> 6) * 256);
+    if ((tid & 63) == 0) atomicMin(s_min, static_cast<unsigned>(t >> 32));
+    __syncthreads();
+    return need * kWaves >= topk ? *s_min : 0u;   // uniform
+}
+
 template <int kThreads, int kRows = kNbhdRows>
-__device__ inline uint32_t nbhd_finish(const Nbhd<kThreads, kRows>& nb, int64_t n, const float (&q)[kDim], float qn, int topk,
-                                       SelectSmem& sel, int* s_bins) {
+__device__ inline uint32_t nbhd_finish(const Nbhd<kThreads, kRows>& nb, const float (&q)[kDim], float qn, int topk, int* s_scratch) {
     constexpr int kPer = Nbhd<kThreads, kRows>::kPer;
     const int tid = threadIdx.x;
-    if (!nb.have || topk < 1) return 0u;   // uniform
-    uint32_t vals[kPer];
+    if (!nb.have) return 0u;   // uniform
+    uint64_t keys[kPer];
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
-        const int64_t r = nb.lo + u * kThreads + tid;
-        const float s = cosine_score(q, qn, nb.rows[u]);
-        vals[u] = (r < n && r != nb.center) ? score_to_ordered(s) : 0u;   // (an exact score's image is never 0)
+        keys[u] = 0ull;
+        if (u < nb.per) {   // uniform
+            const int64_t r = nb.lo + u * kThreads + tid;
+            const float s = cosine_score(q, qn, nb.rows[u]);
+            // unique keys: the score's image in the high word, the position in the low word
+            if (r != nb.center) keys[u] = (static_cast<uint64_t>(score_to_ordered(s)) << 32) | static_cast<uint32_t>(u * kThreads + tid + 1);
+        }
     }
-    // "any v with at least topk of the scores at or above it" by ONE linear histogram pass (kth_of_values: five barriers
-    // where the radix select over 64-bit keys took eight or more — this workgroup is the last one out of the sample launch
-    // of a query alone); -inf: fewer than topk rows
-    const float v = kth_of_values<kThreads, kPer>(vals, kRows, topk, &s_bins[kSelBins + 13], sel, s_bins);
-    return v > -3.0e38f ? score_to_ordered(v) : 0u;
+    return nbhd_select<kThreads, kPer>(keys, 64 * nb.per, topk, s_scratch);
+}
+
+// The same bound from kRounds x kPerRound x kThreads rows with only kPerRound rows of a thread in flight at a time: for a
+// workgroup that has TIME but few registers — the neighbourhood rider of a streamed fp32 scan shares the kernel's 80-VGPR
+// budget, and its launch lasts 80 us.  (How tight the bound is decides what the next launch costs on a catalogue of few
+// large clusters: at 300 contiguous clusters of 33 k rows a streamed fp32 query took 164 us with 1024 rows behind the
+// bound — about the 14th percentile of the cluster — against 89 us with 2048.)
+template <int kThreads, int kPerRound, int kRounds>
+__device__ inline uint32_t nbhd_bound_rounds(const float* __restrict__ feats, int64_t n, int64_t row_base, int64_t exclude_global,
+                                             const float (&q)[kDim], float qn, int topk, int* s_scratch) {
+    constexpr int kKeys = kPerRound * kRounds;
+    constexpr int64_t kRows = static_cast<int64_t>(kKeys) * kThreads;
+    const int tid = threadIdx.x;
+    const int64_t center = exclude_global - row_base;
+    if (!(center >= 0 && center < n && n >= kRows && topk >= 1)) return 0u;   // uniform
+    int64_t lo = center - kRows / 2;
+    if (lo > n - kRows) lo = n - kRows;
+    if (lo < 0) lo = 0;
+    uint64_t keys[kKeys];
+#pragma unroll
+    for (int round = 0; round < kRounds; ++round) {
+        Row rows[kPerRound];
+#pragma unroll
+        for (int u = 0; u < kPerRound; ++u) rows[u] = load_row(feats, lo + (round * kPerRound + u) * kThreads + tid);
+#pragma unroll
+        for (int u = 0; u < kPerRound; ++u) {
+            const int slot = round * kPerRound + u;
+            const int64_t r = lo + slot * kThreads + tid;
+            const float s = cosine_score(q, qn, rows[u]);
+            keys[slot] = r != center ? (static_cast<uint64_t>(score_to_ordered(s)) << 32) | static_cast<uint32_t>(slot * kThreads + tid + 1) : 0ull;
+        }
+        asm volatile("" ::: "memory");   // the next round's loads stay behind this round's scores
+    }
+    return nbhd_select<kThreads, kKeys>(keys, 64 * kKeys, topk, s_scratch);
 }
 
 template <int kThreads, int kRows = kNbhdRows>
 __device__ inline uint32_t nbhd_bound(const float* __restrict__ feats, int64_t n, int64_t row_base, int64_t exclude_global,
-                                      const float (&q)[kDim], float qn, int topk, SelectSmem& sel, int* s_bins) {
-    const Nbhd<kThreads, kRows> nb = nbhd_request<kThreads, kRows>(feats, n, row_base, exclude_global);
-    return nbhd_finish<kThreads, kRows>(nb, n, q, qn, topk, sel, s_bins);
+                                      const float (&q)[kDim], float qn, int topk, int* s_scratch) {
+    const Nbhd<kThreads, kRows> nb = nbhd_request<kThreads, kRows>(feats, n, row_base, exclude_global, topk);
+    return nbhd_finish<kThreads, kRows>(nb, q, qn, topk, s_scratch);
 }
 
 // The neighbourhood workgroup of a sample launch or of a streamed launch's riders: the bound goes, under the query's
 // epoch, to slot kNbhdSlot of the query's sample buffer — read by the NEXT launch on the stream (plain store: a
 // kernel boundary lies between).  Always stores, so that a slot never keeps an older query's value under a live epoch.
-template <int kThreads>
+template <int kThreads, int kRows = kNbhdRows>
 __device__ inline void nbhd_to_slot(const float* __restrict__ feats, int64_t n, int64_t row_base, const float* query_ptr,
                                     const float (&by_value)[kDim], int64_t exclude_global, int topk, uint32_t epoch,
-                                    unsigned long long* __restrict__ sample_buf, SelectSmem& sel, int* s_bins) {
-    const Nbhd<kThreads> nb = nbhd_request<kThreads>(feats, n, row_base, exclude_global);   // the rows first ...
-    float q[kDim];                                                                            // ... then the query
+                                    unsigned long long* __restrict__ sample_buf, int* s_scratch /* Nbhd<kThreads, kRows>::kScratch ints */) {
+    const Nbhd<kThreads, kRows> nb = nbhd_request<kThreads, kRows>(feats, n, row_base, exclude_global, topk);   // the rows first ...
+    float q[kDim];                                                                                  // ... then the query
     if (query_ptr) {
 #pragma unroll
         for (int j = 0; j < kDim; ++j) q[j] = query_ptr[j];
@@ -303,7 +367,7 @@ __device__ inline void nbhd_to_slot(const float* __restrict__ feats, int64_t n, 
 #pragma unroll
         for (int j = 0; j < kDim; ++j) q[j] = by_value[j];
     }
-    const uint32_t v = nbhd_finish<kThreads>(nb, n, q, query_norm(q), topk, sel, s_bins);
+    const uint32_t v = nbhd_finish<kThreads, kRows>(nb, q, query_norm(q), topk, s_scratch);
     if (threadIdx.x == 0) sample_buf[kNbhdSlot] = tag_value(epoch, v);
 }
 
@@ -336,11 +400,12 @@ __device__ __forceinline__ bool sample_arrive_and_select(SeedCtl* ctl, unsigned 
 // A REGION is kHalfSeedBlock rows from row g * stride_rows on (stride_rows >= kHalfSeedBlock: no row is in two regions),
 // one row per lane: every wave leaves the best EXACT score of its 64 rows (the excluded row left out) at
 // out[g * 8 + wave], under the query's epoch, written through to device scope (the last rider of the same launch
-// reads it).  Rider `rider` of `next.n_wgs` takes regions rider, rider + n_wgs, ...; four regions per memory round
-// trip.  Called by all kHalfSeedBlock threads.
+// reads it).  Rider `rider` of `next.n_wgs` takes regions rider, rider + n_wgs, ...; kAhead regions per memory round
+// trip (4 in the sample launch of a query alone, where the round trips are the launch; 2 for the riders of a streamed
+// scan, which have the whole launch and share the scanners' register budget).  Called by all kHalfSeedBlock threads.
+template <int kAhead = 4>
 __device__ __forceinline__ void f32_sample_regions(const float* __restrict__ feats, int64_t n, int64_t row_base, const NextSeed& next,
                                                    int rider) {
-    constexpr int kAhead = 4;
     const int tid = threadIdx.x;
     unsigned long long* const out = static_cast<unsigned long long*>(next.out);
     Row rows[kAhead];

@@ -101,11 +101,24 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
                                static_cast<int64_t>(0), prev.topk, prev.out_keys, static_cast<int64_t*>(nullptr),
                                static_cast<float*>(nullptr), static_cast<int64_t>(0), static_cast<int64_t>(0),
                                static_cast<int64_t>(0));
+                MI355REC_KPHASE(5);
             } else if (next.nbhd && blockIdx.x == gridDim.x - 1u) {   // the next query's neighbourhood
-                nbhd_to_slot<kBlock>(feats, n, row_base, next.query_ptr, next.q, next.exclude_global, next.topk, next.epoch,
-                                     static_cast<unsigned long long*>(next.out), s_ride.scan.sel, reinterpret_cast<int*>(s_ride.scan.cand));
+                // (2048 rows, two per thread in flight at a time: the scanners of this kernel live in 80 VGPRs and four rows
+                // in flight beside their keys did not fit; this workgroup has the whole launch to itself)
+                float nq[kDim];
+                if (next.query_ptr) {
+#pragma unroll
+                    for (int j = 0; j < kDim; ++j) nq[j] = next.query_ptr[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < kDim; ++j) nq[j] = next.q[j];
+                }
+                const uint32_t v = nbhd_bound_rounds<kBlock, 2, 2>(feats, n, row_base, next.exclude_global, nq, query_norm(nq), next.topk,
+                                                                   reinterpret_cast<int*>(s_ride.scan.cand));
+                if (threadIdx.x == 0) static_cast<unsigned long long*>(next.out)[kNbhdSlot] = tag_value(next.epoch, v);
+                MI355REC_KPHASE(5);
             } else {                              // a seed rider: its share of the next query's sample
-                f32_sample_regions(feats, n, row_base, next, static_cast<int>(blockIdx.x - nblocks - 1u));
+                f32_sample_regions<2>(feats, n, row_base, next, static_cast<int>(blockIdx.x - nblocks - 1u));
                 if (next.ctl) {   // uniform: the last rider out turns the sample into the next launch's bound
                     float v;
                     if (sample_arrive_and_select<kBlock>(next.ctl, next.done_base, static_cast<unsigned>(next.n_wgs),
@@ -115,6 +128,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
                         if (threadIdx.x == 0) next.ctl->cutoff = tag_value(next.epoch, __float_as_uint(v));
                     }
                 }
+                MI355REC_KPHASE(5);
             }
             return;
         }
@@ -303,10 +317,10 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
 __global__ __launch_bounds__(kHalfSeedBlock) void seed_f32_kernel(const float* __restrict__ feats, int64_t n, int64_t row_base, NextSeed next) {
     __shared__ SelectSmem s_sel;
     __shared__ int s_flag, s_seeds;
-    __shared__ int s_bins[kSelScratch];
+    __shared__ int s_bins[Nbhd<kHalfSeedBlock>::kScratch > kSelScratch ? Nbhd<kHalfSeedBlock>::kScratch : kSelScratch];
     if (static_cast<int>(blockIdx.x) >= next.regions) {   // uniform: the neighbourhood workgroup
         nbhd_to_slot<kHalfSeedBlock>(feats, n, row_base, next.query_ptr, next.q, next.exclude_global, next.topk, next.epoch,
-                                     static_cast<unsigned long long*>(next.out), s_sel, s_bins);
+                                     static_cast<unsigned long long*>(next.out), s_bins);
         return;
     }
     f32_sample_regions(feats, n, row_base, next, static_cast<int>(blockIdx.x));
@@ -355,149 +369,6 @@ struct MultiQueryArg {
     float q[kMultiQueries][kDim];
     long long exclude[kMultiQueries];   // global row to skip per query, -1 = none
 };
-
-// Wave-level twin of block_select_threshold: the calling wave holds `c` unique
-// keys in registers (0 = empty), `hist` is 256 ints of LDS private to the wave.
-// No barriers: LDS operations of one wave execute in order.
-template <int kKeys>
-__device__ inline uint64_t wave_select_threshold(const uint64_t (&mine)[kKeys], int need, bool exact,
-                                                 int slack, int* hist) {
-    const int lane = threadIdx.x & 63;
-    uint32_t mx = 0, mn = ~0u;
-#pragma unroll
-    for (int r = 0; r < kKeys; ++r) {
-        if (mine[r]) {
-            const uint32_t hi = static_cast<uint32_t>(mine[r] >> 32);
-            mx = hi > mx ? hi : mx;
-            mn = hi < mn ? hi : mn;
-        }
-    }
-    mx = wave_max_u32(mx);
-    mn = wave_min_u32(mn);
-    const uint64_t base = static_cast<uint64_t>(mn) << 32;
-    const uint64_t span = (static_cast<uint64_t>(mx - mn) << 32) | 0xffffffffull;
-    int shift = (64 - __clzll(static_cast<long long>(span))) - 8;
-    if (shift < 0) shift = 0;
-    uint64_t prefix = 0, mask = 0;
-    const int top = 255 - 4 * lane;
-    hist[top] = 0; hist[top - 1] = 0; hist[top - 2] = 0; hist[top - 3] = 0;
-    for (;;) {
-#pragma unroll
-        for (int r = 0; r < kKeys; ++r) {
-            const uint64_t k = mine[r];
-            if (k) {
-                const uint64_t v = k - base;
-                if ((v & mask) == prefix) atomicAdd(&hist[static_cast<int>((v >> shift) & 255u)], 1);
-            }
-        }
-        const int h0 = hist[top], h1 = hist[top - 1], h2 = hist[top - 2], h3 = hist[top - 3];
-        hist[top] = 0; hist[top - 1] = 0; hist[top - 2] = 0; hist[top - 3] = 0;
-        const int lane_sum = h0 + h1 + h2 + h3;
-        int cum = wave_inclusive_scan(lane_sum) - lane_sum;
-        const int hs[4] = {h0, h1, h2, h3};
-        int digit = 0, above = 0, in_bin = 0;
-        bool found = false;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            if (cum < need && cum + hs[b] >= need) {
-                found = true;
-                digit = top - b;
-                above = cum;
-                in_bin = hs[b];
-            }
-            cum += hs[b];
-        }
-        const uint64_t who = __ballot(found);
-        const int src = __ffsll(static_cast<long long>(who)) - 1;  // exactly one lane when the precondition holds
-        digit = __builtin_amdgcn_readlane(digit, src);
-        above = __builtin_amdgcn_readlane(above, src);
-        in_bin = __builtin_amdgcn_readlane(in_bin, src);
-        prefix |= static_cast<uint64_t>(digit) << shift;
-        mask |= 255ull << shift;
-        need -= above;
-        if (shift == 0 || in_bin == need || (!exact && in_bin - need <= slack)) break;
-        shift = shift > 8 ? shift - 8 : 0;
-    }
-    return base + prefix;
-}
-
-// Wave-level compaction of one query's candidate buffer: keep the keys >= T where
-// T bounds the topk-th best.  Returns the new filter threshold (key > thr passes).
-template <int kKeys>
-__device__ inline uint64_t wave_compact(uint64_t* cand, int* count, int topk, bool exact, int* hist) {
-    const int lane = threadIdx.x & 63;
-    const int c = *count;
-    if (c <= topk) return 0ull;
-    uint64_t mine[kKeys];
-#pragma unroll
-    for (int r = 0; r < kKeys; ++r) {
-        const int i = lane + r * 64;
-        mine[r] = i < c ? cand[i] : 0ull;
-    }
-    int slack = topk / 4;
-    if (slack < 16) slack = 16;
-    const uint64_t t = wave_select_threshold<kKeys>(mine, topk, exact, slack, hist);
-    int base = 0;
-#pragma unroll
-    for (int r = 0; r < kKeys; ++r) {
-        const bool keep = mine[r] >= t;  // t >= 1, so empty slots drop out
-        const uint64_t b = __ballot(keep);
-        if (keep) cand[base + lanes_below(b)] = mine[r];
-        base += __popcll(b);
-    }
-    if (lane == 0) *count = base;
-    return t - 1ull;
-}
-
-// The same with the count kept in a (wave-uniform) REGISTER.  A count that lane 0 stores to LDS and
-// the other lanes load back right away is a data race as far as the compiler is concerned (each lane
-// is a thread: it may keep using the value it loaded before) — callers that compact between two
-// workgroup barriers can use wave_compact; a wave that compacts in the middle of its own work must
-// carry the count itself.
-template <int kKeys>
-__device__ inline uint64_t wave_compact_reg(uint64_t* cand, int& c, int topk, bool exact, int* hist) {
-    const int lane = threadIdx.x & 63;
-    if (c <= topk) return 0ull;   // uniform
-    uint64_t mine[kKeys];
-#pragma unroll
-    for (int r = 0; r < kKeys; ++r) {
-        const int i = lane + r * 64;
-        mine[r] = i < c ? cand[i] : 0ull;
-    }
-    int slack = topk / 4;
-    if (slack < 16) slack = 16;
-    const uint64_t t = wave_select_threshold<kKeys>(mine, topk, exact, slack, hist);
-    int base = 0;
-#pragma unroll
-    for (int r = 0; r < kKeys; ++r) {
-        const bool keep = mine[r] >= t;  // t >= 1, so empty slots drop out
-        const uint64_t b = __ballot(keep);
-        if (keep) cand[base + lanes_below(b)] = mine[r];
-        base += __popcll(b);
-    }
-    c = base;
-    return t - 1ull;
-}
-
-// Wave-level ranking of c <= kRankDirectMax unique keys into dst (descending, best topk).
-__device__ inline void wave_rank_and_store(const uint64_t* keys, int c, uint64_t* dst, int topk) {
-    const int lane = threadIdx.x & 63;
-    for (int i = lane; i < topk; i += 64)
-        if (i >= c) dst[i] = 0ull;
-    for (int i = lane; i < c; i += 64) {
-        const uint64_t mine = keys[i];
-        int rank = 0;
-        int j = 0;
-        for (; j + 8 <= c; j += 8) {
-            const uint64_t k0 = keys[j], k1 = keys[j + 1], k2 = keys[j + 2], k3 = keys[j + 3];
-            const uint64_t k4 = keys[j + 4], k5 = keys[j + 5], k6 = keys[j + 6], k7 = keys[j + 7];
-            rank += (k0 > mine) + (k1 > mine) + (k2 > mine) + (k3 > mine) +
-                    (k4 > mine) + (k5 > mine) + (k6 > mine) + (k7 > mine);
-        }
-        for (; j < c; ++j) rank += (keys[j] > mine);
-        if (rank < topk) dst[rank] = mine;
-    }
-}
 
 // One group of up to kMultiQueries queries against the whole shard.  `load_query(t,
 // q12, excl)` hands thread t < kQ its query (called by the first kQ threads only).

@@ -37,20 +37,35 @@ __device__ __forceinline__ uint64_t ld_key(const uint64_t* p) {
     }
 }
 
+// The exact fallback: the topk-th largest key among the `n_live` lists named in `live` (0 if they hold fewer than topk
+// keys).  Empty slots are skipped and a wave adds the keys that share its first key's digit with ONE LDS atomic: the
+// keys that end up here are close together (that is why the threshold let too many through), so in the upper byte
+// passes every lane would otherwise add to the same histogram word — 77 000 serialised atomics per pass made this a
+// 330 us affair when it first ran on a catalogue of few large clusters.
 template <int kThreads, bool kCoherent = false>
-__device__ inline uint64_t merge_global_radix_select(const uint64_t* lists,
-                                                     int64_t total, int list_len, int64_t list_stride,
-                                                     int topk, int* s_hist, int* s_pair) {
-    // returns the topk-th largest key (0 if fewer than topk non-zero keys)
+__device__ inline uint64_t merge_global_radix_select(const uint64_t* lists, const unsigned short* live, int n_live,
+                                                     int list_len, int64_t list_stride, int topk, int* s_hist, int* s_pair) {
+    const int lane = threadIdx.x & 63;
+    const int total = n_live * list_len;
     uint64_t prefix = 0, mask = 0;
     int remaining = topk;
     for (int pass = 7; pass >= 0; --pass) {
         for (int i = threadIdx.x; i < 256; i += kThreads) s_hist[i] = 0;
         __syncthreads();
         const int shift = pass * 8;
-        for (int64_t i = threadIdx.x; i < total; i += kThreads) {
-            const uint64_t k = ld_key<kCoherent>(&lists[(i / list_len) * list_stride + (i % list_len)]);
-            if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255], 1);
+        for (int i0 = 0; i0 < total; i0 += kThreads) {   // uniform trip count: every lane takes part in the ballots
+            const int i = i0 + static_cast<int>(threadIdx.x);
+            const uint64_t k = i < total ? ld_key<kCoherent>(&lists[static_cast<int64_t>(live[i / list_len]) * list_stride + (i % list_len)]) : 0ull;
+            const bool in = k != 0ull && (k & mask) == prefix;
+            const int bin = static_cast<int>((k >> shift) & 255u);
+            const uint64_t who = __ballot(in);
+            if (who) {   // wave-uniform
+                const int lead = __ffsll(static_cast<long long>(who)) - 1;
+                const int b0 = __builtin_amdgcn_readlane(bin, lead);
+                const uint64_t same = __ballot(in && bin == b0);
+                if (lane == lead) atomicAdd(&s_hist[b0], __popcll(same));
+                else if (in && bin != b0) atomicAdd(&s_hist[bin], 1);
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -229,8 +244,25 @@ __device__ __forceinline__ void merge_body(
                 if (j == first - 1) {  // the whole first chunk passed: look deeper
                     s_active[(u * kThreads + tid) / kMergeFirst] = 0;
                     s_more = 1;
+                    atomicAdd(&s_pair[1], 1);
                 }
             }
+        }
+        // THE KEYS SIT IN FEW LISTS: the same argument one level down.  When `deep_need` = ceil(topk / first) lists passed
+        // their whole first chunk, those lists hold `first` keys each at or above the smallest of their chunk-end keys — a
+        // threshold that is at least the one above (every one of those chunk ends passed it).  A catalogue of few LARGE
+        // clusters: 65 workgroups met the query's cluster and kept 30 ... 100 keys each, a hundred others one stray key;
+        // the 100th largest head was a stray, all 4 000 keys of the 65 lists "survived", overflowed the riding merger's
+        // 2048 slots and sent every third launch of a streamed fp32 scan through the exact fallback (160 us per query
+        // where the scan takes 80).  On a shuffled catalogue under a launch-wide bound few lists get this far and the
+        // second select is not run.
+        __syncthreads();
+        const int deep_need = (topk + first - 1) / first;
+        if (first > 1 && s_pair[1] >= deep_need) {   // uniform
+#pragma unroll
+            for (int u = 0; u < kFirstPer; ++u) hk[u] = (j == first - 1 && k[u] >= thr) ? k[u] : 0ull;
+            const uint64_t t2 = block_select_threshold<kThreads, kFirstPer>(hk, deep_need, false, deep_need / 8, s_sel);
+            thr = t2 > thr ? t2 : thr;
         }
         }
     } else {
@@ -299,21 +331,58 @@ __device__ __forceinline__ void merge_body(
     }
     __syncthreads();
     if (s_overflow) {
-        // exact fallback: radix-select the topk-th key over everything
-        const int64_t total = static_cast<int64_t>(n_lists) * list_len;
-        uint64_t kth = merge_global_radix_select<kThreads, kCoherent>(lists, total, list_len, list_stride, topk, s_sel.hist, s_pair);
-        if (kth == 0) kth = 1;
-        if (tid == 0) s_count = 0;
+        // Too many keys passed the threshold.  The survivor buffer is full of genuine keys, so the topk-th largest of THEM
+        // is a valid, much higher threshold: take it, and gather again in one sweep over the non-empty lists.  Only if that
+        // overflows too (mass ties: thousands of equal scores) does the exact radix select over those lists run.
+        if (tid == 0) s_pair[1] = 0;
         __syncthreads();
-        for (int64_t i0 = 0; i0 < total; i0 += kThreads) {
-            const int64_t i = i0 + tid;
-            const uint64_t k = (i < total) ? ld_key<kCoherent>(&lists[(i / list_len) * list_stride + (i % list_len)]) : 0ull;
-            if (k >= kth) {
-                const int pos = atomicAdd(&s_count, 1);  // exactly topk keys when unique
-                if (pos < kSurvCap) s_surv[pos] = k;
+        for (int l = tid; l < n_lists; l += kThreads)
+            if (ld_key<kCoherent>(&lists[static_cast<int64_t>(l) * list_stride]) != 0ull) s_active[atomicAdd(&s_pair[1], 1)] = static_cast<unsigned short>(l);
+        uint64_t retry_thr;
+        {
+            uint64_t mine[kSurvPer];
+#pragma unroll
+            for (int r = 0; r < kSurvPer; ++r) mine[r] = s_surv[tid + r * kThreads];
+            retry_thr = block_select_threshold<kThreads, kSurvPer>(mine, topk, false, topk / 8, s_sel);   // (barriers inside)
+        }
+        __syncthreads();
+        const int live = s_pair[1];
+        const int total = live * list_len;
+        if (tid == 0) {
+            s_count = 0;
+            s_overflow = 0;
+        }
+        __syncthreads();
+        for (int i0 = 0; i0 < total; i0 += kThreads) {   // uniform trip count: every lane takes part in the ballot
+            const int i = i0 + tid;
+            const uint64_t k = i < total ? ld_key<kCoherent>(&lists[static_cast<int64_t>(s_active[i / list_len]) * list_stride + (i % list_len)]) : 0ull;
+            const bool pass = k >= retry_thr;   // retry_thr >= 1
+            const uint64_t who = __ballot(pass);
+            int base = 0;
+            if ((tid & 63) == 0 && who) base = atomicAdd(&s_count, __popcll(who));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (pass) {
+                const int slot = base + lanes_below(who);
+                if (slot < kSurvCap) s_surv[slot] = k;
+                else s_overflow = 1;
             }
         }
         __syncthreads();
+        if (s_overflow) {   // uniform
+            __syncthreads();
+            uint64_t kth = merge_global_radix_select<kThreads, kCoherent>(lists, s_active, live, list_len, list_stride, topk, s_sel.hist, s_pair);
+            if (kth == 0) kth = 1;
+            if (tid == 0) s_count = 0;
+            __syncthreads();
+            for (int i = tid; i < total; i += kThreads) {
+                const uint64_t k = ld_key<kCoherent>(&lists[static_cast<int64_t>(s_active[i / list_len]) * list_stride + (i % list_len)]);
+                if (k >= kth) {
+                    const int pos = atomicAdd(&s_count, 1);  // exactly topk keys when unique
+                    if (pos < kSurvCap) s_surv[pos] = k;
+                }
+            }
+            __syncthreads();
+        }
     }
 
     MI355REC_MPHASE(2);   // deeper rounds done

@@ -265,12 +265,12 @@ __device__ __forceinline__ void hm_sample_regions(const uint4* __restrict__ half
 // launch on the stream (the pass), so plain stores do.  Called by all kHmBlock threads.
 __device__ __forceinline__ void hm_nbhd_queries(const float* __restrict__ feats, int64_t n, int64_t row_base, const HalfMultiArg& arg,
                                                 int n_queries, int first, int every, int topk, uint32_t epoch,
-                                                unsigned long long* __restrict__ seed_vals, SelectSmem& sel, int* s_bins) {
+                                                unsigned long long* __restrict__ seed_vals, int* s_scratch /* Nbhd<kHmBlock>::kScratch ints */) {
     for (int j = first; j < n_queries; j += every) {   // uniform
         if (j != first) __syncthreads();   // the select before is done with the shared memory
         float q[kDim];   // (the query first: with the rows requested ahead of it the riding variant of the pass kernel spilled)
         hm_load_query(arg, j, q);
-        const uint32_t v = nbhd_bound<kHmBlock>(feats, n, row_base, arg.exclude[j], q, query_norm(q), topk, sel, s_bins);
+        const uint32_t v = nbhd_bound<kHmBlock>(feats, n, row_base, arg.exclude[j], q, query_norm(q), topk, s_scratch);
         if (threadIdx.x == 0) seed_vals[kHmNbhdBase + j] = tag_value(epoch, v);
     }
 }
@@ -605,10 +605,9 @@ __global__ __launch_bounds__(kHmBlock) void seed_half_multi_kernel(
     __shared__ unsigned s_round;
     MI355REC_PHASE(0);
     if (static_cast<int>(blockIdx.x) >= regions) {   // uniform: a neighbourhood workgroup (they do not arrive: the PASS reads their slots)
-        __shared__ SelectSmem s_sel;
-        __shared__ int s_bins[kSelScratch];
+        __shared__ int s_scratch[Nbhd<kHmBlock>::kScratch];
         hm_nbhd_queries(feats, n, row_base, arg, n_queries, static_cast<int>(blockIdx.x) - regions, static_cast<int>(gridDim.x) - regions, topk,
-                        epoch, seed_vals, s_sel, s_bins);
+                        epoch, seed_vals, s_scratch);
         return;
     }
     float q_pre[kDim];   // the queries are requested BEFORE the rows (and looked at behind them: loads complete in order)
@@ -700,8 +699,7 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
             const int extra = static_cast<int>(bid - nblocks);
             if (extra >= ride.merge_wgs + ride.seed_wgs) {   // the next batch's neighbourhood bounds (read by the next launch)
                 hm_nbhd_queries(feats, n, row_base, next, ride.next_queries, extra - ride.merge_wgs - ride.seed_wgs, ride.nb_wgs,
-                                ride.next_topk, ride.next_epoch, ride.next_seed_vals, *reinterpret_cast<SelectSmem*>(&s_mem.scan.hist[0][0]),
-                                reinterpret_cast<int*>(&s_mem.scan.keys[0][0]));
+                                ride.next_topk, ride.next_epoch, ride.next_seed_vals, reinterpret_cast<int*>(&s_mem.scan.keys[0][0]));
             } else if (extra < ride.merge_wgs) {   // a merger: queries extra, extra + merge_wgs, ... of the previous batch, one after the other
                 for (int pq = extra; pq < ride.prev_queries; pq += ride.merge_wgs) {
                     if (pq != extra) __syncthreads();   // the merge before is done with the shared memory

@@ -225,9 +225,8 @@ __global__ __launch_bounds__(kHalfSeedBlock) void seed_q8_kernel(
     const float* __restrict__ query_ptr /* null: the query is qarg.q */, int64_t exclude_global,
     unsigned long long* __restrict__ seed_vals, uint32_t epoch, int regions, int topk) {
     if (static_cast<int>(blockIdx.x) >= regions) {   // uniform
-        __shared__ SelectSmem s_sel;
-        __shared__ int s_bins[kSelScratch];
-        nbhd_to_slot<kHalfSeedBlock>(feats, n, row_base, query_ptr, qarg.q, exclude_global, topk, epoch, seed_vals, s_sel, s_bins);
+        __shared__ int s_scratch[Nbhd<kHalfSeedBlock>::kScratch];
+        nbhd_to_slot<kHalfSeedBlock>(feats, n, row_base, query_ptr, qarg.q, exclude_global, topk, epoch, seed_vals, s_scratch);
         return;
     }
     // the region's rows are requested FIRST: they need nothing of the query, whose 12 floats sit behind two dependent
@@ -358,7 +357,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
                                static_cast<int64_t>(0));
             } else if (next.nbhd && blockIdx.x == gridDim.x - 1u) {   // the next query's neighbourhood: read by the NEXT launch
                 nbhd_to_slot<kBlock>(feats, n, row_base, next.query_ptr, next.q, next.exclude_global, next.topk, next.epoch,
-                                     static_cast<unsigned long long*>(next.out), s_mem.scan.sel, reinterpret_cast<int*>(s_mem.scan.cand));
+                                     static_cast<unsigned long long*>(next.out), reinterpret_cast<int*>(s_mem.scan.cand));
             } else {
                 const Q8Query nq = q8_seed_rider(feats, q8, n, row_base, next, static_cast<int>(blockIdx.x - nblocks - 1u));
                 // Last rider out turns the sample into the cutoff (handoff.hip.h, sample_arrive_and_select: no device-wide

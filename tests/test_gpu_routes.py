@@ -1,4 +1,4 @@
-"""Which route a call takes under AUTO, cell by cell (DESIGN.md §4.10 "AUTO route by rows, batch, topn"): every
+"""Which route a call takes under AUTO, cell by cell (DESIGN.md §6 "Routes"): every
 cell makes ONE call and asserts the route counter of mi355rec_stats_t that moved — and that no other did.
 (seven scan routes + the two-pass matrix-core path, and nothing reported which one a call took.)
 Results are checked against the oracle for one query per cell: a route that is taken must also be right."""
