@@ -72,17 +72,25 @@ typedef float bq_f16v __attribute__((ext_vector_type(16)));
 
 constexpr int kBqMaxBlocks = 32;             // 32 queries per block -> 1024 queries per chunk
 constexpr int kBqMaxQueries = kBqMaxBlocks * 32;
-// Candidate rows kept per query: a power of two near rows / 64 between these two (the host's choice, mi355rec.hip;
-// 8 MiB ... 256 MiB of row ids per 1024-query chunk).  The passes read it from counters[6] where they flush their
-// staging buffers — not a kernel argument: the pass kernel's register allocation is what it is.
+// Candidate RECORDS kept per query: a power of two near rows / 64 between these two (the host's choice, engine_batch.hip.h;
+// 16 MiB ... 512 MiB per 1024-query chunk).  A record = what ONE lane of pass 2 found for its query in one 32-row sub-tile:
+// `row_lo` (low word) and a 16-bit mask (bits 32..47), bit i = row row_lo + (i & 3) + 8 (i >> 2) — up to 16 rows per
+// appended word.  On shuffled rows a record holds one row; where a query's neighbours lie next to each other (a
+// catalogue sorted by genre: 33 000 rows of a cluster within the fp16 margin of the cutoff) it holds most of sixteen, and
+// round 4's one-atomic-per-row lists made pass 2 eight times longer there (1.75 ms against 0.2).
+// The passes read the cap from counters[6] where they flush their staging buffers — not a kernel argument: the pass
+// kernel's register allocation is what it is.
 constexpr int kBqCapMin = 2048;
 constexpr int kBqCapMax = 65536;
 constexpr int kBqSpecialCap = 1024;          // special rows kept per chunk
 constexpr int kBqNbhdRows = 1024;            // rows around a query's excluded row that give its neighbourhood bound (handoff.hip.h)
 constexpr int kBqFinalBlock = 256;           // threads of the finalize workgroup
-constexpr int kBqFinalChunk = 2048;          // candidates scored between two cuts of the finalize workgroup's key buffer
+constexpr int kBqFinalChunk = 1536;          // candidate rows scored between two cuts of the finalize workgroup's key buffer
+                                             // (with the 16 KiB of expanded rows beside it the workgroup stays under 40 KiB of LDS: four per CU)
 constexpr int kBqFinalKeys = kBqFinalChunk + 1024;   // keys that buffer holds: a chunk + what a cut may leave (<= 1024)
 constexpr int kBqFinalPerThread = kBqFinalKeys / kBqFinalBlock;
+constexpr int kBqFinalRows = kBqFinalBlock * 16;     // rows one batch of records (a record per thread) can expand to
+constexpr int kBqFinalAhead = 3;             // rows a finalize thread keeps in flight (a chunk = two rounds of three)
 constexpr int kBqPassBlock = 256;            // 4 waves, one per SIMD; 4-5 workgroups per CU
 constexpr float kBqMargin = 1.0e-3f;         // fp16 subnormals kept (verified per device by bq_selfcheck_kernel)
 constexpr float kBqMarginFlush = 1.5e-3f;    // bound if they were flushed
@@ -261,12 +269,14 @@ constexpr int kBqStage = 256;   // entries per wave (2 KiB); a block adds at mos
     } while (0)
 #endif
 
+// staged entry: x = query | mask << 16, y = row_lo
 __device__ __forceinline__ void bq_flush_stage(const uint2* stage, int staged, int lane, int* __restrict__ cand_count,
-                                               uint32_t* __restrict__ cand_rows, int cand_cap) {
+                                               uint64_t* __restrict__ cand_recs, int cand_cap) {
     for (int e = lane; e < staged; e += 64) {
         const uint2 qr = stage[e];
-        const int pos = atomicAdd(&cand_count[qr.x * kBqCountStride], 1);
-        if (pos < cand_cap) cand_rows[static_cast<int64_t>(qr.x) * cand_cap + pos] = qr.y;
+        const uint32_t q = qr.x & 0xffffu;
+        const int pos = atomicAdd(&cand_count[q * kBqCountStride], 1);
+        if (pos < cand_cap) cand_recs[static_cast<int64_t>(q) * cand_cap + pos] = (static_cast<uint64_t>(qr.x >> 16) << 32) | qr.y;
     }
 }
 
@@ -296,7 +306,7 @@ template <int NB, bool kCollect, int kVariant = 0, bool kFromReplica = false, bo
 __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu) void bq_pass_kernel(
     const float* __restrict__ feats, int64_t n, int64_t n_tiles, int tile_step, const uint32_t* __restrict__ bfrag,
     float* __restrict__ gmax /* [NB][8][2 * grid][4] */, int* __restrict__ cand_count,
-    uint32_t* __restrict__ cand_rows /* [query][counters[6]] */, int* __restrict__ counters,
+    uint64_t* __restrict__ cand_recs /* [query][counters[6]] records */, int* __restrict__ counters,
     uint32_t* __restrict__ special_rows, const uint2* __restrict__ half = nullptr,
     uint4* __restrict__ tile_max = nullptr /* [visited tile][NB / 8][64] */, int max_step = 1 /* pass 2: pass 1's tile_step */,
     const float* __restrict__ qthr = nullptr, const uint32_t* __restrict__ qflags = nullptr,
@@ -613,32 +623,27 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
             // about 160 times per pass (measured: 555 vs 485 us).
             // The rare path, and not a cheap one: measured (tools/bq_exp.sh), the blocks that hold a hit cost three times
             // what a block without one does — 27 % of a whole pass at 0.13 hits per (tile, block).  So no ballot and
-            // branch per result register: each lane first packs the SIGN bits of its 16 results into a mask (one
-            // v_alignbit each: mask = mask << 1 | sign), and only lanes with a clear bit walk it, one hit per round —
-            // the rounds are wave-uniform and there is usually exactly one.
+            // branch per result register: each lane packs the SIGN bits of its 16 results into a mask (one v_alignbit
+            // each: mask = mask << 1 | sign) and stages ONE record — (its query, the first of its 16 rows, the mask of
+            // those that hit) — whatever the number of hits.
             auto push_hits = [&](const bq_f16v& d, int blk, int sub) {
                 const uint32_t q = static_cast<uint32_t>(blk * 32 + r);
                 uint32_t signs = 0u;
 #pragma unroll
                 for (int i = 15; i >= 0; --i) signs = __builtin_amdgcn_alignbit(signs, __float_as_uint(d[i]), 31);   // bit i = sign of d[i]
-                uint32_t hits = ~signs & 0xffffu;   // D >= +0: approx >= T'
+                const uint32_t hits = ~signs & 0xffffu;   // D >= +0: approx >= T'
                 // opaque on purpose: otherwise the compiler hoists the row ids out of this rare path into the tile
                 // prologue and spills them
                 uint32_t row_lo = static_cast<uint32_t>(tile * 64) + static_cast<uint32_t>(sub * 32 + 4 * h);
                 asm volatile("" : "+v"(row_lo));
-                for (uint64_t who = __ballot(hits != 0u); who; who = __ballot(hits != 0u)) {   // wave-uniform rounds
-                    const int n_hit = __popcll(who);
-                    if (staged + n_hit > kStageCap) {
-                        bq_flush_stage(stage, staged, lane, cand_count, cand_rows, counters[6]);
-                        staged = 0;
-                    }
-                    if (hits) {
-                        const int i = __builtin_ctz(hits);
-                        hits &= hits - 1u;
-                        stage[staged + lanes_below(who)] = make_uint2(q, row_lo + static_cast<uint32_t>((i & 3) + 8 * (i >> 2)));
-                    }
-                    staged += n_hit;
+                const uint64_t who = __ballot(hits != 0u);
+                const int n_hit = __popcll(who);
+                if (staged + n_hit > kStageCap) {   // wave-uniform
+                    bq_flush_stage(stage, staged, lane, cand_count, cand_recs, counters[6]);
+                    staged = 0;
                 }
+                if (hits) stage[staged + lanes_below(who)] = make_uint2(q | (hits << 16), row_lo);
+                staged += n_hit;
             };
             // ONE hit test per query block (both 32-row sub-tiles): 16 maxima + 1 compare + 1
             // branch per two MFMAs
@@ -754,7 +759,7 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
         }
         tile = after;
     }
-    if constexpr (kCollect) bq_flush_stage(stage, staged, lane, cand_count, cand_rows, counters[6]);
+    if constexpr (kCollect) bq_flush_stage(stage, staged, lane, cand_count, cand_recs, counters[6]);
     if constexpr (kCollect && kTileMax) {
         if (lane == 0) atomicAdd(&counters[3], pairs_done);   // diagnostics: one atomic per wave and pass
     }
@@ -875,28 +880,33 @@ __global__ __launch_bounds__(kBqSelectBlock) void bq_select_kernel(
 }
 
 // ---- exact scores and top-N of the candidates ---------------------------------------
-// One workgroup per query.  Candidates = rows that passed the pre-filter + the
-// chunk's special rows (disjoint sets).  Queries that cannot be served here are
-// appended to the queue of the exact multi-query scan.
+// One workgroup per query.  Candidates = the rows named by the query's records (pass 2) + the chunk's special rows
+// (disjoint sets).  Queries that cannot be served here are appended to the queue of the exact multi-query scan.
 __global__ __launch_bounds__(kBqFinalBlock) void bq_finalize_kernel(
     const float* __restrict__ feats, int64_t row_base, const float* __restrict__ queries,
     const long long* __restrict__ exclude /* may be null */, int n_queries, int topk,
     const uint32_t* __restrict__ qflags, const int* __restrict__ cand_count,
-    const uint32_t* __restrict__ cand_rows, int cand_cap, int* __restrict__ counters,
+    const uint64_t* __restrict__ cand_recs, int cand_cap, int* __restrict__ counters,
     const uint32_t* __restrict__ special_rows, int* __restrict__ queue /* [n_queries] */,
     uint64_t* __restrict__ out_keys, int64_t* __restrict__ out_idx, float* __restrict__ out_score,
-    const uint32_t* __restrict__ nb_vals /* the neighbourhood bounds (bq_prepare_kernel), or null */) {
+    const uint32_t* __restrict__ nb_vals /* the neighbourhood bounds (bq_prepare_kernel), or null */,
+    int* __restrict__ cand_examined /* [n_queries]: rows this query's records named (diagnostics) */) {
     // Until round 4's end a query kept at most 2048 candidates, all of them in this buffer at once — and a catalogue
     // whose rows CLUSTER (3000 clusters of 3300 rows, spread 0.03: profiles/r04_clustered.jsonl) sent 986 of 1024
-    // queries to the exact queue, 43 ms per batch instead of 0.55.  Now the global list holds up to 65536 rows per query and the
-    // buffer is worked in chunks: score 2048 candidates, cut to a little over topk, go on — with the cut's threshold
-    // as a floor for what is appended later.
+    // queries to the exact queue, 43 ms per batch instead of 0.55.  Now the global list holds up to 65536 records per
+    // query and is worked in batches: a record per thread is expanded to its rows in LDS, the rows are scored
+    // kBqFinalChunk at a time — kBqFinalAhead of a thread's rows in flight: with one, 33 000 candidates of a query in a
+    // large cluster were 130 dependent round trips — then the key buffer is cut to a little over topk, with the cut's
+    // threshold as a floor for what is appended later.
     __shared__ uint64_t s_keys[kBqFinalKeys];
     __shared__ uint64_t s_top[kMultiMaxTopK];
+    __shared__ uint32_t s_rows[kBqFinalRows];
     __shared__ SelectSmem s_sel;
     __shared__ int s_n;
+    __shared__ int s_wave_rows[kBqFinalBlock / 64];
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
     const int n_cand = cand_count[q * kBqCountStride];
     const int n_special = counters[0];
     const bool served = qflags[q] == kBqFlagOk && n_cand <= cand_cap && n_special <= kBqSpecialCap;
@@ -904,6 +914,7 @@ __global__ __launch_bounds__(kBqFinalBlock) void bq_finalize_kernel(
         if (tid == 0) {
             queue[atomicAdd(&counters[1], 1)] = q;
             atomicAdd(&counters[5], 1);   // cumulative since the scratch was allocated (mi355rec_stats_t::route_exact_queue)
+            cand_examined[q] = 0;
         }
         return;
     }
@@ -914,7 +925,6 @@ __global__ __launch_bounds__(kBqFinalBlock) void bq_finalize_kernel(
     const long long excl = exclude ? exclude[q] : -1ll;
     if (tid == 0) s_n = 0;
     __syncthreads();
-    const int total = n_cand + n_special;
     uint64_t floor_key = 0;   // uniform: keys at or below it cannot be among the best topk any more
     if (nb_vals) {            // (at least topk rows score >= the neighbourhood's exact bound: a key AT it stays)
         const uint32_t nbv = nb_vals[q];
@@ -942,23 +952,64 @@ __global__ __launch_bounds__(kBqFinalBlock) void bq_finalize_kernel(
         c = s_n;
         if (t > floor_key + 1) floor_key = t - 1;   // (at least topk keys >= t are kept)
     };
-    for (int base = 0; base < total; base += kBqFinalChunk) {   // uniform
-        const int end = base + kBqFinalChunk < total ? base + kBqFinalChunk : total;
-        for (int i = base + tid; i < end; i += kBqFinalBlock) {
-            const uint32_t row = i < n_cand ? cand_rows[static_cast<int64_t>(q) * cand_cap + i] : special_rows[i - n_cand];
-            const Row rr = load_row(feats, static_cast<int64_t>(row));
-            const float s = cosine_score(qv, qn, rr);
-            const int64_t g = row_base + row;
-            const uint64_t key = pack_key(s, static_cast<uint32_t>(g));
-            if (g != excl && key > floor_key) s_keys[atomicAdd(&s_n, 1)] = key;
+    // the rows [0, m) of `rows` (LDS or global), kBqFinalChunk between two cuts
+    auto score_rows = [&](const uint32_t* rows, int m) {
+        for (int base = 0; base < m; base += kBqFinalChunk) {   // uniform
+            const int end = base + kBqFinalChunk < m ? base + kBqFinalChunk : m;
+            for (int i0 = base + tid; i0 < end; i0 += kBqFinalBlock * kBqFinalAhead) {
+                uint32_t row[kBqFinalAhead];
+                Row rr[kBqFinalAhead];
+#pragma unroll
+                for (int u = 0; u < kBqFinalAhead; ++u) {
+                    const int i = i0 + u * kBqFinalBlock;
+                    row[u] = rows[i < end ? i : base];   // (a valid row: the load below is unconditional)
+                    rr[u] = load_row(feats, static_cast<int64_t>(row[u]));
+                }
+#pragma unroll
+                for (int u = 0; u < kBqFinalAhead; ++u) {
+                    const float s = cosine_score(qv, qn, rr[u]);
+                    const int64_t g = row_base + row[u];
+                    const uint64_t key = pack_key(s, static_cast<uint32_t>(g));
+                    if (i0 + u * kBqFinalBlock < end && g != excl && key > floor_key) s_keys[atomicAdd(&s_n, 1)] = key;
+                }
+            }
+            __syncthreads();
+            c = s_n;
+            __syncthreads();   // (everybody has read the count before a cut resets it)
+            // a cut leaves at most max(topk, kRankDirectMax) keys (ties cannot inflate it: keys are unique), so the next
+            // chunk always fits; what the last one leaves is what the ranking below can take
+            if (c > topk && c > kRankDirectMax) cut();
+        }
+    };
+    int examined = 0;
+    uint64_t rec_next = tid < n_cand ? cand_recs[static_cast<int64_t>(q) * cand_cap + tid] : 0ull;
+    for (int rbase = 0; rbase < n_cand; rbase += kBqFinalBlock) {   // uniform: a record per thread, the next batch's requested
+        const uint64_t rec = rec_next;
+        rec_next = rbase + kBqFinalBlock + tid < n_cand ? cand_recs[static_cast<int64_t>(q) * cand_cap + rbase + kBqFinalBlock + tid] : 0ull;
+        uint32_t mask = static_cast<uint32_t>(rec >> 32) & 0xffffu;
+        const uint32_t row_lo = static_cast<uint32_t>(rec);
+        const int mine = __popc(mask);
+        const int incl = wave_inclusive_scan(mine);
+        if (lane == 63) s_wave_rows[tid >> 6] = incl;
+        __syncthreads();
+        int at = incl - mine, m = 0;
+#pragma unroll
+        for (int w = 0; w < kBqFinalBlock / 64; ++w) {
+            const int t = s_wave_rows[w];
+            at += w < (tid >> 6) ? t : 0;
+            m += t;
+        }
+        while (mask) {
+            const int i = __builtin_ctz(mask);
+            mask &= mask - 1u;
+            s_rows[at++] = row_lo + static_cast<uint32_t>((i & 3) + 8 * (i >> 2));
         }
         __syncthreads();
-        c = s_n;
-        __syncthreads();   // (everybody has read the count before a cut resets it)
-        // a cut leaves at most max(topk, kRankDirectMax) keys (ties cannot inflate it: keys are unique), so the next chunk
-        // always fits; what the last one leaves is what the ranking below can take
-        if (c > topk && c > kRankDirectMax) cut();
+        examined += m;
+        score_rows(s_rows, m);   // (ends with a barrier: s_rows and s_wave_rows are free again)
     }
+    score_rows(special_rows, n_special);
+    if (tid == 0) cand_examined[q] = examined;
     block_rank_and_store<kBqFinalBlock>(s_keys, c, s_top, topk);
     __syncthreads();
     for (int i = tid; i < topk; i += kBqFinalBlock) {

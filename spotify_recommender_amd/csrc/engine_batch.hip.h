@@ -402,7 +402,9 @@ int ensure_bq_alloc(mi355rec* h) {
     // rows that cluster a whole cluster's worth (profiles/r04_clustered.jsonl); past it the query goes to the exact queue.
     b.cand_cap = kBqCapMin;
     while (b.cand_cap < kBqCapMax && static_cast<int64_t>(b.cand_cap) * 64 < h->n) b.cand_cap *= 2;
-    HIP_TRY(h, hipMalloc(&b.cand_rows, sizeof(uint32_t) * static_cast<size_t>(kBqMaxQueries) * b.cand_cap));
+    HIP_TRY(h, hipMalloc(&b.cand_rows, sizeof(uint64_t) * static_cast<size_t>(kBqMaxQueries) * b.cand_cap));
+    HIP_TRY(h, hipMalloc(&b.cand_examined, sizeof(int) * kBqMaxQueries));
+    HIP_TRY(h, hipMemsetAsync(b.cand_examined, 0, sizeof(int) * kBqMaxQueries, h->stream));
     HIP_TRY(h, hipMalloc(&b.counters, sizeof(int) * 8));   // [0..3]: batched.hip.h; [4]: the queued scan's arrival counter; [6]: cand_cap
     HIP_TRY(h, hipMemsetAsync(b.counters, 0, sizeof(int) * 8, h->stream));
     HIP_TRY(h, hipMemcpyAsync(b.counters + 6, &b.cand_cap, sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -446,7 +448,7 @@ int ensure_bq_alloc(mi355rec* h) {
 
 void free_bq(mi355rec* h) {
     auto& b = h->bq;
-    void* dev[] = {b.bfrag, b.qnorm, b.qthr, b.qflags, b.cand_count, b.cand_rows, b.counters, b.special_rows, b.nb_vals,
+    void* dev[] = {b.bfrag, b.qnorm, b.qthr, b.qflags, b.cand_count, b.cand_rows, b.cand_examined, b.counters, b.special_rows, b.nb_vals,
                    b.gmax, b.queue, b.qlists, b.d_queries, b.d_exclude, b.tile_max};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -539,7 +541,8 @@ int enqueue_bq_chunk(mi355rec* h, const float* d_queries, const long long* d_exc
     hipLaunchKernelGGL(bq_finalize_kernel, dim3(count), dim3(kBqFinalBlock), 0, s, h->d_feats, h->row_base, d_queries,
                        d_exclude, count, topn, b.qflags, b.cand_count, b.cand_rows, b.cand_cap, b.counters, b.special_rows, b.queue,
                        out_keys, out_idx, out_score,
-                       (d_exclude != nullptr && h->n >= kNbhdRows) ? static_cast<const uint32_t*>(b.nb_vals) : static_cast<const uint32_t*>(nullptr));
+                       (d_exclude != nullptr && h->n >= kNbhdRows) ? static_cast<const uint32_t*>(b.nb_vals) : static_cast<const uint32_t*>(nullptr),
+                       b.cand_examined);
     // The exact multi-query scan for whatever the bound could not be claimed for, its merge included (usually
     // nothing: the launch exits at once on an empty queue).
     hipLaunchKernelGGL((scan_multi_queued_kernel<MultiConfig>), dim3(b.qgrid), dim3(MultiConfig::kBlock), 0, s,

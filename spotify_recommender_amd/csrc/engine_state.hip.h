@@ -224,8 +224,9 @@ struct mi355rec {
         float* qthr = nullptr;
         uint32_t* qflags = nullptr;
         int* cand_count = nullptr;
-        uint32_t* cand_rows = nullptr;   // [1024][cand_cap]
-        int cand_cap = 0;                // candidate rows kept per query, also in counters[6] for the passes
+        uint64_t* cand_rows = nullptr;   // [1024][cand_cap] candidate records (batched.hip.h: up to 16 rows each)
+        int* cand_examined = nullptr;    // [1024] rows the finalize expanded each query's records to (diagnostics)
+        int cand_cap = 0;                // candidate records kept per query, also in counters[6] for the passes
         int* counters = nullptr;         // [4]
         uint32_t* special_rows = nullptr;
         uint32_t* nb_vals = nullptr;     // [1024] the queries' neighbourhood bounds (bq_prepare_kernel), ordered-u32, 0 = none

@@ -400,8 +400,7 @@ int mi355rec_batched_last_counters(mi355rec_t* h, int32_t* special_rows, int32_t
     std::vector<int> cand(kBqMaxQueries);
     std::vector<uint32_t> flags(kBqMaxQueries);
     HIP_TRY(h, hipMemcpy(counters, h->bq.counters, sizeof counters, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy2D(cand.data(), sizeof(int), h->bq.cand_count, sizeof(int) * kBqCountStride, sizeof(int),
-                           kBqMaxQueries, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(cand.data(), h->bq.cand_examined, sizeof(int) * kBqMaxQueries, hipMemcpyDeviceToHost));   // rows, not records
     HIP_TRY(h, hipMemcpy(flags.data(), h->bq.qflags, sizeof(uint32_t) * kBqMaxQueries, hipMemcpyDeviceToHost));
     int64_t total = 0;
     int mx = 0;
