@@ -39,6 +39,7 @@
 #ifndef MI355REC_H
 #define MI355REC_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -195,6 +196,10 @@ void mi355rec_destroy(mi355rec_t* h);
 const char* mi355rec_last_error(const mi355rec_t* h);
 
 int mi355rec_stats(const mi355rec_t* h, mi355rec_stats_t* out);
+/* The same for a caller that may have been built against an EARLIER header: mi355rec_stats_t only ever grows at its end, and
+ * this copies min(out_size, sizeof(mi355rec_stats_t)) bytes — a shorter struct gets the fields it knows, never an overrun.
+ * Pass sizeof(mi355rec_stats_t) of the header you compiled with.  *written (may be NULL) = the bytes copied. */
+int mi355rec_stats_sized(const mi355rec_t* h, void* out, size_t out_size, size_t* written);
 
 /* ---- synchronous host API (what the C++ Recommender shim calls) ---------- */
 

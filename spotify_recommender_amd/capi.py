@@ -7,11 +7,14 @@ fallback for the hot path.
 from __future__ import annotations
 
 import ctypes
+import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "libmi355rec.so"
+# MI355REC_LIB: another build of the same C-ABI (tests/test_gpu_experiments.py runs the A/B routes of the MI355REC_EXPERIMENTS
+# build this way, in a child process; the product never sets it)
+LIB_PATH = Path(os.environ["MI355REC_LIB"]) if os.environ.get("MI355REC_LIB") else PKG / "libmi355rec.so"
 
 DIM = 12
 MAX_TOPN_FAST = 1024
@@ -79,6 +82,7 @@ SIGNATURES = {
     "mi355rec_destroy": (None, [c_void_p]),
     "mi355rec_last_error": (c_char_p, [c_void_p]),
     "mi355rec_stats": (c_int, [c_void_p, POINTER(Stats)]),
+    "mi355rec_stats_sized": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, POINTER(ctypes.c_size_t)]),
     "mi355rec_scores_row": (c_int, [c_void_p, c_int64, c_void_p]),
     "mi355rec_scores": (c_int, [c_void_p, c_void_p, c_void_p]),
     "mi355rec_query_row_topn": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, POINTER(c_int)]),
@@ -166,7 +170,6 @@ def lib() -> ctypes.CDLL:
         except Exception:  # pragma: no cover
             pass
         handle = ctypes.CDLL(str(LIB_PATH))
-        import os
         lenient = os.environ.get("MI355REC_CAPI_LENIENT") == "1"   # tools only: A/B against a library of an EARLIER round (--lib)
         for name, (restype, argtypes) in SIGNATURES.items():
             try:

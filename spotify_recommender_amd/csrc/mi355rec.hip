@@ -167,6 +167,18 @@ int mi355rec_stats(const mi355rec_t* hc, mi355rec_stats_t* out) {
     return MI355REC_OK;
 }
 
+int mi355rec_stats_sized(const mi355rec_t* h, void* out, size_t out_size, size_t* written) {
+    if (!out || out_size == 0) return fail(const_cast<mi355rec_t*>(h), MI355REC_ERR_INVALID_ARG, "null argument");
+    mi355rec_stats_t full;
+    std::memset(&full, 0, sizeof full);
+    const int rc = mi355rec_stats(h, &full);
+    if (rc) return rc;
+    const size_t n = out_size < sizeof full ? out_size : sizeof full;
+    std::memcpy(out, &full, n);
+    if (written) *written = n;
+    return MI355REC_OK;
+}
+
 // ---- asynchronous device API -------------------------------------------------
 
 int mi355rec_enqueue_row_keys(mi355rec_t* h, int64_t local_row, int topn,

@@ -144,3 +144,23 @@ def test_forced_routes_and_the_exact_queue(catalogues):
         assert eng.stats().route_exact_queue == 2
         for b in (3, 17, 20):
             assert_topn_matches(bi[b][:counts[b]], bs[b][:counts[b]], oracle.scores(f, q[b], threads=0), -1, 10)
+
+
+def test_stats_for_a_caller_built_against_a_shorter_struct(catalogues):
+    """mi355rec_stats_sized copies no more than the caller's struct holds (mi355rec_stats_t grew without a size
+    field): the first 64 bytes equal those of the full struct, the bytes behind them stay untouched."""
+    import ctypes
+    from spotify_recommender_amd import capi
+    from spotify_recommender_amd.engine import CosineEngine
+    with CosineEngine(catalogues[30_000]) as eng:
+        eng.query_row_topn(5, 10)
+        full = eng.stats()
+        size = ctypes.sizeof(full)
+        buf = (ctypes.c_ubyte * (size + 64))(*([0xAB] * (size + 64)))
+        wrote = ctypes.c_size_t(0)
+        capi.check(capi.lib().mi355rec_stats_sized(eng._h, buf, 64, ctypes.byref(wrote)), eng._h)
+        assert wrote.value == 64
+        assert bytes(buf[:64]) == bytes(full)[:64] and set(buf[64:]) == {0xAB}
+        capi.check(capi.lib().mi355rec_stats_sized(eng._h, buf, size + 64, ctypes.byref(wrote)), eng._h)
+        assert wrote.value == size and set(buf[size:]) == {0xAB}
+        assert capi.lib().mi355rec_stats_sized(eng._h, None, 64, None) == capi.ERR_INVALID_ARG
