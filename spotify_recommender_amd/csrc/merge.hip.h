@@ -101,6 +101,8 @@ struct MergeSmemT {
     int count;
     int overflow;
     int more;
+    int deeper;   // lists whose whole first chunk passed the threshold (they are walked)
+    int n_active; // non-empty lists compacted into `active` (the one-phase path over few lists)
     unsigned short active[kMaxLists];
 };
 
@@ -135,6 +137,8 @@ __device__ __forceinline__ void merge_body(
         s_pair[0] = 0;
         s_pair[1] = 0;
         s_more = 0;
+        sm.deeper = 0;
+        sm.n_active = 0;
     }
     __syncthreads();
     int probe = 1;
@@ -144,6 +148,7 @@ __device__ __forceinline__ void merge_body(
     int slack = need_lists / 8;
     uint64_t thr = 1;  // accept every non-empty key
     int first = 0;     // keys [0, first) of every list are already dealt with
+    bool synced = false;   // uniform: the branch below has already put a barrier behind its survivors
 
     const int64_t total_keys = static_cast<int64_t>(n_lists) * list_len;
     if (total_keys <= kSurvCap) {
@@ -204,16 +209,13 @@ __device__ __forceinline__ void merge_body(
         const bool sparse = nonempty < need_lists && full_chunks > 0 && static_cast<int64_t>(nonempty) * list_len <= kSurvCap;   // uniform
         if (nonempty >= need_lists)  // uniform
             thr = block_select_threshold<kThreads, kFirstPer>(hk, need_lists, false, slack, s_sel);
-        __syncthreads();   // (everybody has read the two counts)
-        if (tid == 0) s_pair[1] = 0;
-        __syncthreads();
         if (sparse) {   // uniform
 #pragma unroll
             for (int u = 0; u < kFirstPer; ++u)
-                if (hk[u]) s_active[atomicAdd(&s_pair[1], 1)] = static_cast<unsigned short>((u * kThreads + tid) / kMergeFirst);
+                if (hk[u]) s_active[atomicAdd(&sm.n_active, 1)] = static_cast<unsigned short>((u * kThreads + tid) / kMergeFirst);
             __syncthreads();
             first = list_len;   // every key is taken here: no deeper rounds (s_more stays 0)
-            const int total = s_pair[1] * list_len;   // <= kSurvCap
+            const int total = sm.n_active * list_len;   // <= kSurvCap
             // all loads are requested before the first is looked at: ONE memory round trip, not one per kThreads keys
             uint64_t kk[kSurvPer];
 #pragma unroll
@@ -244,7 +246,7 @@ __device__ __forceinline__ void merge_body(
                 if (j == first - 1) {  // the whole first chunk passed: look deeper
                     s_active[(u * kThreads + tid) / kMergeFirst] = 0;
                     s_more = 1;
-                    atomicAdd(&s_pair[1], 1);
+                    atomicAdd(&sm.deeper, 1);
                 }
             }
         }
@@ -257,8 +259,9 @@ __device__ __forceinline__ void merge_body(
         // where the scan takes 80).  On a shuffled catalogue under a launch-wide bound few lists get this far and the
         // second select is not run.
         __syncthreads();
+        synced = true;
         const int deep_need = (topk + first - 1) / first;
-        if (first > 1 && s_pair[1] >= deep_need) {   // uniform
+        if (first > 1 && sm.deeper >= deep_need) {   // uniform
 #pragma unroll
             for (int u = 0; u < kFirstPer; ++u) hk[u] = (j == first - 1 && k[u] >= thr) ? k[u] : 0ull;
             const uint64_t t2 = block_select_threshold<kThreads, kFirstPer>(hk, deep_need, false, deep_need / 8, s_sel);
@@ -283,7 +286,7 @@ __device__ __forceinline__ void merge_body(
         if (s_pair[0] >= need_lists)  // uniform; the select needs >= need_lists non-empty probes
             thr = block_select_threshold<kThreads, kHeadsPer>(heads, need_lists, false, slack, s_sel);
     }
-    __syncthreads();
+    if (!synced) __syncthreads();   // uniform
     MI355REC_MPHASE(1);   // first chunk loaded, threshold selected, survivors appended
 
     // Deeper rounds: round d looks at keys [first + d*C, first + (d+1)*C) of every

@@ -225,8 +225,10 @@ __global__ __launch_bounds__(kHalfSeedBlock) void seed_q8_kernel(
     const float* __restrict__ query_ptr /* null: the query is qarg.q */, int64_t exclude_global,
     unsigned long long* __restrict__ seed_vals, uint32_t epoch, int regions, int topk) {
     if (static_cast<int>(blockIdx.x) >= regions) {   // uniform
-        __shared__ int s_scratch[Nbhd<kHalfSeedBlock>::kScratch];
-        nbhd_to_slot<kHalfSeedBlock>(feats, n, row_base, query_ptr, qarg.q, exclude_global, topk, epoch, seed_vals, s_scratch);
+        // (1024 rows: this workgroup is the last one out of the sample launch of a query alone, and the scan subtracts a margin
+        // of ~0.01 from whatever bound it is given — the 10th percentile of the neighbourhood serves it as well as the 5th)
+        __shared__ int s_scratch[Nbhd<kHalfSeedBlock, 1024>::kScratch];
+        nbhd_to_slot<kHalfSeedBlock, 1024>(feats, n, row_base, query_ptr, qarg.q, exclude_global, topk, epoch, seed_vals, s_scratch);
         return;
     }
     // the region's rows are requested FIRST: they need nothing of the query, whose 12 floats sit behind two dependent
