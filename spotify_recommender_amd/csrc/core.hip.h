@@ -39,7 +39,7 @@ constexpr int kProbeBlock = 512;      // stream_probe_kernel
 constexpr int kMergeBlock = 1024;
 constexpr int kMergeMaxLists = 2048;
 constexpr int kMergeSurvCap = 4096;
-constexpr int kMergeChunk = 16;       // keys probed per list per deeper merge round
+constexpr int kMergeChunk = 16;       // keys probed per list in the FIRST deeper merge round (then 32, 64, 128: merge.hip.h)
 constexpr int kMergeFirst = 4;        // keys of every list loaded up front (many-lists case)
 constexpr int kMergeFirstPerThread = 8;  // covers kMergeMaxLists * kMergeFirst keys
 constexpr int kMergeSurvPerThread = kMergeSurvCap / kMergeBlock;

@@ -177,7 +177,8 @@ int enqueue_half_multi(mi355rec* h, const float* queries, const float* const* qp
 constexpr int kHmRiders = 16;       // seed riders per 1024 rows of a sampled region: a rider's wave gets through a 128-row
                                     // chunk every ~2 us beside a pass (as a scanner's does), 16 (or 32) of them take 33 us
 constexpr int kHmMergesPerWg = 3;   // queries of the previous batch one merging workgroup takes, one after the other (~10 us each)
-constexpr int kHmNbhdPerWg = 4;     // queries of the next batch one neighbourhood workgroup takes, one after the other (~4 us each)
+constexpr int kHmNbhdPerWg = 4;     // queries of the next batch one neighbourhood workgroup takes, one after the other (~7 us each beside a
+                                    // pass; with 8 the workgroup outlasted it: a 32-query launch 51.4 -> 58.7 us)
 
 int ensure_mstream(mi355rec* h) {
     if (h->mstream_ready) return MI355REC_OK;

@@ -289,25 +289,33 @@ __device__ __forceinline__ void merge_body(
     if (!synced) __syncthreads();   // uniform
     MI355REC_MPHASE(1);   // first chunk loaded, threshold selected, survivors appended
 
-    // Deeper rounds: round d looks at keys [first + d*C, first + (d+1)*C) of every
-    // list that is still active (its previous chunk passed entirely); the loads
-    // of a round are independent and issued before any of them is consumed.
+    // Deeper rounds: round d looks at the next chunk of every list that is still active (its previous chunk passed
+    // entirely); chunks grow (16, 32, 64, 128 keys: a list that is still there after two rounds is a long one), the loads of
+    // a round are independent and issued before any of them is consumed, and the thread that holds a chunk's LAST key is the
+    // one that keeps its list active — no second, dependent look at the list per round.  (Until round 5: 16 keys per round and
+    // a re-load of every active list's last key, two dependent round trips per 16 keys: 65 lists of 30 ... 100 keys — a
+    // catalogue of few large clusters — took 12 us to walk.)
     // With the first-chunk phase above this loop usually does not run at all.
-    for (int round = 0; first + round * kMergeChunk < list_len && !s_overflow; ++round) {
+    int start = first;
+    for (int round = 0; start < list_len && !s_overflow; ++round) {
         // s_more was raised by whoever marked a list active for this round
         if (!s_more) break;  // uniform: read after a barrier, rewritten only after the next one
         __syncthreads();
         if (tid == 0) s_more = 0;
         __syncthreads();
-        const int total = n_lists * kMergeChunk;
-        for (int t0 = 0; t0 < total; t0 += kThreads * 8) {
+        const int log_chunk = 4 + (round < 3 ? round : 3);
+        const int chunk = 1 << log_chunk;   // (kMergeChunk = 16 is the first)
+        const int total = n_lists << log_chunk;
+        for (int t0 = 0; t0 < total; t0 += kThreads * 8) {   // (a list's chunk never straddles two iterations: chunk divides kThreads * 8)
             uint64_t k[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int t = t0 + u * kThreads + tid;
-                const int l = t / kMergeChunk;
-                const int pos = first + round * kMergeChunk + (t % kMergeChunk);
-                const bool live = t < total && pos < list_len && s_active[l] == round;
+                const int l = t >> log_chunk;
+                const int pos = start + (t & (chunk - 1));
+                // (== round + 1: the holder of this chunk's last key, in another wave, has already promoted the list)
+                const unsigned a = t < total ? s_active[l] : 0xffffu;
+                const bool live = pos < list_len && (a == static_cast<unsigned>(round) || a == static_cast<unsigned>(round) + 1u);
                 k[u] = live ? ld_key<kCoherent>(&lists[static_cast<int64_t>(l) * list_stride + pos]) : 0ull;
             }
 #pragma unroll
@@ -316,21 +324,16 @@ __device__ __forceinline__ void merge_body(
                     const int slot = atomicAdd(&s_count, 1);
                     if (slot < kSurvCap) s_surv[slot] = k[u];
                     else s_overflow = 1;
+                    const int t = t0 + u * kThreads + tid;
+                    if ((t & (chunk - 1)) == chunk - 1 && start + chunk < list_len) {   // the chunk's last key passed and the list goes on
+                        s_active[t >> log_chunk] = static_cast<unsigned short>(round + 1);
+                        s_more = 1;
+                    }
                 }
             }
         }
         __syncthreads();
-        // a list stays active iff the LAST key of this chunk passed
-        for (int l = tid; l < n_lists; l += kThreads) {
-            if (s_active[l] == round) {
-                const int last = first + (round + 1) * kMergeChunk - 1;
-                if (last < list_len && ld_key<kCoherent>(&lists[static_cast<int64_t>(l) * list_stride + last]) >= thr) {
-                    s_active[l] = static_cast<unsigned short>(round + 1);
-                    s_more = 1;
-                }
-            }
-        }
-        __syncthreads();
+        start += chunk;
     }
     __syncthreads();
     if (s_overflow) {
@@ -391,7 +394,9 @@ __device__ __forceinline__ void merge_body(
     MI355REC_MPHASE(2);   // deeper rounds done
     int c = s_count < kSurvCap ? s_count : kSurvCap;
     __syncthreads();
-    if (c > topk && c > kRankDirectMax) {  // uniform: too many to rank, cut to exactly topk in O(c)
+    // (from kRankCountMax keys up the ranking below is a bitonic sort — 45 barrier stages for 512 slots, 8 us in this
+    // 1024-thread workgroup: a survivor set of 300 keys, which a catalogue of few large clusters leaves, is cut first)
+    if (c > topk && c > kRankCountMax) {  // uniform: too many to rank by counting, cut to a little over topk in O(c)
         uint64_t mine[kSurvPer];
 #pragma unroll
         for (int r = 0; r < kSurvPer; ++r) {
