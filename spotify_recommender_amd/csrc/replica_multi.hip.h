@@ -748,7 +748,11 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
     // catalogue sorted by genre: thirteen steps of 256 rows for a 3300-row cluster, every row a candidate) is spread over
     // as many workgroups, one wave each, instead of queueing on ONE workgroup's per-query lock (measured at 10 M rows, 3000
     // contiguous clusters, 12 queries: 82 us per pass with consecutive steps on consecutive waves).
+#if MI355_HM_EXP == 5   // EXPERIMENT (right results): round 4's mapping — the eight waves of a workgroup take eight consecutive steps
+    int64_t step = static_cast<int64_t>(bid) * kHmWaves + wave;
+#else
     int64_t step = static_cast<int64_t>(wave) * nblocks + bid;
+#endif
     auto load_chunk = [&](HalfTile& dst, int64_t st, int u) {
         int64_t pair = (st * kHmChunks + u) * 64 + lane;
         pair = pair < n_pairs ? pair : last_pair;   // unconditional prefetch (see scan_kernel)
