@@ -75,6 +75,12 @@ def parse_args():
                          "spotify_recommender_amd/synth.py) covers 3000 and 300 contiguous clusters with and without the genre "
                          "ramp instead of the one shape the default run carries")
     ap.add_argument("--no-clustered", action="store_true", help="skip the `clustered` object")
+    ap.add_argument("--lanes", type=int, default=0,
+                    help="lanes of the handle the timed stream of single queries is dealt over (mi355rec_create_lane: the same rows and "
+                         "replicas, own stream state, own HIP stream; 0 = 2 for the single-process stream, 1 = one handle as until round 4)")
+    ap.add_argument("--no-single-lane", action="store_true",
+                    help="skip the `single_lane` leg (the same stream through ONE handle): for profiling runs whose kernel averages must be "
+                         "those of the timed region alone")
     ap.add_argument("--no-config0", action="store_true",
                     help="skip the `config0` object (BASELINE configs[0]: a 114 000-track CSV -> songs_data.bin -> top-10 on the GPU "
                          "path and on the product's CPU backend)")
@@ -181,6 +187,30 @@ def probe_gbps_of(eng, torch, which, n_bytes, dev):
     ms = float(eng.stats().last_scan_ms)
     eng.set_timing(False)
     return n_bytes / (ms * 1e-3) / 1e9 if ms > 0 else None
+
+
+def probe_concurrent_gbps(lanes, lane_streams, torch, which, n_bytes, dev):
+    """The same plain read-only stream from EVERY lane at once, each on its own HIP stream, over the one buffer they share: the
+    aggregate rate = lanes x bytes / the mean duration of a probe launch while the others' are in flight (lane 0's events) —
+    the ceiling of a kernel whose launches overlap the same way.  None when the handle has no such buffer."""
+    from spotify_recommender_amd import capi
+    sinks = [torch.zeros(4096, dtype=torch.int32, device=dev) for _ in lanes]
+    torch.cuda.synchronize()
+    try:
+        for _ in range(3):
+            for ln, ls, sk in zip(lanes, lane_streams, sinks):
+                ln.enqueue_stream_probe(sk, stream=ls, which=which)
+    except capi.Mi355Error:
+        return None
+    torch.cuda.synchronize()
+    lanes[0].set_timing(True)
+    for _ in range(20):
+        for ln, ls, sk in zip(lanes, lane_streams, sinks):
+            ln.enqueue_stream_probe(sk, stream=ls, which=which)
+    torch.cuda.synchronize()
+    ms = float(lanes[0].stats().last_scan_ms)
+    lanes[0].set_timing(False)
+    return len(lanes) * n_bytes / (ms * 1e-3) / 1e9 if ms > 0 else None
 
 
 def stream_leg(eng, torch, rows, topn, steps, warmup):
@@ -890,12 +920,29 @@ def main():
     # k + 1 (mi355rec_enqueue_row_keys_streamed), the last one is flushed INSIDE the timed
     # region; every step is still one full pass over the catalogue for one query.
     streamed = sharded is None and not args.no_streamed and topn <= 1024
-    ring = [torch.zeros(topn, dtype=torch.int64, device=dev) for _ in range(4)]
+    # LANES: a handle is one chain of launches (query k + 1's launch needs query k's lists and sample), so its launches never
+    # overlap and the chip idles while one drains and the next ramps up; lanes (mi355rec_create_lane) are further handles
+    # over the same rows and replicas, each on its own HIP stream, and the stream of queries is dealt over them in turn.
+    n_lanes = args.lanes if args.lanes > 0 else (2 if (streamed and world == 1) else 1)
+    if not streamed:
+        n_lanes = 1
+    lanes = [eng] + [eng.lane() for _ in range(n_lanes - 1)]
+    if n_lanes > 1 and args.no_replica:
+        for ln in lanes[1:]:
+            ln.set_replica(capi.REPLICA_OFF)
+    # (each lane on the stream the library created with it: those sit on different hardware queues — two streams from torch's
+    # pool, created after the handles, landed on ONE queue and the lanes ran at a single handle's rate)
+    lane_streams = [ln.own_stream() for ln in lanes] if n_lanes > 1 else [None]
+    rings = [[torch.zeros(topn, dtype=torch.int64, device=dev) for _ in range(4)] for _ in lanes]
+    torch.cuda.synchronize()
+
+    def ring_of(k):
+        return rings[k % n_lanes][(k // n_lanes) % 4]
 
     def step(k):
         if sharded is None:
             if streamed:
-                eng.enqueue_row_keys_streamed(q_rows[k], topn, ring[k % 4])
+                lanes[k % n_lanes].enqueue_row_keys_streamed(q_rows[k], topn, ring_of(k), stream=lane_streams[k % n_lanes])
             else:
                 eng.enqueue_row_keys(q_rows[k], topn, out_keys)
         else:
@@ -905,7 +952,8 @@ def main():
 
     def flush():
         if streamed:
-            eng.enqueue_flush()
+            for ln, ls in zip(lanes, lane_streams):
+                ln.enqueue_flush(stream=ls)
         if sharded is not None:
             sharded.flush_window()
 
@@ -919,7 +967,11 @@ def main():
         step(k)
     flush()
     fence()
-    rc_before = eng.replica_counters() if replica else None
+    def lane_counters():
+        cs = [ln.replica_counters() for ln in lanes]
+        return {k: sum(c[k] for c in cs) for k in cs[0]}
+
+    rc_before = lane_counters() if replica else None
     # a timed launch costs ~6 us of stream time (start / stop signals around the dispatch): 16 timed launches
     # in a long run (every 19th of the default 300), 3 in a short one (the driver's 20-step run: every 7th)
     stride = args.event_stride if args.event_stride > 0 else max(1, -(-args.steps // (16 if args.steps >= 64 else 3)))
@@ -934,9 +986,13 @@ def main():
     fence()
     st = eng.stats()  # averages the HIP events recorded inside the timed region
     eng.set_timing(False)
-    rc_after = eng.replica_counters() if replica else None
+    rc_after = lane_counters() if replica else None
     # what the timed stream itself produced for its last two queries (checked against the oracle below)
-    timed_tail = [(q_rows[k], ring[k % 4].clone()) for k in (total_q - 2, total_q - 1)] if streamed and args.steps >= 2 else []
+    timed_tail = [(q_rows[k], ring_of(k).clone()) for k in (total_q - 2, total_q - 1)] if streamed and args.steps >= 2 else []
+    # the same stream through ONE handle (what `value` was until round 4): a launch that has the chip to itself
+    single_lane = None
+    if n_lanes > 1 and not args.no_single_lane and rank == 0:
+        single_lane, _ = stream_leg(eng, torch, q_rows, topn, min(args.steps, 300), min(max(args.warmup, 4), 20))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -968,7 +1024,8 @@ def main():
     # same process, and a complete headline of its own for a reader who prices a query at 48 B/row.
     fp32_rows = None
     if replica and sharded is None and streamed:
-        eng.set_replica(capi.REPLICA_OFF)
+        for ln in lanes:
+            ln.set_replica(capi.REPLICA_OFF)
         for k in range(args.warmup):
             step(k)
         flush()
@@ -988,17 +1045,32 @@ def main():
             eng.query_row_topn(q_rows[k], topn)
             lat32.append((time.perf_counter() - t1) * 1e3)
         lat32.sort()
-        eng.set_replica(replica_mode)
+        alone32 = None
+        if n_lanes > 1 and not args.no_single_lane:
+            alone32, _ = stream_leg(eng, torch, q_rows, topn, min(args.steps, 100), min(max(args.warmup, 4), 10))
+        for ln in lanes:
+            ln.set_replica(replica_mode)
         k_ms = float(st32.last_scan_ms)
         fp32_rows = {"kernel": "mi355::scan_kernel<ScanCfg<512,1,6,2>, true, false, 0, true>", "steps": args.steps,
                      "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 5), "value": round(1.0 / dt, 2),
                      "unit": "queries/s", "p50_ms": round(lat32[len(lat32) // 2], 4) if lat32 else None,
                      "roofline": {"bound": roofline_bound((hi - lo) * BYTES_PER_ROW), "algorithmic_bytes_per_launch": (hi - lo) * BYTES_PER_ROW,
                                   "avg_kernel_ms": round(k_ms, 5),
-                                  "achieved": round((hi - lo) * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
+                                  "launches_in_flight": n_lanes,
+                                  "achieved": round(n_lanes * (hi - lo) * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
+                                  "achieved_per_launch": round((hi - lo) * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
+                                  "sustained_gbps": round((hi - lo) * BYTES_PER_ROW / dt / 1e9, 1),
                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                  "frac": round((hi - lo) * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if k_ms > 0 else None,
+                                  "frac": round(n_lanes * (hi - lo) * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if k_ms > 0 else None,
+                                  "achieved_note": (f"{n_lanes} lanes: `achieved` = {n_lanes} x algorithmic bytes / avg_kernel_ms (the launches of the lanes "
+                                                    "overlap); `sustained_gbps` = value x algorithmic bytes, launch gaps included" if n_lanes > 1 else None),
                                   **traffic_fields()}}
+        if alone32 is not None:
+            a_us = alone32["scan_kernel_us"]
+            alone32["roofline"] = {"achieved": round((hi - lo) * BYTES_PER_ROW / (a_us * 1e-6) / 1e9, 1) if a_us > 0 else None, "peak": HBM_PEAK_GBPS,
+                                   "unit": "GB/s", "frac": round((hi - lo) * BYTES_PER_ROW / (a_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if a_us > 0 else None,
+                                   "note": "one handle: algorithmic bytes / the kernel's mean duration with the chip to itself"}
+            fp32_rows["single_lane"] = alone32
 
     # micro-batched throughput, outside the timed region:
     # 12 queries share one pass over the catalogue, seed/final merge launches shared by 36
@@ -1219,17 +1291,35 @@ def main():
         if replica:
             probe_q8 = probe_gbps_of(eng, torch, capi.PROBE_Q8_REPLICA, (rows_l + 3) // 4 * 48, dev)
             probe_fp16 = probe_gbps_of(eng, torch, capi.PROBE_FP16_REPLICA, (rows_l + 1) // 2 * 48, dev)
+    probe_lanes = None   # the buffer the headline kernel streams, read by every lane at once
+    if not args.no_kernel_events and n_lanes > 1:
+        rows_l = hi - lo
+        if replica:
+            probe_lanes = probe_concurrent_gbps(lanes, lane_streams, torch, capi.PROBE_Q8_REPLICA, (rows_l + 3) // 4 * 48, dev)
+        else:
+            probe_lanes = probe_concurrent_gbps(lanes, lane_streams, torch, capi.PROBE_FP32_ROWS, rows_l * BYTES_PER_ROW, dev)
 
     if rank == 0:
         qps = args.steps / elapsed
         scan_ms = float(st.last_scan_ms) if not args.no_kernel_events else 0.0
         row_bytes, alg_bytes, kernel_fmt, kernel_pmc, dtype_label, replica_label = replica_desc(st_headline)
-        achieved = (alg_bytes / (scan_ms * 1e-3) / 1e9) if scan_ms > 0 else None
+        # with lanes, `n_lanes` launches of this kernel are in flight at any time: the rate the chip sustains on the kernel is
+        # lanes x bytes / the mean duration of a launch (the events bracket one lane's launches, the other lanes' overlap them)
+        per_launch = (alg_bytes / (scan_ms * 1e-3) / 1e9) if scan_ms > 0 else None
+        achieved = per_launch * n_lanes if per_launch else None
         # a pass only finds its bytes in the 256 MiB Infinity Cache if the whole buffer survives one
         # full pass of itself plus the fp32 fetches: half the cache is the most that can be hoped for
         cache_resident = alg_bytes <= 128 * 2**20
         own_probe = {12: probe_q8, 24: probe_fp16}.get(row_bytes, probe_gbps)   # the plain read of the buffer THIS kernel streams
-        if cache_resident and own_probe:
+        if n_lanes > 1 and row_bytes == 24:
+            probe_lanes = None   # (measured over the 8-bit replica or the fp32 rows only)
+        if n_lanes > 1 and probe_lanes:
+            own_probe = probe_lanes
+        if n_lanes > 1 and probe_lanes and cache_resident:
+            peak, peak_source = probe_lanes, (f"measured: {n_lanes} plain read-only streams at once (one per lane, each on its own HIP stream) over the "
+                                             "same buffer, resident in the Infinity Cache as the timed stream leaves it: lanes x bytes / the mean "
+                                             "duration of a probe launch (stream_probe_kernel, 20 launches per lane)")
+        elif cache_resident and own_probe:
             # a cache-resident buffer has no spec-sheet ceiling: the measured plain read of the same buffer is the ceiling
             peak, peak_source = own_probe, ("measured: plain read-only stream over the same buffer, resident in the Infinity Cache as "
                                             "the timed stream leaves it (stream_probe_kernel, 20 launches)")
@@ -1257,6 +1347,11 @@ def main():
                                f"row-sharded across {world} MI355X, one process per GPU, one all-gather of {topn} keys/rank "
                                + ("(BASELINE configs[3])" if (n == 10_000_000 and topn == 100) else "")),
                 "rows": n, "topn": topn, "rows_per_gpu": hi - lo, "queries_per_step": 1,
+                "lanes": n_lanes,
+                "lanes_note": (f"the stream of queries is dealt over {n_lanes} lanes of one handle (mi355rec_create_lane: the same rows and replicas, "
+                               "own stream state), each on its own HIP stream — a handle's launches form one chain and cannot overlap each "
+                               "other, two chains fill each other's ramps; `single_lane` is the same stream through one handle"
+                               if n_lanes > 1 else None),
                 "merge": ("inside the next query's scan launch (streamed), last one flushed in the timed region"
                           if streamed else ("own launch per query" if sharded is None else
                                             f"local merge streamed; one all-gather + one batched merge per {args.window} queries")),
@@ -1278,11 +1373,19 @@ def main():
                 "bytes_per_row": row_bytes,
                 "survey_bytes_per_row": BYTES_PER_ROW,
                 "avg_kernel_ms": round(scan_ms, 5) if scan_ms else None,
+                "launches_in_flight": n_lanes,
+                "achieved_per_launch": round(per_launch, 1) if per_launch else None,
+                "achieved_note": (f"{n_lanes} lanes: {n_lanes} launches of this kernel overlap, `achieved` = {n_lanes} x algorithmic bytes / avg_kernel_ms "
+                                  "(a launch takes longer while another lane's is in flight; `achieved_per_launch` is one launch's own rate); "
+                                  "`sustained_gbps` = value x algorithmic bytes, launch gaps included; the kernel with the chip to itself: `single_lane`"
+                                  if n_lanes > 1 else None),
+                "sustained_gbps": round(qps * alg_bytes / 1e9, 1),
                 "merge_kernel_ms": round(float(st.last_merge_ms), 5),
                 # plain reads of each buffer, GB/s (a kernel is only ever compared with the probe of ITS buffer)
                 "stream_probes_gbps": {"fp32_rows": round(probe_gbps, 1) if probe_gbps else None,
                                        "q8_replica": round(probe_q8, 1) if probe_q8 else None,
-                                       "fp16_replica": round(probe_fp16, 1) if probe_fp16 else None},
+                                       "fp16_replica": round(probe_fp16, 1) if probe_fp16 else None,
+                                       "own_buffer_all_lanes_at_once": round(probe_lanes, 1) if probe_lanes else None},
                 "frac_of_own_buffer_probe": round(achieved / own_probe, 4) if (achieved and own_probe) else None,
                 "infinity_cache_resident": bool(cache_resident),
             },
@@ -1301,6 +1404,16 @@ def main():
                 line["roofline"]["at_survey_bytes_per_row"] = {"equivalent_gbps": round(eq, 1),
                                                                "note": f"{(hi - lo) * BYTES_PER_ROW / 1e6:.0f} MB-equivalent per query; the kernel moves {row_bytes / BYTES_PER_ROW:.2f}x "
                                                                        "of that, so this is a throughput figure, not a fraction of any memory's peak"}
+        if single_lane is not None:
+            k_us = single_lane["scan_kernel_us"]
+            alone = (alg_bytes / (k_us * 1e-6) / 1e9) if k_us > 0 else None
+            alone_probe = {12: probe_q8, 24: probe_fp16}.get(row_bytes, probe_gbps)
+            single_lane["roofline"] = {"achieved": round(alone, 1) if alone else None, "unit": "GB/s",
+                                       "peak": round(alone_probe, 1) if (alone_probe and cache_resident) else HBM_PEAK_GBPS,
+                                       "frac": (round(alone / (alone_probe if (alone_probe and cache_resident) else HBM_PEAK_GBPS), 4) if alone else None),
+                                       "note": "one handle, one chain of launches: algorithmic bytes / the kernel's mean duration with the chip "
+                                               "to itself, against the ONE plain read stream over the same buffer (what `roofline` was until round 4)"}
+            line["single_lane"] = single_lane
         if fp32_rows is not None:
             line["fp32_rows"] = fp32_rows
             # SURVEY.md §8(d) prices a query at 48 B/row: that is the fp32 scan's roofline, measured in this run

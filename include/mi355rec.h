@@ -190,6 +190,27 @@ int mi355rec_rebuild_replica(mi355rec_t* h);
  * the exact chain.  Either pointer may be NULL. */
 int mi355rec_replica_counters(mi355rec_t* h, int64_t* scans, int64_t* rescored_rows);
 
+/* LANES: another handle over the SAME device rows and the same replicas (nothing is copied or rebuilt: a lane costs its
+ * per-workgroup lists and sample buffers, ~20 MB at 10 M rows), with its own stream state — its own chain of streamed
+ * queries, its own stash, its own hand-off buffers.  A handle is a single chain: query k + 1's launch carries query k's
+ * merge and needs query k's sample, so consecutive launches of ONE handle never overlap and the chip idles while one
+ * drains and the next ramps up (a streamed query at 10 M rows: 24.3 us per query where its kernel has the bandwidth for
+ * 19).  Two lanes on two streams, queries dealt alternately, fill each other's ramps: 17-18 us per query on the same GPU
+ * (bench.py --lanes).  Results per lane are exactly those of the parent (same kernels, same rows).
+ * The reference has nothing like it (one query per process, Recommender.cu:275-318); mi355rec_sharded_* with
+ * MI355REC_PLACEMENT_REPLICATED is the same idea across devices.
+ * Rules: a lane is used from one thread at a time like any handle, on a stream of its own; the parent and its lanes may be
+ * destroyed in any order (the rows and replicas go with the last one); mi355rec_rebuild_replica is refused while lanes
+ * exist; a lane of a lane is a lane of the same group. */
+int mi355rec_create_lane(mi355rec_t* parent, mi355rec_t** out);
+/* The HIP stream (hipStream_t) the library created with the handle, for callers that want to enqueue on it: THE stream to
+ * run a lane on.  A process has few hardware queues (four by default on ROCm) and a stream is bound to one when it is
+ * created; two lanes whose streams share a hardware queue do not overlap at all (measured: two streams taken from a
+ * framework's pool after the handles existed landed on ONE queue and the lanes ran at a single handle's rate).  The
+ * parent's own stream and a lane's are created one after the other and sit on different queues.  The synchronous calls
+ * of the handle use this stream too: work enqueued on it by the caller is ordered with them. */
+void* mi355rec_own_stream(mi355rec_t* h);
+
 /* Replaces Recommender::~Recommender (Recommender.cu:86-98). */
 void mi355rec_destroy(mi355rec_t* h);
 
@@ -474,8 +495,10 @@ int mi355rec_create_sharded(const float* feats_host, int64_t n, int dim, int n_d
  *       pays the exchange).
  *   MI355REC_PLACEMENT_AUTO        = SHARDED (over the device count chosen by the size of the catalogue when
  *       n_devices = 0).
- * devices: an explicit list of n_devices device ordinals (a device may repeat: virtual shards / replicas, how both
- * placements are exercised on a one-GPU box), or NULL: devices 0 .. n_devices-1, n_devices = 0 letting the library
+ * devices: an explicit list of n_devices device ordinals (a device may repeat: virtual shards, how the sharded placement
+ * is exercised on a one-GPU box; a REPLICATED placement that lists a device more than once gets LANES there —
+ * mi355rec_create_lane: one copy of the rows and replicas, several chains of launches that overlap; {0, 0} on one GPU
+ * serves a stream at ~57 k queries/s where one handle does 41 k), or NULL: devices 0 .. n_devices-1, n_devices = 0 letting the library
  * choose (SHARDED / AUTO: mi355rec_auto_shards; REPLICATED: every visible device).
  * For a replicated handle mi355rec_sharded_info reports one "shard" of n rows per replica, and the transport is
  * meaningless (mi355rec_sharded_set_transport accepts and ignores it). */

@@ -14,6 +14,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -89,6 +90,16 @@ struct mi355rec {
     int64_t row_base = 0;
     const float* d_feats = nullptr;
     float* owned_feats = nullptr;
+    // LANES (mi355rec_create_lane): further handles over the SAME rows and replicas, each with its own stream state.  Once a
+    // lane exists the rows the first handle owned and both replicas belong to the group: freed by whoever is destroyed last.
+    struct SharedRows {
+        std::atomic<int> refs{1};
+        void* owned_feats = nullptr;
+        void* d_half = nullptr;
+        void* d_q8 = nullptr;
+    };
+    SharedRows* shared = nullptr;
+    bool is_lane = false;
 
     int cus = 0;
     int grid = 0;
@@ -438,7 +449,9 @@ void plan_half_grid(mi355rec* h) {
 }
 
 void free_replica(mi355rec* h) {
-    void* bufs[] = {h->d_half, h->d_q8, h->d_half_mseed, h->d_half_rescored, h->d_half_mcuts, h->d_half_mctl};
+    // (the replicas themselves stay while a group of lanes shares them: mi355rec_destroy releases the group's reference)
+    void* bufs[] = {h->shared ? nullptr : h->d_half, h->shared ? nullptr : h->d_q8, h->d_half_mseed, h->d_half_rescored, h->d_half_mcuts,
+                    h->d_half_mctl};
     h->d_half_mcuts = nullptr;
     h->d_half_mctl = nullptr;
     for (void* b : bufs)
@@ -449,9 +462,16 @@ void free_replica(mi355rec* h) {
     h->d_half_rescored = nullptr;
 }
 
+// The per-handle state that goes with a replica (sample values, cutoffs and arrival counters of the multi-query pass,
+// the "rows re-scored" slots): a lane has its own, over replicas it shares.
+int alloc_replica_state(mi355rec* h);
 int alloc_replica(mi355rec* h, int64_t n_padded) {
     HIP_TRY(h, hipMalloc(&h->d_half, static_cast<size_t>(n_padded) * 24));
     HIP_TRY(h, hipMalloc(&h->d_q8, static_cast<size_t>((h->n + 3) / 4) * 48));
+    return alloc_replica_state(h);
+}
+
+int alloc_replica_state(mi355rec* h) {
     HIP_TRY(h, hipMalloc(&h->d_half_mseed, sizeof(unsigned long long) * kHmSampleSlots));
     HIP_TRY(h, hipMalloc(&h->d_half_rescored, sizeof(unsigned long long) * kRideMaxLists));
     HIP_TRY(h, hipMalloc(&h->d_half_mcuts, sizeof(unsigned long long) * kHmQueries));

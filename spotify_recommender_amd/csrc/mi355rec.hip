@@ -59,7 +59,7 @@ void mi355rec_destroy(mi355rec_t* h) {
     if (h->d_mstream_cuts) (void)hipFree(h->d_mstream_cuts);
     if (h->d_mstream_ctl) (void)hipFree(h->d_mstream_ctl);
     for (hipEvent_t e : h->ev_pass) (void)hipEventDestroy(e);
-    if (h->owned_feats) (void)hipFree(h->owned_feats);
+    if (h->owned_feats && !h->shared) (void)hipFree(h->owned_feats);
     if (h->d_block_lists) (void)hipFree(h->d_block_lists);
     if (h->d_lone_ctr) (void)hipFree(h->d_lone_ctr);
     {
@@ -81,7 +81,58 @@ void mi355rec_destroy(mi355rec_t* h) {
     if (h->h_done) (void)hipHostFree(h->h_done);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->order_ev) (void)hipEventDestroy(h->order_ev);
+    if (h->shared && h->shared->refs.fetch_sub(1) == 1) {   // the last of a group of lanes: the rows and the replicas go with it
+        void* bufs[] = {h->shared->owned_feats, h->shared->d_half, h->shared->d_q8};
+        for (void* b : bufs)
+            if (b) (void)hipFree(b);
+        delete h->shared;
+    }
     delete h;
+}
+
+void* mi355rec_own_stream(mi355rec_t* h) { return h ? static_cast<void*>(h->stream) : nullptr; }
+
+int mi355rec_create_lane(mi355rec_t* parent, mi355rec_t** out) {
+    if (out) *out = nullptr;
+    if (!parent || !out) return fail(parent, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (parent->n < 1) return fail(parent, MI355REC_ERR_INVALID_ARG, "an empty shard has no lanes");
+    DeviceGuard guard(parent->device);
+    mi355rec_t* lane = nullptr;
+    // the parent's rows, borrowed; no replica of its own (it takes the parent's below)
+    const int rc = create_common(parent->d_feats, true, parent->n, kDim, parent->device, parent->row_base, MI355REC_CREATE_NO_REPLICA, &lane);
+    if (rc != MI355REC_OK) {
+        parent->err = g_last_error;
+        return rc;
+    }
+    lane->is_lane = true;
+    lane->replica_allowed = parent->replica_allowed;
+    if (parent->d_half) {
+        const int src = alloc_replica_state(lane);
+        if (src != MI355REC_OK) {
+            parent->err = lane->err;
+            mi355rec_destroy(lane);
+            return src;
+        }
+        if (hipStreamSynchronize(lane->stream) != hipSuccess) {
+            mi355rec_destroy(lane);
+            return fail(parent, MI355REC_ERR_HIP, "hipStreamSynchronize(lane)");
+        }
+    }
+    if (!parent->shared) {   // from now on the group owns what the parent owned
+        parent->shared = new mi355rec::SharedRows();
+        parent->shared->owned_feats = parent->owned_feats;
+        parent->shared->d_half = parent->d_half;
+        parent->shared->d_q8 = parent->d_q8;
+    }
+    parent->shared->refs.fetch_add(1);
+    lane->shared = parent->shared;
+    lane->d_half = parent->d_half;
+    lane->d_q8 = parent->d_q8;
+    lane->margin_mix = parent->margin_mix;
+    lane->margin_mfma = parent->margin_mfma;
+    lane->replica_build_ms = 0.f;
+    *out = lane;
+    return MI355REC_OK;
 }
 
 const char* mi355rec_last_error(const mi355rec_t* h) {
@@ -552,6 +603,8 @@ int mi355rec_rebuild_replica(mi355rec_t* h) {
     if (h->n == 0) return MI355REC_OK;
     if (!h->replica_allowed)
         return fail(h, MI355REC_ERR_INVALID_ARG, "this handle was created without a replica (MI355REC_CREATE_NO_REPLICA)");
+    if (h->shared)
+        return fail(h, MI355REC_ERR_INVALID_ARG, "the replicas are shared with lanes (mi355rec_create_lane): destroy the lanes, rebuild, create them again");
     DeviceGuard guard(h->device);
     int rc = sync_api_begin(h);
     if (rc) return rc;

@@ -142,8 +142,14 @@ int create_on(const float* feats_host, int64_t n, int dim, const int* devices, i
             bounds(n, n_shards, r, s.lo, s.hi);
         }
         if (hipSetDevice(s.device) != hipSuccess) return bail(sfail(nullptr, MI355REC_ERR_HIP, "hipSetDevice(%d) failed", s.device));
-        const int rc = mi355rec_create(s.hi > s.lo ? feats_host + s.lo * MI355REC_DIM : nullptr, s.hi - s.lo, dim, s.device,
-                                       s.lo, &s.engine);
+        // a replica on a device that already holds one is a LANE of it (mi355rec_create_lane: the same rows and replicas,
+        // own stream state): listing a device twice buys the overlap of two chains of launches, not a second copy
+        int same = -1;
+        for (int p = 0; p < r && replicated && same < 0; ++p)
+            if (h->shards[p].device == s.device) same = p;
+        const int rc = same >= 0 ? mi355rec_create_lane(h->shards[same].engine, &s.engine)
+                                 : mi355rec_create(s.hi > s.lo ? feats_host + s.lo * MI355REC_DIM : nullptr, s.hi - s.lo, dim, s.device,
+                                                   s.lo, &s.engine);
         if (rc != MI355REC_OK) return bail(sfail(nullptr, rc, "shard %d on device %d: %s", r, s.device, mi355rec_last_global_error()));
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess)

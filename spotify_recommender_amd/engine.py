@@ -65,6 +65,25 @@ class CosineEngine:
         self.rows = int(arr.shape[0])
         self.row_base = int(row_base)
 
+    def lane(self) -> "CosineEngine":
+        """Another handle over the same rows and replicas with its own stream state (mi355rec_create_lane): queries dealt
+        alternately over two lanes on two streams overlap where one handle's launches cannot."""
+        other = CosineEngine.__new__(CosineEngine)
+        other._lib = self._lib
+        other._h = ctypes.c_void_p()
+        other._keepalive = self._keepalive
+        other.device = self.device
+        other.rows = self.rows
+        other.row_base = self.row_base
+        capi.check(self._lib.mi355rec_create_lane(self._h, ctypes.byref(other._h)), self._h)
+        return other
+
+    def own_stream(self):
+        """The HIP stream the library created with this handle, as a torch stream (mi355rec_own_stream): the stream to run a
+        lane on — streams taken from torch's pool later may share a hardware queue, and then lanes do not overlap."""
+        import torch
+        return torch.cuda.ExternalStream(int(self._lib.mi355rec_own_stream(self._h)), device=self.device)
+
     # -- lifetime ---------------------------------------------------------
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:

@@ -1,0 +1,97 @@
+"""Lanes (mi355rec_create_lane): further handles over the SAME device rows and replicas, each with its own stream state.  Results
+of every lane are the oracle's on every route; lanes run interleaved on their own streams; the group outlives its parent."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.parity import assert_topn_matches
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def catalogue():
+    import torch
+    assert torch.cuda.is_available()
+    rng = np.random.default_rng(123)
+    f = rng.random((1_300_000, 12), dtype=np.float32)      # >= 1 M rows: single queries stream the 8-bit replica
+    return f, torch.from_numpy(f).cuda()
+
+
+def check_keys(f, row, keys, topn):
+    from spotify_recommender_amd.engine import unpack_keys
+    idx, sc = unpack_keys(keys)
+    assert_topn_matches(idx, sc, oracle.scores(f, f[row]), row, topn)
+
+
+def test_lanes_interleaved_on_their_own_streams(catalogue):
+    import torch
+    from spotify_recommender_amd.engine import CosineEngine
+    f, t = catalogue
+    topn = 50
+    with CosineEngine(t) as eng:
+        lanes = [eng, eng.lane(), eng.lane()]
+        streams = [ln.own_stream() for ln in lanes]
+        st0 = eng.stats()
+        rows = [(k * 7919 + 5) % f.shape[0] for k in range(30)]
+        outs = [torch.zeros(topn, dtype=torch.int64, device="cuda") for _ in rows]
+        torch.cuda.synchronize()
+        for k, r in enumerate(rows):
+            lanes[k % 3].enqueue_row_keys_streamed(r, topn, outs[k], stream=streams[k % 3])
+        for ln, s in zip(lanes, streams):
+            ln.enqueue_flush(stream=s)
+        torch.cuda.synchronize()
+        for k, r in enumerate(rows):
+            check_keys(f, r, outs[k].cpu().numpy(), topn)
+        # every lane took the 8-bit route over the SHARED replica (nothing was rebuilt: a lane reports no build time)
+        for ln in lanes[1:]:
+            st = ln.stats()
+            assert st.route_q8 == 10 and st.replica_active == 1 and st.replica_build_ms == 0.0
+        assert lanes[0].stats().route_q8 - st0.route_q8 == 10
+        # the other routes of a lane: a query alone, a multi-query pass, a 1024-query batch, the fp32 rows
+        ln = lanes[1]
+        idx, sc = ln.query_row_topn(rows[3], topn)
+        assert_topn_matches(idx, sc, oracle.scores(f, f[rows[3]]), rows[3], topn)
+        qr = np.array(rows[:12], dtype=np.int64)
+        bi, bs, cnt = ln.query_batch_topn(f[qr], qr, topn)
+        for b in range(12):
+            assert_topn_matches(bi[b][:cnt[b]], bs[b][:cnt[b]], oracle.scores(f, f[qr[b]]), int(qr[b]), topn)
+        qr = (np.arange(70, dtype=np.int64) * 104729) % f.shape[0]
+        bi, bs, cnt = lanes[2].query_batch_topn(f[qr], qr, topn)
+        for b in (0, 33, 69):
+            assert_topn_matches(bi[b][:cnt[b]], bs[b][:cnt[b]], oracle.scores(f, f[qr[b]]), int(qr[b]), topn)
+        from spotify_recommender_amd import capi
+        ln.set_replica(capi.REPLICA_OFF)
+        idx, sc = ln.query_row_topn(rows[4], topn)
+        assert_topn_matches(idx, sc, oracle.scores(f, f[rows[4]]), rows[4], topn)
+        for extra in lanes[1:]:
+            extra.close()
+
+
+def test_the_group_outlives_its_parent_and_refuses_a_rebuild(catalogue):
+    import torch
+    from spotify_recommender_amd import capi
+    from spotify_recommender_amd.engine import CosineEngine
+    f, _ = catalogue
+    topn = 10
+    eng = CosineEngine(f[:1_050_000])            # host rows: the parent OWNS the device copy
+    lane = eng.lane()
+    with pytest.raises(capi.Mi355Error):
+        eng.rebuild_replica()                    # the replicas are shared
+    row = 777_777
+    want = oracle.scores(f[:1_050_000], f[row])
+    idx, sc = lane.query_row_topn(row, topn)
+    assert_topn_matches(idx, sc, want, row, topn)
+    eng.close()                                  # the parent goes first: rows and replicas stay with the lane
+    out = torch.zeros(topn, dtype=torch.int64, device="cuda")
+    lane.enqueue_row_keys_streamed(row, topn, out)
+    lane.enqueue_flush()
+    torch.cuda.synchronize()
+    check_keys(f[:1_050_000], row, out.cpu().numpy(), topn)
+    lane2 = lane.lane()                          # a lane of a lane: the same group
+    idx, sc = lane2.query_row_topn(row, topn)
+    assert_topn_matches(idx, sc, want, row, topn)
+    lane.close()
+    idx, sc = lane2.query_row_topn(row + 1, topn)
+    assert_topn_matches(idx, sc, oracle.scores(f[:1_050_000], f[row + 1]), row + 1, topn)
+    lane2.close()

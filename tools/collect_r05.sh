@@ -16,10 +16,10 @@ case ${PART:-A} in
 A)
   python bench.py > $O/bench.json 2> $O/bench.err
   echo "bench done"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --no-cpu-baseline --no-config0 --no-clustered --latency-queries 50 > $O/trace.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --no-cpu-baseline --no-config0 --no-clustered --no-single-lane --latency-queries 50 > $O/trace.log 2>&1
   echo "trace done"
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-config0 --no-clustered --no-c5-shard --latency-queries 5 > $O/fetch.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-config0 --no-clustered --no-c5-shard --latency-queries 5 > $O/write.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-config0 --no-clustered --no-single-lane --no-c5-shard --latency-queries 5 > $O/fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-config0 --no-clustered --no-single-lane --no-c5-shard --latency-queries 5 > $O/write.log 2>&1
   ;;
 B)
   S="python3 tools/run_half_multi.py --fp16 --only-stream 12 --calls 60"
