@@ -191,8 +191,11 @@ def probe_gbps_of(eng, torch, which, n_bytes, dev):
 
 def probe_concurrent_gbps(lanes, lane_streams, torch, which, n_bytes, dev):
     """The same plain read-only stream from EVERY lane at once, each on its own HIP stream, over the one buffer they share: the
-    aggregate rate = lanes x bytes / the mean duration of a probe launch while the others' are in flight (lane 0's events) —
-    the ceiling of a kernel whose launches overlap the same way.  None when the handle has no such buffer."""
+    aggregate rate while they overlap = lanes x bytes / the mean duration of a probe launch with the others' in flight (lane 0's
+    HIP events over 30 launches) — a kernel-level ceiling without launch gaps, so a sustained rate held against it is on the safe
+    side.  (A wall-clock version of this probe is bounded by how fast Python can enqueue 19 us kernels, not by the chip: 6.4 TB/s
+    where the events say 8.4 and MI355X_MICROARCH.md measures 7.4-8.6 TB/s for Infinity-Cache-served reads.)  None when the handle
+    has no such buffer."""
     from spotify_recommender_amd import capi
     sinks = [torch.zeros(4096, dtype=torch.int32, device=dev) for _ in lanes]
     torch.cuda.synchronize()
@@ -204,7 +207,7 @@ def probe_concurrent_gbps(lanes, lane_streams, torch, which, n_bytes, dev):
         return None
     torch.cuda.synchronize()
     lanes[0].set_timing(True)
-    for _ in range(20):
+    for _ in range(30):
         for ln, ls, sk in zip(lanes, lane_streams, sinks):
             ln.enqueue_stream_probe(sk, stream=ls, which=which)
     torch.cuda.synchronize()
@@ -1057,13 +1060,17 @@ def main():
                      "roofline": {"bound": roofline_bound((hi - lo) * BYTES_PER_ROW), "algorithmic_bytes_per_launch": (hi - lo) * BYTES_PER_ROW,
                                   "avg_kernel_ms": round(k_ms, 5),
                                   "launches_in_flight": n_lanes,
-                                  "achieved": round(n_lanes * (hi - lo) * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
+                                  "achieved": (round((hi - lo) * BYTES_PER_ROW / dt / 1e9, 1) if n_lanes > 1 else
+                                               (round((hi - lo) * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None)),
                                   "achieved_per_launch": round((hi - lo) * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
-                                  "sustained_gbps": round((hi - lo) * BYTES_PER_ROW / dt / 1e9, 1),
                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                  "frac": round(n_lanes * (hi - lo) * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if k_ms > 0 else None,
-                                  "achieved_note": (f"{n_lanes} lanes: `achieved` = {n_lanes} x algorithmic bytes / avg_kernel_ms (the launches of the lanes "
-                                                    "overlap); `sustained_gbps` = value x algorithmic bytes, launch gaps included" if n_lanes > 1 else None),
+                                  "frac": (round((hi - lo) * BYTES_PER_ROW / dt / 1e9 / HBM_PEAK_GBPS, 4) if n_lanes > 1 else
+                                           (round((hi - lo) * BYTES_PER_ROW / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if k_ms > 0 else None)),
+                                  "achieved_note": (f"{n_lanes} lanes: `achieved` = steps x algorithmic bytes / elapsed (value x 48 B x rows, launch gaps included); "
+                                                    "ALGORITHMIC bytes: the lanes scan the same rows a fraction of a launch apart, so part of the second lane's rows may come "
+                                                    "from the Infinity Cache rather than HBM — FETCH_SIZE counts L2 misses, in front of that cache, and cannot tell "
+                                                    "(1.02x the algorithmic bytes per launch either way, profiles/*_pmc_hbm_traffic.json); "
+                                                    "the kernel alone, every byte from HBM: `single_lane`" if n_lanes > 1 else None),
                                   **traffic_fields()}}
         if alone32 is not None:
             a_us = alone32["scan_kernel_us"]
@@ -1095,18 +1102,21 @@ def main():
     # queries); the exact 12-query pass (mi355::scan_multi_kernel) is timed beside it.
     micro = None
     if topn <= 128:
-        def batch_leg(nb, calls, path, streamed_batches=False):
+        def batch_leg(nb, calls, path, streamed_batches=False, over_lanes=False):
             b_rows = np.array(q_rows[:nb], dtype=np.int64)
-            rings = [torch.zeros(nb * topn, dtype=torch.int64, device=dev) for _ in range(4)]
+            rings = [torch.zeros(nb * topn, dtype=torch.int64, device=dev) for _ in range(8)]
             eng.set_batch_path(path)
             state = {"k": 0}
+            use = lanes if (over_lanes and streamed_batches and n_lanes > 1) else [eng]
+            use_streams = lane_streams if len(use) > 1 else [None]
 
             def batch_step():
-                b_keys = rings[state["k"] % 4]
+                k = state["k"]
+                b_keys = rings[k % 8]
                 state["k"] += 1
                 if sharded is None:
                     if streamed_batches:
-                        eng.enqueue_batch_keys_streamed(q_vecs[:nb], b_rows, topn, b_keys)
+                        use[k % len(use)].enqueue_batch_keys_streamed(q_vecs[:nb], b_rows, topn, b_keys, stream=use_streams[k % len(use)])
                     else:
                         eng.enqueue_batch_keys(q_vecs[:nb], b_rows, topn, b_keys)
                 else:
@@ -1117,17 +1127,18 @@ def main():
                 for _ in range(calls):
                     batch_step()
                 if streamed_batches:
-                    eng.enqueue_flush()
+                    for ln, ls in zip(use, use_streams):
+                        ln.enqueue_flush(stream=ls)
 
             dt = timed(run, 1) / calls
             eng.set_batch_path(capi.BATCH_AUTO)
-            return dt, rings[(state["k"] - 1) % 4]
+            return dt, rings[(state["k"] - 1) % 8]
 
         nb = 12 if sharded is None else 72
         stream_ok = replica and sharded is None
-        dt, b_keys = batch_leg(nb, 30 if sharded is None else 6, capi.BATCH_AUTO, stream_ok)
+        dt, b_keys = batch_leg(nb, 30 if sharded is None else 6, capi.BATCH_AUTO, stream_ok, over_lanes=True)
         micro = {"queries_per_call": nb, "value": round(nb / dt, 1), "unit": "queries/s",
-                 "ms_per_call": round(dt * 1e3, 5),
+                 "ms_per_call": round(dt * 1e3, 5), "lanes": n_lanes if stream_ok else 1,
                  "note": ("a STREAM of 12-query batches (mi355rec_enqueue_batch_keys_streamed, the flush inside the timed "
                           "region): one launch per batch = one 24 B/row pass over the fp16 replica with an fp16 matrix-core "
                           "pre-filter (mi355::scan_half_multi_kernel<true>), the previous batch's merges and the next batch's "
@@ -1147,8 +1158,13 @@ def main():
                                  "achieved": round(alg12 / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None, "peak": HBM_PEAK_GBPS,
                                  "unit": "GB/s", "frac": round(alg12 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if k_ms > 0 else None}
             for name, nq in (("two_queries", 2), ("thirty_two_queries", 32)):
-                d, _ = batch_leg(nq, 20, capi.BATCH_AUTO, True)
+                d, _ = batch_leg(nq, 20, capi.BATCH_AUTO, True, over_lanes=True)
                 micro[name] = {"ms_per_call": round(d * 1e3, 5), "value": round(nq / d, 1), "unit": "queries/s"}
+            if n_lanes > 1:   # the same streams of batches through ONE handle (what these figures were until round 4)
+                micro["single_lane"] = {}
+                for name, nq in (("twelve_queries", 12), ("thirty_two_queries", 32)):
+                    d, _ = batch_leg(nq, 20, capi.BATCH_AUTO, True)
+                    micro["single_lane"][name] = {"ms_per_call": round(d * 1e3, 5), "value": round(nq / d, 1), "unit": "queries/s"}
             d, _ = batch_leg(12, 20, capi.BATCH_AUTO, False)
             micro["single_call_12"] = {"ms_per_call": round(d * 1e3, 5), "value": round(12 / d, 1), "unit": "queries/s",
                                        "note": "one batch alone (mi355rec_enqueue_batch_keys): sample launch + pass + merge launch"}
@@ -1306,7 +1322,11 @@ def main():
         # with lanes, `n_lanes` launches of this kernel are in flight at any time: the rate the chip sustains on the kernel is
         # lanes x bytes / the mean duration of a launch (the events bracket one lane's launches, the other lanes' overlap them)
         per_launch = (alg_bytes / (scan_ms * 1e-3) / 1e9) if scan_ms > 0 else None
-        achieved = per_launch * n_lanes if per_launch else None
+        # With lanes the launches of this kernel OVERLAP (by how much varies along the stream), so no single launch's duration says
+        # what the chip sustains on it: `achieved` is then the sustained rate of the timed region itself — every step's algorithmic
+        # bytes / the elapsed time `value` is made of, launch gaps included — held against the kernel-level rate of as many plain
+        # read streams at once.
+        achieved = (qps * alg_bytes / 1e9) if n_lanes > 1 else per_launch
         # a pass only finds its bytes in the 256 MiB Infinity Cache if the whole buffer survives one
         # full pass of itself plus the fp32 fetches: half the cache is the most that can be hoped for
         cache_resident = alg_bytes <= 128 * 2**20
@@ -1318,7 +1338,9 @@ def main():
         if n_lanes > 1 and probe_lanes and cache_resident:
             peak, peak_source = probe_lanes, (f"measured: {n_lanes} plain read-only streams at once (one per lane, each on its own HIP stream) over the "
                                              "same buffer, resident in the Infinity Cache as the timed stream leaves it: lanes x bytes / the mean "
-                                             "duration of a probe launch (stream_probe_kernel, 20 launches per lane)")
+                                             "duration of a probe launch while the other lane's is in flight (stream_probe_kernel, HIP events, 30 "
+                                             "launches per lane) — no launch gaps in it, while `achieved` has them; MI355X_MICROARCH.md measures "
+                                             "7.4-8.6 TB/s for Infinity-Cache-served reads")
         elif cache_resident and own_probe:
             # a cache-resident buffer has no spec-sheet ceiling: the measured plain read of the same buffer is the ceiling
             peak, peak_source = own_probe, ("measured: plain read-only stream over the same buffer, resident in the Infinity Cache as "
@@ -1375,11 +1397,11 @@ def main():
                 "avg_kernel_ms": round(scan_ms, 5) if scan_ms else None,
                 "launches_in_flight": n_lanes,
                 "achieved_per_launch": round(per_launch, 1) if per_launch else None,
-                "achieved_note": (f"{n_lanes} lanes: {n_lanes} launches of this kernel overlap, `achieved` = {n_lanes} x algorithmic bytes / avg_kernel_ms "
-                                  "(a launch takes longer while another lane's is in flight; `achieved_per_launch` is one launch's own rate); "
-                                  "`sustained_gbps` = value x algorithmic bytes, launch gaps included; the kernel with the chip to itself: `single_lane`"
+                "achieved_note": (f"{n_lanes} lanes: launches of this kernel overlap, so `achieved` = steps x algorithmic bytes / elapsed (= value x bytes: "
+                                  "the sustained rate of the timed region, launch gaps included); `peak` is a kernel-level figure without gaps; "
+                                  "`achieved_per_launch` = bytes / avg_kernel_ms is ONE launch's own rate while another lane's is in flight (the figure "
+                                  "a kernel trace's average duration gives); the kernel with the chip to itself is in `single_lane`"
                                   if n_lanes > 1 else None),
-                "sustained_gbps": round(qps * alg_bytes / 1e9, 1),
                 "merge_kernel_ms": round(float(st.last_merge_ms), 5),
                 # plain reads of each buffer, GB/s (a kernel is only ever compared with the probe of ITS buffer)
                 "stream_probes_gbps": {"fp32_rows": round(probe_gbps, 1) if probe_gbps else None,
@@ -1417,12 +1439,21 @@ def main():
         if fp32_rows is not None:
             line["fp32_rows"] = fp32_rows
             # SURVEY.md §8(d) prices a query at 48 B/row: that is the fp32 scan's roofline, measured in this run
-            line["roofline"]["survey_frac"] = fp32_rows["roofline"]["frac"]
-            line["roofline"]["survey_achieved"] = fp32_rows["roofline"]["achieved"]
-            line["roofline"]["survey_kernel"] = "mi355::scan_kernel over the fp32 rows (48 B/row): the `fp32_rows` object"
-            if probe_gbps and fp32_rows["roofline"]["achieved"]:
-                fp32_rows["roofline"]["stream_probe_gbps"] = round(probe_gbps, 1)
-                fp32_rows["roofline"]["frac_of_stream_probe"] = round(fp32_rows["roofline"]["achieved"] / probe_gbps, 4)
+            alone = (fp32_rows.get("single_lane") or {}).get("roofline")
+            if alone:   # the HBM-bound figure is the kernel ALONE (every byte from HBM); with lanes part of the rows come from the cache
+                line["roofline"]["survey_frac"] = alone["frac"]
+                line["roofline"]["survey_achieved"] = alone["achieved"]
+                line["roofline"]["survey_frac_algorithmic_with_lanes"] = fp32_rows["roofline"]["frac"]
+                line["roofline"]["survey_kernel"] = ("mi355::scan_kernel over the fp32 rows (48 B/row), one handle, the chip to itself: "
+                                                     "`fp32_rows.single_lane`; `fp32_rows` itself is the same stream over the lanes")
+            else:
+                line["roofline"]["survey_frac"] = fp32_rows["roofline"]["frac"]
+                line["roofline"]["survey_achieved"] = fp32_rows["roofline"]["achieved"]
+                line["roofline"]["survey_kernel"] = "mi355::scan_kernel over the fp32 rows (48 B/row): the `fp32_rows` object"
+            tgt = alone if alone else fp32_rows["roofline"]   # (a ratio of ONE kernel's rate to ONE plain stream's)
+            if probe_gbps and tgt["achieved"]:
+                tgt["stream_probe_gbps"] = round(probe_gbps, 1)
+                tgt["frac_of_stream_probe"] = round(tgt["achieved"] / probe_gbps, 4)
         elif not replica:
             line["roofline"]["survey_frac"] = line["roofline"]["frac"]
             line["roofline"]["survey_achieved"] = line["roofline"]["achieved"]

@@ -12,6 +12,7 @@ ap.add_argument("--topn", type=int, default=100)
 ap.add_argument("--steps", type=int, default=600)
 ap.add_argument("--handles", type=int, default=2)
 ap.add_argument("--separate", action="store_true")
+ap.add_argument("--batch", type=int, default=0, help="streams of batches of this many queries (mi355rec_enqueue_batch_keys_streamed) instead of single queries")
 ap.add_argument("--torch-streams", action="store_true", help="streams from torch's pool instead of the handles' own (they may share a hardware queue)")
 ap.add_argument("--fp32", action="store_true", help="the fp32 rows (mi355rec_set_replica(OFF)) instead of the 8-bit replica")
 a = ap.parse_args()
@@ -34,10 +35,18 @@ for nh in sorted({1, a.handles}):
             e.set_replica(capi.REPLICA_OFF)
     streams = [torch.cuda.Stream() for _ in range(nh)] if a.torch_streams else [e.own_stream() for e in engs]
     rings = [[torch.zeros(a.topn, dtype=torch.int64, device="cuda") for _ in range(8)] for _ in range(nh)]
+    if a.batch:
+        rings = [[torch.zeros(a.batch * a.topn, dtype=torch.int64, device="cuda") for _ in range(8)] for _ in range(nh)]
+        sel = np.array(rows[:a.batch], dtype=np.int64)
+        qv = t[torch.from_numpy(sel).cuda()].cpu().numpy()
+
     def run(n0, n1):
         for k in range(n0, n1):
             h = k % nh
-            engs[h].enqueue_row_keys_streamed(rows[k], a.topn, rings[h][(k // nh) % 8], stream=streams[h])
+            if a.batch:
+                engs[h].enqueue_batch_keys_streamed(qv, sel, a.topn, rings[h][(k // nh) % 8], stream=streams[h])
+            else:
+                engs[h].enqueue_row_keys_streamed(rows[k], a.topn, rings[h][(k // nh) % 8], stream=streams[h])
     run(0, 40)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -46,7 +55,7 @@ for nh in sorted({1, a.handles}):
         engs[h].enqueue_flush(stream=streams[h])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    out[f"handles_{nh}"] = {"us_per_query": round(dt * 1e6 / a.steps, 2), "queries_per_s": round(a.steps / dt, 1)}
+    out[f"handles_{nh}"] = {"us_per_call": round(dt * 1e6 / a.steps, 2), "queries_per_s": round(a.steps * max(1, a.batch) / dt, 1)}
     for e in reversed(engs):
         e.close()
 print(json.dumps(out))
