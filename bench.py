@@ -942,10 +942,15 @@ def main():
     def ring_of(k):
         return rings[k % n_lanes][(k // n_lanes) % 4]
 
+    # (bound once, as a C host would call it: the row and the output pointer are all that changes per query)
+    import ctypes
+    ring_ptrs = [[ctypes.c_void_p(t.data_ptr()) for t in rs] for rs in rings]
+    lane_calls = [ln.bound_enqueue_row_keys_streamed(topn, ls) for ln, ls in zip(lanes, lane_streams)] if streamed else []
+
     def step(k):
         if sharded is None:
             if streamed:
-                lanes[k % n_lanes].enqueue_row_keys_streamed(q_rows[k], topn, ring_of(k), stream=lane_streams[k % n_lanes])
+                lane_calls[k % n_lanes](q_rows[k], ring_ptrs[k % n_lanes][(k // n_lanes) % 4])
             else:
                 eng.enqueue_row_keys(q_rows[k], topn, out_keys)
         else:
