@@ -1141,7 +1141,7 @@ def main():
 
         nb = 12 if sharded is None else 72
         stream_ok = replica and sharded is None
-        dt, b_keys = batch_leg(nb, 30 if sharded is None else 6, capi.BATCH_AUTO, stream_ok, over_lanes=True)
+        dt, b_keys = batch_leg(nb, 40 if sharded is None else 6, capi.BATCH_AUTO, stream_ok, over_lanes=True)
         micro = {"queries_per_call": nb, "value": round(nb / dt, 1), "unit": "queries/s",
                  "ms_per_call": round(dt * 1e3, 5), "lanes": n_lanes if stream_ok else 1,
                  "note": ("a STREAM of 12-query batches (mi355rec_enqueue_batch_keys_streamed, the flush inside the timed "
@@ -1163,12 +1163,12 @@ def main():
                                  "achieved": round(alg12 / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None, "peak": HBM_PEAK_GBPS,
                                  "unit": "GB/s", "frac": round(alg12 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if k_ms > 0 else None}
             for name, nq in (("two_queries", 2), ("thirty_two_queries", 32)):
-                d, _ = batch_leg(nq, 20, capi.BATCH_AUTO, True, over_lanes=True)
+                d, _ = batch_leg(nq, 40, capi.BATCH_AUTO, True, over_lanes=True)
                 micro[name] = {"ms_per_call": round(d * 1e3, 5), "value": round(nq / d, 1), "unit": "queries/s"}
             if n_lanes > 1:   # the same streams of batches through ONE handle (what these figures were until round 4)
                 micro["single_lane"] = {}
                 for name, nq in (("twelve_queries", 12), ("thirty_two_queries", 32)):
-                    d, _ = batch_leg(nq, 20, capi.BATCH_AUTO, True)
+                    d, _ = batch_leg(nq, 40, capi.BATCH_AUTO, True)
                     micro["single_lane"][name] = {"ms_per_call": round(d * 1e3, 5), "value": round(nq / d, 1), "unit": "queries/s"}
             d, _ = batch_leg(12, 20, capi.BATCH_AUTO, False)
             micro["single_call_12"] = {"ms_per_call": round(d * 1e3, 5), "value": round(12 / d, 1), "unit": "queries/s",
