@@ -402,7 +402,27 @@ def config0_object(torch, np):
                 lat.append((time.perf_counter() - t1) * 1e6)
             lat.sort()
             leg, last = stream_leg(eng, torch, q_rows, topn, 1000, 100)
-            out["gpu"] = {"route": "fp32 rows (48 B/row; shards below 1 M rows are launch-bound either way)" if not st.replica_active else "replica",
+            # ... and the same stream over two lanes of the handle (mi355rec_create_lane), bound calls, each lane on its own stream
+            lane = eng.lane()
+            pair = [eng, lane]
+            calls = [e.bound_enqueue_row_keys_streamed(topn, e.own_stream()) for e in pair]
+            lrings = [[torch.zeros(topn, dtype=torch.int64, device="cuda") for _ in range(4)] for _ in pair]
+            lptrs = [[ctypes.c_void_p(t.data_ptr()) for t in rs] for rs in lrings]
+            torch.cuda.synchronize()
+
+            def lanes_run(k0, k1):
+                for k in range(k0, k1):
+                    calls[k & 1](int(q_rows[k % len(q_rows)]), lptrs[k & 1][(k >> 1) & 3])
+                for e in pair:
+                    e.enqueue_flush(stream=e.own_stream())
+                torch.cuda.synchronize()
+            lanes_run(0, 100)
+            t1 = time.perf_counter()
+            lanes_run(100, 2100)
+            dt2 = (time.perf_counter() - t1) / 2000
+            lane.close()
+            out["gpu"] = {"two_lanes_streamed_queries_per_s": round(1.0 / dt2, 1), "two_lanes_streamed_us_per_query": round(dt2 * 1e6, 2),
+                          "route": "fp32 rows (48 B/row; shards below 1 M rows are launch-bound either way)" if not st.replica_active else "replica",
                           "one_query_alone_p50_us": round(lat[len(lat) // 2], 1), "one_query_alone_p99_us": round(lat[int(len(lat) * 0.99)], 1),
                           "streamed_queries_per_s": leg["queries_per_s"], "streamed_us_per_query": leg["us_per_step"],
                           "scan_kernel_us": leg["scan_kernel_us"]}

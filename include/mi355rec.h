@@ -208,7 +208,9 @@ int mi355rec_create_lane(mi355rec_t* parent, mi355rec_t** out);
  * created; two lanes whose streams share a hardware queue do not overlap at all (measured: two streams taken from a
  * framework's pool after the handles existed landed on ONE queue and the lanes ran at a single handle's rate).  The
  * parent's own stream and a lane's are created one after the other and sit on different queues.  The synchronous calls
- * of the handle use this stream too: work enqueued on it by the caller is ordered with them. */
+ * of the handle use this stream too: work enqueued on it by the caller is ordered with them.  It was created with
+ * hipStreamNonBlocking: it does NOT wait for work on the null stream (e.g. a memset of the buffer a query writes to —
+ * synchronise or use an event first). */
 void* mi355rec_own_stream(mi355rec_t* h);
 
 /* Replaces Recommender::~Recommender (Recommender.cu:86-98). */
