@@ -406,8 +406,9 @@ int ensure_bq_alloc(mi355rec* h) {
     HIP_TRY(h, hipMalloc(&b.cand_rows, sizeof(uint64_t) * static_cast<size_t>(kBqMaxQueries) * b.cand_cap));
     HIP_TRY(h, hipMalloc(&b.cand_examined, sizeof(int) * kBqMaxQueries));
     HIP_TRY(h, hipMemsetAsync(b.cand_examined, 0, sizeof(int) * kBqMaxQueries, h->stream));
-    HIP_TRY(h, hipMalloc(&b.counters, sizeof(int) * 8));   // [0..3]: batched.hip.h; [4]: the queued scan's arrival counter; [6]: cand_cap
-    HIP_TRY(h, hipMemsetAsync(b.counters, 0, sizeof(int) * 8, h->stream));
+    // [0..3]: batched.hip.h; [5]: queries ever queued; [6]: cand_cap; [8 .. 8 + 128): the queued scan's arrival counters, one per group of queries
+    HIP_TRY(h, hipMalloc(&b.counters, sizeof(int) * (8 + 128)));
+    HIP_TRY(h, hipMemsetAsync(b.counters, 0, sizeof(int) * (8 + 128), h->stream));
     HIP_TRY(h, hipMemcpyAsync(b.counters + 6, &b.cand_cap, sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMalloc(&b.special_rows, sizeof(uint32_t) * kBqSpecialCap));
     HIP_TRY(h, hipMalloc(&b.nb_vals, sizeof(uint32_t) * kBqMaxQueries));
@@ -548,7 +549,7 @@ int enqueue_bq_chunk(mi355rec* h, const float* d_queries, const long long* d_exc
     // nothing: the launch exits at once on an empty queue).
     hipLaunchKernelGGL((scan_multi_queued_kernel<MultiConfig>), dim3(b.qgrid), dim3(MultiConfig::kBlock), 0, s,
                        h->d_feats, h->n, b.qiters, h->row_base, d_queries, d_exclude, b.queue, b.counters + 1, topn,
-                       b.qlists, reinterpret_cast<unsigned*>(b.counters + 4), out_keys, out_idx, out_score,
+                       b.qlists, reinterpret_cast<unsigned*>(b.counters + 8), out_keys, out_idx, out_score,
                        static_cast<int64_t>(topn));
     HIP_TRY(h, hipGetLastError());
     ++b.launches;

@@ -564,10 +564,11 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
 // to block_lists[position in the queue][workgroup][topk].  Exits at once when the
 // queue is empty — the usual case, in which this launch costs its dispatch and nothing else.
 // The merge of those lists is part of the launch as well (it used to be a second kernel that
-// every batched call paid for): the workgroup that finishes LAST merges every queued query's lists
-// into that query's output row.  Rare path, so the hand-off is the plain one: a device-wide fence
-// before each workgroup counts itself out and one behind the count of the last (`arrive` is zero
-// between launches: the last workgroup resets it, and a launch with an empty queue never touches it).
+// every batched call paid for): the workgroup that finishes a GROUP last merges that group's lists
+// into its queries' output rows while the others scan the next group (`arrive`: one counter per group,
+// kBqMaxQueries / kMultiQueries < 128 of them).  Rare path, so the hand-off is the plain one: a device-wide
+// fence before each workgroup counts itself out and one behind the count of the last (the counters are zero
+// between launches: the last workgroup of a group resets its own, and a launch with an empty queue touches none).
 // (Launch bounds it can meet: one workgroup per CU is all the launch ever has — its grid is the CU count and the merge's
 // shared memory, 120 KB, allows no second one — so two waves per SIMD, not the pass kernel's four: the compiler used to
 // warn "desired occupancy was 4, final occupancy is 2".)
@@ -581,6 +582,12 @@ __global__ __launch_bounds__(Cfg::kBlock, 2) void scan_multi_queued_kernel(
     int64_t out_query_stride) {
     const int count = *queue_count;
     if (count == 0) return;   // uniform over the whole grid
+    // Every group of kMultiQueries queued queries is counted out on its OWN counter, and the workgroup that leaves a group
+    // last merges that group's queries while the others go on scanning the next group: a whole chunk in the queue (1024
+    // queries: hostile data) used to end with ONE workgroup merging a thousand queries, 10 ms, behind an idle chip.
+    // (`arrive[g]` is zero between launches: the last workgroup of a group resets it.)
+    __shared__ int s_last;
+    __shared__ MergeSmemT<Cfg::kBlock, 1024, kMergeSurvCap> s_merge;   // (one workgroup per CU fits with this: the launch has no more)
     for (int g0 = 0; g0 < count; g0 += kMultiQueries) {
         const int nq = count - g0 < kMultiQueries ? count - g0 : kMultiQueries;
         auto load_query = [&](int t, float (&qv)[kDim], long long& excl) {
@@ -592,23 +599,24 @@ __global__ __launch_bounds__(Cfg::kBlock, 2) void scan_multi_queued_kernel(
         multi_scan_group<Cfg>(feats, n, static_cast<int64_t>(0), static_cast<int64_t>(0), iters, row_base, load_query,
                               nq, g0, topk, block_lists, static_cast<const uint64_t*>(nullptr), 0);
         __syncthreads();
-    }
-    __shared__ int s_last;
-    __threadfence();   // this workgroup's lists are visible device-wide ...
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const bool last = atomicAdd(arrive, 1u) + 1u == gridDim.x;   // ... before it is counted
-        if (last) *arrive = 0u;
-        s_last = last ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_last) return;   // uniform
-    __threadfence();       // ... and the last one sees everybody's
-    __shared__ MergeSmemT<Cfg::kBlock, 1024, kMergeSurvCap> s_merge;   // (one workgroup per CU fits with this: the launch has no more)
-    for (int b = 0; b < count; ++b) {
-        merge_body(s_merge, block_lists, static_cast<int>(gridDim.x), topk, static_cast<int64_t>(topk),
-                   static_cast<int64_t>(gridDim.x) * topk, topk, out_keys_base, out_idx_base, out_score_base, out_query_stride,
-                   static_cast<int64_t>(b), static_cast<int64_t>(queue[b]));
+        __threadfence();   // this workgroup's lists of the group are visible device-wide ...
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned* const ctr = arrive + g0 / kMultiQueries;
+            const bool last = atomicAdd(ctr, 1u) + 1u == gridDim.x;   // ... before it is counted
+            if (last) *ctr = 0u;
+            s_last = last ? 1 : 0;
+        }
+        __syncthreads();
+        if (s_last) {          // uniform
+            __threadfence();   // ... and the last one sees everybody's
+            for (int b = g0; b < g0 + nq; ++b) {
+                merge_body(s_merge, block_lists, static_cast<int>(gridDim.x), topk, static_cast<int64_t>(topk),
+                           static_cast<int64_t>(gridDim.x) * topk, topk, out_keys_base, out_idx_base, out_score_base, out_query_stride,
+                           static_cast<int64_t>(b), static_cast<int64_t>(queue[b]));
+                __syncthreads();
+            }
+        }
         __syncthreads();
     }
 }
