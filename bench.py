@@ -890,7 +890,7 @@ def main():
                                        "rows": args.rows, "topn": args.topn, "gpus": args.gpus,
                                        "devices_visible": torch.cuda.device_count()}) + "\n").encode())
         return
-    if world == 1 and (args.gpus > 1 or args.virtual_shards > 1):
+    if world == 1 and (args.gpus > 1 or args.virtual_shards > 1 or args.preflight):   # (--preflight on one GPU: the node handle over device 0)
         # Launched plainly: ONE process drives every GPU through the product's C-ABI
         # (mi355rec_create_sharded: what the C++ Recommender uses).  Under torch.distributed.run
         # (WORLD_SIZE = N) the one-process-per-GPU path below runs instead.
