@@ -6,13 +6,16 @@
  * load this library, and only as the checker / reported CPU baseline.  The
  * product path (spotify_recommender_amd/, include/) never links or calls it.
  *
- * Pinning status (see oracle/README.md):
+ * Pinning status (see oracle/README.md): the SCORING chain is PARITY UNPINNED
+ * by the strict rule — no vector made by a reference build, or held by the
+ * reference's tests, exists for it:
  *   - The reference hot-path file (Recommender.cu) cannot be compiled in the
  *     build container without stand-ins for CUDA headers, so there is no
- *     oracle/_ref build of it.
- *   - This restatement is pinned by the reference outputs recorded in
+ *     oracle/_ref build of it, and the reference ships no tests or vectors.
+ *   - The restatement reproduces the reference outputs recorded in
  *     SURVEY.md §8(c)/§6.2 (tie-order fixture, zero-query fixture, 1 M and
- *     10 M mt19937(12345) top-3 ids + scores) — tests/test_oracle_pins.py.
+ *     10 M mt19937(12345) top-3 ids + scores) — tests/test_oracle_pins.py —
+ *     which the survey took from a stub-header build: agreement, not a pin.
  *   - The heap replay is pinned against the real libstdc++
  *     std::priority_queue (tests/heap_check.cpp).
  *
