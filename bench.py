@@ -936,7 +936,12 @@ def main():
         eng.set_replica(replica_mode)
     st_headline = eng.stats()       # which copy of the rows the headline's queries scan
     replica = bool(st_headline.replica_active)
-    sharded = ShardedEngine(eng, max_topn=topn, always_gather=force_sharded) if (world > 1 or force_sharded) else None
+    # (one process per GPU: every rank deals its windowed stream over lanes of its engine as well — ShardedEngine(lanes=))
+    # (from 2 M rows per rank: below that a rank's step is bound by the host's per-query work, which a second lane adds to —
+    # measured on one GPU through the same path (BENCH_FORCE_SHARDED=1), one lane / two: 10 M rows 39.6 k / 45.7 k queries/s, 5 M 54.2 / 67.2 k,
+    # 2.5 M 72.0 / 77.0 k, 1.25 M 73.5 / 59.1 k)
+    rank_lanes = args.lanes if args.lanes > 0 else (2 if (hi - lo) >= 2_000_000 else 1)
+    sharded = ShardedEngine(eng, max_topn=topn, always_gather=force_sharded, lanes=rank_lanes) if (world > 1 or force_sharded) else None
     out_keys = torch.zeros(topn, dtype=torch.int64, device=dev)
 
     # A stream of single queries: the merge of query k rides in the scan launch of query
@@ -1394,7 +1399,7 @@ def main():
                                f"row-sharded across {world} MI355X, one process per GPU, one all-gather of {topn} keys/rank "
                                + ("(BASELINE configs[3])" if (n == 10_000_000 and topn == 100) else "")),
                 "rows": n, "topn": topn, "rows_per_gpu": hi - lo, "queries_per_step": 1,
-                "lanes": n_lanes,
+                "lanes": n_lanes if sharded is None else rank_lanes,
                 "lanes_note": (f"the stream of queries is dealt over {n_lanes} lanes of one handle (mi355rec_create_lane: the same rows and replicas, "
                                "own stream state), each on its own HIP stream — a handle's launches form one chain and cannot overlap each "
                                "other, two chains fill each other's ramps; `single_lane` is the same stream through one handle"

@@ -524,7 +524,9 @@ class ShardedEngine:
     enqueued on the current stream; nothing synchronises the host.
     """
 
-    def __init__(self, local, max_topn: int, group=None, device=None, always_gather: bool = False):
+    def __init__(self, local, max_topn: int, group=None, device=None, always_gather: bool = False, lanes: int = 1):
+        """lanes > 1: the windowed stream of single queries is dealt over that many lanes of `local` (CosineEngine.lane(): the
+        same rows and replicas, own stream state), each on its own stream — a rank's launches then overlap as on one GPU."""
         import torch
         import torch.distributed as dist
 
@@ -545,6 +547,14 @@ class ShardedEngine:
             device if device is not None else "cuda").type == "cuda"
         dev = device if device is not None else torch.device("cuda", local.device)
         self.device = dev
+        self._lanes = [local]
+        self._lane_streams = [None]
+        if int(lanes) > 1 and hasattr(local, "lane"):
+            self._lanes = [local] + [local.lane() for _ in range(int(lanes) - 1)]
+            self._lane_streams = [ln.own_stream() for ln in self._lanes]
+            self._lane_ev = [torch.cuda.Event() for _ in self._lanes]      # "this lane's launches so far" -> the collective's stream
+            self._buf_ev = [None, None]                                    # "window buffer b has been gathered" -> the lanes
+        self._w_calls = 0
         self.local_keys = torch.zeros(self.max_topn, dtype=torch.int64, device=dev)
         self.gathered = torch.zeros(self.world * self.max_topn, dtype=torch.int64, device=dev)
         self.out_keys = torch.zeros(self.max_topn, dtype=torch.int64, device=dev)
@@ -605,18 +615,48 @@ class ShardedEngine:
             self._w_idx = [torch.full((w * k,), -1, dtype=torch.int64, device=dev) for _ in range(2)]
             self._w_score = [torch.zeros(w * k, dtype=torch.float32, device=dev) for _ in range(2)]
             self._w_shape = (w, k)
+            if len(self._lanes) > 1:   # (the lanes' streams do not wait for the stream that just zeroed these buffers)
+                torch.cuda.current_stream().synchronize()
+                self._buf_ev = [None, None]
+            # a real engine underneath (not a test double): the call bound once — output pointers per slot instead of a tensor
+            # slice per query, the handle and the lane's stream resolved here (this loop is what every rank runs per query:
+            # 15 us of Python per query made eight ranks no faster than one)
+            self._w_fast = None
+            if all(hasattr(ln, "_h") and hasattr(ln, "_lib") for ln in self._lanes):
+                self._w_ptrs = [[ctypes.c_void_p(t.data_ptr() + s * k * 8) for s in range(w)] for t in self._w_local]
+                self._w_fast = [(ln._lib.mi355rec_enqueue_query_keys_streamed, ln._h,
+                                 ln._stream_ptr(ls) if ls is not None else None) for ln, ls in zip(self._lanes, self._lane_streams)]
             self._w_count = 0
             self._w_cur = 0
             self._w_pending = None
         slot, buf = self._w_count, self._w_cur
-        self.local.enqueue_query_keys_streamed(query, exclude_global, k, self._w_local[buf][slot * k:(slot + 1) * k])
+        nl = len(self._lanes)
+        lane = self._w_calls % nl
+        self._w_calls += 1
+        if nl > 1 and slot == 0 and self._buf_ev[buf] is not None:
+            for ls in self._lane_streams:   # this buffer's previous window has been gathered before a lane writes to it again
+                ls.wait_event(self._buf_ev[buf])
+        if self._w_fast is not None:
+            fn, h, sp = self._w_fast[lane]
+            q = query if (isinstance(query, np.ndarray) and query.dtype == np.float32 and query.size == capi.DIM
+                          and query.flags.c_contiguous) else _np_f32(query).reshape(capi.DIM)
+            rc = fn(h, ctypes.c_void_p(q.ctypes.data), int(exclude_global), k, self._w_ptrs[buf][slot],
+                    sp if sp is not None else CosineEngine._stream_ptr(None))
+            if rc:
+                capi.check(rc, h)
+        elif nl > 1:
+            self._lanes[lane].enqueue_query_keys_streamed(query, exclude_global, k, self._w_local[buf][slot * k:(slot + 1) * k],
+                                                          stream=self._lane_streams[lane])
+        else:
+            self.local.enqueue_query_keys_streamed(query, exclude_global, k, self._w_local[buf][slot * k:(slot + 1) * k])
         self._w_count += 1
         done = 0
-        if self._w_pending is not None and self._w_count >= 2:   # the window before is complete behind this call
+        lag = 2 * nl   # a lane runs one call behind and its merge rides in the call after that: two calls PER LANE
+        if self._w_pending is not None and self._w_count >= lag:   # the window before is complete behind this call
             done = self._merge_window(*self._w_pending)
             self._w_pending = None
         if self._w_count == w:
-            if w >= 3:   # (a smaller window would fill again before its predecessor is two calls old)
+            if w >= lag + 1:   # (a smaller window would fill again before its predecessor is `lag` calls old)
                 self._w_pending = (buf, w)
                 self._w_cur = 1 - buf
                 self._w_count = 0
@@ -630,6 +670,11 @@ class ShardedEngine:
         w, k = self._w_shape
         need = cnt * k
         local = self._w_local[buf][:need]
+        if len(self._lanes) > 1:   # the collective's stream waits for what every lane has been given so far
+            cur = self._torch.cuda.current_stream()
+            for ls, ev in zip(self._lane_streams, self._lane_ev):
+                ev.record(ls)
+                cur.wait_event(ev)
         if self.world == 1 and not self.always_gather:
             gathered = local
         else:
@@ -637,6 +682,10 @@ class ShardedEngine:
             self._all_gather(gathered, local)
         self.local.enqueue_merge_keys_batch(gathered, self.world, k, need, k, cnt, k, self._w_keys[buf][:need],
                                             self._w_idx[buf][:need], self._w_score[buf][:need])
+        if len(self._lanes) > 1:
+            ev = self._torch.cuda.Event()
+            ev.record(self._torch.cuda.current_stream())
+            self._buf_ev[buf] = ev
         self.window_keys = self._w_keys[buf][:need].view(cnt, k)
         self.window_idx = self._w_idx[buf][:need].view(cnt, k)
         self.window_score = self._w_score[buf][:need].view(cnt, k)
@@ -655,7 +704,8 @@ class ShardedEngine:
         pending = getattr(self, "_w_pending", None)
         if cnt == 0 and pending is None:
             return 0
-        self.local.enqueue_flush()
+        for ln, ls in zip(self._lanes, self._lane_streams):
+            ln.enqueue_flush(stream=ls) if ls is not None else ln.enqueue_flush()
         done = 0
         if pending is not None:
             done = self._merge_window(*pending)

@@ -51,6 +51,22 @@ def _worker(rank, world, port, n_rows, result_dir):
             want = oracle.scores(f, f[q])
             ci, _ = oracle.topn_canonical(want, int(q), 50)
             assert got[b].tolist() == ci.tolist(), (rank, "batch", q)
+        # the windowed stream of single queries over two lanes per rank (ShardedEngine(lanes=2)): every rank makes the same calls
+        sh2 = ShardedEngine(eng, max_topn=100, lanes=2)
+        stream_rows = [11, n_rows // 2, n_rows - 1, 5, 99, n_rows // 3, 7, 8, 9, 10, 12, 13, 100]
+        got = []
+        for q in stream_rows:
+            if sh2.enqueue_query_windowed(f[q], q, 20, window=5):
+                torch.cuda.synchronize()
+                got.extend(sh2.window_idx.cpu().numpy())
+        sh2.flush_window()
+        torch.cuda.synchronize()
+        for _keys, widx, _sc in sh2.merged_windows:
+            got.extend(widx.cpu().numpy())
+        assert len(got) == len(stream_rows), (rank, len(got))
+        for q, idx in zip(stream_rows, got):
+            ci, _ = oracle.topn_canonical(oracle.scores(f, f[q]), int(q), 20)
+            assert idx.tolist() == ci.tolist(), (rank, "lanes", q)
         np.savez(Path(result_dir) / f"rank{rank}.npz", **out)
         eng.close()
     finally:
