@@ -91,6 +91,30 @@ def test_randomised_parity():
                     assert not got[cnt:].any()
                 except AssertionError as e:  # pragma: no cover
                     raise AssertionError(f"case {case} streamed: rows {rows} q {r} topn {s_topn}: {e}") from e
+            # the same kind of stream dealt over two LANES of the handle (shared rows and replicas, own stream state), each on
+            # the stream the library created with it
+            if case % 3 == 0:
+                lane = eng.lane()
+                pair, pstreams = [eng, lane], [eng.own_stream(), lane.own_stream()]
+                l_rows = [int(r) for r in rng.integers(0, rows, size=5)]
+                l_keys = [torch.zeros(s_topn, dtype=torch.int64, device="cuda") for _ in l_rows]
+                torch.cuda.synchronize()
+                for i, (r, k) in enumerate(zip(l_rows, l_keys)):
+                    pair[i % 2].enqueue_row_keys_streamed(r, s_topn, k, stream=pstreams[i % 2])
+                for e, ps in zip(pair, pstreams):
+                    e.enqueue_flush(stream=ps)
+                torch.cuda.synchronize()
+                lane.close()
+                for r, k in zip(l_rows, l_keys):
+                    want = oracle.scores(f, f[r])
+                    got = k.cpu().numpy().view(np.uint64)
+                    cnt = min(s_topn, rows - 1)
+                    idx = (~got[:cnt] & np.uint64(0xffffffff)).astype(np.int64)
+                    try:
+                        assert_topn_matches(idx, None, want, r, s_topn, ref_idx=oracle.topn_heap(want, r, s_topn))
+                        assert not got[cnt:].any()
+                    except AssertionError as e:  # pragma: no cover
+                        raise AssertionError(f"case {case} lanes: rows {rows} q {r} topn {s_topn}: {e}") from e
             eng.set_batch_path(1 if case % 2 else 0)   # odd cases: the exact multi-query pass; even: AUTO
             idx, sc, counts = eng.query_batch_topn(f[qrows], excl, topn)
             for b in range(batch):
