@@ -1285,7 +1285,35 @@ def main():
                 "queued_to_exact_scan": diag["queued_queries"], "special_rows": diag["special_rows"],
             }
 
+        def batched_over_lanes(engine, q_d, rows_d, ref_keys, reps=16, lane=None):
+            """The same 1024-query batches dealt alternately over TWO LANES of the handle, each on its own stream: a batch's
+            passes are VALU-bound with the chip full, but its small latency-bound launches (prepare, select, finalize, the
+            queue's: ~60 us of 600) run beside the other lane's passes.  Aggregate figures; one batch's own latency is
+            `ms_per_call` of the parent object."""
+            ln = lane if lane is not None else engine.lane()
+            pair, pst = [engine, ln], [engine.own_stream(), ln.own_stream()]
+            lk = [[torch.zeros(bq * topn, dtype=torch.int64, device=dev) for _ in range(2)] for _ in pair]
+            torch.cuda.synchronize()
+
+            def run(count):
+                for k in range(count):
+                    pair[k & 1].enqueue_batch_keys_dev(q_d, rows_d, topn, lk[k & 1][(k >> 1) & 1], stream=pst[k & 1])
+                torch.cuda.synchronize()
+            run(4)
+            t1 = time.perf_counter()
+            run(reps)
+            d2 = (time.perf_counter() - t1) / reps
+            same = bool(torch.equal(lk[1][0], ref_keys)) and bool(torch.equal(lk[0][0], ref_keys))
+            status = ln.lane_status()
+            if lane is None:
+                ln.close()
+            return {"lanes": 2, "ms_per_call": round(d2 * 1e3, 4), "value": round(bq / d2, 1), "unit": "queries/s",
+                    "matches_one_handle": same, "lane_stream": status,
+                    "note": "aggregate over two lanes of the handle (mi355rec_create_lane), batches dealt alternately, each lane on its own stream"}
+
         batched = measure_batched(eng, bq_step, hi - lo)
+        if sharded is None and world == 1 and n_lanes > 1:
+            batched["two_lanes"] = batched_over_lanes(eng, q_dev, bq_dev, bq_keys, lane=lanes[1])
         # the first and last query of the batch against the single-query path
         ok = True
         for k in (0, bq - 1):
@@ -1315,6 +1343,8 @@ def main():
                 batched["configs4_shard"] = measure_batched(eng5, lambda: eng5.enqueue_batch_keys_dev(q5, q5_rows, topn, k5), c5_rows)
                 batched["configs4_shard"]["workload"] = ("one 12.5 M-row shard of BASELINE configs[4] (100 M rows over 8 GPUs), 1024 "
                                                          "device-resident queries per call, top-100")
+                if n_lanes > 1:
+                    batched["configs4_shard"]["two_lanes"] = batched_over_lanes(eng5, q5, q5_rows, k5)
                 # two of its queries against the single-query path of the same handle
                 ok5 = True
                 one = torch.zeros(topn, dtype=torch.int64, device=dev)
@@ -1400,6 +1430,7 @@ def main():
                                + ("(BASELINE configs[3])" if (n == 10_000_000 and topn == 100) else "")),
                 "rows": n, "topn": topn, "rows_per_gpu": hi - lo, "queries_per_step": 1,
                 "lanes": n_lanes if sharded is None else rank_lanes,
+                "lane_streams": ([ln.lane_status() for ln in lanes[1:]] if (sharded is None and n_lanes > 1) else None),
                 "lanes_note": (f"the stream of queries is dealt over {n_lanes} lanes of one handle (mi355rec_create_lane: the same rows and replicas, "
                                "own stream state), each on its own HIP stream — a handle's launches form one chain and cannot overlap each "
                                "other, two chains fill each other's ramps; `single_lane` is the same stream through one handle"

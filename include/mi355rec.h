@@ -212,6 +212,11 @@ int mi355rec_create_lane(mi355rec_t* parent, mi355rec_t** out);
  * hipStreamNonBlocking: it does NOT wait for work on the null stream (e.g. a memset of the buffer a query writes to —
  * synchronise or use an event first). */
 void* mi355rec_own_stream(mi355rec_t* h);
+/* What mi355rec_create_lane found when it chose the lane's stream: it times a small kernel on the parent's stream alone and
+ * on both streams at once, and replaces the lane's stream (each new stream is bound to the next hardware queue) until the pair
+ * runs side by side.  *stream_attempts = streams tried (0 on a handle that is not a lane); *overlaps_parent = 1 side by side,
+ * 0 none of them did (the lane then buys nothing: use one handle), -1 not testable (under 10 000 rows). */
+int mi355rec_lane_status(const mi355rec_t* h, int* stream_attempts, int* overlaps_parent);
 
 /* Replaces Recommender::~Recommender (Recommender.cu:86-98). */
 void mi355rec_destroy(mi355rec_t* h);

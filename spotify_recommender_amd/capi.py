@@ -83,6 +83,7 @@ SIGNATURES = {
     "mi355rec_last_error": (c_char_p, [c_void_p]),
     "mi355rec_create_lane": (c_int, [c_void_p, POINTER(c_void_p)]),
     "mi355rec_own_stream": (c_void_p, [c_void_p]),
+    "mi355rec_lane_status": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     "mi355rec_stats": (c_int, [c_void_p, POINTER(Stats)]),
     "mi355rec_stats_sized": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, POINTER(ctypes.c_size_t)]),
     "mi355rec_scores_row": (c_int, [c_void_p, c_int64, c_void_p]),

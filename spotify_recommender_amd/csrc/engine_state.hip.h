@@ -100,6 +100,8 @@ struct mi355rec {
     };
     SharedRows* shared = nullptr;
     bool is_lane = false;
+    int lane_stream_attempts = 0;   // streams mi355rec_create_lane went through until one overlapped the parent's (0: not tested)
+    int lane_overlaps = -1;         // 1: the lane's stream and its parent's run kernels side by side; 0: no such stream was found; -1: not tested
 
     int cus = 0;
     int grid = 0;

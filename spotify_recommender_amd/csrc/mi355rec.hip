@@ -92,6 +92,57 @@ void mi355rec_destroy(mi355rec_t* h) {
 
 void* mi355rec_own_stream(mi355rec_t* h) { return h ? static_cast<void*>(h->stream) : nullptr; }
 
+namespace {
+// Do kernels on a's own stream and on b's run side by side?  A process has few hardware queues (four by default) and a stream
+// is bound to one of them when it is created; streams that share a queue run their kernels strictly one after the other,
+// and then two lanes are worth exactly one handle.  Measured, not guessed: a one-workgroup read of 480 KB of the rows
+// (~30 us) on a's stream alone, then one on each stream at once; side by side the pair takes what one takes.
+// Returns 1 / 0, or -1 when it cannot tell (a shard of under 10 000 rows, or a HIP error).
+int streams_overlap(mi355rec* a, mi355rec* b) {
+    constexpr int64_t kVec = 30000;   // float4s: 10 000 rows
+    if (a->n * 3 < kVec || !a->d_seed_keys || !b->d_seed_keys) return -1;
+    hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+    for (hipEvent_t& x : e)
+        if (hipEventCreate(&x) != hipSuccess) {
+            for (hipEvent_t y : e)
+                if (y) (void)hipEventDestroy(y);
+            return -1;
+        }
+    const float4* rows = reinterpret_cast<const float4*>(a->d_feats);
+    auto once = [&](bool both) -> float {
+        (void)hipEventRecord(e[0], a->stream);
+        hipLaunchKernelGGL(stream_probe_kernel, dim3(1), dim3(kProbeBlock), 0, a->stream, rows, kVec, reinterpret_cast<uint32_t*>(a->d_seed_keys));
+        if (both)
+            hipLaunchKernelGGL(stream_probe_kernel, dim3(1), dim3(kProbeBlock), 0, b->stream, rows, kVec, reinterpret_cast<uint32_t*>(b->d_seed_keys));
+        (void)hipEventRecord(e[1], a->stream);
+        if (both) (void)hipEventRecord(e[2], b->stream);
+        if (hipStreamSynchronize(a->stream) != hipSuccess || hipStreamSynchronize(b->stream) != hipSuccess) return -1.0f;
+        float t1 = 0.f, t2 = 0.f;
+        if (hipEventElapsedTime(&t1, e[0], e[1]) != hipSuccess) return -1.0f;
+        if (both && hipEventElapsedTime(&t2, e[0], e[2]) != hipSuccess) return -1.0f;
+        return t1 > t2 ? t1 : t2;
+    };
+    (void)once(true);   // (warm: code objects, the rows in the cache)
+    float alone = once(false), pair = once(true);
+    for (int k = 0; k < 2; ++k) {   // the better of three
+        const float a2 = once(false), p2 = once(true);
+        if (a2 > 0.f && (alone <= 0.f || a2 < alone)) alone = a2;
+        if (p2 > 0.f && (pair <= 0.f || p2 < pair)) pair = p2;
+    }
+    for (hipEvent_t x : e) (void)hipEventDestroy(x);
+    (void)hipGetLastError();
+    if (alone <= 0.f || pair <= 0.f) return -1;
+    return pair < 1.5f * alone ? 1 : 0;
+}
+}  // namespace
+
+int mi355rec_lane_status(const mi355rec_t* h, int* stream_attempts, int* overlaps_parent) {
+    if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    if (stream_attempts) *stream_attempts = h->lane_stream_attempts;
+    if (overlaps_parent) *overlaps_parent = h->lane_overlaps;
+    return MI355REC_OK;
+}
+
 int mi355rec_create_lane(mi355rec_t* parent, mi355rec_t** out) {
     if (out) *out = nullptr;
     if (!parent || !out) return fail(parent, MI355REC_ERR_INVALID_ARG, "null argument");
@@ -131,6 +182,17 @@ int mi355rec_create_lane(mi355rec_t* parent, mi355rec_t** out) {
     lane->margin_mix = parent->margin_mix;
     lane->margin_mfma = parent->margin_mfma;
     lane->replica_build_ms = 0.f;
+    // A stream for the lane that really runs beside the parent's: test the one create_common made, and while the two share a
+    // hardware queue replace it (every new stream is bound to the next queue), at most once round all of them.
+    for (int attempt = 1; attempt <= 6; ++attempt) {
+        lane->lane_stream_attempts = attempt;
+        lane->lane_overlaps = streams_overlap(parent, lane);
+        if (lane->lane_overlaps != 0) break;   // side by side, or cannot tell
+        hipStream_t fresh = nullptr;
+        if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) break;
+        (void)hipStreamDestroy(lane->stream);
+        lane->stream = fresh;
+    }
     *out = lane;
     return MI355REC_OK;
 }

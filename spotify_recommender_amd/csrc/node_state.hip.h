@@ -68,7 +68,8 @@ struct Shard {
     int device = 0;
     int64_t lo = 0, hi = 0;
     mi355rec_t* engine = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // the engine's own stream (mi355rec_own_stream): not this struct's to destroy
+    bool owns_stream = false;
     hipEvent_t done = nullptr;          // this shard's keys are in place
     mi355rec_key_t* local_keys = nullptr;   // RCCL transport: send buffer on the shard's device
     mi355rec_key_t* gathered = nullptr;     // RCCL transport: receive buffer on the shard's device

@@ -85,7 +85,7 @@ void mi355rec_sharded_destroy(mi355rec_sharded_t* h) {
         if (s.local_keys) (void)hipFree(s.local_keys);
         if (s.gathered) (void)hipFree(s.gathered);
         if (s.done) (void)hipEventDestroy(s.done);
-        if (s.stream) (void)hipStreamDestroy(s.stream);
+        if (s.stream && s.owns_stream) (void)hipStreamDestroy(s.stream);
     }
     if (!h->shards.empty() && hipSetDevice(h->shards[0].device) == hipSuccess) {
         if (h->gather0) (void)hipFree(h->gather0);
@@ -151,8 +151,12 @@ int create_on(const float* feats_host, int64_t n, int dim, const int* devices, i
                                  : mi355rec_create(s.hi > s.lo ? feats_host + s.lo * MI355REC_DIM : nullptr, s.hi - s.lo, dim, s.device,
                                                    s.lo, &s.engine);
         if (rc != MI355REC_OK) return bail(sfail(nullptr, rc, "shard %d on device %d: %s", r, s.device, mi355rec_last_global_error()));
-        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess)
+        // The shard works on the stream its engine was created with: for a lane that is the stream mi355rec_create_lane CHOSE
+        // because kernels on it run beside the first replica's (a hardware queue of its own) — a stream made here would be
+        // bound to whichever queue is next, possibly the same one.
+        s.stream = static_cast<hipStream_t>(mi355rec_own_stream(s.engine));
+        s.owns_stream = false;
+        if (!s.stream || hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess)
             return bail(sfail(nullptr, MI355REC_ERR_HIP, "stream / event creation on device %d failed", s.device));
     }
     // Peer mappings.  Stores into the first device's gather buffers need ITS memory mapped on every

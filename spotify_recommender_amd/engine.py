@@ -78,6 +78,12 @@ class CosineEngine:
         capi.check(self._lib.mi355rec_create_lane(self._h, ctypes.byref(other._h)), self._h)
         return other
 
+    def lane_status(self) -> dict:
+        """What mi355rec_create_lane found for this lane's stream: {"stream_attempts", "overlaps_parent" (1 / 0 / -1)}."""
+        a, o = ctypes.c_int(0), ctypes.c_int(-1)
+        capi.check(self._lib.mi355rec_lane_status(self._h, ctypes.byref(a), ctypes.byref(o)), self._h)
+        return {"stream_attempts": a.value, "overlaps_parent": o.value}
+
     def own_stream(self):
         """The HIP stream the library created with this handle, as a torch stream (mi355rec_own_stream): the stream to run a
         lane on — streams taken from torch's pool later may share a hardware queue, and then lanes do not overlap."""

@@ -95,3 +95,20 @@ def test_the_group_outlives_its_parent_and_refuses_a_rebuild(catalogue):
     idx, sc = lane2.query_row_topn(row + 1, topn)
     assert_topn_matches(idx, sc, oracle.scores(f[:1_050_000], f[row + 1]), row + 1, topn)
     lane2.close()
+
+
+def test_a_lane_gets_a_stream_that_runs_beside_its_parents(catalogue):
+    """mi355rec_create_lane times a small kernel on the parent's stream alone and on both streams at once and goes through
+    streams until the pair overlaps (a process has four hardware queues; streams that share one serialise): every lane of a
+    group of five reports a stream that overlaps the parent's, found within six attempts — and a torch-pool stream pair made
+    here, with nine streams alive, is allowed to collide (that is the trap this guards against)."""
+    from spotify_recommender_amd.engine import CosineEngine
+    _, t = catalogue
+    with CosineEngine(t) as eng:
+        assert eng.lane_status() == {"stream_attempts": 0, "overlaps_parent": -1}
+        lanes = [eng.lane() for _ in range(4)]
+        for ln in lanes:
+            st = ln.lane_status()
+            assert st["overlaps_parent"] == 1 and 1 <= st["stream_attempts"] <= 6, st
+        for ln in lanes:
+            ln.close()
