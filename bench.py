@@ -245,6 +245,7 @@ def clustered_object(args, torch, np, dev, shapes):
     — where an evenly spaced sample misses the query's own cluster and the launch-wide bound has to come from the excluded
     row's neighbourhood (csrc/handoff.hip.h).  Same sizes as the headline (rows x top-N), its own catalogue and handle per
     shape; a few results of each are checked against the oracle."""
+    import ctypes
     from oracle import oracle
     from spotify_recommender_amd import CosineEngine, capi
     from spotify_recommender_amd.engine import unpack_keys
@@ -264,6 +265,27 @@ def clustered_object(args, torch, np, dev, shapes):
             eng.set_replica(capi.REPLICA_AUTO)
             shape["replica_q8_stream"], last = stream_leg(eng, torch, q_rows, topn, 200, 20)
             checks.append(last)
+            # the same stream over two lanes of the handle, each on its own stream
+            lane = eng.lane()
+            pair = [eng, lane]
+            calls = [e.bound_enqueue_row_keys_streamed(topn, e.own_stream()) for e in pair]
+            lrings = [[torch.zeros(topn, dtype=torch.int64, device=dev) for _ in range(4)] for _ in pair]
+            lptrs = [[ctypes.c_void_p(tt.data_ptr()) for tt in rs] for rs in lrings]
+            torch.cuda.synchronize()
+
+            def lanes_run(k0, k1):
+                for k in range(k0, k1):
+                    calls[k & 1](int(q_rows[k % len(q_rows)]), lptrs[k & 1][(k >> 1) & 3])
+                for e in pair:
+                    e.enqueue_flush(stream=e.own_stream())
+                torch.cuda.synchronize()
+            lanes_run(0, 40)
+            t1 = time.perf_counter()
+            lanes_run(40, 440)
+            dt2 = (time.perf_counter() - t1) / 400
+            checks.append((int(q_rows[439 % len(q_rows)]), lrings[1][(439 >> 1) & 3].clone()))
+            lane.close()
+            shape["replica_q8_stream_two_lanes"] = {"us_per_step": round(dt2 * 1e6, 2), "queries_per_s": round(1.0 / dt2, 1)}
             lat = []
             for k in range(100):
                 t1 = time.perf_counter()
