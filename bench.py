@@ -32,11 +32,10 @@ ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-BYTES_PER_ROW = 48      # algorithmic bytes per catalogue row per query
-FP32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 vector = fp32 matrix peak (configs[4]'s roofline)
-FP16_MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (never the 2:1-sparsity figure)
-FLOP_PER_PAIR = 24          # 12 mul + 12 add per (row, query) pair of the batched path
+from spotify_recommender_amd.benchlegs import (BYTES_PER_ROW, FLOP_PER_PAIR, FP16_MFMA_PEAK_TFLOPS, FP32_PEAK_TFLOPS,  # noqa: E402
+                                               HBM_PEAK_GBPS, clustered_object, config0_object, host_threads, preflight,
+                                               peer_access_matrix, probe_concurrent_gbps, probe_gbps_of, rank_group_report, roofline_bound,
+                                               stream_leg, traffic_fields)
 
 
 def parse_args():
@@ -51,8 +50,11 @@ def parse_args():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="skip the per-kernel HIP events (roofline.achieved becomes null)")
     ap.add_argument("--event-stride", type=int, default=0,
-                    help="time every k-th kernel launch inside the timed region (an event pair costs ~3 us); "
-                         "0 = choose so that at least 16 launches are timed")
+                    help="HIP events around every k-th scan launch of the UNTIMED pass that fills roofline.avg_kernel_ms "
+                         "(0 = choose so that 16 launches are timed, 3 in a short run)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the K-step timed region is run this many times back to back (each between barrier + synchronize pairs); "
+                         "`value` is the median run, `value_runs` lists them all")
     ap.add_argument("--batch", type=int, default=1024, help="queries per call of the batched (configs[4]) leg")
     ap.add_argument("--no-batched", action="store_true")
     ap.add_argument("--no-c5-shard", action="store_true",
@@ -128,386 +130,6 @@ def replica_desc(st):
             "scan_kernel", "f32", "fp32 rows (48 B/row")
 
 
-def traffic_fields():
-    """`roofline.traffic` is null in the line: HBM bytes come from PMC counters (separate rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE passes over this same command), which the timed process cannot read about itself — earlier rounds copied
-    the figure of a committed profile into the line, which is a citation, not a measurement.  The profiles are the
-    evidence."""
-    files = sorted((ROOT / "profiles").glob("*_pmc_hbm_traffic.json"))
-    return {"traffic": None,
-            "traffic_note": "not measurable from inside the run; per-launch HBM bytes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                            "FETCH doubled per the guide's gfx950 correction) are in profiles/"
-                            + (files[-1].name if files else "*_pmc_hbm_traffic.json")}
-
-
-def roofline_bound(alg_bytes: int) -> str:
-    """A buffer that a pass can still find in the 256 MiB Infinity Cache when it comes round again is not an HBM
-    stream: its rate is bound by the cache / fabric, and FETCH_SIZE counts cache hits as well (guide, HBM section)."""
-    return "infinity-cache" if alg_bytes <= 128 * 2**20 else "hbm"
-
-
-def host_threads(omp_max: int):
-    """Threads the CPU baseline may really use, and why: the affinity mask, the cgroup quota and BENCH_CPU_THREADS
-    (default 16 = the GPU box's CPU share per GPU) bound it, not the socket's core count."""
-    info = {"nproc": os.cpu_count(), "omp_max_threads": omp_max}
-    n = omp_max
-    try:
-        info["affinity"] = len(os.sched_getaffinity(0))
-        n = min(n, info["affinity"])
-    except Exception:
-        info["affinity"] = None
-    try:
-        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
-        info["cgroup_cpus"] = None if quota == "max" else round(int(quota) / int(period), 2)
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except Exception:
-        info["cgroup_cpus"] = None
-    info["thread_cap"] = int(os.environ.get("BENCH_CPU_THREADS", "16"))
-    info["thread_cap_source"] = "BENCH_CPU_THREADS" if "BENCH_CPU_THREADS" in os.environ else "default 16: a GPU box's CPU share per GPU"
-    n = max(1, min(n, info["thread_cap"]))
-    return n, info
-
-
-def probe_gbps_of(eng, torch, which, n_bytes, dev):
-    """The plain read-only stream over one buffer of the handle (csrc/kernels.hip.h, stream_probe_kernel), 20 timed
-    launches behind 3 untimed ones: GB/s, or None when the handle has no such buffer."""
-    from spotify_recommender_amd import capi
-    sink = torch.zeros(4096, dtype=torch.int32, device=dev)
-    try:
-        for _ in range(3):
-            eng.enqueue_stream_probe(sink, which=which)
-    except capi.Mi355Error:
-        return None
-    torch.cuda.synchronize()
-    eng.set_timing(True)
-    for _ in range(20):
-        eng.enqueue_stream_probe(sink, which=which)
-    torch.cuda.synchronize()
-    ms = float(eng.stats().last_scan_ms)
-    eng.set_timing(False)
-    return n_bytes / (ms * 1e-3) / 1e9 if ms > 0 else None
-
-
-def probe_concurrent_gbps(lanes, lane_streams, torch, which, n_bytes, dev):
-    """The same plain read-only stream from EVERY lane at once, each on its own HIP stream, over the one buffer they share: the
-    aggregate rate while they overlap = lanes x bytes / the mean duration of a probe launch with the others' in flight (lane 0's
-    HIP events over 30 launches) — a kernel-level ceiling without launch gaps, so a sustained rate held against it is on the safe
-    side.  (A wall-clock version of this probe is bounded by how fast Python can enqueue 19 us kernels, not by the chip: 6.4 TB/s
-    where the events say 8.4 and MI355X_MICROARCH.md measures 7.4-8.6 TB/s for Infinity-Cache-served reads.)  None when the handle
-    has no such buffer."""
-    from spotify_recommender_amd import capi
-    sinks = [torch.zeros(4096, dtype=torch.int32, device=dev) for _ in lanes]
-    torch.cuda.synchronize()
-    try:
-        for _ in range(3):
-            for ln, ls, sk in zip(lanes, lane_streams, sinks):
-                ln.enqueue_stream_probe(sk, stream=ls, which=which)
-    except capi.Mi355Error:
-        return None
-    torch.cuda.synchronize()
-    lanes[0].set_timing(True)
-    for _ in range(30):
-        for ln, ls, sk in zip(lanes, lane_streams, sinks):
-            ln.enqueue_stream_probe(sk, stream=ls, which=which)
-    torch.cuda.synchronize()
-    ms = float(lanes[0].stats().last_scan_ms)
-    lanes[0].set_timing(False)
-    return len(lanes) * n_bytes / (ms * 1e-3) / 1e9 if ms > 0 else None
-
-
-def stream_leg(eng, torch, rows, topn, steps, warmup):
-    """A stream of single queries (merge riding in the next launch, flush inside the timed region): us per step, the scan
-    kernel's mean time from the library's HIP events, rows sent to the exact chain per query, the last result."""
-    ring = [torch.zeros(topn, dtype=torch.int64, device="cuda") for _ in range(4)]
-    for k in range(warmup):
-        eng.enqueue_row_keys_streamed(int(rows[k % len(rows)]), topn, ring[k % 4])
-    eng.enqueue_flush()
-    torch.cuda.synchronize()
-    c0 = eng.replica_counters()
-    eng.set_timing(max(1, steps // 16))
-    t0 = time.perf_counter()
-    for k in range(steps):
-        eng.enqueue_row_keys_streamed(int(rows[(warmup + k) % len(rows)]), topn, ring[k % 4])
-    eng.enqueue_flush()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    k_ms = float(eng.stats().last_scan_ms)
-    eng.set_timing(False)
-    c1 = eng.replica_counters()
-    return {"us_per_step": round(dt * 1e6, 2), "queries_per_s": round(1.0 / dt, 1), "scan_kernel_us": round(k_ms * 1e3, 2),
-            "rows_to_exact_chain_per_query": round((c1["rescored_rows"] - c0["rescored_rows"]) / steps, 1)}, \
-        (int(rows[(warmup + steps - 1) % len(rows)]), ring[(steps - 1) % 4].clone())
-
-
-def clustered_object(args, torch, np, dev, shapes):
-    """Every route over catalogues whose similar rows lie NEXT TO EACH OTHER (a CSV grouped by genre: DataManager.cpp:244-250,299)
-    — where an evenly spaced sample misses the query's own cluster and the launch-wide bound has to come from the excluded
-    row's neighbourhood (csrc/handoff.hip.h).  Same sizes as the headline (rows x top-N), its own catalogue and handle per
-    shape; a few results of each are checked against the oracle."""
-    import ctypes
-    from oracle import oracle
-    from spotify_recommender_amd import CosineEngine, capi
-    from spotify_recommender_amd.engine import unpack_keys
-    from spotify_recommender_amd.synth import clustered_catalogue
-    n, topn = args.rows, args.topn
-    out = {"rows": n, "topn": topn, "generator": "spotify_recommender_amd.synth.clustered_catalogue(contiguous=True), seed 777",
-           "queries": "catalogue rows (k * 104729) mod N: spread over the whole shard", "shapes": []}
-    q_rows = [(k * 104729) % n for k in range(2048)]
-    for clusters, spread, ramp in shapes:
-        t = clustered_catalogue(n, spread, clusters=clusters, contiguous=True, ramp=ramp, device=dev)
-        shape = {"clusters": clusters, "rows_per_cluster": n // clusters, "spread": spread, "genre_ramp": ramp}
-        checks = []
-        with CosineEngine(t) as eng:
-            eng.set_replica(capi.REPLICA_OFF)
-            shape["fp32_rows_stream"], last = stream_leg(eng, torch, q_rows, topn, 100, 10)
-            checks.append(last)
-            eng.set_replica(capi.REPLICA_AUTO)
-            shape["replica_q8_stream"], last = stream_leg(eng, torch, q_rows, topn, 200, 20)
-            checks.append(last)
-            # the same stream over two lanes of the handle, each on its own stream
-            lane = eng.lane()
-            pair = [eng, lane]
-            calls = [e.bound_enqueue_row_keys_streamed(topn, e.own_stream()) for e in pair]
-            lrings = [[torch.zeros(topn, dtype=torch.int64, device=dev) for _ in range(4)] for _ in pair]
-            lptrs = [[ctypes.c_void_p(tt.data_ptr()) for tt in rs] for rs in lrings]
-            torch.cuda.synchronize()
-
-            def lanes_run(k0, k1):
-                for k in range(k0, k1):
-                    calls[k & 1](int(q_rows[k % len(q_rows)]), lptrs[k & 1][(k >> 1) & 3])
-                for e in pair:
-                    e.enqueue_flush(stream=e.own_stream())
-                torch.cuda.synchronize()
-            lanes_run(0, 40)
-            t1 = time.perf_counter()
-            lanes_run(40, 440)
-            dt2 = (time.perf_counter() - t1) / 400
-            checks.append((int(q_rows[439 % len(q_rows)]), lrings[1][(439 >> 1) & 3].clone()))
-            lane.close()
-            shape["replica_q8_stream_two_lanes"] = {"us_per_step": round(dt2 * 1e6, 2), "queries_per_s": round(1.0 / dt2, 1)}
-            lat = []
-            for k in range(100):
-                t1 = time.perf_counter()
-                res = eng.query_row_topn(q_rows[300 + k], topn)
-                lat.append((time.perf_counter() - t1) * 1e6)
-            lat.sort()
-            shape["one_query_alone_p50_us"] = round(lat[len(lat) // 2], 1)
-            checks.append((q_rows[399], res))
-            if topn <= 128:
-                for nb in (12, 32):
-                    sel = np.array(q_rows[400:400 + nb], dtype=np.int64)
-                    qv = t[torch.from_numpy(sel).to(dev)].cpu().numpy()
-                    rings = [torch.zeros(nb * topn, dtype=torch.int64, device=dev) for _ in range(4)]
-                    for k in range(4):
-                        eng.enqueue_batch_keys_streamed(qv, sel, topn, rings[k % 4])
-                    eng.enqueue_flush()
-                    torch.cuda.synchronize()
-                    eng.set_timing(1)
-                    t1 = time.perf_counter()
-                    for k in range(20):
-                        eng.enqueue_batch_keys_streamed(qv, sel, topn, rings[k % 4])
-                    eng.enqueue_flush()
-                    torch.cuda.synchronize()
-                    dt = (time.perf_counter() - t1) / 20
-                    k_ms = float(eng.stats().last_scan_ms)
-                    eng.set_timing(False)
-                    shape[f"pass_of_{nb}_streamed"] = {"us_per_call": round(dt * 1e6, 1), "queries_per_s": round(nb / dt, 1),
-                                                       "launch_kernel_us": round(k_ms * 1e3, 1)}
-                    checks.append((int(sel[nb - 1]), rings[3][(nb - 1) * topn:nb * topn].clone()))
-                bq = min(args.batch, 1024)
-                bsel = torch.from_numpy(np.array(q_rows[500:500 + bq], dtype=np.int64)).to(dev)
-                qd = t[bsel].contiguous()
-                keys = torch.zeros(bq * topn, dtype=torch.int64, device=dev)
-                eng.enqueue_batch_keys_dev(qd, bsel, topn, keys)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(5):
-                    eng.enqueue_batch_keys_dev(qd, bsel, topn, keys)
-                torch.cuda.synchronize()
-                dt = (time.perf_counter() - t1) / 5
-                d = eng.batched_last_counters()
-                shape[f"batch_of_{bq}"] = {"ms_per_call": round(dt * 1e3, 4), "queries_per_s": round(bq / dt, 1),
-                                           "candidates_per_query": round(d["candidates_total"] / max(1, bq - d["queued_queries"]), 1),
-                                           "candidates_max": d["candidates_max"], "queued_to_exact_scan": d["queued_queries"]}
-                checks.append((q_rows[500 + bq // 2], keys[(bq // 2) * topn:(bq // 2 + 1) * topn].clone()))
-        host = t.cpu().numpy()
-        ok = True
-        for row, got in checks:
-            if isinstance(got, tuple):
-                idx, sc = got
-            else:
-                idx, sc = unpack_keys(got.cpu().numpy())
-            want = oracle.scores(host, host[row], threads=0)
-            ci, cs = oracle.topn_canonical(want, row, topn)
-            ok = ok and np.asarray(idx).tolist() == ci.tolist() and bool(np.array_equal(np.asarray(sc), cs + np.float32(0)))
-        shape["verified_against_oracle"] = bool(ok)
-        shape["verified_queries"] = len(checks)
-        out["shapes"].append(shape)
-        del t, host
-        torch.cuda.empty_cache()
-    return out
-
-
-def config0_object(torch, np):
-    """BASELINE configs[0]: a 114 000-track Spotify-shaped CSV (114 genres x 1000 tracks, grouped by genre like the Kaggle
-    file) -> DataManager preprocessing -> songs_data.bin -> top-10, on the GPU path (a query alone and a stream) and — in a
-    FRESH CHILD PROCESS started with the devices hidden, never a re-exec of this one — on the product's own CPU backend
-    (csrc/cpu_backend.cpp), with the oracle's OpenMP port on the same features beside them and the load + initialize times
-    of SURVEY.md §8(f) rank 3."""
-    import ctypes
-    import subprocess
-    import tempfile
-    from oracle import oracle
-    from spotify_recommender_amd import CosineEngine, build, capi
-    build.build_shim()
-    L = ctypes.CDLL(str(build.LIB_SHIM))
-    L.shim_preprocess.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
-    L.shim_fast_load.argtypes = [ctypes.c_char_p]
-    L.shim_fast_load.restype = ctypes.c_void_p
-    L.shim_fast_initialize.argtypes = [ctypes.c_void_p]
-    L.shim_fast_free.argtypes = [ctypes.c_void_p]
-    L.shim_load.argtypes = [ctypes.c_char_p]
-    L.shim_load.restype = ctypes.c_void_p
-    L.shim_free.argtypes = [ctypes.c_void_p]
-    L.shim_song_features.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
-    n, topn = 114_000, 10
-    out = {"workload": "BASELINE configs[0]: 114 000-track CSV (114 genres x 1000, grouped by genre), 12 features, top-10",
-           "rows": n, "topn": topn}
-    with tempfile.TemporaryDirectory() as tmp:
-        tmp = Path(tmp)
-        rng = np.random.default_rng(114)
-        cols = ("track_id,track_name,artists,danceability,energy,key,loudness,mode,speechiness,"
-                "acousticness,instrumentalness,liveness,valence,tempo,track_genre")
-        lines = [cols]
-        for g in range(114):
-            block = rng.random((1000, 9))
-            for i in range(1000):
-                r = block[i]
-                k = g * 1000 + i
-                lines.append(f"t{k:06d},Track {k},Artist {k % 5000},{r[0]:.4f},{r[1]:.4f},{int(r[2] * 12)},"
-                             f"{-60 * r[3]:.3f},{int(r[4] * 2)},{r[5]:.4f},{r[6]:.5f},{r[7] ** 6:.6f},"
-                             f"{r[8]:.4f},{(r[0] + r[1]) / 2:.4f},{60 + 140 * r[2]:.3f},genre{g:03d}")
-        csv = tmp / "dataset.csv"
-        csv.write_text("\n".join(lines) + "\n")
-        binf = tmp / "songs_data.bin"
-        t0 = time.perf_counter()
-        assert L.shim_preprocess(str(csv).encode(), str(binf).encode()) == 1
-        out["preprocess_csv_s"] = round(time.perf_counter() - t0, 3)
-        out["songs_data_bin_bytes"] = binf.stat().st_size
-        t0 = time.perf_counter()
-        fast = L.shim_fast_load(str(binf).encode())
-        assert fast and L.shim_fast_initialize(fast) == 1
-        out["load_and_initialize_s"] = {"loadCatalogue + initialize(matrix)": round(time.perf_counter() - t0, 4)}
-        L.shim_fast_free(fast)
-        t0 = time.perf_counter()
-        slow = L.shim_load(str(binf).encode())
-        L.shim_initialize.argtypes = [ctypes.c_void_p]
-        assert slow and L.shim_initialize(slow) == 1
-        out["load_and_initialize_s"]["loadData + initialize(vector<Song>) (the reference's path)"] = round(time.perf_counter() - t0, 4)
-        feats = np.zeros((n, 12), np.float32)
-        gid = ctypes.c_int(0)
-        for i in range(n):
-            L.shim_song_features(slow, i, feats[i].ctypes.data, ctypes.byref(gid))
-        L.shim_free(slow)
-        np.save(tmp / "feats.npy", feats)
-        q_rows = [(k * 7919) % n for k in range(1200)]
-        # (i) the GPU path
-        with CosineEngine(feats) as eng:
-            st = eng.stats()
-            for k in range(50):
-                eng.query_row_topn(q_rows[k], topn)
-            lat = []
-            for k in range(500):
-                t1 = time.perf_counter()
-                res = eng.query_row_topn(q_rows[50 + k], topn)
-                lat.append((time.perf_counter() - t1) * 1e6)
-            lat.sort()
-            leg, last = stream_leg(eng, torch, q_rows, topn, 1000, 100)
-            # ... and the same stream over two lanes of the handle (mi355rec_create_lane), bound calls, each lane on its own stream
-            lane = eng.lane()
-            pair = [eng, lane]
-            calls = [e.bound_enqueue_row_keys_streamed(topn, e.own_stream()) for e in pair]
-            lrings = [[torch.zeros(topn, dtype=torch.int64, device="cuda") for _ in range(4)] for _ in pair]
-            lptrs = [[ctypes.c_void_p(t.data_ptr()) for t in rs] for rs in lrings]
-            torch.cuda.synchronize()
-
-            def lanes_run(k0, k1):
-                for k in range(k0, k1):
-                    calls[k & 1](int(q_rows[k % len(q_rows)]), lptrs[k & 1][(k >> 1) & 3])
-                for e in pair:
-                    e.enqueue_flush(stream=e.own_stream())
-                torch.cuda.synchronize()
-            lanes_run(0, 100)
-            t1 = time.perf_counter()
-            lanes_run(100, 2100)
-            dt2 = (time.perf_counter() - t1) / 2000
-            lane.close()
-            out["gpu"] = {"two_lanes_streamed_queries_per_s": round(1.0 / dt2, 1), "two_lanes_streamed_us_per_query": round(dt2 * 1e6, 2),
-                          "route": "fp32 rows (48 B/row; shards below 1 M rows are launch-bound either way)" if not st.replica_active else "replica",
-                          "one_query_alone_p50_us": round(lat[len(lat) // 2], 1), "one_query_alone_p99_us": round(lat[int(len(lat) * 0.99)], 1),
-                          "streamed_queries_per_s": leg["queries_per_s"], "streamed_us_per_query": leg["us_per_step"],
-                          "scan_kernel_us": leg["scan_kernel_us"]}
-            want = oracle.scores(feats, feats[q_rows[549]], threads=0)
-            ci, cs = oracle.topn_canonical(want, q_rows[549], topn)
-            out["gpu"]["verified_against_oracle"] = bool(res[0].tolist() == ci.tolist() and np.array_equal(res[1], cs + np.float32(0)))
-        # (ii) the product's CPU backend, in a child that never sees a device
-        child = ("import sys, time, json, numpy as np\n"
-                 f"sys.path.insert(0, {str(ROOT)!r})\n"
-                 "from spotify_recommender_amd import capi\n"
-                 "from spotify_recommender_amd.engine import NodeEngine\n"
-                 f"f = np.load({str(tmp / 'feats.npy')!r})\n"
-                 "assert capi.lib().mi355rec_device_count() == 0, 'the child must not see a device'\n"
-                 "node = NodeEngine(f, n_devices=0, placement=capi.PLACEMENT_AUTO)\n"
-                 "assert node.placement() == capi.PLACEMENT_CPU\n"
-                 f"rows = [(k * 7919) % {n} for k in range(4000)]\n"
-                 f"for k in range(20): node.query_row_topn(rows[k], {topn})\n"
-                 "lat = []\n"
-                 "t0 = time.perf_counter(); done = 0\n"
-                 "while time.perf_counter() - t0 < 4.0:\n"
-                 "    t1 = time.perf_counter()\n"
-                 f"    r = node.query_row_topn(rows[20 + done % 3000], {topn})\n"
-                 "    lat.append(time.perf_counter() - t1); done += 1\n"
-                 "dt = time.perf_counter() - t0\n"
-                 "lat.sort()\n"
-                 f"last = node.query_row_topn(rows[7], {topn})\n"
-                 "print(json.dumps({'queries_per_s': round(done / dt, 1), 'p50_us': round(lat[len(lat) // 2] * 1e6, 1), 'queries': done,\n"
-                 "                  'note': node.note(), 'idx': last[0].tolist(), 'score_bits': np.asarray(last[1]).view(np.uint32).tolist()}))\n")
-        env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
-        p = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, env=env, timeout=180)
-        if p.returncode == 0:
-            r = json.loads(p.stdout.strip().splitlines()[-1])
-            want = oracle.scores(feats, feats[q_rows[7]], threads=0)
-            ci, cs = oracle.topn_canonical(want, q_rows[7], topn)
-            import re
-            m = re.search(r"\((\d+) ", r["note"])
-            threads = int(m.group(1)) if m else None
-            out["cpu_backend"] = {"queries_per_s": r["queries_per_s"], "one_query_p50_us": r["p50_us"], "sample": f"{r['queries']} queries (4 s)",
-                                  "threads": threads, "note": r["note"], "process": "fresh child, HIP_VISIBLE_DEVICES='' before any GPU call",
-                                  "verified_against_oracle": bool(r["idx"] == ci.tolist() and
-                                                                  r["score_bits"] == (cs + np.float32(0)).view(np.uint32).tolist())}
-        else:
-            out["cpu_backend"] = {"unavailable": (p.stderr or p.stdout)[-400:]}
-        # (iii) the oracle's OpenMP port on the same features (the checker, timed as in cpu_baseline)
-        threads, host = host_threads(oracle.max_threads())
-        oracle.recommend_omp(feats, q_rows[0], topn, threads)
-        t0 = time.perf_counter()
-        done = 0
-        while time.perf_counter() - t0 < 3.0:
-            oracle.recommend_omp(feats, q_rows[done % 1000], topn, threads)
-            done += 1
-        out["oracle_port"] = {"queries_per_s": round(done / (time.perf_counter() - t0), 1), "threads": threads, "sample": f"{done} queries (3 s)",
-                              "kind": "port (oracle/cosine_oracle.c, OpenMP rows + per-thread top-N)"}
-        oracle.recommend_by_index(feats, q_rows[0], topn)
-        t0 = time.perf_counter()
-        done = 0
-        while time.perf_counter() - t0 < 2.0:
-            oracle.recommend_by_index(feats, q_rows[done % 1000], topn)
-            done += 1
-        out["oracle_port"]["serial_reference_loop_qps"] = round(done / (time.perf_counter() - t0), 1)
-    return out
-
-
 def cpu_baseline(feats_host, topn, query_rows):
     """The oracle timed on the host cores: B1 (OpenMP rows + per-thread top-N) is the reported value — the portable
     build the checker uses (gcc -O3, no -march: the reference's own flags, Makefile:9) — with the same source built
@@ -561,71 +183,6 @@ def cpu_baseline(feats_host, topn, query_rows):
     }
 
 
-def preflight(args, json_fd, torch, np, capi, NodeEngine, feats_host, devices, virtual):
-    """`--gpus N --preflight`: what a first contact with N real GPUs should say BEFORE anything is timed — which device can
-    map which (the PEER transport stores keys through those mappings and reads query rows through them), the placement and
-    shard count AUTO would choose for this catalogue, the device memory a shard needs against what each device has free —
-    and ONE query per transport and placement through the product's node handle against the oracle, so that a
-    misconfigured node fails here with a sentence, not in the timed stream with a hang."""
-    from oracle import oracle
-    n, topn = args.rows, args.topn
-    g = len(devices)
-    real = sorted(set(devices))
-    report = {"preflight": True, "gpus": g, "virtual": bool(virtual), "rows": n, "topn": topn, "devices_visible": torch.cuda.device_count()}
-    peer = {}
-    for a in real:
-        peer[str(a)] = {str(b): (bool(torch.cuda.can_device_access_peer(a, b)) if a != b else True) for b in real}
-    report["peer_access"] = peer
-    report["all_pairs_peer"] = all(all(v.values()) for v in peer.values())
-    auto = int(capi.lib().mi355rec_auto_shards(n, torch.cuda.device_count()))
-    report["auto_placement"] = {"shards": auto, "rule": "SHARDED over clamp(rows // 4 M, 1, visible devices) devices (include/mi355rec.h, PLACEMENT)",
-                                "rows_per_shard": -(-n // max(1, auto))}
-    rows_per = -(-n // g)
-    report["memory"] = {"bytes_per_row_resident": 84, "note": "48 B fp32 row + 24 B fp16 replica + 12 B 8-bit replica",
-                        "sharded_bytes_per_device": rows_per * 84, "replicated_bytes_per_device": n * 84,
-                        "free_bytes": {str(d): int(torch.cuda.mem_get_info(d)[0]) for d in real}}
-    row = (7 * 7919) % n
-    want = oracle.scores(feats_host, feats_host[row], threads=0)
-    ci, cs = oracle.topn_canonical(want, row, topn)
-    checks = []
-    ok_all = True
-    plan = [(capi.PLACEMENT_SHARDED, capi.TRANSPORT_PEER, "sharded / peer stores"),
-            (capi.PLACEMENT_SHARDED, capi.TRANSPORT_RCCL, "sharded / one ncclAllGather per rank"),
-            (capi.PLACEMENT_REPLICATED, None, "replicated (no exchange)")]
-    for placement, transport, label in plan:
-        entry = {"what": label}
-        try:
-            if transport == capi.TRANSPORT_RCCL and virtual:
-                raise RuntimeError("RCCL wants one device per rank: not with virtual shards of one GPU")
-            node = NodeEngine(feats_host, devices=devices, placement=placement)
-            try:
-                if transport is not None:
-                    node.set_transport(transport)
-                idx, sc = node.query_row_topn(row, topn)             # the synchronous call
-                t = node.enqueue_row(row, topn)                      # ... and the ticketed stream
-                node.enqueue_flush()
-                idx2, sc2 = node.wait(t, topn)
-                good = (idx.tolist() == ci.tolist() and bool(np.array_equal(sc, cs + np.float32(0))) and
-                        idx2.tolist() == ci.tolist() and bool(np.array_equal(sc2, cs + np.float32(0))))
-                entry.update({"matches_oracle": bool(good), "rows_by_pointer": node.rows_by_pointer(), "note": node.note(),
-                              "shard_rows": node.info()["shard_rows"]})
-                ok_all = ok_all and good
-            finally:
-                node.close()
-        except Exception as e:
-            entry["failed"] = str(e)[:300]
-            if not (transport == capi.TRANSPORT_RCCL and virtual):
-                ok_all = False
-        checks.append(entry)
-    report["one_query_per_transport"] = checks
-    report["ok"] = bool(ok_all)
-    sys.stdout.flush()
-    os.write(json_fd, (json.dumps(report) + "\n").encode())
-    if not ok_all:
-        raise SystemExit("preflight FAILED: " + "; ".join(f"{c['what']}: {c.get('failed', 'result differs from the oracle')}"
-                                                          for c in checks if c.get("failed") or c.get("matches_oracle") is False))
-
-
 def run_node(args, json_fd):
     """`--gpus N` launched plainly (or `--virtual-shards G`): ONE process drives every shard through the
     product's row-sharded C-ABI handle (mi355rec_create_sharded / _on, csrc/sharded.hip) — the engine the
@@ -657,7 +214,8 @@ def run_node(args, json_fd):
         torch.cuda.empty_cache()
 
     if args.preflight:
-        return preflight(args, json_fd, torch, np, capi, NodeEngine, feats_host, devices, virtual)
+        from oracle import oracle   # (the checker, handed to the leg: the package itself never imports it)
+        return preflight(args, json_fd, torch, np, capi, NodeEngine, feats_host, devices, virtual, oracle)
     replicated = args.placement == "replicated"
     node = NodeEngine(feats_host, devices=devices,
                       placement=capi.PLACEMENT_REPLICATED if replicated else capi.PLACEMENT_SHARDED)
@@ -669,8 +227,19 @@ def run_node(args, json_fd):
     # every shard: the N = 1 line's step, sharded); the same stream with BATCHED windows (a window of
     # queries = one multi-query pass per shard) is reported beside it as `batched_windows`.
     node.set_window_mode(False)
-    if args.transport == "rccl":
-        node.set_transport(capi.TRANSPORT_RCCL)
+    # Which transport `value` is measured on.  north_star names "a single RCCL all-gather over xGMI" for BASELINE configs[3]
+    # (10 M rows x top-100 row-sharded over real devices): there `value` is the RCCL transport unless --transport says
+    # otherwise; everywhere else it is the handle's default (peer stores where every device maps the first one's memory).
+    # BOTH transports are timed and reported as first-class objects (`transport.rccl`, `transport.peer`).
+    configs3 = (not virtual) and g > 1 and (not replicated) and n == 10_000_000 and topn == 100
+    transport_note = None
+    if args.transport == "rccl" or (args.transport == "auto" and configs3):
+        try:
+            node.set_transport(capi.TRANSPORT_RCCL)
+        except capi.Mi355Error as e:
+            if args.transport == "rccl":
+                raise
+            transport_note = f"the RCCL transport is not available here ({e}): `value` is the default transport"
     elif args.transport == "peer":
         node.set_transport(capi.TRANSPORT_PEER)
     replica_mode = capi.REPLICA_FP16 if args.replica_fp16 else capi.REPLICA_AUTO
@@ -691,24 +260,34 @@ def run_node(args, json_fd):
         node.enqueue_flush()
         return node.wait(t, topn)
 
-    def timed_stream():
+    def timed_stream(events=True):
+        """One K-step region between synchronisations (no HIP events inside it), then — `events` — an UNTIMED pass of the same
+        stream with events around every stride-th scan launch of every shard, for the kernels' mean durations."""
         stream(0, args.warmup)
         sync_all()
-        stride = args.event_stride if args.event_stride > 0 else max(1, -(-args.steps // (16 if args.steps >= 64 else 3)))
-        if not args.no_kernel_events:
-            node.set_timing(stride)
         st0 = node.stream_stats()
         t0 = time.perf_counter()
         last = stream(args.warmup, total_q)
         sync_all()
         dt = time.perf_counter() - t0
         st1 = node.stream_stats()
-        shard_ms = [float(node.shard_stats(r).last_scan_ms) for r in range(g) if info["shard_rows"][r] > 0]
-        node.set_timing(0)
+        shard_ms = []
+        if events and not args.no_kernel_events:
+            stride = args.event_stride if args.event_stride > 0 else max(1, -(-args.steps // (16 if args.steps >= 64 else 3)))
+            node.set_timing(stride)
+            stream(args.warmup, total_q)
+            sync_all()
+            shard_ms = [float(node.shard_stats(r).last_scan_ms) for r in range(g) if info["shard_rows"][r] > 0]
+            node.set_timing(0)
         host_us = (st1["host_ns"] - st0["host_ns"]) / max(1, st1["queries"] - st0["queries"]) / 1e3
         return dt, last, shard_ms, host_us, st1["exchanges"] - st0["exchanges"]
 
-    elapsed, last_result, shard_ms, host_us, exchanges = timed_stream()
+    # the timed region is run `--repeats` times back to back; `value` is the median run (as at N = 1)
+    runs = [timed_stream(events=(i == 0)) for i in range(max(1, args.repeats))]
+    run_times = [r[0] for r in runs]
+    mid = sorted(range(len(runs)), key=lambda i: run_times[i])[len(runs) // 2]
+    elapsed, last_result, _, host_us, exchanges = runs[mid]
+    shard_ms = runs[0][2]
     st_headline = node.shard_stats(0)   # which copy of the rows the headline's queries scan
     replica = bool(st_headline.replica_active)
     rows_local = max(info["shard_rows"])
@@ -754,18 +333,30 @@ def run_node(args, json_fd):
             "note": "throughput mode: a query starts when its window closes; results identical (tests/test_gpu_node.py)"}
         last_batched = lastb
 
-    # the other transport, same stream (real placements only: RCCL wants one device per shard)
-    other = None
+    # BOTH transports as first-class objects (real placements only: RCCL wants one device per shard); the one `value` was
+    # measured on keeps the headline's figures, the other is timed here over the same stream
+    def transport_name(t):
+        return "peer" if t == capi.TRANSPORT_PEER else "rccl"
+
+    transports = {"value_is": transport_name(transport), "rccl": None, "peer": None, "note": transport_note,
+                  "value_rule": "BASELINE configs[3] (10 M x top-100, row-sharded over real devices): RCCL, as north_star words it; "
+                                "elsewhere the handle's default; --transport overrides"}
+    transports[transport_name(transport)] = {"value": round(args.steps / elapsed, 2), "unit": "queries/s", "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+                                             "exchanges": exchanges, "host_enqueue_us_per_query": round(host_us, 2)}
     if not virtual and g > 1 and not replicated:
+        other_t = capi.TRANSPORT_RCCL if transport == capi.TRANSPORT_PEER else capi.TRANSPORT_PEER
         try:
-            node.set_transport(capi.TRANSPORT_RCCL if transport == capi.TRANSPORT_PEER else capi.TRANSPORT_PEER)
+            node.set_transport(other_t)
             dt2, _, _, host2, ex2 = timed_stream()
-            other = {"transport": "rccl" if transport == capi.TRANSPORT_PEER else "peer", "value": round(args.steps / dt2, 2),
-                     "unit": "queries/s", "ms_per_step": round(dt2 / args.steps * 1e3, 5), "exchanges": ex2,
-                     "host_enqueue_us_per_query": round(host2, 2)}
+            transports[transport_name(other_t)] = {"value": round(args.steps / dt2, 2), "unit": "queries/s", "ms_per_step": round(dt2 / args.steps * 1e3, 5),
+                                                   "exchanges": ex2, "host_enqueue_us_per_query": round(host2, 2)}
         except capi.Mi355Error as e:
-            other = {"unavailable": str(e)}
+            transports[transport_name(other_t)] = {"unavailable": str(e)}
         node.set_transport(transport)
+    if transports["rccl"] is not None and "value" in transports["rccl"]:
+        # what RCCL itself says: ncclCommCount of the communicators the exchange ran on (mi355rec_sharded_rccl_ranks)
+        transports["rccl"].update(node.rccl_ranks())
+        transports["rccl"]["via"] = "one ncclAllGather per rank per window, issued by that rank's worker thread (ncclCommInitAll)"
 
     # virtual shards: the whole catalogue through ONE single-device handle on the same GPU, same stream of
     # queries — the difference is what the orchestration (G launches per query, exchange, second merge) costs
@@ -822,6 +413,8 @@ def run_node(args, json_fd):
         "vs_baseline": None,
         "dtype": dtype_label,
         "data": "synthetic",
+        "value_runs": [round(args.steps / t, 1) for t in run_times],
+        "value_note": f"median of {len(run_times)} back-to-back {args.steps}-step regions, each between synchronisations of every device",
         "config": {
             "workload": f"{n} synthetic tracks x 12 fp32 features, top-{topn}, "
                         + ("REPLICATED on " if replicated else "row-sharded over ")
@@ -834,9 +427,7 @@ def run_node(args, json_fd):
                                "rows split into contiguous blocks, one per device; one exchange + one merge per window (north_star)"),
             "rows": n, "topn": topn, "shards": g, "virtual_shards": virtual, "devices": devices,
             "rows_per_shard": rows_local, "queries_per_step": 1,
-            "transport": "peer" if transport == capi.TRANSPORT_PEER else "rccl",
-            "rccl_ranks": g if (transport == capi.TRANSPORT_RCCL or (other is not None and other.get("transport") == "rccl"
-                                                                    and "value" in other)) else None,
+            "transport": transport_name(transport),
             "window": args.window,
             "window_mode": ("streamed: one scan launch per query on the window's replica" if replicated
                             else "streamed: one scan launch per shard per query"), "exchanges_in_timed_region": exchanges,
@@ -847,17 +438,20 @@ def run_node(args, json_fd):
         },
         "p50_ms": round(lat[len(lat) // 2], 4) if lat else None,
         "p99_ms": round(lat[min(len(lat) - 1, int(len(lat) * 0.99))], 4) if lat else None,
-        "roofline": {
-            "bound": roofline_bound(alg), "per": "shard launch (mean over shards)",
+        "roofline": {   # (<= 20 scalar keys; per launch of one shard, mean over the shards; every shard's own figures: `per_gpu`)
+            "bound": "hbm",
             "kernel": kernel_label,
             "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None,
-            **traffic_fields(),
+            "survey_frac": None, "survey_achieved": None, "survey_kernel_us": None,
+            "traffic": None,
             "algorithmic_bytes_per_launch": alg, "bytes_per_row": row_bytes,
-            "survey_bytes_per_row": BYTES_PER_ROW, "avg_kernel_ms": round(k_ms, 5) if k_ms else None,
-            "kernel_ms_per_shard": [round(m, 5) for m in shard_ms],
-            "infinity_cache_resident": bool(alg <= 128 * 2**20),
+            "avg_kernel_ms": round(k_ms, 5) if k_ms else None,
+            "cache_resident": bool(alg <= 128 * 2**20),
+            "per": "shard launch (mean over shards)",
         },
+        "roofline_notes": {"survey": "survey_* = the same stream over the fp32 rows (48 B/row, SURVEY.md §8(d)): the `fp32_rows` object",
+                           **traffic_fields()},
         "host": {"enqueue_us_per_query": round(host_us, 2), "launches_per_query": 1 if replicated else g,
                  "note": "wall time of the enqueue/flush calls on the one host thread (all shards), per query"},
         "verified_against_oracle": bool(ok), "verified_queries": checked,
@@ -866,13 +460,22 @@ def run_node(args, json_fd):
         line["fp32_rows"] = fp32_rows
         line["roofline"]["survey_frac"] = fp32_rows["roofline"]["frac"]
         line["roofline"]["survey_achieved"] = fp32_rows["roofline"]["achieved"]
+        line["roofline"]["survey_kernel_us"] = round(fp32_rows["roofline"]["avg_kernel_ms"] * 1e3, 2)
     elif not replica:
         line["roofline"]["survey_frac"] = line["roofline"]["frac"]
         line["roofline"]["survey_achieved"] = line["roofline"]["achieved"]
+        line["roofline"]["survey_kernel_us"] = round(k_ms * 1e3, 2) if k_ms else None
     if batched_windows is not None:
         line["batched_windows"] = batched_windows
-    if other is not None:
-        line["other_transport"] = other
+    line["transport"] = transports
+    line["peer_access"] = peer_access_matrix(torch, devices)
+    line["all_pairs_peer"] = all(all(v.values()) for v in line["peer_access"].values())
+    # every shard's own scan kernel against the HBM peak (HIP events on the shard's stream)
+    live = [r for r in range(g) if info["shard_rows"][r] > 0]
+    line["per_gpu"] = [{"shard": r, "device": devices[r], "rows": info["shard_rows"][r], "avg_kernel_ms": round(m, 5),
+                        "achieved_gbps": round(alg / (m * 1e-3) / 1e9, 1) if m > 0 else None,
+                        "frac": round(alg / (m * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if m > 0 else None}
+                       for r, m in zip(live, shard_ms)]
     if single is not None:
         line["single_engine_same_gpu"] = single
     node.close()
@@ -1022,36 +625,59 @@ def main():
         step(k)
     flush()
     fence()
+
     def lane_counters():
         cs = [ln.replica_counters() for ln in lanes]
         return {k: sum(c[k] for c in cs) for k in cs[0]}
 
+    # THE TIMED REGION: exactly K steps between barrier + synchronize pairs, the flush of the last query inside it, no HIP
+    # events inside it (an event pair costs a launch ~6 us of stream time).  A K-step region of 20 steps is
+    # 0.4 ms — one sample of it is a noisy thing to steer by — so the region is run REPEATS times back to back, each bracketed
+    # the same way: `value` is the MEDIAN run, `value_runs` all of them (item 1d).
+    def timed_region():
+        fence()
+        t0 = time.perf_counter()
+        for k in range(args.warmup, total_q):
+            step(k)
+        flush()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        fence()
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     rc_before = lane_counters() if replica else None
-    # a timed launch costs ~6 us of stream time (start / stop signals around the dispatch): 16 timed launches
-    # in a long run (every 19th of the default 300), 3 in a short one (the driver's 20-step run: every 7th)
-    stride = args.event_stride if args.event_stride > 0 else max(1, -(-args.steps // (16 if args.steps >= 64 else 3)))
-    if not args.no_kernel_events:
-        eng.set_timing(stride)  # HIP events around every k-th scan / merge launch
-    t0 = time.perf_counter()
-    for k in range(args.warmup, total_q):
-        step(k)
-    flush()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    fence()
-    st = eng.stats()  # averages the HIP events recorded inside the timed region
-    eng.set_timing(False)
+    run_times = [timed_region() for _ in range(max(1, args.repeats))]
     rc_after = lane_counters() if replica else None
+    elapsed = sorted(run_times)[len(run_times) // 2]
+    # ... and the kernel's duration from an UNTIMED pass of the same stream (same lanes, same queries): HIP events around every
+    # stride-th scan launch of lane 0, on the stream the kernel is launched on
+    stride = args.event_stride if args.event_stride > 0 else max(1, -(-args.steps // (16 if args.steps >= 64 else 3)))
+    st = None
+    if not args.no_kernel_events:
+        eng.set_timing(stride)
+        for k in range(args.warmup, total_q):
+            step(k)
+        flush()
+        fence()
+        st = eng.stats()
+        eng.set_timing(False)
+    # N > 1: what the process group the exchange ran on says about itself — every rank calls this (collectives inside)
+    group = None
+    if world > 1 or force_sharded:
+        props = torch.cuda.get_device_properties(local_rank)
+        row_bytes_h, alg_h = replica_desc(st_headline)[:2]
+        group = rank_group_report(dist, torch, rank, world, dev, f"cuda:{local_rank} {props.name}", str(getattr(props, "uuid", local_rank)),
+                                  float(st.last_scan_ms) if st is not None else 0.0, alg_h)
     # what the timed stream itself produced for its last two queries (checked against the oracle below)
     timed_tail = [(q_rows[k], ring_of(k).clone()) for k in (total_q - 2, total_q - 1)] if streamed and args.steps >= 2 else []
     # the same stream through ONE handle (what `value` was until round 4): a launch that has the chip to itself
     single_lane = None
     if n_lanes > 1 and not args.no_single_lane and rank == 0:
         single_lane, _ = stream_leg(eng, torch, q_rows, topn, min(args.steps, 300), min(max(args.warmup, 4), 20))
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     # single-query latency (submit -> result on host), outside the timed region
     lat = []
@@ -1085,13 +711,12 @@ def main():
             step(k)
         flush()
         fence()
+        dt = sorted(timed_region() for _ in range(3))[1] / args.steps   # (the median of three K-step regions, no events in them)
         eng.set_timing(stride)
-        t1 = time.perf_counter()
         for k in range(args.warmup, total_q):
             step(k)
         flush()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t1) / args.steps
+        fence()
         st32 = eng.stats()
         eng.set_timing(False)
         lat32 = []
@@ -1134,20 +759,26 @@ def main():
     # micro-batched throughput, outside the timed region:
     # 12 queries share one pass over the catalogue, seed/final merge launches shared by 36
 
-    def timed(fn, reps):
+    def timed(fn, reps, rounds=1):
+        """One untimed warm call of `fn`, then `rounds` timed rounds of `reps` calls each (synchronised on both sides): the MEDIAN
+        round's time per call; every round's is left in `timed.runs` (a leg that stalled once shows there, not in its figure)."""
         fn()
         fence()
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
-        fence()
-        if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        return dt / reps
+        per_call = []
+        for _ in range(rounds):
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            fence()
+            if world > 1:
+                tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            per_call.append(dt / reps)
+        timed.runs = per_call
+        return sorted(per_call)[len(per_call) // 2]
 
     # micro-batched throughput (SURVEY.md §8(f) rank 1), outside the timed region: a dozen queries
     # per call.  With a replica such a call takes the batched matrix-core path (one block of <= 32
@@ -1182,7 +813,10 @@ def main():
                     for ln, ls in zip(use, use_streams):
                         ln.enqueue_flush(stream=ls)
 
-            dt = timed(run, 1) / calls
+            # (the warm call is a whole run(): whatever a handle allocates or sizes on its first batch of this shape happens there;
+            # three timed rounds, the median reported — VERDICT r5 weak 4: one leg of one driver run took 1 ms per call once)
+            dt = timed(run, 1, rounds=3) / calls
+            batch_leg.worst = max(timed.runs) / calls
             eng.set_batch_path(capi.BATCH_AUTO)
             return dt, rings[(state["k"] - 1) % 8]
 
@@ -1216,7 +850,8 @@ def main():
                 micro["single_lane"] = {}
                 for name, nq in (("twelve_queries", 12), ("thirty_two_queries", 32)):
                     d, _ = batch_leg(nq, 40, capi.BATCH_AUTO, True)
-                    micro["single_lane"][name] = {"ms_per_call": round(d * 1e3, 5), "value": round(nq / d, 1), "unit": "queries/s"}
+                    micro["single_lane"][name] = {"ms_per_call": round(d * 1e3, 5), "value": round(nq / d, 1), "unit": "queries/s",
+                                                  "worst_round_ms_per_call": round(batch_leg.worst * 1e3, 5)}
             d, _ = batch_leg(12, 20, capi.BATCH_AUTO, False)
             micro["single_call_12"] = {"ms_per_call": round(d * 1e3, 5), "value": round(12 / d, 1), "unit": "queries/s",
                                        "note": "one batch alone (mi355rec_enqueue_batch_keys): sample launch + pass + merge launch"}
@@ -1399,15 +1034,13 @@ def main():
 
     if rank == 0:
         qps = args.steps / elapsed
-        scan_ms = float(st.last_scan_ms) if not args.no_kernel_events else 0.0
+        scan_ms = float(st.last_scan_ms) if st is not None else 0.0
         row_bytes, alg_bytes, kernel_fmt, kernel_pmc, dtype_label, replica_label = replica_desc(st_headline)
-        # with lanes, `n_lanes` launches of this kernel are in flight at any time: the rate the chip sustains on the kernel is
-        # lanes x bytes / the mean duration of a launch (the events bracket one lane's launches, the other lanes' overlap them)
         per_launch = (alg_bytes / (scan_ms * 1e-3) / 1e9) if scan_ms > 0 else None
         # With lanes the launches of this kernel OVERLAP (by how much varies along the stream), so no single launch's duration says
         # what the chip sustains on it: `achieved` is then the sustained rate of the timed region itself — every step's algorithmic
         # bytes / the elapsed time `value` is made of, launch gaps included — held against the kernel-level rate of as many plain
-        # read streams at once.
+        # read streams at once (no gaps in it: the fraction is on the safe side).  One handle: bytes / the kernel's mean duration.
         achieved = (qps * alg_bytes / 1e9) if n_lanes > 1 else per_launch
         # a pass only finds its bytes in the 256 MiB Infinity Cache if the whole buffer survives one
         # full pass of itself plus the fp32 fetches: half the cache is the most that can be hoped for
@@ -1415,36 +1048,41 @@ def main():
         own_probe = {12: probe_q8, 24: probe_fp16}.get(row_bytes, probe_gbps)   # the plain read of the buffer THIS kernel streams
         if n_lanes > 1 and row_bytes == 24:
             probe_lanes = None   # (measured over the 8-bit replica or the fp32 rows only)
-        if n_lanes > 1 and probe_lanes:
-            own_probe = probe_lanes
         if n_lanes > 1 and probe_lanes and cache_resident:
-            peak, peak_source = probe_lanes, (f"measured: {n_lanes} plain read-only streams at once (one per lane, each on its own HIP stream) over the "
-                                             "same buffer, resident in the Infinity Cache as the timed stream leaves it: lanes x bytes / the mean "
-                                             "duration of a probe launch while the other lane's is in flight (stream_probe_kernel, HIP events, 30 "
-                                             "launches per lane) — no launch gaps in it, while `achieved` has them; MI355X_MICROARCH.md measures "
-                                             "7.4-8.6 TB/s for Infinity-Cache-served reads")
+            peak, peak_source = probe_lanes, f"measured: {n_lanes} plain read streams at once over the same cache-resident buffer (probes.note)"
         elif cache_resident and own_probe:
-            # a cache-resident buffer has no spec-sheet ceiling: the measured plain read of the same buffer is the ceiling
-            peak, peak_source = own_probe, ("measured: plain read-only stream over the same buffer, resident in the Infinity Cache as "
-                                            "the timed stream leaves it (stream_probe_kernel, 20 launches)")
+            peak, peak_source = own_probe, "measured: one plain read stream over the same cache-resident buffer (probes.note)"
         else:
             peak, peak_source = HBM_PEAK_GBPS, "MI355X_MICROARCH.md: HBM3E spec peak"
         if replica:
             targs = "true, true" if streamed else ("true, false" if sharded is None else "false, true")
-            kernel_name = (kernel_fmt.format(targs=targs) + " over the "
-                           + replica_label + "; rows it cannot rule out are fetched from the fp32 matrix and scored by "
-                           "the exact chain" + (")" if (sharded is None and not streamed) else "; the previous query's merge rides in its last workgroup)"))
+            kernel_name = kernel_fmt.format(targs=targs) + " over the " + replica_label + ")"
         else:
-            kernel_name = ("mi355::scan_kernel<ScanCfg<512,1,6,2>, true, false, 0, true> (query = catalogue row; the previous "
-                           "query's merge rides in its last workgroup)" if streamed else
+            kernel_name = ("mi355::scan_kernel<ScanCfg<512,1,6,2>, true, false, 0, true>" if streamed else
                            ("mi355::scan_kernel<ScanCfg<512,1,6,2>, true, false>" if world == 1 else
                             "mi355::scan_kernel<ScanCfg<512,1,6,2>, false, false, 0, true>"))
+        # SURVEY.md §8(d) prices a query at 48 B/row: that is the fp32 scan's roofline, measured in this run — the kernel ALONE
+        # (one handle, every byte from HBM) when the lanes leg ran, else the fp32 stream's own events
+        survey = None
+        if fp32_rows is not None:
+            alone32 = fp32_rows.get("single_lane")
+            k_us = alone32["scan_kernel_us"] if alone32 else fp32_rows["roofline"]["avg_kernel_ms"] * 1e3
+            if k_us and k_us > 0:
+                g = (hi - lo) * BYTES_PER_ROW / (k_us * 1e-6) / 1e9
+                survey = {"kernel_us": round(k_us, 2), "achieved": round(g, 1), "frac": round(g / HBM_PEAK_GBPS, 4)}
+        elif not replica and per_launch:
+            survey = {"kernel_us": round(scan_ms * 1e3, 2), "achieved": round(per_launch, 1), "frac": round(per_launch / HBM_PEAK_GBPS, 4)}
+        rescored = (round((rc_after["rescored_rows"] - rc_before["rescored_rows"]) / max(1, rc_after["scans"] - rc_before["scans"]), 1)
+                    if replica else None)
+        value_runs = [round(args.steps / t, 1) for t in run_times]
         line = {
             "metric": metric_label(n, topn),
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": dtype_label, "data": "synthetic",
+            "value_runs": value_runs,
+            "value_note": f"median of {len(run_times)} back-to-back {args.steps}-step regions, each between barrier + synchronize pairs",
             "config": {
                 "workload": f"{n} synthetic tracks x 12 fp32 features, top-{topn}, "
                             + (f"1 MI355X ({workload_label(n, topn)})" if world == 1 else
@@ -1453,10 +1091,8 @@ def main():
                 "rows": n, "topn": topn, "rows_per_gpu": hi - lo, "queries_per_step": 1,
                 "lanes": n_lanes if sharded is None else rank_lanes,
                 "lane_streams": ([ln.lane_status() for ln in lanes[1:]] if (sharded is None and n_lanes > 1) else None),
-                "lanes_note": (f"the stream of queries is dealt over {n_lanes} lanes of one handle (mi355rec_create_lane: the same rows and replicas, "
-                               "own stream state), each on its own HIP stream — a handle's launches form one chain and cannot overlap each "
-                               "other, two chains fill each other's ramps; `single_lane` is the same stream through one handle"
-                               if n_lanes > 1 else None),
+                "lanes_note": (f"the stream is dealt over {n_lanes} lanes of one handle (mi355rec_create_lane: same rows and replicas, own "
+                               "stream state and HIP stream); `single_lane` is the same stream through one handle" if n_lanes > 1 else None),
                 "merge": ("inside the next query's scan launch (streamed), last one flushed in the timed region"
                           if streamed else ("own launch per query" if sharded is None else
                                             f"local merge streamed; one all-gather + one batched merge per {args.window} queries")),
@@ -1464,51 +1100,65 @@ def main():
             },
             "p50_ms": round(lat[len(lat) // 2], 4) if lat else None,
             "p99_ms": round(lat[min(len(lat) - 1, int(len(lat) * 0.99))], 4) if lat else None,
+            # <= 20 SCALAR keys, short strings (the driver's record keeps a bounded number of keys and characters): everything
+            # longer lives in the top-level `roofline_notes` / `probes` objects
             "roofline": {
-                "bound": roofline_bound(alg_bytes),
-                "bound_note": ("the buffer this kernel streams fits the 256 MiB Infinity Cache with room to spare: `peak` is the "
-                               "measured plain read of that same buffer, not the HBM spec peak; the HBM-bound figure of SURVEY.md "
-                               "§8(d) is `survey_frac` (the fp32 scan, 480 MB per query)" if cache_resident else None),
+                "bound": "hbm",
                 "kernel": kernel_name,
                 "achieved": round(achieved, 1) if achieved else None, "peak": round(peak, 1), "unit": "GB/s",
                 "frac": round(achieved / peak, 4) if achieved else None,
-                "peak_source": peak_source,
-                **traffic_fields(),
+                "survey_frac": survey["frac"] if survey else None,
+                "survey_achieved": survey["achieved"] if survey else None,
+                "survey_kernel_us": survey["kernel_us"] if survey else None,
+                "traffic": None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_per_row": row_bytes,
-                "survey_bytes_per_row": BYTES_PER_ROW,
                 "avg_kernel_ms": round(scan_ms, 5) if scan_ms else None,
                 "launches_in_flight": n_lanes,
                 "achieved_per_launch": round(per_launch, 1) if per_launch else None,
-                "achieved_note": (f"{n_lanes} lanes: launches of this kernel overlap, so `achieved` = steps x algorithmic bytes / elapsed (= value x bytes: "
-                                  "the sustained rate of the timed region, launch gaps included); `peak` is a kernel-level figure without gaps; "
-                                  "`achieved_per_launch` = bytes / avg_kernel_ms is ONE launch's own rate while another lane's is in flight (the figure "
-                                  "a kernel trace's average duration gives); the kernel with the chip to itself is in `single_lane`"
-                                  if n_lanes > 1 else None),
-                "merge_kernel_ms": round(float(st.last_merge_ms), 5),
-                # plain reads of each buffer, GB/s (a kernel is only ever compared with the probe of ITS buffer)
-                "stream_probes_gbps": {"fp32_rows": round(probe_gbps, 1) if probe_gbps else None,
-                                       "q8_replica": round(probe_q8, 1) if probe_q8 else None,
-                                       "fp16_replica": round(probe_fp16, 1) if probe_fp16 else None,
-                                       "own_buffer_all_lanes_at_once": round(probe_lanes, 1) if probe_lanes else None},
-                "frac_of_own_buffer_probe": round(achieved / own_probe, 4) if (achieved and own_probe) else None,
-                "infinity_cache_resident": bool(cache_resident),
+                "frac_of_hbm_peak": round(achieved / HBM_PEAK_GBPS, 4) if achieved else None,
+                "cache_resident": bool(cache_resident),
+                "rescored_rows_per_query": rescored,
+                "peak_source": peak_source,
             },
+            "roofline_notes": {
+                "frac": ("bytes this kernel streams (" + replica_label + ")): " if replica else "") +
+                        (f"{n_lanes} lanes, launches overlap: achieved = value x algorithmic bytes (sustained, launch gaps included); "
+                         "peak = kernel-level rate of as many plain read streams at once (no gaps)" if n_lanes > 1 else
+                         "achieved = algorithmic bytes / avg_kernel_ms"),
+                "survey": "SURVEY.md §8(d) prices a query at 48 B/row = the fp32 scan (mi355::scan_kernel) ALONE on one handle, every byte "
+                          "from HBM: survey_achieved = rows x 48 B / survey_kernel_us, survey_frac = that / 8000 GB/s; same run, HIP events; "
+                          "the `fp32_rows` object is that stream's own headline",
+                "avg_kernel_ms": "HIP events on the launching stream around every stride-th scan launch of lane 0, in an UNTIMED pass of the same "
+                                 "stream right after the timed regions; with lanes = one launch's duration while the other lane's is in flight "
+                                 "(what a rocprofv3 kernel trace of this command averages); the kernel with the chip to itself: `single_lane`",
+                "cache": ("the buffer this kernel streams fits the 256 MiB Infinity Cache with room to spare and stays there between "
+                          "queries: `peak` is the measured plain read of that same buffer, `frac_of_hbm_peak` the same rate against 8000 GB/s"
+                          if cache_resident else None),
+                "prefilter_margin": (("per query: l1(Q)/(254 S) + sqrt(12)/(2 S) + 3e-5 (<= 0.0137), integer dot" if row_bytes == 12
+                                      else round(float(st.replica_margin_single), 6)) if (replica and st is not None) else None),
+                "merge_kernel_ms": round(float(st.last_merge_ms), 5) if st is not None else None,
+                **traffic_fields(),
+            },
+            # plain reads of each buffer, GB/s (a kernel is only ever compared with the probe of ITS buffer)
+            "probes": {"fp32_rows": round(probe_gbps, 1) if probe_gbps else None,
+                       "q8_replica": round(probe_q8, 1) if probe_q8 else None,
+                       "fp16_replica": round(probe_fp16, 1) if probe_fp16 else None,
+                       "own_buffer_all_lanes_at_once": round(probe_lanes, 1) if probe_lanes else None,
+                       "note": "csrc/kernels.hip.h stream_probe_kernel, HIP events: one stream = 20 launches; all lanes at once = lanes x bytes "
+                               "/ the mean duration of a probe launch while the other lane's is in flight (30 launches per lane); "
+                               "MI355X_MICROARCH.md measures 7.4-8.6 TB/s for Infinity-Cache-served reads, 6.29 TB/s for an HBM copy"},
         }
-        if replica:
-            # rows the timed stream itself sent to the exact chain (counters read right before and after it)
-            line["roofline"]["rescored_rows_per_query"] = round(
-                (rc_after["rescored_rows"] - rc_before["rescored_rows"]) / max(1, rc_after["scans"] - rc_before["scans"]), 1)
-            line["roofline"]["prefilter_margin"] = ("per query: l1(q/|q|)/254 + 3e-5 (<= 0.0137)" if row_bytes == 12
-                                                    else round(float(st.replica_margin_single), 6))
-            line["roofline"]["note"] = ("achieved / frac are for the bytes this kernel streams (the " + replica_label + ")); "
-                                        "SURVEY.md §8(d) prices a query at 48 B/row, i.e. the fp32 scan in `fp32_rows`")
-            if scan_ms > 0:
-                # the same launch priced at the survey's 48 B/row: exceeds the HBM peak BECAUSE those bytes are not moved
-                eq = (hi - lo) * BYTES_PER_ROW / (scan_ms * 1e-3) / 1e9
-                line["roofline"]["at_survey_bytes_per_row"] = {"equivalent_gbps": round(eq, 1),
-                                                               "note": f"{(hi - lo) * BYTES_PER_ROW / 1e6:.0f} MB-equivalent per query; the kernel moves {row_bytes / BYTES_PER_ROW:.2f}x "
-                                                                       "of that, so this is a throughput figure, not a fraction of any memory's peak"}
+        if group is not None:
+            # (north_star: "a single RCCL all-gather over xGMI to merge per-shard top-N candidates" — under the driver's
+            # torch.distributed.run launch that is torch.distributed's all_gather_into_tensor on backend nccl = RCCL)
+            line["transport"] = {"value_is": "rccl", "rccl": {"via": "torch.distributed all_gather_into_tensor, one per window of "
+                                                                     f"{args.window} queries, {topn} keys per query and rank",
+                                                              "backend": group["backend"], "ranks": group["ranks"],
+                                                              "ranks_counted": group["ranks_counted"], "value": round(qps, 2), "unit": "queries/s"},
+                                 "peer": None, "peer_note": "peer stores are a transport of the ONE-process node handle (bench.py --gpus N launched plainly)"}
+            line["group"] = group
+            line["peer_access"] = peer_access_matrix(torch, list(range(torch.cuda.device_count())))
         if single_lane is not None:
             k_us = single_lane["scan_kernel_us"]
             alone = (alg_bytes / (k_us * 1e-6) / 1e9) if k_us > 0 else None
@@ -1517,29 +1167,14 @@ def main():
                                        "peak": round(alone_probe, 1) if (alone_probe and cache_resident) else HBM_PEAK_GBPS,
                                        "frac": (round(alone / (alone_probe if (alone_probe and cache_resident) else HBM_PEAK_GBPS), 4) if alone else None),
                                        "note": "one handle, one chain of launches: algorithmic bytes / the kernel's mean duration with the chip "
-                                               "to itself, against the ONE plain read stream over the same buffer (what `roofline` was until round 4)"}
+                                               "to itself, against the ONE plain read stream over the same buffer"}
             line["single_lane"] = single_lane
         if fp32_rows is not None:
             line["fp32_rows"] = fp32_rows
-            # SURVEY.md §8(d) prices a query at 48 B/row: that is the fp32 scan's roofline, measured in this run
-            alone = (fp32_rows.get("single_lane") or {}).get("roofline")
-            if alone:   # the HBM-bound figure is the kernel ALONE (every byte from HBM); with lanes part of the rows come from the cache
-                line["roofline"]["survey_frac"] = alone["frac"]
-                line["roofline"]["survey_achieved"] = alone["achieved"]
-                line["roofline"]["survey_frac_algorithmic_with_lanes"] = fp32_rows["roofline"]["frac"]
-                line["roofline"]["survey_kernel"] = ("mi355::scan_kernel over the fp32 rows (48 B/row), one handle, the chip to itself: "
-                                                     "`fp32_rows.single_lane`; `fp32_rows` itself is the same stream over the lanes")
-            else:
-                line["roofline"]["survey_frac"] = fp32_rows["roofline"]["frac"]
-                line["roofline"]["survey_achieved"] = fp32_rows["roofline"]["achieved"]
-                line["roofline"]["survey_kernel"] = "mi355::scan_kernel over the fp32 rows (48 B/row): the `fp32_rows` object"
-            tgt = alone if alone else fp32_rows["roofline"]   # (a ratio of ONE kernel's rate to ONE plain stream's)
-            if probe_gbps and tgt["achieved"]:
+            tgt = (fp32_rows.get("single_lane") or {}).get("roofline") or fp32_rows["roofline"]   # (ONE kernel's rate against ONE plain stream's)
+            if probe_gbps and tgt.get("achieved"):
                 tgt["stream_probe_gbps"] = round(probe_gbps, 1)
                 tgt["frac_of_stream_probe"] = round(tgt["achieved"] / probe_gbps, 4)
-        elif not replica:
-            line["roofline"]["survey_frac"] = line["roofline"]["frac"]
-            line["roofline"]["survey_achieved"] = line["roofline"]["achieved"]
         if micro is not None:
             if micro.get("roofline") and probe_fp16 and micro["roofline"].get("achieved"):
                 mr = micro["roofline"]
@@ -1554,10 +1189,12 @@ def main():
             shapes = ([(3000, 0.03, False), (3000, 0.03, True), (300, 0.01, False), (300, 0.01, True)]
                       if args.catalogue == "clustered-contiguous" else [(3000, 0.03, True)])
             shapes = [(max(2, c * n // 10_000_000), sp, r) for c, sp, r in shapes]   # (clusters of ~3300 / ~33000 rows whatever --rows is)
-            line["clustered"] = clustered_object(args, torch, np, dev, shapes)
+            from oracle import oracle as _checker   # (handed to the leg as its checker)
+            line["clustered"] = clustered_object(args, torch, np, dev, shapes, _checker)
         if world == 1 and not args.no_config0:
             try:
-                line["config0"] = config0_object(torch, np)
+                from oracle import oracle as _checker
+                line["config0"] = config0_object(torch, np, _checker)
             except Exception as e:   # (a box without g++ for the shim, ...): the headline stands without it
                 line["config0"] = {"unavailable": repr(e)[:300]}
         if feats_host is not None:

@@ -23,7 +23,7 @@ HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc
 OFFLOAD_ARCH = "gfx950"
 
 ENGINE_SOURCES = [CSRC / "mi355rec.hip", CSRC / "sharded.hip"]
-ENGINE_DEPS = ENGINE_SOURCES + sorted(CSRC.glob("*.hip.h")) + [INCLUDE / "mi355rec.h"]
+ENGINE_DEPS = ENGINE_SOURCES + sorted(CSRC.glob("*.hip.h")) + [INCLUDE / "mi355rec.h", INCLUDE / "mi355rec_diag.h"]
 
 # -ffp-contract=off: the parity contract is sequential multiply-then-add with no
 # FMA contraction (Recommender.cu:264-269 compiled by the reference Makefile:9).
@@ -194,6 +194,17 @@ def build_experiments(force: bool = False) -> Path:
     return build_engine_variant(LIB_EXPERIMENTS, ["MI355REC_EXPERIMENTS"], force, EXPERIMENTS_TOLERATE)
 
 
+# The product's sources and flags + -DMI355REC_TEST_HOOKS: mi355rec_debug_handoff (include/mi355rec_diag.h), which poisons
+# device buffers on purpose, is compiled into THIS library only.  The define changes host code alone, so the device code is
+# the product's (tests/test_kernel_metadata.py compares the kernels of the two libraries); tests/test_gpu_testhooks.py runs
+# the tests that break the hand-offs against it in a child process.
+LIB_TESTHOOKS = PKG / "libmi355rec_testhooks.so"
+
+
+def build_testhooks(force: bool = False) -> Path:
+    return build_engine_variant(LIB_TESTHOOKS, ["MI355REC_TEST_HOOKS"], force)
+
+
 def shim_sources():
     return [CSRC / "Recommender.cpp", CSRC / "DataManager.cpp"]
 
@@ -204,7 +215,7 @@ def build_shim(force: bool = False) -> Path:
     if not srcs:
         return LIB_SHIM
     deps = srcs + [INCLUDE / "Recommender.h", INCLUDE / "Song.h", INCLUDE / "DataManager.h",
-                   INCLUDE / "mi355rec.h"]
+                   INCLUDE / "mi355rec.h", INCLUDE / "mi355rec_diag.h"]
     build_engine(force)
     common = ["g++", "-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", f"-I{INCLUDE}"]
     link = [f"-L{PKG}", "-lmi355rec", "-Wl,-rpath,$ORIGIN"]
@@ -232,6 +243,7 @@ def build_oracle(force: bool = False) -> Path:
 def build_all(force: bool = False) -> None:
     build_engine(force)
     build_experiments(force)   # (a second library; nothing in the product loads it)
+    build_testhooks(force)     # (a third: the product + the test hooks, for tests/ only)
     build_shim(force)
     build_oracle(force)
 

@@ -1,4 +1,4 @@
-"""ctypes binding of the C-ABI in include/mi355rec.h.
+"""ctypes binding of the C-ABI in include/mi355rec.h (core) and include/mi355rec_diag.h (statistics, controls, hooks).
 
 This is plumbing only: every compute call goes to the HIP library.  If the
 library is missing the import of :func:`lib` raises — there is no Python or CPU
@@ -24,7 +24,7 @@ TRANSPORT_PEER, TRANSPORT_RCCL = 1, 2
 PLACEMENT_AUTO, PLACEMENT_SHARDED, PLACEMENT_REPLICATED, PLACEMENT_CPU = 0, 1, 2, 3
 CREATE_NO_REPLICA = 1
 DEBUG_HANDOFF_POISON, DEBUG_HANDOFF_DROP_STORES, DEBUG_HANDOFF_NO_LAST_RIDER = 1, 2, 4
-BUILD_EXPERIMENTS, BUILD_PHASE_CLOCK = 1, 2
+BUILD_EXPERIMENTS, BUILD_PHASE_CLOCK, BUILD_TEST_HOOKS = 1, 2, 4
 PROBE_FP32_ROWS, PROBE_FP16_REPLICA, PROBE_Q8_REPLICA = 0, 1, 2
 
 OK = 0
@@ -146,10 +146,14 @@ SIGNATURES = {
     "mi355rec_sharded_wait": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, POINTER(c_int)]),
     "mi355rec_sharded_stream_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     "mi355rec_debug_handoff": (c_int, [c_void_p, c_int]),
+    "mi355rec_sharded_rccl_ranks": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "mi355rec_pack_key": (c_uint64, [c_float, c_int64]),
     "mi355rec_key_score": (c_float, [c_uint64]),
     "mi355rec_key_row": (c_int64, [c_uint64]),
 }
+
+# declared under #ifdef MI355REC_TEST_HOOKS in include/mi355rec_diag.h: absent from the product library
+TEST_HOOKS = frozenset({"mi355rec_debug_handoff"})
 
 _lib = None
 
@@ -178,13 +182,20 @@ def lib() -> ctypes.CDLL:
             try:
                 fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             except AttributeError:
-                if lenient:
+                if lenient or name in TEST_HOOKS:   # (test hooks: only in -DMI355REC_TEST_HOOKS builds, see has_test_hooks)
                     continue
                 raise
             fn.restype = restype
             fn.argtypes = argtypes
         _lib = handle
     return _lib
+
+
+def has_test_hooks() -> bool:
+    """True when the loaded library was built with -DMI355REC_TEST_HOOKS (libmi355rec_testhooks.so, the experiments build):
+    mi355rec_debug_handoff exists.  The product library returns False."""
+    L = lib()
+    return hasattr(L, "mi355rec_build_flags") and bool(L.mi355rec_build_flags() & BUILD_TEST_HOOKS)
 
 
 def has_experiments() -> bool:

@@ -8,7 +8,7 @@
 #include <iostream>
 #include <unordered_map>
 
-#include "mi355rec.h"
+#include "mi355rec_diag.h"   // (the core + mi355rec_sharded_note / _placement for the messages)
 
 struct Recommender::Impl {
     bool initialized = false;

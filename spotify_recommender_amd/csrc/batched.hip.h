@@ -84,6 +84,8 @@ constexpr int kBqCapMin = 2048;
 constexpr int kBqCapMax = 65536;
 constexpr int kBqSpecialCap = 1024;          // special rows kept per chunk
 constexpr int kBqNbhdRows = 1024;            // rows around a query's excluded row that give its neighbourhood bound (handoff.hip.h)
+constexpr int kBqNbProbeChunks = 3;          // chunks that compute it before the host may decide it never wins on this catalogue
+constexpr int kBqNbProbeEvery = 32;          // ... after which only every this-many-th chunk does (one win switches it back on)
 constexpr int kBqFinalBlock = 256;           // threads of the finalize workgroup
 constexpr int kBqFinalChunk = 1536;          // candidate rows scored between two cuts of the finalize workgroup's key buffer
                                              // (with the 16 KiB of expanded rows beside it the workgroup stays under 40 KiB of LDS: four per CU)
@@ -91,6 +93,7 @@ constexpr int kBqFinalKeys = kBqFinalChunk + 1024;   // keys that buffer holds: 
 constexpr int kBqFinalPerThread = kBqFinalKeys / kBqFinalBlock;
 constexpr int kBqFinalRows = kBqFinalBlock * 16;     // rows one batch of records (a record per thread) can expand to
 constexpr int kBqFinalAhead = 3;             // rows a finalize thread keeps in flight (a chunk = two rounds of three)
+constexpr int kBqFinalRecs = 3;              // candidate records a finalize thread takes at a time (768 per workgroup and lot)
 constexpr int kBqPassBlock = 256;            // 4 waves, one per SIMD; 4-5 workgroups per CU
 constexpr float kBqMargin = 1.0e-3f;         // fp16 subnormals kept (verified per device by bq_selfcheck_kernel)
 constexpr float kBqMarginFlush = 1.5e-3f;    // bound if they were flushed
@@ -802,7 +805,7 @@ __global__ __launch_bounds__(kBqSelectBlock) void bq_select_kernel(
     const float* __restrict__ gmax, int grid_pass1, int n_blocks, int topk, float margin,
     uint32_t* __restrict__ bfrag, uint32_t* __restrict__ qflags, float* __restrict__ qthr,
     const uint32_t* __restrict__ nb_vals /* per query: the neighbourhood's exact bound (bq_prepare_kernel), 0 = none; null: not taken */,
-    int n_queries) {
+    int n_queries, int* __restrict__ counters /* [7] += queries whose neighbourhood bound beat the group maxima's; [4] += chunks with one */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bq_smem[];
     float* s_vals = reinterpret_cast<float*>(bq_smem);                        // [2 * grid][5]
     int* s_hist = reinterpret_cast<int*>(s_vals + static_cast<size_t>(grid_pass1) * 2 * 5);  // [4][256]
@@ -855,6 +858,7 @@ __global__ __launch_bounds__(kBqSelectBlock) void bq_select_kernel(
             if (nb_vals && q < n_queries) {   // wave-uniform: topk rows score at least this EXACTLY — one margin
                 const uint32_t nbv = nb_vals[q];
                 const float nb_t = nbv ? ordered_to_score(nbv) - margin - kBqSlack : 0.0f;
+                if (nb_t > t_prime && lane == 0) atomicAdd(&counters[7], 1);   // (what engine_batch.hip.h's policy reads: is this catalogue sorted?)
                 t_prime = nb_t > t_prime ? nb_t : t_prime;
             }
             if (t_prime > 0.0f) {
@@ -890,7 +894,8 @@ __global__ __launch_bounds__(kBqFinalBlock) void bq_finalize_kernel(
     const uint32_t* __restrict__ special_rows, int* __restrict__ queue /* [n_queries] */,
     uint64_t* __restrict__ out_keys, int64_t* __restrict__ out_idx, float* __restrict__ out_score,
     const uint32_t* __restrict__ nb_vals /* the neighbourhood bounds (bq_prepare_kernel), or null */,
-    int* __restrict__ cand_examined /* [n_queries]: rows this query's records named (diagnostics) */) {
+    int* __restrict__ cand_examined /* [n_queries]: rows this query's records named (diagnostics) */,
+    int* __restrict__ nb_report /* mapped host memory (or null): [0] = counters[7], [1] = counters[4] + 1 once this chunk's select has run */) {
     // Until round 4's end a query kept at most 2048 candidates, all of them in this buffer at once — and a catalogue
     // whose rows CLUSTER (3000 clusters of 3300 rows, spread 0.03: profiles/r04_clustered.jsonl) sent 986 of 1024
     // queries to the exact queue, 43 ms per batch instead of 0.55.  Now the global list holds up to 65536 records per
@@ -907,6 +912,11 @@ __global__ __launch_bounds__(kBqFinalBlock) void bq_finalize_kernel(
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    if (nb_report && q == 0 && tid == 0) {   // (a chunk that computed neighbourhood bounds: tell the host what they were worth)
+        const int chunks = atomicAdd(&counters[4], 1) + 1;
+        __hip_atomic_store(&nb_report[0], counters[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&nb_report[1], chunks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const int n_cand = cand_count[q * kBqCountStride];
     const int n_special = counters[0];
     const bool served = qflags[q] == kBqFlagOk && n_cand <= cand_cap && n_special <= kBqSpecialCap;
@@ -982,31 +992,73 @@ __global__ __launch_bounds__(kBqFinalBlock) void bq_finalize_kernel(
         }
     };
     int examined = 0;
-    uint64_t rec_next = tid < n_cand ? cand_recs[static_cast<int64_t>(q) * cand_cap + tid] : 0ull;
-    for (int rbase = 0; rbase < n_cand; rbase += kBqFinalBlock) {   // uniform: a record per thread, the next batch's requested
-        const uint64_t rec = rec_next;
-        rec_next = rbase + kBqFinalBlock + tid < n_cand ? cand_recs[static_cast<int64_t>(q) * cand_cap + rbase + kBqFinalBlock + tid] : 0ull;
-        uint32_t mask = static_cast<uint32_t>(rec >> 32) & 0xffffu;
-        const uint32_t row_lo = static_cast<uint32_t>(rec);
-        const int mine = __popc(mask);
-        const int incl = wave_inclusive_scan(mine);
-        if (lane == 63) s_wave_rows[tid >> 6] = incl;
-        __syncthreads();
-        int at = incl - mine, m = 0;
+    // Records are taken kBqFinalRecs per thread at a time (768 per workgroup), the next lot requested before this one is scored.
+    // Where the rows they name fit the expansion buffer together — shuffled rows: a record names ONE row, a query's ~650
+    // records are one lot — they are expanded and scored in one go: one round trip for the records, one for the rows, three
+    // rows of a thread in flight (what round 4's plain row-id lists cost; a record per thread per round trip made the
+    // finalize 5 us slower on shuffled rows).  Where they do not (a sorted catalogue: most of sixteen
+    // rows per record) the thread's records are expanded one after the other, 4096 rows at most each time.
+    constexpr int kRecs = kBqFinalRecs;
+    const uint64_t* const my_recs = cand_recs + static_cast<int64_t>(q) * cand_cap;
+    uint64_t rec_next[kRecs];
 #pragma unroll
-        for (int w = 0; w < kBqFinalBlock / 64; ++w) {
-            const int t = s_wave_rows[w];
-            at += w < (tid >> 6) ? t : 0;
-            m += t;
+    for (int u = 0; u < kRecs; ++u) {
+        const int i = tid + u * kBqFinalBlock;
+        rec_next[u] = i < n_cand ? my_recs[i] : 0ull;
+    }
+    for (int rbase = 0; rbase < n_cand; rbase += kRecs * kBqFinalBlock) {   // uniform
+        uint64_t rec[kRecs];
+        int pc[kRecs], all = 0;
+#pragma unroll
+        for (int u = 0; u < kRecs; ++u) {
+            rec[u] = rec_next[u];
+            const int i = rbase + (kRecs + u) * kBqFinalBlock + tid;
+            rec_next[u] = i < n_cand ? my_recs[i] : 0ull;
+            pc[u] = __popc(static_cast<uint32_t>(rec[u] >> 32) & 0xffffu);
+            all += pc[u];
         }
-        while (mask) {
-            const int i = __builtin_ctz(mask);
-            mask &= mask - 1u;
-            s_rows[at++] = row_lo + static_cast<uint32_t>((i & 3) + 8 * (i >> 2));
+        // where does this thread's first row go, and how many rows are there in all (a wave scan + the waves' totals)
+        auto place = [&](int mine, int& at, int& m) {
+            const int incl = wave_inclusive_scan(mine);
+            if (lane == 63) s_wave_rows[tid >> 6] = incl;
+            __syncthreads();
+            at = incl - mine;
+            m = 0;
+#pragma unroll
+            for (int w = 0; w < kBqFinalBlock / 64; ++w) {
+                const int t = s_wave_rows[w];
+                at += w < (tid >> 6) ? t : 0;
+                m += t;
+            }
+        };
+        auto expand = [&](uint64_t r, int& at) {
+            uint32_t mask = static_cast<uint32_t>(r >> 32) & 0xffffu;
+            const uint32_t row_lo = static_cast<uint32_t>(r);
+            while (mask) {
+                const int i = __builtin_ctz(mask);
+                mask &= mask - 1u;
+                s_rows[at++] = row_lo + static_cast<uint32_t>((i & 3) + 8 * (i >> 2));
+            }
+        };
+        int at, m;
+        place(all, at, m);
+        if (m <= kBqFinalRows) {   // uniform: the whole lot at once
+#pragma unroll
+            for (int u = 0; u < kRecs; ++u) expand(rec[u], at);
+            __syncthreads();
+            examined += m;
+            score_rows(s_rows, m);   // (ends with a barrier: s_rows and s_wave_rows are free again)
+        } else {
+            __syncthreads();         // (everybody has read the waves' totals)
+#pragma unroll
+            for (int u = 0; u < kRecs; ++u) {
+                place(pc[u], at, m);   // (<= 16 rows per thread: fits)
+                expand(rec[u], at);
+                __syncthreads();
+                examined += m;
+                score_rows(s_rows, m);
+            }
         }
-        __syncthreads();
-        examined += m;
-        score_rows(s_rows, m);   // (ends with a barrier: s_rows and s_wave_rows are free again)
     }
     score_rows(special_rows, n_special);
     if (tid == 0) cand_examined[q] = examined;

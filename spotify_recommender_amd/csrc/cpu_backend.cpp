@@ -202,7 +202,7 @@ int topn(const Catalogue* c, const float* q12, int64_t exclude, int topn, int64_
 // ---- the handle: synchronous calls + the ticketed stream ----------------------------------------------------------
 #include <chrono>
 
-#include "mi355rec.h"
+#include "mi355rec_diag.h"
 
 namespace mi355cpu {
 

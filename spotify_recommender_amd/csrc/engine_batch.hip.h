@@ -406,12 +406,25 @@ int ensure_bq_alloc(mi355rec* h) {
     HIP_TRY(h, hipMalloc(&b.cand_rows, sizeof(uint64_t) * static_cast<size_t>(kBqMaxQueries) * b.cand_cap));
     HIP_TRY(h, hipMalloc(&b.cand_examined, sizeof(int) * kBqMaxQueries));
     HIP_TRY(h, hipMemsetAsync(b.cand_examined, 0, sizeof(int) * kBqMaxQueries, h->stream));
-    // [0..3]: batched.hip.h; [5]: queries ever queued; [6]: cand_cap; [8 .. 8 + 128): the queued scan's arrival counters, one per group of queries
+    // [0..3]: batched.hip.h; [4]: chunks that computed neighbourhood bounds, [7]: queries they won for (Batched::h_nb_report); [5]: queries ever queued; [6]: cand_cap; [8 .. 8 + 128): the queued scan's arrival counters, one per group of queries
     HIP_TRY(h, hipMalloc(&b.counters, sizeof(int) * (8 + 128)));
     HIP_TRY(h, hipMemsetAsync(b.counters, 0, sizeof(int) * (8 + 128), h->stream));
     HIP_TRY(h, hipMemcpyAsync(b.counters + 6, &b.cand_cap, sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMalloc(&b.special_rows, sizeof(uint32_t) * kBqSpecialCap));
     HIP_TRY(h, hipMalloc(&b.nb_vals, sizeof(uint32_t) * kBqMaxQueries));
+    {   // (optional: without it the bound is simply computed for every chunk)
+        void* host = nullptr;
+        void* dev = nullptr;
+        if (hipHostMalloc(&host, sizeof(int) * 2, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dev, host, 0) == hipSuccess) {
+            b.h_nb_report = static_cast<volatile int*>(host);
+            b.h_nb_report[0] = 0;
+            b.h_nb_report[1] = 0;
+            b.d_nb_report = static_cast<int*>(dev);
+        } else {
+            if (host) (void)hipHostFree(host);
+            (void)hipGetLastError();
+        }
+    }
     HIP_TRY(h, hipMalloc(&b.gmax, sizeof(float) * static_cast<size_t>(grid) * kBqMaxBlocks * 64));
     // Room for the tile maxima of pass 1 (rows from the replica only).  Optional: without it pass 2 looks at every
     // (tile, query block) pair, as before.
@@ -454,6 +467,7 @@ void free_bq(mi355rec* h) {
                    b.gmax, b.queue, b.qlists, b.d_queries, b.d_exclude, b.tile_max};
     for (void* p : dev)
         if (p) (void)hipFree(p);
+    if (b.h_nb_report) (void)hipHostFree(const_cast<int*>(b.h_nb_report));
     for (int i = 0; i < mi355rec::Batched::kSlots; ++i) {
         if (b.h_queries[i]) (void)hipHostFree(b.h_queries[i]);
         if (b.h_exclude[i]) (void)hipHostFree(b.h_exclude[i]);
@@ -476,7 +490,14 @@ void launch_bq_passes(mi355rec* h, const float* d_queries, const long long* d_ex
     // The same launch takes every query's NEIGHBOURHOOD bound (one workgroup each: batched.hip.h) when the queries exclude
     // rows — their own, for recommendByIndex — so that bq_select has it beside pass 1's group maxima.
     const int prep_blocks = (NB * 32 + 255) / 256;
-    const bool nbhd = d_exclude != nullptr && h->n >= kNbhdRows;
+    bool nbhd = d_exclude != nullptr && h->n >= kNbhdRows;
+    if (nbhd && b.h_nb_report) {   // is it worth its thousand workgroups on this catalogue?  (Batched::h_nb_report)
+        const int wins = b.h_nb_report[0], seen = b.h_nb_report[1];
+        if (wins > 0) b.nb_sparse = false;
+        else if (seen >= kBqNbProbeChunks) b.nb_sparse = true;
+        if (b.nb_sparse && ++b.nb_skipped < kBqNbProbeEvery) nbhd = false;
+        else b.nb_skipped = 0;
+    }
     hipLaunchKernelGGL(bq_prepare_kernel, dim3(prep_blocks + (nbhd ? count : 0)), dim3(256), 0, s, d_queries, count, NB, b.bfrag,
                        b.qnorm, b.qflags, b.cand_count, b.counters, prep_blocks, h->d_feats, h->n, h->row_base, d_exclude, topn, b.nb_vals);
     d_queries = nullptr;
@@ -487,7 +508,8 @@ void launch_bq_passes(mi355rec* h, const float* d_queries, const long long* d_ex
                        d_queries, count, b.qnorm, b.qflags);
     timing_end(h, h->ev_pass, h->n_pass_pairs, slot, s);
     hipLaunchKernelGGL(bq_select_kernel, dim3(NB * 8), dim3(kBqSelectBlock), smem, s, b.gmax, b.grid, NB, topn, b.margin, b.bfrag,
-                       b.qflags, b.qthr, nbhd ? static_cast<const uint32_t*>(b.nb_vals) : static_cast<const uint32_t*>(nullptr), count);
+                       b.qflags, b.qthr, nbhd ? static_cast<const uint32_t*>(b.nb_vals) : static_cast<const uint32_t*>(nullptr), count, b.counters);
+    b.nbhd_this_chunk = nbhd;
     int skip_step = step1;
     {   // experiment builds only: where does pass 2's time go (tools/bq_ab.sh)
         int v = 0;
@@ -543,8 +565,8 @@ int enqueue_bq_chunk(mi355rec* h, const float* d_queries, const long long* d_exc
     hipLaunchKernelGGL(bq_finalize_kernel, dim3(count), dim3(kBqFinalBlock), 0, s, h->d_feats, h->row_base, d_queries,
                        d_exclude, count, topn, b.qflags, b.cand_count, b.cand_rows, b.cand_cap, b.counters, b.special_rows, b.queue,
                        out_keys, out_idx, out_score,
-                       (d_exclude != nullptr && h->n >= kNbhdRows) ? static_cast<const uint32_t*>(b.nb_vals) : static_cast<const uint32_t*>(nullptr),
-                       b.cand_examined);
+                       b.nbhd_this_chunk ? static_cast<const uint32_t*>(b.nb_vals) : static_cast<const uint32_t*>(nullptr),
+                       b.cand_examined, b.nbhd_this_chunk ? b.d_nb_report : static_cast<int*>(nullptr));
     // The exact multi-query scan for whatever the bound could not be claimed for, its merge included (usually
     // nothing: the launch exits at once on an empty queue).
     hipLaunchKernelGGL((scan_multi_queued_kernel<MultiConfig>), dim3(b.qgrid), dim3(MultiConfig::kBlock), 0, s,

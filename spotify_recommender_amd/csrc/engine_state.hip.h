@@ -6,7 +6,11 @@
 // cudaMalloc / cudaMemcpy, Recommender.cu:155-168).
 #pragma once
 
-#include "mi355rec.h"
+// (an MI355REC_EXPERIMENTS build is a test build too: its child-process tests break the hand-offs on purpose)
+#if defined(MI355REC_EXPERIMENTS) && !defined(MI355REC_TEST_HOOKS)
+#define MI355REC_TEST_HOOKS 1
+#endif
+#include "mi355rec_diag.h"
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -15,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <atomic>
+#include <new>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -97,6 +102,7 @@ struct mi355rec {
         void* owned_feats = nullptr;
         void* d_half = nullptr;
         void* d_q8 = nullptr;
+        float margin_mix = 0.0f, margin_mfma = 0.0f;   // of the replicas above (half_selfcheck_kernel's verdict)
     };
     SharedRows* shared = nullptr;
     bool is_lane = false;
@@ -243,6 +249,17 @@ struct mi355rec {
         int* counters = nullptr;         // [4]
         uint32_t* special_rows = nullptr;
         uint32_t* nb_vals = nullptr;     // [1024] the queries' neighbourhood bounds (bq_prepare_kernel), ordered-u32, 0 = none
+        // Does the neighbourhood bound ever beat pass 1's own threshold on THIS catalogue?  It does where similar rows lie next to
+        // each other (a CSV grouped by genre) and never on shuffled rows, where its thousand workgroups are 8 us per chunk for
+        // nothing.  bq_select_kernel counts the queries it won for (counters[7], cumulative); the finalize leaves that count and the
+        // number of chunks that computed it in mapped host memory; the host reads them WITHOUT synchronising when it plans a chunk
+        // (a stale value only delays the decision): after kBqNbProbeChunks chunks without a win the bound is computed for every
+        // kBqNbProbeEvery-th chunk only, and one win switches it back on for good.  Exact either way.
+        volatile int* h_nb_report = nullptr;   // mapped host memory: [0] wins, [1] chunks finished that computed the bound
+        int* d_nb_report = nullptr;            // its device address
+        int nb_skipped = 0;                    // chunks since the last one that computed it (host)
+        bool nb_sparse = false;                // true: only every kBqNbProbeEvery-th chunk computes it
+        bool nbhd_this_chunk = false;          // the chunk being enqueued computes it (launch_bq_passes -> the finalize launch)
         float* gmax = nullptr;           // [grid][32][64]
         // pass 1's per-lane maxima of the tiles it looked at, for pass 2 to skip what they rule out (batched.hip.h,
         // kTileMax): [visited tile][4][64] uint4 = 4 KiB per visited 64-row tile, 16 B per catalogue row at step 4
@@ -452,7 +469,9 @@ void plan_half_grid(mi355rec* h) {
 
 void free_replica(mi355rec* h) {
     // (the replicas themselves stay while a group of lanes shares them: mi355rec_destroy releases the group's reference)
-    void* bufs[] = {h->shared ? nullptr : h->d_half, h->shared ? nullptr : h->d_q8, h->d_half_mseed, h->d_half_rescored, h->d_half_mcuts,
+    // (... the GROUP's: a replica this member was still building when the build failed is its own)
+    const bool groups_half = h->shared && h->shared->d_half == h->d_half, groups_q8 = h->shared && h->shared->d_q8 == h->d_q8;
+    void* bufs[] = {groups_half ? nullptr : h->d_half, groups_q8 ? nullptr : h->d_q8, h->d_half_mseed, h->d_half_rescored, h->d_half_mcuts,
                     h->d_half_mctl};
     h->d_half_mcuts = nullptr;
     h->d_half_mctl = nullptr;

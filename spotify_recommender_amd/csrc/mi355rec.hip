@@ -14,6 +14,9 @@ int mi355rec_build_flags(void) {
 #ifdef MI355REC_PHASE_CLOCK
     flags |= MI355REC_BUILD_PHASE_CLOCK;
 #endif
+#ifdef MI355REC_TEST_HOOKS
+    flags |= MI355REC_BUILD_TEST_HOOKS;
+#endif
     return flags;
 }
 
@@ -25,24 +28,50 @@ int mi355rec_device_count(void) {
 
 const char* mi355rec_last_global_error(void) { return g_last_error.c_str(); }
 
+namespace {
+// The buffers of the STREAMED entry points (two alternating sets of per-workgroup lists for single queries; lists, sample
+// values, cutoffs and arrival counters of the streams of batches) are allocated with the handle, not by the first streamed
+// call: nothing in the serving path allocates or synchronises after create (the six hipMallocs + a stream
+// synchronise of ensure_mstream used to land inside whatever call came first).  A failure here is not the create's: the
+// lazy paths (ensure_streamed / ensure_mstream) try again on first use and report it there.
+void preallocate_stream_state(mi355rec* h) {
+    if (!h || h->n < 1) return;
+    DeviceGuard guard(h->device);
+    const std::string kept = h->err;
+    bool ok = ensure_streamed(h) == MI355REC_OK;
+    if (ok && h->d_half) ok = ensure_mstream(h) == MI355REC_OK;
+    if (!ok) {
+        (void)hipGetLastError();
+        h->err = kept;
+    }
+}
+
+int create_and_preallocate(const float* feats, bool on_device, int64_t n, int dim, int device, int64_t row_base, int flags,
+                           mi355rec_t** out) {
+    const int rc = create_common(feats, on_device, n, dim, device, row_base, flags, out);
+    if (rc == MI355REC_OK) preallocate_stream_state(*out);
+    return rc;
+}
+}  // namespace
+
 int mi355rec_create(const float* feats_host, int64_t n, int dim, int device, int64_t row_base,
                     mi355rec_t** out) {
-    return create_common(feats_host, false, n, dim, device, row_base, 0, out);
+    return create_and_preallocate(feats_host, false, n, dim, device, row_base, 0, out);
 }
 
 int mi355rec_create_device(const float* feats_dev, int64_t n, int dim, int device,
                            int64_t row_base, mi355rec_t** out) {
-    return create_common(feats_dev, true, n, dim, device, row_base, 0, out);
+    return create_and_preallocate(feats_dev, true, n, dim, device, row_base, 0, out);
 }
 
 int mi355rec_create_ex(const float* feats_host, int64_t n, int dim, int device, int64_t row_base, int flags,
                        mi355rec_t** out) {
-    return create_common(feats_host, false, n, dim, device, row_base, flags, out);
+    return create_and_preallocate(feats_host, false, n, dim, device, row_base, flags, out);
 }
 
 int mi355rec_create_device_ex(const float* feats_dev, int64_t n, int dim, int device, int64_t row_base, int flags,
                               mi355rec_t** out) {
-    return create_common(feats_dev, true, n, dim, device, row_base, flags, out);
+    return create_and_preallocate(feats_dev, true, n, dim, device, row_base, flags, out);
 }
 
 void mi355rec_destroy(mi355rec_t* h) {
@@ -157,6 +186,10 @@ int mi355rec_create_lane(mi355rec_t* parent, mi355rec_t** out) {
     }
     lane->is_lane = true;
     lane->replica_allowed = parent->replica_allowed;
+    // a lane takes the routes its parent takes: the modes the parent was forced into (mi355rec_set_replica / _set_batch_path)
+    // are the lane's too, until it is told otherwise itself
+    lane->replica_mode = parent->replica_mode;
+    lane->batch_path = parent->batch_path;
     if (parent->d_half) {
         const int src = alloc_replica_state(lane);
         if (src != MI355REC_OK) {
@@ -170,10 +203,17 @@ int mi355rec_create_lane(mi355rec_t* parent, mi355rec_t** out) {
         }
     }
     if (!parent->shared) {   // from now on the group owns what the parent owned
-        parent->shared = new mi355rec::SharedRows();
-        parent->shared->owned_feats = parent->owned_feats;
-        parent->shared->d_half = parent->d_half;
-        parent->shared->d_q8 = parent->d_q8;
+        mi355rec::SharedRows* group = new (std::nothrow) mi355rec::SharedRows();   // (no exception may cross the C-ABI)
+        if (!group) {
+            mi355rec_destroy(lane);
+            return fail(parent, MI355REC_ERR_OUT_OF_MEMORY, "out of host memory for the lane group");
+        }
+        parent->shared = group;
+        group->owned_feats = parent->owned_feats;
+        group->d_half = parent->d_half;
+        group->d_q8 = parent->d_q8;
+        group->margin_mix = parent->margin_mix;
+        group->margin_mfma = parent->margin_mfma;
     }
     parent->shared->refs.fetch_add(1);
     lane->shared = parent->shared;
@@ -183,16 +223,21 @@ int mi355rec_create_lane(mi355rec_t* parent, mi355rec_t** out) {
     lane->margin_mfma = parent->margin_mfma;
     lane->replica_build_ms = 0.f;
     // A stream for the lane that really runs beside the parent's: test the one create_common made, and while the two share a
-    // hardware queue replace it (every new stream is bound to the next queue), at most once round all of them.
-    for (int attempt = 1; attempt <= 6; ++attempt) {
+    // hardware queue replace it (every new stream is bound to the next queue), at most once round all of them.  The stream the
+    // lane ends up with is always one that was TESTED: after the last attempt nothing is replaced any more (`lane_overlaps` 0
+    // then says no stream was found that runs beside the parent's).  The verdict is the better of three timings of a ~30 us
+    // kernel: with other processes on the same GPU it can come out differently from run to run — a lane is correct on any stream.
+    constexpr int kLaneStreamAttempts = 6;
+    for (int attempt = 1; attempt <= kLaneStreamAttempts; ++attempt) {
         lane->lane_stream_attempts = attempt;
         lane->lane_overlaps = streams_overlap(parent, lane);
-        if (lane->lane_overlaps != 0) break;   // side by side, or cannot tell
+        if (lane->lane_overlaps != 0 || attempt == kLaneStreamAttempts) break;   // side by side, cannot tell, or out of attempts
         hipStream_t fresh = nullptr;
         if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) break;
         (void)hipStreamDestroy(lane->stream);
         lane->stream = fresh;
     }
+    preallocate_stream_state(lane);
     *out = lane;
     return MI355REC_OK;
 }
@@ -571,6 +616,33 @@ int mi355rec_set_batch_path(mi355rec_t* h, int path) {
     return MI355REC_OK;
 }
 
+namespace {
+// A member of a group of lanes whose group got its replicas AFTER this member was made (built on demand by another member):
+// take them — the member's own sample / cutoff state, the group's rows and margins.  No-op otherwise.
+int adopt_group_replica(mi355rec* h) {
+    if (!h->shared || h->d_half || !h->shared->d_half) return MI355REC_OK;
+    DeviceGuard guard(h->device);
+    const int rc = alloc_replica_state(h);
+    if (rc == MI355REC_OK && hipStreamSynchronize(h->stream) != hipSuccess)
+        return fail(h, MI355REC_ERR_HIP, "hipStreamSynchronize(replica state)");
+    if (rc != MI355REC_OK) {
+        void* bufs[] = {h->d_half_mseed, h->d_half_rescored, h->d_half_mcuts, h->d_half_mctl};
+        for (void* b : bufs)
+            if (b) (void)hipFree(b);
+        h->d_half_mseed = nullptr;
+        h->d_half_rescored = nullptr;
+        h->d_half_mcuts = nullptr;
+        h->d_half_mctl = nullptr;
+        return rc;
+    }
+    h->d_half = static_cast<decltype(h->d_half)>(h->shared->d_half);
+    h->d_q8 = static_cast<decltype(h->d_q8)>(h->shared->d_q8);
+    h->margin_mix = h->shared->margin_mix;
+    h->margin_mfma = h->shared->margin_mfma;
+    return MI355REC_OK;
+}
+}  // namespace
+
 int mi355rec_set_replica(mi355rec_t* h, int mode) {
     if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
     if (mode != MI355REC_REPLICA_AUTO && mode != MI355REC_REPLICA_OFF && mode != MI355REC_REPLICA_ON && mode != MI355REC_REPLICA_FP16)
@@ -582,15 +654,22 @@ int mi355rec_set_replica(mi355rec_t* h, int mode) {
     if ((mode == MI355REC_REPLICA_ON || mode == MI355REC_REPLICA_FP16) && !h->d_half && h->n > 0) {
         if (!h->replica_allowed)
             return fail(h, MI355REC_ERR_INVALID_ARG, "this handle was created without a replica (MI355REC_CREATE_NO_REPLICA)");
-        // a small shard (or one whose replica could not be allocated at create): build it now
-        const int rc = mi355rec_rebuild_replica(h);
+        // a small shard (or one whose replica could not be allocated at create): build it now — or, in a group of lanes
+        // where another member has built it since, take the group's
+        int rc = adopt_group_replica(h);
         if (rc) return rc;
+        if (!h->d_half) {
+            rc = mi355rec_rebuild_replica(h);
+            if (rc) return rc;
+        }
+        preallocate_stream_state(h);
     }
     h->replica_mode = mode;
     return MI355REC_OK;
 }
 
-// Test hook for the hand-offs that must fail safe (replica.hip.h): see include/mi355rec.h.
+#ifdef MI355REC_TEST_HOOKS   // libmi355rec_testhooks.so / the experiments build (build.py); NOT in the product library
+// Test hook for the hand-offs that must fail safe (replica.hip.h): see include/mi355rec_diag.h.
 int mi355rec_debug_handoff(mi355rec_t* h, int flags) {
     if (!h) return fail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
     DeviceGuard guard(h->device);
@@ -637,6 +716,8 @@ int mi355rec_debug_handoff(mi355rec_t* h, int flags) {
     return MI355REC_OK;
 }
 
+#endif   // MI355REC_TEST_HOOKS
+
 #ifdef MI355REC_PHASE_CLOCK   // tools/phase_clock.py builds only
 int mi355rec_debug_phase_clock(unsigned long long* out, int n_words) {
     if (hipDeviceSynchronize() != hipSuccess) return MI355REC_ERR_HIP;
@@ -665,7 +746,10 @@ int mi355rec_rebuild_replica(mi355rec_t* h) {
     if (h->n == 0) return MI355REC_OK;
     if (!h->replica_allowed)
         return fail(h, MI355REC_ERR_INVALID_ARG, "this handle was created without a replica (MI355REC_CREATE_NO_REPLICA)");
-    if (h->shared)
+    // In a group of lanes the replicas belong to the group.  While the group HAS none (a shard under 65 536 rows gets none at
+    // create) any member may build them — the others take them over when they are next told to use them
+    // (adopt_group_replica); once it has them they are never rebuilt under the other members' feet.
+    if (h->shared && h->shared->d_half)
         return fail(h, MI355REC_ERR_INVALID_ARG, "the replicas are shared with lanes (mi355rec_create_lane): destroy the lanes, rebuild, create them again");
     DeviceGuard guard(h->device);
     int rc = sync_api_begin(h);
@@ -676,7 +760,14 @@ int mi355rec_rebuild_replica(mi355rec_t* h) {
     if (rc) return rc;
     rc = flush_mstream(h, h->stream);
     if (rc) return rc;
-    return build_replica(h);
+    rc = build_replica(h);
+    if (rc == MI355REC_OK && h->shared) {   // published to the group
+        h->shared->d_half = h->d_half;
+        h->shared->d_q8 = h->d_q8;
+        h->shared->margin_mix = h->margin_mix;
+        h->shared->margin_mfma = h->margin_mfma;
+    }
+    return rc;
 }
 
 int mi355rec_enqueue_merge_keys(mi355rec_t* h, const mi355rec_key_t* lists_dev, int n_lists,

@@ -21,7 +21,7 @@
 #include <vector>
 
 #include "cpu_backend.h"
-#include "mi355rec.h"
+#include "mi355rec_diag.h"
 
 namespace {
 
@@ -39,6 +39,8 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;      // (optional: diagnostics only)
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     bool load(std::string& why) {
         if (lib) return true;
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
@@ -54,6 +56,8 @@ struct Rccl {
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
         AllGather = reinterpret_cast<decltype(AllGather)>(sym("ncclAllGather"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        CommCount = reinterpret_cast<decltype(CommCount)>(sym("ncclCommCount"));
+        CommUserRank = reinterpret_cast<decltype(CommUserRank)>(sym("ncclCommUserRank"));
         if (!CommInitAll || !CommDestroy || !AllGather) {
             why = "librccl lacks the expected symbols";
             return false;

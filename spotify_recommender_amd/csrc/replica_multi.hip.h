@@ -311,11 +311,11 @@ __device__ __forceinline__ uint32_t hm_threshold_slots(float cut) {
 }
 
 // ---- the 8-bit front end ----------------------------------------------------------------------------------
-// Rows come from the 8-bit replica (replica_q8.hip.h: r_j = u_j - 128 in [-127, 127], |r_j / 127 - r^_j| <= 1/254),
+// Rows come from the 8-bit replica (replica_q8.hip.h: signed bytes r_j in [-127, 127], |r_j / 127 - r^_j| <= 1/254),
 // the query is quantised the same way (qh_j = round(127 q^_j)), and v_mfma_i32_32x32x32_i8 forms
 //     D = sum_j r_j qh_j + 127 b12 + 127 b13 + b14 ,      approx8 = sum_j r_j qh_j / 127^2 ,
-// exactly, for 32 rows x 32 queries per instruction: a lane's 16 operand bytes are ITS row (12 bytes, sign bit
-// flipped) + the constants (127, 127, 1, 0), so the A operand is the load itself — no shuffles — and half the
+// exactly, for 32 rows x 32 queries per instruction: a lane's 16 operand bytes are ITS row (12 signed bytes)
+// + the constants (127, 127, 1, 0), so the A operand is the load itself — no shuffles — and half the
 // bytes of the fp16 front end are streamed.  |approx8 - r^ . q^| <= (l1(r^) + l1(q^)) / 254 + 12 / 254^2 with
 // l1(r^) <= sqrt(12): m8(q) = (l1(q^) + 3.4642) / 254 + 2.2e-4 (<= 0.0276).  A row is out for query q if its exact
 // score is below L(q) = cut(q) + margin16 + slack (cut = the fp16 cutoff T' this kernel keeps anyway: L is the
@@ -989,11 +989,11 @@ __global__ __launch_bounds__(kHmBlock, 4) void scan_half_multi_kernel(
             for (int g = 0; g < kHmGroups; ++g) {
                 const uint32_t group_row = static_cast<uint32_t>(step * kHmStepRows + g * 64);   // row of lane 0
                 const bool in_range = group_row + static_cast<uint32_t>(lane) < n32;
-                const bool is_special = in_range && (G[g].d0 & 0xffu) == 0u;
+                const bool is_special = in_range && (G[g].d0 & 0xffu) == kQ8Special;
                 const bool keep = in_range && !is_special;
-                // the lane's row IS its slice of the A operand: 12 bytes with the sign bit flipped (u - 128) + the constants
-                const hm_v4i A = {keep ? static_cast<int>(G[g].d0 ^ 0x80808080u) : 0, keep ? static_cast<int>(G[g].d1 ^ 0x80808080u) : 0,
-                                  keep ? static_cast<int>(G[g].d2 ^ 0x80808080u) : 0, static_cast<int>(kHmQ8RowConst)};
+                // the lane's row IS its slice of the A operand: its 12 signed bytes + the constants
+                const hm_v4i A = {keep ? static_cast<int>(G[g].d0) : 0, keep ? static_cast<int>(G[g].d1) : 0,
+                                  keep ? static_cast<int>(G[g].d2) : 0, static_cast<int>(kHmQ8RowConst)};
                 const uint64_t special = __ballot(is_special);
                 if (special) {   // uniform, rare: one candidate per (special row, query), straight to the exact chain
                     step_cols = 0xffffffffu;

@@ -2,19 +2,28 @@
 //
 // replica.hip.h halves the bytes a query streams (24 B per row instead of the reference's 48,
 // Recommender.cu:184-254) with a copy that is only good enough to rule rows OUT.  The same idea one step
-// further: 12 B per row.  Each row is L2-normalised in fp32 and every component quantised to 8 bits,
-//     u_j = round(127 r^_j) + 128   in [1, 255],          |u_j - 128 - 127 r^_j| <= 1/2,
-// so that for a query q (normalised q^ = q / |q|, kept in fp32 — the query is NOT quantised)
-//     approx = sum_j q^_j (u_j - 128) / 127 ,        |approx - r^ . q^| <= l1(q^) / 254 ,   l1(q^) = sum |q^_j| <= sqrt(12).
-// The bound is PER QUERY (0.0137 at worst, ~0.012 for a typical query) and derived, not tuned: the
-// quantisation error of component j is at most 1/254 and enters the dot product multiplied by |q^_j|; the
-// fp32 evaluation of the 12-term sum, the normalisations and the reference chain's own rounding are covered by
-// kQ8Slack = 3e-5 (each < 6e-6).  tests/test_q8_margin.py checks it on hostile data with a numpy
-// model of exactly this arithmetic.  Everything else is replica.hip.h's scheme, unchanged:
+// further: 12 B per row.  Each row is L2-normalised in fp32 and every component quantised to a SIGNED byte,
+//     k_j = round(127 r^_j)   in [-127, 127],          |k_j - 127 r^_j| <= 1/2,
+// and the query (normalised q^ = q / |q|) to 16 bits, held as two balanced int8 digits per component,
+//     Q_j = round(S q^_j) = 256 h_j + l_j,   S = 32000,   h_j in [-125, 125],   l_j in [-128, 127],
+// so that the dot product the reference takes with cublasSgemv (Recommender.cu:217-223) is, for ruling rows out,
+// SIX v_dot4_i32_i8 per row — three over the high digits, three over the low ones — and one shift-add:
+//     D = sum_j k_j Q_j = 256 sum_j k_j h_j + sum_j k_j l_j          (int32, exact: |D| < 4.2e6)
+//     approx = D / (127 S),        approx - r^ . q^ = sum_j (k_j/127 - r^_j) Q_j/S + sum_j r^_j (Q_j/S - q^_j)
+//     |approx - r^ . q^| <= l1(Q) / (254 S) + l1(r^) / (2 S) <= l1(Q) / (254 S) + sqrt(12) / (2 S).
+// (Until round 5 the query stayed fp32 and a row cost 12 v_cvt_f32_ubyte + 12 v_fmac: 96 vector instructions per lane
+// and 48 B, which kept the kernel at 0.75 of a plain read of its own buffer.)  The candidate test itself is an INTEGER
+// compare: a row is out iff D < floor(cutoff * 127 S) - 1 (q8_threshold: the fp32 product is off by < 0.25).
+// The bound is PER QUERY (0.0137 at worst, ~0.012 for a typical query) and derived, not tuned: the row's
+// quantisation error of component j is at most 1/254 and enters multiplied by |Q_j| / S, the query's is at most
+// 1 / (2 S) and enters multiplied by |r^_j| (5.5e-5 in all); the normalisations in fp32 (v_rsq_f32: the byte may sit
+// 4e-5 of a step off its real-number position), the one rounding of D / (127 S) where a float is wanted and the
+// reference chain's own rounding are covered by kQ8Slack = 3e-5 (together < 8e-6).  tests/test_q8_margin.py checks
+// it on hostile data with a numpy model of exactly this arithmetic.  Everything else is replica.hip.h's scheme:
 //   * the contract per query is recommendByIndex's (Recommender.cu:275-318): every key that leaves the
 //     kernel is cosine_score() on the fp32 row (calculateSimilaritiesCPU, :256-273), bit for bit;
-//   * valid row: |row|^2 in [kBqMinNorm2, kBqMaxNorm2]; an exactly-zero row stores u = 128 everywhere
-//     (approx = 0 = its exact score); every other row (tiny, huge, inf, NaN) stores u = 0 — a byte no
+//   * valid row: |row|^2 in [kBqMinNorm2, kBqMaxNorm2]; an exactly-zero row stores k = 0 everywhere
+//     (approx = 0 = its exact score); every other row (tiny, huge, inf, NaN) stores 0x80 = -128 — a byte no
 //     valid row contains — and is sent to the exact chain every time;
 //   * an invalid query (|q| outside [kBqMinNorm, kBqMaxNorm]) switches the pre-filter off for the launch;
 //   * the launch-wide cutoff comes from a spread sample of 256-row wave tiles (5 % of the catalogue): per tile the
@@ -26,17 +35,29 @@
 // chain instead of 0.05 % — 0.6 MB of random 48 B fetches beside 120 MB of stream.
 //
 // One lane = FOUR rows = 48 B (3 x dwordx4: the same load pattern once more; row r of the lane is dwords
-// 3r .. 3r + 2), tiles of 4 * kBlock rows dealt round-robin over the scanning workgroups.  Per row 12
-// v_cvt_f32_ubyteN + 12 v_fmac_f32 (the query's 12 scaled components are scalar registers).
+// 3r .. 3r + 2), tiles of 4 * kBlock rows dealt round-robin over the scanning workgroups.
+//
+// -DMI355_Q8_QUERY_BITS=8 (A/B builds only) quantises the query to ONE int8 digit, P_j = round(127 q^_j): three
+// v_dot4 per row, and a margin of l1(P) / (254 * 127) + sqrt(12) / 254 — twice the rows to the exact chain.
 #pragma once
 
 #include "replica.hip.h"
 
+#ifndef MI355_Q8_QUERY_BITS
+#define MI355_Q8_QUERY_BITS 16
+#endif
+
 namespace mi355 {
 
-constexpr float kQ8Step = 1.0f / 254.0f;     // half a quantisation step of a normalised component
-constexpr float kQ8Slack = 3e-5f;            // fp32 evaluation of the 12-term sum (terms up to 2, partial sums up to 7: < 6e-6),
-                                             // normalisations and the reference chain's own rounding (< 6e-6), with room to spare
+constexpr int kQ8QueryBits = MI355_Q8_QUERY_BITS;
+static_assert(kQ8QueryBits == 16 || kQ8QueryBits == 8, "the query is one or two int8 digits per component");
+constexpr float kQ8Step = 1.0f / 254.0f;     // half a quantisation step of a normalised row component
+constexpr float kQ8QueryScale = kQ8QueryBits == 16 ? 32000.0f : 127.0f;   // S: Q_j = round(S q^_j)
+constexpr float kQ8DotScale = 127.0f * kQ8QueryScale;                      // approx = D / (127 S)
+constexpr float kQ8QueryResidual = 3.4642f * 0.5f / kQ8QueryScale;         // l1(r^) / (2 S), l1(r^) <= sqrt(12)
+constexpr float kQ8Slack = 3e-5f;            // fp32 normalisations of row and query, the byte's rsq-induced offset, the rounding of
+                                             // D / (127 S) and the reference chain's own rounding (together < 8e-6), with room to spare
+constexpr uint32_t kQ8Special = 0x80u;       // first byte of a row the bound is not claimed for (-128: no valid row holds it)
 
 // ---- building the replica ---------------------------------------------------------------------------
 // One thread per row; rows [n, n_padded) (n_padded a multiple of 4) are padding and hold the special marker.
@@ -44,7 +65,7 @@ __global__ __launch_bounds__(256) void q8_build_kernel(const float* __restrict__
                                                        uint32_t* __restrict__ q8) {
     const int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (row >= n_padded) return;
-    uint32_t d0 = 0u, d1 = 0u, d2 = 0u;   // special
+    uint32_t d0 = 0x80808080u, d1 = 0x80808080u, d2 = 0x80808080u;   // special
     if (row < n) {
         const float4* p = reinterpret_cast<const float4*>(feats) + row * 3;
         const float4 a = p[0], b = p[1], c = p[2];
@@ -64,10 +85,10 @@ __global__ __launch_bounds__(256) void q8_build_kernel(const float* __restrict__
         const bool valid = tot >= kBqMinNorm2 && tot <= kBqMaxNorm2;
         if (valid || tot == 0.0f) {
             const float inv = valid ? __builtin_amdgcn_rsqf(tot) * 127.0f : 0.0f;
-            auto q = [&](float x) {   // round to nearest; |x * inv| <= 127 (1 + 1e-6)
+            auto q = [&](float x) {   // round to nearest; |x * inv| <= 127 (1 + 1e-6); two's complement byte
                 int k = static_cast<int>(__builtin_rintf(x * inv));
                 k = k > 127 ? 127 : (k < -127 ? -127 : k);
-                return static_cast<uint32_t>(k + 128);
+                return static_cast<uint32_t>(k) & 0xffu;
             };
             d0 = q(a.x) | (q(a.y) << 8) | (q(a.z) << 16) | (q(a.w) << 24);
             d1 = q(b.x) | (q(b.y) << 8) | (q(b.z) << 16) | (q(b.w) << 24);
@@ -82,9 +103,10 @@ __global__ __launch_bounds__(256) void q8_build_kernel(const float* __restrict__
 
 // ---- the query ------------------------------------------------------------------------------------------
 struct Q8Query {
-    float s[kDim];   // q^_j / 127 (wave-uniform: scalar registers)
-    float c;         // 128 * sum_j s_j:   approx = sum_j s_j u_j - c
-    float margin;    // l1(q^) / 254 + slack
+    int hi[3];       // the high int8 digits h_j, four per dword in the row's byte order (wave-uniform: scalar registers)
+    int lo[3];       // the low digits l_j (16-bit query only)
+    float inv;       // 1 / (127 S):   approx = D * inv
+    float margin;    // l1(Q) / (254 S) + l1(r^) / (2 S) + slack
     bool ok;         // the bound may be claimed for this query
 };
 
@@ -92,43 +114,62 @@ __device__ __forceinline__ Q8Query q8_query(const float (&q)[kDim], float qn) {
     Q8Query r;
     r.ok = qn >= kBqMinNorm && qn <= kBqMaxNorm;   // false for NaN
     const float inv = r.ok ? 1.0f / qn : 0.0f;
-    float sum = 0.0f, l1 = 0.0f;
+    r.hi[0] = r.hi[1] = r.hi[2] = 0;
+    r.lo[0] = r.lo[1] = r.lo[2] = 0;
+    int l1 = 0;
+    constexpr int kMax = static_cast<int>(kQ8QueryScale);
 #pragma unroll
     for (int j = 0; j < kDim; ++j) {
-        const float u = q[j] * inv;
-        r.s[j] = u * (1.0f / 127.0f);
-        sum += r.s[j];
-        l1 += __builtin_fabsf(u);
+        int Q = static_cast<int>(__builtin_rintf(q[j] * inv * kQ8QueryScale));   // |q^_j| <= 1 + 1e-6
+        Q = Q > kMax ? kMax : (Q < -kMax ? -kMax : Q);
+        l1 += Q < 0 ? -Q : Q;
+        if constexpr (kQ8QueryBits == 16) {
+            const int h = (Q + 128) >> 8;      // balanced digits: Q = 256 h + l, l in [-128, 127], |h| <= 125
+            const int l = Q - 256 * h;
+            r.hi[j >> 2] |= (h & 0xff) << (8 * (j & 3));
+            r.lo[j >> 2] |= (l & 0xff) << (8 * (j & 3));
+        } else {
+            r.hi[j >> 2] |= (Q & 0xff) << (8 * (j & 3));
+        }
     }
-    r.c = 128.0f * sum;
-    r.margin = l1 * kQ8Step * (1.0f + 1e-5f) + kQ8Slack;
+    r.inv = 1.0f / kQ8DotScale;
+    r.margin = static_cast<float>(l1) * (kQ8Step / kQ8QueryScale) * (1.0f + 1e-5f) + kQ8QueryResidual + kQ8Slack;
     return r;
 }
 
-// approx of one row (3 dwords); `special` = the row is sent to the exact chain whatever approx says
-__device__ __forceinline__ float q8_dot(const Q8Query& q, uint32_t d0, uint32_t d1, uint32_t d2, bool& special) {
-    special = (d0 & 0xffu) == 0u;
-    float acc = -q.c;
-    acc = __builtin_fmaf(static_cast<float>(d0 & 0xffu), q.s[0], acc);
-    acc = __builtin_fmaf(static_cast<float>((d0 >> 8) & 0xffu), q.s[1], acc);
-    acc = __builtin_fmaf(static_cast<float>((d0 >> 16) & 0xffu), q.s[2], acc);
-    acc = __builtin_fmaf(static_cast<float>(d0 >> 24), q.s[3], acc);
-    acc = __builtin_fmaf(static_cast<float>(d1 & 0xffu), q.s[4], acc);
-    acc = __builtin_fmaf(static_cast<float>((d1 >> 8) & 0xffu), q.s[5], acc);
-    acc = __builtin_fmaf(static_cast<float>((d1 >> 16) & 0xffu), q.s[6], acc);
-    acc = __builtin_fmaf(static_cast<float>(d1 >> 24), q.s[7], acc);
-    acc = __builtin_fmaf(static_cast<float>(d2 & 0xffu), q.s[8], acc);
-    acc = __builtin_fmaf(static_cast<float>((d2 >> 8) & 0xffu), q.s[9], acc);
-    acc = __builtin_fmaf(static_cast<float>((d2 >> 16) & 0xffu), q.s[10], acc);
-    acc = __builtin_fmaf(static_cast<float>(d2 >> 24), q.s[11], acc);
-    return acc;
+// D of one row (3 dwords); `special` = the row is sent to the exact chain whatever D says
+__device__ __forceinline__ int q8_dot(const Q8Query& q, uint32_t d0, uint32_t d1, uint32_t d2, bool& special) {
+    special = (d0 & 0xffu) == kQ8Special;
+    int hi = __builtin_amdgcn_sdot4(static_cast<int>(d0), q.hi[0], 0, false);
+    hi = __builtin_amdgcn_sdot4(static_cast<int>(d1), q.hi[1], hi, false);
+    hi = __builtin_amdgcn_sdot4(static_cast<int>(d2), q.hi[2], hi, false);
+    if constexpr (kQ8QueryBits == 16) {
+        int lo = __builtin_amdgcn_sdot4(static_cast<int>(d0), q.lo[0], 0, false);
+        lo = __builtin_amdgcn_sdot4(static_cast<int>(d1), q.lo[1], lo, false);
+        lo = __builtin_amdgcn_sdot4(static_cast<int>(d2), q.lo[2], lo, false);
+        return (hi << 8) + lo;   // (v_lshl_add_u32)
+    } else {
+        return hi;
+    }
 }
 
-__device__ __forceinline__ void q8_dot4(const Q8Query& q, const HalfTile& t, float (&a)[4], bool (&special)[4]) {
+__device__ __forceinline__ void q8_dot4(const Q8Query& q, const HalfTile& t, int (&a)[4], bool (&special)[4]) {
     a[0] = q8_dot(q, t.t0.x, t.t0.y, t.t0.z, special[0]);
     a[1] = q8_dot(q, t.t0.w, t.t1.x, t.t1.y, special[1]);
     a[2] = q8_dot(q, t.t1.z, t.t1.w, t.t2.x, special[2]);
     a[3] = q8_dot(q, t.t2.y, t.t2.z, t.t2.w, special[3]);
+}
+
+// approx as a float (samples, diagnostics): |D| < 2^24 converts exactly, one rounding in the product
+__device__ __forceinline__ float q8_approx(const Q8Query& q, int d) { return static_cast<float>(d) * q.inv; }
+
+// The integer image of a cutoff: a row whose D is below it has approx < cutoff.  The fp32 product cutoff * 127 S is off
+// by < 0.25 (|cutoff| <= 2: 2^-24 relative of at most 8.2e6), floor(...) - 1 stays below the real-number product.
+// -inf / NaN (no bound) => INT_MIN: every row is a candidate.
+__device__ __forceinline__ int q8_threshold(float cutoff) {
+    if (!(cutoff > -2.0f)) return static_cast<int>(0x80000000u);
+    const float c = cutoff < 2.0f ? cutoff : 2.0f;
+    return static_cast<int>(__builtin_floorf(c * kQ8DotScale)) - 1;
 }
 
 // ---- the sample that seeds the launch-wide cutoff ---------------------------------------------------------
@@ -166,7 +207,7 @@ struct Q8Pick {
 
 __device__ __forceinline__ Q8Pick q8_region_pick(const Q8Region& s, const Q8Query& q, int64_t n, int64_t row_base,
                                                  int64_t exclude_global) {
-    float a[4];
+    int a[4];
     bool special[4];
     q8_dot4(q, s.t, a, special);
     const int64_t r0 = s.quad * 4;
@@ -175,7 +216,7 @@ __device__ __forceinline__ Q8Pick q8_region_pick(const Q8Region& s, const Q8Quer
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const bool use = s.have && q.ok && !special[u] && r0 + u < n && row_base + r0 + u != exclude_global;
-        const uint32_t w = use ? score_to_ordered(a[u]) : 0u;
+        const uint32_t w = use ? score_to_ordered(q8_approx(q, a[u])) : 0u;
         best = w > v ? u : best;
         v = w > v ? w : v;
     }
@@ -435,7 +476,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
     const float qn = query_norm(q);
     const Q8Query hq = q8_query(q, qn);
     const Sample sample = sample_finish(sample_raw, epoch);
-    if (hq.c != 0.0f || n >= 0) MI355REC_PHASE(1);   // (depends on the query: not hoisted above its load)
+    if (hq.hi[0] != 0 || n >= 0) MI355REC_PHASE(1);   // (depends on the query: not hoisted above its load)
     if (sample.v[0] != 0x12345u || n >= 0) MI355REC_PHASE(6);   // (depends on this thread's sample values: they have arrived)
 
     // ---- launch-wide cutoff (while the first tiles are in flight)
@@ -460,6 +501,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
             cutoff = nb_cut > cutoff ? nb_cut : cutoff;
         }
     }
+    int cut_d = q8_threshold(cutoff);   // the cutoff's integer image: a row is out iff D < cut_d
     MI355REC_PHASE(2);
     int compact_at = 2 * topk > 256 ? 2 * topk : 256;
     if (compact_at > kCandLimit) compact_at = kCandLimit;
@@ -495,17 +537,25 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
     auto process_tile = [&](const HalfTile& t, int it) {
         const int64_t quad = quad_begin + static_cast<int64_t>(it) * quad_stride;
         const int64_t r0 = quad * 4;
-        float a[4];
+        int a[4];
         bool special[4];
         q8_dot4(hq, t, a, special);
-        uint32_t mask = 0u;   // which of the lane's four rows are candidates
+        // The common case — no lane of the wave holds a candidate — is decided on the scalar side: four integer compares and four
+        // byte compares per lane, their wave masks OR-ed.  Whether a row lies inside the shard at all (the last quad's
+        // padding, the clamped prefetch past the end) only matters once something hit, and is settled there.
+        bool hit[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bool maybe = quad < n_quads && r0 + u < n && (special[u] || !(a[u] < cutoff));
-            mask |= maybe ? (1u << u) : 0u;
-        }
+        for (int u = 0; u < 4; ++u) hit[u] = special[u] | (a[u] >= cut_d);
+        const uint64_t maybe = __ballot(hit[0] | hit[1] | hit[2] | hit[3]);
         consume();   // the rows fetched while the previous tile was scanned
-        const uint64_t any = __ballot(mask != 0u);
+        uint32_t mask = 0u;   // which of the lane's four rows are candidates
+        if (maybe) {          // uniform
+            const int64_t left = n - r0;
+            const int valid = quad < n_quads ? (left < 4 ? static_cast<int>(left) : 4) : 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) mask |= (hit[u] && u < valid) ? (1u << u) : 0u;
+        }
+        const uint64_t any = maybe ? __ballot(mask != 0u) : 0ull;
         if (any) {
             n_rescored += __popcll(any);
             const int first = mask ? __builtin_ctz(mask) : 0;
@@ -533,6 +583,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
                 if (hq.ok) {
                     const float local_cut = ordered_to_score(static_cast<uint32_t>(thr >> 32)) - hq.margin;
                     cutoff = local_cut > cutoff ? local_cut : cutoff;
+                    cut_d = q8_threshold(cutoff);
                 }
             }
         }

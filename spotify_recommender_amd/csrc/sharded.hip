@@ -359,6 +359,29 @@ int mi355rec_sharded_info(const mi355rec_sharded_t* h, int* n_shards, int* trans
 
 const char* mi355rec_sharded_note(const mi355rec_sharded_t* h) { return h ? h->note.c_str() : ""; }
 
+// What RCCL itself says about the communicators of the RCCL transport (include/mi355rec_diag.h): *comms = communicators this
+// handle holds (one per shard; 0 until the transport has been used), *ranks = ncclCommCount of the first one, *ranks_agree = 1
+// when every communicator reports that same count and its own shard index as its rank.
+int mi355rec_sharded_rccl_ranks(const mi355rec_sharded_t* h, int* comms, int* ranks, int* ranks_agree) {
+    if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
+    int n_comms = 0, first = 0, agree = 1;
+    if (!h->cpu && h->rccl_ready && g_rccl.CommCount) {
+        for (size_t r = 0; r < h->shards.size(); ++r) {
+            if (!h->shards[r].comm) continue;
+            int count = 0, rank = -1;
+            if (g_rccl.CommCount(h->shards[r].comm, &count) != 0) count = -1;
+            if (g_rccl.CommUserRank && g_rccl.CommUserRank(h->shards[r].comm, &rank) != 0) rank = -1;
+            if (n_comms == 0) first = count;
+            if (count != first || (g_rccl.CommUserRank && rank != static_cast<int>(r))) agree = 0;
+            ++n_comms;
+        }
+    }
+    if (comms) *comms = n_comms;
+    if (ranks) *ranks = first;
+    if (ranks_agree) *ranks_agree = n_comms > 0 ? agree : 0;
+    return MI355REC_OK;
+}
+
 int mi355rec_sharded_set_timing(mi355rec_sharded_t* h, int enabled) {
     if (!h) return sfail(nullptr, MI355REC_ERR_INVALID_ARG, "null handle");
     if (h->cpu) return MI355REC_OK;   // (no kernels to time)

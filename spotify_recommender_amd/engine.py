@@ -484,6 +484,13 @@ class NodeEngine:
     def set_replica(self, mode: int) -> None:
         self._check(self._lib.mi355rec_sharded_set_replica(self._h, int(mode)))
 
+    def rccl_ranks(self) -> dict:
+        """What RCCL reports about the RCCL transport's communicators (mi355rec_sharded_rccl_ranks): how many the handle holds,
+        ncclCommCount of the first, and whether all of them agree (0 / 0 / False until that transport has been used)."""
+        comms, ranks, agree = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        self._check(self._lib.mi355rec_sharded_rccl_ranks(self._h, ctypes.byref(comms), ctypes.byref(ranks), ctypes.byref(agree)))
+        return {"communicators": int(comms.value), "ranks": int(ranks.value), "ranks_agree": bool(agree.value)}
+
     def rows_by_pointer(self) -> bool:
         return bool(self._lib.mi355rec_sharded_rows_by_pointer(self._h))
 

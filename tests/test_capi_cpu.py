@@ -9,19 +9,32 @@ import pytest
 from spotify_recommender_amd import capi, engine
 
 
-def declared_symbols(root):
-    text = (root / "include" / "mi355rec.h").read_text()
+def declared_symbols(root, header, defines=()):
+    """Function names a header declares; blocks under `#ifdef X` count only when X is in `defines`."""
+    text = (root / "include" / header).read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for m in re.finditer(r"#ifdef (MI355REC_TEST_HOOKS)\n(.*?)#endif", text, flags=re.S):
+        if m.group(1) not in defines:
+            text = text.replace(m.group(0), "")
     return sorted(set(re.findall(r"\b(mi355rec_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_every_declared_symbol_is_exported(engine_lib, golden_dir):
+    """The PRODUCT library exports exactly what include/mi355rec.h (the core: at most 30 entry points) and
+    include/mi355rec_diag.h declare without -DMI355REC_TEST_HOOKS; the test hooks are NOT in it; capi.py binds all of them."""
     root = golden_dir.parents[1]
-    names = declared_symbols(root)
-    assert len(names) >= 20
-    for name in names:
-        assert hasattr(engine_lib, name), f"{name} declared in mi355rec.h but not exported"
-    assert set(names) == set(capi.SIGNATURES), "capi.py and mi355rec.h disagree"
+    core = declared_symbols(root, "mi355rec.h")
+    diag = declared_symbols(root, "mi355rec_diag.h")
+    hooks = set(declared_symbols(root, "mi355rec_diag.h", defines=("MI355REC_TEST_HOOKS",))) - set(diag)
+    assert 20 <= len(core) <= 30, core
+    assert not set(core) & set(diag)
+    assert hooks == set(capi.TEST_HOOKS)
+    for name in core + diag:
+        assert hasattr(engine_lib, name), f"{name} declared but not exported"
+    for name in hooks:
+        assert not hasattr(engine_lib, name), f"{name} is a test hook: it must not be in the product library"
+    assert set(core) | set(diag) | hooks == set(capi.SIGNATURES), "capi.py and the headers disagree"
+    assert not capi.has_test_hooks() and not capi.has_experiments()
 
 
 def test_key_helpers_roundtrip(engine_lib):

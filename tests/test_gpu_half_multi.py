@@ -343,6 +343,10 @@ def test_stream_of_batches_fails_safe_under_stale_hand_offs(Engine, torch_cuda):
     mi355rec_debug_handoff: stale samples of earlier batches (a perfect score under the last epochs), cutoffs of
     +1.0, dropped stores, launches without a last rider.  Wrong-epoch values count as absent, so every key list must
     still be the one the plain (not streamed) path returns.  (tests/test_gpu_replica.py has the single-query twin.)"""
+    from spotify_recommender_amd import capi as _capi
+    if not _capi.has_test_hooks():
+        pytest.skip("mi355rec_debug_handoff is not in the product library: this test runs against libmi355rec_testhooks.so "
+                    "(tests/test_gpu_testhooks.py, a child process)")
     from spotify_recommender_amd import capi
     torch = torch_cuda
     rng = np.random.default_rng(99)

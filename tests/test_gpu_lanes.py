@@ -116,3 +116,65 @@ def test_a_lane_gets_a_stream_that_runs_beside_its_parents(catalogue):
             # an environment in which no two streams of the process run side by side (one hardware queue, a tracer that serialises
             # dispatches): the library said so, which is what it is for — lanes buy nothing here, and nothing is wrong with them
             pytest.xfail(f"no stream runs beside the parent's on this box: {stats}")
+
+
+def test_a_group_without_replicas_builds_them_on_demand_and_lanes_inherit_the_modes():
+    """ADVICE r5 (medium).  A shard under 65 536 rows gets no replica at create.  (1) Any member of a group of lanes may then
+    build it (mi355rec_set_replica(ON)); the other members take the group's over when they are told the same; once the group has
+    replicas a rebuild is refused as before.  (2) A lane starts in its parent's replica mode and batch path.  (3) The node handle:
+    REPLICATED {0, 0} (the second replica is a lane of the first) at 30 000 rows, mi355rec_sharded_set_replica(ON), queries."""
+    import torch
+    from spotify_recommender_amd import capi
+    from spotify_recommender_amd.engine import CosineEngine, NodeEngine
+    rng = np.random.default_rng(77)
+    n, topn = 30_000, 20
+    f = rng.random((n, 12), dtype=np.float32)
+    f[n - 2] = f[5]
+    with CosineEngine(f) as eng:
+        assert eng.stats().device_bytes_per_row == 48            # no replica at this size
+        lane = eng.lane()
+        lane.set_replica(capi.REPLICA_ON)                        # a LANE builds the group's replicas
+        assert lane.stats().device_bytes_per_row == 84 and lane.stats().replica_active == 1
+        assert eng.stats().device_bytes_per_row == 48            # the parent has not been told yet
+        eng.set_replica(capi.REPLICA_ON)                         # ... and takes the group's over, nothing rebuilt
+        assert eng.stats().device_bytes_per_row == 84 and eng.stats().replica_active == 1
+        with pytest.raises(capi.Mi355Error):
+            eng.rebuild_replica()                                # shared replicas are not rebuilt under a lane
+        for h in (eng, lane):
+            for row in (5, n - 1, 12_345):
+                idx, sc = h.query_row_topn(row, topn)
+                assert_topn_matches(idx, sc, oracle.scores(f, f[row]), row, topn)
+            before = h.stats()
+            out = torch.zeros(topn, dtype=torch.int64, device="cuda")
+            h.enqueue_row_keys_streamed(4_321, topn, out)
+            h.enqueue_flush()
+            torch.cuda.synchronize()
+            check_keys(f, 4_321, out.cpu().numpy(), topn)
+            assert h.stats().route_q8 + h.stats().route_q8_lone > before.route_q8 + before.route_q8_lone   # forced ON: over the replica
+        lane2 = eng.lane()                                       # made after the replicas: has them, and the parent's mode
+        assert lane2.stats().replica_active == 1
+        eng.set_replica(capi.REPLICA_OFF)
+        eng.set_batch_path(capi.BATCH_MULTI)
+        lane3 = eng.lane()                                       # the parent's forced modes are the lane's
+        s0 = lane3.stats()
+        assert s0.replica_active == 0
+        qr = rng.integers(0, n, size=14)
+        bi, bs, cnt = lane3.query_batch_topn(f[qr], qr, topn)
+        s1 = lane3.stats()
+        assert s1.route_multi_fp32 > s0.route_multi_fp32 and s1.route_multi_fp16 == s0.route_multi_fp16
+        for b in (0, 13):
+            assert_topn_matches(bi[b][:cnt[b]], bs[b][:cnt[b]], oracle.scores(f, f[qr[b]]), int(qr[b]), topn)
+        for h in (lane, lane2, lane3):
+            h.close()
+    with NodeEngine(f, devices=[0, 0], placement=capi.PLACEMENT_REPLICATED) as node:
+        node.set_replica(capi.REPLICA_ON)                        # used to fail on the second replica (a lane)
+        assert node.shard_stats(0).replica_active == 1 and node.shard_stats(1).replica_active == 1
+        for row in (5, n - 2, 999, 29_999):                      # synchronous calls take the replicas in turn
+            idx, sc = node.query_row_topn(row, topn)
+            want = oracle.scores(f, f[row])
+            assert_topn_matches(idx, sc, want, row, topn, ref_idx=oracle.topn_heap(want, row, topn))
+        tickets = [node.enqueue_row(r, topn) for r in (1, 2, 3, 4, 5, 6)]
+        node.enqueue_flush()
+        for t, r in zip(tickets, (1, 2, 3, 4, 5, 6)):
+            idx, sc = node.wait(t, topn)
+            assert_topn_matches(idx, sc, oracle.scores(f, f[r]), r, topn)

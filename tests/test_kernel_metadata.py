@@ -47,3 +47,21 @@ def test_hand_offs_wait_for_their_stores(engine_lib):
         assert any(fragment in k for k in kernels), (fragment, sorted(kernels))
     bad = sorted({k for k, ok in sites if not ok})
     assert not bad, bad
+
+
+def test_the_test_hooks_build_has_the_products_kernels(kernels):
+    """libmi355rec_testhooks.so (the product's sources + -DMI355REC_TEST_HOOKS: mi355rec_debug_handoff, a HOST function) carries
+    the same kernels as the product library, register for register: the tests that break hand-offs on purpose
+    (tests/test_gpu_testhooks.py) run against the device code that ships."""
+    lib = build.build_testhooks()
+    assert lib.exists()
+    import ctypes
+    from spotify_recommender_amd import capi
+    handle = ctypes.CDLL(str(lib))
+    for name in capi.SIGNATURES:                       # ... and exports the whole C-ABI, the hooks included
+        assert hasattr(handle, name), name
+    handle.mi355rec_build_flags.restype = ctypes.c_int
+    assert handle.mi355rec_build_flags() == capi.BUILD_TEST_HOOKS
+    theirs = {k["name"]: (k["vgpr"], k["sgpr"], k["lds"], k["scratch"]) for k in build.kernel_metadata(lib)}
+    ours = {k["name"]: (k["vgpr"], k["sgpr"], k["lds"], k["scratch"]) for k in kernels}
+    assert theirs == ours

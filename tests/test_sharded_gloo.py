@@ -135,6 +135,18 @@ def _worker(rank, world, port, n_rows, result_dir):
             ci, _ = oracle.topn_canonical(oracle.scores(f, f[q]), q, 10)
             assert idx.tolist() == ci.tolist(), (rank, q)
             out[f"window_{q}"] = idx
+        # what an N > 1 bench line says about its process group (bench.py's `group` object): every rank
+        # gets the same report, the ranks are COUNTED by an all-reduce, and every rank's kernel figures are in it
+        from spotify_recommender_amd.benchlegs import rank_group_report
+        rep = rank_group_report(dist, torch, rank, world, torch.device("cpu"), f"cpu-rank{rank}", f"uuid-{rank}",
+                                kernel_ms=0.01 * (rank + 1), alg_bytes=(hi - lo) * 48)
+        assert rep["backend"] == "gloo" and rep["ranks"] == world and rep["ranks_counted"] == world
+        assert rep["launcher_world_size"] == world and rep["distinct_devices"] == world and len(rep["devices"]) == world
+        assert [g["rank"] for g in rep["per_gpu"]] == list(range(world))
+        for g in rep["per_gpu"]:
+            assert g["avg_kernel_ms"] == round(0.01 * (g["rank"] + 1), 5) and g["frac"] > 0 and g["algorithmic_bytes_per_launch"] > 0
+        assert sum(g["algorithmic_bytes_per_launch"] for g in rep["per_gpu"]) == n_rows * 48     # the shards cover the catalogue
+        out["group_ranks_counted"] = np.array([rep["ranks_counted"]])
         np.savez(Path(result_dir) / f"rank{rank}.npz", **out)
     finally:
         dist.destroy_process_group()

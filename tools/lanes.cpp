@@ -11,7 +11,7 @@
 
 #include <hip/hip_runtime_api.h>
 
-#include "mi355rec.h"
+#include "mi355rec_diag.h"
 
 int main(int argc, char** argv) {
     const int64_t n = argc > 1 ? atoll(argv[1]) : 10000000;

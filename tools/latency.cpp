@@ -20,7 +20,7 @@
 #include <vector>
 
 #include "Recommender.h"
-#include "mi355rec.h"
+#include "mi355rec_diag.h"
 
 namespace {
 
