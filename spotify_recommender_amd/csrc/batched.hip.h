@@ -186,16 +186,24 @@ __global__ __launch_bounds__(256) void bq_prepare_kernel(
     int* __restrict__ counters /* [0] special rows, [1] queued queries, [2] chunk-wide queue flag,
                                   [3] (tile, query block) pairs pass 2 ran its MFMAs for (diagnostics) */,
     int prep_blocks, const float* __restrict__ feats, int64_t n, int64_t row_base, const long long* __restrict__ exclude /* may be null */,
-    int topk, uint32_t* __restrict__ nb_vals /* [n_queries] */) {
+    int topk, uint32_t* __restrict__ nb_vals /* [n_queries] */, const float* __restrict__ anchors /* the handle's anchor table, or null */) {
     if (static_cast<int>(blockIdx.x) >= prep_blocks) {   // uniform: a neighbourhood workgroup
         __shared__ int s_scratch[Nbhd<256, kBqNbhdRows>::kScratch];
         const int nq = static_cast<int>(blockIdx.x) - prep_blocks;
         // (1024 rows here, not the single queries' 2048: a thousand of these workgroups ride in every chunk's first launch)
-        const Nbhd<256, kBqNbhdRows> nb = nbhd_request<256, kBqNbhdRows>(feats, n, row_base, exclude ? exclude[nq] : -1ll, topk);
+        const long long excl = exclude ? exclude[nq] : -1ll;
         float qv[kDim];
+        uint32_t v;
+        if (nbhd_has_center(n, row_base, excl)) {   // uniform: the rows are requested before the query is loaded
+            const Nbhd<256, kBqNbhdRows> nb = nbhd_request<256, kBqNbhdRows>(feats, n, row_base, excl, topk);
 #pragma unroll
-        for (int j = 0; j < kDim; ++j) qv[j] = queries[static_cast<int64_t>(nq) * kDim + j];
-        const uint32_t v = nbhd_finish<256, kBqNbhdRows>(nb, qv, query_norm(qv), topk, s_scratch);
+            for (int j = 0; j < kDim; ++j) qv[j] = queries[static_cast<int64_t>(nq) * kDim + j];
+            v = nbhd_finish<256, kBqNbhdRows>(nb, qv, query_norm(qv), topk, s_scratch);
+        } else {                                    // a query by value: around its anchor (handoff.hip.h)
+#pragma unroll
+            for (int j = 0; j < kDim; ++j) qv[j] = queries[static_cast<int64_t>(nq) * kDim + j];
+            v = nbhd_bound<256, kBqNbhdRows>(feats, n, row_base, excl, qv, query_norm(qv), topk, s_scratch, anchors);
+        }
         if (threadIdx.x == 0) nb_vals[nq] = v;
         return;
     }

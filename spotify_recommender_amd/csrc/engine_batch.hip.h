@@ -90,10 +90,11 @@ bool half_multi_ok(const mi355rec* h, int topn) {
            h->hg.seed_grid * kHalfSeedWaves >= topn;
 }
 
-void fill_half_multi_arg(HalfMultiArg& arg, float margin, const float* queries, const float* const* qptrs, const int64_t* exclude,
+void fill_half_multi_arg(HalfMultiArg& arg, const mi355rec* h, const float* queries, const float* const* qptrs, const int64_t* exclude,
                          int g0, int nq) {
     std::memset(&arg, 0, sizeof arg);
-    arg.margin = margin;
+    arg.margin = h->margin_mfma;
+    arg.anchors = h->d_anchor;
     for (int q = 0; q < kHmQueries; ++q) {
         arg.exclude[q] = -1;
         if (q >= nq) continue;
@@ -128,7 +129,7 @@ int enqueue_half_multi(mi355rec* h, const float* queries, const float* const* qp
     HalfMultiArg arg;
     for (int g0 = 0; g0 < count; g0 += kHmQueries) {
         const int nq = count - g0 < kHmQueries ? count - g0 : kHmQueries;
-        fill_half_multi_arg(arg, h->margin_mfma, queries, qptrs, exclude, g0, nq);
+        fill_half_multi_arg(arg, h, queries, qptrs, exclude, g0, nq);
         const uint32_t epoch = next_epoch(h);
         // the sample launch's last workgroup selects the cutoffs; the pass reads them (stream order)
         const unsigned long long* const cuts = h->d_half_mcuts;
@@ -233,7 +234,13 @@ int launch_mstash(mi355rec* h, hipStream_t s, const HalfMultiArg* next, int next
         ride.seed_wgs = kHmRiders << ride.sample_log2;
         MI355REC_EXP_INT(ride.seed_wgs, "MI355REC_EXP_RIDERS", 1, 512);
         if (ride.seed_wgs > h->hg.seed_grid) ride.seed_wgs = h->hg.seed_grid;
-        ride.nb_wgs = (next_nq + kHmNbhdPerWg - 1) / kHmNbhdPerWg;
+        // (a query that excludes no row of this shard looks for its anchor first — handoff.hip.h, nbhd_anchor: two more round
+        // trips per query — so a workgroup takes half as many of a batch that holds such queries)
+        bool anchors = false;
+        for (int q = 0; q < next_nq; ++q)
+            anchors = anchors || next->exclude[q] < h->row_base || next->exclude[q] >= h->row_base + h->n;
+        const int per_wg = anchors ? (kHmNbhdPerWg + 1) / 2 : kHmNbhdPerWg;
+        ride.nb_wgs = (next_nq + per_wg - 1) / per_wg;
         ride.next_queries = next_nq;
         ride.regions = h->hg.seed_grid;
         ride.stride_rows = h->hg.seed_stride;
@@ -308,7 +315,7 @@ int enqueue_mstream(mi355rec* h, const float* queries, const float* const* qptrs
     int rc = ensure_mstream(h);
     if (rc) return rc;
     HalfMultiArg arg;
-    fill_half_multi_arg(arg, h->margin_mfma, queries, qptrs, exclude, g0, nq);
+    fill_half_multi_arg(arg, h, queries, qptrs, exclude, g0, nq);
     int seed_buf = 0;
     bool cuts_ready = false;
     const uint32_t epoch = next_epoch(h);   // the tag of this batch's sample values and cutoffs
@@ -490,7 +497,7 @@ void launch_bq_passes(mi355rec* h, const float* d_queries, const long long* d_ex
     // The same launch takes every query's NEIGHBOURHOOD bound (one workgroup each: batched.hip.h) when the queries exclude
     // rows — their own, for recommendByIndex — so that bq_select has it beside pass 1's group maxima.
     const int prep_blocks = (NB * 32 + 255) / 256;
-    bool nbhd = d_exclude != nullptr && h->n >= kNbhdRows;
+    bool nbhd = h->n >= kNbhdRows;   // (queries without an excluded row here take the bound around their anchor: handoff.hip.h)
     if (nbhd && b.h_nb_report) {   // is it worth its thousand workgroups on this catalogue?  (Batched::h_nb_report)
         const int wins = b.h_nb_report[0], seen = b.h_nb_report[1];
         if (wins > 0) b.nb_sparse = false;
@@ -499,7 +506,8 @@ void launch_bq_passes(mi355rec* h, const float* d_queries, const long long* d_ex
         else b.nb_skipped = 0;
     }
     hipLaunchKernelGGL(bq_prepare_kernel, dim3(prep_blocks + (nbhd ? count : 0)), dim3(256), 0, s, d_queries, count, NB, b.bfrag,
-                       b.qnorm, b.qflags, b.cand_count, b.counters, prep_blocks, h->d_feats, h->n, h->row_base, d_exclude, topn, b.nb_vals);
+                       b.qnorm, b.qflags, b.cand_count, b.counters, prep_blocks, h->d_feats, h->n, h->row_base, d_exclude, topn, b.nb_vals,
+                       static_cast<const float*>(h->d_anchor));
     d_queries = nullptr;
     int slot = timing_begin(h, h->ev_pass, h->n_pass_pairs, h->pass_launches, s);
     hipLaunchKernelGGL((bq_pass_kernel<NB, false, 0, kFromReplica, kTileMax>), dim3(b.grid), dim3(kBqPassBlock), 0, s, h->d_feats, h->n,

@@ -33,9 +33,11 @@ bool q8_hoists(const mi355rec* h) { return h->qg.riders > 0 && h->qg.r_iters >= 
 // where the extra fetch per sampled wave is not on the launch's critical path.
 bool q8_exact_sample(const mi355rec* h) { return h->qg.iters >= 3; }
 
-// Is the row a query excludes a row of THIS shard?  Then its neighbourhood gives the scan a bound (handoff.hip.h).
+// Does a neighbourhood give the scan a bound (handoff.hip.h)?  Around the row the query excludes when that is a row of THIS
+// shard, else (a query by value, a row of another shard) around the query's anchor — on every shard large enough to have one.
 bool nbhd_applies(const mi355rec* h, int64_t exclude_global) {
-    return exclude_global >= h->row_base && exclude_global < h->row_base + h->n && h->n >= kNbhdRows;
+    (void)exclude_global;
+    return h->n >= kNbhdRows;
 }
 
 // The sample launch of a query ALONE over a replica (the first query of a stream as well): the sampled regions and,
@@ -48,7 +50,8 @@ void enqueue_half_seed(mi355rec* h, int kind, const float* qptr, const QueryArg&
         if (h->qg.seed_grid + extra <= 0) return;
 #define SEED_Q8(EXACT)                                                                                                     \
     hipLaunchKernelGGL((seed_q8_kernel<EXACT>), dim3(h->qg.seed_grid + extra), dim3(kHalfSeedBlock), 0, s, h->d_feats, h->d_q8, \
-                       h->n, h->qg.seed_stride, h->row_base, qa, qptr, exclude_global, seed_buf, epoch, h->qg.seed_grid, topn)
+                       h->n, h->qg.seed_stride, h->row_base, qa, qptr, exclude_global, seed_buf, epoch, h->qg.seed_grid, topn, \
+                       static_cast<const float*>(h->d_anchor))
         if (q8_exact_sample(h)) SEED_Q8(true);
         else SEED_Q8(false);
 #undef SEED_Q8
@@ -74,6 +77,7 @@ bool enqueue_f32_seed(mi355rec* h, const float* qptr, const float* query12, int6
                       unsigned long long* seed_buf, SeedCtl* ctl, unsigned* ctl_done, uint32_t epoch, hipStream_t s) {
     NextSeed sd;
     std::memset(&sd, 0, sizeof sd);
+    sd.anchors = h->d_anchor;
     sd.query_ptr = qptr;
     if (!qptr) std::memcpy(sd.q, query12, sizeof sd.q);
     sd.exclude_global = exclude_global;
@@ -378,6 +382,7 @@ int launch_stashed(mi355rec* h, hipStream_t s, bool with_next, const float* next
     if (h->pending) prev = PrevMerge{h->d_stream_lists[h->pending_buf], h->pending_lists, h->pending_topn, h->pending_out};
     NextSeed next;
     std::memset(&next, 0, sizeof next);
+    next.anchors = h->d_anchor;
     next.query_ptr = nullptr;
     next.exclude_global = -1;
     int scanners, iters;

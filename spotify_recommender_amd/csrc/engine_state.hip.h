@@ -160,6 +160,7 @@ struct mi355rec {
     } routes;
     ReplicaGeom hg;                     // geometry of the scan over the fp16 replica ...
     uint4* d_q8 = nullptr;              // 8-bit replica (replica_q8.hip.h): ((n + 3) / 4) quads of rows x 48 B
+    float* d_anchor = nullptr;          // the anchor table (handoff.hip.h, nbhd_anchor): kAnchorRows rows x 48 B, a copy made at create
     ReplicaGeom qg;                     // ... and over the 8-bit one
     int replica_mode = 0;               // MI355REC_REPLICA_AUTO / _OFF / _ON
     bool replica_allowed = true;        // false: created with MI355REC_CREATE_NO_REPLICA
@@ -551,6 +552,21 @@ int build_replica_inner(mi355rec* h) {
     return MI355REC_OK;
 }
 
+// The anchor table: a contiguous copy of kAnchorRows rows spread evenly over the shard (handoff.hip.h).  A snapshot, like the
+// replicas: rebuilt by mi355rec_rebuild_replica; a stale one only picks a poorer centre (the bound is computed from the rows).
+int build_anchors(mi355rec* h) {
+    if (!h->d_anchor) return MI355REC_OK;
+    // anchor i = row i * stride + stride / 2 (anchor_row): one strided 2-D copy, 48 B per row; a shard with fewer rows than
+    // anchors (stride 1) fills what it has and leaves the rest zero (a zero row scores 0: never the best of a useful search)
+    const int64_t stride = h->n >= kAnchorRows ? h->n / kAnchorRows : 1;
+    const size_t rows = h->n >= kAnchorRows ? kAnchorRows : static_cast<size_t>(h->n);
+    HIP_TRY(h, hipMemsetAsync(h->d_anchor, 0, sizeof(float) * kDim * kAnchorRows, h->stream));
+    HIP_TRY(h, hipMemcpy2DAsync(h->d_anchor, sizeof(float) * kDim, h->d_feats + (stride >> 1) * kDim, sizeof(float) * kDim * static_cast<size_t>(stride),
+                                sizeof(float) * kDim, rows, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MI355REC_OK;
+}
+
 int create_common(const float* feats, bool on_device, int64_t n, int dim, int device,
                   int64_t row_base, int flags, mi355rec_t** out) {
     if (out) *out = nullptr;
@@ -651,6 +667,8 @@ int create_common(const float* feats, bool on_device, int64_t n, int dim, int de
         return cleanup(MI355REC_ERR_OUT_OF_MEMORY, "hipMalloc(seed keys)", e);
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess)
         return cleanup(MI355REC_ERR_HIP, "hipStreamCreate", e);
+    if (n >= kNbhdRows && (e = hipMalloc(&h->d_anchor, sizeof(float) * kDim * kAnchorRows)) != hipSuccess)
+        return cleanup(MI355REC_ERR_OUT_OF_MEMORY, "hipMalloc(anchor table)", e);
     if ((e = hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming)) != hipSuccess)
         return cleanup(MI355REC_ERR_HIP, "hipEventCreate", e);
     if (on_device) {
@@ -665,6 +683,14 @@ int create_common(const float* feats, bool on_device, int64_t n, int dim, int de
     // Shards below kReplicaMinRows get none: no AUTO path reads it there (single queries switch over at 1 M
     // rows, batches at 65536); mi355rec_set_replica(ON) builds it on demand.  If the +75 % cannot be had the
     // handle degrades to fp32-only (same results, 48 B/row) and says so in mi355rec_last_error.
+    if (h->d_anchor) {
+        const int arc = build_anchors(h);
+        if (arc != MI355REC_OK) {
+            rc = arc;
+            mi355rec_destroy(h);
+            return rc;
+        }
+    }
     h->replica_allowed = (flags & MI355REC_CREATE_NO_REPLICA) == 0;
     if (n >= kReplicaMinRows && h->replica_allowed) {
         const int brc = build_replica(h);

@@ -88,6 +88,7 @@ struct NextSeed {
     uint32_t done_base;        // ctl->done before this launch's riders arrive
     int debug_skip;            // test hook (0 in the product): the riders do NOT store regions below this one
     int nbhd;                  // 1: the grid's last workgroup computes the next query's neighbourhood bound into out[kNbhdSlot]
+    const float* anchors;      // the handle's anchor table (nbhd_anchor), or null
 };
 
 // ---- selecting from <= 2048 sample values ----------------------------------------------------------------------
@@ -291,6 +292,82 @@ __device__ inline uint32_t nbhd_select(const uint64_t (&keys)[kKeys], int rows_p
     return need * kWaves >= topk ? *s_min : 0u;   // uniform
 }
 
+// ---- a query that excludes no row of this shard: where do ITS neighbours lie? ---------------------------------------
+// The neighbourhood above is taken around the row a query excludes — its own, for recommendByIndex (Recommender.cu:275-318).
+// A query by VALUE (mi355rec_query_topn with exclude = -1: a new track), or one whose excluded row lives on another shard,
+// has no such row, and on a catalogue sorted by genre ran with the spread sample's bound alone (2-11x the by-row times,
+// VERDICT r5 "missing" 3).  Its ANCHOR: kAnchorRows rows spread evenly over the shard — one every n / 4096 rows: a cluster
+// of a few thousand neighbouring rows holds one or more of them — scored exactly; the best of them stands in for the
+// excluded row.  On shuffled rows the anchor is an arbitrary good row and the bound around it is merely valid, as the
+// neighbourhood of an excluded row is there.
+// The anchors' rows are read from the handle's ANCHOR TABLE (`anchors`: a contiguous copy of those 4096 rows, 196 KB, made at
+// create by one strided device-to-device copy: engine_state.hip.h, build_anchors) — taken from the matrix itself they are 4096 reads a page apart, every lane of every load
+// on a line and a TLB entry of its own: the one workgroup that does this held a streamed launch up by 7 us (31.8 instead of
+// 24.4 us at 10 M rows) and the thousand of a batch cost 0.6 ms.  The table only CHOOSES the centre (a stale table — the
+// caller overwrote a borrowed matrix and has not rebuilt yet — still gives a valid bound: that is computed from the rows).
+// `anchors` null: read from the matrix.  Called by ALL kThreads threads (one barrier pair); kAhead rows of a thread in
+// flight at a time; `s_scratch`: 3 * kThreads / 64 + 1 ints of LDS nobody else is using.  Returns a LOCAL row in [0, n).
+constexpr int kAnchorRows = 4096;
+
+__host__ __device__ inline int64_t anchor_row(int64_t n, int i) {   // which row anchor i is
+    const int64_t stride = n >= kAnchorRows ? n / kAnchorRows : 1;
+    const int64_t r = static_cast<int64_t>(i) * stride + (stride >> 1);
+    return r < n ? r : n - 1;
+}
+
+template <int kThreads, int kAhead = 4>
+__device__ inline int64_t nbhd_anchor(const float* __restrict__ feats, const float* __restrict__ anchors, int64_t n,
+                                      const float (&q)[kDim], float qn, int* s_scratch) {
+    constexpr int kWaves = kThreads / 64;
+    constexpr int kPer = kAnchorRows / kThreads;
+    static_assert(kAnchorRows % kThreads == 0 && kPer % kAhead == 0, "whole rounds of kAhead rows per thread");
+    const int tid = threadIdx.x;
+    uint32_t best = 0u;
+    int best_i = tid;
+#pragma unroll 1
+    for (int k0 = 0; k0 < kPer; k0 += kAhead) {
+        Row rows[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const int i = (k0 + u) * kThreads + tid;
+            rows[u] = anchors ? load_row(anchors, static_cast<int64_t>(i)) : load_row(feats, anchor_row(n, i));
+        }
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const uint32_t o = score_to_ordered(cosine_score(q, qn, rows[u]));
+            if (o > best) {
+                best = o;
+                best_i = (k0 + u) * kThreads + tid;
+            }
+        }
+    }
+    const uint32_t top = wave_max_u32(best);
+    const int holder = static_cast<int>(__builtin_ctzll(__ballot(best == top)));   // (never empty)
+    const int wave_i = __builtin_amdgcn_readlane(best_i, holder);
+    if ((tid & 63) == 0) {
+        s_scratch[2 * (tid >> 6)] = static_cast<int>(top);
+        s_scratch[2 * (tid >> 6) + 1] = wave_i;
+    }
+    __syncthreads();
+    uint32_t all = 0u;
+    int which = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {   // (uniform: every thread reads the same entries)
+        const uint32_t t = static_cast<uint32_t>(s_scratch[2 * w]);
+        if (w == 0 || t > all) {
+            all = t;
+            which = s_scratch[2 * w + 1];
+        }
+    }
+    __syncthreads();   // (the scratch is free again)
+    return anchor_row(n, which);
+}
+
+// Is the row a query excludes a row of this shard?  (Otherwise its neighbourhood is taken around its anchor.)
+__device__ __forceinline__ bool nbhd_has_center(int64_t n, int64_t row_base, int64_t exclude_global) {
+    return exclude_global >= row_base && exclude_global - row_base < n;
+}
+
 template <int kThreads, int kRows = kNbhdRows>
 __device__ inline uint32_t nbhd_finish(const Nbhd<kThreads, kRows>& nb, const float (&q)[kDim], float qn, int topk, int* s_scratch) {
     constexpr int kPer = Nbhd<kThreads, kRows>::kPer;
@@ -317,12 +394,15 @@ __device__ inline uint32_t nbhd_finish(const Nbhd<kThreads, kRows>& nb, const fl
 // bound — about the 14th percentile of the cluster — against 89 us with 2048.)
 template <int kThreads, int kPerRound, int kRounds>
 __device__ inline uint32_t nbhd_bound_rounds(const float* __restrict__ feats, int64_t n, int64_t row_base, int64_t exclude_global,
-                                             const float (&q)[kDim], float qn, int topk, int* s_scratch) {
+                                             const float (&q)[kDim], float qn, int topk, int* s_scratch,
+                                             const float* __restrict__ anchors = nullptr) {
     constexpr int kKeys = kPerRound * kRounds;
     constexpr int64_t kRows = static_cast<int64_t>(kKeys) * kThreads;
     const int tid = threadIdx.x;
-    const int64_t center = exclude_global - row_base;
-    if (!(center >= 0 && center < n && n >= kRows && topk >= 1)) return 0u;   // uniform
+    if (!(n >= kRows && topk >= 1)) return 0u;   // uniform
+    // (the query excludes no row of this shard: around its anchor — found with kPerRound rows in flight, this workgroup's budget)
+    const int64_t center = nbhd_has_center(n, row_base, exclude_global) ? exclude_global - row_base
+                                                                        : nbhd_anchor<kThreads, kPerRound>(feats, anchors, n, q, qn, s_scratch);
     int64_t lo = center - kRows / 2;
     if (lo > n - kRows) lo = n - kRows;
     if (lo < 0) lo = 0;
@@ -346,7 +426,10 @@ __device__ inline uint32_t nbhd_bound_rounds(const float* __restrict__ feats, in
 
 template <int kThreads, int kRows = kNbhdRows>
 __device__ inline uint32_t nbhd_bound(const float* __restrict__ feats, int64_t n, int64_t row_base, int64_t exclude_global,
-                                      const float (&q)[kDim], float qn, int topk, int* s_scratch) {
+                                      const float (&q)[kDim], float qn, int topk, int* s_scratch,
+                                      const float* __restrict__ anchors = nullptr) {
+    if (!nbhd_has_center(n, row_base, exclude_global) && n >= kRows)   // uniform: around the query's anchor
+        exclude_global = row_base + nbhd_anchor<kThreads>(feats, anchors, n, q, qn, s_scratch);
     const Nbhd<kThreads, kRows> nb = nbhd_request<kThreads, kRows>(feats, n, row_base, exclude_global, topk);
     return nbhd_finish<kThreads, kRows>(nb, q, qn, topk, s_scratch);
 }
@@ -357,17 +440,30 @@ __device__ inline uint32_t nbhd_bound(const float* __restrict__ feats, int64_t n
 template <int kThreads, int kRows = kNbhdRows>
 __device__ inline void nbhd_to_slot(const float* __restrict__ feats, int64_t n, int64_t row_base, const float* query_ptr,
                                     const float (&by_value)[kDim], int64_t exclude_global, int topk, uint32_t epoch,
-                                    unsigned long long* __restrict__ sample_buf, int* s_scratch /* Nbhd<kThreads, kRows>::kScratch ints */) {
-    const Nbhd<kThreads, kRows> nb = nbhd_request<kThreads, kRows>(feats, n, row_base, exclude_global, topk);   // the rows first ...
-    float q[kDim];                                                                                  // ... then the query
-    if (query_ptr) {
+                                    unsigned long long* __restrict__ sample_buf, int* s_scratch /* Nbhd<kThreads, kRows>::kScratch ints */,
+                                    const float* __restrict__ anchors = nullptr) {
+    float q[kDim];
+    auto load_query = [&]() {
+        if (query_ptr) {
 #pragma unroll
-        for (int j = 0; j < kDim; ++j) q[j] = query_ptr[j];
-    } else {
+            for (int j = 0; j < kDim; ++j) q[j] = query_ptr[j];
+        } else {
 #pragma unroll
-        for (int j = 0; j < kDim; ++j) q[j] = by_value[j];
+            for (int j = 0; j < kDim; ++j) q[j] = by_value[j];
+        }
+    };
+    uint32_t v;
+    if (nbhd_has_center(n, row_base, exclude_global) || n < kRows) {   // uniform
+        const Nbhd<kThreads, kRows> nb = nbhd_request<kThreads, kRows>(feats, n, row_base, exclude_global, topk);   // the rows first ...
+        load_query();                                                                                               // ... then the query
+        v = nbhd_finish<kThreads, kRows>(nb, q, query_norm(q), topk, s_scratch);
+    } else {   // no excluded row here: the query first, its anchor, the rows around that
+        load_query();
+        const float qn = query_norm(q);
+        const int64_t anchor = nbhd_anchor<kThreads>(feats, anchors, n, q, qn, s_scratch);
+        const Nbhd<kThreads, kRows> nb = nbhd_request<kThreads, kRows>(feats, n, row_base, row_base + anchor, topk);
+        v = nbhd_finish<kThreads, kRows>(nb, q, qn, topk, s_scratch);
     }
-    const uint32_t v = nbhd_finish<kThreads, kRows>(nb, q, query_norm(q), topk, s_scratch);
     if (threadIdx.x == 0) sample_buf[kNbhdSlot] = tag_value(epoch, v);
 }
 

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_kernel(
                     for (int j = 0; j < kDim; ++j) nq[j] = next.q[j];
                 }
                 const uint32_t v = nbhd_bound_rounds<kBlock, 2, 2>(feats, n, row_base, next.exclude_global, nq, query_norm(nq), next.topk,
-                                                                   reinterpret_cast<int*>(s_ride.scan.cand));
+                                                                   reinterpret_cast<int*>(s_ride.scan.cand), next.anchors);
                 if (threadIdx.x == 0) static_cast<unsigned long long*>(next.out)[kNbhdSlot] = tag_value(next.epoch, v);
                 MI355REC_KPHASE(5);
             } else {                              // a seed rider: its share of the next query's sample
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(kHalfSeedBlock) void seed_f32_kernel(const float* _
     __shared__ int s_bins[Nbhd<kHalfSeedBlock>::kScratch > kSelScratch ? Nbhd<kHalfSeedBlock>::kScratch : kSelScratch];
     if (static_cast<int>(blockIdx.x) >= next.regions) {   // uniform: the neighbourhood workgroup
         nbhd_to_slot<kHalfSeedBlock>(feats, n, row_base, next.query_ptr, next.q, next.exclude_global, next.topk, next.epoch,
-                                     static_cast<unsigned long long*>(next.out), s_bins);
+                                     static_cast<unsigned long long*>(next.out), s_bins, next.anchors);
         return;
     }
     f32_sample_regions(feats, n, row_base, next, static_cast<int>(blockIdx.x));
@@ -565,7 +565,8 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_multi_kernel
 // queue is empty — the usual case, in which this launch costs its dispatch and nothing else.
 // The merge of those lists is part of the launch as well (it used to be a second kernel that
 // every batched call paid for): the workgroup that finishes a GROUP last merges that group's lists
-// into its queries' output rows while the others scan the next group (`arrive`: one counter per group,
+// into its queries' output rows while the others scan the next group — in practice the same workgroup
+// for every group, see below (`arrive`: one counter per group,
 // kBqMaxQueries / kMultiQueries < 128 of them).  Rare path, so the hand-off is the plain one: a device-wide
 // fence before each workgroup counts itself out and one behind the count of the last (the counters are zero
 // between launches: the last workgroup of a group resets its own, and a launch with an empty queue touches none).
@@ -583,8 +584,12 @@ __global__ __launch_bounds__(Cfg::kBlock, 2) void scan_multi_queued_kernel(
     const int count = *queue_count;
     if (count == 0) return;   // uniform over the whole grid
     // Every group of kMultiQueries queued queries is counted out on its OWN counter, and the workgroup that leaves a group
-    // last merges that group's queries while the others go on scanning the next group: a whole chunk in the queue (1024
-    // queries: hostile data) used to end with ONE workgroup merging a thousand queries, 10 ms, behind an idle chip.
+    // last merges that group's queries while the others go on scanning the next group.  What that buys is modest:
+    // the workgroup that merged group g starts group g + 1 a merge late, so it is the last one out of g + 1 as well and
+    // merges that too — ONE workgroup still does every merge, and the chain is groups x (scan + merge), only with the other
+    // workgroups' scans no longer waiting for it (a whole 1024-query chunk in the queue, hostile data: 58 -> 55.8 ms).  Handing
+    // the merges to whichever workgroups are idle would take a ticket counter and a wait on the groups' counters; on a path
+    // that exists for inputs the bound cannot be claimed for, that was not built.
     // (`arrive[g]` is zero between launches: the last workgroup of a group resets it.)
     __shared__ int s_last;
     __shared__ MergeSmemT<Cfg::kBlock, 1024, kMergeSurvCap> s_merge;   // (one workgroup per CU fits with this: the launch has no more)

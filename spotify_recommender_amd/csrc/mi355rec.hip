@@ -98,6 +98,7 @@ void mi355rec_destroy(mi355rec_t* h) {
     }
     if (h->d_stream_lists[0]) (void)hipFree(h->d_stream_lists[0]);
     if (h->d_stream_lists[1]) (void)hipFree(h->d_stream_lists[1]);
+    if (h->d_anchor) (void)hipFree(h->d_anchor);
     if (h->d_seed_keys) (void)hipFree(h->d_seed_keys);
     if (h->d_seed_vals) (void)hipFree(h->d_seed_vals);
     free_replica(h);
@@ -760,6 +761,8 @@ int mi355rec_rebuild_replica(mi355rec_t* h) {
     if (rc) return rc;
     rc = flush_mstream(h, h->stream);
     if (rc) return rc;
+    rc = build_anchors(h);   // (the other snapshot of the rows)
+    if (rc) return rc;
     rc = build_replica(h);
     if (rc == MI355REC_OK && h->shared) {   // published to the group
         h->shared->d_half = h->d_half;
@@ -948,16 +951,13 @@ int mi355rec_query_batch_topn(mi355rec_t* h, const float* queries, int batch,
     return MI355REC_OK;
 }
 
-int mi355rec_query_topn(mi355rec_t* h, const float* query12, int64_t exclude_global, int topn,
-                        int64_t* out_idx, float* out_score, int* out_count) {
-    return mi355rec_query_batch_topn(h, query12, 1, &exclude_global, topn, out_idx, out_score, out_count);
-}
-
-int mi355rec_query_row_topn(mi355rec_t* h, int64_t local_row, int topn, int64_t* out_idx,
-                            float* out_score, int* out_count) {
-    if (!h || !out_idx) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
-    if (local_row < 0 || local_row >= h->n)
-        return fail(h, MI355REC_ERR_INVALID_ARG, "Invalid song index: %lld", (long long)local_row);
+namespace {
+// One query, synchronously, results in the caller's host buffers: the query is resident memory (`qptr`: a row of this handle)
+// or 12 floats by value (`query12`).  What Recommender::recommendByIndex sits on (Recommender.cu:275-318) — and, since round 6,
+// mi355rec_query_topn as well: a query by value used to go through the batch entry point with a batch of one (no completion
+// word, a stream synchronise, two D2H copies: ~9 us more per call at 10 M rows).
+int sync_single_query(mi355rec_t* h, const float* qptr, const float* query12, int64_t exclude_global, int topn, int64_t* out_idx,
+                      float* out_score, int* out_count) {
     int rc = check_topn(h, topn, true);
     if (rc) return rc;
     DeviceGuard guard(h->device);
@@ -974,7 +974,7 @@ int mi355rec_query_row_topn(mi355rec_t* h, int64_t local_row, int topn, int64_t*
     // memory; the host spins on the word
     const bool notify = direct && eff <= kMaxTopK && eff > 0;
     const uint32_t want = notify ? (++h->done_seq ? h->done_seq : ++h->done_seq) : 0u;   // never 0
-    rc = enqueue_query(h, h->d_feats + local_row * kDim, nullptr, h->row_base + local_row, eff, h->d_keys, direct ? h->hd_idx : h->d_idx,
+    rc = enqueue_query(h, qptr, query12, exclude_global, eff, h->d_keys, direct ? h->hd_idx : h->d_idx,
                        direct ? h->hd_score : h->d_score, h->stream, want);
     if (rc) return rc;
     if (!direct) {
@@ -997,6 +997,22 @@ int mi355rec_query_row_topn(mi355rec_t* h, int64_t local_row, int topn, int64_t*
     }
     if (out_count) *out_count = c;
     return MI355REC_OK;
+}
+}  // namespace
+
+int mi355rec_query_topn(mi355rec_t* h, const float* query12, int64_t exclude_global, int topn,
+                        int64_t* out_idx, float* out_score, int* out_count) {
+    if (!h || !query12 || !out_idx) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (h->n == 0) return mi355rec_query_batch_topn(h, query12, 1, &exclude_global, topn, out_idx, out_score, out_count);   // (an empty shard: all-empty lists)
+    return sync_single_query(h, nullptr, query12, exclude_global, topn, out_idx, out_score, out_count);
+}
+
+int mi355rec_query_row_topn(mi355rec_t* h, int64_t local_row, int topn, int64_t* out_idx,
+                            float* out_score, int* out_count) {
+    if (!h || !out_idx) return fail(h, MI355REC_ERR_INVALID_ARG, "null argument");
+    if (local_row < 0 || local_row >= h->n)
+        return fail(h, MI355REC_ERR_INVALID_ARG, "Invalid song index: %lld", (long long)local_row);
+    return sync_single_query(h, h->d_feats + local_row * kDim, nullptr, h->row_base + local_row, topn, out_idx, out_score, out_count);
 }
 
 // ---- key helpers -----------------------------------------------------------------

@@ -79,6 +79,7 @@ struct HalfMultiArg {
     long long exclude[kHmQueries];        // global row to skip, -1 = none
     uint32_t ptr_mask;
     float margin;                         // error bound the pre-filter may claim on this device (set by the host)
+    const float* anchors;                 // the handle's anchor table (handoff.hip.h: queries that exclude no row of this shard), or null
 };
 
 __host__ __device__ inline void hm_set_pointer(HalfMultiArg& arg, int i, const float* p) {
@@ -270,7 +271,7 @@ __device__ __forceinline__ void hm_nbhd_queries(const float* __restrict__ feats,
         if (j != first) __syncthreads();   // the select before is done with the shared memory
         float q[kDim];   // (the query first: with the rows requested ahead of it the riding variant of the pass kernel spilled)
         hm_load_query(arg, j, q);
-        const uint32_t v = nbhd_bound<kHmBlock>(feats, n, row_base, arg.exclude[j], q, query_norm(q), topk, s_scratch);
+        const uint32_t v = nbhd_bound<kHmBlock>(feats, n, row_base, arg.exclude[j], q, query_norm(q), topk, s_scratch, arg.anchors);
         if (threadIdx.x == 0) seed_vals[kHmNbhdBase + j] = tag_value(epoch, v);
     }
 }

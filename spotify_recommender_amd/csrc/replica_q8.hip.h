@@ -264,12 +264,13 @@ template <bool kExact>
 __global__ __launch_bounds__(kHalfSeedBlock) void seed_q8_kernel(
     const float* __restrict__ feats, const uint4* __restrict__ q8, int64_t n, int64_t stride_rows, int64_t row_base, QueryArg qarg,
     const float* __restrict__ query_ptr /* null: the query is qarg.q */, int64_t exclude_global,
-    unsigned long long* __restrict__ seed_vals, uint32_t epoch, int regions, int topk) {
+    unsigned long long* __restrict__ seed_vals, uint32_t epoch, int regions, int topk,
+    const float* __restrict__ anchors /* the handle's anchor table (handoff.hip.h), or null */) {
     if (static_cast<int>(blockIdx.x) >= regions) {   // uniform
         // (1024 rows: this workgroup is the last one out of the sample launch of a query alone, and the scan subtracts a margin
         // of ~0.01 from whatever bound it is given — the 10th percentile of the neighbourhood serves it as well as the 5th)
         __shared__ int s_scratch[Nbhd<kHalfSeedBlock, 1024>::kScratch];
-        nbhd_to_slot<kHalfSeedBlock, 1024>(feats, n, row_base, query_ptr, qarg.q, exclude_global, topk, epoch, seed_vals, s_scratch);
+        nbhd_to_slot<kHalfSeedBlock, 1024>(feats, n, row_base, query_ptr, qarg.q, exclude_global, topk, epoch, seed_vals, s_scratch, anchors);
         return;
     }
     // the region's rows are requested FIRST: they need nothing of the query, whose 12 floats sit behind two dependent
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(Cfg::kBlock, Cfg::kMinWaves) void scan_q8_kernel(
                                static_cast<int64_t>(0));
             } else if (next.nbhd && blockIdx.x == gridDim.x - 1u) {   // the next query's neighbourhood: read by the NEXT launch
                 nbhd_to_slot<kBlock>(feats, n, row_base, next.query_ptr, next.q, next.exclude_global, next.topk, next.epoch,
-                                     static_cast<unsigned long long*>(next.out), reinterpret_cast<int*>(s_mem.scan.cand));
+                                     static_cast<unsigned long long*>(next.out), reinterpret_cast<int*>(s_mem.scan.cand), next.anchors);
             } else {
                 const Q8Query nq = q8_seed_rider(feats, q8, n, row_base, next, static_cast<int>(blockIdx.x - nblocks - 1u));
                 // Last rider out turns the sample into the cutoff (handoff.hip.h, sample_arrive_and_select: no device-wide

@@ -129,6 +129,51 @@ def test_queries_by_value_and_excluded_rows_that_are_not_the_query(catalogue, en
     eng.set_replica(capi.REPLICA_AUTO)
 
 
+def test_queries_by_value_take_the_neighbourhood_of_their_anchor(catalogue, engine, torch_cuda):
+    """VERDICT r5 "missing" 3.  A query by VALUE that excludes nothing (mi355rec_query_topn(q, -1): a new track) has no excluded
+    row to take a neighbourhood around; it takes it around its ANCHOR — the best of 4096 rows spread evenly over the shard
+    (csrc/handoff.hip.h, nbhd_anchor), which on a catalogue sorted by genre lies in the query's own cluster.  The queries here
+    are perturbed catalogue rows and catalogue rows themselves, passed by value with nothing excluded: results are the oracle's
+    (the row itself included, where the query is one), and over the 8-bit replica the rows sent to the exact chain stay within
+    what the by-row queries of test_single_query_routes_lone_and_streamed are held to — without the anchor the spread sample's
+    cutoff let 1.2-1.4 % of the shard through (round 4)."""
+    torch = torch_cuda
+    from spotify_recommender_amd import capi
+    from spotify_recommender_amd.engine import unpack_keys
+    f, eng = catalogue["host"], engine
+    rng = np.random.default_rng(77)
+    rows = query_rows(10, 31)
+    queries = [f[r].copy() if i % 2 == 0 else (f[r] + rng.normal(0, 0.004, 12)).astype(np.float32) for i, r in enumerate(rows)]
+    wants = [oracle.scores(f, np.ascontiguousarray(q), threads=0) for q in queries]
+    for mode, name in ((capi.REPLICA_OFF, "fp32 rows"), (capi.REPLICA_AUTO, "8-bit replica")):
+        eng.set_replica(mode)
+        for q, want in zip(queries[:4], wants[:4]):                       # alone, synchronous
+            idx, sc = eng.query_topn(q, -1, TOPN)
+            assert_topn_matches(idx, sc, want, -1, TOPN, ref_idx=oracle.topn_heap(want, -1, TOPN))
+        keys = torch.zeros((len(rows), TOPN), dtype=torch.int64, device="cuda")
+        c0 = eng.replica_counters()
+        for i, q in enumerate(queries):                                    # a stream: the riders of launch k find query k + 1's anchor
+            eng.enqueue_query_keys_streamed(q, -1, TOPN, keys[i])
+        eng.enqueue_flush()
+        torch.cuda.synchronize()
+        c1 = eng.replica_counters()
+        for i, want in enumerate(wants):
+            idx, sc = unpack_keys(keys[i].cpu().numpy())
+            assert_topn_matches(idx, sc, want, -1, TOPN, ref_idx=oracle.topn_heap(want, -1, TOPN))
+        if mode == capi.REPLICA_AUTO:
+            per_query = (c1["rescored_rows"] - c0["rescored_rows"]) / len(rows)
+            assert per_query < 4 * catalogue["rows_per_cluster"] + 4000, per_query
+    eng.set_replica(capi.REPLICA_AUTO)
+    # ... and in batches: a multi-query pass and a two-pass batch of queries by value
+    for nb in (12, 64):
+        sel = query_rows(nb, 41 + nb)
+        qv = np.stack([(f[r] + rng.normal(0, 0.004, 12)).astype(np.float32) for r in sel])
+        bi, bs, cnt = eng.query_batch_topn(qv, None, TOPN)
+        for b in (0, nb // 2, nb - 1):
+            want = oracle.scores(f, qv[b], threads=0)
+            assert_topn_matches(bi[b][:cnt[b]], bs[b][:cnt[b]], want, -1, TOPN)
+
+
 @pytest.mark.parametrize("batch", [12, 32])
 def test_multi_query_pass_alone_and_streamed(catalogue, engine, torch_cuda, batch):
     """One pass over the fp16 replica for 12 / 32 queries (csrc/replica_multi.hip.h): a call on its own and a stream of

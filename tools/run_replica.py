@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--contiguous", action="store_true", help="clustered: a cluster's rows lie next to each other")
     ap.add_argument("--ramp", action="store_true", help="clustered + contiguous: features[11] = cluster / (clusters - 1), the genre ramp of a CSV grouped by genre (DataManager.cpp:244-250,299)")
     ap.add_argument("--clusters", type=int, default=3000, help="clustered: number of clusters")
+    ap.add_argument("--by-value", action="store_true",
+                    help="the timed legs pass the same catalogue rows BY VALUE with nothing excluded (mi355rec_enqueue_query_keys_streamed / "
+                         "mi355rec_query_topn(q, -1)): the neighbourhood bound then comes from the query's anchor (csrc/handoff.hip.h)")
     args = ap.parse_args()
     if args.lib:
         from spotify_recommender_amd import capi as _capi
@@ -46,7 +49,8 @@ def main():
     else:
         t = synthetic_catalogue(args.rows, seed=12345)
     rows = [(k * 7919 + 13) % args.rows for k in range(max(args.check, args.steps + 20, 200))]   # 200: the latency loop below
-    out = {"rows": args.rows, "topn": args.topn}
+    out = {"rows": args.rows, "topn": args.topn, "by_value": bool(args.by_value)}
+    qvecs = t[torch.tensor(rows, device=t.device)].cpu().numpy() if args.by_value else None
     with CosineEngine(t) as eng:
         st = eng.stats()
         out["replica_build_ms"] = round(float(st.replica_build_ms), 3)
@@ -79,15 +83,20 @@ def main():
             if (args.only >= 0 and args.only != mode) or (mode == capi.REPLICA_FP16 and not fp16):
                 continue
             eng.set_replica(mode)
+            def step(i, k):
+                if args.by_value:
+                    eng.enqueue_query_keys_streamed(qvecs[i], -1, args.topn, ring[k % 64])
+                else:
+                    eng.enqueue_row_keys_streamed(rows[i], args.topn, ring[k % 64])
             for i in range(20):
-                eng.enqueue_row_keys_streamed(rows[i], args.topn, ring[i % 64])
+                step(i, i)
             eng.enqueue_flush()
             torch.cuda.synchronize()
             eng.set_timing(8)
             c0 = eng.replica_counters()
             t0 = time.perf_counter()
             for i in range(args.steps):
-                eng.enqueue_row_keys_streamed(rows[20 + i], args.topn, ring[i % 64])
+                step(20 + i, i)
             eng.enqueue_flush()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / args.steps
@@ -102,7 +111,10 @@ def main():
             lat = []
             for i in range(200):
                 t1 = time.perf_counter()
-                eng.query_row_topn(rows[i], args.topn)
+                if args.by_value:
+                    eng.query_topn(qvecs[i], -1, args.topn)
+                else:
+                    eng.query_row_topn(rows[i], args.topn)
                 lat.append(time.perf_counter() - t1)
             lat.sort()
             out[name]["p50_us"] = round(lat[len(lat) // 2] * 1e6, 1)
