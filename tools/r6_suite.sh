@@ -1,4 +1,4 @@
-# Round 6: every GPU test, smoke(), then the bench line at the driver's form (20 steps) and at 300 steps.
+# Round 6: every GPU test + smoke, then queries by value alone (latency), then PART A of the evidence runs.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r6suite
@@ -7,17 +7,8 @@ timeout -k 10 1000 python -m pytest tests -x -q -m gpu > $O/tests.log 2>&1 || { 
 tail -3 $O/tests.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || { tail -20 $O/smoke.log; exit 1; }
 tail -1 $O/smoke.log
-python bench.py --steps 20 --warmup 5 > $O/bench20.json 2> $O/bench20.err || { tail -20 $O/bench20.err; exit 1; }
-python bench.py --steps 300 --warmup 30 --no-config0 --no-clustered > $O/bench300.json 2> $O/bench300.err || { tail -20 $O/bench300.err; exit 1; }
-python - <<'PY'
-import json
-for f in ("bench20", "bench300"):
-    d = json.load(open(f"gpurun_out/r6suite/{f}.json"))
-    print(f, json.dumps({k: d.get(k) for k in ("value", "value_runs", "ms_per_step", "p50_ms", "verified_against_oracle", "verified_queries")}))
-    print(json.dumps(d["roofline"]))
-    print(json.dumps(d.get("single_lane")))
-    m = d["microbatch"]
-    print(m["ms_per_call"], m.get("single_lane"), m.get("thirty_two_queries"))
-    b = d.get("batched", {})
-    print(b.get("ms_per_call"), (b.get("configs4_shard") or {}).get("ms_per_call"), (b.get("two_lanes") or {}).get("ms_per_call"))
-PY
+for V in "" "--by-value"; do
+  timeout -k 10 200 python3 tools/run_replica.py --rows 10000000 --topn 100 --steps 300 --check 4 --only 2 $V 2>> $O/err.log | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['by_value'], d['replica_q8'])"
+  timeout -k 10 200 python3 tools/run_replica.py --rows 10000000 --topn 100 --steps 300 --check 4 --only 2 --catalogue clustered --contiguous --ramp --clusters 3000 --spread 0.03 $V 2>> $O/err.log | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['by_value'], d['replica_q8'])"
+done
+PART=A bash tools/collect_r06.sh
