@@ -91,6 +91,30 @@ def test_randomised_parity():
                     assert not got[cnt:].any()
                 except AssertionError as e:  # pragma: no cover
                     raise AssertionError(f"case {case} streamed: rows {rows} q {r} topn {s_topn}: {e}") from e
+            # queries BY VALUE (round 6: their launch-wide bound comes from their anchor's neighbourhood, csrc/handoff.hip.h): a
+            # catalogue row passed by value, a perturbed one, noise; nothing excluded or an arbitrary row excluded; alone and streamed
+            v_topn = int(rng.choice([1, 10, 100, 300]))
+            v_q = [f[int(rng.integers(0, rows))].copy(),
+                   (f[int(rng.integers(0, rows))] * np.float32(1.0 + 0.01 * rng.standard_normal())).astype(np.float32),
+                   rng.random(12, dtype=np.float32)]
+            v_ex = [-1, int(rng.integers(0, rows)), -1]
+            v_keys = [torch.zeros(v_topn, dtype=torch.int64, device="cuda") for _ in v_q]
+            for q, ex, k in zip(v_q, v_ex, v_keys):
+                eng.enqueue_query_keys_streamed(q, ex, v_topn, k)
+            eng.enqueue_flush()
+            torch.cuda.synchronize()
+            for q, ex, k in zip(v_q, v_ex, v_keys):
+                want = oracle.scores(f, np.ascontiguousarray(q))
+                got = k.cpu().numpy().view(np.uint64)
+                cnt = min(v_topn, rows - (1 if ex >= 0 else 0))
+                idx = (~got[:cnt] & np.uint64(0xffffffff)).astype(np.int64)
+                try:
+                    assert_topn_matches(idx, None, want, ex, v_topn, ref_idx=oracle.topn_heap(want, ex, v_topn))
+                    assert not got[cnt:].any()
+                    i2, s2 = eng.query_topn(q, ex, v_topn)
+                    assert_topn_matches(i2, s2, want, ex, v_topn, ref_idx=oracle.topn_heap(want, ex, v_topn))
+                except AssertionError as e:  # pragma: no cover
+                    raise AssertionError(f"case {case} by value: rows {rows} excl {ex} topn {v_topn}: {e}") from e
             # the same kind of stream dealt over two LANES of the handle (shared rows and replicas, own stream state), each on
             # the stream the library created with it
             if case % 3 == 0:
