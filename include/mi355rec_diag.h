@@ -110,8 +110,8 @@ int mi355rec_create_device_ex(const float* feats_dev, int64_t n, int dim, int de
  * A handle with a replica holds two encodings of the normalised rows: fp16
  * (24 B/row, csrc/replica.hip.h: what the multi-query and batched passes
  * read, error bound 1.0e-3) and 8-bit (12 B/row, csrc/replica_q8.hip.h: what
- * single queries scan; the query stays fp32, the bound is per query,
- * l1(q/|q|)/254 + 3e-5 <= 0.0137).  Both are pre-filters in front of the same
+ * single queries scan: signed bytes against a 16-bit query held as two int8 digits, six v_dot4_i32_i8 per
+ * row and an integer candidate test; the bound is per query, l1(Q)/(254 S) + sqrt(12)/(2 S) + 3e-5 <= 0.0137, S = 32000).  Both are pre-filters in front of the same
  * exact chain; MI355REC_REPLICA_FP16 exists for A/B measurements.
  * The batched matrix-core path reads its rows from the replica too (they are
  * stored in exactly the form its MFMA operand wants) unless the mode is OFF.
