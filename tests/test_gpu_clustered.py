@@ -236,6 +236,42 @@ def test_a_batch_of_1024_queries(catalogue, engine, torch_cuda):
         assert rows[b] not in idx, b
 
 
+def test_the_neighbourhood_policy_of_batches_keeps_it_on_where_it_wins_and_exact_where_it_is_off(catalogue, torch_cuda):
+    """Round 6: the two-pass batch computes its queries' neighbourhood bounds only where they win (engine_batch.hip.h: the
+    device reports how often they beat pass 1's own threshold; after three chunks without a win only every 32nd chunk computes
+    them).  On a catalogue sorted by genre they win for most queries, so chunk after chunk must keep them — seen from outside as
+    candidates per query that stay where the first chunk's were (without the bound they are several times as many); on a
+    SHUFFLED copy of the same rows the policy switches them off, and chunks before, at and after the switch return the oracle's
+    lists all the same."""
+    torch = torch_cuda
+    from spotify_recommender_amd.engine import CosineEngine, unpack_keys
+    f = catalogue["host"]
+    rng = np.random.default_rng(9)
+    bq = 256
+    for name, host in (("sorted", f), ("shuffled", f[rng.permutation(N)])):
+        dev = torch.from_numpy(host).cuda()
+        with CosineEngine(dev) as eng:
+            keys = torch.zeros(bq * TOPN, dtype=torch.int64, device="cuda")
+            per_chunk = []
+            for chunk in range(8):
+                sel = torch.from_numpy(query_rows(bq, 500 + chunk)).cuda()
+                eng.enqueue_batch_keys_dev(dev[sel].contiguous(), sel, TOPN, keys)
+                torch.cuda.synchronize()
+                d = eng.batched_last_counters()
+                per_chunk.append(d["candidates_total"] / max(1, bq - d["queued_queries"]))
+                if chunk in (0, 2, 3, 4, 7):     # (the policy may switch after chunk 2)
+                    rows = sel.cpu().numpy()
+                    for b in (0, bq // 2, bq - 1):
+                        idx, sc = unpack_keys(keys[b * TOPN:(b + 1) * TOPN].cpu().numpy())
+                        want = oracle.scores(host, host[rows[b]], threads=0)
+                        assert_topn_matches(idx, sc, want, int(rows[b]), TOPN, ref_idx=oracle.topn_heap(want, int(rows[b]), TOPN))
+            if name == "sorted":
+                # the bound stays on: no later chunk lets several times the first chunks' candidates through
+                assert max(per_chunk[3:]) < 2.0 * max(per_chunk[:3]) + 500, per_chunk
+        del dev
+        torch.cuda.empty_cache()
+
+
 def test_rounds_of_topn_above_1024(catalogue, engine):
     """topn > 1024 is served in rounds of 1024; round r looks for keys BELOW the last key of round r - 1, so a lower bound on
     the BEST keys (sample or neighbourhood) must not be applied to it.  2500 results from inside a cluster and from its edge."""

@@ -230,6 +230,11 @@ def test_stream_over_the_rccl_transport(Node):
             idx, sc = node.wait(t, 20)
             want = oracle.scores(f, f[r])
             assert_topn_matches(idx, sc, want, r, 20, ref_idx=oracle.topn_heap(want, r, 20))
+        # what RCCL itself says about the communicators the exchange just ran on (mi355rec_sharded_rccl_ranks: ncclCommCount /
+        # ncclCommUserRank) — the figure bench.py --gpus N puts in its line as `transport.rccl.ranks`
+        assert node.rccl_ranks() == {"communicators": 1, "ranks": 1, "ranks_agree": True}
+    with Node(f, n_devices=1) as node:        # ... and before that transport has been used: nothing to report
+        assert node.rccl_ranks() == {"communicators": 0, "ranks": 0, "ranks_agree": False}
 
 
 # ---- placement: the size-aware default and the replicated mode ----------------------------
