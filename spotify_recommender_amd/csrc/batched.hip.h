@@ -259,6 +259,10 @@ constexpr int kBqStage = 256;   // entries per wave (2 KiB); a block adds at mos
 #ifndef MI355_BQ_SCHED
 #define MI355_BQ_SCHED 0
 #endif
+// The reduction of pass 2's hit test: 0 = the v_max3_i32 tree (the product), 1 = packed signs (an A/B build).
+#ifndef MI355_BQ_REDUCE
+#define MI355_BQ_REDUCE 0
+#endif
 #if MI355_BQ_SCHED & 1
 #define MI355_BQ_PRIO(p) __builtin_amdgcn_s_setprio(p)
 #else
@@ -659,6 +663,21 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
             // ONE hit test per query block (both 32-row sub-tiles): 16 maxima + 1 compare + 1
             // branch per two MFMAs
             auto check2 = [&](const bq_f16v& da, const bq_f16v& db, int blk) {
+#if MI355_BQ_REDUCE == 1
+                // A/B variant (tools/bq_reduce.sh — never the product): the test only needs SIGNS, so the two
+                // sub-tiles' accumulators are packed pairwise to fp16 (v_cvt_pkrtz_f16_f32: the sign survives, a negative
+                // underflow is -0) and the sixteen packed registers are AND-ed (three at a time where the compiler finds
+                // v_bitop3_b32): a half of the result has its sign bit SET iff every value of that sub-tile is negative.
+                // 16 + 8 + 2 vector instructions per two MFMAs against the tree's 14 + 3 + 1.
+                uint32_t all_neg = 0xffffffffu;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) all_neg &= __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(da[i], db[i]));
+                const bool hit_a = (all_neg & 0x00008000u) == 0u, hit_b = (all_neg & 0x80000000u) == 0u;
+                if (__builtin_expect(__ballot(hit_a | hit_b) != 0ull, 0)) {
+                    if (__ballot(hit_a)) push_hits(da, blk, 0);
+                    if (__ballot(hit_b)) push_hits(db, blk, 1);
+                }
+#else
                 int u0, u1, v0, v1;
                 tree(da, u0, u1);
                 tree(db, v0, v1);
@@ -668,6 +687,7 @@ __global__ __launch_bounds__(kBqPassBlock, BqPassCfg<kCollect>::kMinBlocksPerCu)
                     if (__ballot(ma >= 0)) push_hits(da, blk, 0);
                     if (__ballot(mb >= 0)) push_hits(db, blk, 1);
                 }
+#endif
             };
             // Four accumulator tiles: while block b's two tiles are reduced and tested, block
             // b + 1's two MFMAs are in flight.  A ROLLED loop over pairs of blocks (unrolled
