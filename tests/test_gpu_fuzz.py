@@ -94,6 +94,7 @@ def test_randomised_parity():
             # queries BY VALUE (round 6: their launch-wide bound comes from their anchor's neighbourhood, csrc/handoff.hip.h): a
             # catalogue row passed by value, a perturbed one, noise; nothing excluded or an arbitrary row excluded; alone and streamed
             v_topn = int(rng.choice([1, 10, 100, 300]))
+            v_sync_topn = int(rng.choice([v_topn, 1500]))   # (1500: rounds of 1024 through the synchronous by-value call)
             v_q = [f[int(rng.integers(0, rows))].copy(),
                    (f[int(rng.integers(0, rows))] * np.float32(1.0 + 0.01 * rng.standard_normal())).astype(np.float32),
                    rng.random(12, dtype=np.float32)]
@@ -111,8 +112,8 @@ def test_randomised_parity():
                 try:
                     assert_topn_matches(idx, None, want, ex, v_topn, ref_idx=oracle.topn_heap(want, ex, v_topn))
                     assert not got[cnt:].any()
-                    i2, s2 = eng.query_topn(q, ex, v_topn)
-                    assert_topn_matches(i2, s2, want, ex, v_topn, ref_idx=oracle.topn_heap(want, ex, v_topn))
+                    i2, s2 = eng.query_topn(q, ex, v_sync_topn)
+                    assert_topn_matches(i2, s2, want, ex, v_sync_topn, ref_idx=oracle.topn_heap(want, ex, v_sync_topn))
                 except AssertionError as e:  # pragma: no cover
                     raise AssertionError(f"case {case} by value: rows {rows} excl {ex} topn {v_topn}: {e}") from e
             # the same kind of stream dealt over two LANES of the handle (shared rows and replicas, own stream state), each on
