@@ -685,6 +685,22 @@ def main():
     if n_lanes > 1 and not args.no_single_lane and rank == 0:
         single_lane, _ = stream_leg(eng, torch, q_rows, topn, min(args.steps, 300), min(max(args.warmup, 4), 20))
 
+    # the same queries BY VALUE with nothing excluded (mi355rec_enqueue_query_keys_streamed(q, -1), mi355rec_query_topn(q, -1): a new
+    # track) through one handle: their launch-wide bound comes from the neighbourhood of their anchor
+    by_value = by_value_last = None
+    if sharded is None and streamed and rank == 0 and not args.no_single_lane:
+        nv = min(256, len(q_rows))
+        v_vecs = np.ascontiguousarray(q_vecs[:nv], dtype=np.float32)
+        by_value, by_value_last = stream_leg(eng, torch, q_rows[:nv], topn, min(args.steps, 300), min(max(args.warmup, 4), 20), vectors=v_vecs)
+        lat_v = []
+        for k in range(min(100, nv)):
+            t1 = time.perf_counter()
+            eng.query_topn(v_vecs[k], -1, topn)
+            lat_v.append((time.perf_counter() - t1) * 1e3)
+        lat_v.sort()
+        by_value["one_query_alone_p50_ms"] = round(lat_v[len(lat_v) // 2], 4)
+        by_value["note"] = "one handle; compare `single_lane` (the same rows by index) and `p50_ms`"
+
     # single-query latency (submit -> result on host), outside the timed region
     lat = []
     host_idx = None
@@ -1180,6 +1196,8 @@ def main():
                                        "note": "one handle, one chain of launches: algorithmic bytes / the kernel's mean duration with the chip "
                                                "to itself, against the ONE plain read stream over the same buffer"}
             line["single_lane"] = single_lane
+        if by_value is not None:
+            line["by_value"] = by_value
         if fp32_rows is not None:
             line["fp32_rows"] = fp32_rows
             tgt = (fp32_rows.get("single_lane") or {}).get("roofline") or fp32_rows["roofline"]   # (ONE kernel's rate against ONE plain stream's)
@@ -1233,6 +1251,13 @@ def main():
                 want = oracle.scores(feats_host, feats_host[row], threads=0)
                 ci, cs = oracle.topn_canonical(want, row, topn)
                 ok = ok and host_idx[0].tolist() == ci.tolist() and bool(np.array_equal(host_idx[1], cs + np.float32(0)))
+                checked += 1
+            if by_value_last is not None:                 # the last query of the by-value stream: nothing excluded
+                vec = v_vecs[-1 - by_value_last[0]]
+                rows_got, sc_got = unpack_keys(by_value_last[1].cpu().numpy())
+                want = oracle.scores(feats_host, np.ascontiguousarray(vec), threads=0)
+                ci, cs = oracle.topn_canonical(want, -1, topn)
+                ok = ok and rows_got.tolist() == ci.tolist() and bool(np.array_equal(sc_got, cs + np.float32(0)))
                 checked += 1
             if batched is not None:
                 for k in (1, args.batch // 2):

@@ -109,15 +109,31 @@ def probe_concurrent_gbps(lanes, lane_streams, torch, which, n_bytes, dev):
     return len(lanes) * n_bytes / (ms * 1e-3) / 1e9 if ms > 0 else None
 
 
-def stream_leg(eng, torch, rows, topn, steps, warmup):
+def stream_leg(eng, torch, rows, topn, steps, warmup, vectors=None):
     """A stream of single queries through ONE handle (merge riding in the next launch, flush inside the timed region, no HIP
     events in it): us per step and rows sent to the exact chain per query; then the scan kernel's mean duration from an UNTIMED
-    pass of the same stream with the library's HIP events around every launch; the last result of the timed pass."""
+    pass of the same stream with the library's HIP events around every launch; the last result of the timed pass.
+    `vectors` (len(rows) x 12 floats, host): the queries are passed BY VALUE with nothing excluded
+    (mi355rec_enqueue_query_keys_streamed(q, -1)) instead of by row — the last result then carries exclude = -1."""
     ring = [torch.zeros(topn, dtype=torch.int64, device="cuda") for _ in range(4)]
+    by_value = None
+    if vectors is not None:
+        import ctypes
+        from spotify_recommender_amd import capi
+        fn, h = eng._lib.mi355rec_enqueue_query_keys_streamed, eng._h   # (bound once: the conversions of the generic wrapper are ~10 us per call)
+        ptrs = [ctypes.c_void_p(t.data_ptr()) for t in ring]
+        qptr = [vectors[i].ctypes.data_as(ctypes.c_void_p) for i in range(len(vectors))]
+        stream0 = eng._stream_ptr(None)
+
+        def by_value(i, k):
+            capi.check(fn(h, qptr[i], -1, topn, ptrs[k % 4], stream0), h)
 
     def run(k0, count):
         for k in range(count):
-            eng.enqueue_row_keys_streamed(int(rows[(k0 + k) % len(rows)]), topn, ring[k % 4])
+            if by_value:
+                by_value((k0 + k) % len(rows), k)
+            else:
+                eng.enqueue_row_keys_streamed(int(rows[(k0 + k) % len(rows)]), topn, ring[k % 4])
         eng.enqueue_flush()
         torch.cuda.synchronize()
 
@@ -127,7 +143,7 @@ def stream_leg(eng, torch, rows, topn, steps, warmup):
     run(warmup, steps)
     dt = (time.perf_counter() - t0) / steps
     c1 = eng.replica_counters()
-    last = (int(rows[(warmup + steps - 1) % len(rows)]), ring[(steps - 1) % 4].clone())
+    last = (int(rows[(warmup + steps - 1) % len(rows)]) if vectors is None else -1 - ((warmup + steps - 1) % len(rows)), ring[(steps - 1) % 4].clone())
     eng.set_timing(1)
     run(warmup, min(steps, 64))
     k_ms = float(eng.stats().last_scan_ms)
@@ -161,6 +177,15 @@ def clustered_object(args, torch, np, dev, shapes, oracle):
             eng.set_replica(capi.REPLICA_AUTO)
             shape["replica_q8_stream"], last = stream_leg(eng, torch, q_rows, topn, 200, 20)
             checks.append(last)
+            # the same rows passed BY VALUE with nothing excluded (a new track): the launch-wide bound then comes from the
+            # neighbourhood of the query's ANCHOR (csrc/handoff.hip.h) — VERDICT r5 "missing" 3
+            v_rows = q_rows[:256]
+            v_vecs = np.ascontiguousarray(t[torch.tensor(v_rows, device=dev)].cpu().numpy())
+            eng.set_replica(capi.REPLICA_OFF)
+            shape["fp32_rows_stream_by_value"], _ = stream_leg(eng, torch, v_rows, topn, 100, 10, vectors=v_vecs)
+            eng.set_replica(capi.REPLICA_AUTO)
+            shape["replica_q8_stream_by_value"], last_v = stream_leg(eng, torch, v_rows, topn, 200, 20, vectors=v_vecs)
+            checks.append((("by value", v_vecs[-1 - last_v[0]]), last_v[1]))
             # the same stream over two lanes of the handle, each on its own stream
             lane = eng.lane()
             pair = [eng, lane]
@@ -190,6 +215,13 @@ def clustered_object(args, torch, np, dev, shapes, oracle):
             lat.sort()
             shape["one_query_alone_p50_us"] = round(lat[len(lat) // 2], 1)
             checks.append((q_rows[399], res))
+            lat = []
+            for k in range(100):
+                t1 = time.perf_counter()
+                eng.query_topn(v_vecs[k], -1, topn)
+                lat.append((time.perf_counter() - t1) * 1e6)
+            lat.sort()
+            shape["one_query_alone_by_value_p50_us"] = round(lat[len(lat) // 2], 1)
             if topn <= 128:
                 for nb in (12, 32):
                     sel = np.array(q_rows[400:400 + nb], dtype=np.int64)
@@ -240,7 +272,11 @@ def clustered_object(args, torch, np, dev, shapes, oracle):
                 idx, sc = got
             else:
                 idx, sc = unpack_keys(got.cpu().numpy())
-            want = oracle.scores(host, host[row], threads=0)
+            if isinstance(row, tuple):   # ("by value", vector): nothing excluded
+                want = oracle.scores(host, np.ascontiguousarray(row[1]), threads=0)
+                row = -1
+            else:
+                want = oracle.scores(host, host[row], threads=0)
             ci, cs = oracle.topn_canonical(want, row, topn)
             ok = ok and np.asarray(idx).tolist() == ci.tolist() and bool(np.array_equal(np.asarray(sc), cs + np.float32(0)))
         shape["verified_against_oracle"] = bool(ok)
