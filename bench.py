@@ -496,7 +496,10 @@ def main():
     # wins).  It shortens the way back from torch.cuda.synchronize() by ~10 us — nothing in a 300-step region, 3-7 % of the
     # driver's 20-step one (0.39 ms: profiles/r06_region_timeline_20steps.txt; A/B: docs/LAB_NOTES.md R6.6) — and is reported
     # in the line (`config.host_wait`).  The library's own synchronous calls spin on a word in pinned memory either way.
-    os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
+    # (One process on one or more GPUs only: under torch.distributed.run the runtime's default stays — RCCL's own threads wait
+    # on the same signals, and that combination has never run on this build's boxes.)
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and os.environ.get("BENCH_FORCE_SHARDED") != "1":
+        os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -1123,7 +1126,8 @@ def main():
                                             f"local merge streamed; one all-gather + one batched merge per {args.window} queries")),
                 "seed": args.seed, "generator": "torch.rand(seed) uniform[0,1) on device",
                 "host_wait": ("polled completion signals (HSA_ENABLE_INTERRUPT=0, set by bench.py)" if os.environ.get("HSA_ENABLE_INTERRUPT") == "0"
-                              else f"HSA_ENABLE_INTERRUPT={os.environ.get('HSA_ENABLE_INTERRUPT')} (the caller's)"),
+                              else ("the runtime's default (interrupt-driven)" if os.environ.get("HSA_ENABLE_INTERRUPT") is None
+                                    else f"HSA_ENABLE_INTERRUPT={os.environ.get('HSA_ENABLE_INTERRUPT')} (the caller's)")),
             },
             "p50_ms": round(lat[len(lat) // 2], 4) if lat else None,
             "p99_ms": round(lat[min(len(lat) - 1, int(len(lat) * 0.99))], 4) if lat else None,
